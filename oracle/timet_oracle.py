@@ -1,0 +1,490 @@
+"""CPU oracle for the TimeTuning training hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain torch-CPU tensor code, the algorithm the reference runs for one
+training iteration.  It is the checker the HIP path is
+compared against; it is never imported by ``timetuning_amd`` (the product) and the only
+callers allowed are ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py``.
+
+Parity status: PINNED.  ``oracle/gen_golden.py`` imports the reference itself from
+``/root/reference`` (with stubs for its un-installed third-party imports), drives it on
+seeded inputs and writes ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every
+function below against those vectors.  The reference has no tests or golden vectors of its
+own, so these generated fixtures are the only pin that exists.
+
+Each function cites the reference lines it follows (paths relative to ``/root/reference``).
+The structure is deliberately the reference's own (two backbone passes per extractor call,
+a Python loop over samples, fp64 label propagation on the host) because the same code is
+the timed host-CPU baseline.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# ViT backbone  (dino_vision_transformer.py)
+# --------------------------------------------------------------------------------------
+
+
+def _ln(x, w, b, eps=1e-6):
+    # nn.LayerNorm(eps=1e-6): dino_vision_transformer.py:283-287 (partial(nn.LayerNorm, eps=1e-6))
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def prepare_tokens(p, x, patch_size):
+    """dino_vision_transformer.py:236-247 with PatchEmbed :166-171.  224x224 inputs take the
+    identity branch of interpolate_pos_encoding (:214-218)."""
+    B = x.shape[0]
+    t = F.conv2d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], stride=patch_size)
+    t = t.flatten(2).transpose(1, 2)
+    cls = p["cls_token"].expand(B, -1, -1)
+    t = torch.cat((cls, t), dim=1)
+    if t.shape[1] != p["pos_embed"].shape[1]:
+        raise ValueError("oracle only restates the identity pos-embed branch (npatch == N, w == h)")
+    return t + p["pos_embed"]
+
+
+def attention(p, pre, x, num_heads):
+    """dino_vision_transformer.py:120-132.  Returns (projected output, attention probabilities)."""
+    B, N, C = x.shape
+    hd = C // num_heads
+    qkv = F.linear(x, p[pre + "qkv.weight"], p[pre + "qkv.bias"])
+    qkv = qkv.reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = (q @ k.transpose(-2, -1)) * (hd ** -0.5)
+    attn = attn.softmax(dim=-1)
+    y = (attn @ v).transpose(1, 2).reshape(B, N, C)
+    y = F.linear(y, p[pre + "proj.weight"], p[pre + "proj.bias"])
+    return y, attn
+
+
+def block(p, i, x, num_heads, return_attention=False):
+    """dino_vision_transformer.py:147-153 (drop_path is identity: drop rates are 0, :177-178)."""
+    pre = f"blocks.{i}."
+    y, attn = attention(p, pre + "attn.", _ln(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"]), num_heads)
+    if return_attention:
+        return attn
+    x = x + y
+    h = _ln(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"])
+    h = F.linear(h, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"])
+    h = F.gelu(h)  # nn.GELU() = exact erf form (:89-105)
+    h = F.linear(h, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
+    return x + h
+
+
+def get_intermediate_layers(p, x, cfg):
+    """dino_vision_transformer.py:265-273 with n=1: final-LayerNorm'd tokens of the last block."""
+    t = prepare_tokens(p, x, cfg["patch_size"])
+    for i in range(cfg["depth"]):
+        t = block(p, i, t, cfg["num_heads"])
+    return _ln(t, p["norm.weight"], p["norm.bias"])
+
+
+def get_last_selfattention(p, x, cfg):
+    """dino_vision_transformer.py:256-263: a second pass that returns block[-1]'s probabilities."""
+    t = prepare_tokens(p, x, cfg["patch_size"])
+    for i in range(cfg["depth"] - 1):
+        t = block(p, i, t, cfg["num_heads"])
+    return block(p, cfg["depth"] - 1, t, cfg["num_heads"], return_attention=True)
+
+
+# --------------------------------------------------------------------------------------
+# FeatureExtractor  (models.py:903-1078)
+# --------------------------------------------------------------------------------------
+
+SPATIAL_RESOLUTIONS = {"dino-s16": 14, "dino-b16": 14, "dino-s8": 28, "tiny-s16": 14}  # models.py:76
+
+
+class FeatureExtractorOracle:
+    """Functional twin of ``FeatureExtractor`` restricted to the "dino" branch (models.py:965-969)."""
+
+    def __init__(self, cfg, backbone, head=None, unfreeze_layers=(), spatial_resolution=14):
+        self.cfg = dict(cfg)
+        self.backbone = OrderedDict(backbone)  # name -> tensor
+        self.head = OrderedDict(head) if head else None
+        self.spatial_resolution = spatial_resolution
+        self.backbone_dim = cfg["embed_dim"]
+        self.feature_dim = cfg["embed_dim"]
+        if self.head:
+            last = [k for k in self.head if k.endswith("weight")][-1]
+            self.feature_dim = self.head[last].shape[0]
+        # freeze_backbone (models.py:929-935): substring match on parameter names
+        for name, t in self.backbone.items():
+            t.requires_grad_(any(u in name for u in unfreeze_layers))
+        if self.head:
+            for t in self.head.values():
+                t.requires_grad_(True)
+
+    def named_parameters(self):
+        for k, v in self.backbone.items():
+            yield "backbone." + k, v
+        if self.head:
+            for k, v in self.head.items():
+                yield "head." + k, v
+
+    def parameters(self):
+        return [v for _, v in self.named_parameters()]
+
+    def clone(self):
+        c = copy.copy(self)
+        c.backbone = OrderedDict((k, v.detach().clone()) for k, v in self.backbone.items())
+        c.head = OrderedDict((k, v.detach().clone()) for k, v in self.head.items()) if self.head else None
+        return c
+
+    def apply_head(self, x):
+        # Linear GELU Linear GELU ... Linear (models.py:915-926)
+        n_lin = len(self.head) // 2
+        for i in range(n_lin):
+            x = F.linear(x, self.head[f"{2 * i}.weight"], self.head[f"{2 * i}.bias"])
+            if i != n_lin - 1:
+                x = F.gelu(x)
+        return x
+
+    def get_features(self, x, faithful=True):
+        feats = get_intermediate_layers(self.backbone, x, self.cfg)[:, 1:]
+        attn = None
+        if faithful:  # the reference always pays for the second pass (models.py:968)
+            with torch.no_grad():
+                attn = get_last_selfattention(self.backbone, x, self.cfg).detach()
+        return feats, attn
+
+    def forward(self, x, use_head=True, faithful=True):
+        """models.py:1070-1078."""
+        x, attn = self.get_features(x, faithful)
+        if self.head is not None and use_head:
+            ns, npatch, dim = x.shape
+            x = self.apply_head(x.reshape(ns * npatch, dim)).view(ns, npatch, -1)
+        return x, attn
+
+    __call__ = forward
+
+
+# --------------------------------------------------------------------------------------
+# Sinkhorn-Knopp  (my_utils.py:246-274)  and schedules (my_utils.py:278-283)
+# --------------------------------------------------------------------------------------
+
+
+@torch.no_grad()
+def sinkhorn(Q, nmb_iters, world_size=1, all_reduce=None):
+    """my_utils.py:246-274.  ``Q`` is ``[K, B_local]``.  ``all_reduce`` is the SUM collective the
+    reference issues through torch.distributed (:252,261,272); pass a callable for W>1."""
+    Q = Q.detach().clone()
+    sum_Q = torch.sum(Q)
+    if world_size > 1:
+        sum_Q = all_reduce(sum_Q)
+    Q /= sum_Q
+    K, B = Q.shape
+    r = torch.ones(K, dtype=Q.dtype) / K
+    c = torch.ones(B, dtype=Q.dtype) / (B * world_size)
+    if world_size > 1:
+        curr_sum = all_reduce(torch.sum(Q, dim=1))
+    for _ in range(nmb_iters):
+        u = curr_sum if world_size > 1 else torch.sum(Q, dim=1)
+        Q *= (r / u).unsqueeze(1)
+        Q *= (c / torch.sum(Q, dim=0)).unsqueeze(0)
+        if world_size > 1:
+            curr_sum = all_reduce(torch.sum(Q, dim=1))
+    return (Q / torch.sum(Q, dim=0, keepdim=True)).t().float()
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep):
+    """my_utils.py:278-283."""
+    iters = np.arange(epochs * niter_per_ep)
+    return final_value + 0.5 * (base_value - final_value) * (1 + np.cos(np.pi * iters / len(iters)))
+
+
+# --------------------------------------------------------------------------------------
+# Label propagation  (mask_propagation.py:377-496)
+# --------------------------------------------------------------------------------------
+
+
+def restrict_neighborhood(h, w, size_mask_neighborhood):
+    """mask_propagation.py:377-391, vectorised: mask[(i,j),(i',j')] = |i-i'|<=r and |j-j'|<=r."""
+    ii = torch.arange(h).view(h, 1, 1, 1)
+    jj = torch.arange(w).view(1, w, 1, 1)
+    pi = torch.arange(h).view(1, 1, h, 1)
+    pj = torch.arange(w).view(1, 1, 1, w)
+    m = ((ii - pi).abs() <= size_mask_neighborhood) & ((jj - pj).abs() <= size_mask_neighborhood)
+    return m.reshape(h * w, h * w).float()
+
+
+def label_propagation(size_mask_neighborhood, topk, spatial_resolution, frame_tar, list_frame_feats,
+                      list_segs, mask_neighborhood):
+    """mask_propagation.py:396-445 with ``features_exist=True``.
+
+    frame_tar: [n, D] target-frame tokens; list_frame_feats: list of [D, n]; list_segs: list of
+    [1, C, h, w] fp64.  Returns (seg_tar [1,C,h,w] fp64, frame_tar.T)."""
+    h = w = spatial_resolution
+    features = frame_tar
+    return_feat_tar = features.T
+    ncontext = len(list_frame_feats)
+    feat_sources = torch.stack(list_frame_feats)                      # [c, D, n]
+    feat_tar = F.normalize(features, dim=1, p=2)                      # over D
+    feat_sources = F.normalize(feat_sources, dim=1, p=2)              # over D
+    feat_tar = feat_tar.unsqueeze(0).repeat(ncontext, 1, 1)
+    aff = torch.exp(torch.bmm(feat_tar, feat_sources) / 0.1)          # [c, n_tar, n_src]   (:422)
+    if size_mask_neighborhood > 0:
+        aff = aff * mask_neighborhood                                 # (:429)
+    aff = aff.transpose(2, 1).reshape(-1, h * w)                      # [c*n_src, n_tar]    (:431)
+    tk_val, _ = torch.topk(aff, dim=0, k=topk)
+    tk_val_min, _ = torch.min(tk_val, dim=0)
+    aff[aff < tk_val_min] = 0                                         # ties kept (:434)
+    aff = aff / torch.sum(aff, keepdim=True, axis=0)                  # (:436)
+    segs = torch.cat(list_segs)                                       # [c, C, h, w]
+    nmb_context, C, h, w = segs.shape
+    segs = segs.reshape(nmb_context, C, -1).transpose(2, 1).reshape(-1, C).T   # [C, c*n]   (:442)
+    seg_tar = torch.mm(segs.double(), aff.double())                   # fp64 (:443)
+    return seg_tar.reshape(1, C, h, w), return_feat_tar
+
+
+def propagate_labels(n_last_frames, size_mask_neighborhood, topk, spatial_resolution, frame_list, first_seg):
+    """mask_propagation.py:448-496 with ``features_exist=True``.
+
+    frame_list: [fs, n, D]; first_seg: [1, C, g, g].  Returns the list of fs-1 maps [C,g,g] fp64."""
+    first_seg = first_seg.double()  # (:456) nearest-resize to (g, g) is the identity here
+    mask = restrict_neighborhood(spatial_resolution, spatial_resolution, size_mask_neighborhood)
+    frame1_feat = frame_list[0].T
+    que = []
+    out = []
+    for cnt in range(1, frame_list.shape[0]):
+        used_feats = [frame1_feat] + [pr[0] for pr in que]
+        used_segs = [first_seg] + [pr[1] for pr in que]
+        seg, feat_tar = label_propagation(size_mask_neighborhood, topk, spatial_resolution,
+                                          frame_list[cnt], used_feats, used_segs, mask)
+        if len(que) == n_last_frames:
+            que.pop(0)
+        que.append([feat_tar, seg])
+        out.append(seg.squeeze(0))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# TimeT objective  (time_tuning.py:80-302)
+# --------------------------------------------------------------------------------------
+
+
+class TimeTOracle:
+    def __init__(self, feature_extractor: FeatureExtractorOracle, prototypes: torch.Tensor, world_size=1,
+                 all_reduce=None):
+        self.feature_extractor = feature_extractor
+        self.prototypes = prototypes.clone().requires_grad_(True)
+        self.teacher = None
+        self.teacher_prototypes = None
+        self.queue = None
+        self.momentum_schedule = None
+        self.world_size = world_size
+        self.all_reduce = all_reduce
+
+    # -- parameters in the reference's named_parameters() order (prototypes first: :93) ------
+    def named_parameters(self):
+        yield "prototypes", self.prototypes
+        for k, v in self.feature_extractor.named_parameters():
+            yield "feature_extractor." + k, v
+
+    def init_momentum_teacher(self):
+        """time_tuning.py:96-104."""
+        self.teacher = self.feature_extractor.clone()
+        for t in self.teacher.parameters():
+            t.requires_grad_(False)
+        self.teacher_prototypes = self.prototypes.detach().clone()
+
+    def init_queue(self, queue_size):
+        """time_tuning.py:106-107."""
+        self.queue = torch.zeros((queue_size, self.feature_extractor.feature_dim), dtype=self.prototypes.dtype)
+
+    def set_momentum_teacher_schedular_params(self, m0, m1, epochs, iters):
+        self.momentum_schedule = cosine_scheduler(m0, m1, epochs, iters)
+
+    @torch.no_grad()
+    def update_momentum_teacher(self, step):
+        """time_tuning.py:109-118: teacher <- teacher*(1-m) + student*m, m = schedule[step]."""
+        m = self.momentum_schedule[step]
+        for q, k in zip(self.feature_extractor.parameters(), self.teacher.parameters()):
+            k.copy_(k * (1.0 - m) + q.detach() * m)
+        tp = self.teacher_prototypes * (1.0 - m) + self.prototypes.detach() * m
+        self.teacher_prototypes = F.normalize(tp, dim=1, p=2)
+
+    @torch.no_grad()
+    def normalize_prototypes(self):
+        """time_tuning.py:124-128."""
+        self.prototypes.copy_(F.normalize(self.prototypes.detach().clone(), dim=1, p=2))
+
+    def get_feature_prototype_similarity(self, x, use_teacher=False):
+        """time_tuning.py:130-141."""
+        nx = F.normalize(x, dim=-1, p=2)
+        protos = self.teacher_prototypes if use_teacher else self.prototypes
+        return torch.mm(nx, protos.t())
+
+    def find_optimal_assignment(self, scores, epsilon, sinkhorn_iterations):
+        """time_tuning.py:157-168."""
+        with torch.no_grad():
+            q = torch.exp(scores / epsilon).t()
+            return sinkhorn(q, sinkhorn_iterations, self.world_size, self.all_reduce)
+
+    def get_scores(self, features, epsilon, sinkhorn_iterations, use_teacher=False):
+        """time_tuning.py:195-217."""
+        bs, npatch, dim = features.shape
+        flat = features.contiguous().view(bs * npatch, dim)
+        batch_scores = self.get_feature_prototype_similarity(flat, use_teacher)
+        scores = batch_scores
+        if self.queue is not None and self.queue[-1].count_nonzero() != 0:
+            queue_scores = self.get_feature_prototype_similarity(self.queue.view(-1, dim), use_teacher)
+            scores = torch.cat([batch_scores, queue_scores], dim=0)
+        q = self.find_optimal_assignment(scores, epsilon, sinkhorn_iterations)
+        return q[: bs * npatch].view(bs, npatch, -1), batch_scores.view(bs, npatch, -1)
+
+    def make_seg_maps(self, q_i, feats_i, n_last_frames, size_mask_neighborhood, topk):
+        """time_tuning.py:143-154."""
+        g = self.feature_extractor.spatial_resolution
+        seed = q_i.view(g, g, -1).permute(2, 0, 1).unsqueeze(0)
+        return torch.stack(propagate_labels(n_last_frames, size_mask_neighborhood, topk, g, feats_i, seed))
+
+    def get_loss(self, x, n_last_frames=7, size_mask_neighborhood=6, topk=5, epsilon=0.05,
+                 sinkhorn_iterations=10, queue_perm=None, faithful=True, return_aux=False):
+        """time_tuning.py:224-302 (``mask_features=False`` branch).
+
+        ``queue_perm``: the permutation ``torch.randperm(bs*n)`` draws at :259; passing it makes the
+        queue update reproducible.  ``faithful`` keeps the reference's redundant passes."""
+        fe = self.feature_extractor
+        g = fe.spatial_resolution
+        bs, fs, c, h, w = x.shape
+        flat = x.view(bs * fs, c, h, w)
+        if self.teacher is not None:
+            with torch.no_grad():
+                teacher_features, _ = self.teacher(flat, faithful=faithful)
+            teacher_features = teacher_features.view(bs, fs, *teacher_features.shape[1:])
+        features, _ = fe(flat, faithful=faithful)
+        with torch.no_grad():
+            if faithful:
+                backbone_features, _ = fe(flat, use_head=False, faithful=True)
+            else:
+                backbone_features, _ = fe(flat, use_head=False, faithful=False)
+        npatch, dim = features.shape[1:]
+        features = features.view(bs, fs, npatch, dim)
+        backbone_features = backbone_features.view(bs, fs, npatch, -1)
+        source_features = features[:, 0]
+
+        if self.queue is not None:  # :250-261
+            qf = (teacher_features[:, 0] if self.teacher is not None else features[:, 0]).reshape(-1, dim)
+            m = min(bs * 10, self.queue.size(0))
+            perm = torch.randperm(qf.size(0)) if queue_perm is None else torch.as_tensor(queue_perm)
+            idx = perm[:m]
+            self.queue[m:] = self.queue[:-m].clone()
+            self.queue[:m] = qf[idx].detach()
+
+        if self.teacher is not None:  # :263-275
+            batch_q = self.get_scores(teacher_features[:, 0], epsilon, sinkhorn_iterations, use_teacher=True)[0]
+            if faithful:
+                self.get_scores(source_features, epsilon, sinkhorn_iterations)
+                self.get_scores(teacher_features[:, -1], epsilon, sinkhorn_iterations, use_teacher=True)
+            target_batch_scores = self.get_scores(features[:, -1], epsilon, sinkhorn_iterations)[1]
+        else:
+            batch_q, _ = self.get_scores(source_features, epsilon, sinkhorn_iterations)
+            _, target_batch_scores = self.get_scores(features[:, -1], epsilon, sinkhorn_iterations)
+
+        batch_loss = 0
+        labels_all, pmaps = [], []
+        for i in range(bs):  # :277-301
+            maps = self.make_seg_maps(batch_q[i], backbone_features[i], n_last_frames, size_mask_neighborhood, topk)
+            p_map = maps[-1]
+            target_scores = target_batch_scores[i].view(g, g, -1).permute(2, 0, 1)
+            labels = p_map.unsqueeze(0).argmax(dim=1).long()
+            loss = F.cross_entropy(target_scores.unsqueeze(0) / 0.1, labels)
+            batch_loss = batch_loss + loss.mean()
+            labels_all.append(labels[0])
+            pmaps.append(p_map)
+        loss = batch_loss / bs
+        if return_aux:
+            return loss, dict(batch_q=batch_q, target_scores=target_batch_scores, labels=torch.stack(labels_all),
+                              p_map=torch.stack(pmaps), features=features, backbone_features=backbone_features)
+        return loss
+
+
+# --------------------------------------------------------------------------------------
+# SwavOptimizer  (time_tuning.py:379-429): AdamW + cosine LR + weight-decay reschedule
+# --------------------------------------------------------------------------------------
+
+
+def param_groups(model: TimeTOracle, backbone_lr, lr, weight_decay):
+    """time_tuning.py:391-415: groups ordered prototypes, head, backbone; each split into
+    (decayed, undecayed[bias or 1-D])."""
+    groups = []
+    for filt, g_lr in (("prototypes", lr), ("feature_extractor.head", lr), ("feature_extractor.backbone", backbone_lr)):
+        dec, nodec = [], []
+        for name, p in model.named_parameters():
+            if p.requires_grad and filt in name:
+                (nodec if (name.endswith(".bias") or p.dim() == 1) else dec).append((name, p))
+        groups.append(dict(params=dec, weight_decay=weight_decay, lr=g_lr, base_lr=g_lr))
+        groups.append(dict(params=nodec, weight_decay=0.0, lr=g_lr, base_lr=g_lr))
+    return groups
+
+
+class SwavOptimizerOracle:
+    """Restates torch.optim.AdamW (betas (0.9, 0.999), eps 1e-8, decoupled decay) as driven by
+    time_tuning.py:420-429, plus CosineAnnealingLR(T_max=I*E, eta_min=0)."""
+
+    def __init__(self, model, backbone_lr, lr, wd_schedule, num_itr, num_epochs, use_lr_scheduler=True):
+        self.groups = param_groups(model, backbone_lr, lr, wd_schedule[0])
+        self.wd_schedule = wd_schedule
+        self.T_max = num_itr * num_epochs
+        self.use_lr_scheduler = use_lr_scheduler
+        self.global_step = 0
+        self.state = {}
+
+    @torch.no_grad()
+    def step(self):
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        for g in self.groups:
+            for name, p in g["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state.setdefault(name, dict(step=0, m=torch.zeros_like(p), v=torch.zeros_like(p)))
+                st["step"] += 1
+                t = st["step"]
+                p.mul_(1 - g["lr"] * g["weight_decay"])
+                st["m"].mul_(b1).add_(p.grad, alpha=1 - b1)
+                st["v"].mul_(b2).addcmul_(p.grad, p.grad, value=1 - b2)
+                bc1 = 1 - b1 ** t
+                bc2 = 1 - b2 ** t
+                denom = (st["v"].sqrt() / math.sqrt(bc2)).add_(eps)
+                p.addcdiv_(st["m"], denom, value=-g["lr"] / bc1)
+        self.global_step += 1
+        if self.use_lr_scheduler:  # closed form of CosineAnnealingLR with eta_min = 0
+            for g in self.groups:
+                g["lr"] = g["base_lr"] * 0.5 * (1 + math.cos(math.pi * self.global_step / self.T_max))
+        for g in self.groups:  # :427-429 (IndexError on the very last step is the reference's own)
+            if g["weight_decay"] != 0:
+                g["weight_decay"] = float(self.wd_schedule[self.global_step])
+
+    def zero_grad(self):
+        for g in self.groups:
+            for _, p in g["params"]:
+                p.grad = None
+
+
+# --------------------------------------------------------------------------------------
+# builders
+# --------------------------------------------------------------------------------------
+
+
+def build_oracle(arch="dino-s16", num_prototypes=200, head_layer_list=(1024, 1024, 512, 256), mode="dino",
+                 seed=1, dtype=torch.float32, unfreeze_layers=("blocks.11", "blocks.10"), vit_cfg=None,
+                 world_size=1, all_reduce=None):
+    """Model with the portable synthetic weights (timetuning_amd.synth)."""
+    from timetuning_amd import synth
+
+    cfg = dict(vit_cfg or synth.ARCHS[arch])
+    bb = OrderedDict((k, torch.from_numpy(v).to(dtype)) for k, v in synth.make_vit_weights(mode=mode, seed=seed, **cfg).items())
+    head = None
+    if head_layer_list:
+        head = OrderedDict((k, torch.from_numpy(v).to(dtype))
+                           for k, v in synth.make_head_weights(cfg["embed_dim"], head_layer_list, mode=mode, seed=seed).items())
+    fe = FeatureExtractorOracle(cfg, bb, head, unfreeze_layers, SPATIAL_RESOLUTIONS.get(arch, 224 // cfg["patch_size"]))
+    protos = torch.from_numpy(synth.make_prototypes(num_prototypes, fe.feature_dim, seed)).to(dtype)
+    return TimeTOracle(fe, protos, world_size, all_reduce)

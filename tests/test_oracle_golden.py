@@ -1,0 +1,183 @@
+"""Pins the CPU oracle (oracle/timet_oracle.py) to vectors produced by the reference itself
+(oracle/gen_golden.py -> tests/golden/*.npz).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import timet_oracle as O
+from timetuning_amd import synth
+
+
+def test_cosine_scheduler_kat(golden):
+    g = golden("schedules")
+    np.testing.assert_allclose(O.cosine_scheduler(0.04, 0.4, 1, 4), g["wd_1_4"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(O.cosine_scheduler(0.995, 1.0, 2, 5), g["ema_2_5"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(O.cosine_scheduler(0.04, 0.4, 3, 7), g["wd_3_7"], rtol=0, atol=1e-15)
+    # SURVEY 8(a) A15 known answer
+    np.testing.assert_allclose(g["wd_1_4"], [0.04, 0.09272078, 0.22, 0.34727922], atol=1e-8)
+
+
+def test_sinkhorn_kat(golden):
+    g = golden("sinkhorn")
+    kat = torch.from_numpy(g["kat_in"])
+    np.testing.assert_allclose(O.sinkhorn(kat, 3).numpy(), g["kat_it3"], rtol=1e-6)
+    np.testing.assert_allclose(O.sinkhorn(kat, 0).numpy(), g["kat_it0"], rtol=1e-6)
+    # SURVEY 8(c) known answers
+    np.testing.assert_allclose(g["kat_it3"][0], [0.40406331, 0.59593672], rtol=1e-6)
+    np.testing.assert_allclose(g["kat_it0"][0], [0.2, 0.8], rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_sinkhorn_random(golden, tag):
+    g = golden("sinkhorn")
+    scores = torch.from_numpy(g[f"{tag}_scores"])
+    q = O.sinkhorn(torch.exp(scores / 0.05).t(), int(g[f"{tag}_iters"]))
+    assert rel_err(q.numpy(), g[f"{tag}_q"]) < 1e-6
+    np.testing.assert_allclose(q.sum(1).numpy(), 1.0, rtol=1e-5)
+
+
+def test_sinkhorn_world2_equals_concat(golden):
+    """my_utils.py:250-272 with W=2 equals the single-process solve over concatenated columns."""
+    g = golden("sinkhorn_w2")
+    scores = torch.from_numpy(g["scores"])
+    q = O.sinkhorn(torch.exp(scores / 0.05).t(), int(g["iters"]))
+    assert rel_err(q.numpy(), g["q"]) < 2e-6
+
+
+def test_window_mask_counts(golden):
+    g = golden("label_prop")
+    assert int(O.restrict_neighborhood(14, 14, 6).sum()) == int(g["mask_nnz_g14_r6"]) == 19600
+    assert int(O.restrict_neighborhood(28, 28, 6).sum()) == int(g["mask_nnz_g28_r6"]) == 103684
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
+def test_label_propagation(golden, tag):
+    g = golden("label_prop")
+    gg, fs, D, K, nlast, r, topk = [int(v) for v in g[f"{tag}_cfg"]]
+    feats = torch.from_numpy(g[f"{tag}_feats"])
+    q0 = torch.from_numpy(g[f"{tag}_q0"])
+    seed = q0.view(gg, gg, K).permute(2, 0, 1).unsqueeze(0)
+    maps = torch.stack(O.propagate_labels(nlast, r, topk, gg, feats, seed)).numpy()
+    assert maps.dtype == np.float64
+    assert rel_err(maps, g[f"{tag}_maps"]) < 1e-12
+    assert (maps.argmax(1) == g[f"{tag}_maps"].argmax(1)).all()
+
+
+def _build_from_fixture(g, teacher=False, queue=0):
+    D, depth, heads, patch = [int(v) for v in g["vit_cfg"]]
+    cfg = dict(embed_dim=D, depth=depth, num_heads=heads, patch_size=patch)
+    K = int(g["cfg"][2])
+    m = O.build_oracle("dino-s16", K, tuple(int(v) for v in g["head_list"]), mode=str(g["mode"]), vit_cfg=cfg)
+    if teacher:
+        m.init_momentum_teacher()
+    if queue:
+        m.init_queue(queue)
+    return m
+
+
+def test_extractor_tiny(golden):
+    g = golden("timet_tiny")
+    m = _build_from_fixture(g)
+    bs, fs = int(g["cfg"][0]), int(g["cfg"][1])
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1)).view(bs * fs, 3, 224, 224)
+    with torch.no_grad():
+        f, attn = m.feature_extractor(x)
+        bf, _ = m.feature_extractor(x, use_head=False)
+    assert rel_err(f.numpy(), g["features"]) < 1e-5
+    assert rel_err(bf.numpy(), g["backbone_features"]) < 1e-5
+    assert rel_err(attn[:, :, 0, :].numpy(), g["attn_cls_row"]) < 1e-5
+
+
+def test_get_loss_internals_tiny(golden):
+    g = golden("aux_tiny")
+    t = golden("timet_tiny")
+    m = _build_from_fixture(t)
+    bs, fs, K = [int(v) for v in g["cfg"]]
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1))
+    loss, aux = m.get_loss(x, return_aux=True)
+    assert rel_err(aux["batch_q"].numpy(), g["q"]) < 1e-4
+    assert rel_err(aux["target_scores"].detach().numpy(), g["target_scores"]) < 1e-5
+    assert rel_err(aux["p_map"].numpy(), g["p_map"]) < 1e-4
+    mism = (aux["labels"].numpy() != g["labels"])
+    # a label may flip only where the reference's own top-2 margin is at rounding level
+    assert (g["label_margin"].reshape(mism.shape)[mism] < 1e-6).all()
+    assert abs(loss.item() - float(t["loss0"])) < 1e-5
+
+
+def _run_steps(g, teacher, queue):
+    bs, fs, K, _, _, steps, E, I = [int(v) for v in g["cfg"]]
+    m = _build_from_fixture(g, teacher, queue)
+    opt = O.SwavOptimizerOracle(m, 1e-5, 1e-4, O.cosine_scheduler(0.04, 0.4, E, I), I, E)
+    if teacher:
+        m.set_momentum_teacher_schedular_params(0.995, 1.0, E, I)
+    params = dict(m.named_parameters())
+    assert [len(gr["params"]) for gr in opt.groups] == list(g["group_sizes"])
+    for s in range(steps):
+        x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1 + s))
+        loss = m.get_loss(x, queue_perm=g[f"perm{s}"])
+        assert abs(loss.item() - float(g[f"loss{s}"])) < 2e-5, (s, loss.item(), float(g[f"loss{s}"]))
+        opt.zero_grad()
+        loss.backward()
+        names = [str(n) for n in g[f"gradnorm_names{s}"]]
+        mine = np.array([params[n].grad.double().norm().item() for n in names])
+        np.testing.assert_allclose(mine, g[f"gradnorm{s}"], rtol=2e-4, atol=1e-9)
+        for key in g.files:
+            if key.startswith(f"grad{s}:"):
+                assert rel_err(params[key.split(":", 1)[1]].grad.numpy(), g[key]) < 2e-4, key
+        opt.step()
+        m.normalize_prototypes()
+        if teacher:
+            m.update_momentum_teacher(opt.global_step)
+        for key in g.files:
+            if key.startswith(f"param{s}:"):
+                assert rel_err(params[key.split(":", 1)[1]].detach().numpy(), g[key]) < 1e-6, key
+        np.testing.assert_allclose([gr["lr"] for gr in opt.groups], g[f"lr{s}"], rtol=1e-12)
+        np.testing.assert_allclose([gr["weight_decay"] for gr in opt.groups], g[f"wd{s}"], rtol=1e-12)
+        if teacher:
+            assert rel_err(m.teacher_prototypes.numpy(), g[f"teacher_prototypes{s}"]) < 1e-6
+            assert rel_err(m.teacher.backbone["blocks.11.mlp.fc2.weight"].numpy(), g[f"teacher_fc2_{s}"]) < 1e-6
+            assert rel_err(m.teacher.backbone["blocks.3.attn.qkv.weight"].numpy().reshape(-1)[::97], g[f"teacher_b3qkv_{s}"]) < 1e-6
+        if queue:
+            assert rel_err(m.queue[:64].numpy(), g[f"queue_head{s}"]) < 1e-5
+            assert abs(m.queue.double().sum().item() - float(g[f"queue_sum{s}"])) < 1e-3
+
+
+def test_training_steps_tiny(golden):
+    _run_steps(golden("timet_tiny"), False, 0)
+
+
+def test_training_steps_tiny_teacher_queue(golden):
+    _run_steps(golden("timet_tiny_tq"), True, 40)
+
+
+def test_state_dict_layout(golden):
+    """SURVEY section 5 checkpoint layout: key names the build must reproduce."""
+    keys = [str(k) for k in golden("timet_tiny_tq")["state_dict_keys"]]
+    assert keys[0] == "prototypes"
+    assert "feature_extractor.backbone.blocks.11.mlp.fc2.weight" in keys
+    assert "feature_extractor.head.6.bias" in keys
+    assert "teacher.backbone.cls_token" in keys and "teacher_prototypes" in keys
+
+
+def test_full_size_c1_single_pass(golden):
+    """ViT-S/16, bs 2 x 2 frames, K=50 (BASELINE config C1).  Runs the oracle with ONE backbone pass per
+    extractor call (faithful=False) and checks it still reproduces the reference, which runs 4."""
+    g = golden("timet_c1")
+    m = _build_from_fixture(g)
+    bs, fs = int(g["cfg"][0]), int(g["cfg"][1])
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1))
+    loss, aux = m.get_loss(x, faithful=False, return_aux=True)
+    assert abs(loss.item() - float(g["loss0"])) < 2e-5
+    f = aux["features"].detach().reshape(bs * fs, 196, -1)
+    bf = aux["backbone_features"].reshape(bs * fs, 196, -1)
+    assert rel_err(f[:, ::49, ::16].numpy(), g["features_slice"]) < 1e-5
+    assert rel_err(bf[:, ::49, ::16].numpy(), g["backbone_features_slice"]) < 1e-5
+    assert abs(f.double().norm().item() / float(g["features_norm"]) - 1) < 1e-6
+    loss.backward()
+    params = dict(m.named_parameters())
+    for key in g.files:
+        if key.startswith("grad0:"):
+            mine = params[key.split(":", 1)[1]].grad.numpy()
+            mine = mine if mine.size < 70000 else mine.reshape(-1)[::97]
+            assert rel_err(mine, g[key]) < 5e-4, key

@@ -1,0 +1,149 @@
+"""Portable synthetic weights and clips.
+
+There is no network on the build or GPU boxes, so the pretrained DINO checkpoint the
+reference pulls through ``torch.hub`` (reference ``models.py:780-785``) cannot be used.
+Every tensor is instead drawn from a counter-based generator (numpy Philox) keyed by the
+tensor's state_dict name, so that the golden-vector generator (which imports the
+reference), the CPU oracle, the tests and ``bench.py`` all regenerate bit-identical
+weights without shipping 87 MB of parameters.
+
+Two initialisation modes:
+
+``dino``    mirrors ``dino_vision_transformer.py:201-212``: ``trunc_normal(std=0.02)`` for
+            Linear / conv / pos_embed / cls_token, LayerNorm gamma=1 beta=0, biases 0.
+``stress``  same shapes, but non-zero biases, non-unit LayerNorm gains and a larger
+            weight std, so that a kernel which drops a bias, a gain or mis-scales the
+            attention logits cannot pass a parity test by accident.
+"""
+from __future__ import annotations
+
+import hashlib
+from collections import OrderedDict
+
+import numpy as np
+
+# (embed_dim, depth, heads, patch) per architecture name used by the reference
+# (``models.py:780-785`` hub entries; ``dino_vision_transformer.py:276-294`` factories).
+ARCHS = {
+    "dino-s16": dict(embed_dim=384, depth=12, num_heads=6, patch_size=16),
+    "dino-s8": dict(embed_dim=384, depth=12, num_heads=6, patch_size=8),
+    "dino-b16": dict(embed_dim=768, depth=12, num_heads=12, patch_size=16),
+    # not a reference architecture: a cheap ViT for CPU-sized parity tests.  It is only
+    # reachable through explicit ``vit_cfg=`` arguments, never through the CLI.
+    "tiny-s16": dict(embed_dim=64, depth=12, num_heads=2, patch_size=16),
+}
+
+
+def _philox(name: str, seed: int) -> np.random.Generator:
+    digest = hashlib.sha256(f"{seed}:{name}".encode()).digest()
+    key = np.frombuffer(digest[:16], dtype=np.uint64)
+    return np.random.Generator(np.random.Philox(key=key))
+
+
+def normal(name: str, shape, std: float = 1.0, mean: float = 0.0, seed: int = 1) -> np.ndarray:
+    """fp32 normal tensor that depends only on (name, seed, shape)."""
+    g = _philox(name, seed)
+    a = g.standard_normal(size=tuple(shape), dtype=np.float32)
+    if std != 1.0:
+        a *= np.float32(std)
+    if mean != 0.0:
+        a += np.float32(mean)
+    return a
+
+
+def vit_param_shapes(embed_dim: int, depth: int, num_heads: int, patch_size: int,
+                     img_size: int = 224, in_chans: int = 3, mlp_ratio: int = 4) -> "OrderedDict[str, tuple]":
+    """state_dict layout of the DINO ViT (``dino_vision_transformer.py:174-199``)."""
+    n = (img_size // patch_size) ** 2
+    D = embed_dim
+    H = D * mlp_ratio
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    s["cls_token"] = (1, 1, D)
+    s["pos_embed"] = (1, n + 1, D)
+    s["patch_embed.proj.weight"] = (D, in_chans, patch_size, patch_size)
+    s["patch_embed.proj.bias"] = (D,)
+    for i in range(depth):
+        p = f"blocks.{i}."
+        s[p + "norm1.weight"] = (D,)
+        s[p + "norm1.bias"] = (D,)
+        s[p + "attn.qkv.weight"] = (3 * D, D)
+        s[p + "attn.qkv.bias"] = (3 * D,)
+        s[p + "attn.proj.weight"] = (D, D)
+        s[p + "attn.proj.bias"] = (D,)
+        s[p + "norm2.weight"] = (D,)
+        s[p + "norm2.bias"] = (D,)
+        s[p + "mlp.fc1.weight"] = (H, D)
+        s[p + "mlp.fc1.bias"] = (H,)
+        s[p + "mlp.fc2.weight"] = (D, H)
+        s[p + "mlp.fc2.bias"] = (D,)
+    s["norm.weight"] = (D,)
+    s["norm.bias"] = (D,)
+    return s
+
+
+def head_param_shapes(in_dim: int, head_layer_list) -> "OrderedDict[str, tuple]":
+    """``nn.Sequential`` indices 0,2,4,.. are the Linears (``models.py:915-926``)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    prev = in_dim
+    for i, width in enumerate(head_layer_list):
+        s[f"{2 * i}.weight"] = (width, prev)
+        s[f"{2 * i}.bias"] = (width,)
+        prev = width
+    return s
+
+
+def _fill(name: str, shape, mode: str, seed: int) -> np.ndarray:
+    is_norm = ".norm" in name or name.startswith("norm")
+    if is_norm and name.endswith("weight"):
+        if mode == "dino":
+            return np.ones(shape, np.float32)
+        return normal(name, shape, 0.1, 1.0, seed)
+    if name.endswith("bias"):
+        if mode == "dino":
+            return np.zeros(shape, np.float32)
+        return normal(name, shape, 0.05, 0.0, seed)
+    std = 0.02 if mode == "dino" else 0.06
+    return np.clip(normal(name, shape, std, 0.0, seed), -2.0, 2.0)
+
+
+def make_vit_weights(prefix: str = "", mode: str = "dino", seed: int = 1, **cfg) -> "OrderedDict[str, np.ndarray]":
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for k, shp in vit_param_shapes(**cfg).items():
+        out[prefix + k] = _fill("backbone." + k, shp, mode, seed)
+    return out
+
+
+def make_head_weights(in_dim: int, head_layer_list, prefix: str = "", mode: str = "dino",
+                      seed: int = 1) -> "OrderedDict[str, np.ndarray]":
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for k, shp in head_param_shapes(in_dim, head_layer_list).items():
+        if k.endswith("weight"):
+            fan_in = shp[1]
+            # nn.Linear's default scale (uniform(+-1/sqrt(fan_in))) has std 1/sqrt(3 fan_in)
+            out[prefix + k] = normal("head." + k, shp, (1.0 / (3.0 * fan_in)) ** 0.5, 0.0, seed)
+        else:
+            out[prefix + k] = normal("head." + k, shp, 0.02 if mode == "dino" else 0.05, 0.0, seed)
+    return out
+
+
+def make_prototypes(num_prototypes: int, dim: int, seed: int = 1) -> np.ndarray:
+    """``normalize(randn(K, dim))`` (``time_tuning.py:90-93``) from the portable stream."""
+    p = normal("prototypes", (num_prototypes, dim), 1.0, 0.0, seed)
+    p /= np.maximum(np.linalg.norm(p, axis=1, keepdims=True), 1e-12).astype(np.float32)
+    return p.astype(np.float32)
+
+
+def make_clips(bs: int, fs: int, img: int = 224, seed: int = 1, coherent: bool = True,
+               name: str = "clips") -> np.ndarray:
+    """Synthetic normalised clips ``[bs, fs, 3, img, img]`` fp32.
+
+    The real loader yields ImageNet-normalised pixels (``time_tuning.py:592``), i.e. roughly
+    unit normal.  ``coherent=True`` makes frame t a (2t, 2t)-pixel roll of frame 0 plus a
+    little noise so that label propagation has real temporal structure to follow.
+    """
+    if not coherent:
+        return normal(name, (bs, fs, 3, img, img), 1.0, 0.0, seed)
+    base = normal(name + ".base", (bs, 1, 3, img, img), 1.0, 0.0, seed)
+    noise = normal(name + ".noise", (bs, fs, 3, img, img), 0.05, 0.0, seed)
+    frames = [np.roll(base[:, 0], shift=(2 * t, 2 * t), axis=(-2, -1)) for t in range(fs)]
+    return (np.stack(frames, axis=1) + noise).astype(np.float32)
