@@ -1,0 +1,168 @@
+/*
+ * timetuning_hip.h - C ABI of libtimetuning_hip.so (gfx950 / MI355X).
+ *
+ * The reference (SMSD75/Timetuning) is pure Python on top of ATen; it has no FFI of its own.
+ * The entry points below are the op sites of its training hot path (SURVEY.md section 2.4,
+ * k1-k19) restated as a C ABI: what a maintainer would bind with ctypes in place of the
+ * ATen calls.  Each declaration cites the reference lines it replaces (paths relative to the
+ * reference checkout).  INTEGRATION.md shows the reference-side ctypes stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (row-major, contiguous unless a leading
+ *     dimension is passed) unless the parameter says otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls enqueue work
+ *     and return, they never synchronise, allocate or free;
+ *   - return value: 0 on success, a negative TT_E* code otherwise; tt_last_error() returns a
+ *     thread-local message for the last failing call;
+ *   - workspaces are caller-owned; the matching *_workspace_bytes() gives the size.
+ */
+#ifndef TIMETUNING_HIP_H
+#define TIMETUNING_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TT_OK 0
+#define TT_EINVAL (-1)   /* bad shape / alignment / null pointer */
+#define TT_ELAUNCH (-2)  /* HIP launch error */
+#define TT_EUNSUPPORTED (-3)
+
+typedef void* tt_stream_t;
+
+const char* tt_last_error(void);
+int tt_abi_version(void);
+/* Fills name (<= cap bytes) with the gcnArchName of the current device; returns CU count or <0. */
+int tt_device_info(char* name, int cap);
+
+/* ---- k4,k6,k7,k8,k9: nn.Linear forward  (dino_vision_transformer.py:94-103,115-117,122,130;
+ *      models.py:915-926,1075-1077)
+ *   y[M,N] = act(x[M,K] @ w[N,K]^T + bias) (+ residual)
+ *   act: 0 none, 1 exact-erf GELU.  pre_act (optional, [M,N]) receives x@w^T+bias before the
+ *   activation (saved for backward).  residual (optional, [M,N]) is added after the activation;
+ *   it may alias y. */
+int tt_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                  float* pre_act, int M, int N, int K, int act, tt_stream_t stream);
+
+/* ---- k16: nn.Linear backward (autograd of the sites above)
+ *   dx[M,K] = dy[M,N] @ w[N,K]            (* gelu'(gelu_pre[M,K]) if gelu_pre != NULL)
+ *   dw[N,K] = dy[M,N]^T @ x[M,K],  db[N] = column sums of dy (db may be NULL)
+ *   workspace for tt_linear_bwd_weight: tt_colsum_workspace_bytes(M, N) when db != NULL. */
+int tt_linear_bwd_data(const float* dy, const float* w, const float* gelu_pre, float* dx, int M, int N, int K,
+                       tt_stream_t stream);
+int tt_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
+                         void* workspace, size_t workspace_bytes, tt_stream_t stream);
+size_t tt_colsum_workspace_bytes(int M, int N);
+/* out[N] = sum over rows of a[M,N] (deterministic two-stage reduction). */
+int tt_colsum(const float* a, float* out, int M, int N, void* workspace, size_t workspace_bytes, tt_stream_t stream);
+
+/* ---- generic fp32 MFMA GEMM used by the sites above and by k11/k14:
+ *   C[M,N] = alpha * op(A)[M,K] @ op(B)[K,N]
+ *   a_mmajor = 0: A stored [M][lda] (k contiguous); 1: stored [K][lda] (m contiguous)
+ *   b_nmajor = 0: B stored [N][ldb] (k contiguous, the nn.Linear weight layout); 1: stored [K][ldb]
+ *   batch > 1 runs `batch` independent problems at the given element strides. */
+int tt_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                int a_mmajor, int b_nmajor, float alpha, int batch, long long strideA, long long strideB,
+                long long strideC, tt_stream_t stream);
+
+/* ---- k1,k2: PatchEmbed conv (kernel = stride = P) + cls token + pos-embed
+ *      (dino_vision_transformer.py:166-171, 236-247)
+ *   img [F_src,C,H,W]; frame_map (optional int32[F]): output frame f reads img[frame_map[f]];
+ *   w [D, C*P*P]; bias [D]; cls [D]; pos [(n+1), D]; tokens [F, n+1, D], n = (H/P)*(W/P). */
+int tt_patch_embed_fwd(const float* img, const int32_t* frame_map, const float* w, const float* bias,
+                       const float* cls, const float* pos, float* tokens, int F, int C, int H, int W, int P, int D,
+                       tt_stream_t stream);
+
+/* ---- k3: LayerNorm over the last dim (dino_vision_transformer.py:139,143,196; eps = 1e-6)
+ *   mean/rstd (optional, [rows]) are saved for backward. */
+int tt_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                     int rows, int D, float eps, tt_stream_t stream);
+/*   dx [rows,D]; dgamma/dbeta [D] optional (NULL for frozen norms).  add_to_dx != 0 accumulates
+ *   into dx (residual branch).  workspace: tt_layernorm_bwd_workspace_bytes(rows, D). */
+int tt_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                     float* dx, float* dgamma, float* dbeta, int rows, int D, int add_to_dx, void* workspace,
+                     size_t workspace_bytes, tt_stream_t stream);
+size_t tt_layernorm_bwd_workspace_bytes(int rows, int D);
+
+/* ---- k5 (+k10): multi-head self-attention core (dino_vision_transformer.py:122-129)
+ *   qkv [F, N, 3*H*hd] as written by the qkv Linear (q | k | v, each head-major);
+ *   out [F, N, H*hd] = softmax(q k^T * scale) v ; lse [F,H,N] optional (saved for backward);
+ *   probs [F,H,N,N] optional (get_last_selfattention, :256-263).  hd must be 64, N <= 256. */
+int tt_attention_fwd(const float* qkv, float* out, float* lse, float* probs, int F, int N, int H, int hd,
+                     float scale, tt_stream_t stream);
+/*   dqkv [F,N,3*H*hd] from dout [F,N,H*hd]; workspace: tt_attention_bwd_workspace_bytes. */
+int tt_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F,
+                     int N, int H, int hd, float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream);
+size_t tt_attention_bwd_workspace_bytes(int F, int N, int H, int hd);
+
+/* ---- k11: F.normalize(x, dim=-1) (time_tuning.py:136; mask_propagation.py:418-419)
+ *   xn[rows,D] = x / max(||x||, 1e-12); inv_norm[rows] optional.  x rows may be strided (ldx). */
+int tt_l2norm_fwd(const float* x, int ldx, float* xn, float* inv_norm, int rows, int D, tt_stream_t stream);
+/*   dx = (dxn - xn * <xn, dxn>) * inv_norm */
+int tt_l2norm_bwd(const float* dxn, const float* xn, const float* inv_norm, float* dx, int rows, int D,
+                  tt_stream_t stream);
+/* ---- k18: in-place row L2 normalisation of the prototypes (time_tuning.py:124-128). */
+int tt_normalize_rows_inplace(float* w, int rows, int D, tt_stream_t stream);
+
+/* ---- k12: Sinkhorn-Knopp (time_tuning.py:157-168 + my_utils.py:246-274)
+ *   scores [B_total, K] (all columns of the global problem: local batch, queue rows, and for
+ *   world_size > 1 every rank's rows after an all-gather); q_out [rows_out, K] receives the
+ *   assignment of rows [row0, row0+rows_out).  Implements Q=exp(scores/eps)^T, Q/=sum,
+ *   `iters` x (row-normalise to 1/K, column-normalise to 1/B_total), final column normalise,
+ *   in scaling-vector form.  workspace: tt_sinkhorn_workspace_bytes(B_total, K). */
+int tt_sinkhorn(const float* scores, float* q_out, int B_total, int K, int row0, int rows_out, float eps,
+                int iters, void* workspace, size_t workspace_bytes, tt_stream_t stream);
+size_t tt_sinkhorn_workspace_bytes(int B_total, int K);
+
+/* ---- k14: temporal label propagation (time_tuning.py:143-154 -> mask_propagation.py:396-496)
+ *   xn   [fs, bs, n, D]  L2-normalised backbone tokens, time-major (frame t of clip b at [t][b])
+ *   seg0 [bs, n, K] fp32 Sinkhorn assignment of frame 0 (the seed labels)
+ *   labels [bs, n] int64 = argmax_K of the propagated map of the LAST frame
+ *   pmap_last [bs, n, K] fp64 optional (the map itself).
+ *   workspace: tt_label_propagate_workspace_bytes(...). */
+int tt_label_propagate(const float* xn, const float* seg0, int64_t* labels, double* pmap_last, int bs, int fs, int g,
+                       int D, int K, int n_last_frames, int radius, int topk, float temperature, void* workspace,
+                       size_t workspace_bytes, tt_stream_t stream);
+size_t tt_label_propagate_workspace_bytes(int bs, int fs, int g, int D, int K, int n_last_frames);
+
+/* ---- k15: CrossEntropyLoss(scores/temp, labels), mean over patches then batch
+ *      (time_tuning.py:296-302), with its gradient w.r.t. scores.
+ *   scores [rows,K]; labels int64[rows]; loss_out[1]; dscores [rows,K] (= d loss / d scores).
+ *   workspace: tt_ce_workspace_bytes(rows). */
+int tt_ce_loss_fwd_bwd(const float* scores, const int64_t* labels, float* loss_out, float* dscores, int rows, int K,
+                       float temperature, void* workspace, size_t workspace_bytes, tt_stream_t stream);
+size_t tt_ce_workspace_bytes(int rows);
+
+/* ---- k13: queue FIFO update (time_tuning.py:258-261): shift down by m rows, write feats[idx[i]]
+ *   at the head.  queue [Q,D]; feats [R,D]; idx int64[m].  scratch [Q,D] (caller-owned). */
+int tt_queue_push(float* queue, float* scratch, const float* feats, const int64_t* idx, int Q, int D, int m,
+                  tt_stream_t stream);
+
+/* ---- k17: AdamW over a table of tensors (time_tuning.py:413-429; torch.optim.AdamW defaults)
+ *   Up to TT_MAX_TENSORS per call.  step is the 1-based step count of every tensor in the call. */
+#define TT_MAX_TENSORS 40
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  long long n;
+  float lr;
+  float weight_decay;
+} tt_adamw_tensor;
+int tt_adamw_step(const tt_adamw_tensor* tensors, int count, int step, float beta1, float beta2, float eps,
+                  tt_stream_t stream);
+
+/* ---- k19: EMA teacher update (time_tuning.py:109-118): t = t*(1-m) + s*m over n floats. */
+int tt_ema_update(float* teacher, const float* student, long long n, double momentum, tt_stream_t stream);
+
+/* ---- misc elementwise used between the sites above */
+int tt_add_inplace(float* dst, const float* src, long long n, tt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIMETUNING_HIP_H */

@@ -1,0 +1,244 @@
+"""GPU parity tests, one per C-ABI op, against the CPU oracle / plain torch fp64 on seeded inputs.
+Every call goes through libtimetuning_hip.so (ctypes); nothing here can pass on a CPU fallback.
+Tolerance: the north-star bound is 1e-3 relative fp32; the kernels are exact-f32 MFMA / VALU, so the
+tests hold them to 2e-5 (measured headroom) unless stated."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from oracle import timet_oracle as O
+from timetuning_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from timetuning_amd import hip_ops
+
+    return hip_ops
+
+
+def dev(a):
+    return torch.as_tensor(a).cuda().contiguous()
+
+
+def rnd(name, *shape, std=1.0):
+    return torch.from_numpy(synth.normal("t." + name, shape, std))
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (591, 1152, 384), (130, 72, 20), (64, 64, 64), (257, 200, 256), (25216, 384, 1536)])
+def test_linear_fwd(ops, M, N, K):
+    x, w, b, r = rnd("lx", M, K), rnd("lw", N, K, std=0.05), rnd("lb", N), rnd("lr", M, N)
+    ref = F.linear(x.double(), w.double(), b.double())
+    y = ops.linear_fwd(dev(x), dev(w), dev(b))
+    assert rel_err(y.cpu(), ref) < TOL
+    y2, pre = ops.linear_fwd(dev(x), dev(w), dev(b), residual=dev(r), act=1, save_pre=True)
+    assert rel_err(pre.cpu(), ref) < TOL
+    assert rel_err(y2.cpu(), F.gelu(ref) + r.double()) < TOL
+    y3 = ops.linear_fwd(dev(x), dev(w))
+    assert rel_err(y3.cpu(), F.linear(x.double(), w.double())) < TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(788, 384, 1536), (394, 1024, 384), (130, 72, 20), (6272, 200, 256)])
+def test_linear_bwd(ops, M, N, K):
+    dy, w, x, pre = rnd("bdy", M, N), rnd("bw", N, K, std=0.05), rnd("bx", M, K), rnd("bpre", M, K)
+    dx = ops.linear_bwd_data(dev(dy), dev(w))
+    assert rel_err(dx.cpu(), dy.double() @ w.double()) < TOL
+    pr = pre.double().requires_grad_(True)
+    F.gelu(pr).backward(dy.double() @ w.double())
+    dx2 = ops.linear_bwd_data(dev(dy), dev(w), gelu_pre=dev(pre))
+    assert rel_err(dx2.cpu(), pr.grad) < TOL
+    dw, db = ops.linear_bwd_weight(dev(dy), dev(x))
+    assert rel_err(dw.cpu(), dy.double().T @ x.double()) < TOL
+    assert rel_err(db.cpu(), dy.double().sum(0)) < TOL
+
+
+def test_gemm_batched_and_layouts(ops):
+    A, B = rnd("ga", 5, 196, 64), rnd("gb", 5, 196, 64)
+    C = ops.gemm(dev(A), dev(B))
+    assert rel_err(C.cpu(), A.double() @ B.double().transpose(1, 2)) < TOL
+    A2, B2 = rnd("ga2", 300, 132), rnd("gb2", 300, 88)  # both stored [K][*]
+    C2 = ops.gemm(dev(A2), dev(B2), a_mmajor=True, b_nmajor=True, alpha=0.5)
+    assert rel_err(C2.cpu(), 0.5 * A2.double().T @ B2.double()) < TOL
+
+
+@pytest.mark.parametrize("patch,D,Fr", [(16, 384, 5), (8, 64, 2)])
+def test_patch_embed(ops, patch, D, Fr):
+    n = (224 // patch) ** 2
+    p = {"patch_embed.proj.weight": rnd("pw", D, 3, patch, patch, std=0.05), "patch_embed.proj.bias": rnd("pb", D),
+         "cls_token": rnd("pc", 1, 1, D), "pos_embed": rnd("pp", 1, n + 1, D)}
+    x = rnd("pimg", Fr, 3, 224, 224)
+    ref = O.prepare_tokens({k: v.double() for k, v in p.items()}, x.double(), patch)
+    tok = ops.patch_embed_fwd(dev(x), dev(p["patch_embed.proj.weight"].reshape(D, -1)), dev(p["patch_embed.proj.bias"]),
+                              dev(p["cls_token"].reshape(D)), dev(p["pos_embed"].reshape(n + 1, D)), patch)
+    assert rel_err(tok.cpu(), ref) < TOL
+    fmap = torch.tensor([Fr - 1, 0, 1], dtype=torch.int32)
+    tok2 = ops.patch_embed_fwd(dev(x), dev(p["patch_embed.proj.weight"].reshape(D, -1)), dev(p["patch_embed.proj.bias"]),
+                               dev(p["cls_token"].reshape(D)), dev(p["pos_embed"].reshape(n + 1, D)), patch, frame_map=dev(fmap))
+    assert rel_err(tok2.cpu(), ref[fmap.long()]) < TOL
+
+
+@pytest.mark.parametrize("rows,D", [(788, 384), (37, 768), (5, 64), (3, 1000)])
+def test_layernorm(ops, rows, D):
+    x, g, b, dy = rnd("nx", rows, D) * 3 + 0.7, rnd("ng", D) * 0.1 + 1, rnd("nb", D), rnd("ndy", rows, D)
+    xd = x.double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.layer_norm(xd, (D,), gd, bd, 1e-6)
+    ref.backward(dy.double())
+    y, mean, rstd = ops.layernorm_fwd(dev(x), dev(g), dev(b), save_stats=True)
+    assert rel_err(y.cpu(), ref.detach()) < TOL
+    dx, dg, db = ops.layernorm_bwd(dev(dy), dev(x), dev(g), mean, rstd)
+    assert rel_err(dx.cpu(), xd.grad) < 5e-5
+    assert rel_err(dg.cpu(), gd.grad) < 5e-5
+    assert rel_err(db.cpu(), bd.grad) < 5e-5
+    acc = dev(rnd("nacc", rows, D))
+    dx2, _, _ = ops.layernorm_bwd(dev(dy), dev(x), dev(g), mean, rstd, need_wgrad=False, dx_accum=acc.clone())
+    assert rel_err(dx2.cpu(), xd.grad + acc.cpu().double()) < 5e-5
+
+
+def _attn_ref(qkv, H):
+    Fr, N, D3 = qkv.shape
+    D = D3 // 3
+    hd = D // H
+    t = qkv.reshape(Fr, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    a = ((q @ k.transpose(-2, -1)) * hd ** -0.5)
+    lse = torch.logsumexp(a, -1)
+    p = a.softmax(-1)
+    return (p @ v).transpose(1, 2).reshape(Fr, N, D), lse, p
+
+
+@pytest.mark.parametrize("Fr,N,H", [(3, 197, 6), (2, 50, 2), (1, 256, 1), (2, 120, 3), (1, 17, 12)])
+def test_attention_fwd_bwd(ops, Fr, N, H):
+    qkv = rnd("aq", Fr, N, 3 * H * 64) * 1.5
+    do = rnd("ado", Fr, N, H * 64)
+    qd = qkv.double().requires_grad_(True)
+    ref, lse_ref, p_ref = _attn_ref(qd, H)
+    ref.backward(do.double())
+    out, lse, probs = ops.attention_fwd(dev(qkv), H, save_lse=True, return_probs=True)
+    assert rel_err(out.cpu(), ref.detach()) < TOL
+    assert rel_err(lse.cpu(), lse_ref.detach()) < TOL
+    assert rel_err(probs.cpu(), p_ref.detach()) < TOL
+    dqkv = ops.attention_bwd(dev(qkv), out, dev(do), lse, H)
+    assert rel_err(dqkv.cpu(), qd.grad) < 5e-5
+
+
+def test_l2norm(ops):
+    x, dxn = rnd("l2x", 700, 256) * 4, rnd("l2d", 700, 256)
+    xd = x.double().requires_grad_(True)
+    ref = F.normalize(xd, dim=-1)
+    ref.backward(dxn.double())
+    xn, inv = ops.l2norm_fwd(dev(x), save_inv=True)
+    assert rel_err(xn.cpu(), ref.detach()) < TOL
+    dx = ops.l2norm_bwd(dev(dxn), xn, inv)
+    assert rel_err(dx.cpu(), xd.grad) < TOL
+    big = dev(rnd("l2s", 20, 3, 96))  # row-strided view: rows of the middle slice
+    view = big[:, 1, :]
+    assert rel_err(ops.l2norm_fwd(view).cpu(), F.normalize(view.cpu().double(), dim=-1)) < TOL
+    w = dev(rnd("l2w", 200, 256))
+    ref_w = F.normalize(w.cpu().double(), dim=1)
+    ops.normalize_rows_(w)
+    assert rel_err(w.cpu(), ref_w) < TOL
+
+
+def test_sinkhorn_golden(ops, golden):
+    g = golden("sinkhorn")
+    kat = torch.log(torch.from_numpy(g["kat_in"]).t().contiguous()) * 0.05  # scores whose exp(./eps)^T is the KAT matrix
+    assert rel_err(ops.sinkhorn(dev(kat), 3).cpu(), g["kat_it3"]) < 1e-5
+    assert rel_err(ops.sinkhorn(dev(kat), 0).cpu(), g["kat_it0"]) < 1e-5
+    for tag in "abcd":
+        q = ops.sinkhorn(dev(g[f"{tag}_scores"]), int(g[f"{tag}_iters"]))
+        assert rel_err(q.cpu(), g[f"{tag}_q"]) < 5e-5, tag
+    g2 = golden("sinkhorn_w2")  # global problem solved once, rank 1's rows requested
+    q = ops.sinkhorn(dev(g2["scores"]), int(g2["iters"]), row0=196, rows_out=196)
+    assert rel_err(q.cpu(), g2["q"][196:]) < 5e-5
+
+
+def test_sinkhorn_c2_size_vs_oracle(ops):
+    """BASELINE C2: K=200, B=6272 (+ queue rows variant), checked against the oracle and by invariants."""
+    for B in (6272, 6272 + 2048):
+        x = F.normalize(rnd(f"skx{B}", B, 64), dim=1)
+        p = F.normalize(rnd("skp", 200, 64), dim=1)
+        scores = x @ p.t()
+        q = ops.sinkhorn(dev(scores), 10).cpu()
+        ref = O.sinkhorn(torch.exp(scores.double() / 0.05).t(), 10)
+        assert rel_err(q, ref) < 5e-5
+        assert rel_err(q.sum(1), torch.ones(B)) < 1e-5          # rows of q sum to 1
+        col = q.double().sum(0)                                   # prototypes are used (nearly) equally
+        assert (col.max() / col.min()) < 1.05
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
+def test_label_propagation_golden(ops, golden, tag):
+    g = golden("label_prop")
+    gg, fs, D, K, nlast, r, topk = [int(v) for v in g[f"{tag}_cfg"]]
+    feats = torch.from_numpy(g[f"{tag}_feats"])                      # [fs, n, D]
+    if D % 4:
+        pytest.skip("feature dim not a multiple of 4")
+    xn = ops.l2norm_fwd(dev(feats.reshape(-1, D))).reshape(fs, 1, gg * gg, D)
+    labels, pmap = ops.label_propagate(xn, dev(g[f"{tag}_q0"]).reshape(1, gg * gg, K), nlast, r, topk, 0.1, return_pmap=True)
+    ref = g[f"{tag}_maps"][-1].reshape(K, gg * gg).T                 # [n, K] fp64
+    got = pmap.cpu().numpy()[0]
+    # a near-tie in the top-k can legitimately swap one source; require agreement on (almost) all queries
+    bad = np.abs(got - ref).max(1) > 1e-5 * np.abs(ref).max()
+    assert bad.mean() <= 0.01, f"{bad.sum()} of {bad.size} queries differ"
+    assert (labels.cpu().numpy()[0] != ref.argmax(1)).mean() <= 0.01
+
+
+def test_label_propagation_batch(ops):
+    bs, fs, g, D, K = 3, 4, 14, 384, 200
+    feats = rnd("lpf", fs, bs, g * g, D)
+    feats[1:] = 0.7 * feats[:1] + 0.3 * feats[1:]
+    q0 = F.softmax(rnd("lpq", bs, g * g, K) * 3, -1)
+    xn = ops.l2norm_fwd(dev(feats.reshape(-1, D))).reshape(fs, bs, g * g, D)
+    labels, pmap = ops.label_propagate(xn, dev(q0), return_pmap=True)
+    for b in range(bs):
+        seed = q0[b].view(g, g, K).permute(2, 0, 1).unsqueeze(0)
+        ref = O.propagate_labels(7, 6, 5, g, feats[:, b], seed)[-1].reshape(K, g * g).T.numpy()
+        bad = np.abs(pmap[b].cpu().numpy() - ref).max(1) > 1e-5 * np.abs(ref).max()
+        assert bad.mean() <= 0.01
+        assert (labels[b].cpu().numpy() != ref.argmax(1)).mean() <= 0.01
+
+
+def test_ce_loss(ops):
+    rows, K = 392, 200
+    s, lab = rnd("ces", rows, K) * 0.3, torch.from_numpy(np.random.default_rng(0).integers(0, K, rows))
+    sd = s.double().requires_grad_(True)
+    ref = F.cross_entropy(sd / 0.1, lab)
+    ref.backward()
+    loss, ds = ops.ce_loss_fwd_bwd(dev(s), dev(lab), 0.1)
+    assert abs(loss.item() - ref.item()) < 1e-5
+    assert rel_err(ds.cpu(), sd.grad) < TOL
+
+
+def test_adamw_ema_queue(ops):
+    shapes = [(200, 256), (1024,), (384, 1536), (7,)]
+    ps = [torch.nn.Parameter(rnd(f"op{i}", *s)) for i, s in enumerate(shapes)]
+    ref_opt = torch.optim.AdamW([{"params": ps[:2], "lr": 1e-3, "weight_decay": 0.04}, {"params": ps[2:], "lr": 1e-4, "weight_decay": 0.0}])
+    mine = [dict(p=dev(p.detach().clone()), m=None, v=None) for p in ps]
+    for e in mine:
+        e["m"], e["v"] = torch.zeros_like(e["p"]), torch.zeros_like(e["p"])
+    for step in range(1, 4):
+        grads = [rnd(f"og{step}.{i}", *s) for i, s in enumerate(shapes)]
+        for p, gr in zip(ps, grads):
+            p.grad = gr.clone()
+        ref_opt.step()
+        ents = [(e["p"], dev(gr), e["m"], e["v"], 1e-3 if i < 2 else 1e-4, 0.04 if i < 2 else 0.0) for i, (e, gr) in enumerate(zip(mine, grads))]
+        ops.adamw_step_(ents, step)
+        for e, p in zip(mine, ps):
+            assert rel_err(e["p"].cpu(), p.detach()) < 1e-6
+    t, s = rnd("et", 100003), rnd("es", 100003)
+    m = 0.9951234567
+    tt = ops.ema_update_(dev(t), dev(s), m)
+    assert rel_err(tt.cpu(), t * (1.0 - m) + s * m) < 1e-6
+    queue, feats = rnd("qq", 40, 32), rnd("qf", 392, 32)
+    idx = torch.randperm(392)[:20]
+    ref_q = queue.clone()
+    ref_q[20:] = ref_q[:-20].clone()
+    ref_q[:20] = feats[idx]
+    qd = ops.queue_push_(dev(queue), dev(feats), dev(idx))
+    assert torch.equal(qd.cpu(), ref_q)

@@ -1,0 +1,108 @@
+"""ctypes binding of libtimetuning_hip.so (the C ABI in include/timetuning_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a symbol cannot be
+resolved, importing a HIP op raises.  ``build()`` compiles the library in-tree with hipcc
+(gfx950); the resulting ``timetuning_amd/libtimetuning_hip.so`` travels to the GPU box.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtimetuning_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+c_f32p = C.c_void_p
+c_vp = C.c_void_p
+c_i = C.c_int
+c_ll = C.c_longlong
+c_f = C.c_float
+c_d = C.c_double
+c_sz = C.c_size_t
+
+
+class AdamwTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_longlong),
+                ("lr", C.c_float), ("weight_decay", C.c_float)]
+
+
+# name -> (restype, argtypes); must list every symbol include/timetuning_hip.h declares
+SIGNATURES = {
+    "tt_last_error": (C.c_char_p, []),
+    "tt_abi_version": (c_i, []),
+    "tt_device_info": (c_i, [C.c_char_p, c_i]),
+    "tt_linear_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
+    "tt_linear_bwd_data": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp]),
+    "tt_linear_bwd_weight": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "tt_colsum_workspace_bytes": (c_sz, [c_i, c_i]),
+    "tt_colsum": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_sz, c_vp]),
+    "tt_gemm_f32": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_ll, c_ll, c_ll, c_vp]),
+    "tt_patch_embed_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "tt_layernorm_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_vp]),
+    "tt_layernorm_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "tt_layernorm_bwd_workspace_bytes": (c_sz, [c_i, c_i]),
+    "tt_attention_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp]),
+    "tt_attention_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
+    "tt_attention_bwd_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "tt_l2norm_fwd": (c_i, [c_vp, c_i, c_vp, c_vp, c_i, c_i, c_vp]),
+    "tt_l2norm_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp]),
+    "tt_normalize_rows_inplace": (c_i, [c_vp, c_i, c_i, c_vp]),
+    "tt_sinkhorn": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_i, c_vp, c_sz, c_vp]),
+    "tt_sinkhorn_workspace_bytes": (c_sz, [c_i, c_i]),
+    "tt_label_propagate": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
+    "tt_label_propagate_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "tt_ce_loss_fwd_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
+    "tt_ce_workspace_bytes": (c_sz, [c_i]),
+    "tt_queue_push": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp]),
+    "tt_adamw_step": (c_i, [C.POINTER(AdamwTensor), c_i, c_i, c_f, c_f, c_f, c_vp]),
+    "tt_ema_update": (c_i, [c_vp, c_vp, c_ll, c_d, c_vp]),
+    "tt_add_inplace": (c_i, [c_vp, c_vp, c_ll, c_vp]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into timetuning_amd/libtimetuning_hip.so (hipcc cross-compiles without a GPU)."""
+    proc = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or proc.returncode != 0:
+        print(proc.stdout[-4000:])
+        print(proc.stderr[-4000:])
+    if proc.returncode != 0:
+        raise HipLibraryError("building libtimetuning_hip.so failed")
+    return LIB_PATH
+
+
+def load():
+    """Return the loaded library with argtypes set; raises HipLibraryError (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or `make -C timetuning_amd/csrc`). There is no CPU fallback for the HIP path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().tt_last_error().decode(errors="replace")
+        raise HipLibraryError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,218 @@
+// Fused multi-head self-attention for ViT token counts (N <= 256, head_dim = 64), fp32 on
+// v_mfma_f32_16x16x4_f32.  Replaces q@k^T*scale -> softmax -> @v (dino_vision_transformer.py:125-129)
+// without ever writing the N x N matrix to HBM (the reference materialises attn[F,h,N,N] per layer).
+//
+// Layout trick: each wave owns 16 query rows and computes S^T = K Q^T, so the MFMA C/D layout puts the
+// query on the lane (col = lane & 15) and the keys on registers (key = 16*tile + 4*(lane >> 4) + e).  The whole
+// score row of a query (<= 256 keys = 64 registers) therefore lives in one lane-column: the softmax needs two
+// cross-lane steps (xor 16, xor 32) instead of a 64-lane reduction, and P^T is already in B-operand layout for
+// O^T = V^T P^T (the accumulator feeds the next MFMA with no LDS round trip and no shuffle).
+//
+// A workgroup = 4 waves = 64 queries of one (frame, head); K and V stream through LDS in 32-key chunks
+// (double-buffered, next chunk's global loads in flight during the current chunk's MFMAs).  q/k/v are read
+// straight out of the qkv Linear's [F, N, 3*H*64] output (256-byte contiguous head rows): no permute kernel.
+#include "common.hpp"
+
+namespace tt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HD = 64;
+constexpr int KCH = 32;        // keys per LDS chunk
+constexpr int KSTR = 66;       // K row stride (floats): (2*i + g) distinct banks for the A-operand read
+constexpr int VSTR = 68;       // V row stride: 16*g + i distinct banks
+
+template <int NT>  // NT = number of 16-key tiles kept in registers (N <= 16 * NT)
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                            float* __restrict__ lse, float* __restrict__ probs, int N, int H,
+                                                            float scale) {
+  constexpr int NC = (NT + 1) / 2;  // chunks of 32 keys
+  __shared__ __attribute__((aligned(16))) float smem[2 * KCH * KSTR + 2 * KCH * VSTR];
+  float* Ks = smem;                   // [2][KCH][KSTR]
+  float* Vs = smem + 2 * KCH * KSTR;  // [2][KCH][VSTR]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = lane & 15, g = lane >> 4;
+  const int f = blockIdx.z, h = blockIdx.y;
+  const int D3 = 3 * H * HD;
+  const float* base = qkv + (long long)f * N * D3 + h * HD;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const bool wave_active = q0 < N;
+
+  // ---- stage the 64 x 64 Q tile through LDS (coalesced 16-B loads), then pull this lane's 16 operands
+  {
+    float* Qs = smem;  // [64][KSTR], aliases the K buffers before the main loop
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      const int q = blockIdx.x * 64 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < N) v = *reinterpret_cast<const float4*>(base + (long long)q * D3 + c4);
+      float2* d = reinterpret_cast<float2*>(Qs + row * KSTR + c4);
+      d[0] = make_float2(v.x, v.y);
+      d[1] = make_float2(v.z, v.w);
+    }
+  }
+  __syncthreads();
+  float qreg[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) qreg[s] = smem[(wave * 16 + qi) * KSTR + 4 * s + g] * scale;
+  __syncthreads();
+
+  float4 st[2];
+  auto gload = [&](int chunk, int which) {  // which: 1 = K, 2 = V
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      const int key = chunk * KCH + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (key < N) v = *reinterpret_cast<const float4*>(base + (long long)key * D3 + which * H * HD + c4);
+      st[i] = v;
+    }
+  };
+  auto swrite_k = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      float2* d = reinterpret_cast<float2*>(Ks + (buf * KCH + row) * KSTR + c4);
+      d[0] = make_float2(st[i].x, st[i].y);
+      d[1] = make_float2(st[i].z, st[i].w);
+    }
+  };
+  auto swrite_v = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      *reinterpret_cast<float4*>(Vs + (buf * KCH + row) * VSTR + c4) = st[i];
+    }
+  };
+
+  // ---- phase 1: S^T = K Q^T, all key tiles kept in registers
+  f32x4 sacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  gload(0, 1);
+  swrite_k(0);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < NC) gload(c + 1, 1);
+    if (wave_active) {
+      const float* kp = Ks + (buf * KCH + qi) * KSTR + g;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        // two independent accumulator chains (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
+        sacc[2 * c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[4 * s], qreg[s], sacc[2 * c], 0, 0, 0);
+        if (2 * c + 1 < NT)
+          sacc[2 * c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[16 * KSTR + 4 * s], qreg[s], sacc[2 * c + 1], 0, 0, 0);
+      }
+    }
+    if (c + 1 < NC) swrite_k(buf ^ 1);
+    __syncthreads();
+  }
+
+  // first V chunk's loads fly under the softmax
+  gload(0, 2);
+
+  // ---- softmax over the key axis (registers + 2 cross-lane steps)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = 16 * t + 4 * g + e;
+      if (key >= N) sacc[t][e] = -INFINITY;
+      mx = fmaxf(mx, sacc[t][e]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float p = expf(sacc[t][e] - mx);
+      sacc[t][e] = p;
+      sum += p;
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  const int q = q0 + qi;
+  if (wave_active && q < N) {
+    if (lse && g == 0) lse[((long long)f * H + h) * N + q] = mx + logf(sum);
+    if (probs) {
+      float* pr = probs + (((long long)f * H + h) * N + q) * N;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = 16 * t + 4 * g + e;
+          if (key < N) pr[key] = sacc[t][e] * inv;
+        }
+    }
+  }
+
+  // ---- phase 2: O^T = V^T P^T
+  f32x4 oacc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) oacc[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  swrite_v(0);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < NC) gload(c + 1, 2);
+    if (wave_active) {
+#pragma unroll
+      for (int tt2 = 0; tt2 < 2; ++tt2) {
+        const int t = 2 * c + tt2;
+        if (t < NT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float* vp = Vs + (buf * KCH + 16 * tt2 + 4 * g + e) * VSTR + qi;
+            const float pb = sacc[t][e];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[16 * d], pb, oacc[d], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (c + 1 < NC) swrite_v(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (wave_active && q < N) {
+    float* o = out + ((long long)f * N + q) * (H * HD) + h * HD + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      *reinterpret_cast<float4*>(o + 16 * d) = make_float4(oacc[d][0] * inv, oacc[d][1] * inv, oacc[d][2] * inv, oacc[d][3] * inv);
+  }
+}
+
+template <int NT>
+static int launch_fwd(const float* qkv, float* out, float* lse, float* probs, int F, int N, int H, float scale, hipStream_t s) {
+  dim3 grid((N + 63) / 64, H, F);
+  hipLaunchKernelGGL((attention_fwd_kernel<NT>), grid, dim3(256), 0, s, qkv, out, lse, probs, N, H, scale);
+  TT_CHECK_LAUNCH("attention_fwd");
+  return TT_OK;
+}
+
+}  // namespace tt
+
+extern "C" int tt_attention_fwd(const float* qkv, float* out, float* lse, float* probs, int F, int N, int H, int hd,
+                                float scale, tt_stream_t stream) {
+  using namespace tt;
+  TT_REQUIRE(qkv && out, "attention_fwd: null pointer");
+  TT_REQUIRE(hd == 64, "attention_fwd: head_dim must be 64 (got %d)", hd);
+  TT_REQUIRE(F > 0 && H > 0 && N > 0 && N <= 256, "attention_fwd: need 0 < N <= 256 (got %d); larger token grids need the KV-tiled variant", N);
+  TT_REQUIRE(aligned16(qkv) && aligned16(out), "attention_fwd: buffers must be 16-byte aligned");
+  hipStream_t s = as_stream(stream);
+  const int nt = (N + 15) / 16;
+  if (nt <= 4) return launch_fwd<4>(qkv, out, lse, probs, F, N, H, scale, s);
+  if (nt <= 8) return launch_fwd<8>(qkv, out, lse, probs, F, N, H, scale, s);
+  if (nt <= 13) return launch_fwd<13>(qkv, out, lse, probs, F, N, H, scale, s);
+  return launch_fwd<16>(qkv, out, lse, probs, F, N, H, scale, s);
+}

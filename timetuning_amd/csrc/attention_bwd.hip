@@ -1,0 +1,269 @@
+// Backward of the fused attention core (autograd of dino_vision_transformer.py:125-129) for the two trainable
+// blocks, fp32 on v_mfma_f32_16x16x4_f32.  Probabilities are recomputed from q, k and the forward's
+// log-sum-exp (nothing N x N is stored).  Two launches:
+//   dq kernel  - a wave owns 16 queries; per 16-key tile: S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta),
+//                dQ^T += K^T dS^T.  It also produces delta_q = <dO_q, O_q> and stores it for the second kernel.
+//   dkv kernel - a wave owns 16 keys; per 16-query tile: S = Q K^T, dP = dO V^T, P, dS, dV^T += dO^T P, dK^T += Q^T dS.
+// In both, the freshly computed accumulator tile (P / dS) is used as the B operand of the next MFMA directly from
+// registers: the C/D layout (col = lane & 15, row = 4 * (lane >> 4) + e) is the B layout for k = row, so no LDS
+// round trip or shuffle is needed.  No atomics: each output element has exactly one owner (deterministic).
+#include "common.hpp"
+
+namespace tt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BHD = 64, BCH = 32, BSTR = 68;  // chunk rows, LDS row stride (16 g + i banks for the transposed reads)
+
+// Loads a 64 x 64 tile (rows row0.., row stride ld) through LDS and returns this lane's 16 operand values
+// r[s] = tile[wave * 16 + (lane & 15)][4 s + (lane >> 4)].
+__device__ __forceinline__ void tile_to_regs(const float* __restrict__ src, long long ld, int row0, int nrows, float* stage,
+                                             float (&r)[16], int tid) {
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + row < nrows) v = *reinterpret_cast<const float4*>(src + (long long)(row0 + row) * ld + c4);
+    *reinterpret_cast<float4*>(stage + row * BSTR + c4) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 16; ++s) r[s] = stage[(wave * 16 + li) * BSTR + 4 * s + g];
+}
+
+__global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                               const float* __restrict__ dout, const float* __restrict__ lse,
+                                                               float* __restrict__ dqkv, float* __restrict__ delta, int N, int H,
+                                                               float scale) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * BCH * BSTR + 64 * BSTR];
+  float* Ks = smem;                   // [2][32][68]
+  float* Vs = smem + 2 * BCH * BSTR;  // [2][32][68]
+  float* stage = smem + 4 * BCH * BSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, qi = lane & 15, g = lane >> 4;
+  const int f = blockIdx.z, h = blockIdx.y, D = H * BHD, D3 = 3 * D;
+  const float* base = qkv + (long long)f * N * D3 + h * BHD;
+  const int q0 = blockIdx.x * 64, q = q0 + wave * 16 + qi;
+  const bool wave_active = q0 + wave * 16 < N;
+
+  float qreg[16], doreg[16], oreg[16];
+  tile_to_regs(base, D3, q0, N, stage, qreg, tid);
+  tile_to_regs(dout + (long long)f * N * D + h * BHD, D, q0, N, stage, doreg, tid);
+  tile_to_regs(out + (long long)f * N * D + h * BHD, D, q0, N, stage, oreg, tid);
+  float dl = 0.f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    dl += doreg[s] * oreg[s];
+    qreg[s] *= scale;
+  }
+  dl += __shfl_xor(dl, 16, 64);
+  dl += __shfl_xor(dl, 32, 64);
+  const float lse_q = (q < N) ? lse[((long long)f * H + h) * N + q] : 0.f;
+  if (q < N && g == 0) delta[((long long)f * H + h) * N + q] = dl;
+
+  float4 stk[2], stv[2];
+  auto gload = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      const int key = chunk * BCH + row;
+      stk[i] = stv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (key < N) {
+        stk[i] = *reinterpret_cast<const float4*>(base + (long long)key * D3 + D + c4);
+        stv[i] = *reinterpret_cast<const float4*>(base + (long long)key * D3 + 2 * D + c4);
+      }
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      *reinterpret_cast<float4*>(Ks + (buf * BCH + row) * BSTR + c4) = stk[i];
+      *reinterpret_cast<float4*>(Vs + (buf * BCH + row) * BSTR + c4) = stv[i];
+    }
+  };
+
+  f32x4 dq[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nchunks = (N + BCH - 1) / BCH;
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) gload(c + 1);
+    if (wave_active) {
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const float* kp = Ks + (buf * BCH + 16 * t2 + qi) * BSTR + g;
+        const float* vp = Vs + (buf * BCH + 16 * t2 + qi) * BSTR + g;
+        f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[4 * s], qreg[s], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[4 * s], doreg[s], dp, 0, 0, 0);
+        }
+        float ds[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = c * BCH + 16 * t2 + 4 * g + e;
+          const float p = (key < N) ? expf(sa[e] - lse_q) : 0.f;
+          ds[e] = p * (dp[e] - dl);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* kt = Ks + (buf * BCH + 16 * t2 + 4 * g + e) * BSTR + qi;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) dq[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt[16 * d], ds[e], dq[d], 0, 0, 0);
+        }
+      }
+    }
+    if (c + 1 < nchunks) swrite(buf ^ 1);
+    __syncthreads();
+  }
+  if (wave_active && q < N) {
+    float* o = dqkv + ((long long)f * N + q) * D3 + h * BHD + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      *reinterpret_cast<float4*>(o + 16 * d) = make_float4(dq[d][0] * scale, dq[d][1] * scale, dq[d][2] * scale, dq[d][3] * scale);
+  }
+}
+
+__global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                float* __restrict__ dqkv, int N, int H, float scale) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * BCH * BSTR + 64 * BSTR + 4 * BCH];
+  float* Qs = smem;                    // [2][32][68]
+  float* Os = smem + 2 * BCH * BSTR;   // dO chunks [2][32][68]
+  float* stage = smem + 4 * BCH * BSTR;
+  float* Ls = stage + 64 * BSTR;       // [2][32] lse, then [2][32] delta
+  float* Dl = Ls + 2 * BCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ki = lane & 15, g = lane >> 4;
+  const int f = blockIdx.z, h = blockIdx.y, D = H * BHD, D3 = 3 * D;
+  const float* base = qkv + (long long)f * N * D3 + h * BHD;
+  const float* dob = dout + (long long)f * N * D + h * BHD;
+  const int k0 = blockIdx.x * 64, key = k0 + wave * 16 + ki;
+  const bool wave_active = k0 + wave * 16 < N;
+
+  float kreg[16], vreg[16];
+  tile_to_regs(base + D, D3, k0, N, stage, kreg, tid);
+  tile_to_regs(base + 2 * D, D3, k0, N, stage, vreg, tid);
+#pragma unroll
+  for (int s = 0; s < 16; ++s) kreg[s] *= scale;
+
+  float4 stq[2], sto[2];
+  float stl = 0.f, std_ = 0.f;
+  auto gload = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      const int q = chunk * BCH + row;
+      stq[i] = sto[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < N) {
+        stq[i] = *reinterpret_cast<const float4*>(base + (long long)q * D3 + c4);
+        sto[i] = *reinterpret_cast<const float4*>(dob + (long long)q * D + c4);
+      }
+    }
+    if (tid < BCH) {
+      const int q = chunk * BCH + tid;
+      stl = (q < N) ? lse[((long long)f * H + h) * N + q] : 0.f;
+      std_ = (q < N) ? delta[((long long)f * H + h) * N + q] : 0.f;
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      *reinterpret_cast<float4*>(Qs + (buf * BCH + row) * BSTR + c4) = stq[i];
+      *reinterpret_cast<float4*>(Os + (buf * BCH + row) * BSTR + c4) = sto[i];
+    }
+    if (tid < BCH) {
+      Ls[buf * BCH + tid] = stl;
+      Dl[buf * BCH + tid] = std_;
+    }
+  };
+
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int nchunks = (N + BCH - 1) / BCH;
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) gload(c + 1);
+    if (wave_active) {
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const float* qp = Qs + (buf * BCH + 16 * t2 + ki) * BSTR + g;
+        const float* op = Os + (buf * BCH + 16 * t2 + ki) * BSTR + g;
+        f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(qp[4 * s], kreg[s], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(op[4 * s], vreg[s], dp, 0, 0, 0);
+        }
+        float p[4], ds[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ql = 16 * t2 + 4 * g + e;
+          const bool ok = (c * BCH + ql < N) && (key < N);
+          p[e] = ok ? expf(sa[e] - Ls[buf * BCH + ql]) : 0.f;
+          ds[e] = p[e] * (dp[e] - Dl[buf * BCH + ql]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* ot = Os + (buf * BCH + 16 * t2 + 4 * g + e) * BSTR + ki;
+          const float* qt = Qs + (buf * BCH + 16 * t2 + 4 * g + e) * BSTR + ki;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            dv[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(ot[16 * d], p[e], dv[d], 0, 0, 0);
+            dk[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(qt[16 * d], ds[e], dk[d], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (c + 1 < nchunks) swrite(buf ^ 1);
+    __syncthreads();
+  }
+  if (wave_active && key < N) {
+    float* ok_ = dqkv + ((long long)f * N + key) * D3 + D + h * BHD + 4 * g;
+    float* ov = ok_ + D;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      *reinterpret_cast<float4*>(ok_ + 16 * d) = make_float4(dk[d][0] * scale, dk[d][1] * scale, dk[d][2] * scale, dk[d][3] * scale);
+      *reinterpret_cast<float4*>(ov + 16 * d) = make_float4(dv[d][0], dv[d][1], dv[d][2], dv[d][3]);
+    }
+  }
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" size_t tt_attention_bwd_workspace_bytes(int F, int N, int H, int hd) {
+  (void)hd;
+  return (size_t)F * H * N * sizeof(float);
+}
+
+extern "C" int tt_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N,
+                                int H, int hd, float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(qkv && out && dout && lse && dqkv && workspace, "attention_bwd: null pointer");
+  TT_REQUIRE(hd == 64, "attention_bwd: head_dim must be 64 (got %d)", hd);
+  TT_REQUIRE(F > 0 && H > 0 && N > 0, "attention_bwd: bad shape");
+  TT_REQUIRE(workspace_bytes >= tt_attention_bwd_workspace_bytes(F, N, H, hd), "attention_bwd: workspace too small");
+  TT_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), "attention_bwd: buffers must be 16-byte aligned");
+  hipStream_t s = as_stream(stream);
+  float* delta = static_cast<float*>(workspace);
+  dim3 grid((N + 63) / 64, H, F);
+  hipLaunchKernelGGL(attention_bwd_dq_kernel, grid, dim3(256), 0, s, qkv, out, dout, lse, dqkv, delta, N, H, scale);
+  hipLaunchKernelGGL(attention_bwd_dkv_kernel, grid, dim3(256), 0, s, qkv, dout, lse, delta, dqkv, N, H, scale);
+  TT_CHECK_LAUNCH("attention_bwd");
+  return TT_OK;
+}

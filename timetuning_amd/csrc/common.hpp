@@ -1,0 +1,71 @@
+// Shared host/device helpers for libtimetuning_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+
+#include "../../include/timetuning_hip.h"
+
+namespace tt {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(tt_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define TT_REQUIRE(cond, ...)         \
+  do {                                \
+    if (!(cond)) {                    \
+      ::tt::set_error(__VA_ARGS__);   \
+      return TT_EINVAL;               \
+    }                                 \
+  } while (0)
+
+#define TT_CHECK_LAUNCH(name)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      ::tt::set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return TT_ELAUNCH;                                                   \
+    }                                                                      \
+  } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- device helpers -------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact-erf GELU (nn.GELU default) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// XCD-aware bijective remap of a linear workgroup id (guide T1): the dispatcher deals consecutive
+// ids round-robin over the 8 XCDs; this hands each XCD a contiguous run of logical tiles so that
+// neighbouring tiles (which share an operand panel) hit the same 4 MiB L2.
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, slot = id >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+}  // namespace tt

@@ -1,0 +1,339 @@
+// fp32 GEMM on the CDNA4 matrix cores: v_mfma_f32_32x32x2_f32 (exact f32 in / f32 accumulate).
+//
+// Why f32 MFMA and not bf16: the north-star contract is <= 1e-3 relative fp32 on patch embeddings
+// after 12 residual blocks, and gfx950 has no TF32/xf32 path; the f32 MFMA is bit-for-bit an fmaf
+// chain at the f32 vector rate (157 TFLOP/s) while leaving the VALU free for epilogues.
+//
+// Tiling: 256 threads = 4 waves in a 2x2 grid; each wave owns WM x WN accumulator tiles of 32x32
+// (block tile 64*WM x 64*WN), K is consumed in slabs of BK = 16 through a double-buffered LDS image
+// stored k-major ([k][m] / [k][n]) so that one ds_read_b32 per lane yields an MFMA operand:
+//   A operand lane l holds A[row = l & 31][k = l >> 5],  B operand lane l holds B[k = l >> 5][col = l & 31].
+// Global loads are 16 B per lane; a k-contiguous source (activations [M][K], nn.Linear weights [N][K])
+// is transposed on the way into LDS, an m/n-contiguous source (dgrad / wgrad operands) is copied.
+// The next slab's global loads are issued before the current slab's 8 x WM x WN MFMAs and written to
+// the other LDS buffer afterwards: one barrier per slab.
+//
+// Epilogue (fused): alpha, bias, pre-activation store, exact GELU,
+// row scale, GELU-derivative multiply (dgrad through fc1 / head activations), residual add, and for the
+// patch-embed instance the row remap to token order plus the pos-embed add.
+#include "common.hpp"
+
+namespace tt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  float alpha;
+  const float* bias;       // [N]
+  const float* residual;   // [M][ldc]
+  float* pre_out;          // [M][ldc]
+  const float* gelu_pre;   // [M][ldc]: C *= gelu'(gelu_pre)
+  const float* row_scale;  // [M]
+  int act;                 // 1 = GELU
+  long long strideA, strideB, strideC;
+  // patch-embed (AMODE == 2)
+  const int* frame_map;
+  int Cin, H, W, P, gw, n_patch;
+  const float* pos;  // [(n_patch+1)][N]
+};
+
+constexpr int BK = 16;
+
+template <int WM, int WN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (LDA + LDB)];
+  float* As = lds;
+  float* Bs = lds + 2 * BK * LDA;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int ntn = (g.N + BN - 1) / BN;
+  const int ntm = (g.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const float* __restrict__ A = g.A + (long long)blockIdx.y * g.strideA;
+  const float* __restrict__ B = g.B + (long long)blockIdx.y * g.strideB;
+  float* __restrict__ C = g.C + (long long)blockIdx.y * g.strideC;
+
+  float4 ra[WM], rb[WN];
+
+  auto load_a = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int u = tid + 256 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (AMODE == 1) {  // stored [K][lda], m contiguous
+        const int kr = u / (BM / 4), mc = (u % (BM / 4)) * 4;
+        const int k = k0 + kr, m = m0 + mc;
+        if (k < g.K && m < g.M) v = *reinterpret_cast<const float4*>(A + (long long)k * g.lda + m);
+      } else {
+        const int row = u >> 2, kc = (u & 3) * 4;
+        const int m = m0 + row, k = k0 + kc;
+        if (m < g.M && k < g.K) {
+          if (AMODE == 0) {
+            v = *reinterpret_cast<const float4*>(A + (long long)m * g.lda + k);
+          } else {  // patch gather: row = (frame, py, px), k = (c, i, j)
+            const int f = m / g.n_patch, pi = m - f * g.n_patch;
+            const int py = pi / g.gw, px = pi - py * g.gw;
+            const int pp = g.P * g.P;
+            const int c = k / pp, rem = k - c * pp;
+            const int ii = rem / g.P, jj = rem - ii * g.P;
+            const int src = g.frame_map ? g.frame_map[f] : f;
+            v = *reinterpret_cast<const float4*>(
+                A + (((long long)src * g.Cin + c) * g.H + (py * g.P + ii)) * g.W + px * g.P + jj);
+          }
+        }
+      }
+      ra[i] = v;
+    }
+  };
+  auto load_b = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      const int u = tid + 256 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (BMODE == 1) {  // stored [K][ldb], n contiguous
+        const int kr = u / (BN / 4), nc = (u % (BN / 4)) * 4;
+        const int k = k0 + kr, n = n0 + nc;
+        if (k < g.K && n < g.N) v = *reinterpret_cast<const float4*>(B + (long long)k * g.ldb + n);
+      } else {  // stored [N][ldb], k contiguous
+        const int row = u >> 2, kc = (u & 3) * 4;
+        const int n = n0 + row, k = k0 + kc;
+        if (n < g.N && k < g.K) v = *reinterpret_cast<const float4*>(B + (long long)n * g.ldb + k);
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_a = [&](int buf) {
+    float* dst = As + buf * BK * LDA;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int u = tid + 256 * i;
+      if (AMODE == 1) {
+        const int kr = u / (BM / 4), mc = (u % (BM / 4)) * 4;
+        *reinterpret_cast<float4*>(dst + kr * LDA + mc) = ra[i];
+      } else {
+        const int row = u >> 2, kc = (u & 3) * 4;
+        dst[(kc + 0) * LDA + row] = ra[i].x;
+        dst[(kc + 1) * LDA + row] = ra[i].y;
+        dst[(kc + 2) * LDA + row] = ra[i].z;
+        dst[(kc + 3) * LDA + row] = ra[i].w;
+      }
+    }
+  };
+  auto store_b = [&](int buf) {
+    float* dst = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      const int u = tid + 256 * i;
+      if (BMODE == 1) {
+        const int kr = u / (BN / 4), nc = (u % (BN / 4)) * 4;
+        *reinterpret_cast<float4*>(dst + kr * LDB + nc) = rb[i];
+      } else {
+        const int row = u >> 2, kc = (u & 3) * 4;
+        dst[(kc + 0) * LDB + row] = rb[i].x;
+        dst[(kc + 1) * LDB + row] = rb[i].y;
+        dst[(kc + 2) * LDB + row] = rb[i].z;
+        dst[(kc + 3) * LDB + row] = rb[i].w;
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (g.K + BK - 1) / BK;
+  load_a(0);
+  load_b(0);
+  store_a(0);
+  store_b(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+      load_a((kt + 1) * BK);
+      load_b((kt + 1) * BK);
+    }
+    const float* pa = As + buf * BK * LDA + h * LDA + wm * (32 * WM) + r;
+    const float* pb = Bs + buf * BK * LDB + h * LDB + wn * (32 * WN) + r;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = pa[kk * 2 * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = pb[kk * 2 * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_a(buf ^ 1);
+      store_b(buf ^ 1);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = n0 + wn * (32 * WN) + j * 32 + r;
+      if (n >= g.N) continue;
+      const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * (32 * WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m >= g.M) continue;
+        float v = acc[i][j][e] * g.alpha + bias;
+        long long off;
+        if (AMODE == 2) {
+          const int f = m / g.n_patch, pi = m - f * g.n_patch;
+          off = ((long long)f * (g.n_patch + 1) + 1 + pi) * g.ldc + n;
+          v += g.pos[(long long)(1 + pi) * g.N + n];
+        } else {
+          off = (long long)m * g.ldc + n;
+        }
+        if (g.pre_out) g.pre_out[off] = v;
+        if (g.act == 1) v = gelu_f(v);
+        if (g.row_scale) v *= g.row_scale[m];
+        if (g.gelu_pre) v *= gelu_grad_f(g.gelu_pre[off]);
+        if (g.residual) v += g.residual[off];
+        C[off] = v;
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int AMODE, int BMODE>
+static int launch_cfg(const GemmArgs& g, int batch, hipStream_t s) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+  dim3 grid(ntm * ntn, batch, 1);
+  hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, AMODE, BMODE>), grid, dim3(256), 0, s, g);
+  TT_CHECK_LAUNCH("gemm_f32");
+  return TT_OK;
+}
+
+// Tile choice: the matrix pipe is the bound, so what matters is how evenly the tiles fill 256 CUs.
+// cost(cfg) = ceil(tiles / 256) * tile_area (makespan in MFMA work per CU); small penalty for small tiles
+// (more LDS traffic and epilogue per flop).
+template <int AMODE, int BMODE>
+static int launch_mode(const GemmArgs& g, int batch, hipStream_t s) {
+  struct Cfg { int wm, wn; double pen; };
+  const Cfg cfgs[4] = {{2, 2, 1.00}, {1, 2, 1.04}, {2, 1, 1.04}, {1, 1, 1.10}};
+  int best = 0;
+  double best_cost = 1e300;
+  for (int c = 0; c < 4; ++c) {
+    const long long bm = 64 * cfgs[c].wm, bn = 64 * cfgs[c].wn;
+    const long long tiles = ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (long long)batch;
+    const double cost = (double)((tiles + 255) / 256) * (double)(bm * bn) * cfgs[c].pen;
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  switch (best) {
+    case 0: return launch_cfg<2, 2, AMODE, BMODE>(g, batch, s);
+    case 1: return launch_cfg<1, 2, AMODE, BMODE>(g, batch, s);
+    case 2: return launch_cfg<2, 1, AMODE, BMODE>(g, batch, s);
+    default: return launch_cfg<1, 1, AMODE, BMODE>(g, batch, s);
+  }
+}
+
+int launch_gemm(const GemmArgs& g, int amode, int bmode, int batch, hipStream_t s) {
+  TT_REQUIRE(g.A && g.B && g.C, "gemm: null operand");
+  TT_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && batch > 0, "gemm: bad shape M=%d N=%d K=%d batch=%d", g.M, g.N, g.K, batch);
+  TT_REQUIRE(aligned16(g.A) && aligned16(g.B), "gemm: operands must be 16-byte aligned");
+  if (amode == 1) TT_REQUIRE(g.lda % 4 == 0 && g.M % 4 == 0, "gemm: m-major A needs lda, M multiples of 4");
+  else if (amode == 0) TT_REQUIRE(g.lda % 4 == 0 && g.K % 4 == 0, "gemm: k-major A needs lda, K multiples of 4");
+  else TT_REQUIRE(g.P % 4 == 0 && g.W % 4 == 0, "gemm: patch size and image width must be multiples of 4");
+  if (bmode == 1) TT_REQUIRE(g.ldb % 4 == 0 && g.N % 4 == 0, "gemm: n-major B needs ldb, N multiples of 4");
+  else TT_REQUIRE(g.ldb % 4 == 0 && g.K % 4 == 0, "gemm: k-major B needs ldb, K multiples of 4");
+  TT_REQUIRE(batch == 1 || ((g.strideA % 4 == 0) && (g.strideB % 4 == 0)), "gemm: batch strides must be multiples of 4");
+  if (amode == 0 && bmode == 0) return launch_mode<0, 0>(g, batch, s);
+  if (amode == 0 && bmode == 1) return launch_mode<0, 1>(g, batch, s);
+  if (amode == 1 && bmode == 1) return launch_mode<1, 1>(g, batch, s);
+  if (amode == 1 && bmode == 0) return launch_mode<1, 0>(g, batch, s);
+  if (amode == 2 && bmode == 0) return launch_mode<2, 0>(g, batch, s);
+  set_error("gemm: unsupported operand layout (%d, %d)", amode, bmode);
+  return TT_EUNSUPPORTED;
+}
+
+}  // namespace tt
+
+using tt::GemmArgs;
+
+static GemmArgs base_args(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc) {
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.alpha = 1.f;
+  return g;
+}
+
+extern "C" int tt_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                           int a_mmajor, int b_nmajor, float alpha, int batch, long long strideA, long long strideB,
+                           long long strideC, tt_stream_t stream) {
+  GemmArgs g = base_args(A, B, C, M, N, K, lda, ldb, ldc);
+  g.alpha = alpha;
+  g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
+  return tt::launch_gemm(g, a_mmajor ? 1 : 0, b_nmajor ? 1 : 0, batch, tt::as_stream(stream));
+}
+
+extern "C" int tt_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                             float* pre_act, int M, int N, int K, int act, tt_stream_t stream) {
+  GemmArgs g = base_args(x, w, y, M, N, K, K, K, N);
+  g.bias = bias; g.residual = residual; g.pre_out = pre_act; g.act = act;
+  return tt::launch_gemm(g, 0, 0, 1, tt::as_stream(stream));
+}
+
+extern "C" int tt_linear_bwd_data(const float* dy, const float* w, const float* gelu_pre, float* dx, int M, int N,
+                                  int K, tt_stream_t stream) {
+  // dx[M,K] = dy[M,N] @ w[N,K]: reduction over N; w is "n-major" for this product (stored [N_red][K_out]).
+  GemmArgs g = base_args(dy, w, dx, M, K, N, N, K, K);
+  g.gelu_pre = gelu_pre;
+  return tt::launch_gemm(g, 0, 1, 1, tt::as_stream(stream));
+}
+
+extern "C" int tt_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
+                                    void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  // dw[N,K] = dy[M,N]^T @ x[M,K]: reduction over M; both operands are stored [M_red][*].
+  GemmArgs g = base_args(dy, x, dw, N, K, M, N, K, K);
+  int rc = tt::launch_gemm(g, 1, 1, 1, tt::as_stream(stream));
+  if (rc != TT_OK || !db) return rc;
+  return tt_colsum(dy, db, M, N, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tt_patch_embed_gemm(const float* img, const int32_t* frame_map, const float* w, const float* bias,
+                                   const float* pos, float* tokens, int F, int C, int H, int W, int P, int D,
+                                   tt_stream_t stream) {
+  const int gw = W / P, gh = H / P, n = gw * gh;
+  GemmArgs g = base_args(img, w, tokens, F * n, D, C * P * P, 0, C * P * P, D);
+  g.bias = bias; g.frame_map = frame_map; g.Cin = C; g.H = H; g.W = W; g.P = P; g.gw = gw; g.n_patch = n; g.pos = pos;
+  return tt::launch_gemm(g, 2, 0, 1, tt::as_stream(stream));
+}
+
+namespace tt {
+// plain (optionally batched) NT product used by other translation units (label propagation)
+int launch_gemm_plain(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int batch,
+                      long long sA, long long sB, long long sC, hipStream_t s) {
+  GemmArgs g = base_args(A, B, C, M, N, K, lda, ldb, ldc);
+  g.strideA = sA; g.strideB = sB; g.strideC = sC;
+  return launch_gemm(g, 0, 0, batch, s);
+}
+}  // namespace tt

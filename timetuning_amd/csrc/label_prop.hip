@@ -1,0 +1,274 @@
+// Temporal label propagation (time_tuning.py:143-154 -> mask_propagation.py:396-496), batched over clips.
+//
+// The reference loops in Python over samples and frames, builds a dense [c*n, n] affinity per target frame,
+// masks it to a (2r+1)^2 window, keeps the per-query top-k sources, column-normalises and multiplies the fp64
+// label maps by it - on the host, one sample at a time.  Here, per target frame t:
+//   1. cosine similarities target x context: batched fp32 MFMA GEMM over (clip, context frame)   [gemm_f32.hip]
+//   2. one workgroup per (clip, query patch): window gather -> exp(sim / 0.1) -> exact k-th largest with
+//      multiplicity (k rounds of block arg-max) -> keep >= threshold (ties kept, as `aff[aff < min] = 0`) ->
+//      fp32 normalise -> fp64 weighted sum of the kept sources' label rows.
+// Because at most a handful of sources survive per query, step 2 is a sparse gather, not a GEMM.  Frame t's
+// maps become context for frame t+1, so the frames are sequential; everything inside a frame is parallel.
+// The last frame also emits argmax_K (the hard labels the loss consumes, time_tuning.py:296).
+#include "common.hpp"
+
+namespace tt {
+
+int launch_gemm_plain(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int batch,
+                      long long sA, long long sB, long long sC, hipStream_t s);
+
+constexpr int LP_MAXC = 8;      // context frames (frame 0 + n_last_frames <= 7)
+constexpr int LP_CAND = 8;      // candidates per thread: ceil(8 * 25^2 / 256) would need r <= 12 ... see host check
+constexpr int LP_MAXKEEP = 64;  // kept sources per query (top-k plus ties)
+
+struct LpArgs {
+  const float* sims;        // [bs][c][n][n]  (target, source)
+  const float* seg0;        // [bs][n][K] fp32 (frame 0 labels)
+  const double* seg_prev;   // base of fp64 maps: frame f (>=1) at seg_prev + (f-1) * bs*n*K
+  double* seg_out;          // [bs][n][K] this frame's map
+  int64_t* labels;          // [bs][n] or null
+  int ctx_frame[LP_MAXC];
+  int c, bs, g, K, radius, topk;
+  float temp;
+};
+
+__global__ __launch_bounds__(256) void label_prop_kernel(LpArgs a) {
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ float s_thr;
+  __shared__ int s_cnt[4];
+  __shared__ float s_sum[4];
+  __shared__ int keep_src[LP_MAXKEEP];   // ctx * n + source patch
+  __shared__ float keep_w[LP_MAXKEEP];
+  __shared__ double s_best[4];
+  __shared__ int s_besti[4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = a.g * a.g;
+  const int qi = blockIdx.x, b = blockIdx.y;
+  const int qy = qi / a.g, qx = qi - qy * a.g;
+  const int y0 = max(0, qy - a.radius), y1 = min(a.g - 1, qy + a.radius);
+  const int x0 = max(0, qx - a.radius), x1 = min(a.g - 1, qx + a.radius);
+  const int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
+  const int per_ctx = ww * wh, total = per_ctx * a.c;
+
+  // ---- gather this thread's candidates: affinity = exp(sim / temp) inside the window (mask_propagation.py:422-429)
+  float val[LP_CAND];
+  int src[LP_CAND];
+#pragma unroll
+  for (int i = 0; i < LP_CAND; ++i) {
+    const int cand = tid + 256 * i;
+    val[i] = -1.f;  // below every affinity (exp > 0)
+    src[i] = -1;
+    if (cand < total) {
+      const int j = cand / per_ctx, w = cand - j * per_ctx;
+      const int sy = y0 + w / ww, sx = x0 + w % ww;
+      const int sp = sy * a.g + sx;
+      const float sim = a.sims[(((long long)b * a.c + j) * n + qi) * n + sp];
+      val[i] = expf(sim / a.temp);
+      src[i] = j * n + sp;
+    }
+  }
+
+  // ---- k-th largest with multiplicity: k rounds of (value, lowest candidate id) arg-max, removing one instance
+  float thr = 0.f;
+  bool taken[LP_CAND];
+#pragma unroll
+  for (int i = 0; i < LP_CAND; ++i) taken[i] = false;
+  const int rounds = min(a.topk, total);
+  for (int rd = 0; rd < rounds; ++rd) {
+    float bv = -2.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < LP_CAND; ++i) {
+      const int cand = tid + 256 * i;
+      if (!taken[i] && src[i] >= 0 && (val[i] > bv || (val[i] == bv && cand < bi))) {
+        bv = val[i];
+        bi = cand;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      s_val[wave] = bv;
+      s_idx[wave] = bi;
+    }
+    __syncthreads();
+    bv = s_val[0];
+    bi = s_idx[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) {
+        bv = s_val[w];
+        bi = s_idx[w];
+      }
+    thr = bv;
+#pragma unroll
+    for (int i = 0; i < LP_CAND; ++i)
+      if (tid + 256 * i == bi) taken[i] = true;
+    __syncthreads();
+  }
+  // fewer candidates than topk: the reference's top-k then includes masked zeros, threshold 0 keeps everything
+  if (total < a.topk) thr = 0.f;
+
+  // ---- keep >= threshold (ties kept), deterministic compaction in candidate order, fp32 column sum
+  int mycount = 0;
+  float mysum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP_CAND; ++i)
+    if (src[i] >= 0 && val[i] >= thr) {
+      ++mycount;
+      mysum += val[i];
+    }
+  // exclusive prefix of counts across the block in thread order (candidate order within a thread is i-major,
+  // which is not global candidate order, but it is a fixed order: results are reproducible run to run)
+  int incl = mycount;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  float wsum = wave_sum(mysum);
+  if (lane == 63) s_cnt[wave] = incl;
+  if (lane == 0) s_sum[wave] = wsum;
+  __syncthreads();
+  int offset = incl - mycount;
+  for (int w = 0; w < wave; ++w) offset += s_cnt[w];
+  const int nkeep = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  const float colsum = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+#pragma unroll
+  for (int i = 0; i < LP_CAND; ++i)
+    if (src[i] >= 0 && val[i] >= thr) {
+      if (offset < LP_MAXKEEP) {
+        keep_src[offset] = src[i];
+        keep_w[offset] = val[i] / colsum;  // aff / aff.sum(0) in fp32 (mask_propagation.py:436)
+      }
+      ++offset;
+    }
+  __syncthreads();
+  const int nk = min(nkeep, LP_MAXKEEP);
+
+  // ---- seg_tar[:, q] = sum_s segs[:, s] * aff[s, q] in fp64 (mask_propagation.py:442-444)
+  double best = -1.0;
+  int besti = 0x7fffffff;
+  const long long fstride = (long long)a.bs * n * a.K;
+  for (int k = tid; k < a.K; k += 256) {
+    double acc = 0.0;
+    for (int e = 0; e < nk; ++e) {
+      const int j = keep_src[e] / n, sp = keep_src[e] - j * n;
+      const int fr = a.ctx_frame[j];
+      const long long off = ((long long)b * n + sp) * a.K + k;
+      const double sv = (fr == 0) ? (double)a.seg0[off] : a.seg_prev[(long long)(fr - 1) * fstride + off];
+      acc += sv * (double)keep_w[e];
+    }
+    a.seg_out[((long long)b * n + qi) * a.K + k] = acc;
+    if (acc > best) {  // k ascending within a thread: first maximum wins
+      best = acc;
+      besti = k;
+    }
+  }
+  if (!a.labels) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) {
+      best = ov;
+      besti = oi;
+    }
+  }
+  if (lane == 0) {
+    s_best[wave] = best;
+    s_besti[wave] = besti;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    best = s_best[0];
+    besti = s_besti[0];
+    for (int w = 1; w < 4; ++w)
+      if (s_best[w] > best || (s_best[w] == best && s_besti[w] < besti)) {
+        best = s_best[w];
+        besti = s_besti[w];
+      }
+    a.labels[(long long)b * n + qi] = besti;  // torch.argmax: first index of the maximum
+  }
+}
+
+__global__ void f64_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += st) dst[i] = src[i];
+}
+
+static int lp_cmax(int fs, int n_last) {
+  int c = 1 + (fs - 2 < n_last ? fs - 2 : n_last);
+  return c < 1 ? 1 : c;
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" size_t tt_label_propagate_workspace_bytes(int bs, int fs, int g, int D, int K, int n_last_frames) {
+  (void)D;
+  const size_t n = (size_t)g * g;
+  const size_t sims = (size_t)bs * lp_cmax(fs, n_last_frames) * n * n * sizeof(float);
+  const size_t segs = (size_t)(fs > 1 ? fs - 1 : 1) * bs * n * K * sizeof(double);
+  return ((sims + 255) / 256) * 256 + segs;
+}
+
+extern "C" int tt_label_propagate(const float* xn, const float* seg0, int64_t* labels, double* pmap_last, int bs, int fs, int g,
+                                  int D, int K, int n_last_frames, int radius, int topk, float temperature, void* workspace,
+                                  size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(xn && seg0 && labels && workspace, "label_propagate: null pointer");
+  TT_REQUIRE(bs > 0 && fs >= 2 && g > 0 && D > 0 && K > 0, "label_propagate: need fs >= 2 and positive sizes");
+  TT_REQUIRE(n_last_frames >= 0 && n_last_frames + 1 <= LP_MAXC, "label_propagate: n_last_frames must be <= %d", LP_MAXC - 1);
+  TT_REQUIRE(radius > 0, "label_propagate: size_mask_neighborhood must be > 0 (the unrestricted variant is not on the training path)");
+  TT_REQUIRE(topk >= 1, "label_propagate: topk >= 1");
+  const int win = (2 * radius + 1 < g ? 2 * radius + 1 : g);
+  TT_REQUIRE((long long)win * win * lp_cmax(fs, n_last_frames) <= 256LL * LP_CAND,
+             "label_propagate: window %dx%d with %d context frames exceeds %d candidates per query", win, win,
+             lp_cmax(fs, n_last_frames), 256 * LP_CAND);
+  TT_REQUIRE(D % 4 == 0, "label_propagate: feature dim must be a multiple of 4");
+  TT_REQUIRE(workspace_bytes >= tt_label_propagate_workspace_bytes(bs, fs, g, D, K, n_last_frames), "label_propagate: workspace too small");
+  hipStream_t s = as_stream(stream);
+  const int n = g * g;
+  const size_t sims_bytes = (((size_t)bs * lp_cmax(fs, n_last_frames) * n * n * sizeof(float)) + 255) / 256 * 256;
+  float* sims = static_cast<float*>(workspace);
+  double* segs = reinterpret_cast<double*>(static_cast<char*>(workspace) + sims_bytes);
+  const long long fstride = (long long)bs * n * K;
+  for (int t = 1; t < fs; ++t) {
+    LpArgs a{};
+    int c = 0;
+    a.ctx_frame[c++] = 0;  // the first frame is always context (mask_propagation.py:482-483)
+    const int lo = (t - n_last_frames > 1) ? t - n_last_frames : 1;
+    for (int fr = lo; fr < t; ++fr) a.ctx_frame[c++] = fr;
+    // cosine similarities: sims[b][j] = xn[t][b] @ xn[ctx_j][b]^T
+    for (int j = 0; j < c; ++j) {
+      int rc = launch_gemm_plain(xn + (long long)t * bs * n * D, xn + (long long)a.ctx_frame[j] * bs * n * D, sims + (long long)j * n * n,
+                                 n, n, D, D, D, n, bs, (long long)n * D, (long long)n * D, (long long)c * n * n, s);
+      if (rc != TT_OK) return rc;
+    }
+    a.sims = sims;
+    a.seg0 = seg0;
+    a.seg_prev = segs;
+    a.seg_out = segs + (long long)(t - 1) * fstride;
+    a.labels = (t == fs - 1) ? labels : nullptr;
+    a.c = c; a.bs = bs; a.g = g; a.K = K; a.radius = radius; a.topk = topk; a.temp = temperature;
+    hipLaunchKernelGGL(label_prop_kernel, dim3(n, bs), dim3(256), 0, s, a);
+    TT_CHECK_LAUNCH("label_propagate");
+  }
+  if (pmap_last) {
+    const long long cnt = fstride;
+    hipLaunchKernelGGL(f64_copy_kernel, dim3(1024), dim3(256), 0, s, segs + (long long)(fs - 2) * fstride, pmap_last, cnt);
+    TT_CHECK_LAUNCH("label_propagate.copy");
+  }
+  return TT_OK;
+}

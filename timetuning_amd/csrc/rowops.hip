@@ -1,0 +1,413 @@
+// Row-wise and element-wise kernels (HBM-bound): LayerNorm fwd/bwd, L2 row normalisation fwd/bwd,
+// deterministic column sums, cls-token rows, AdamW over a tensor table, EMA lerp, queue FIFO update.
+// One 64-lane wave owns one row; a row (D <= 1024) is held in registers between the statistics pass
+// and the output pass so that each element is read once and written once.
+#include "common.hpp"
+
+namespace tt {
+
+constexpr int kMaxPerLane = 16;  // D <= 1024
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (dino_vision_transformer.py:139,143,196)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long long)row * D;
+  float v[kMaxPerLane];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = (c < D) ? xr[c] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    const float d = (c < D) ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  float* yr = y + (long long)row * D;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) yr[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+  }
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+}
+
+// Backward.  Each workgroup owns a contiguous run of rows; its 4 waves walk them, keep per-column partial
+// sums of dgamma/dbeta in registers and combine them through LDS into partial[wg][2][D]; a column-sum
+// pass over the partials finishes (deterministic: no atomics).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            float* __restrict__ partial, int rows, int D, int rows_per_wg,
+                                                            int add_to_dx) {
+  __shared__ float red[4][2][64 * kMaxPerLane];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * rows_per_wg;
+  const int r1 = min(rows, r0 + rows_per_wg);
+  float dg[kMaxPerLane], db[kMaxPerLane], gm[kMaxPerLane];
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    dg[i] = 0.f;
+    db[i] = 0.f;
+    const int c = lane + 64 * i;
+    gm[i] = (c < D) ? gamma[c] : 0.f;
+  }
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + (long long)row * D;
+    const float* dyr = dy + (long long)row * D;
+    float xh[kMaxPerLane], gy[kMaxPerLane];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i) {
+      const int c = lane + 64 * i;
+      const float xv = (c < D) ? xr[c] : 0.f;
+      const float dv = (c < D) ? dyr[c] : 0.f;
+      xh[i] = (c < D) ? (xv - mu) * rs : 0.f;
+      gy[i] = dv * gm[i];
+      dg[i] += dv * xh[i];
+      db[i] += dv;
+      s1 += gy[i] * xh[i];
+      s2 += gy[i];
+    }
+    const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+    float* dxr = dx + (long long)row * D;
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) {
+        const float o = rs * (gy[i] - c2 - xh[i] * c1);
+        dxr[c] = add_to_dx ? dxr[c] + o : o;
+      }
+    }
+  }
+  if (!partial) return;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    red[wave][0][lane + 64 * i] = dg[i];
+    red[wave][1][lane + 64 * i] = db[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      a += red[w][0][c];
+      b += red[w][1][c];
+    }
+    partial[((long long)blockIdx.x * 2 + 0) * D + c] = a;
+    partial[((long long)blockIdx.x * 2 + 1) * D + c] = b;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column sums: out[n] = sum_m a[m][n] (row stride lda).  Stage 1 writes partial[chunk][n]; stage 2 folds.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ a, float* __restrict__ partial, int M, int N,
+                                                     int lda, int rows_per_chunk) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  float s = 0.f;
+  if (n < N)
+    for (int m = m0 + rg; m < m1; m += 4) s += a[(long long)m * lda + n];
+  red[rg][lane] = s;
+  __syncthreads();
+  if (rg == 0 && n < N) partial[(long long)blockIdx.y * N + n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ partial, float* __restrict__ out, int chunks,
+                                                     int N, int pstride, int poff) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += partial[(long long)c * pstride + poff + n];
+  out[n] = s;
+}
+
+static int colsum_chunks(int M) {
+  int chunks = (M + 255) / 256;
+  return chunks > 128 ? 128 : (chunks < 1 ? 1 : chunks);
+}
+
+// ------------------------------------------------------------------------------------------------
+// F.normalize(x, dim=-1)  (time_tuning.py:136, :124-128; mask_propagation.py:418-419)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* x, int ldx, float* xn, float* __restrict__ inv_norm,
+                                                         int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long long)row * ldx;
+  float v[kMaxPerLane];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = (c < D) ? xr[c] : 0.f;
+    s += v[i] * v[i];
+  }
+  const float nrm = sqrtf(wave_sum(s));
+  const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+  float* yr = xn + (long long)row * D;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) yr[c] = v[i] * inv;
+  }
+  if (inv_norm && lane == 0) inv_norm[row] = inv;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ xn,
+                                                         const float* __restrict__ inv_norm, float* __restrict__ dx,
+                                                         int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float a[kMaxPerLane], b[kMaxPerLane];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    a[i] = (c < D) ? dxn[(long long)row * D + c] : 0.f;
+    b[i] = (c < D) ? xn[(long long)row * D + c] : 0.f;
+    s += a[i] * b[i];
+  }
+  const float dot = wave_sum(s), inv = inv_norm[row];
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) dx[(long long)row * D + c] = (a[i] - b[i] * dot) * inv;
+  }
+}
+
+// cls rows of the token tensor: tokens[f][0][:] = cls + pos[0] (dino_vision_transformer.py:241-245)
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ tokens, int F,
+                                int D, long long frame_stride) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * D) return;
+  const int f = i / D, c = i - f * D;
+  tokens[(long long)f * frame_stride + c] = cls[c] + pos[c];
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] += src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdamW (torch.optim.AdamW single-tensor semantics, time_tuning.py:413-429) over a table of tensors.
+// ------------------------------------------------------------------------------------------------
+struct AdamTable {
+  tt_adamw_tensor t[TT_MAX_TENSORS];
+};
+__global__ __launch_bounds__(256) void adamw_kernel(AdamTable tab, float beta1, float beta2, float eps, float bc1,
+                                                    float bc2_sqrt) {
+  const tt_adamw_tensor t = tab.t[blockIdx.y];
+  const float decay = 1.0f - t.lr * t.weight_decay;
+  const float step_size = t.lr / bc1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < t.n; i += (long long)gridDim.x * 256) {
+    const float g = t.g[i];
+    float p = t.p[i] * decay;
+    float m = t.m[i];
+    m = m + (g - m) * (1.0f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = t.v[i] * beta2 + (1.0f - beta2) * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p -= step_size * (m / denom);
+    t.p[i] = p;
+    t.m[i] = m;
+    t.v[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const float* __restrict__ s, long long n, float m,
+                                                  float one_minus_m) {
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  for (; i + 3 < n; i += stride) {
+    float4 a = *reinterpret_cast<float4*>(t + i);
+    const float4 b = *reinterpret_cast<const float4*>(s + i);
+    a.x = a.x * one_minus_m + b.x * m;
+    a.y = a.y * one_minus_m + b.y * m;
+    a.z = a.z * one_minus_m + b.z * m;
+    a.w = a.w * one_minus_m + b.w * m;
+    *reinterpret_cast<float4*>(t + i) = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long j = (n & ~3LL) + threadIdx.x;
+    t[j] = t[j] * one_minus_m + s[j] * m;
+  }
+}
+
+// queue FIFO (time_tuning.py:258-261): new[r] = r < m ? feats[idx[r]] : old[r - m]
+__global__ void queue_push_kernel(const float* __restrict__ old_q, float* __restrict__ new_q, const float* __restrict__ feats,
+                                  const int64_t* __restrict__ idx, int Q, int D, int m) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Q * D) return;
+  const int r = (int)(i / D), c = (int)(i - (long long)r * D);
+  new_q[i] = (r < m) ? feats[idx[r] * (long long)D + c] : old_q[(long long)(r - m) * D + c];
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" int tt_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                int rows, int D, float eps, tt_stream_t stream) {
+  TT_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
+  TT_REQUIRE(rows > 0 && D > 0 && D <= 64 * kMaxPerLane, "layernorm_fwd: need 0 < D <= %d (got %d)", 64 * kMaxPerLane, D);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta, y, mean, rstd,
+                     rows, D, eps);
+  TT_CHECK_LAUNCH("layernorm_fwd");
+  return TT_OK;
+}
+
+static int ln_bwd_wgs(int rows) {
+  int w = (rows + 31) / 32;
+  return w > 512 ? 512 : (w < 1 ? 1 : w);
+}
+extern "C" size_t tt_layernorm_bwd_workspace_bytes(int rows, int D) { return (size_t)ln_bwd_wgs(rows) * 2 * D * sizeof(float); }
+
+extern "C" int tt_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                float* dx, float* dgamma, float* dbeta, int rows, int D, int add_to_dx, void* workspace,
+                                size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
+  TT_REQUIRE(rows > 0 && D > 0 && D <= 64 * kMaxPerLane, "layernorm_bwd: need 0 < D <= %d", 64 * kMaxPerLane);
+  const bool want = dgamma || dbeta;
+  TT_REQUIRE(!want || (dgamma && dbeta), "layernorm_bwd: dgamma and dbeta must be given together");
+  const int wgs = ln_bwd_wgs(rows);
+  const int rpw = (rows + wgs - 1) / wgs;
+  if (want) TT_REQUIRE(workspace && workspace_bytes >= tt_layernorm_bwd_workspace_bytes(rows, D), "layernorm_bwd: workspace too small");
+  float* partial = want ? static_cast<float*>(workspace) : nullptr;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(wgs), dim3(256), 0, as_stream(stream), dy, x, gamma, mean, rstd, dx, partial, rows,
+                     D, rpw, add_to_dx);
+  TT_CHECK_LAUNCH("layernorm_bwd");
+  if (want) {
+    hipLaunchKernelGGL(colsum_stage2, dim3((D + 255) / 256), dim3(256), 0, as_stream(stream), partial, dgamma, wgs, D, 2 * D, 0);
+    hipLaunchKernelGGL(colsum_stage2, dim3((D + 255) / 256), dim3(256), 0, as_stream(stream), partial, dbeta, wgs, D, 2 * D, D);
+    TT_CHECK_LAUNCH("layernorm_bwd.reduce");
+  }
+  return TT_OK;
+}
+
+extern "C" size_t tt_colsum_workspace_bytes(int M, int N) { return (size_t)colsum_chunks(M) * N * sizeof(float); }
+
+extern "C" int tt_colsum(const float* a, float* out, int M, int N, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(a && out && M > 0 && N > 0, "colsum: bad arguments");
+  TT_REQUIRE(workspace && workspace_bytes >= tt_colsum_workspace_bytes(M, N), "colsum: workspace too small");
+  const int chunks = colsum_chunks(M);
+  const int rpc = (M + chunks - 1) / chunks;
+  float* partial = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(colsum_stage1, dim3((N + 63) / 64, chunks), dim3(256), 0, as_stream(stream), a, partial, M, N, N, rpc);
+  hipLaunchKernelGGL(colsum_stage2, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), partial, out, chunks, N, N, 0);
+  TT_CHECK_LAUNCH("colsum");
+  return TT_OK;
+}
+
+extern "C" int tt_l2norm_fwd(const float* x, int ldx, float* xn, float* inv_norm, int rows, int D, tt_stream_t stream) {
+  TT_REQUIRE(x && xn && rows > 0 && D > 0 && D <= 64 * kMaxPerLane && ldx >= D, "l2norm_fwd: bad arguments (D=%d ldx=%d)", D, ldx);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, ldx, xn, inv_norm, rows, D);
+  TT_CHECK_LAUNCH("l2norm_fwd");
+  return TT_OK;
+}
+
+extern "C" int tt_l2norm_bwd(const float* dxn, const float* xn, const float* inv_norm, float* dx, int rows, int D,
+                             tt_stream_t stream) {
+  TT_REQUIRE(dxn && xn && inv_norm && dx && rows > 0 && D > 0 && D <= 64 * kMaxPerLane, "l2norm_bwd: bad arguments");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), dxn, xn, inv_norm, dx, rows, D);
+  TT_CHECK_LAUNCH("l2norm_bwd");
+  return TT_OK;
+}
+
+extern "C" int tt_normalize_rows_inplace(float* w, int rows, int D, tt_stream_t stream) {
+  return tt_l2norm_fwd(w, D, w, nullptr, rows, D, stream);
+}
+
+extern "C" int tt_patch_embed_gemm(const float* img, const int32_t* frame_map, const float* w, const float* bias, const float* pos,
+                                   float* tokens, int F, int C, int H, int W, int P, int D, tt_stream_t stream);
+
+extern "C" int tt_patch_embed_fwd(const float* img, const int32_t* frame_map, const float* w, const float* bias, const float* cls,
+                                  const float* pos, float* tokens, int F, int C, int H, int W, int P, int D, tt_stream_t stream) {
+  TT_REQUIRE(img && w && bias && cls && pos && tokens, "patch_embed: null pointer");
+  TT_REQUIRE(F > 0 && P > 0 && H % P == 0 && W % P == 0, "patch_embed: H, W must be multiples of the patch size");
+  const int n = (H / P) * (W / P);
+  int rc = tt_patch_embed_gemm(img, frame_map, w, bias, pos, tokens, F, C, H, W, P, D, stream);
+  if (rc != TT_OK) return rc;
+  hipLaunchKernelGGL(cls_rows_kernel, dim3((F * D + 255) / 256), dim3(256), 0, as_stream(stream), cls, pos, tokens, F, D,
+                     (long long)(n + 1) * D);
+  TT_CHECK_LAUNCH("patch_embed.cls");
+  return TT_OK;
+}
+
+extern "C" int tt_add_inplace(float* dst, const float* src, long long n, tt_stream_t stream) {
+  TT_REQUIRE(dst && src && n > 0, "add_inplace: bad arguments");
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dst, src, n);
+  TT_CHECK_LAUNCH("add_inplace");
+  return TT_OK;
+}
+
+extern "C" int tt_adamw_step(const tt_adamw_tensor* tensors, int count, int step, float beta1, float beta2, float eps,
+                             tt_stream_t stream) {
+  TT_REQUIRE(tensors && count > 0 && count <= TT_MAX_TENSORS && step >= 1, "adamw: need 1..%d tensors and step >= 1", TT_MAX_TENSORS);
+  AdamTable tab{};
+  long long maxn = 0;
+  for (int i = 0; i < count; ++i) {
+    TT_REQUIRE(tensors[i].p && tensors[i].g && tensors[i].m && tensors[i].v && tensors[i].n > 0, "adamw: tensor %d has a null pointer", i);
+    tab.t[i] = tensors[i];
+    if (tensors[i].n > maxn) maxn = tensors[i].n;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  long long bx = (maxn + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)bx, count), dim3(256), 0, as_stream(stream), tab, beta1, beta2, eps, (float)bc1,
+                     (float)sqrt(bc2));
+  TT_CHECK_LAUNCH("adamw");
+  return TT_OK;
+}
+
+extern "C" int tt_ema_update(float* teacher, const float* student, long long n, double momentum, tt_stream_t stream) {
+  TT_REQUIRE(teacher && student && n > 0, "ema: bad arguments");
+  TT_REQUIRE(aligned16(teacher) && aligned16(student), "ema: buffers must be 16-byte aligned");
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), teacher, student, n, (float)momentum,
+                     (float)(1.0 - momentum));
+  TT_CHECK_LAUNCH("ema");
+  return TT_OK;
+}
+
+extern "C" int tt_queue_push(float* queue, float* scratch, const float* feats, const int64_t* idx, int Q, int D, int m,
+                             tt_stream_t stream) {
+  TT_REQUIRE(queue && scratch && feats && idx && Q > 0 && D > 0 && m > 0 && m <= Q, "queue_push: bad arguments");
+  const long long n = (long long)Q * D;
+  hipLaunchKernelGGL(queue_push_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), queue, scratch, feats, idx,
+                     Q, D, m);
+  TT_CHECK_LAUNCH("queue_push");
+  hipError_t e = hipMemcpyAsync(queue, scratch, n * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream));
+  if (e != hipSuccess) {
+    set_error("queue_push: copy failed: %s", hipGetErrorString(e));
+    return TT_ELAUNCH;
+  }
+  return TT_OK;
+}

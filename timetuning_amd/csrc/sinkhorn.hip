@@ -1,0 +1,216 @@
+// Sinkhorn-Knopp optimal assignment (time_tuning.py:157-168 + my_utils.py:246-274) and the
+// cross-entropy objective (time_tuning.py:296-302).
+//
+// Scaling-vector form.  With E[b][k] = exp(scores[b][k] / eps) the reference's in-place updates of
+// Q = diag(a) E^T diag(b) only ever change the two vectors:
+//   row step   a_k <- (1/K) / sum_b E[b][k] * b_b        (Q *= (r/u)[:,None],  u = Q.sum(1))
+//   col step   b_b <- (1/B) / sum_k a_k * E[b][k]        (Q *= (c/Q.sum(0))[None,:])
+//   output     q[b][k] = a_k E[b][k] / sum_k a_k E[b][k] (final Q / Q.sum(0), transposed)
+// so E is written once and then only READ (one pass per iteration: the column step of iteration i and the
+// row sums of iteration i+1 share a sweep), no transposes, no in-place N x K rewrites.  The initial
+// Q /= sum(Q) cancels in the first row step and is not computed.  E stays [B][K] (a row = one patch's K
+// scores = one coalesced wave read); a workgroup owns a run of rows, keeps its per-prototype partial sums in
+// registers and publishes partial[wg][k]; the next launch folds the partials in a fixed order
+// (deterministic, no atomics).  Kernel boundaries (~1.5 us) are cheaper than a grid barrier (~4-7 us) on
+// this chip, so each iteration is its own launch.
+#include "common.hpp"
+
+namespace tt {
+
+constexpr int SK_KPL = 8;     // K <= 512
+constexpr int SK_MAXWG = 128;
+
+static int sk_wgs(int B) {
+  int w = (B + 15) / 16;  // >= 16 rows per workgroup
+  return w > SK_MAXWG ? SK_MAXWG : (w < 1 ? 1 : w);
+}
+
+// E = exp(scores/eps); partial[wg][k] = sum over this workgroup's rows of E[b][k]
+__global__ __launch_bounds__(256) void sk_init_kernel(const float* __restrict__ scores, float* __restrict__ E,
+                                                      float* __restrict__ partial, int B, int K, float eps, int rows_per_wg) {
+  __shared__ float red[4][64 * SK_KPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(B, r0 + rows_per_wg);
+  float acc[SK_KPL];
+#pragma unroll
+  for (int i = 0; i < SK_KPL; ++i) acc[i] = 0.f;
+  for (int b = r0 + wave; b < r1; b += 4) {
+#pragma unroll
+    for (int i = 0; i < SK_KPL; ++i) {
+      const int k = lane + 64 * i;
+      if (k < K) {
+        const float e = expf(scores[(long long)b * K + k] / eps);
+        E[(long long)b * K + k] = e;
+        acc[i] += e;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < SK_KPL; ++i) red[wave][lane + 64 * i] = acc[i];
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256)
+    partial[(long long)blockIdx.x * K + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+}
+
+// One Sinkhorn iteration (row step + column step) or, with LAST, the final column normalisation + output.
+template <bool LAST>
+__global__ __launch_bounds__(256) void sk_iter_kernel(const float* __restrict__ E, const float* __restrict__ partial_in,
+                                                      float* __restrict__ partial_out, float* __restrict__ q_out, int B, int K,
+                                                      int nwg_in, int rows_per_wg, int row0, int rows_out, int uniform_a) {
+  __shared__ float a_s[64 * SK_KPL];
+  __shared__ float red[4][64 * SK_KPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // row step: a_k = (1/K) / u_k, u_k folded from the previous launch's partial sums in fixed order
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float a = 1.0f;
+    if (!uniform_a) {
+      float u = 0.f;
+      for (int w = 0; w < nwg_in; ++w) u += partial_in[(long long)w * K + k];
+      a = (1.0f / (float)K) / u;
+    }
+    a_s[k] = a;
+  }
+  __syncthreads();
+  float a[SK_KPL], acc[SK_KPL];
+#pragma unroll
+  for (int i = 0; i < SK_KPL; ++i) {
+    const int k = lane + 64 * i;
+    a[i] = (k < K) ? a_s[k] : 0.f;
+    acc[i] = 0.f;
+  }
+  int r0, r1;
+  if (LAST) {
+    r0 = row0 + blockIdx.x * rows_per_wg;
+    r1 = min(row0 + rows_out, r0 + rows_per_wg);
+  } else {
+    r0 = blockIdx.x * rows_per_wg;
+    r1 = min(B, r0 + rows_per_wg);
+  }
+  const float c = 1.0f / (float)B;
+  for (int b = r0 + wave; b < r1; b += 4) {
+    float e[SK_KPL];
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < SK_KPL; ++i) {
+      const int k = lane + 64 * i;
+      e[i] = (k < K) ? E[(long long)b * K + k] : 0.f;
+      t += a[i] * e[i];
+    }
+    t = wave_sum(t);
+    if (LAST) {
+#pragma unroll
+      for (int i = 0; i < SK_KPL; ++i) {
+        const int k = lane + 64 * i;
+        if (k < K) q_out[(long long)(b - row0) * K + k] = a[i] * e[i] / t;
+      }
+    } else {
+      const float bb = c / t;  // column step
+#pragma unroll
+      for (int i = 0; i < SK_KPL; ++i) acc[i] += e[i] * bb;
+    }
+  }
+  if (LAST) return;
+#pragma unroll
+  for (int i = 0; i < SK_KPL; ++i) red[wave][lane + 64 * i] = acc[i];
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256)
+    partial_out[(long long)blockIdx.x * K + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+}
+
+// ---- cross entropy -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ scores, const int64_t* __restrict__ labels,
+                                                 float* __restrict__ row_loss, float* __restrict__ dscores, int rows, int K,
+                                                 float temp) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float z[SK_KPL];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < SK_KPL; ++i) {
+    const int k = lane + 64 * i;
+    z[i] = (k < K) ? scores[(long long)row * K + k] / temp : -INFINITY;
+    mx = fmaxf(mx, z[i]);
+  }
+  mx = wave_max(mx);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < SK_KPL; ++i) {
+    z[i] = expf(z[i] - mx);  // exp(-inf) = 0 for the padding lanes
+    s += z[i];
+  }
+  s = wave_sum(s);
+  const int lab = (int)labels[row];
+  const float zl = scores[(long long)row * K + lab] / temp;
+  if (lane == 0) row_loss[row] = (mx + logf(s)) - zl;
+  if (dscores) {
+    const float gscale = 1.0f / (temp * (float)rows);
+#pragma unroll
+    for (int i = 0; i < SK_KPL; ++i) {
+      const int k = lane + 64 * i;
+      if (k < K) dscores[(long long)row * K + k] = (z[i] / s - (k == lab ? 1.0f : 0.0f)) * gscale;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, float* __restrict__ out, int n) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)v[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)n);
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" size_t tt_sinkhorn_workspace_bytes(int B_total, int K) {
+  return ((size_t)B_total * K + 2ull * SK_MAXWG * K) * sizeof(float);
+}
+
+extern "C" int tt_sinkhorn(const float* scores, float* q_out, int B_total, int K, int row0, int rows_out, float eps,
+                           int iters, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(scores && q_out && workspace, "sinkhorn: null pointer");
+  TT_REQUIRE(B_total > 0 && K > 0 && K <= 64 * SK_KPL, "sinkhorn: need 0 < K <= %d (got %d)", 64 * SK_KPL, K);
+  TT_REQUIRE(row0 >= 0 && rows_out > 0 && row0 + rows_out <= B_total, "sinkhorn: output rows [%d, %d) outside [0, %d)", row0,
+             row0 + rows_out, B_total);
+  TT_REQUIRE(iters >= 0 && eps > 0.f, "sinkhorn: bad iters/eps");
+  TT_REQUIRE(workspace_bytes >= tt_sinkhorn_workspace_bytes(B_total, K), "sinkhorn: workspace too small");
+  hipStream_t s = as_stream(stream);
+  float* E = static_cast<float*>(workspace);
+  float* part[2] = {E + (size_t)B_total * K, E + (size_t)B_total * K + (size_t)SK_MAXWG * K};
+  const int wgs = sk_wgs(B_total);
+  const int rpw = (B_total + wgs - 1) / wgs;
+  hipLaunchKernelGGL(sk_init_kernel, dim3(wgs), dim3(256), 0, s, scores, E, part[0], B_total, K, eps, rpw);
+  int cur = 0;
+  for (int it = 0; it + 1 < iters; ++it) {  // iterations 1 .. iters-1 (each prepares the next row step)
+    hipLaunchKernelGGL((sk_iter_kernel<false>), dim3(wgs), dim3(256), 0, s, E, part[cur], part[cur ^ 1], (float*)nullptr, B_total, K,
+                       wgs, rpw, 0, 0, 0);
+    cur ^= 1;
+  }
+  // last iteration's row step + column normalisation, written straight to q for the requested rows
+  const int owgs = sk_wgs(rows_out);
+  const int orpw = (rows_out + owgs - 1) / owgs;
+  hipLaunchKernelGGL((sk_iter_kernel<true>), dim3(owgs), dim3(256), 0, s, E, part[cur], (float*)nullptr, q_out, B_total, K, wgs, orpw,
+                     row0, rows_out, iters == 0 ? 1 : 0);
+  TT_CHECK_LAUNCH("sinkhorn");
+  return TT_OK;
+}
+
+extern "C" size_t tt_ce_workspace_bytes(int rows) { return (size_t)rows * sizeof(float); }
+
+extern "C" int tt_ce_loss_fwd_bwd(const float* scores, const int64_t* labels, float* loss_out, float* dscores, int rows, int K,
+                                  float temperature, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(scores && labels && loss_out && workspace, "ce_loss: null pointer");
+  TT_REQUIRE(rows > 0 && K > 0 && K <= 64 * SK_KPL && temperature > 0.f, "ce_loss: need 0 < K <= %d", 64 * SK_KPL);
+  TT_REQUIRE(workspace_bytes >= tt_ce_workspace_bytes(rows), "ce_loss: workspace too small");
+  hipStream_t s = as_stream(stream);
+  float* row_loss = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(ce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, scores, labels, row_loss, dscores, rows, K, temperature);
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, row_loss, loss_out, rows);
+  TT_CHECK_LAUNCH("ce_loss");
+  return TT_OK;
+}

@@ -1,0 +1,311 @@
+"""Torch-tensor front end of the C ABI (include/timetuning_hip.h).
+
+PyTorch supplies device memory and the HIP stream only; all arithmetic happens in
+libtimetuning_hip.so.  Every function validates device / dtype / contiguity and raises if
+the library is unavailable - there is no eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+f32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str, dtype=f32) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.HipLibraryError(f"{name}: expected a tensor in GPU memory (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ---- Linear ------------------------------------------------------------------------------------
+
+def linear_fwd(x, w, bias=None, residual=None, act: int = 0, save_pre: bool = False, out=None):
+    """y = act(x @ w.T + bias) (+ residual).  x [M,K], w [N,K].  Returns y or (y, pre_act)."""
+    lib = _lib.load()
+    _chk(x, "x"); _chk(w, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    y = out if out is not None else torch.empty((M, N), dtype=f32, device=x.device)
+    pre = torch.empty((M, N), dtype=f32, device=x.device) if save_pre else None
+    if bias is not None: _chk(bias, "bias")
+    if residual is not None: _chk(residual, "residual")
+    _lib.check(lib.tt_linear_fwd(_p(x), _p(w), _p(bias), _p(residual), _p(y), _p(pre), M, N, K, act, _stream()), "tt_linear_fwd")
+    return (y, pre) if save_pre else y
+
+
+def linear_bwd_data(dy, w, gelu_pre=None, out=None):
+    """dx = dy @ w (* gelu'(gelu_pre))."""
+    lib = _lib.load()
+    _chk(dy, "dy"); _chk(w, "w")
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = out if out is not None else torch.empty((M, K), dtype=f32, device=dy.device)
+    _lib.check(lib.tt_linear_bwd_data(_p(dy), _p(w), _p(gelu_pre), _p(dx), M, N, K, _stream()), "tt_linear_bwd_data")
+    return dx
+
+
+def linear_bwd_weight(dy, x, need_bias=True, dw_out=None, db_out=None):
+    """dw = dy.T @ x, db = dy.sum(0)."""
+    lib = _lib.load()
+    _chk(dy, "dy"); _chk(x, "x")
+    M, N = dy.shape
+    K = x.shape[1]
+    dw = dw_out if dw_out is not None else torch.empty((N, K), dtype=f32, device=dy.device)
+    db = (db_out if db_out is not None else torch.empty((N,), dtype=f32, device=dy.device)) if need_bias else None
+    nb = lib.tt_colsum_workspace_bytes(M, N)
+    ws = _ws(nb, dy.device)
+    _lib.check(lib.tt_linear_bwd_weight(_p(dy), _p(x), _p(dw), _p(db), M, N, K, _p(ws), nb, _stream()), "tt_linear_bwd_weight")
+    return dw, db
+
+
+def colsum(a):
+    lib = _lib.load()
+    _chk(a, "a")
+    M, N = a.shape
+    out = torch.empty((N,), dtype=f32, device=a.device)
+    nb = lib.tt_colsum_workspace_bytes(M, N)
+    ws = _ws(nb, a.device)
+    _lib.check(lib.tt_colsum(_p(a), _p(out), M, N, _p(ws), nb, _stream()), "tt_colsum")
+    return out
+
+
+def gemm(A, B, a_mmajor=False, b_nmajor=False, alpha=1.0, out=None):
+    """C = alpha * op(A) @ op(B) (see tt_gemm_f32).  2-D operands, or 3-D for a batch."""
+    lib = _lib.load()
+    _chk(A, "A"); _chk(B, "B")
+    batch = 1
+    sA = sB = sC = 0
+    if A.dim() == 3:
+        batch = A.shape[0]
+        A2, B2 = A[0], B[0]
+        sA, sB = A.stride(0), B.stride(0)
+    else:
+        A2, B2 = A, B
+    if a_mmajor:
+        K, M = A2.shape
+    else:
+        M, K = A2.shape
+    if b_nmajor:
+        Kb, N = B2.shape
+    else:
+        N, Kb = B2.shape
+    assert K == Kb, (A.shape, B.shape)
+    shape = (batch, M, N) if A.dim() == 3 else (M, N)
+    Cm = out if out is not None else torch.empty(shape, dtype=f32, device=A.device)
+    sC = M * N if batch > 1 else 0
+    _lib.check(lib.tt_gemm_f32(_p(A), _p(B), _p(Cm), M, N, K, A2.stride(0), B2.stride(0), N, int(a_mmajor), int(b_nmajor),
+                               float(alpha), batch, sA, sB, sC, _stream()), "tt_gemm_f32")
+    return Cm
+
+
+# ---- ViT pieces ----------------------------------------------------------------------------------
+
+def patch_embed_fwd(img, w, bias, cls, pos, patch: int, frame_map=None):
+    """img [F_src,C,H,W] -> tokens [F, n+1, D] (conv k=s=patch, cls token, pos-embed)."""
+    lib = _lib.load()
+    _chk(img, "img"); _chk(w, "w"); _chk(bias, "bias"); _chk(cls, "cls"); _chk(pos, "pos")
+    Fs, Cc, H, W = img.shape
+    D = w.shape[0]
+    F = Fs if frame_map is None else frame_map.numel()
+    if frame_map is not None: _chk(frame_map, "frame_map", torch.int32)
+    n = (H // patch) * (W // patch)
+    if pos.numel() != (n + 1) * D:
+        raise ValueError("pos_embed does not match the token grid (only the identity branch of interpolate_pos_encoding is built)")
+    tokens = torch.empty((F, n + 1, D), dtype=f32, device=img.device)
+    _lib.check(lib.tt_patch_embed_fwd(_p(img), _p(frame_map), _p(w), _p(bias), _p(cls), _p(pos), _p(tokens), F, Cc, H, W, patch, D,
+                                      _stream()), "tt_patch_embed_fwd")
+    return tokens
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-6, save_stats=False, out=None):
+    lib = _lib.load()
+    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = out if out is not None else torch.empty_like(x)
+    mean = torch.empty((rows,), dtype=f32, device=x.device) if save_stats else None
+    rstd = torch.empty((rows,), dtype=f32, device=x.device) if save_stats else None
+    _lib.check(lib.tt_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, float(eps), _stream()), "tt_layernorm_fwd")
+    return (y, mean, rstd) if save_stats else y
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, dx_accum=None):
+    """Returns (dx, dgamma, dbeta).  dx_accum: tensor to accumulate dx into (residual branch)."""
+    lib = _lib.load()
+    _chk(dy, "dy"); _chk(x, "x")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    dx = dx_accum if dx_accum is not None else torch.empty_like(x)
+    dg = torch.empty((D,), dtype=f32, device=x.device) if need_wgrad else None
+    db = torch.empty((D,), dtype=f32, device=x.device) if need_wgrad else None
+    nb = lib.tt_layernorm_bwd_workspace_bytes(rows, D)
+    ws = _ws(nb, x.device)
+    _lib.check(lib.tt_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), rows, D,
+                                    1 if dx_accum is not None else 0, _p(ws), nb, _stream()), "tt_layernorm_bwd")
+    return dx, dg, db
+
+
+def attention_fwd(qkv, num_heads: int, save_lse=False, return_probs=False):
+    """qkv [F,N,3*D] -> out [F,N,D] (+ lse [F,H,N], probs [F,H,N,N])."""
+    lib = _lib.load()
+    _chk(qkv, "qkv")
+    F, N, D3 = qkv.shape
+    D = D3 // 3
+    hd = D // num_heads
+    out = torch.empty((F, N, D), dtype=f32, device=qkv.device)
+    lse = torch.empty((F, num_heads, N), dtype=f32, device=qkv.device) if save_lse else None
+    probs = torch.empty((F, num_heads, N, N), dtype=f32, device=qkv.device) if return_probs else None
+    _lib.check(lib.tt_attention_fwd(_p(qkv), _p(out), _p(lse), _p(probs), F, N, num_heads, hd, float(hd ** -0.5), _stream()),
+               "tt_attention_fwd")
+    return out, lse, probs
+
+
+def attention_bwd(qkv, out, dout, lse, num_heads: int):
+    lib = _lib.load()
+    _chk(qkv, "qkv"); _chk(out, "out"); _chk(dout, "dout"); _chk(lse, "lse")
+    F, N, D3 = qkv.shape
+    hd = D3 // 3 // num_heads
+    dqkv = torch.empty_like(qkv)
+    nb = lib.tt_attention_bwd_workspace_bytes(F, N, num_heads, hd)
+    ws = _ws(nb, qkv.device)
+    _lib.check(lib.tt_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), F, N, num_heads, hd, float(hd ** -0.5), _p(ws), nb,
+                                    _stream()), "tt_attention_bwd")
+    return dqkv
+
+
+# ---- prototypes / assignment ---------------------------------------------------------------------
+
+def l2norm_fwd(x, save_inv=False, out=None):
+    """F.normalize(x, dim=-1).  x may be a row-strided 2-D view (stride(1) == 1)."""
+    lib = _lib.load()
+    if x.dim() != 2 or x.stride(1) != 1 or not x.is_cuda or x.dtype != f32:
+        raise ValueError("l2norm_fwd: expected a 2-D fp32 GPU tensor with unit inner stride")
+    rows, D = x.shape
+    xn = out if out is not None else torch.empty((rows, D), dtype=f32, device=x.device)
+    inv = torch.empty((rows,), dtype=f32, device=x.device) if save_inv else None
+    _lib.check(lib.tt_l2norm_fwd(_p(x), x.stride(0), _p(xn), _p(inv), rows, D, _stream()), "tt_l2norm_fwd")
+    return (xn, inv) if save_inv else xn
+
+
+def l2norm_bwd(dxn, xn, inv):
+    lib = _lib.load()
+    _chk(dxn, "dxn"); _chk(xn, "xn"); _chk(inv, "inv")
+    rows, D = xn.shape
+    dx = torch.empty_like(xn)
+    _lib.check(lib.tt_l2norm_bwd(_p(dxn), _p(xn), _p(inv), _p(dx), rows, D, _stream()), "tt_l2norm_bwd")
+    return dx
+
+
+def normalize_rows_(w):
+    lib = _lib.load()
+    _chk(w, "w")
+    _lib.check(lib.tt_normalize_rows_inplace(_p(w), w.shape[0], w.shape[1], _stream()), "tt_normalize_rows_inplace")
+    return w
+
+
+def sinkhorn(scores, iters: int, eps: float = 0.05, row0: int = 0, rows_out: Optional[int] = None):
+    """scores [B_total, K] -> q [rows_out, K] for rows [row0, row0+rows_out)."""
+    lib = _lib.load()
+    _chk(scores, "scores")
+    B, K = scores.shape
+    rows_out = B - row0 if rows_out is None else rows_out
+    q = torch.empty((rows_out, K), dtype=f32, device=scores.device)
+    nb = lib.tt_sinkhorn_workspace_bytes(B, K)
+    ws = _ws(nb, scores.device)
+    _lib.check(lib.tt_sinkhorn(_p(scores), _p(q), B, K, row0, rows_out, float(eps), int(iters), _p(ws), nb, _stream()), "tt_sinkhorn")
+    return q
+
+
+def label_propagate(xn, seg0, n_last_frames=7, radius=6, topk=5, temperature=0.1, return_pmap=False):
+    """xn [fs,bs,n,D] normalised tokens (time-major), seg0 [bs,n,K] -> labels [bs,n] int64 (+ pmap [bs,n,K] fp64)."""
+    lib = _lib.load()
+    _chk(xn, "xn"); _chk(seg0, "seg0")
+    fs, bs, n, D = xn.shape
+    K = seg0.shape[-1]
+    g = int(round(n ** 0.5))
+    assert g * g == n
+    labels = torch.empty((bs, n), dtype=torch.int64, device=xn.device)
+    pmap = torch.empty((bs, n, K), dtype=torch.float64, device=xn.device) if return_pmap else None
+    nb = lib.tt_label_propagate_workspace_bytes(bs, fs, g, D, K, n_last_frames)
+    ws = _ws(nb, xn.device)
+    _lib.check(lib.tt_label_propagate(_p(xn), _p(seg0), _p(labels), _p(pmap), bs, fs, g, D, K, n_last_frames, radius, topk,
+                                      float(temperature), _p(ws), nb, _stream()), "tt_label_propagate")
+    return (labels, pmap) if return_pmap else labels
+
+
+def ce_loss_fwd_bwd(scores, labels, temperature=0.1, need_grad=True):
+    """mean CE of scores/temperature vs labels; returns (loss[1], dscores or None)."""
+    lib = _lib.load()
+    _chk(scores, "scores"); _chk(labels, "labels", torch.int64)
+    rows, K = scores.shape
+    loss = torch.empty((1,), dtype=f32, device=scores.device)
+    ds = torch.empty_like(scores) if need_grad else None
+    nb = lib.tt_ce_workspace_bytes(rows)
+    ws = _ws(nb, scores.device)
+    _lib.check(lib.tt_ce_loss_fwd_bwd(_p(scores), _p(labels), _p(loss), _p(ds), rows, K, float(temperature), _p(ws), nb, _stream()),
+               "tt_ce_loss_fwd_bwd")
+    return loss, ds
+
+
+def queue_push_(queue, feats, idx):
+    lib = _lib.load()
+    _chk(queue, "queue"); _chk(feats, "feats"); _chk(idx, "idx", torch.int64)
+    Q, D = queue.shape
+    m = idx.numel()
+    scratch = torch.empty_like(queue)
+    _lib.check(lib.tt_queue_push(_p(queue), _p(scratch), _p(feats), _p(idx), Q, D, m, _stream()), "tt_queue_push")
+    return queue
+
+
+# ---- optimiser -------------------------------------------------------------------------------------
+
+def adamw_step_(entries: Sequence[tuple], step: int, beta1=0.9, beta2=0.999, eps=1e-8):
+    """entries: (param, grad, exp_avg, exp_avg_sq, lr, weight_decay) tuples, all fp32 GPU contiguous."""
+    lib = _lib.load()
+    cap = 40
+    for i in range(0, len(entries), cap):
+        chunk = entries[i:i + cap]
+        arr = (_lib.AdamwTensor * len(chunk))()
+        for j, (p, g, m, v, lr, wd) in enumerate(chunk):
+            for t, nm in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
+                _chk(t, nm)
+            arr[j] = _lib.AdamwTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(wd))
+        _lib.check(lib.tt_adamw_step(arr, len(chunk), int(step), float(beta1), float(beta2), float(eps), _stream()), "tt_adamw_step")
+
+
+def ema_update_(teacher, student, momentum: float):
+    """teacher <- teacher * (1 - m) + student * m  (time_tuning.py:113-115)."""
+    lib = _lib.load()
+    _chk(teacher, "teacher"); _chk(student, "student")
+    assert teacher.numel() == student.numel()
+    _lib.check(lib.tt_ema_update(_p(teacher), _p(student), teacher.numel(), float(momentum), _stream()), "tt_ema_update")
+    return teacher
+
+
+def add_(dst, src):
+    lib = _lib.load()
+    _chk(dst, "dst"); _chk(src, "src")
+    _lib.check(lib.tt_add_inplace(_p(dst), _p(src), dst.numel(), _stream()), "tt_add_inplace")
+    return dst
