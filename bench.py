@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the TimeTuning training hot path on MI355X (driver contract: see the task statement).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one full training iteration of BASELINE.json configs[1] (C2): ViT-S/16, 4-frame 224x224 clips,
+32 clips per GPU, 200 prototypes, no queue / teacher - ``TimeT.get_loss`` forward + backward, AdamW step,
+prototype renormalisation.  Synthetic clips and random-init weights (portable generator), resident in HBM before the
+timed region.  Prints ONE JSON line on rank 0:
+  metric/value   clip-frames/sec, whole job (N GPUs x 32 clips x 4 frames per step), weak scaling
+  roofline       the dominant kernel (fp32-MFMA GEMM instantiation with the largest share): algorithmic flops of its
+                 launches in one instrumented step / their HIP-event durations, against the 157.3 TFLOP/s f32 matrix peak
+  cpu_baseline   the CPU oracle (reference-faithful structure) timed on this host's cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+TILE_NAMES = {0: "128x128", 1: "64x128", 2: "128x64", 3: "64x64"}
+
+
+def build_model(arch, K, device, teacher=False, queue=0, world=1):
+    from timetuning_amd import synth
+    from timetuning_amd.models import DistributedDataParallelModel, FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    fe = FeatureExtractor(arch, "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="dino",
+                          return_attention=False)
+    model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, fe.feature_dim))).to(device)
+    if world > 1:
+        model = DistributedDataParallelModel(model, device.index)
+    return model
+
+
+def train_step(model, opt, x, use_teacher):
+    loss = model(x, None, True, False)
+    opt.step(loss)
+    model.normalize_prototypes()
+    if use_teacher:
+        model.update_momentum_teacher(min(opt.global_step, len(model.momentum_schedule) - 1))
+    return loss
+
+
+def instrumented_step(model, opt, x, use_teacher):
+    """One more identical step with every GEMM launch bracketed by HIP events on the launch stream."""
+    from timetuning_amd import hip_ops
+
+    rec = []
+    hip_ops.PROFILE = rec
+    try:
+        train_step(model, opt, x, use_teacher)
+        torch.cuda.synchronize()
+    finally:
+        hip_ops.PROFILE = None
+    by = {}
+    for name, tile, flops, e0, e1 in rec:
+        d = by.setdefault((name, tile), [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += flops
+        d[2] += e0.elapsed_time(e1) * 1e-3
+    return by
+
+
+def sinkhorn_rate(device, B=6272, K=200, iters=10, reps=30):
+    from timetuning_amd import hip_ops, synth
+
+    x = torch.nn.functional.normalize(torch.from_numpy(synth.normal("bench.sk.x", (B, 256))), dim=1)
+    p = torch.from_numpy(synth.make_prototypes(K, 256))
+    scores = (x @ p.t()).to(device)
+    for _ in range(3):
+        hip_ops.sinkhorn(scores, iters)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        hip_ops.sinkhorn(scores, iters)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    algo_bytes = 4.0 * K * B * (2 * iters + 2)
+    return iters / sec, algo_bytes / sec / 1e9
+
+
+def cpu_baseline(fs, K, budget_s=30.0):
+    """The oracle in the reference's own structure (4 backbone passes per frame, per-sample host propagation) on a
+    bounded sample of the C2 step: bs=2 clips instead of 32 (per-clip work is identical)."""
+    from oracle import timet_oracle as O
+    from timetuning_amd import synth
+
+    # torch-CPU stops scaling (and then collapses) well below the socket's core count on these op sizes: use at most 32
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    bs = 2
+    om = O.build_oracle("dino-s16", K, (1024, 1024, 512, 256), mode="dino")
+    opt = O.SwavOptimizerOracle(om, 1e-5, 1e-4, O.cosine_scheduler(0.04, 0.4, 1, 8), 8, 1)
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1))
+    n, t_total = 0, 0.0
+    while n < 3 and (n == 0 or t_total + t_total / n < budget_s):
+        t0 = time.perf_counter()
+        loss = om.get_loss(x, faithful=True)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        om.normalize_prototypes()
+        t_total += time.perf_counter() - t0
+        n += 1
+    return {"value": round(bs * fs * n / t_total, 4), "unit": "clip-frames/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} training step(s) of {bs} clips x {fs} frames (C2 step = 32 clips; per-clip work identical), torch-CPU fp32, "
+                      "reference-faithful structure (4 ViT passes per frame, per-sample host label propagation)",
+            "seconds_per_step": round(t_total / n, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch_size", type=int, default=32, help="clips per GPU (C2: 32)")
+    ap.add_argument("--num_frames", type=int, default=4)
+    ap.add_argument("--num_clusters", type=int, default=200)
+    ap.add_argument("--architecture", default="dino-s16")
+    ap.add_argument("--use_teacher", action="store_true")
+    ap.add_argument("--use_queue", action="store_true")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+
+    from timetuning_amd import synth
+    from timetuning_amd.my_utils import cosine_scheduler
+    from timetuning_amd.time_tuning import SwavOptimizer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", local if world > 1 else 0)
+
+    bs, fs, K = a.batch_size, a.num_frames, a.num_clusters
+    model = build_model(a.architecture, K, device, world=world)
+    total_steps = a.steps + a.warmup + 2
+    opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, 1, total_steps), total_steps, 1)
+    if a.use_teacher:
+        model.init_momentum_teacher()
+        model.set_momentum_teacher_schedular_params(0.995, 1.0, 1, total_steps)
+    if a.use_queue:
+        model.init_queue(16384 // world)
+        model.queue.copy_(torch.nn.functional.normalize(torch.randn_like(model.queue), dim=1))
+        model._queue_rows_pushed = model.queue.shape[0]
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1 + rank)).to(device)  # resident in HBM before timing
+
+    for _ in range(a.warmup):
+        train_step(model, opt, x, a.use_teacher)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = train_step(model, opt, x, a.use_teacher)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    out = None
+    if rank == 0:
+        prof = instrumented_step(model, opt, x, a.use_teacher)
+        (dom_name, dom_tile), (cnt, flops, sec) = max(prof.items(), key=lambda kv: kv[1][2])
+        all_flops = sum(v[1] for v in prof.values())
+        all_sec = sum(v[2] for v in prof.values())
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "dominant_kernel_traffic.json")
+        if os.path.isfile(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        sk_rate, sk_gbs = sinkhorn_rate(device) if world == 1 else (None, None)
+        out = {
+            "metric": "clip-frames/sec", "value": round(world * bs * fs * a.steps / elapsed, 2), "unit": "clip-frames/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C2: ViT-S/16 full TimeT training step (fwd+bwd+AdamW), {fs}-frame 224x224 clips, {bs} clips/GPU, "
+                                   f"{K} prototypes" + (", EMA teacher" if a.use_teacher else "") + (", queue" if a.use_queue else ""),
+                       "architecture": a.architecture, "clips_per_gpu": bs, "num_frames": fs, "num_clusters": K,
+                       "global_batch": bs * world, "parallelism": f"dp{world}"},
+            "loss": round(final_loss, 5),
+            "roofline": {"bound": "mfma", "kernel": f"gemm_f32_kernel<{TILE_NAMES[dom_tile]},{dom_name}>", "launches_per_step": cnt,
+                         "achieved": round(flops / sec / 1e12, 2), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flops / sec / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "avg_launch_us": round(sec / cnt * 1e6, 2),
+                         "all_gemm_tflops": round(all_flops / all_sec / 1e12, 2),
+                         "gemm_share_of_step": round(all_sec / (elapsed / a.steps), 3)},
+            "sinkhorn": None if sk_rate is None else {"iters_per_sec": round(sk_rate, 1), "algorithmic_GBps": round(sk_gbs, 1),
+                                                      "shape": "K=200 x B=6272, 10 iterations"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fs, K)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,10 @@ int tt_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
                 int a_mmajor, int b_nmajor, float alpha, int batch, long long strideA, long long strideB,
                 long long strideC, tt_stream_t stream);
 
+/* Which tile shape the launcher picks for an M x N (x batch) product: 0 = 128x128, 1 = 64x128, 2 = 128x64,
+ * 3 = 64x64 (block tile; 4 waves each).  Exposed so that profilers can attribute launches to instantiations. */
+int tt_gemm_tile_choice(int M, int N, int batch);
+
 /* ---- k1,k2: PatchEmbed conv (kernel = stride = P) + cls token + pos-embed
  *      (dino_vision_transformer.py:166-171, 236-247)
  *   img [F_src,C,H,W]; frame_map (optional int32[F]): output frame f reads img[frame_map[f]];
@@ -77,14 +81,17 @@ int tt_patch_embed_fwd(const float* img, const int32_t* frame_map, const float* 
                        tt_stream_t stream);
 
 /* ---- k3: LayerNorm over the last dim (dino_vision_transformer.py:139,143,196; eps = 1e-6)
- *   mean/rstd (optional, [rows]) are saved for backward. */
+ *   mean/rstd (optional, [rows]) are saved for backward.  `rows` counts OUTPUT rows.
+ *   skip_group = 0: x is [rows, D].  skip_group = N (tokens per frame): x is [F, N, D] and the output
+ *   [F*(N-1), D] drops token 0 of every frame - the final norm followed by `[:, 1:]` (models.py:966-967). */
 int tt_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                     int rows, int D, float eps, tt_stream_t stream);
-/*   dx [rows,D]; dgamma/dbeta [D] optional (NULL for frozen norms).  add_to_dx != 0 accumulates
- *   into dx (residual branch).  workspace: tt_layernorm_bwd_workspace_bytes(rows, D). */
+                     int rows, int D, float eps, int skip_group, tt_stream_t stream);
+/*   dx has x's layout; dgamma/dbeta [D] optional (NULL for frozen norms).  add_to_dx != 0 accumulates
+ *   into dx (residual branch).  With skip_group the rows of dx that belong to token 0 are not touched.
+ *   workspace: tt_layernorm_bwd_workspace_bytes(rows, D). */
 int tt_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                     float* dx, float* dgamma, float* dbeta, int rows, int D, int add_to_dx, void* workspace,
-                     size_t workspace_bytes, tt_stream_t stream);
+                     float* dx, float* dgamma, float* dbeta, int rows, int D, int add_to_dx, int skip_group,
+                     void* workspace, size_t workspace_bytes, tt_stream_t stream);
 size_t tt_layernorm_bwd_workspace_bytes(int rows, int D);
 
 /* ---- k5 (+k10): multi-head self-attention core (dino_vision_transformer.py:122-129)

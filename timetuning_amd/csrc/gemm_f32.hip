@@ -236,18 +236,23 @@ static int launch_cfg(const GemmArgs& g, int batch, hipStream_t s) {
 // Tile choice: the matrix pipe is the bound, so what matters is how evenly the tiles fill 256 CUs.
 // cost(cfg) = ceil(tiles / 256) * tile_area (makespan in MFMA work per CU); small penalty for small tiles
 // (more LDS traffic and epilogue per flop).
-template <int AMODE, int BMODE>
-static int launch_mode(const GemmArgs& g, int batch, hipStream_t s) {
+int gemm_tile_choice(int M, int N, int batch) {
   struct Cfg { int wm, wn; double pen; };
   const Cfg cfgs[4] = {{2, 2, 1.00}, {1, 2, 1.04}, {2, 1, 1.04}, {1, 1, 1.10}};
   int best = 0;
   double best_cost = 1e300;
   for (int c = 0; c < 4; ++c) {
     const long long bm = 64 * cfgs[c].wm, bn = 64 * cfgs[c].wn;
-    const long long tiles = ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (long long)batch;
+    const long long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long long)batch;
     const double cost = (double)((tiles + 255) / 256) * (double)(bm * bn) * cfgs[c].pen;
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
+  return best;
+}
+
+template <int AMODE, int BMODE>
+static int launch_mode(const GemmArgs& g, int batch, hipStream_t s) {
+  const int best = gemm_tile_choice(g.M, g.N, batch);
   switch (best) {
     case 0: return launch_cfg<2, 2, AMODE, BMODE>(g, batch, s);
     case 1: return launch_cfg<1, 2, AMODE, BMODE>(g, batch, s);
@@ -285,6 +290,8 @@ static GemmArgs base_args(const float* A, const float* B, float* C, int M, int N
   g.alpha = 1.f;
   return g;
 }
+
+extern "C" int tt_gemm_tile_choice(int M, int N, int batch) { return tt::gemm_tile_choice(M, N, batch); }
 
 extern "C" int tt_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                            int a_mmajor, int b_nmajor, float alpha, int batch, long long strideA, long long strideB,

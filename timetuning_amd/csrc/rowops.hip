@@ -14,11 +14,13 @@ constexpr int kMaxPerLane = 16;  // D <= 1024
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            int rows, int D, float eps) {
+                                                            int rows, int D, float eps, int skip_group) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* xr = x + (long long)row * D;
+  // skip_group = N: the input is [F][N][D] tokens and the output drops token 0 (cls) of every frame
+  const long long in_row = skip_group ? (long long)(row / (skip_group - 1)) * skip_group + 1 + row % (skip_group - 1) : row;
+  const float* xr = x + in_row * D;
   float v[kMaxPerLane];
   float s = 0.f;
 #pragma unroll
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
                                                             float* __restrict__ partial, int rows, int D, int rows_per_wg,
-                                                            int add_to_dx) {
+                                                            int add_to_dx, int skip_group) {
   __shared__ float red[4][2][64 * kMaxPerLane];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_wg;
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
   for (int row = r0 + wave; row < r1; row += 4) {
     const float mu = mean[row], rs = rstd[row];
-    const float* xr = x + (long long)row * D;
+    const long long in_row = skip_group ? (long long)(row / (skip_group - 1)) * skip_group + 1 + row % (skip_group - 1) : row;
+    const float* xr = x + in_row * D;
     const float* dyr = dy + (long long)row * D;
     float xh[kMaxPerLane], gy[kMaxPerLane];
     float s1 = 0.f, s2 = 0.f;
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       s2 += gy[i];
     }
     const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
-    float* dxr = dx + (long long)row * D;
+    float* dxr = dx + in_row * D;
 #pragma unroll
     for (int i = 0; i < kMaxPerLane; ++i) {
       const int c = lane + 64 * i;
@@ -270,11 +273,12 @@ __global__ void queue_push_kernel(const float* __restrict__ old_q, float* __rest
 using namespace tt;
 
 extern "C" int tt_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                                int rows, int D, float eps, tt_stream_t stream) {
+                                int rows, int D, float eps, int skip_group, tt_stream_t stream) {
+  TT_REQUIRE(skip_group == 0 || (skip_group >= 2 && rows % (skip_group - 1) == 0), "layernorm_fwd: rows must be a multiple of skip_group - 1");
   TT_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
   TT_REQUIRE(rows > 0 && D > 0 && D <= 64 * kMaxPerLane, "layernorm_fwd: need 0 < D <= %d (got %d)", 64 * kMaxPerLane, D);
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta, y, mean, rstd,
-                     rows, D, eps);
+                     rows, D, eps, skip_group);
   TT_CHECK_LAUNCH("layernorm_fwd");
   return TT_OK;
 }
@@ -286,8 +290,9 @@ static int ln_bwd_wgs(int rows) {
 extern "C" size_t tt_layernorm_bwd_workspace_bytes(int rows, int D) { return (size_t)ln_bwd_wgs(rows) * 2 * D * sizeof(float); }
 
 extern "C" int tt_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                float* dx, float* dgamma, float* dbeta, int rows, int D, int add_to_dx, void* workspace,
-                                size_t workspace_bytes, tt_stream_t stream) {
+                                float* dx, float* dgamma, float* dbeta, int rows, int D, int add_to_dx, int skip_group,
+                                void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(skip_group == 0 || (skip_group >= 2 && rows % (skip_group - 1) == 0), "layernorm_bwd: rows must be a multiple of skip_group - 1");
   TT_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
   TT_REQUIRE(rows > 0 && D > 0 && D <= 64 * kMaxPerLane, "layernorm_bwd: need 0 < D <= %d", 64 * kMaxPerLane);
   const bool want = dgamma || dbeta;
@@ -297,7 +302,7 @@ extern "C" int tt_layernorm_bwd(const float* dy, const float* x, const float* ga
   if (want) TT_REQUIRE(workspace && workspace_bytes >= tt_layernorm_bwd_workspace_bytes(rows, D), "layernorm_bwd: workspace too small");
   float* partial = want ? static_cast<float*>(workspace) : nullptr;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(wgs), dim3(256), 0, as_stream(stream), dy, x, gamma, mean, rstd, dx, partial, rows,
-                     D, rpw, add_to_dx);
+                     D, rpw, add_to_dx, skip_group);
   TT_CHECK_LAUNCH("layernorm_bwd");
   if (want) {
     hipLaunchKernelGGL(colsum_stage2, dim3((D + 255) / 256), dim3(256), 0, as_stream(stream), partial, dgamma, wgs, D, 2 * D, 0);

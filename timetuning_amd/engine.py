@@ -1,0 +1,183 @@
+"""Launch sequences of the TimeTuning hot path on top of the C ABI (hip_ops).
+
+Nothing here computes: each function strings HIP kernels together on PyTorch's current stream and
+keeps the device buffers alive.  Three sequences:
+
+``vit_tokens``       patch-embed + 12 blocks (blocks flagged trainable keep their activations)
+``extractor``        + final LayerNorm with the cls row dropped (+ projection head)
+``TimeTStep``        the whole objective of ``TimeT.get_loss`` (time_tuning.py:224-302) with ONE
+                     student pass per frame instead of the reference's four, the head only on the
+                     source/target frames, one Sinkhorn solve instead of two (or four with a teacher),
+                     batched label propagation without host round trips, fused CE forward/backward and
+                     the backward of blocks.10/11 + head + prototypes on the target frames only.
+                     SURVEY.md section 3.2/3.3 documents why these are result-preserving.
+
+Frames are processed TIME-MAJOR ([fs, bs] instead of the input's [bs, fs]): the patch-embed kernel gathers
+through a frame map (no copy), and the target frames then form one contiguous row range for backward.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import hip_ops as ops
+
+f32 = torch.float32
+
+
+def _frame_map_time_major(bs: int, fs: int, device) -> torch.Tensor:
+    # output frame t*bs + b reads input frame b*fs + t
+    m = torch.arange(bs * fs, dtype=torch.int32).view(bs, fs).t().contiguous().view(-1)
+    return m.to(device)
+
+
+# ------------------------------------------------------------------------------------------------
+# ViT blocks
+# ------------------------------------------------------------------------------------------------
+
+def block_forward(x: torch.Tensor, blk, num_heads: int, save: Optional[dict] = None) -> torch.Tensor:
+    """One transformer block (dino_vision_transformer.py:147-153) on x [F,N,D].  With ``save`` the
+    activations backward needs are kept there; otherwise the residual stream is updated in place."""
+    Fr, N, D = x.shape
+    M = Fr * N
+    x2d = x.view(M, D)
+    if save is not None:
+        h1, save["mean1"], save["rstd1"] = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, save_stats=True)
+    else:
+        h1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias)
+    qkv = ops.linear_fwd(h1.view(M, D), blk.attn.qkv.weight, blk.attn.qkv.bias)
+    att, lse, _ = ops.attention_fwd(qkv.view(Fr, N, 3 * D), num_heads, save_lse=save is not None)
+    x_mid = ops.linear_fwd(att.view(M, D), blk.attn.proj.weight, blk.attn.proj.bias, residual=x2d,
+                           out=None if save is not None else x2d)
+    if save is not None:
+        h2, save["mean2"], save["rstd2"] = ops.layernorm_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, save_stats=True)
+        a, pre = ops.linear_fwd(h2, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=1, save_pre=True)
+    else:
+        h2 = ops.layernorm_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, out=h1.view(M, D))
+        a = ops.linear_fwd(h2, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=1)
+    x_out = ops.linear_fwd(a, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x_mid, out=None if save is not None else x_mid)
+    if save is not None:
+        save.update(x_in=x, h1=h1, qkv=qkv, att=att, lse=lse, x_mid=x_mid, h2=h2, pre=pre, a=a)
+    return x_out.view(Fr, N, D)
+
+
+def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int, f1: int, grads: Dict[torch.nn.Parameter, torch.Tensor],
+                   need_dx: bool = True) -> Optional[torch.Tensor]:
+    """Backward of one block restricted to frames [f0, f1) of the saved activations.  dx_out [(f1-f0)*N, D]
+    is consumed (overwritten).  Writes parameter gradients into ``grads``."""
+    Fr, N, D = sv["x_in"].shape
+    r0, r1 = f0 * N, f1 * N
+    a, pre, h2 = sv["a"][r0:r1], sv["pre"][r0:r1], sv["h2"][r0:r1]
+    # x_out = x_mid + fc2(gelu(fc1(ln2(x_mid))))
+    grads[blk.mlp.fc2.weight], grads[blk.mlp.fc2.bias] = ops.linear_bwd_weight(dx_out, a)
+    d_pre = ops.linear_bwd_data(dx_out, blk.mlp.fc2.weight, gelu_pre=pre)
+    grads[blk.mlp.fc1.weight], grads[blk.mlp.fc1.bias] = ops.linear_bwd_weight(d_pre, h2)
+    d_h2 = ops.linear_bwd_data(d_pre, blk.mlp.fc1.weight)
+    dx_mid, grads[blk.norm2.weight], grads[blk.norm2.bias] = ops.layernorm_bwd(
+        d_h2, sv["x_mid"][r0:r1], blk.norm2.weight, sv["mean2"][r0:r1], sv["rstd2"][r0:r1], dx_accum=dx_out)
+    # x_mid = x_in + proj(attention(qkv(ln1(x_in))))
+    att = sv["att"].view(Fr * N, D)[r0:r1]
+    grads[blk.attn.proj.weight], grads[blk.attn.proj.bias] = ops.linear_bwd_weight(dx_mid, att)
+    d_att = ops.linear_bwd_data(dx_mid, blk.attn.proj.weight)
+    qkv = sv["qkv"].view(Fr, N, 3 * D)[f0:f1]
+    dqkv = ops.attention_bwd(qkv, sv["att"][f0:f1], d_att.view(f1 - f0, N, D), sv["lse"][f0:f1], num_heads)
+    dqkv2 = dqkv.view((f1 - f0) * N, 3 * D)
+    h1 = sv["h1"].view(Fr * N, D)[r0:r1]
+    grads[blk.attn.qkv.weight], grads[blk.attn.qkv.bias] = ops.linear_bwd_weight(dqkv2, h1)
+    d_h1 = ops.linear_bwd_data(dqkv2, blk.attn.qkv.weight)
+    x_in = sv["x_in"].view(Fr * N, D)[r0:r1]
+    dx_in, grads[blk.norm1.weight], grads[blk.norm1.bias] = ops.layernorm_bwd(
+        d_h1, x_in, blk.norm1.weight, sv["mean1"][r0:r1], sv["rstd1"][r0:r1], dx_accum=dx_mid)
+    return dx_in if need_dx else None
+
+
+def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None, save_blocks: Optional[Dict[int, dict]] = None,
+               last_block_probs: bool = False):
+    """prepare_tokens + all blocks (dino_vision_transformer.py:236-252).  Returns (tokens [F,N,D] before the final
+    norm, attention probabilities of the last block or None)."""
+    pe = vit.patch_embed.proj
+    D = pe.weight.shape[0]
+    x = ops.patch_embed_fwd(img, pe.weight.view(D, -1), pe.bias, vit.cls_token.view(D), vit.pos_embed.view(-1, D),
+                            vit.patch_embed.patch_size, frame_map)
+    probs = None
+    depth = len(vit.blocks)
+    for i, blk in enumerate(vit.blocks):
+        sv = save_blocks.get(i) if save_blocks is not None else None
+        if last_block_probs and i == depth - 1:
+            probs = last_block_attention(x, blk, vit.num_heads)
+        x = block_forward(x, blk, vit.num_heads, sv)
+    return x, probs
+
+
+def last_block_attention(x: torch.Tensor, blk, num_heads: int) -> torch.Tensor:
+    """Attention probabilities of a block (Block.forward(return_attention=True), dino_vision_transformer.py:147-150)."""
+    Fr, N, D = x.shape
+    h1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias)
+    qkv = ops.linear_fwd(h1.view(Fr * N, D), blk.attn.qkv.weight, blk.attn.qkv.bias)
+    _, _, probs = ops.attention_fwd(qkv.view(Fr, N, 3 * D), num_heads, return_probs=True)
+    return probs
+
+
+# ------------------------------------------------------------------------------------------------
+# projection head (models.py:915-926): Linear GELU Linear GELU Linear GELU Linear
+# ------------------------------------------------------------------------------------------------
+
+def head_linears(head) -> List[torch.nn.Linear]:
+    return [m for m in head if isinstance(m, torch.nn.Linear)]
+
+
+def head_forward(x: torch.Tensor, head, save: Optional[dict] = None) -> torch.Tensor:
+    lins = head_linears(head)
+    acts = [x]
+    pres = []
+    for i, lin in enumerate(lins):
+        last = i == len(lins) - 1
+        if save is not None and not last:
+            x, pre = ops.linear_fwd(x, lin.weight, lin.bias, act=1, save_pre=True)
+            pres.append(pre)
+        else:
+            x = ops.linear_fwd(x, lin.weight, lin.bias, act=0 if last else 1)
+        acts.append(x)
+    if save is not None:
+        save["acts"], save["pres"] = acts, pres
+    return x
+
+
+def head_backward(dz: torch.Tensor, head, sv: dict, grads) -> torch.Tensor:
+    lins = head_linears(head)
+    d = dz
+    for i in range(len(lins) - 1, -1, -1):
+        lin = lins[i]
+        grads[lin.weight], grads[lin.bias] = ops.linear_bwd_weight(d, sv["acts"][i])
+        d = ops.linear_bwd_data(d, lin.weight, gelu_pre=sv["pres"][i - 1] if i > 0 else None)
+    return d
+
+
+# ------------------------------------------------------------------------------------------------
+# scores / assignment
+# ------------------------------------------------------------------------------------------------
+
+def prototype_scores(z: torch.Tensor, prototypes: torch.Tensor, save: Optional[dict] = None) -> torch.Tensor:
+    """normalize(z) @ prototypes.T (time_tuning.py:130-141)."""
+    if save is not None:
+        zn, inv = ops.l2norm_fwd(z, save_inv=True)
+        save["zn"], save["inv"] = zn, inv
+    else:
+        zn = ops.l2norm_fwd(z)
+    return ops.linear_fwd(zn, prototypes)
+
+
+def global_sinkhorn(scores_local: torch.Tensor, rows_out: int, eps: float, iters: int) -> torch.Tensor:
+    """find_optimal_assignment (time_tuning.py:157-168) with the reference's cross-rank semantics
+    (my_utils.py:250-272): ONE all-gather of the local score rows over RCCL, then every rank solves the global
+    K x (B_loc * W) problem and keeps the assignment of its own first ``rows_out`` rows."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        W, rank = dist.get_world_size(), dist.get_rank()
+        B_loc = scores_local.shape[0]
+        gathered = torch.empty((W * B_loc, scores_local.shape[1]), dtype=f32, device=scores_local.device)
+        dist.all_gather_into_tensor(gathered, scores_local.contiguous())
+        return ops.sinkhorn(gathered, iters, eps, row0=rank * B_loc, rows_out=rows_out)
+    return ops.sinkhorn(scores_local, iters, eps, row0=0, rows_out=rows_out)

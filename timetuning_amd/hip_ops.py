@@ -38,6 +38,27 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+# bench.py sets PROFILE to a list to get (layout, tile_choice, flops, start_event, end_event) per GEMM launch,
+# recorded with HIP events on the stream the kernel is launched on.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, name: str, M: int, N: int, K: int, batch: int = 1):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.append((name, _lib.load().tt_gemm_tile_choice(M, N, batch), 2.0 * M * N * K * batch, e0, e1))
+
+
 # ---- Linear ------------------------------------------------------------------------------------
 
 def linear_fwd(x, w, bias=None, residual=None, act: int = 0, save_pre: bool = False, out=None):
@@ -51,7 +72,9 @@ def linear_fwd(x, w, bias=None, residual=None, act: int = 0, save_pre: bool = Fa
     pre = torch.empty((M, N), dtype=f32, device=x.device) if save_pre else None
     if bias is not None: _chk(bias, "bias")
     if residual is not None: _chk(residual, "residual")
+    e0 = _prof_begin()
     _lib.check(lib.tt_linear_fwd(_p(x), _p(w), _p(bias), _p(residual), _p(y), _p(pre), M, N, K, act, _stream()), "tt_linear_fwd")
+    _prof_end(e0, "NT", M, N, K)
     return (y, pre) if save_pre else y
 
 
@@ -62,7 +85,9 @@ def linear_bwd_data(dy, w, gelu_pre=None, out=None):
     M, N = dy.shape
     K = w.shape[1]
     dx = out if out is not None else torch.empty((M, K), dtype=f32, device=dy.device)
+    e0 = _prof_begin()
     _lib.check(lib.tt_linear_bwd_data(_p(dy), _p(w), _p(gelu_pre), _p(dx), M, N, K, _stream()), "tt_linear_bwd_data")
+    _prof_end(e0, "NN", M, K, N)
     return dx
 
 
@@ -76,6 +101,13 @@ def linear_bwd_weight(dy, x, need_bias=True, dw_out=None, db_out=None):
     db = (db_out if db_out is not None else torch.empty((N,), dtype=f32, device=dy.device)) if need_bias else None
     nb = lib.tt_colsum_workspace_bytes(M, N)
     ws = _ws(nb, dy.device)
+    if PROFILE is not None:  # time the GEMM alone: issue the bias column-sum as its own call
+        e0 = _prof_begin()
+        _lib.check(lib.tt_linear_bwd_weight(_p(dy), _p(x), _p(dw), None, M, N, K, _p(ws), nb, _stream()), "tt_linear_bwd_weight")
+        _prof_end(e0, "TN", N, K, M)
+        if db is not None:
+            _lib.check(lib.tt_colsum(_p(dy), _p(db), M, N, _p(ws), nb, _stream()), "tt_colsum")
+        return dw, db
     _lib.check(lib.tt_linear_bwd_weight(_p(dy), _p(x), _p(dw), _p(db), M, N, K, _p(ws), nb, _stream()), "tt_linear_bwd_weight")
     return dw, db
 
@@ -134,36 +166,52 @@ def patch_embed_fwd(img, w, bias, cls, pos, patch: int, frame_map=None):
     if pos.numel() != (n + 1) * D:
         raise ValueError("pos_embed does not match the token grid (only the identity branch of interpolate_pos_encoding is built)")
     tokens = torch.empty((F, n + 1, D), dtype=f32, device=img.device)
+    e0 = _prof_begin()
     _lib.check(lib.tt_patch_embed_fwd(_p(img), _p(frame_map), _p(w), _p(bias), _p(cls), _p(pos), _p(tokens), F, Cc, H, W, patch, D,
                                       _stream()), "tt_patch_embed_fwd")
+    _prof_end(e0, "patch", F * n, D, Cc * patch * patch)
     return tokens
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-6, save_stats=False, out=None):
+def layernorm_fwd(x, gamma, beta, eps=1e-6, save_stats=False, out=None, drop_first_token=False):
+    """LayerNorm over the last dim.  drop_first_token: x is [F,N,D] and the result is [F*(N-1), D] (cls row removed)."""
     lib = _lib.load()
     _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
     D = x.shape[-1]
     rows = x.numel() // D
-    y = out if out is not None else torch.empty_like(x)
+    skip = 0
+    if drop_first_token:
+        skip = x.shape[-2]
+        rows = rows // skip * (skip - 1)
+        y = out if out is not None else torch.empty((rows, D), dtype=f32, device=x.device)
+    else:
+        y = out if out is not None else torch.empty_like(x)
     mean = torch.empty((rows,), dtype=f32, device=x.device) if save_stats else None
     rstd = torch.empty((rows,), dtype=f32, device=x.device) if save_stats else None
-    _lib.check(lib.tt_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, float(eps), _stream()), "tt_layernorm_fwd")
+    _lib.check(lib.tt_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, float(eps), skip, _stream()), "tt_layernorm_fwd")
     return (y, mean, rstd) if save_stats else y
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, dx_accum=None):
-    """Returns (dx, dgamma, dbeta).  dx_accum: tensor to accumulate dx into (residual branch)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, dx_accum=None, drop_first_token=False):
+    """Returns (dx, dgamma, dbeta).  dx_accum: tensor to accumulate dx into (residual branch).
+    drop_first_token: dy is [F*(N-1), D] against x [F,N,D]; dx is [F,N,D] with zero cls rows."""
     lib = _lib.load()
     _chk(dy, "dy"); _chk(x, "x")
     D = x.shape[-1]
-    rows = x.numel() // D
-    dx = dx_accum if dx_accum is not None else torch.empty_like(x)
+    rows = dy.numel() // D
+    skip = x.shape[-2] if drop_first_token else 0
+    if dx_accum is not None:
+        dx = dx_accum
+    elif drop_first_token:
+        dx = torch.zeros_like(x)
+    else:
+        dx = torch.empty_like(x)
     dg = torch.empty((D,), dtype=f32, device=x.device) if need_wgrad else None
     db = torch.empty((D,), dtype=f32, device=x.device) if need_wgrad else None
     nb = lib.tt_layernorm_bwd_workspace_bytes(rows, D)
     ws = _ws(nb, x.device)
     _lib.check(lib.tt_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), rows, D,
-                                    1 if dx_accum is not None else 0, _p(ws), nb, _stream()), "tt_layernorm_bwd")
+                                    1 if dx_accum is not None else 0, skip, _p(ws), nb, _stream()), "tt_layernorm_bwd")
     return dx, dg, db
 
 

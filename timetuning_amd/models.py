@@ -1,0 +1,150 @@
+"""FeatureExtractor and the data-parallel wrapper - the reference's ``models.py`` surface for the
+training path (``models.py:903-1078``, ``:1292-1306``), backed by the HIP kernels.
+
+Only the ``"dino-*"`` branch of ``get_features`` (``models.py:965-969``) exists: BASELINE's configs
+use nothing else, and the other backbones are out of scope.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import dino_vision_transformer as dvt
+from . import engine, synth
+from . import hip_ops as ops
+
+# models.py:76
+spatial_resolutions = {"dino-s16": 14, "dino-b16": 14, "dino-s8": 28}
+
+
+def get_backbone(name: str, model_path: str = "", vit_cfg: Optional[dict] = None, init: str = "dino", seed: int = 1):
+    """models.py:773-900 for the DINO entries.  The reference downloads pretrained weights through
+    ``torch.hub`` (:780-785); there is no network here, so the same architecture is built locally and
+    filled from ``model_path`` (a state_dict or a checkpoint with a ``"model"``/``"state_dict"`` entry) or, when the
+    path is empty or missing, from the portable synthetic generator.  Unknown names raise (the reference prints
+    the error and then fails on ``None.eval()``, :897-900)."""
+    if vit_cfg is None:
+        if name not in synth.ARCHS or name not in spatial_resolutions:
+            raise ValueError(f"unknown architecture {name!r}; built: {sorted(spatial_resolutions)}")
+        vit_cfg = synth.ARCHS[name]
+    cfg = dict(vit_cfg)
+    model = dvt.VisionTransformer(patch_size=cfg["patch_size"], embed_dim=cfg["embed_dim"], depth=cfg["depth"],
+                                  num_heads=cfg["num_heads"], mlp_ratio=4, qkv_bias=True)
+    import os
+
+    if model_path and os.path.isfile(model_path):
+        sd = torch.load(model_path, map_location="cpu")
+        for key in ("model", "state_dict", "teacher", "student"):
+            if isinstance(sd, dict) and key in sd and isinstance(sd[key], dict):
+                sd = sd[key]
+                break
+        sd = {k.replace("module.", "").replace("backbone.", ""): v for k, v in sd.items()}
+        missing = model.load_state_dict(sd, strict=False)
+        if missing.missing_keys:
+            raise RuntimeError(f"{model_path}: missing backbone tensors {missing.missing_keys[:4]} ...")
+    else:
+        weights = synth.make_vit_weights(mode=init, seed=seed, **cfg)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
+    model.eval()
+    return model
+
+
+class FeatureExtractor(nn.Module):
+    """``FeatureExtractor(arcitecture, model_path, head_layer_list=[], unfreeze_layers=[], kqv="all")``
+    (``models.py:903-935``, argument spelling kept).  ``forward(x, use_head=True) -> (features, attentions)``.
+
+    Extra keyword-only arguments (not in the reference) select the synthetic initialisation used when no
+    checkpoint is available, and ``return_attention=False`` skips the second output, which the reference pays a
+    second full backbone pass for (:968) although nothing on the default training path reads it."""
+
+    def __init__(self, arcitecture, model_path="", head_layer_list: Sequence[int] = (), unfreeze_layers: Sequence[str] = (),
+                 kqv="all", *, vit_cfg: Optional[dict] = None, init: str = "dino", seed: int = 1, return_attention: bool = True):
+        super().__init__()
+        self.backbone = get_backbone(arcitecture, model_path, vit_cfg, init, seed)
+        self.freeze_backbone(unfreeze_layers=unfreeze_layers)
+        self.architecture = arcitecture
+        self.kqv = kqv
+        self.return_attention = return_attention
+        self.feature_dim = self.backbone.embed_dim  # the reference probes this with a 224x224 forward (:911-912)
+        self.spatial_resolution = spatial_resolutions.get(arcitecture, 224 // self.backbone.patch_embed.patch_size)
+        self.head = None
+        head_layer_list = list(head_layer_list)
+        if len(head_layer_list):
+            layers: List[nn.Module] = [nn.Linear(self.feature_dim, head_layer_list[0]), nn.GELU()]
+            for i in range(1, len(head_layer_list)):
+                layers.append(nn.Linear(head_layer_list[i - 1], head_layer_list[i]))
+                if i != len(head_layer_list) - 1:
+                    layers.append(nn.GELU())
+            self.head = nn.Sequential(*layers)
+            if not (model_path and __import__("os").path.isfile(model_path)):
+                hw = synth.make_head_weights(self.feature_dim, head_layer_list, mode=init, seed=seed)
+                self.head.load_state_dict({k: torch.from_numpy(v) for k, v in hw.items()}, strict=True)
+            self.feature_dim = head_layer_list[-1]
+
+    def freeze_backbone(self, unfreeze_layers=()):
+        """models.py:929-935: substring match on backbone parameter names."""
+        for name, param in self.backbone.named_parameters():
+            param.requires_grad = any(u in name for u in unfreeze_layers)
+
+    def trainable_block_ids(self) -> List[int]:
+        ids = []
+        for i, blk in enumerate(self.backbone.blocks):
+            flags = [p.requires_grad for p in blk.parameters()]
+            if any(flags):
+                if not all(flags):
+                    raise NotImplementedError("partially unfrozen blocks are not built (the reference unfreezes whole blocks)")
+                ids.append(i)
+        return ids
+
+    # -- inference surface -----------------------------------------------------------------------
+    @torch.no_grad()
+    def get_features(self, input):
+        """models.py:965-969: final-norm'd patch tokens (cls dropped) and the last block's attention."""
+        x = self.backbone._check(input)
+        tok, probs = engine.vit_tokens(self.backbone, x, last_block_probs=self.return_attention)
+        Fr, N, D = tok.shape
+        feats = ops.layernorm_fwd(tok, self.backbone.norm.weight, self.backbone.norm.bias, drop_first_token=True)
+        return feats.view(Fr, N - 1, D), probs
+
+    @torch.no_grad()
+    def forward(self, x, use_head=True):
+        """models.py:1070-1078 (inference: no autograd graph; training goes through TimeT.get_loss)."""
+        feats, attn = self.get_features(x)
+        if self.head is not None and use_head:
+            Fr, n, D = feats.shape
+            feats = engine.head_forward(feats.view(Fr * n, D), self.head).view(Fr, n, -1)
+        return feats, attn
+
+
+class DistributedDataParallelModel(nn.Module):
+    """``models.py:1292-1306`` surface (``forward``, ``get_non_ddp_model``, attribute fall-through) without
+    ``torch.nn.parallel.DistributedDataParallel``: the step's backward already produces every gradient in one
+    shot, so the exchange is a single flat RCCL all-reduce issued by ``TimeT`` itself (time_tuning.py), and the
+    Sinkhorn solve all-gathers the score rows (engine.global_sinkhorn).  Parameters are broadcast from rank 0 at
+    construction, as DDP does."""
+
+    def __init__(self, model, gpu):
+        super().__init__()
+        self.model = model
+        self.gpu = gpu
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            with torch.no_grad():
+                for t in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t.data, src=0)
+            model.data_parallel = True
+
+    def forward(self, *input):
+        return self.model(*input)
+
+    def get_non_ddp_model(self):
+        return self.model
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__("model"), name)

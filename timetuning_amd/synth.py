@@ -30,7 +30,7 @@ ARCHS = {
     "dino-b16": dict(embed_dim=768, depth=12, num_heads=12, patch_size=16),
     # not a reference architecture: a cheap ViT for CPU-sized parity tests.  It is only
     # reachable through explicit ``vit_cfg=`` arguments, never through the CLI.
-    "tiny-s16": dict(embed_dim=64, depth=12, num_heads=2, patch_size=16),
+    "tiny-s16": dict(embed_dim=128, depth=12, num_heads=2, patch_size=16),
 }
 
 

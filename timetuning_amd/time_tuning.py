@@ -1,0 +1,576 @@
+"""TimeT objective, SwavOptimizer and the command line - the reference's ``time_tuning.py`` surface
+(``time_tuning.py:80-302``, ``:379-429``, ``:508-717``) on the MI355X kernels.
+
+What is the same: class and method names, argument names and defaults, state_dict keys, the flag set
+and its quirks (see ``build_parser``), the numerical result of one training iteration.
+What is different by design: ``get_loss`` runs as ONE fused forward+backward launch sequence
+(``engine`` / ``_run_step``) instead of autograd over ATen ops; ``loss.backward()`` only hands the
+already-computed gradients to the parameters.
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import math
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import engine
+from . import hip_ops as ops
+from .models import DistributedDataParallelModel, FeatureExtractor
+from .my_utils import cosine_scheduler
+
+world_size = 1  # module global, as in the reference (time_tuning.py:75,511-512)
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+
+class PatchPrototypeSimilarity(nn.Module):
+    """Patch-token x prototype scores + Sinkhorn-Knopp assignment: the north-star's name for what the
+    reference spreads over ``get_feature_prototype_similarity`` / ``find_optimal_assignment`` / ``get_scores``
+    (``time_tuning.py:130-141,157-168,195-217``).  It owns nothing: prototypes, teacher prototypes and the queue
+    stay attributes of the ``TimeT`` it is attached to (so the state_dict layout is the reference's).
+
+    ``forward(features[bs,n,dim], use_teacher=False) -> (q[bs,n,K], scores[bs,n,K])``; inference only - the
+    training gradient flows through ``TimeT.get_loss``'s fused step."""
+
+    def __init__(self, owner: "TimeT", epsilon: float = 0.05, sinkhorn_iterations: int = 10):
+        super().__init__()
+        object.__setattr__(self, "_owner", owner)  # not a sub-module: avoids a parameter cycle
+        self.epsilon = epsilon
+        self.sinkhorn_iterations = sinkhorn_iterations
+
+    def similarity(self, x: torch.Tensor, use_teacher: bool = False) -> torch.Tensor:
+        o = self._owner
+        protos = o.teacher_prototypes if use_teacher else o.prototypes
+        return engine.prototype_scores(x.contiguous(), protos.detach())
+
+    @torch.no_grad()
+    def forward(self, features: torch.Tensor, use_teacher: bool = False, epsilon: Optional[float] = None,
+                sinkhorn_iterations: Optional[int] = None):
+        o = self._owner
+        bs, n, dim = features.shape
+        eps = self.epsilon if epsilon is None else epsilon
+        iters = self.sinkhorn_iterations if sinkhorn_iterations is None else sinkhorn_iterations
+        batch_scores = self.similarity(features.reshape(bs * n, dim), use_teacher)
+        scores = batch_scores
+        if o.queue is not None and o.queue_is_full():
+            scores = torch.cat([batch_scores, self.similarity(o.queue, use_teacher)], dim=0)
+        q = engine.global_sinkhorn(scores, bs * n, eps, int(iters))
+        return q.view(bs, n, -1), batch_scores.view(bs, n, -1)
+
+
+class _FusedLoss(torch.autograd.Function):
+    """Bridges the fused step into autograd: forward runs the whole HIP forward+backward sequence and keeps the
+    parameter gradients; backward scales them by the incoming gradient (1 for ``loss.backward()``)."""
+
+    @staticmethod
+    def forward(ctx, model, x, hp, need_grad, *params):
+        loss, grads = model._run_step(x, hp, need_grad)
+        ctx.grads = [grads.get(p) for p in params] if need_grad else None
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        if ctx.grads is None:
+            raise RuntimeError("the fused TimeT step was run without gradients")
+        out = [None if g is None else g for g in ctx.grads]
+        live = [g for g in out if g is not None]
+        torch._foreach_mul_(live, gout)
+        return (None, None, None, None, *out)
+
+
+class TimeT(nn.Module):
+    """``TimeT(feature_extractor, prototype_number=10, prototype_init=None)`` (``time_tuning.py:80-93``)."""
+
+    def __init__(self, feature_extractor: FeatureExtractor, prototype_number=10, prototype_init=None):
+        super().__init__()
+        self.feature_extractor = feature_extractor
+        self.teacher = None
+        self.max_epochs = None
+        self.train_iters_per_epoch = None
+        self.teacher_prototypes = None
+        self.queue = None
+        self.momentum_schedule = None
+        self.data_parallel = False
+        self._queue_rows_pushed = 0
+        self._frame_maps: Dict[tuple, torch.Tensor] = {}
+        if prototype_init is None:
+            prototype_init = F.normalize(torch.randn((prototype_number, feature_extractor.feature_dim)), dim=-1, p=2)
+        self.prototypes = nn.Parameter(prototype_init)
+        self.similarity = PatchPrototypeSimilarity(self)
+        self.last_aux: Dict[str, torch.Tensor] = {}
+
+    # -- teacher / queue state (time_tuning.py:96-128) ---------------------------------------------
+    def init_momentum_teacher(self, teacher=None, prototypes=None):
+        if teacher is None:
+            self.teacher = copy.deepcopy(self.feature_extractor)
+            self.teacher.requires_grad_(False)
+            self.teacher_prototypes = nn.Parameter(self.prototypes.detach().clone())
+            self.teacher_prototypes.requires_grad_(False)
+        else:
+            self.teacher = teacher
+            self.teacher_prototypes = prototypes
+        self._ema_flat = None
+
+    def init_queue(self, queue_size):
+        self.queue = torch.zeros((queue_size, self.feature_extractor.feature_dim), device=self.prototypes.device)
+        self._queue_rows_pushed = 0
+
+    def queue_is_full(self) -> bool:
+        """``self.queue[-1].count_nonzero() != 0`` (time_tuning.py:207) tracked on the host: the FIFO's last row
+        becomes non-zero exactly when ``queue_size`` rows have been pushed, so no device sync is needed."""
+        return self.queue is not None and self._queue_rows_pushed >= self.queue.shape[0]
+
+    def set_momentum_teacher_schedular_params(self, momentum_teacher, momentum_teacher_end, max_epochs, train_iter_per_epoch):
+        self.momentum_schedule = cosine_scheduler(momentum_teacher, momentum_teacher_end, max_epochs, train_iter_per_epoch)
+
+    def _flatten_for_ema(self):
+        """Re-homes student and teacher extractor parameters into two flat buffers (same order) so that the EMA
+        of 23.8 M parameters is one launch instead of ~150."""
+        sp, tp = list(self.feature_extractor.parameters()), list(self.teacher.parameters())
+        ok = self._ema_flat is not None
+        if ok:
+            fs_, ft_, offs = self._ema_flat
+            ok = all(p.data_ptr() == fs_.data_ptr() + 4 * o for p, o in zip(sp, offs)) and \
+                all(p.data_ptr() == ft_.data_ptr() + 4 * o for p, o in zip(tp, offs))
+        if ok:
+            return self._ema_flat
+        offs, total = [], 0
+        for p in sp:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        dev = self.prototypes.device
+        fs_, ft_ = torch.zeros(total, device=dev), torch.zeros(total, device=dev)
+        for plist, flat in ((sp, fs_), (tp, ft_)):
+            for p, o in zip(plist, offs):
+                view = flat[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+        self._ema_flat = (fs_, ft_, offs)
+        return self._ema_flat
+
+    def update_momentum_teacher(self, step, writer=None):
+        """teacher <- teacher * (1 - m) + student * m with m = momentum_schedule[step] (time_tuning.py:109-118;
+        the student gets weight m ~ 0.995 - the reference's convention, kept)."""
+        with torch.no_grad():
+            momentum = float(self.momentum_schedule[step])
+            if writer is not None:
+                writer.add_scalar("momentum", momentum, step)
+            fs_, ft_, _ = self._flatten_for_ema()
+            ops.ema_update_(ft_, fs_, momentum)
+            ops.ema_update_(self.teacher_prototypes.data, self.prototypes.data, momentum)
+            ops.normalize_rows_(self.teacher_prototypes.data)
+
+    def normalize_prototypes(self):
+        with torch.no_grad():
+            ops.normalize_rows_(self.prototypes.data)
+
+    # -- reference method names, delegating to the HIP path ------------------------------------------
+    def get_feature_prototype_similarity(self, x, use_teacher=False):
+        return self.similarity.similarity(x, use_teacher)
+
+    def find_optimal_assignment(self, scores, epsilon, sinkhorn_iterations):
+        with torch.no_grad():
+            return engine.global_sinkhorn(scores.contiguous(), scores.shape[0], epsilon, int(sinkhorn_iterations))
+
+    def get_scores(self, features, epsilon, sinkhorn_iterations, use_teacher=False):
+        return self.similarity(features, use_teacher, epsilon, sinkhorn_iterations)
+
+    def make_seg_maps(self, first_frame_segmentation, orig_x, n_last_frames, size_mask_neighborhood, topk, features_exist=True):
+        """first_frame_segmentation [n,K], orig_x [fs,n,D] backbone tokens -> the LAST frame's map [K,g,g] fp64 stacked
+        as the reference's list tail (time_tuning.py:143-154 returns all fs-1 maps; only [-1] is ever read, :294)."""
+        if not features_exist:
+            raise NotImplementedError("make_seg_maps is only used with precomputed features on the training path")
+        fs, n, D = orig_x.shape
+        g = self.feature_extractor.spatial_resolution
+        xn = ops.l2norm_fwd(orig_x.reshape(fs * n, D).contiguous()).view(fs, 1, n, D)
+        _, pmap = ops.label_propagate(xn, first_frame_segmentation.reshape(1, n, -1).contiguous().float(), n_last_frames,
+                                      size_mask_neighborhood, topk, 0.1, return_pmap=True)
+        return pmap[0].t().reshape(1, -1, g, g)
+
+    def reshape_to_spatial_resolution(self, x, spatial_resolution):
+        return x.view(spatial_resolution, spatial_resolution, -1).permute(2, 0, 1)
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def forward(self, x, annotations=None, train=False, mask_features=False, use_head=True):
+        if not train:
+            with torch.no_grad():
+                return self.feature_extractor(x, use_head=use_head)
+        return self.get_loss(x, annotations=annotations, mask_features=mask_features)
+
+    # -- the objective -----------------------------------------------------------------------------
+    def get_loss(self, x, annotations=None, n_last_frames=7, size_mask_neighborhood=6, topk=5, epsilon=0.05,
+                 sinkhorn_iterations=10, mask_features=False, queue_perm=None):
+        """``time_tuning.py:224-302``.  ``queue_perm`` (not in the reference) injects the permutation that
+        ``torch.randperm`` draws at :259 so that runs can be reproduced exactly."""
+        if mask_features:
+            raise NotImplementedError("--use_mask (attention-masked loss, models.py:93-144) is the next row of the scope "
+                                      "table (SURVEY.md 8(f) N1) and is not built yet")
+        hp = dict(n_last_frames=n_last_frames, radius=size_mask_neighborhood, topk=topk, epsilon=epsilon,
+                  iters=int(sinkhorn_iterations), queue_perm=queue_perm)
+        params = [p for p in self.parameters() if p.requires_grad]
+        need_grad = torch.is_grad_enabled() and len(params) > 0
+        return _FusedLoss.apply(self, x, hp, need_grad, *params)
+
+    def _frame_map(self, bs, fs, device, only_t: Optional[int] = None):
+        key = (bs, fs, only_t, str(device))
+        if key not in self._frame_maps:
+            m = torch.arange(bs * fs, dtype=torch.int32).view(bs, fs).t().contiguous()  # [fs, bs]: t-major
+            m = m.view(-1) if only_t is None else m[only_t].contiguous()
+            self._frame_maps[key] = m.to(device)
+        return self._frame_maps[key]
+
+    def _run_step(self, x: torch.Tensor, hp: dict, need_grad: bool):
+        fe = self.feature_extractor
+        vit = fe.backbone
+        bs, fs, c, h, w = x.shape
+        if fs < 2:
+            raise ValueError("TimeT needs clips of at least 2 frames")
+        Fr = bs * fs
+        xf = vit._check(x.reshape(Fr, c, h, w))
+        dev = xf.device
+        train_ids = fe.trainable_block_ids() if need_grad else []
+        first = min(train_ids) if train_ids else None
+        save = {i: {} for i in range(first, len(vit.blocks))} if first is not None else None
+
+        # ---- student: one pass over all frames, time-major
+        tok, _ = engine.vit_tokens(vit, xf, self._frame_map(bs, fs, dev), save)
+        N, D = tok.shape[1], tok.shape[2]
+        n = N - 1
+        if need_grad:
+            feats, mean_f, rstd_f = ops.layernorm_fwd(tok, vit.norm.weight, vit.norm.bias, save_stats=True, drop_first_token=True)
+        else:
+            feats = ops.layernorm_fwd(tok, vit.norm.weight, vit.norm.bias, drop_first_token=True)
+        xn_bb = ops.l2norm_fwd(feats).view(fs, bs, n, D)           # label-propagation features (pre-head tokens)
+        src_rows, tgt_rows = feats[: bs * n], feats[(fs - 1) * bs * n:]
+        sv_head: Optional[dict] = {} if need_grad else None
+        z_tgt = engine.head_forward(tgt_rows, fe.head, sv_head) if fe.head is not None else tgt_rows
+
+        # ---- assignment source: teacher on frame 0 if present, else the student's frame 0 (no grad either way)
+        if self.teacher is not None:
+            tvit = self.teacher.backbone
+            t_tok, _ = engine.vit_tokens(tvit, xf, self._frame_map(bs, fs, dev, only_t=0))
+            t_feats = ops.layernorm_fwd(t_tok, tvit.norm.weight, tvit.norm.bias, drop_first_token=True)
+            z_q = engine.head_forward(t_feats, self.teacher.head) if self.teacher.head is not None else t_feats
+            protos_q = self.teacher_prototypes.data
+        else:
+            z_q = engine.head_forward(src_rows, fe.head) if fe.head is not None else src_rows
+            protos_q = self.prototypes.data
+
+        if self.queue is not None:  # time_tuning.py:250-261 (before scoring, so the batch is also in the queue)
+            m = min(bs * 10, self.queue.shape[0])
+            perm = hp["queue_perm"]
+            perm = torch.randperm(bs * n) if perm is None else torch.as_tensor(perm)
+            ops.queue_push_(self.queue, z_q, perm[:m].to(device=dev, dtype=torch.int64))
+            self._queue_rows_pushed += m
+
+        scores_q = engine.prototype_scores(z_q, protos_q)
+        if self.queue_is_full():
+            scores_q = torch.cat([scores_q, engine.prototype_scores(self.queue, protos_q)], dim=0)
+        q = engine.global_sinkhorn(scores_q, bs * n, hp["epsilon"], hp["iters"])                 # [bs*n, K]
+
+        sv_sc: Optional[dict] = {} if need_grad else None
+        scores_t = engine.prototype_scores(z_tgt, self.prototypes.data, sv_sc)                 # [bs*n, K]
+        K = scores_t.shape[1]
+        labels = ops.label_propagate(xn_bb, q.view(bs, n, K), hp["n_last_frames"], hp["radius"], hp["topk"], 0.1)
+        loss, dscores = ops.ce_loss_fwd_bwd(scores_t, labels.view(-1), 0.1, need_grad)
+        self.last_aux = dict(q=q.view(bs, n, K), target_scores=scores_t.view(bs, n, K), labels=labels)
+        if not need_grad:
+            return loss, {}
+
+        # ---- backward on the target frames only
+        grads: Dict[nn.Parameter, torch.Tensor] = {}
+        grads[self.prototypes], _ = ops.linear_bwd_weight(dscores, sv_sc["zn"], need_bias=False)
+        dz = ops.l2norm_bwd(ops.linear_bwd_data(dscores, self.prototypes.data), sv_sc["zn"], sv_sc["inv"])
+        d_feats = engine.head_backward(dz, fe.head, sv_head, grads) if fe.head is not None else dz
+        if train_ids:
+            f0 = (fs - 1) * bs
+            wg = vit.norm.weight.requires_grad
+            dx, dg, db = ops.layernorm_bwd(d_feats, tok[f0:], vit.norm.weight, mean_f[f0 * n:], rstd_f[f0 * n:], need_wgrad=wg,
+                                           drop_first_token=True)
+            if wg:
+                grads[vit.norm.weight], grads[vit.norm.bias] = dg, db
+            dx = dx.view(bs * N, D)
+            for i in range(len(vit.blocks) - 1, first - 1, -1):
+                dx = engine.block_backward(dx, vit.blocks[i], vit.num_heads, save[i], f0, Fr, grads, need_dx=i > first)
+        grads = {p: g for p, g in grads.items() if p.requires_grad}
+
+        d = _dist()
+        if d is not None:  # the data-parallel exchange: ONE flat all-reduce (mean) over RCCL
+            keys = list(grads)
+            flat = torch.cat([grads[k].reshape(-1) for k in keys])
+            d.all_reduce(flat)
+            flat /= d.get_world_size()
+            off = 0
+            for k in keys:
+                grads[k] = flat[off:off + k.numel()].view(k.shape)
+                off += k.numel()
+        return loss, grads
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser
+# ------------------------------------------------------------------------------------------------
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (betas (0.9, 0.999), eps 1e-8, decoupled decay), one HIP launch per step for
+    all tensors.  State layout matches torch's (``step``, ``exp_avg``, ``exp_avg_sq``), so optimizer state dicts
+    are interchangeable with the reference's."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        by_step: Dict[int, list] = {}
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                key = (int(st["step"].item()), b1, b2, group["eps"])
+                by_step.setdefault(key, []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], group["weight_decay"]))
+        for (step, b1, b2, eps), entries in by_step.items():
+            ops.adamw_step_(entries, step, b1, b2, eps)
+        return None
+
+
+class SwavOptimizer:
+    """``time_tuning.py:379-429``: AdamW over (prototypes | head | backbone) x (decayed | bias-and-1-D) groups,
+    CosineAnnealingLR, per-step weight-decay reschedule.  ``lr_scheduler == "CosineAnnealingLR"`` is compared by
+    value (the reference uses ``is``, which is True only for the in-file default, :383)."""
+
+    def __init__(self, model, optimizer, use_projection_head, backbone_lr, lr, lr_scheduler, wd_schedule, num_itr=None,
+                 num_epochs=None, exclude_bias_norm=True, writer=None):
+        self.optimizer = self.configure_optimizer(model, optimizer, use_projection_head, backbone_lr, lr, wd_schedule[0],
+                                                  exclude_bias_norm=exclude_bias_norm)
+        if lr_scheduler == "CosineAnnealingLR":
+            self.lr_scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=num_itr * num_epochs, eta_min=0)
+        else:
+            self.lr_scheduler = None
+        self.wd_schedule = wd_schedule
+        self.writer = writer
+        self.global_step = 0
+
+    def get_optimization_dict(self, model, filter_name, exclude_decay=True, weight_decay=0.0001, learning_rate=0.001):
+        params, excluded = [], []
+        for name, param in model.named_parameters():
+            if param.requires_grad and (filter_name in name):
+                if exclude_decay and (name.endswith(".bias") or param.dim() == 1):
+                    excluded.append(param)
+                else:
+                    params.append(param)
+        return [{"params": params, "weight_decay": weight_decay, "lr": learning_rate},
+                {"params": excluded, "weight_decay": 0.0, "lr": learning_rate}]
+
+    def configure_optimizer(self, model, optimizer, use_projection_head, backbone_lr, lr, weight_decay, exclude_bias_norm=True):
+        if optimizer != "AdamW":
+            raise ValueError("only AdamW is built (the reference leaves `opt` undefined for anything else, :413-415)")
+        target = model.get_non_ddp_model() if isinstance(model, DistributedDataParallelModel) else model
+        groups = self.get_optimization_dict(target, "prototypes", exclude_bias_norm, weight_decay, lr)
+        if use_projection_head:
+            groups += self.get_optimization_dict(target, "feature_extractor.head", exclude_bias_norm, weight_decay, lr)
+        groups += self.get_optimization_dict(target, "feature_extractor.backbone", exclude_bias_norm, weight_decay, backbone_lr)
+        return FusedAdamW(groups, lr)
+
+    def state_dict(self):
+        return self.optimizer.state_dict(), self.global_step
+
+    def step(self, loss):
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        self.global_step += 1
+        for param_group in self.optimizer.param_groups:
+            if param_group["weight_decay"] != 0:
+                # the reference indexes wd_schedule[global_step] and raises IndexError on the very last step
+                # (:427-429); the schedule's last value is held instead
+                param_group["weight_decay"] = float(self.wd_schedule[min(self.global_step, len(self.wd_schedule) - 1)])
+
+
+# ------------------------------------------------------------------------------------------------
+# checkpoints (time_tuning.py:460-505)
+# ------------------------------------------------------------------------------------------------
+
+def save_checkpoint(model, optimizer: SwavOptimizer, epch_num: int, filename: str) -> None:
+    opt_state, global_step = optimizer.state_dict()
+    torch.save({"epoch": epch_num, "global_step": global_step, "model": model.state_dict(), "optimizer": opt_state,
+                "scheduler": optimizer.lr_scheduler.state_dict() if optimizer.lr_scheduler is not None else None}, filename)
+
+
+def load_checkpoint(model, swav_optimizer: SwavOptimizer, filename: str) -> int:
+    if not os.path.isfile(filename):
+        print(f"No checkpoint found at {filename}")
+        return 0
+    state = torch.load(filename, map_location="cpu")
+    model.load_state_dict(state["model"])
+    swav_optimizer.optimizer.load_state_dict(state["optimizer"])
+    swav_optimizer.global_step = state["global_step"]
+    if swav_optimizer.lr_scheduler is not None and state.get("scheduler") is not None:
+        swav_optimizer.lr_scheduler.load_state_dict(state["scheduler"])
+    return state["epoch"]
+
+
+# ------------------------------------------------------------------------------------------------
+# command line + driver (time_tuning.py:508-717)
+# ------------------------------------------------------------------------------------------------
+
+def build_parser() -> argparse.ArgumentParser:
+    """Flag names, types and defaults of ``time_tuning.py:674-713``.
+
+    Reproduced quirks: the ``type=bool`` flags treat ANY non-empty string as True (``--use_queue False`` turns the
+    queue ON, as in the reference's README command); ``--epsilon --sinkhorn_iterations --n_last_frames --topk
+    --size_mask_neighborhood --epochs --dataset_path --destination_path`` are parsed but never reach ``get_loss``,
+    which uses its signature defaults (eps 0.05, 10 iterations, 7 frames, radius 6, top-5).
+    Added (not in the reference): ``--dataset synthetic`` and ``--steps_per_epoch`` because the dataset loaders are
+    out of scope here."""
+    p = argparse.ArgumentParser()
+    p.add_argument("--architecture", type=str, default="dino-s16")
+    p.add_argument("--model_path", type=str, default="vits16_800ep.pth.tar")
+    p.add_argument("--dataset", type=str, default="ytvos")
+    p.add_argument("--dataset_path", type=str, default="../data")
+    p.add_argument("--destination_path", type=str, default="ytvos")
+    p.add_argument("--evaluation_protocol", type=str, default="dataset-wise")
+    p.add_argument("--visualization_directory", type=str, default="visualizations")
+    p.add_argument("--logging_directory", type=str, default="logs")
+    p.add_argument("--EMA_decay", type=float, default=0.995)
+    p.add_argument("--lr_scheduler", type=str, default="CosineAnnealingLR")
+    p.add_argument("--head_lr", type=float, default=0.0001)
+    p.add_argument("--batch_size", type=int, default=128)
+    p.add_argument("--num_epochs", type=int, default=100)
+    p.add_argument("--num_workers", type=int, default=10)
+    p.add_argument("--num_clusters", type=int, default=200)
+    p.add_argument("--input_resolution", type=int, default=224)
+    p.add_argument("--many_to_one", type=bool, default=False)
+    p.add_argument("--precision_based", type=bool, default=False)
+    p.add_argument("--num_frames", type=int, default=4)
+    p.add_argument("--n_last_frames", type=int, default=6)
+    p.add_argument("--uvos", type=int, default=False)
+    p.add_argument("--topk", type=int, default=5)
+    p.add_argument("--size_mask_neighborhood", default=6, type=int)
+    p.add_argument("--epsilon", default=0.05, type=float)
+    p.add_argument("--sinkhorn_iterations", default=3, type=float)
+    p.add_argument("--use_projection_head", type=bool, default=True)
+    p.add_argument("--use_queue", type=bool, default=False)
+    p.add_argument("--queue_size", type=int, default=16384)
+    p.add_argument("--use_mask", type=bool, default=False)
+    p.add_argument("--use_teacher", type=bool, default=True)
+    p.add_argument("--load_checkpoint", type=bool, default=False)
+    p.add_argument("--regular_step", type=int, default=3)
+    p.add_argument("-n", "--nodes", default=1, type=int, metavar="N")
+    p.add_argument("-g", "--gpus", default=1, type=int)
+    p.add_argument("-nr", "--nr", default=0, type=int)
+    p.add_argument("--epochs", default=3000, type=int, metavar="N")
+    p.add_argument("--steps_per_epoch", default=8, type=int, help="synthetic data only")
+    return p
+
+
+class SyntheticClips:
+    """Stand-in for ``make_loader`` (data_loader.py:1047-1110): yields ``(data[bs,1,fs,3,H,W], annotations, label)``
+    like the real loader (data_loader.py:743-767), from the portable generator, already on the device."""
+
+    def __init__(self, batch_size, num_frames, resolution, steps, device, rank=0):
+        from . import synth
+
+        self.steps, self.bs, self.fs, self.res, self.device, self.rank = steps, batch_size, num_frames, resolution, device, rank
+        self._synth = synth
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for i in range(self.steps):
+            clips = self._synth.make_clips(self.bs, self.fs, self.res, seed=1000 * self.rank + i + 1)
+            data = torch.from_numpy(clips).unsqueeze(1).to(self.device, non_blocking=True)
+            yield data, torch.zeros(self.bs, 1, self.fs, 1), torch.zeros(self.bs)
+
+
+def time_tuning(gpu=0, args=None):
+    """One process per GPU (``time_tuning.py:508-666``): model, optimiser, epoch loop.  Evaluation every 4 epochs
+    (faiss k-means + Hungarian mIoU on Pascal VOC, :634-646) is out of scope."""
+    import torch.distributed as dist
+
+    global world_size
+    device = torch.device("cuda", gpu)
+    torch.cuda.set_device(device)
+    world_size = args.gpus * args.nodes
+    rank = args.nr * args.gpus + gpu
+    if world_size > 1 and not dist.is_initialized():
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world_size, rank=rank)
+    if args.use_projection_head:
+        fe = FeatureExtractor(args.architecture, args.model_path, [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"],
+                              return_attention=False)
+    else:
+        fe = FeatureExtractor(args.architecture, args.model_path, return_attention=False)
+    model = TimeT(fe, args.num_clusters).to(device)
+    if world_size > 1:
+        model = DistributedDataParallelModel(model, gpu)
+    if args.dataset != "synthetic":
+        raise NotImplementedError("dataset loaders (data_loader.py / video_transformations.py) are out of scope for this build "
+                                  "(SURVEY.md 8(f) N3); run with --dataset synthetic")
+    loader = SyntheticClips(args.batch_size, args.num_frames, args.input_resolution, args.steps_per_epoch, device, rank)
+    num_itr = len(loader)
+    opt = SwavOptimizer(model, "AdamW", args.use_projection_head, args.head_lr / 10, args.head_lr, args.lr_scheduler,
+                        cosine_scheduler(0.04, 0.4, args.num_epochs, num_itr), num_itr, args.num_epochs)
+    if args.use_teacher:
+        model.init_momentum_teacher()
+        model.set_momentum_teacher_schedular_params(args.EMA_decay, 1.0, args.num_epochs, num_itr)
+    if args.use_queue:
+        model.init_queue(args.queue_size // world_size)
+    os.makedirs(args.logging_directory, exist_ok=True)
+    if args.load_checkpoint:
+        load_checkpoint(model, opt, os.path.join(args.logging_directory, "checkpoint.pth"))
+    last = num_itr * args.num_epochs - 1
+    for epoch in range(args.num_epochs):
+        if rank == 0:
+            save_checkpoint(model, opt, epoch, os.path.join(args.logging_directory, "checkpoint.pth"))
+        if world_size > 1:
+            dist.barrier()
+        model.train()
+        for i, (data, annotations, label) in enumerate(loader):
+            data = data.squeeze(1)
+            loss = model(data, annotations, True, args.use_mask)
+            opt.step(loss)
+            model.normalize_prototypes()
+            if args.use_teacher:
+                model.update_momentum_teacher(min(opt.global_step, last))
+            if rank == 0:
+                print("Iteration: {}/{} loss {:.4f}".format(i, num_itr, loss.item()))
+    return model
+
+
+def main(argv=None):
+    import torch.multiprocessing as mp
+
+    args = build_parser().parse_args(argv)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if args.gpus == 1:
+        time_tuning(0, args)
+    else:
+        mp.spawn(time_tuning, nprocs=args.gpus, args=(args,))
+
+
+if __name__ == "__main__":
+    main()
