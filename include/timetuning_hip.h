@@ -55,6 +55,7 @@ int tt_linear_bwd_data(const float* dy, const float* w, const float* gelu_pre, f
                        tt_stream_t stream);
 int tt_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
                          void* workspace, size_t workspace_bytes, tt_stream_t stream);
+size_t tt_linear_bwd_weight_workspace_bytes(int M, int N, int K); /* split-K partials and/or the column-sum scratch */
 size_t tt_colsum_workspace_bytes(int M, int N);
 /* out[N] = sum over rows of a[M,N] (deterministic two-stage reduction). */
 int tt_colsum(const float* a, float* out, int M, int N, void* workspace, size_t workspace_bytes, tt_stream_t stream);

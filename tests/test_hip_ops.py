@@ -30,7 +30,8 @@ def rnd(name, *shape, std=1.0):
     return torch.from_numpy(synth.normal("t." + name, shape, std))
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (591, 1152, 384), (130, 72, 20), (64, 64, 64), (257, 200, 256), (25216, 384, 1536)])
+@pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (591, 1152, 384), (130, 72, 20), (64, 64, 64), (257, 200, 256), (25216, 384, 1536),
+                                   (392, 50, 256), (77, 21, 30), (5, 3, 2)])
 def test_linear_fwd(ops, M, N, K):
     x, w, b, r = rnd("lx", M, K), rnd("lw", N, K, std=0.05), rnd("lb", N), rnd("lr", M, N)
     ref = F.linear(x.double(), w.double(), b.double())
@@ -43,7 +44,8 @@ def test_linear_fwd(ops, M, N, K):
     assert rel_err(y3.cpu(), F.linear(x.double(), w.double())) < TOL
 
 
-@pytest.mark.parametrize("M,N,K", [(788, 384, 1536), (394, 1024, 384), (130, 72, 20), (6272, 200, 256)])
+@pytest.mark.parametrize("M,N,K", [(788, 384, 1536), (394, 1024, 384), (130, 72, 20), (6272, 200, 256), (392, 50, 256), (101, 21, 30),
+                                   (6304, 1536, 384)])
 def test_linear_bwd(ops, M, N, K):
     dy, w, x, pre = rnd("bdy", M, N), rnd("bw", N, K, std=0.05), rnd("bx", M, K), rnd("bpre", M, K)
     dx = ops.linear_bwd_data(dev(dy), dev(w))

@@ -5,17 +5,22 @@
 // chain at the f32 vector rate (157 TFLOP/s) while leaving the VALU free for epilogues.
 //
 // Tiling: 256 threads = 4 waves in a 2x2 grid; each wave owns WM x WN accumulator tiles of 32x32
-// (block tile 64*WM x 64*WN), K is consumed in slabs of BK = 16 through a double-buffered LDS image
-// stored k-major ([k][m] / [k][n]) so that one ds_read_b32 per lane yields an MFMA operand:
-//   A operand lane l holds A[row = l & 31][k = l >> 5],  B operand lane l holds B[k = l >> 5][col = l & 31].
-// Global loads are 16 B per lane; a k-contiguous source (activations [M][K], nn.Linear weights [N][K])
-// is transposed on the way into LDS, an m/n-contiguous source (dgrad / wgrad operands) is copied.
-// The next slab's global loads are issued before the current slab's 8 x WM x WN MFMAs and written to
-// the other LDS buffer afterwards: one barrier per slab.
+// (block tile 64*WM x 64*WN).  K is consumed in slabs of BK through a double-buffered LDS image; the next slab's
+// 16-byte global loads are issued before the current slab's MFMAs and written to the other buffer afterwards
+// (one barrier per slab).
 //
-// Epilogue (fused): alpha, bias, pre-activation store, exact GELU,
-// row scale, GELU-derivative multiply (dgrad through fc1 / head activations), residual add, and for the
-// patch-embed instance the row remap to token order plus the pos-embed add.
+// Operand staging.  The MFMA wants, per lane l, A[row = l & 31][k = l >> 5] and B[k = l >> 5][col = l & 31]; WHICH two k
+// values the two half-waves supply is free as long as A and B agree, so MFMA number i of k-group j uses
+// k = 8 j + 4 (l >> 5) + i.  That makes the operand of a k-contiguous source (activations [M][K], nn.Linear weights
+// [N][K] - every forward GEMM) four consecutive floats of one LDS row: ONE ds_read_b128 feeds four MFMAs, and the
+// global float4 goes to LDS unchanged with one ds_write_b128 (row stride BK + 4 floats: conflict-free for b128).
+// An m/n-contiguous source (dgrad / wgrad operands) keeps a k-major image ([k][m], stride BM + 4) read with ds_read_b32.
+//
+// Epilogue (fused): alpha, bias, pre-activation store, exact GELU, row scale,
+// GELU-derivative multiply (dgrad through fc1 / head activations), residual add, and for the patch-embed instance the
+// row remap to token order plus the pos-embed add.  Split-K (grid.z) serves the weight-gradient products, whose
+// outputs are too small to fill 256 CUs: partial tiles go to a workspace and a second kernel folds them in a fixed
+// order (deterministic, no atomics).
 #include "common.hpp"
 
 namespace tt {
@@ -35,22 +40,33 @@ struct GemmArgs {
   const float* gelu_pre;   // [M][ldc]: C *= gelu'(gelu_pre)
   const float* row_scale;  // [M]
   int act;                 // 1 = GELU
-  long long strideA, strideB, strideC;
+  long long strideA, strideB, strideC;  // batch strides (grid.y)
+  int splits, kchunk;                   // split-K over grid.z: slice z covers k in [z*kchunk, (z+1)*kchunk)
+  long long strideS;                    // element stride between split-K partial outputs
+  int vecA, vecB;                       // 16-byte loads legal for A / B (alignment, leading dimension and extents % 4)
   // patch-embed (AMODE == 2)
   const int* frame_map;
   int Cin, H, W, P, gw, n_patch;
   const float* pos;  // [(n_patch+1)][N]
 };
 
-constexpr int BK = 16;
-
-template <int WM, int WN, int AMODE, int BMODE>
+template <int WM, int WN, int AMODE, int BMODE, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
-  constexpr int LDA = BM + 4, LDB = BN + 4;
-  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (LDA + LDB)];
+  // TT_KLAYOUT selects the [row][k] image (b128 reads) for k-contiguous sources.  Measured on MI355X (tools/ab_gemm.py):
+  // it needs 41 KB of LDS per workgroup against 33.8 KB for the k-major image and loses one resident workgroup per
+  // CU, which costs more (qkv 105 -> 90 TFLOP/s) than the 4x fewer LDS instructions buy; the default is off.
+#ifdef TT_KLAYOUT
+  constexpr bool AK = (AMODE != 1), BKL = (BMODE == 0);
+#else
+  constexpr bool AK = false, BKL = false;
+#endif
+  constexpr int LDA = AK ? BK + 4 : BM + 4, LDB = BKL ? BK + 4 : BN + 4;
+  constexpr int ASZ = AK ? BM * LDA : BK * LDA, BSZ = BKL ? BN * LDB : BK * LDB;
+  constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;  // float4 per thread per slab
+  __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
   float* As = lds;
-  float* Bs = lds + 2 * BK * LDA;
+  float* Bs = lds + 2 * ASZ;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -63,25 +79,45 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
   const float* __restrict__ A = g.A + (long long)blockIdx.y * g.strideA;
   const float* __restrict__ B = g.B + (long long)blockIdx.y * g.strideB;
-  float* __restrict__ C = g.C + (long long)blockIdx.y * g.strideC;
+  float* __restrict__ C = g.C + (long long)blockIdx.y * g.strideC + (long long)blockIdx.z * g.strideS;
+  const int kbeg = blockIdx.z * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
 
-  float4 ra[WM], rb[WN];
+  float4 ra[NA], rb[NB];
 
   auto load_a = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int u = tid + 256 * i;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (AMODE == 1) {  // stored [K][lda], m contiguous
         const int kr = u / (BM / 4), mc = (u % (BM / 4)) * 4;
         const int k = k0 + kr, m = m0 + mc;
-        if (k < g.K && m < g.M) v = *reinterpret_cast<const float4*>(A + (long long)k * g.lda + m);
+        if (k < kend && m < g.M) {
+          const float* p = A + (long long)k * g.lda + m;
+          if (g.vecA) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {  // leading dimension / extent not a multiple of 4: element loads with per-element bounds
+            v.x = p[0];
+            if (m + 1 < g.M) v.y = p[1];
+            if (m + 2 < g.M) v.z = p[2];
+            if (m + 3 < g.M) v.w = p[3];
+          }
+        }
       } else {
-        const int row = u >> 2, kc = (u & 3) * 4;
+        const int row = u / (BK / 4), kc = (u % (BK / 4)) * 4;
         const int m = m0 + row, k = k0 + kc;
-        if (m < g.M && k < g.K) {
+        if (m < g.M && k < kend) {
           if (AMODE == 0) {
-            v = *reinterpret_cast<const float4*>(A + (long long)m * g.lda + k);
+            const float* p = A + (long long)m * g.lda + k;
+            if (g.vecA) {
+              v = *reinterpret_cast<const float4*>(p);
+            } else {
+              v.x = p[0];
+              if (k + 1 < kend) v.y = p[1];
+              if (k + 2 < kend) v.z = p[2];
+              if (k + 3 < kend) v.w = p[3];
+            }
           } else {  // patch gather: row = (frame, py, px), k = (c, i, j)
             const int f = m / g.n_patch, pi = m - f * g.n_patch;
             const int py = pi / g.gw, px = pi - py * g.gw;
@@ -99,52 +135,80 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   };
   auto load_b = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < WN; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const int u = tid + 256 * i;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (BMODE == 1) {  // stored [K][ldb], n contiguous
         const int kr = u / (BN / 4), nc = (u % (BN / 4)) * 4;
         const int k = k0 + kr, n = n0 + nc;
-        if (k < g.K && n < g.N) v = *reinterpret_cast<const float4*>(B + (long long)k * g.ldb + n);
+        if (k < kend && n < g.N) {
+          const float* p = B + (long long)k * g.ldb + n;
+          if (g.vecB) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (n + 1 < g.N) v.y = p[1];
+            if (n + 2 < g.N) v.z = p[2];
+            if (n + 3 < g.N) v.w = p[3];
+          }
+        }
       } else {  // stored [N][ldb], k contiguous
-        const int row = u >> 2, kc = (u & 3) * 4;
+        const int row = u / (BK / 4), kc = (u % (BK / 4)) * 4;
         const int n = n0 + row, k = k0 + kc;
-        if (n < g.N && k < g.K) v = *reinterpret_cast<const float4*>(B + (long long)n * g.ldb + k);
+        if (n < g.N && k < kend) {
+          const float* p = B + (long long)n * g.ldb + k;
+          if (g.vecB) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (k + 1 < kend) v.y = p[1];
+            if (k + 2 < kend) v.z = p[2];
+            if (k + 3 < kend) v.w = p[3];
+          }
+        }
       }
       rb[i] = v;
     }
   };
   auto store_a = [&](int buf) {
-    float* dst = As + buf * BK * LDA;
+    float* dst = As + buf * ASZ;
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int u = tid + 256 * i;
       if (AMODE == 1) {
         const int kr = u / (BM / 4), mc = (u % (BM / 4)) * 4;
         *reinterpret_cast<float4*>(dst + kr * LDA + mc) = ra[i];
       } else {
-        const int row = u >> 2, kc = (u & 3) * 4;
-        dst[(kc + 0) * LDA + row] = ra[i].x;
-        dst[(kc + 1) * LDA + row] = ra[i].y;
-        dst[(kc + 2) * LDA + row] = ra[i].z;
-        dst[(kc + 3) * LDA + row] = ra[i].w;
+        const int row = u / (BK / 4), kc = (u % (BK / 4)) * 4;
+        if (AK) {
+          *reinterpret_cast<float4*>(dst + row * LDA + kc) = ra[i];
+        } else {  // transpose into the k-major image
+          dst[(kc + 0) * LDA + row] = ra[i].x;
+          dst[(kc + 1) * LDA + row] = ra[i].y;
+          dst[(kc + 2) * LDA + row] = ra[i].z;
+          dst[(kc + 3) * LDA + row] = ra[i].w;
+        }
       }
     }
   };
   auto store_b = [&](int buf) {
-    float* dst = Bs + buf * BK * LDB;
+    float* dst = Bs + buf * BSZ;
 #pragma unroll
-    for (int i = 0; i < WN; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const int u = tid + 256 * i;
       if (BMODE == 1) {
         const int kr = u / (BN / 4), nc = (u % (BN / 4)) * 4;
         *reinterpret_cast<float4*>(dst + kr * LDB + nc) = rb[i];
       } else {
-        const int row = u >> 2, kc = (u & 3) * 4;
-        dst[(kc + 0) * LDB + row] = rb[i].x;
-        dst[(kc + 1) * LDB + row] = rb[i].y;
-        dst[(kc + 2) * LDB + row] = rb[i].z;
-        dst[(kc + 3) * LDB + row] = rb[i].w;
+        const int row = u / (BK / 4), kc = (u % (BK / 4)) * 4;
+        if (BKL) {
+          *reinterpret_cast<float4*>(dst + row * LDB + kc) = rb[i];
+        } else {
+          dst[(kc + 0) * LDB + row] = rb[i].x;
+          dst[(kc + 1) * LDB + row] = rb[i].y;
+          dst[(kc + 2) * LDB + row] = rb[i].z;
+          dst[(kc + 3) * LDB + row] = rb[i].w;
+        }
       }
     }
   };
@@ -157,32 +221,52 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = (g.K + BK - 1) / BK;
-  load_a(0);
-  load_b(0);
-  store_a(0);
-  store_b(0);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    load_a(kbeg);
+    load_b(kbeg);
+    store_a(0);
+    store_b(0);
+  }
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) {
-      load_a((kt + 1) * BK);
-      load_b((kt + 1) * BK);
+      load_a(kbeg + (kt + 1) * BK);
+      load_b(kbeg + (kt + 1) * BK);
     }
-    const float* pa = As + buf * BK * LDA + h * LDA + wm * (32 * WM) + r;
-    const float* pb = Bs + buf * BK * LDB + h * LDB + wn * (32 * WN) + r;
+    const float* pa = As + buf * ASZ + (AK ? (wm * (32 * WM) + r) * LDA + 4 * h : (4 * h) * LDA + wm * (32 * WM) + r);
+    const float* pb = Bs + buf * BSZ + (BKL ? (wn * (32 * WN) + r) * LDB + 4 * h : (4 * h) * LDB + wn * (32 * WN) + r);
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[WM], b[WN];
+    for (int j = 0; j < BK / 8; ++j) {
+      float a[WM][4], b[WN][4];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = pa[kk * 2 * LDA + i * 32];
+      for (int i = 0; i < WM; ++i) {
+        if (AK) {
+          const float4 v = *reinterpret_cast<const float4*>(pa + i * 32 * LDA + 8 * j);
+          a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+        } else {
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = pb[kk * 2 * LDB + j * 32];
+          for (int q = 0; q < 4; ++q) a[i][q] = pa[(8 * j + q) * LDA + i * 32];
+        }
+      }
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+      for (int n = 0; n < WN; ++n) {
+        if (BKL) {
+          const float4 v = *reinterpret_cast<const float4*>(pb + n * 32 * LDB + 8 * j);
+          b[n][0] = v.x; b[n][1] = v.y; b[n][2] = v.z; b[n][3] = v.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int q = 0; q < 4; ++q) b[n][q] = pb[(8 * j + q) * LDB + n * 32];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[n][q], acc[i][n], 0, 0, 0);
     }
     if (kt + 1 < nk) {
       store_a(buf ^ 1);
@@ -223,19 +307,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
-template <int WM, int WN, int AMODE, int BMODE>
-static int launch_cfg(const GemmArgs& g, int batch, hipStream_t s) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
-  const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-  dim3 grid(ntm * ntn, batch, 1);
-  hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, AMODE, BMODE>), grid, dim3(256), 0, s, g);
-  TT_CHECK_LAUNCH("gemm_f32");
-  return TT_OK;
+// out[i] = sum_s partial[s][i] (fixed order), 16 B per lane
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, long long n,
+                                                            int splits, long long stride) {
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long long step = (long long)gridDim.x * 256 * 4;
+  for (; i < n; i += step) {
+    float4 s = *reinterpret_cast<const float4*>(partial + i);
+    for (int z = 1; z < splits; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + z * stride + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = s;
+  }
 }
 
-// Tile choice: the matrix pipe is the bound, so what matters is how evenly the tiles fill 256 CUs.
-// cost(cfg) = ceil(tiles / 256) * tile_area (makespan in MFMA work per CU); small penalty for small tiles
-// (more LDS traffic and epilogue per flop).
 int gemm_tile_choice(int M, int N, int batch) {
   struct Cfg { int wm, wn; double pen; };
   const Cfg cfgs[4] = {{2, 2, 1.00}, {1, 2, 1.04}, {2, 1, 1.04}, {1, 1, 1.10}};
@@ -250,10 +336,24 @@ int gemm_tile_choice(int M, int N, int batch) {
   return best;
 }
 
+#ifndef TT_BK
+#define TT_BK 16
+#endif
+constexpr int kBK = TT_BK;
+
+template <int WM, int WN, int AMODE, int BMODE>
+static int launch_cfg(const GemmArgs& g, int batch, hipStream_t s) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+  dim3 grid(ntm * ntn, batch, g.splits);
+  hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, AMODE, BMODE, kBK>), grid, dim3(256), 0, s, g);
+  TT_CHECK_LAUNCH("gemm_f32");
+  return TT_OK;
+}
+
 template <int AMODE, int BMODE>
-static int launch_mode(const GemmArgs& g, int batch, hipStream_t s) {
-  const int best = gemm_tile_choice(g.M, g.N, batch);
-  switch (best) {
+static int launch_mode(const GemmArgs& g, int batch, int tile, hipStream_t s) {
+  switch (tile) {
     case 0: return launch_cfg<2, 2, AMODE, BMODE>(g, batch, s);
     case 1: return launch_cfg<1, 2, AMODE, BMODE>(g, batch, s);
     case 2: return launch_cfg<2, 1, AMODE, BMODE>(g, batch, s);
@@ -261,35 +361,67 @@ static int launch_mode(const GemmArgs& g, int batch, hipStream_t s) {
   }
 }
 
-int launch_gemm(const GemmArgs& g, int amode, int bmode, int batch, hipStream_t s) {
+// Split-K plan for a product whose output is too small to fill the chip: returns the number of K slices (1 = none).
+int gemm_splitk_choice(int M, int N, int K, int* tile_out) {
+  const int tile = gemm_tile_choice(M, N, 1);
+  const int bm = (tile == 0 || tile == 2) ? 128 : 64, bn = (tile == 0 || tile == 1) ? 128 : 64;
+  const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  if (tile_out) *tile_out = tile;
+  if (tiles >= 384 || K < 1024) return 1;
+  int s = (int)((768 + tiles - 1) / tiles);          // aim at >= 3 workgroups per CU
+  const int smax = K / 256;                          // keep >= 256 of K per slice
+  if (s > smax) s = smax;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : s;
+}
+
+int launch_gemm(const GemmArgs& g_in, int amode, int bmode, int batch, hipStream_t s) {
+  GemmArgs g = g_in;
   TT_REQUIRE(g.A && g.B && g.C, "gemm: null operand");
   TT_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && batch > 0, "gemm: bad shape M=%d N=%d K=%d batch=%d", g.M, g.N, g.K, batch);
-  TT_REQUIRE(aligned16(g.A) && aligned16(g.B), "gemm: operands must be 16-byte aligned");
-  if (amode == 1) TT_REQUIRE(g.lda % 4 == 0 && g.M % 4 == 0, "gemm: m-major A needs lda, M multiples of 4");
-  else if (amode == 0) TT_REQUIRE(g.lda % 4 == 0 && g.K % 4 == 0, "gemm: k-major A needs lda, K multiples of 4");
-  else TT_REQUIRE(g.P % 4 == 0 && g.W % 4 == 0, "gemm: patch size and image width must be multiples of 4");
-  if (bmode == 1) TT_REQUIRE(g.ldb % 4 == 0 && g.N % 4 == 0, "gemm: n-major B needs ldb, N multiples of 4");
-  else TT_REQUIRE(g.ldb % 4 == 0 && g.K % 4 == 0, "gemm: k-major B needs ldb, K multiples of 4");
-  TT_REQUIRE(batch == 1 || ((g.strideA % 4 == 0) && (g.strideB % 4 == 0)), "gemm: batch strides must be multiples of 4");
-  if (amode == 0 && bmode == 0) return launch_mode<0, 0>(g, batch, s);
-  if (amode == 0 && bmode == 1) return launch_mode<0, 1>(g, batch, s);
-  if (amode == 1 && bmode == 1) return launch_mode<1, 1>(g, batch, s);
-  if (amode == 1 && bmode == 0) return launch_mode<1, 0>(g, batch, s);
-  if (amode == 2 && bmode == 0) return launch_mode<2, 0>(g, batch, s);
+  if (amode == 2) TT_REQUIRE(g.P % 4 == 0 && g.W % 4 == 0 && aligned16(g.A), "gemm: patch size and image width must be multiples of 4");
+  if (g.splits <= 1) {
+    g.splits = 1;
+    g.kchunk = g.K;
+    g.strideS = 0;
+  }
+  // 16-byte loads need an aligned base, a leading dimension that keeps rows aligned, and whole float4s inside the
+  // extent along the contiguous axis; otherwise (e.g. 50 prototypes) the kernel falls back to element loads
+  const bool batch_ok = batch == 1 || ((g.strideA % 4 == 0) && (g.strideB % 4 == 0));
+  const int kq = (g.K % 4 == 0) && (g.kchunk % 4 == 0);
+  g.vecA = aligned16(g.A) && batch_ok && g.lda % 4 == 0 && (amode == 1 ? g.M % 4 == 0 : kq);
+  g.vecB = aligned16(g.B) && batch_ok && g.ldb % 4 == 0 && (bmode == 1 ? g.N % 4 == 0 : kq);
+  if (amode == 2) g.vecA = 1;
+  const int tile = gemm_tile_choice(g.M, g.N, batch * g.splits);
+  if (amode == 0 && bmode == 0) return launch_mode<0, 0>(g, batch, tile, s);
+  if (amode == 0 && bmode == 1) return launch_mode<0, 1>(g, batch, tile, s);
+  if (amode == 1 && bmode == 1) return launch_mode<1, 1>(g, batch, tile, s);
+  if (amode == 1 && bmode == 0) return launch_mode<1, 0>(g, batch, tile, s);
+  if (amode == 2 && bmode == 0) return launch_mode<2, 0>(g, batch, tile, s);
   set_error("gemm: unsupported operand layout (%d, %d)", amode, bmode);
   return TT_EUNSUPPORTED;
 }
-
-}  // namespace tt
-
-using tt::GemmArgs;
 
 static GemmArgs base_args(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc) {
   GemmArgs g{};
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.alpha = 1.f;
+  g.splits = 1;
   return g;
 }
+
+// plain (optionally batched) NT product used by other translation units (label propagation)
+int launch_gemm_plain(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int batch,
+                      long long sA, long long sB, long long sC, hipStream_t s) {
+  GemmArgs g = base_args(A, B, C, M, N, K, lda, ldb, ldc);
+  g.strideA = sA; g.strideB = sB; g.strideC = sC;
+  return launch_gemm(g, 0, 0, batch, s);
+}
+
+}  // namespace tt
+
+using tt::GemmArgs;
+using tt::base_args;
 
 extern "C" int tt_gemm_tile_choice(int M, int N, int batch) { return tt::gemm_tile_choice(M, N, batch); }
 
@@ -317,12 +449,39 @@ extern "C" int tt_linear_bwd_data(const float* dy, const float* w, const float* 
   return tt::launch_gemm(g, 0, 1, 1, tt::as_stream(stream));
 }
 
+extern "C" size_t tt_linear_bwd_weight_workspace_bytes(int M, int N, int K) {
+  const int s = (((long long)N * K) % 4 == 0) ? tt::gemm_splitk_choice(N, K, M, nullptr) : 1;
+  const size_t split = s > 1 ? (size_t)s * N * K * sizeof(float) : 0;
+  const size_t cs = tt_colsum_workspace_bytes(M, N);
+  return split > cs ? split : cs;
+}
+
 extern "C" int tt_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
                                     void* workspace, size_t workspace_bytes, tt_stream_t stream) {
   // dw[N,K] = dy[M,N]^T @ x[M,K]: reduction over M; both operands are stored [M_red][*].
   GemmArgs g = base_args(dy, x, dw, N, K, M, N, K, K);
-  int rc = tt::launch_gemm(g, 1, 1, 1, tt::as_stream(stream));
-  if (rc != TT_OK || !db) return rc;
+  const int s = (((long long)N * K) % 4 == 0) ? tt::gemm_splitk_choice(N, K, M, nullptr) : 1;
+  int rc;
+  if (s > 1) {
+    TT_REQUIRE(workspace && workspace_bytes >= (size_t)s * N * K * sizeof(float), "linear_bwd_weight: workspace too small for split-K");
+    g.C = static_cast<float*>(workspace);
+    g.splits = s;
+    g.kchunk = ((M + s - 1) / s + tt::kBK - 1) / tt::kBK * tt::kBK;
+    g.strideS = (long long)N * K;
+    rc = tt::launch_gemm(g, 1, 1, 1, tt::as_stream(stream));
+    if (rc != TT_OK) return rc;
+    const long long n = (long long)N * K;
+    TT_REQUIRE(n % 4 == 0, "linear_bwd_weight: N*K must be a multiple of 4");
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(tt::splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, tt::as_stream(stream),
+                       static_cast<const float*>(workspace), dw, n, s, (long long)N * K);
+    TT_CHECK_LAUNCH("splitk_reduce");
+  } else {
+    rc = tt::launch_gemm(g, 1, 1, 1, tt::as_stream(stream));
+    if (rc != TT_OK) return rc;
+  }
+  if (!db) return TT_OK;
   return tt_colsum(dy, db, M, N, workspace, workspace_bytes, stream);
 }
 
@@ -334,13 +493,3 @@ extern "C" int tt_patch_embed_gemm(const float* img, const int32_t* frame_map, c
   g.bias = bias; g.frame_map = frame_map; g.Cin = C; g.H = H; g.W = W; g.P = P; g.gw = gw; g.n_patch = n; g.pos = pos;
   return tt::launch_gemm(g, 2, 0, 1, tt::as_stream(stream));
 }
-
-namespace tt {
-// plain (optionally batched) NT product used by other translation units (label propagation)
-int launch_gemm_plain(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int batch,
-                      long long sA, long long sB, long long sC, hipStream_t s) {
-  GemmArgs g = base_args(A, B, C, M, N, K, lda, ldb, ldc);
-  g.strideA = sA; g.strideB = sB; g.strideC = sC;
-  return launch_gemm(g, 0, 0, batch, s);
-}
-}  // namespace tt

@@ -137,11 +137,18 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ a
 }
 __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ partial, float* __restrict__ out, int chunks,
                                                      int N, int pstride, int poff) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  // 64 columns per workgroup; the 4 waves split the chunks (fixed assignment and order: deterministic)
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += partial[(long long)c * pstride + poff + n];
-  out[n] = s;
+  if (n < N) {
+#pragma unroll 8
+    for (int c = w; c < chunks; c += 4) s += partial[(long long)c * pstride + poff + n];
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && n < N) out[n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 static int colsum_chunks(int M) {
@@ -305,8 +312,8 @@ extern "C" int tt_layernorm_bwd(const float* dy, const float* x, const float* ga
                      D, rpw, add_to_dx, skip_group);
   TT_CHECK_LAUNCH("layernorm_bwd");
   if (want) {
-    hipLaunchKernelGGL(colsum_stage2, dim3((D + 255) / 256), dim3(256), 0, as_stream(stream), partial, dgamma, wgs, D, 2 * D, 0);
-    hipLaunchKernelGGL(colsum_stage2, dim3((D + 255) / 256), dim3(256), 0, as_stream(stream), partial, dbeta, wgs, D, 2 * D, D);
+    hipLaunchKernelGGL(colsum_stage2, dim3((D + 63) / 64), dim3(256), 0, as_stream(stream), partial, dgamma, wgs, D, 2 * D, 0);
+    hipLaunchKernelGGL(colsum_stage2, dim3((D + 63) / 64), dim3(256), 0, as_stream(stream), partial, dbeta, wgs, D, 2 * D, D);
     TT_CHECK_LAUNCH("layernorm_bwd.reduce");
   }
   return TT_OK;
@@ -321,7 +328,7 @@ extern "C" int tt_colsum(const float* a, float* out, int M, int N, void* workspa
   const int rpc = (M + chunks - 1) / chunks;
   float* partial = static_cast<float*>(workspace);
   hipLaunchKernelGGL(colsum_stage1, dim3((N + 63) / 64, chunks), dim3(256), 0, as_stream(stream), a, partial, M, N, N, rpc);
-  hipLaunchKernelGGL(colsum_stage2, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), partial, out, chunks, N, N, 0);
+  hipLaunchKernelGGL(colsum_stage2, dim3((N + 63) / 64), dim3(256), 0, as_stream(stream), partial, out, chunks, N, N, 0);
   TT_CHECK_LAUNCH("colsum");
   return TT_OK;
 }

@@ -9,32 +9,53 @@
 // so E is written once and then only READ (one pass per iteration: the column step of iteration i and the
 // row sums of iteration i+1 share a sweep), no transposes, no in-place N x K rewrites.  The initial
 // Q /= sum(Q) cancels in the first row step and is not computed.  E stays [B][K] (a row = one patch's K
-// scores = one coalesced wave read); a workgroup owns a run of rows, keeps its per-prototype partial sums in
-// registers and publishes partial[wg][k]; the next launch folds the partials in a fixed order
-// (deterministic, no atomics).  Kernel boundaries (~1.5 us) are cheaper than a grid barrier (~4-7 us) on
-// this chip, so each iteration is its own launch.
+// scores = one coalesced wave read).
+//
+// The problem is small (5 MB at C2, L2 / Infinity-Cache resident) and each pass ends in a K-vector reduction,
+// so it is latency-bound, not bandwidth-bound: a few FAT workgroups (1024 threads = 16 waves, one row per wave
+// per step, two rows in flight) keep every pass short and the cross-workgroup fold tiny.  A workgroup owns a run
+// of rows, keeps its per-prototype partial sums in registers and publishes partial[wg][k]; the next launch folds
+// the partials in a fixed order (deterministic, no atomics).  Kernel boundaries (~1.5 us) are cheaper than a grid
+// barrier (~4-7 us) on this chip, so each iteration is its own launch.
 #include "common.hpp"
 
 namespace tt {
 
-constexpr int SK_KPL = 8;     // K <= 512
-constexpr int SK_MAXWG = 128;
+constexpr int SK_KPL = 8;      // K <= 512
+constexpr int SK_MAXWG = 64;
+constexpr int SK_THREADS = 1024;
+constexpr int SK_WAVES = SK_THREADS / 64;
 
 static int sk_wgs(int B) {
-  int w = (B + 15) / 16;  // >= 16 rows per workgroup
+  int w = (B + 2 * SK_WAVES - 1) / (2 * SK_WAVES);  // >= 2 rows per wave
   return w > SK_MAXWG ? SK_MAXWG : (w < 1 ? 1 : w);
 }
 
+// block-wide fold of per-wave register partials acc[SK_KPL] (lane owns k = lane + 64 i) into out[k]
+__device__ __forceinline__ void fold_waves(const float (&acc)[SK_KPL], float (*red)[64 * SK_KPL], float* __restrict__ out, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < SK_KPL; ++i)
+    if (lane + 64 * i < K) red[wave][lane + 64 * i] = acc[i];
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += SK_THREADS) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) s += red[w][k];
+    out[k] = s;
+  }
+}
+
 // E = exp(scores/eps); partial[wg][k] = sum over this workgroup's rows of E[b][k]
-__global__ __launch_bounds__(256) void sk_init_kernel(const float* __restrict__ scores, float* __restrict__ E,
-                                                      float* __restrict__ partial, int B, int K, float eps, int rows_per_wg) {
-  __shared__ float red[4][64 * SK_KPL];
+__global__ __launch_bounds__(SK_THREADS) void sk_init_kernel(const float* __restrict__ scores, float* __restrict__ E,
+                                                             float* __restrict__ partial, int B, int K, float eps, int rows_per_wg) {
+  __shared__ float red[SK_WAVES][64 * SK_KPL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_wg, r1 = min(B, r0 + rows_per_wg);
   float acc[SK_KPL];
 #pragma unroll
   for (int i = 0; i < SK_KPL; ++i) acc[i] = 0.f;
-  for (int b = r0 + wave; b < r1; b += 4) {
+  for (int b = r0 + wave; b < r1; b += SK_WAVES) {
 #pragma unroll
     for (int i = 0; i < SK_KPL; ++i) {
       const int k = lane + 64 * i;
@@ -45,26 +66,23 @@ __global__ __launch_bounds__(256) void sk_init_kernel(const float* __restrict__ 
       }
     }
   }
-#pragma unroll
-  for (int i = 0; i < SK_KPL; ++i) red[wave][lane + 64 * i] = acc[i];
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += 256)
-    partial[(long long)blockIdx.x * K + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+  fold_waves(acc, red, partial + (long long)blockIdx.x * K, K);
 }
 
 // One Sinkhorn iteration (row step + column step) or, with LAST, the final column normalisation + output.
 template <bool LAST>
-__global__ __launch_bounds__(256) void sk_iter_kernel(const float* __restrict__ E, const float* __restrict__ partial_in,
-                                                      float* __restrict__ partial_out, float* __restrict__ q_out, int B, int K,
-                                                      int nwg_in, int rows_per_wg, int row0, int rows_out, int uniform_a) {
+__global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __restrict__ E, const float* __restrict__ partial_in,
+                                                             float* __restrict__ partial_out, float* __restrict__ q_out, int B, int K,
+                                                             int nwg_in, int rows_per_wg, int row0, int rows_out, int uniform_a) {
   __shared__ float a_s[64 * SK_KPL];
-  __shared__ float red[4][64 * SK_KPL];
+  __shared__ float red[SK_WAVES][64 * SK_KPL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // row step: a_k = (1/K) / u_k, u_k folded from the previous launch's partial sums in fixed order
-  for (int k = threadIdx.x; k < K; k += 256) {
+  for (int k = threadIdx.x; k < K; k += SK_THREADS) {
     float a = 1.0f;
     if (!uniform_a) {
       float u = 0.f;
+#pragma unroll 16
       for (int w = 0; w < nwg_in; ++w) u += partial_in[(long long)w * K + k];
       a = (1.0f / (float)K) / u;
     }
@@ -87,34 +105,40 @@ __global__ __launch_bounds__(256) void sk_iter_kernel(const float* __restrict__ 
     r1 = min(B, r0 + rows_per_wg);
   }
   const float c = 1.0f / (float)B;
-  for (int b = r0 + wave; b < r1; b += 4) {
-    float e[SK_KPL];
-    float t = 0.f;
+  // two rows per wave in flight: their loads overlap each other's reduction latency
+  for (int b = r0 + wave; b < r1; b += 2 * SK_WAVES) {
+    const int b2 = b + SK_WAVES;
+    const bool has2 = b2 < r1;
+    float e[SK_KPL], f[SK_KPL];
+    float t = 0.f, t2 = 0.f;
 #pragma unroll
     for (int i = 0; i < SK_KPL; ++i) {
       const int k = lane + 64 * i;
       e[i] = (k < K) ? E[(long long)b * K + k] : 0.f;
+      f[i] = (k < K && has2) ? E[(long long)b2 * K + k] : 0.f;
       t += a[i] * e[i];
+      t2 += a[i] * f[i];
     }
     t = wave_sum(t);
+    t2 = wave_sum(t2);
     if (LAST) {
 #pragma unroll
       for (int i = 0; i < SK_KPL; ++i) {
         const int k = lane + 64 * i;
-        if (k < K) q_out[(long long)(b - row0) * K + k] = a[i] * e[i] / t;
+        if (k < K) {
+          q_out[(long long)(b - row0) * K + k] = a[i] * e[i] / t;
+          if (has2) q_out[(long long)(b2 - row0) * K + k] = a[i] * f[i] / t2;
+        }
       }
     } else {
-      const float bb = c / t;  // column step
+      const float bb = c / t;                 // column step
+      const float bb2 = has2 ? c / t2 : 0.f;
 #pragma unroll
-      for (int i = 0; i < SK_KPL; ++i) acc[i] += e[i] * bb;
+      for (int i = 0; i < SK_KPL; ++i) acc[i] += e[i] * bb + f[i] * bb2;
     }
   }
   if (LAST) return;
-#pragma unroll
-  for (int i = 0; i < SK_KPL; ++i) red[wave][lane + 64 * i] = acc[i];
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += 256)
-    partial_out[(long long)blockIdx.x * K + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+  fold_waves(acc, red, partial_out + (long long)blockIdx.x * K, K);
 }
 
 // ---- cross entropy -----------------------------------------------------------------------------
@@ -184,18 +208,18 @@ extern "C" int tt_sinkhorn(const float* scores, float* q_out, int B_total, int K
   float* part[2] = {E + (size_t)B_total * K, E + (size_t)B_total * K + (size_t)SK_MAXWG * K};
   const int wgs = sk_wgs(B_total);
   const int rpw = (B_total + wgs - 1) / wgs;
-  hipLaunchKernelGGL(sk_init_kernel, dim3(wgs), dim3(256), 0, s, scores, E, part[0], B_total, K, eps, rpw);
+  hipLaunchKernelGGL(sk_init_kernel, dim3(wgs), dim3(SK_THREADS), 0, s, scores, E, part[0], B_total, K, eps, rpw);
   int cur = 0;
   for (int it = 0; it + 1 < iters; ++it) {  // iterations 1 .. iters-1 (each prepares the next row step)
-    hipLaunchKernelGGL((sk_iter_kernel<false>), dim3(wgs), dim3(256), 0, s, E, part[cur], part[cur ^ 1], (float*)nullptr, B_total, K,
-                       wgs, rpw, 0, 0, 0);
+    hipLaunchKernelGGL((sk_iter_kernel<false>), dim3(wgs), dim3(SK_THREADS), 0, s, E, part[cur], part[cur ^ 1], (float*)nullptr,
+                       B_total, K, wgs, rpw, 0, 0, 0);
     cur ^= 1;
   }
   // last iteration's row step + column normalisation, written straight to q for the requested rows
   const int owgs = sk_wgs(rows_out);
   const int orpw = (rows_out + owgs - 1) / owgs;
-  hipLaunchKernelGGL((sk_iter_kernel<true>), dim3(owgs), dim3(256), 0, s, E, part[cur], (float*)nullptr, q_out, B_total, K, wgs, orpw,
-                     row0, rows_out, iters == 0 ? 1 : 0);
+  hipLaunchKernelGGL((sk_iter_kernel<true>), dim3(owgs), dim3(SK_THREADS), 0, s, E, part[cur], (float*)nullptr, q_out, B_total, K, wgs,
+                     orpw, row0, rows_out, iters == 0 ? 1 : 0);
   TT_CHECK_LAUNCH("sinkhorn");
   return TT_OK;
 }

@@ -99,7 +99,7 @@ def linear_bwd_weight(dy, x, need_bias=True, dw_out=None, db_out=None):
     K = x.shape[1]
     dw = dw_out if dw_out is not None else torch.empty((N, K), dtype=f32, device=dy.device)
     db = (db_out if db_out is not None else torch.empty((N,), dtype=f32, device=dy.device)) if need_bias else None
-    nb = lib.tt_colsum_workspace_bytes(M, N)
+    nb = lib.tt_linear_bwd_weight_workspace_bytes(M, N, K)
     ws = _ws(nb, dy.device)
     if PROFILE is not None:  # time the GEMM alone: issue the bias column-sum as its own call
         e0 = _prof_begin()
