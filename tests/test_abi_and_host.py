@@ -1,0 +1,147 @@
+"""CPU-only checks: the C-ABI library builds for gfx950, loads, and exports every symbol the header declares; the host
+mirror of the reference interface (CLI, parameter groups, state_dict layout, schedules, queue bookkeeping) behaves as
+the reference does; and the product path refuses to run without the HIP library / a GPU (no silent fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from timetuning_amd import _lib, synth
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "timetuning_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    if not os.path.isfile(_lib.LIB_PATH):
+        _lib.build()
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/timetuning_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in timetuning_amd/_lib.py"
+    assert set(_lib.SIGNATURES) <= set(declared)
+    assert lib.tt_abi_version() == 1
+    # size queries are pure host functions and can be called without a GPU
+    assert lib.tt_sinkhorn_workspace_bytes(6272, 200) >= 6272 * 200 * 4
+    assert lib.tt_ce_workspace_bytes(100) == 400
+    assert lib.tt_gemm_tile_choice(25216, 1152, 1) in (0, 1, 2, 3)
+
+
+def test_no_cpu_fallback():
+    from timetuning_amd import hip_ops
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    with pytest.raises(_lib.HipLibraryError):
+        hip_ops.linear_fwd(torch.zeros(4, 4), torch.zeros(4, 4))
+    fe = FeatureExtractor("dino-s16", "", [128, 128, 64, 32], unfreeze_layers=["blocks.11", "blocks.10"], vit_cfg=synth.ARCHS["tiny-s16"])
+    model = TimeT(fe, 20)
+    with pytest.raises(_lib.HipLibraryError):
+        model(torch.zeros(1, 2, 3, 224, 224), None, True, False)
+    with pytest.raises(_lib.HipLibraryError):
+        fe(torch.zeros(1, 3, 224, 224))
+
+
+def test_oracle_is_not_imported_by_the_product():
+    import ast
+
+    pkg = os.path.join(REPO, "timetuning_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            tree = ast.parse(open(os.path.join(pkg, fn)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                assert not any(n.split(".")[0] == "oracle" for n in names), f"{fn} imports the oracle"
+
+
+def test_cli_surface_and_bool_quirk():
+    from timetuning_amd.time_tuning import build_parser
+
+    a = build_parser().parse_args([])
+    assert (a.architecture, a.num_clusters, a.num_frames, a.batch_size) == ("dino-s16", 200, 4, 128)
+    assert a.use_teacher is True and a.use_queue is False and a.use_projection_head is True and a.use_mask is False
+    assert (a.EMA_decay, a.queue_size, a.head_lr, a.lr_scheduler) == (0.995, 16384, 1e-4, "CosineAnnealingLR")
+    # type=bool: any non-empty string is True (time_tuning.py:701; README.md:58 passes "--use_queue False")
+    assert build_parser().parse_args(["--use_queue", "False"]).use_queue is True
+    b = build_parser().parse_args(["-g", "8", "-n", "1", "-nr", "0", "--num_clusters", "400", "--use_teacher", ""])
+    assert b.gpus == 8 and b.num_clusters == 400 and b.use_teacher is False
+
+
+def test_param_groups_and_state_dict_layout(golden):
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.my_utils import cosine_scheduler
+    from timetuning_amd.time_tuning import SwavOptimizer, TimeT
+
+    g = golden("timet_tiny_tq")
+    fe = FeatureExtractor("dino-s16", "", [int(v) for v in g["head_list"]], unfreeze_layers=["blocks.11", "blocks.10"],
+                          vit_cfg=synth.ARCHS["tiny-s16"], init="stress")
+    model = TimeT(fe, 20)
+    model.init_momentum_teacher()
+    model.init_queue(40)
+    assert set(model.state_dict().keys()) == {str(k) for k in g["state_dict_keys"]}  # queue is not a buffer (time_tuning.py:107)
+    opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, 1, 4), 4, 1)
+    assert [len(gr["params"]) for gr in opt.optimizer.param_groups] == list(g["group_sizes"]) == [1, 0, 4, 4, 8, 16]
+    assert [gr["lr"] for gr in opt.optimizer.param_groups] == [1e-4, 1e-4, 1e-4, 1e-4, 1e-5, 1e-5]
+    trainable = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    frozen = [n for n, p in model.feature_extractor.backbone.named_parameters() if not p.requires_grad]
+    assert "norm.weight" in frozen and "pos_embed" in frozen and "blocks.9.mlp.fc2.weight" in frozen
+    assert trainable == sum(p.numel() for gr in opt.optimizer.param_groups for p in gr["params"])
+    assert fe.trainable_block_ids() == [10, 11]
+    assert all(not p.requires_grad for p in model.teacher.parameters())
+
+
+def test_full_size_parameter_counts():
+    """5,700,096 trainable parameters in 33 tensors for dino-s16 + head + 200 prototypes."""
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    fe = FeatureExtractor("dino-s16", "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"])
+    model = TimeT(fe, 200)
+    tr = [p for p in model.parameters() if p.requires_grad]
+    assert len(tr) == 33 and sum(p.numel() for p in tr) == 5_700_096
+    assert fe.feature_dim == 256 and fe.spatial_resolution == 14
+    w = synth.make_vit_weights(mode="dino", **synth.ARCHS["dino-s16"])
+    assert np.array_equal(fe.backbone.blocks[3].attn.qkv.weight.detach().numpy(), w["blocks.3.attn.qkv.weight"])
+
+
+def test_queue_fullness_is_tracked_on_the_host():
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    fe = FeatureExtractor("dino-s16", "", [128, 128, 64, 32], vit_cfg=synth.ARCHS["tiny-s16"])
+    m = TimeT(fe, 20)
+    assert not m.queue_is_full()
+    m.init_queue(40)
+    assert m.queue.shape == (40, 32) and not m.queue_is_full()
+    m._queue_rows_pushed = 20
+    assert not m.queue_is_full()
+    m._queue_rows_pushed = 40
+    assert m.queue_is_full()
+
+
+def test_unknown_architecture_raises_clearly():
+    from timetuning_amd.models import FeatureExtractor
+
+    with pytest.raises(ValueError, match="unknown architecture"):
+        FeatureExtractor("resnet50", "")
+
+
+def test_schedules_match_reference(golden):
+    from timetuning_amd.my_utils import cosine_scheduler
+
+    g = golden("schedules")
+    np.testing.assert_allclose(cosine_scheduler(0.04, 0.4, 1, 4), g["wd_1_4"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(cosine_scheduler(0.995, 1.0, 2, 5), g["ema_2_5"], rtol=0, atol=1e-15)

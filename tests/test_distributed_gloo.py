@@ -1,0 +1,103 @@
+"""world_size-2 `gloo` tests (CPU) of the N>1 path: the global Sinkhorn all-gather, the flat gradient all-reduce and the
+data-parallel wrapper.  The collective logic is the product's (timetuning_amd.engine / models); where a HIP kernel would
+run, the CPU oracle is injected as the solver - exactly what the `solver=` hook is for."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_solver(scores, iters, eps, row0=0, rows_out=None):
+    from oracle import timet_oracle as O
+
+    q = O.sinkhorn(torch.exp(scores / eps).t(), iters)
+    rows_out = scores.shape[0] - row0 if rows_out is None else rows_out
+    return q[row0:row0 + rows_out]
+
+
+def _worker(rank, W, port, ret):
+    import sys
+
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from oracle import timet_oracle as O
+    from timetuning_amd import engine, synth
+    from timetuning_amd.models import DistributedDataParallelModel, FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    out = {}
+    # (1) global Sinkhorn: all-gather + redundant global solve == reference W=2 run == its all-reduce formulation
+    g = np.load(os.path.join(GOLDEN, "sinkhorn_w2.npz"))
+    scores = torch.from_numpy(g["scores"])
+    B = scores.shape[0] // W
+    local = scores[rank * B:(rank + 1) * B].contiguous()
+    q = engine.global_sinkhorn(local, B, 0.05, int(g["iters"]), solver=_oracle_solver)
+    out["q_err_vs_reference"] = float((q - torch.from_numpy(g["q"][rank * B:(rank + 1) * B])).abs().max())
+
+    def allreduce(t):
+        t = t.clone()
+        dist.all_reduce(t)
+        return t
+
+    q_r = O.sinkhorn(torch.exp(local / 0.05).t(), int(g["iters"]), world_size=W, all_reduce=allreduce)
+    out["q_err_vs_allreduce_form"] = float((q - q_r).abs().max())
+
+    # (2) flat gradient all-reduce == mean of the per-rank gradients
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(7, 5)), torch.nn.Parameter(torch.zeros(11)), torch.nn.Parameter(torch.zeros(3, 2, 2))]
+    grads = {p: torch.from_numpy(synth.normal(f"ddp.g{i}.r{rank}", tuple(p.shape))) for i, p in enumerate(params)}
+    expect = [sum(torch.from_numpy(synth.normal(f"ddp.g{i}.r{r}", tuple(p.shape))) for r in range(W)) / W for i, p in enumerate(params)]
+    red = engine.allreduce_mean_(dict(grads))
+    out["grad_err"] = max(float((red[p] - e).abs().max()) for p, e in zip(params, expect))
+
+    # (3) the wrapper broadcasts rank 0's parameters and passes attribute access through
+    cfg = synth.ARCHS["tiny-s16"]
+    fe = FeatureExtractor("dino-s16", "", [128, 128, 64, 32], unfreeze_layers=["blocks.11", "blocks.10"], vit_cfg=cfg, init="stress", seed=1 + rank)
+    model = TimeT(fe, 20, prototype_init=torch.from_numpy(synth.make_prototypes(20, 32, seed=1 + rank)))
+    ddp = DistributedDataParallelModel(model, 0)
+    ref = synth.make_prototypes(20, 32, seed=1)
+    out["bcast_err"] = float((ddp.prototypes.detach() - torch.from_numpy(ref)).abs().max())
+    w0 = synth.make_vit_weights(mode="stress", seed=1, **cfg)["blocks.11.mlp.fc2.weight"]
+    out["bcast_err_w"] = float((model.feature_extractor.backbone.blocks[11].mlp.fc2.weight.detach() - torch.from_numpy(w0)).abs().max())
+    ddp.init_queue(40)
+    out["passthrough"] = bool(ddp.queue.shape == (40, 32) and ddp.get_non_ddp_model() is model and ddp.data_parallel)
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world_size_2_gloo():
+    W = 2
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, W, port, ret)) for r in range(W)]
+    [p.start() for p in procs]
+    [p.join(240) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    for r in range(W):
+        o = ret[r]
+        assert o["q_err_vs_reference"] < 2e-6, o
+        assert o["q_err_vs_allreduce_form"] < 2e-6, o
+        assert o["grad_err"] < 1e-6, o
+        assert o["bcast_err"] == 0.0 and o["bcast_err_w"] == 0.0, o
+        assert o["passthrough"], o

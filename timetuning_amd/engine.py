@@ -168,16 +168,41 @@ def prototype_scores(z: torch.Tensor, prototypes: torch.Tensor, save: Optional[d
     return ops.linear_fwd(zn, prototypes)
 
 
-def global_sinkhorn(scores_local: torch.Tensor, rows_out: int, eps: float, iters: int) -> torch.Tensor:
+def global_sinkhorn(scores_local: torch.Tensor, rows_out: int, eps: float, iters: int, solver=None) -> torch.Tensor:
     """find_optimal_assignment (time_tuning.py:157-168) with the reference's cross-rank semantics
     (my_utils.py:250-272): ONE all-gather of the local score rows over RCCL, then every rank solves the global
-    K x (B_loc * W) problem and keeps the assignment of its own first ``rows_out`` rows."""
+    K x (B_loc * W) problem and keeps the assignment of its own first ``rows_out`` rows.  Equal to the reference's
+    1 + 1 + iters all-reduces; every rank must contribute the same number of rows, as there
+    (``c = 1 / (B * world_size)``, my_utils.py:257).
+
+    ``solver(scores, iters, eps, row0=, rows_out=)`` defaults to the HIP kernel; the CPU gloo tests inject the oracle
+    to exercise the collective logic without a GPU."""
     import torch.distributed as dist
 
+    solver = ops.sinkhorn if solver is None else solver
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         W, rank = dist.get_world_size(), dist.get_rank()
         B_loc = scores_local.shape[0]
         gathered = torch.empty((W * B_loc, scores_local.shape[1]), dtype=f32, device=scores_local.device)
         dist.all_gather_into_tensor(gathered, scores_local.contiguous())
-        return ops.sinkhorn(gathered, iters, eps, row0=rank * B_loc, rows_out=rows_out)
-    return ops.sinkhorn(scores_local, iters, eps, row0=0, rows_out=rows_out)
+        return solver(gathered, iters, eps, row0=rank * B_loc, rows_out=rows_out)
+    return solver(scores_local, iters, eps, row0=0, rows_out=rows_out)
+
+
+def allreduce_mean_(grads: Dict[torch.nn.Parameter, torch.Tensor]) -> Dict[torch.nn.Parameter, torch.Tensor]:
+    """The data-parallel gradient exchange (what DDP's bucketed all-reduce does in the reference, models.py:1295):
+    ONE flat all-reduce (SUM) over RCCL followed by the 1/W scale; the returned tensors are views into the flat
+    buffer.  No-op without an initialised process group."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return grads
+    keys = list(grads)
+    flat = torch.cat([grads[k].reshape(-1) for k in keys])
+    dist.all_reduce(flat)
+    flat /= dist.get_world_size()
+    off = 0
+    for k in keys:
+        grads[k] = flat[off:off + k.numel()].view(k.shape)
+        off += k.numel()
+    return grads

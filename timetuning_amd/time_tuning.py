@@ -307,17 +307,7 @@ class TimeT(nn.Module):
                 dx = engine.block_backward(dx, vit.blocks[i], vit.num_heads, save[i], f0, Fr, grads, need_dx=i > first)
         grads = {p: g for p, g in grads.items() if p.requires_grad}
 
-        d = _dist()
-        if d is not None:  # the data-parallel exchange: ONE flat all-reduce (mean) over RCCL
-            keys = list(grads)
-            flat = torch.cat([grads[k].reshape(-1) for k in keys])
-            d.all_reduce(flat)
-            flat /= d.get_world_size()
-            off = 0
-            for k in keys:
-                grads[k] = flat[off:off + k.numel()].view(k.shape)
-                off += k.numel()
-        return loss, grads
+        return loss, engine.allreduce_mean_(grads)  # the data-parallel exchange: ONE flat all-reduce (mean) over RCCL
 
 
 # ------------------------------------------------------------------------------------------------
