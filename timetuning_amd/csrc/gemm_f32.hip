@@ -423,6 +423,11 @@ int launch_gemm_plain(const float* A, const float* B, float* C, int M, int N, in
 using tt::GemmArgs;
 using tt::base_args;
 
+namespace tt {
+int try_launch_gemm_nt_fast(const float* A, const float* B, float* C, int M, int N, int K, const float* bias,
+                            const float* residual, float* pre_out, int act, hipStream_t s);
+}
+
 extern "C" int tt_gemm_tile_choice(int M, int N, int batch) { return tt::gemm_tile_choice(M, N, batch); }
 
 extern "C" int tt_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -436,6 +441,10 @@ extern "C" int tt_gemm_f32(const float* A, const float* B, float* C, int M, int 
 
 extern "C" int tt_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                              float* pre_act, int M, int N, int K, int act, tt_stream_t stream) {
+  if (x && w && y && M > 0 && N > 0 && K > 0) {  // whole-tile, aligned shapes take the lean kernel (gemm_nt_fast.hip)
+    const int rc = tt::try_launch_gemm_nt_fast(x, w, y, M, N, K, bias, residual, pre_act, act, tt::as_stream(stream));
+    if (rc <= 0) return rc;
+  }
   GemmArgs g = base_args(x, w, y, M, N, K, K, K, N);
   g.bias = bias; g.residual = residual; g.pre_out = pre_act; g.act = act;
   return tt::launch_gemm(g, 0, 0, 1, tt::as_stream(stream));

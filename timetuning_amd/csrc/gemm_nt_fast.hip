@@ -1,0 +1,177 @@
+// Lean instance of the f32-MFMA GEMM for the shapes that carry >90 % of a training step: every forward nn.Linear
+// (y = act(x @ w^T + b) (+ residual)) whose extents fill whole tiles (M % BM == 0, N % BN == 0, K % 16 == 0, 16-byte
+// aligned operands).  Same algorithm and LDS image as gemm_f32.hip (k-major double buffer, ds_read_b32 fragments,
+// v_mfma_f32_32x32x2_f32) but with everything the general kernel pays for stripped: no bounds checks, no layout
+// switches, row pointers advanced instead of recomputed, and - the part that matters - the tile leaves through the
+// idle LDS as 16-byte, fully coalesced row-major stores.  tools/mfma_peak.hip measures the inner loop at
+// 133 TFLOP/s, 105 with the natural 64-scalar-stores-per-lane epilogue (store-issue bound) and 121-125 with this one.
+#include "common.hpp"
+
+namespace tt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct FastArgs {
+  const float* A;   // [M][K]
+  const float* B;   // [N][K]
+  float* C;         // [M][N]
+  int M, N, K;
+  const float* bias;      // [N] or null
+  const float* residual;  // [M][N] or null (may alias C)
+  float* pre_out;         // [M][N] or null
+  int act;                // 1 = GELU
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, BK = 16;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  const int ntn = g.N / BN, ntm = g.M / BM;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const int K = g.K;
+
+  // staging: thread owns row (tid >> 2) + 64 i of each operand tile and the 4 k's at (tid & 3) * 4
+  const int srow = tid >> 2, skc = (tid & 3) * 4;
+  const float* pa = g.A + (size_t)(m0 + srow) * K + skc;
+  const float* pb = g.B + (size_t)(n0 + srow) * K + skc;
+  const size_t step64 = (size_t)64 * K;
+  float4 ra[WM], rb[WN];
+  auto gload = [&]() {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) ra[i] = *reinterpret_cast<const float4*>(pa + i * step64);
+#pragma unroll
+    for (int i = 0; i < WN; ++i) rb[i] = *reinterpret_cast<const float4*>(pb + i * step64);
+    pa += BK;
+    pb += BK;
+  };
+  auto sstore = [&](int buf) {
+    float* da = lds + buf * ASZ + skc * LDA + srow;
+    float* db = lds + 2 * ASZ + buf * BSZ + skc * LDB + srow;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      da[0 * LDA + 64 * i] = ra[i].x;
+      da[1 * LDA + 64 * i] = ra[i].y;
+      da[2 * LDA + 64 * i] = ra[i].z;
+      da[3 * LDA + 64 * i] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      db[0 * LDB + 64 * i] = rb[i].x;
+      db[1 * LDB + 64 * i] = rb[i].y;
+      db[2 * LDB + 64 * i] = rb[i].z;
+      db[3 * LDB + 64 * i] = rb[i].w;
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = K / BK;
+  gload();
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload();
+    const float* fa = lds + buf * ASZ + (4 * h) * LDA + wm * (32 * WM) + r;
+    const float* fb = lds + 2 * ASZ + buf * BSZ + (4 * h) * LDB + wn * (32 * WN) + r;
+#pragma unroll
+    for (int j = 0; j < BK / 8; ++j) {
+      float a[WM][4], b[WN][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[i][q] = fa[(8 * j + q) * LDA + i * 32];
+#pragma unroll
+        for (int n = 0; n < WN; ++n) b[n][q] = fb[(8 * j + q) * LDB + n * 32];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[n][q], acc[i][n], 0, 0, 0);
+    }
+    if (kt + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue through LDS: one wave-row (32 * WM tile rows) at a time
+  constexpr int CH = 32 * WM, LDCS = BN + 4, TPR = BN / 4, RPP = 256 / TPR;
+  static_assert(CH * LDCS <= 2 * (ASZ + BSZ), "epilogue staging must fit the pipeline buffers");
+  const int c4 = (tid % TPR) * 4;
+  const int n = n0 + c4;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + n);
+#pragma unroll
+  for (int wmi = 0; wmi < 2; ++wmi) {
+    if (wm == wmi) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            lds[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDCS + wn * (32 * WN) + j * 32 + r] = acc[i][j][e];
+    }
+    __syncthreads();
+    for (int rr = tid / TPR; rr < CH; rr += RPP) {
+      const size_t off = (size_t)(m0 + wmi * CH + rr) * g.N + n;
+      float4 v = *reinterpret_cast<const float4*>(lds + rr * LDCS + c4);
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      if (g.pre_out) *reinterpret_cast<float4*>(g.pre_out + off) = v;
+      if (g.act == 1) {
+        v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+      }
+      if (g.residual) {
+        const float4 rs = *reinterpret_cast<const float4*>(g.residual + off);
+        v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+      }
+      *reinterpret_cast<float4*>(g.C + off) = v;
+    }
+    __syncthreads();
+  }
+}
+
+template <int WM, int WN>
+static int launch_fast(const FastArgs& g, hipStream_t s) {
+  const int tiles = (g.M / (64 * WM)) * (g.N / (64 * WN));
+  hipLaunchKernelGGL((gemm_nt_fast_kernel<WM, WN>), dim3(tiles), dim3(256), 0, s, g);
+  TT_CHECK_LAUNCH("gemm_nt_fast");
+  return TT_OK;
+}
+
+int gemm_tile_choice(int M, int N, int batch);
+
+// Returns TT_OK if launched, 1 if the shape is not eligible (caller falls back to the general kernel).
+int try_launch_gemm_nt_fast(const float* A, const float* B, float* C, int M, int N, int K, const float* bias,
+                            const float* residual, float* pre_out, int act, hipStream_t s) {
+  auto ok16 = [](const void* p) { return p == nullptr || aligned16(p); };
+  if (K % 16 != 0 || K < 16 || !aligned16(A) || !aligned16(B) || !aligned16(C) || !ok16(bias) || !ok16(residual) || !ok16(pre_out)) return 1;
+  FastArgs g{A, B, C, M, N, K, bias, residual, pre_out, act};
+  const int tile = gemm_tile_choice(M, N, 1);
+  const int bm = (tile == 0 || tile == 2) ? 128 : 64, bn = (tile == 0 || tile == 1) ? 128 : 64;
+  if (M % bm != 0 || N % bn != 0) {
+    if (M % 64 == 0 && N % 64 == 0) return launch_fast<1, 1>(g, s);
+    return 1;
+  }
+  switch (tile) {
+    case 0: return launch_fast<2, 2>(g, s);
+    case 1: return launch_fast<1, 2>(g, s);
+    case 2: return launch_fast<2, 1>(g, s);
+    default: return launch_fast<1, 1>(g, s);
+  }
+}
+
+}  // namespace tt

@@ -1,0 +1,155 @@
+// Micro-benchmarks that build the f32 GEMM inner loop up from the bare MFMA rate (development aid).
+//   mode 0: MFMA only, 4 accumulators/wave
+//   mode 1: + LDS fragment reads (ds_read_b32 pattern of gemm_f32.hip) each k-group
+//   mode 2: + per-slab barrier
+//   mode 3: + per-slab LDS writes (transposing) from registers
+//   mode 4: + per-slab global loads (16 B/lane, k-contiguous rows like the NT GEMM) feeding those writes
+//   mode 5: + an epilogue (64 scalar stores per lane) and accumulator reset every 24 slabs (K = 384 tiles)
+//   mode 6: as 5 but the tile leaves through LDS as 16-byte row-major stores
+//   mode 7: as 6 but NOT persistent: one workgroup per tile (grid = tiles), 24 slabs each, exposed first-slab load
+// usage: mfma_peak <mode> <waves_per_simd (1..4)> [iters]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* out, int iters, const float* __restrict__ src, float* __restrict__ cbuf) {
+  __shared__ float lds[2 * 16 * (132 + 132)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  for (int i = tid; i < 2 * 16 * 264; i += 256) lds[i] = (float)(i % 7) * 0.01f;
+  __syncthreads();
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float a0 = lane * 0.001f, a1 = lane * 0.002f, b0 = 0.5f, b1 = 0.25f;
+  float4 st0 = make_float4(a0, a1, b0, b1), st1 = st0;
+  const float* ga = src + (size_t)(blockIdx.x % 197) * 128 * 384;
+  const float* gb = src + (size_t)(197 * 128 * 384) + (size_t)(blockIdx.x % 9) * 128 * 384;
+  for (int it = 0; it < iters; ++it) {
+    const int buf = it & 1;
+    if (MODE >= 4) {
+      const int k0 = (it % 24) * 16;
+      const int u = tid, row = u >> 2, kc = (u & 3) * 4;
+      st0 = *reinterpret_cast<const float4*>(ga + (size_t)row * 384 + k0 + kc);
+      st1 = *reinterpret_cast<const float4*>(gb + (size_t)row * 384 + k0 + kc);
+    }
+    const float* pa = lds + buf * 16 * 264 + (4 * h) * 132 + wm * 64 + r;
+    const float* pb = lds + buf * 16 * 264 + 16 * 132 + (4 * h) * 132 + wn * 64 + r;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float a[2][4], b[2][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (MODE >= 1) {
+          a[0][q] = pa[(8 * j + q) * 132];
+          a[1][q] = pa[(8 * j + q) * 132 + 32];
+          b[0][q] = pb[(8 * j + q) * 132];
+          b[1][q] = pb[(8 * j + q) * 132 + 32];
+        } else {
+          a[0][q] = a0; a[1][q] = a1; b[0][q] = b0; b[1][q] = b1;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[n][q], acc[i][n], 0, 0, 0);
+    }
+    if (MODE >= 3) {
+      float* dst = lds + (buf ^ 1) * 16 * 264;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int u = tid + 256 * i, row = u >> 2, kc = (u & 3) * 4;
+        dst[(kc + 0) * 132 + row] = st0.x; dst[(kc + 1) * 132 + row] = st0.y;
+        dst[(kc + 2) * 132 + row] = st0.z; dst[(kc + 3) * 132 + row] = st0.w;
+        dst[16 * 132 + (kc + 0) * 132 + row] = st1.x; dst[16 * 132 + (kc + 1) * 132 + row] = st1.y;
+        dst[16 * 132 + (kc + 2) * 132 + row] = st1.z; dst[16 * 132 + (kc + 3) * 132 + row] = st1.w;
+      }
+    }
+    if (MODE >= 2) __syncthreads();
+    if (MODE >= 6 && (it % 24) == 23) {
+      float* c = cbuf + (size_t)(blockIdx.x % 4096) * 128 * 128;
+#pragma unroll
+      for (int wmi = 0; wmi < 2; ++wmi) {
+        if (wm == wmi) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                lds[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 132 + wn * 64 + n * 32 + r] = acc[i][n][e];
+                acc[i][n][e] = 0.f;
+              }
+        }
+        __syncthreads();
+        const int c4 = (tid & 31) * 4;
+        for (int rr = tid >> 5; rr < 64; rr += 8) {
+          const float4 t = *reinterpret_cast<const float4*>(lds + rr * 132 + c4);
+          *reinterpret_cast<float4*>(c + (wmi * 64 + rr) * 128 + c4) = t;
+        }
+        __syncthreads();
+      }
+    } else if (MODE == 5 && (it % 24) == 23) {
+      float* c = cbuf + (size_t)(blockIdx.x % 4096) * 128 * 128;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            c[m * 128 + wn * 64 + n * 32 + r] = acc[i][n][e];
+            acc[i][n][e] = 0.f;
+          }
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+  out[blockIdx.x * 256 + tid] = s;
+}
+
+int main(int argc, char** argv) {
+  const int mode = argc > 1 ? atoi(argv[1]) : 0, wps = argc > 2 ? atoi(argv[2]) : 1;
+  int iters = argc > 3 ? atoi(argv[3]) : 2000;
+  const int blocks = (mode == 7) ? 256 * wps * (iters / 24) : 256 * wps;
+  if (mode == 7) iters = 24;
+  float* out;
+  float *src, *cbuf;
+  hipMalloc(&out, blocks * 256 * sizeof(float));
+  hipMalloc(&src, (size_t)(197 + 9) * 128 * 384 * sizeof(float));
+  hipMemset(src, 0, (size_t)(197 + 9) * 128 * 384 * sizeof(float));
+  hipMalloc(&cbuf, (size_t)(blocks > 4096 ? 4096 : blocks) * 128 * 128 * sizeof(float));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  auto launch = [&]() {
+    switch (mode) {
+      case 0: hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
+      case 1: hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
+      case 2: hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
+      case 3: hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
+      case 4: hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
+      case 5: hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
+      default: hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
+    }
+  };
+  launch();
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int i = 0; i < 5; ++i) launch();
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double flops = 5.0 * blocks * 4.0 * iters * 32.0 * 4096.0;
+  printf("mode %d waves/SIMD %d: %.1f TFLOP/s (%.3f ms per launch)\n", mode, wps, flops / (ms * 1e-3) / 1e12, ms / 5);
+  return 0;
+}
