@@ -114,17 +114,19 @@ def _attn_ref(qkv, H):
     return (p @ v).transpose(1, 2).reshape(Fr, N, D), lse, p
 
 
-@pytest.mark.parametrize("Fr,N,H", [(3, 197, 6), (2, 50, 2), (1, 256, 1), (2, 120, 3), (1, 17, 12)])
+@pytest.mark.parametrize("Fr,N,H", [(3, 197, 6), (2, 50, 2), (1, 256, 1), (2, 120, 3), (1, 17, 12), (2, 785, 6), (1, 300, 2)])
 def test_attention_fwd_bwd(ops, Fr, N, H):
+    """N <= 256: register-resident score rows; N > 256 (ViT-S/8: 785 tokens): the KV-tiled online-softmax kernel."""
     qkv = rnd("aq", Fr, N, 3 * H * 64) * 1.5
     do = rnd("ado", Fr, N, H * 64)
     qd = qkv.double().requires_grad_(True)
     ref, lse_ref, p_ref = _attn_ref(qd, H)
     ref.backward(do.double())
-    out, lse, probs = ops.attention_fwd(dev(qkv), H, save_lse=True, return_probs=True)
+    out, lse, probs = ops.attention_fwd(dev(qkv), H, save_lse=True, return_probs=N <= 256)
     assert rel_err(out.cpu(), ref.detach()) < TOL
     assert rel_err(lse.cpu(), lse_ref.detach()) < TOL
-    assert rel_err(probs.cpu(), p_ref.detach()) < TOL
+    if N <= 256:
+        assert rel_err(probs.cpu(), p_ref.detach()) < TOL
     dqkv = ops.attention_bwd(dev(qkv), out, dev(do), lse, H)
     assert rel_err(dqkv.cpu(), qd.grad) < 5e-5
 

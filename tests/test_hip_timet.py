@@ -160,3 +160,37 @@ def test_c2_size_properties():
     assert rel_err(mf.cpu(), of) < TOL
     g = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
     assert torch.isfinite(g).all() and g.abs().max() > 0
+
+
+@pytest.mark.parametrize("arch", ["dino-b16", "dino-s8"])
+def test_other_architectures_vs_oracle(arch):
+    """ViT-B/16 (D=768, 12 heads) and ViT-S/8 (785 tokens: KV-tiled attention, 28x28 propagation grid) against the oracle:
+    extractor outputs and one full loss + gradient."""
+    from oracle import timet_oracle as O
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    K, bs, fs = 40, 1, 2
+    fe = FeatureExtractor(arch, "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="stress", return_attention=False)
+    assert fe.spatial_resolution == (28 if arch == "dino-s8" else 14)
+    model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, 256))).cuda()
+    om = O.build_oracle(arch, K, (1024, 1024, 512, 256), mode="stress")
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=5))
+    with torch.no_grad():
+        of, _ = om.feature_extractor(x.view(bs * fs, 3, 224, 224), faithful=False)
+        obf, _ = om.feature_extractor(x.view(bs * fs, 3, 224, 224), use_head=False, faithful=False)
+    f, _ = model.feature_extractor(x.view(bs * fs, 3, 224, 224).cuda())
+    bf, _ = model.feature_extractor(x.view(bs * fs, 3, 224, 224).cuda(), use_head=False)
+    assert rel_err(f.cpu(), of) < TOL
+    assert rel_err(bf.cpu(), obf) < TOL
+    loss = model.get_loss(x.cuda())
+    loss.backward()
+    oloss, aux = om.get_loss(x, faithful=False, return_aux=True)
+    oloss.backward()
+    mism = (model.last_aux["labels"].cpu() != aux["labels"].reshape(bs, -1)).float().mean().item()
+    assert mism <= 0.01
+    if mism == 0:
+        assert abs(loss.item() - oloss.item()) < 2e-4
+        og = dict(om.named_parameters())
+        for name in ("prototypes", "feature_extractor.head.0.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight"):
+            assert rel_err(dict(model.named_parameters())[name].grad.cpu(), og[name].grad) < TOL, name

@@ -192,6 +192,135 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
   }
 }
 
+// KV-tiled variant for token grids that do not fit a register-resident score row (ViT-S/8: N = 785).  Same wave layout
+// (16 queries per wave, S^T = K Q^T, P^T straight into O^T = V^T P^T), but keys arrive in 32-key chunks and the softmax is
+// the online one: running max m and sum l per query, O rescaled by exp(m_old - m_new) when the max moves.  K and V of a
+// chunk are staged together, double-buffered.  No probability output (only the register-resident kernel serves
+// get_last_selfattention).
+__global__ __launch_bounds__(256) void attention_fwd_flash_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                  float* __restrict__ lse, int N, int H, float scale) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * KCH * KSTR + 2 * KCH * VSTR];
+  float* Ks = smem;
+  float* Vs = smem + 2 * KCH * KSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = lane & 15, g = lane >> 4;
+  const int f = blockIdx.z, h = blockIdx.y;
+  const int D3 = 3 * H * HD;
+  const float* base = qkv + (long long)f * N * D3 + h * HD;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const bool wave_active = q0 < N;
+  {
+    float* Qs = smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      const int q = blockIdx.x * 64 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < N) v = *reinterpret_cast<const float4*>(base + (long long)q * D3 + c4);
+      float2* d = reinterpret_cast<float2*>(Qs + row * KSTR + c4);
+      d[0] = make_float2(v.x, v.y);
+      d[1] = make_float2(v.z, v.w);
+    }
+  }
+  __syncthreads();
+  float qreg[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) qreg[s] = smem[(wave * 16 + qi) * KSTR + 4 * s + g] * scale;
+  __syncthreads();
+
+  float4 stk[2], stv[2];
+  auto gload = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      const int key = chunk * KCH + row;
+      stk[i] = stv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (key < N) {
+        stk[i] = *reinterpret_cast<const float4*>(base + (long long)key * D3 + H * HD + c4);
+        stv[i] = *reinterpret_cast<const float4*>(base + (long long)key * D3 + 2 * H * HD + c4);
+      }
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      float2* d = reinterpret_cast<float2*>(Ks + (buf * KCH + row) * KSTR + c4);
+      d[0] = make_float2(stk[i].x, stk[i].y);
+      d[1] = make_float2(stk[i].z, stk[i].w);
+      *reinterpret_cast<float4*>(Vs + (buf * KCH + row) * VSTR + c4) = stv[i];
+    }
+  };
+
+  f32x4 oacc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) oacc[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const int nchunks = (N + KCH - 1) / KCH;
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) gload(c + 1);
+    if (wave_active) {
+      f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+      const float* kp = Ks + (buf * KCH + qi) * KSTR + g;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[4 * s], qreg[s], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[16 * KSTR + 4 * s], qreg[s], s1, 0, 0, 0);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (c * KCH + 4 * g + e >= N) s0[e] = -INFINITY;
+        if (c * KCH + 16 + 4 * g + e >= N) s1[e] = -INFINITY;
+        mx = fmaxf(mx, fmaxf(s0[e], s1[e]));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);          // finite: chunk 0 always holds key 0
+      const float alpha = expf(m_run - m_new);       // exp(-inf) = 0 on the first chunk
+      float ps = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s0[e] = expf(s0[e] - m_new);
+        s1[e] = expf(s1[e] - m_new);
+        ps += s0[e] + s1[e];
+      }
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) oacc[d][e] *= alpha;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* v0 = Vs + (buf * KCH + 4 * g + e) * VSTR + qi;
+        const float* v1 = Vs + (buf * KCH + 16 + 4 * g + e) * VSTR + qi;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[16 * d], s0[e], oacc[d], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1[16 * d], s1[e], oacc[d], 0, 0, 0);
+      }
+    }
+    if (c + 1 < nchunks) swrite(buf ^ 1);
+    __syncthreads();
+  }
+  const int q = q0 + qi;
+  if (wave_active && q < N) {
+    const float inv = 1.0f / l_run;
+    if (lse && g == 0) lse[((long long)f * H + h) * N + q] = m_run + logf(l_run);
+    float* o = out + ((long long)f * N + q) * (H * HD) + h * HD + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      *reinterpret_cast<float4*>(o + 16 * d) = make_float4(oacc[d][0] * inv, oacc[d][1] * inv, oacc[d][2] * inv, oacc[d][3] * inv);
+  }
+}
+
 template <int NT>
 static int launch_fwd(const float* qkv, float* out, float* lse, float* probs, int F, int N, int H, float scale, hipStream_t s) {
   dim3 grid((N + 63) / 64, H, F);
@@ -207,9 +336,15 @@ extern "C" int tt_attention_fwd(const float* qkv, float* out, float* lse, float*
   using namespace tt;
   TT_REQUIRE(qkv && out, "attention_fwd: null pointer");
   TT_REQUIRE(hd == 64, "attention_fwd: head_dim must be 64 (got %d)", hd);
-  TT_REQUIRE(F > 0 && H > 0 && N > 0 && N <= 256, "attention_fwd: need 0 < N <= 256 (got %d); larger token grids need the KV-tiled variant", N);
+  TT_REQUIRE(F > 0 && H > 0 && N > 0, "attention_fwd: bad shape");
   TT_REQUIRE(aligned16(qkv) && aligned16(out), "attention_fwd: buffers must be 16-byte aligned");
   hipStream_t s = as_stream(stream);
+  if (N > 256) {  // KV-tiled online-softmax kernel (ViT-S/8: 785 tokens)
+    TT_REQUIRE(probs == nullptr, "attention_fwd: attention probabilities are only produced for N <= 256 (got %d)", N);
+    hipLaunchKernelGGL(attention_fwd_flash_kernel, dim3((N + 63) / 64, H, F), dim3(256), 0, s, qkv, out, lse, N, H, scale);
+    TT_CHECK_LAUNCH("attention_fwd_flash");
+    return TT_OK;
+  }
   const int nt = (N + 15) / 16;
   if (nt <= 4) return launch_fwd<4>(qkv, out, lse, probs, F, N, H, scale, s);
   if (nt <= 8) return launch_fwd<8>(qkv, out, lse, probs, F, N, H, scale, s);

@@ -116,11 +116,82 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, const float* __r
   out[blockIdx.x * 256 + tid] = s;
 }
 
+// mode 8: mode 7 with the [row][k] LDS image (row stride 20 floats): one ds_write_b128 per staged float4 and one
+// ds_read_b128 per four MFMA operands (k = 8 j + 4 h + q), 41 KB of LDS per workgroup
+__global__ __launch_bounds__(256) void k8(float* out, int iters, const float* __restrict__ src, float* __restrict__ cbuf) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 256 * 20];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const float* ga = src + (size_t)(blockIdx.x % 197) * 128 * 384;
+  const float* gb = src + (size_t)(197 * 128 * 384) + (size_t)(blockIdx.x % 9) * 128 * 384;
+  const int srow = tid >> 2, skc = (tid & 3) * 4;
+  float4 ra[2], rb[2];
+  auto gload = [&](int k0) {
+    for (int i = 0; i < 2; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(ga + (size_t)(srow + 64 * i) * 384 + k0 + skc);
+      rb[i] = *reinterpret_cast<const float4*>(gb + (size_t)(srow + 64 * i) * 384 + k0 + skc);
+    }
+  };
+  auto sstore = [&](int buf) {
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<float4*>(lds + buf * 5120 + (srow + 64 * i) * 20 + skc) = ra[i];
+      *reinterpret_cast<float4*>(lds + buf * 5120 + 2560 + (srow + 64 * i) * 20 + skc) = rb[i];
+    }
+  };
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < iters) gload(((it + 1) % 24) * 16);
+    const float* pa = lds + buf * 5120 + (wm * 64 + r) * 20 + 4 * h;
+    const float* pb = lds + buf * 5120 + 2560 + (wn * 64 + r) * 20 + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float4 a[2], b[2];
+      a[0] = *reinterpret_cast<const float4*>(pa + 8 * j);
+      a[1] = *reinterpret_cast<const float4*>(pa + 32 * 20 + 8 * j);
+      b[0] = *reinterpret_cast<const float4*>(pb + 8 * j);
+      b[1] = *reinterpret_cast<const float4*>(pb + 32 * 20 + 8 * j);
+      const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
+      const float bv[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[n][q], acc[i][n], 0, 0, 0);
+    }
+    if (it + 1 < iters) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  float* c = cbuf + (size_t)(blockIdx.x % 4096) * 128 * 128;
+  for (int wmi = 0; wmi < 2; ++wmi) {
+    if (wm == wmi) {
+      for (int i = 0; i < 2; ++i)
+        for (int n = 0; n < 2; ++n)
+          for (int e = 0; e < 16; ++e)
+            lds[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 132 + wn * 64 + n * 32 + r] = acc[i][n][e];
+    }
+    __syncthreads();
+    const int c4 = (tid & 31) * 4;
+    for (int rr = tid >> 5; rr < 64; rr += 8) {
+      const float4 t = *reinterpret_cast<const float4*>(lds + rr * 132 + c4);
+      *reinterpret_cast<float4*>(c + (wmi * 64 + rr) * 128 + c4) = t;
+    }
+    __syncthreads();
+  }
+}
+
 int main(int argc, char** argv) {
   const int mode = argc > 1 ? atoi(argv[1]) : 0, wps = argc > 2 ? atoi(argv[2]) : 1;
   int iters = argc > 3 ? atoi(argv[3]) : 2000;
-  const int blocks = (mode == 7) ? 256 * wps * (iters / 24) : 256 * wps;
-  if (mode == 7) iters = 24;
+  const int blocks = (mode >= 7) ? 256 * wps * (iters / 24) : 256 * wps;
+  if (mode >= 7) iters = 24;
   float* out;
   float *src, *cbuf;
   hipMalloc(&out, blocks * 256 * sizeof(float));
@@ -138,7 +209,8 @@ int main(int argc, char** argv) {
       case 3: hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
       case 4: hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
       case 5: hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
-      default: hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
+      case 6: case 7: hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
+      default: hipLaunchKernelGGL(k8, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
     }
   };
   launch();
