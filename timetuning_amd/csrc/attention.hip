@@ -25,7 +25,7 @@ constexpr int VSTR = 68;       // V row stride: 16*g + i distinct banks
 template <int NT>  // NT = number of 16-key tiles kept in registers (N <= 16 * NT)
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             float* __restrict__ lse, float* __restrict__ probs, int N, int H,
-                                                            float scale) {
+                                                            int FH, float scale) {
   constexpr int NC = (NT + 1) / 2;  // chunks of 32 keys
   __shared__ __attribute__((aligned(16))) float smem[2 * KCH * KSTR + 2 * KCH * VSTR];
   float* Ks = smem;                   // [2][KCH][KSTR]
@@ -33,10 +33,12 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = lane & 15, g = lane >> 4;
-  const int f = blockIdx.z, h = blockIdx.y;
+  int fh, qtile;
+  if (!xcd_group_decode(blockIdx.x, (N + 63) / 64, FH, fh, qtile)) return;  // q-tiles of one (frame, head) share an XCD
+  const int f = fh / H, h = fh - f * H;
   const int D3 = 3 * H * HD;
   const float* base = qkv + (long long)f * N * D3 + h * HD;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = qtile * 64 + wave * 16;
   const bool wave_active = q0 < N;
 
   // ---- stage the 64 x 64 Q tile through LDS (coalesced 16-B loads), then pull this lane's 16 operands
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
-      const int q = blockIdx.x * 64 + row;
+      const int q = qtile * 64 + row;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (q < N) v = *reinterpret_cast<const float4*>(base + (long long)q * D3 + c4);
       float2* d = reinterpret_cast<float2*>(Qs + row * KSTR + c4);
@@ -198,23 +200,25 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
 // chunk are staged together, double-buffered.  No probability output (only the register-resident kernel serves
 // get_last_selfattention).
 __global__ __launch_bounds__(256) void attention_fwd_flash_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                  float* __restrict__ lse, int N, int H, float scale) {
+                                                                  float* __restrict__ lse, int N, int H, int FH, float scale) {
   __shared__ __attribute__((aligned(16))) float smem[2 * KCH * KSTR + 2 * KCH * VSTR];
   float* Ks = smem;
   float* Vs = smem + 2 * KCH * KSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = lane & 15, g = lane >> 4;
-  const int f = blockIdx.z, h = blockIdx.y;
+  int fh, qtile;
+  if (!xcd_group_decode(blockIdx.x, (N + 63) / 64, FH, fh, qtile)) return;  // q-tiles of one (frame, head) share an XCD
+  const int f = fh / H, h = fh - f * H;
   const int D3 = 3 * H * HD;
   const float* base = qkv + (long long)f * N * D3 + h * HD;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = qtile * 64 + wave * 16;
   const bool wave_active = q0 < N;
   {
     float* Qs = smem;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
-      const int q = blockIdx.x * 64 + row;
+      const int q = qtile * 64 + row;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (q < N) v = *reinterpret_cast<const float4*>(base + (long long)q * D3 + c4);
       float2* d = reinterpret_cast<float2*>(Qs + row * KSTR + c4);
@@ -323,8 +327,9 @@ __global__ __launch_bounds__(256) void attention_fwd_flash_kernel(const float* _
 
 template <int NT>
 static int launch_fwd(const float* qkv, float* out, float* lse, float* probs, int F, int N, int H, float scale, hipStream_t s) {
-  dim3 grid((N + 63) / 64, H, F);
-  hipLaunchKernelGGL((attention_fwd_kernel<NT>), grid, dim3(256), 0, s, qkv, out, lse, probs, N, H, scale);
+  // 1-D over (frame*head, q-tile), ordered so that the q-tiles sharing K/V sit on one XCD (common.hpp xcd_group_decode)
+  dim3 grid(xcd_group_grid(F * H, (N + 63) / 64));
+  hipLaunchKernelGGL((attention_fwd_kernel<NT>), grid, dim3(256), 0, s, qkv, out, lse, probs, N, H, F * H, scale);
   TT_CHECK_LAUNCH("attention_fwd");
   return TT_OK;
 }
@@ -341,7 +346,8 @@ extern "C" int tt_attention_fwd(const float* qkv, float* out, float* lse, float*
   hipStream_t s = as_stream(stream);
   if (N > 256) {  // KV-tiled online-softmax kernel (ViT-S/8: 785 tokens)
     TT_REQUIRE(probs == nullptr, "attention_fwd: attention probabilities are only produced for N <= 256 (got %d)", N);
-    hipLaunchKernelGGL(attention_fwd_flash_kernel, dim3((N + 63) / 64, H, F), dim3(256), 0, s, qkv, out, lse, N, H, scale);
+    hipLaunchKernelGGL(attention_fwd_flash_kernel, dim3(xcd_group_grid(F * H, (N + 63) / 64)), dim3(256), 0, s, qkv, out, lse, N, H,
+                       F * H, scale);
     TT_CHECK_LAUNCH("attention_fwd_flash");
     return TT_OK;
   }

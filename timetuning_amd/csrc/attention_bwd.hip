@@ -36,15 +36,17 @@ __device__ __forceinline__ void tile_to_regs(const float* __restrict__ src, long
 __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                                const float* __restrict__ dout, const float* __restrict__ lse,
                                                                float* __restrict__ dqkv, float* __restrict__ delta, int N, int H,
-                                                               float scale) {
+                                                               int FH, float scale) {
   __shared__ __attribute__((aligned(16))) float smem[4 * BCH * BSTR + 64 * BSTR];
   float* Ks = smem;                   // [2][32][68]
   float* Vs = smem + 2 * BCH * BSTR;  // [2][32][68]
   float* stage = smem + 4 * BCH * BSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, qi = lane & 15, g = lane >> 4;
-  const int f = blockIdx.z, h = blockIdx.y, D = H * BHD, D3 = 3 * D;
+  int fh, tile64;
+  if (!xcd_group_decode(blockIdx.x, (N + 63) / 64, FH, fh, tile64)) return;  // tiles of one (frame, head) share an XCD
+  const int f = fh / H, h = fh - f * H, D = H * BHD, D3 = 3 * D;
   const float* base = qkv + (long long)f * N * D3 + h * BHD;
-  const int q0 = blockIdx.x * 64, q = q0 + wave * 16 + qi;
+  const int q0 = tile64 * 64, q = q0 + wave * 16 + qi;
   const bool wave_active = q0 + wave * 16 < N;
 
   float qreg[16], doreg[16], oreg[16];
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
 
 __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                float* __restrict__ dqkv, int N, int H, float scale) {
+                                                                float* __restrict__ dqkv, int N, int H, int FH, float scale) {
   __shared__ __attribute__((aligned(16))) float smem[4 * BCH * BSTR + 64 * BSTR + 4 * BCH];
   float* Qs = smem;                    // [2][32][68]
   float* Os = smem + 2 * BCH * BSTR;   // dO chunks [2][32][68]
@@ -141,10 +143,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
   float* Ls = stage + 64 * BSTR;       // [2][32] lse, then [2][32] delta
   float* Dl = Ls + 2 * BCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ki = lane & 15, g = lane >> 4;
-  const int f = blockIdx.z, h = blockIdx.y, D = H * BHD, D3 = 3 * D;
+  int fh, tile64;
+  if (!xcd_group_decode(blockIdx.x, (N + 63) / 64, FH, fh, tile64)) return;
+  const int f = fh / H, h = fh - f * H, D = H * BHD, D3 = 3 * D;
   const float* base = qkv + (long long)f * N * D3 + h * BHD;
   const float* dob = dout + (long long)f * N * D + h * BHD;
-  const int k0 = blockIdx.x * 64, key = k0 + wave * 16 + ki;
+  const int k0 = tile64 * 64, key = k0 + wave * 16 + ki;
   const bool wave_active = k0 + wave * 16 < N;
 
   float kreg[16], vreg[16];
@@ -261,9 +265,9 @@ extern "C" int tt_attention_bwd(const float* qkv, const float* out, const float*
   TT_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), "attention_bwd: buffers must be 16-byte aligned");
   hipStream_t s = as_stream(stream);
   float* delta = static_cast<float*>(workspace);
-  dim3 grid((N + 63) / 64, H, F);
-  hipLaunchKernelGGL(attention_bwd_dq_kernel, grid, dim3(256), 0, s, qkv, out, dout, lse, dqkv, delta, N, H, scale);
-  hipLaunchKernelGGL(attention_bwd_dkv_kernel, grid, dim3(256), 0, s, qkv, dout, lse, delta, dqkv, N, H, scale);
+  dim3 grid(xcd_group_grid(F * H, (N + 63) / 64));
+  hipLaunchKernelGGL(attention_bwd_dq_kernel, grid, dim3(256), 0, s, qkv, out, dout, lse, dqkv, delta, N, H, F * H, scale);
+  hipLaunchKernelGGL(attention_bwd_dkv_kernel, grid, dim3(256), 0, s, qkv, dout, lse, delta, dqkv, N, H, F * H, scale);
   TT_CHECK_LAUNCH("attention_bwd");
   return TT_OK;
 }

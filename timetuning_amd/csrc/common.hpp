@@ -68,4 +68,17 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
   return base + slot;
 }
 
+// 1-D grid decode for kernels where `inner` consecutive workgroups share an operand panel (the q-tiles of one
+// (frame, head) share K and V): the sharing workgroups get block ids congruent mod 8 - the same XCD under the
+// observed round-robin placement - in consecutive dispatch slots, so the panel is fetched into ONE L2 once instead of
+// into up to `inner` of them (measured on attention_fwd: 349 MB -> see profiles/ of HBM-side reads per launch).
+// Placement only affects speed.  Launch with xcd_group_grid(n_outer, inner) blocks; returns false for padding blocks.
+__device__ __forceinline__ bool xcd_group_decode(int b, int inner, int n_outer, int& outer, int& in_idx) {
+  const int x = b & 7, s = b >> 3;
+  in_idx = s % inner;
+  outer = (s / inner) * 8 + x;
+  return outer < n_outer;
+}
+inline int xcd_group_grid(int n_outer, int inner) { return ((n_outer + 7) / 8) * 8 * inner; }
+
 }  // namespace tt
