@@ -184,7 +184,10 @@ def global_sinkhorn(scores_local: torch.Tensor, rows_out: int, eps: float, iters
         W, rank = dist.get_world_size(), dist.get_rank()
         B_loc = scores_local.shape[0]
         gathered = torch.empty((W * B_loc, scores_local.shape[1]), dtype=f32, device=scores_local.device)
-        dist.all_gather_into_tensor(gathered, scores_local.contiguous())
+        try:
+            dist.all_gather_into_tensor(gathered, scores_local.contiguous())
+        except RuntimeError:  # backends without the flat all-gather (gloo on device tensors, used by the 1-GPU 2-rank test)
+            dist.all_gather(list(gathered.chunk(W, dim=0)), scores_local.contiguous())
         return solver(gathered, iters, eps, row0=rank * B_loc, rows_out=rows_out)
     return solver(scores_local, iters, eps, row0=0, rows_out=rows_out)
 
