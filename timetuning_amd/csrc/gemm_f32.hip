@@ -22,6 +22,7 @@
 // outputs are too small to fill 256 CUs: partial tiles go to a workspace and a second kernel folds them in a fixed
 // order (deterministic, no atomics).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace tt {
 
@@ -323,6 +324,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 int gemm_tile_choice(int M, int N, int batch) {
+  static const int forced = [] { const char* e = getenv("TT_FORCE_TILE"); return e ? atoi(e) : -1; }();  // tuning aid
+  if (forced >= 0 && forced <= 3) return forced;
   struct Cfg { int wm, wn; double pen; };
   const Cfg cfgs[4] = {{2, 2, 1.00}, {1, 2, 1.04}, {2, 1, 1.04}, {1, 1, 1.10}};
   int best = 0;
