@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float p = expf(sacc[t][e] - mx);
+      const float p = fast_exp(sacc[t][e] - mx);
       sacc[t][e] = p;
       sum += p;
     }
@@ -285,12 +285,12 @@ __global__ __launch_bounds__(256) void attention_fwd_flash_kernel(const float* _
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);          // finite: chunk 0 always holds key 0
-      const float alpha = expf(m_run - m_new);       // exp(-inf) = 0 on the first chunk
+      const float alpha = fast_exp(m_run - m_new);   // exp(-inf) = 0 on the first chunk
       float ps = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        s0[e] = expf(s0[e] - m_new);
-        s1[e] = expf(s1[e] - m_new);
+        s0[e] = fast_exp(s0[e] - m_new);
+        s1[e] = fast_exp(s1[e] - m_new);
         ps += s0[e] + s1[e];
       }
       ps += __shfl_xor(ps, 16, 64);
@@ -325,6 +325,8 @@ __global__ __launch_bounds__(256) void attention_fwd_flash_kernel(const float* _
   }
 }
 
+int launch_attention_fwd_q2(const float* qkv, float* out, float* lse, int F, int N, int H, float scale, hipStream_t s);  // attention_q2.hip
+
 template <int NT>
 static int launch_fwd(const float* qkv, float* out, float* lse, float* probs, int F, int N, int H, float scale, hipStream_t s) {
   // 1-D over (frame*head, q-tile), ordered so that the q-tiles sharing K/V sit on one XCD (common.hpp xcd_group_decode)
@@ -352,6 +354,7 @@ extern "C" int tt_attention_fwd(const float* qkv, float* out, float* lse, float*
     return TT_OK;
   }
   const int nt = (N + 15) / 16;
+  if (probs == nullptr && N > 64) return launch_attention_fwd_q2(qkv, out, lse, F, N, H, scale, s);  // two q-tiles per wave
   if (nt <= 4) return launch_fwd<4>(qkv, out, lse, probs, F, N, H, scale, s);
   if (nt <= 8) return launch_fwd<8>(qkv, out, lse, probs, F, N, H, scale, s);
   if (nt <= 13) return launch_fwd<13>(qkv, out, lse, probs, F, N, H, scale, s);

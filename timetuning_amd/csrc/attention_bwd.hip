@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int key = c * BCH + 16 * t2 + 4 * g + e;
-          const float p = (key < N) ? expf(sa[e] - lse_q) : 0.f;
+          const float p = (key < N) ? fast_exp(sa[e] - lse_q) : 0.f;
           ds[e] = p * (dp[e] - dl);
         }
 #pragma unroll
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
         for (int e = 0; e < 4; ++e) {
           const int ql = 16 * t2 + 4 * g + e;
           const bool ok = (c * BCH + ql < N) && (key < N);
-          p[e] = ok ? expf(sa[e] - Ls[buf * BCH + ql]) : 0.f;
+          p[e] = ok ? fast_exp(sa[e] - Ls[buf * BCH + ql]) : 0.f;
           ds[e] = p[e] * (dp[e] - Dl[buf * BCH + ql]);
         }
 #pragma unroll

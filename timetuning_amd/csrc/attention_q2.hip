@@ -1,0 +1,215 @@
+// Fused attention forward, two query tiles per wave (N <= 256, head_dim 64, f32 MFMA 16x16x4).
+//
+// Same scheme as attention.hip (S^T = K Q^T keeps a query's score row in one lane-column, P^T feeds O^T = V^T P^T
+// from registers) but each wave owns 32 queries = two 16-query tiles that SHARE every K / V fragment read from LDS:
+// one ds_read_b32 feeds two MFMAs, a workgroup (4 waves) covers 128 queries, and the work between two barriers
+// doubles (64 MFMAs per wave per 32-key chunk), which is what the one-tile version was short of (44 % MFMA busy).
+// Costs ~190 VGPRs (2 waves per SIMD).  The one-tile kernel stays for the probability output.
+#include "common.hpp"
+
+namespace tt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int Q2_HD = 64, Q2_KCH = 32, Q2_KSTR = 66, Q2_VSTR = 68;
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void attention_fwd_q2_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                  float* __restrict__ lse, int N, int H, int FH, float scale) {
+  constexpr int NC = (NT + 1) / 2;
+  __shared__ __attribute__((aligned(16))) float smem[2 * Q2_KCH * Q2_KSTR + 2 * Q2_KCH * Q2_VSTR];
+  float* Ks = smem;
+  float* Vs = smem + 2 * Q2_KCH * Q2_KSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = lane & 15, g = lane >> 4;
+  int fh, qblk;
+  if (!xcd_group_decode(blockIdx.x, (N + 127) / 128, FH, fh, qblk)) return;
+  const int f = fh / H, h = fh - f * H;
+  const int D3 = 3 * H * Q2_HD;
+  const float* base = qkv + (long long)f * N * D3 + h * Q2_HD;
+  const int q0 = qblk * 128 + wave * 32;
+  const bool wave_active = q0 < N;
+
+  // stage the 128 x 64 Q block through LDS (aliases the whole K/V staging area), pull 2 x 16 operands per lane
+  {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      const int q = qblk * 128 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < N) v = *reinterpret_cast<const float4*>(base + (long long)q * D3 + c4);
+      float2* d = reinterpret_cast<float2*>(smem + row * Q2_KSTR + c4);
+      d[0] = make_float2(v.x, v.y);
+      d[1] = make_float2(v.z, v.w);
+    }
+  }
+  __syncthreads();
+  float qreg[2][16];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) qreg[t][s] = smem[(wave * 32 + t * 16 + qi) * Q2_KSTR + 4 * s + g] * scale;
+  __syncthreads();
+
+  float4 st[2];
+  auto gload = [&](int chunk, int which) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      const int key = chunk * Q2_KCH + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (key < N) v = *reinterpret_cast<const float4*>(base + (long long)key * D3 + which * H * Q2_HD + c4);
+      st[i] = v;
+    }
+  };
+  auto swrite_k = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      float2* d = reinterpret_cast<float2*>(Ks + (buf * Q2_KCH + row) * Q2_KSTR + c4);
+      d[0] = make_float2(st[i].x, st[i].y);
+      d[1] = make_float2(st[i].z, st[i].w);
+    }
+  };
+  auto swrite_v = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+      *reinterpret_cast<float4*>(Vs + (buf * Q2_KCH + row) * Q2_VSTR + c4) = st[i];
+    }
+  };
+
+  f32x4 sacc[2][NT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int k = 0; k < NT; ++k) sacc[t][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  gload(0, 1);
+  swrite_k(0);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < NC) gload(c + 1, 1);
+#ifdef ABL_NOQK
+    if (false) {
+#else
+    if (wave_active) {
+#endif
+      const float* kp = Ks + (buf * Q2_KCH + qi) * Q2_KSTR + g;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float k0 = kp[4 * s];
+        sacc[0][2 * c] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0, qreg[0][s], sacc[0][2 * c], 0, 0, 0);
+        sacc[1][2 * c] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0, qreg[1][s], sacc[1][2 * c], 0, 0, 0);
+        if (2 * c + 1 < NT) {
+          const float k1 = kp[16 * Q2_KSTR + 4 * s];
+          sacc[0][2 * c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1, qreg[0][s], sacc[0][2 * c + 1], 0, 0, 0);
+          sacc[1][2 * c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1, qreg[1][s], sacc[1][2 * c + 1], 0, 0, 0);
+        }
+      }
+    }
+    if (c + 1 < NC) swrite_k(buf ^ 1);
+    __syncthreads();
+  }
+  gload(0, 2);
+
+  float inv[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (16 * k + 4 * g + e >= N) sacc[t][k][e] = -INFINITY;
+        mx = fmaxf(mx, sacc[t][k][e]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#ifdef ABL_NOEXP  // timing ablation only (tools/ab_attn.py)
+        const float p = sacc[t][k][e] - mx;
+#else
+        const float p = fast_exp(sacc[t][k][e] - mx);
+#endif
+        sacc[t][k][e] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    inv[t] = 1.0f / sum;
+    const int q = q0 + 16 * t + qi;
+    if (lse && g == 0 && q < N) lse[((long long)f * H + h) * N + q] = mx + logf(sum);
+  }
+
+  f32x4 oacc[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) oacc[t][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  swrite_v(0);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < NC) gload(c + 1, 2);
+#ifdef ABL_NOPV
+    if (false) {
+#else
+    if (wave_active) {
+#endif
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int k = 2 * c + t2;
+        if (k < NT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float* vp = Vs + (buf * Q2_KCH + 16 * t2 + 4 * g + e) * Q2_VSTR + qi;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const float v = vp[16 * d];
+              oacc[0][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, sacc[0][k][e], oacc[0][d], 0, 0, 0);
+              oacc[1][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, sacc[1][k][e], oacc[1][d], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    if (c + 1 < NC) swrite_v(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int q = q0 + 16 * t + qi;
+    if (q < N) {
+      float* o = out + ((long long)f * N + q) * (H * Q2_HD) + h * Q2_HD + 4 * g;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        *reinterpret_cast<float4*>(o + 16 * d) =
+            make_float4(oacc[t][d][0] * inv[t], oacc[t][d][1] * inv[t], oacc[t][d][2] * inv[t], oacc[t][d][3] * inv[t]);
+    }
+  }
+}
+
+template <int NT>
+static int launch_q2(const float* qkv, float* out, float* lse, int F, int N, int H, float scale, hipStream_t s) {
+  hipLaunchKernelGGL((attention_fwd_q2_kernel<NT>), dim3(xcd_group_grid(F * H, (N + 127) / 128)), dim3(256), 0, s, qkv, out, lse, N, H,
+                     F * H, scale);
+  TT_CHECK_LAUNCH("attention_fwd_q2");
+  return TT_OK;
+}
+
+int launch_attention_fwd_q2(const float* qkv, float* out, float* lse, int F, int N, int H, float scale, hipStream_t s) {
+  const int nt = (N + 15) / 16;
+  if (nt <= 8) return launch_q2<8>(qkv, out, lse, F, N, H, scale, s);
+  if (nt <= 13) return launch_q2<13>(qkv, out, lse, F, N, H, scale, s);
+  return launch_q2<16>(qkv, out, lse, F, N, H, scale, s);
+}
+
+}  // namespace tt

@@ -51,6 +51,11 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// exp for softmax probabilities: v_exp_f32 on x * log2(e) (a handful of instructions; ocml's expf is ~10x that and the
+// softmax phase of the attention kernels is pure VALU time during which the matrix pipe idles).  Arguments are <= 0 and
+// > -100 in practice; relative error ~1e-6, far inside the 1e-3 contract (the per-op tests hold 2e-5).
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+
 // exact-erf GELU (nn.GELU default) and its derivative
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {

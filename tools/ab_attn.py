@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""A/B of tt_attention_fwd between library builds in one process. usage: ab_attn.py libA.so libB.so ..."""
+import ctypes as C, os, statistics, sys, torch
+def load(p):
+    lib = C.CDLL(os.path.abspath(p)); lib.tt_attention_fwd.restype = C.c_int
+    lib.tt_attention_fwd.argtypes = [C.c_void_p]*4 + [C.c_int]*4 + [C.c_float, C.c_void_p]; return lib
+libs = [(p, load(p)) for p in sys.argv[1:]]
+F, N, H = 128, 197, 6
+qkv = torch.randn(F, N, 3*H*64, device="cuda"); out = torch.empty(F, N, H*64, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+res = {p: [] for p, _ in libs}
+for rd in range(12):
+    for p, lib in libs:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): assert lib.tt_attention_fwd(qkv.data_ptr(), out.data_ptr(), None, None, F, N, H, 64, 0.125, st) == 0
+        e1.record(); torch.cuda.synchronize()
+        if rd >= 2: res[p].append(e0.elapsed_time(e1)*1e3/5)
+for p, v in res.items(): print(f"{os.path.basename(p):28s} median {statistics.median(v):7.1f} us  min {min(v):7.1f} us")

@@ -25,6 +25,14 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, const float* __r
   for (int i = 0; i < 2; ++i)
     for (int j = 0; j < 2; ++j)
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // optional one-time stagger (env TT_STAGGER_US via kernel arg `iters` high bits would complicate things: compile-time)
+#ifdef STAGGER_CYCLES
+  if (blockIdx.x < 1024) {  // first resident wave of workgroups: delay slots 1..3 of each CU by 1/4, 2/4, 3/4 tile
+    const int slot = (blockIdx.x >> 8) & 3;
+    const long long t0 = clock64();
+    while (clock64() - t0 < (long long)slot * STAGGER_CYCLES) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   float a0 = lane * 0.001f, a1 = lane * 0.002f, b0 = 0.5f, b1 = 0.25f;
   float4 st0 = make_float4(a0, a1, b0, b1), st1 = st0;
   const float* ga = src + (size_t)(blockIdx.x % 197) * 128 * 384;
