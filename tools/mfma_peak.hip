@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -195,6 +196,91 @@ __global__ __launch_bounds__(256) void k8(float* out, int iters, const float* __
   }
 }
 
+// mode 9: mode 7 with hand-pipelined LDS fragment reads (inline asm ds_read_b32 into a register double buffer, counted
+// lgkmcnt waits): the reads of k-pair step+1 are in flight while the MFMAs of step issue.
+__device__ __forceinline__ float lds_rd(unsigned addr, int off) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(off));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ void lds_rd4(unsigned pa, unsigned pb, float (&a)[2], float (&b)[2]) {
+  asm volatile("ds_read_b32 %0, %4 offset:%6\n\tds_read_b32 %1, %4 offset:%7\n\tds_read_b32 %2, %5 offset:%6\n\tds_read_b32 %3, %5 offset:%7"
+               : "=v"(a[0]), "=v"(a[1]), "=v"(b[0]), "=v"(b[1]) : "v"(pa), "v"(pb), "i"(OFF), "i"(OFF + 128));
+}
+__global__ __launch_bounds__(256) void k9(float* out, int iters, const float* __restrict__ src, float* __restrict__ cbuf) {
+  __shared__ float lds[2 * 16 * (132 + 132)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const float* ga = src + (size_t)(blockIdx.x % 197) * 128 * 384;
+  const float* gb = src + (size_t)(197 * 128 * 384) + (size_t)(blockIdx.x % 9) * 128 * 384;
+  const int srow = tid >> 2, skc = (tid & 3) * 4;
+  float4 ra[2], rb[2];
+  auto gload = [&](int k0) {
+    for (int i = 0; i < 2; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(ga + (size_t)(srow + 64 * i) * 384 + k0 + skc);
+      rb[i] = *reinterpret_cast<const float4*>(gb + (size_t)(srow + 64 * i) * 384 + k0 + skc);
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* da = lds + buf * 16 * 264 + skc * 132 + srow;
+    float* db = da + 16 * 132;
+    for (int i = 0; i < 2; ++i) {
+      da[0 * 132 + 64 * i] = ra[i].x; da[1 * 132 + 64 * i] = ra[i].y; da[2 * 132 + 64 * i] = ra[i].z; da[3 * 132 + 64 * i] = ra[i].w;
+      db[0 * 132 + 64 * i] = rb[i].x; db[1 * 132 + 64 * i] = rb[i].y; db[2 * 132 + 64 * i] = rb[i].z; db[3 * 132 + 64 * i] = rb[i].w;
+    }
+  };
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  const unsigned lbase = (unsigned)(unsigned long long)(lds);
+  for (int it = 0; it < iters; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < iters) gload(((it + 1) % 24) * 16);
+    const unsigned pa = lbase + 4u * (buf * 16 * 264 + (4 * h) * 132 + wm * 64 + r);
+    const unsigned pb = lbase + 4u * (buf * 16 * 264 + 16 * 132 + (4 * h) * 132 + wn * 64 + r);
+    float a[2][2], b[2][2];
+#define STEP_OFF(step) (4 * ((8 * ((step) >> 2) + ((step) & 3)) * 132))
+#define RD(step, A, B) lds_rd4<STEP_OFF(step)>(pa, pb, A, B)
+#define MM(A, B)                                                                    \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0], B[0], acc[0][0], 0, 0, 0); \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0], B[1], acc[0][1], 0, 0, 0); \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1], B[0], acc[1][0], 0, 0, 0); \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1], B[1], acc[1][1], 0, 0, 0);
+#define WAITN(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    RD(0, a[0], b[0]);
+    RD(1, a[1], b[1]); WAITN(4) MM(a[0], b[0])
+    RD(2, a[0], b[0]); WAITN(4) MM(a[1], b[1])
+    RD(3, a[1], b[1]); WAITN(4) MM(a[0], b[0])
+    RD(4, a[0], b[0]); WAITN(4) MM(a[1], b[1])
+    RD(5, a[1], b[1]); WAITN(4) MM(a[0], b[0])
+    RD(6, a[0], b[0]); WAITN(4) MM(a[1], b[1])
+    RD(7, a[1], b[1]); WAITN(4) MM(a[0], b[0])
+    WAITN(0) MM(a[1], b[1])
+    if (it + 1 < iters) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  float* c = cbuf + (size_t)(blockIdx.x % 4096) * 128 * 128;
+  for (int wmi = 0; wmi < 2; ++wmi) {
+    if (wm == wmi) {
+      for (int i = 0; i < 2; ++i)
+        for (int n = 0; n < 2; ++n)
+          for (int e = 0; e < 16; ++e)
+            lds[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 132 + wn * 64 + n * 32 + r] = acc[i][n][e];
+    }
+    __syncthreads();
+    const int c4 = (tid & 31) * 4;
+    for (int rr = tid >> 5; rr < 64; rr += 8) {
+      const float4 t = *reinterpret_cast<const float4*>(lds + rr * 132 + c4);
+      *reinterpret_cast<float4*>(c + (wmi * 64 + rr) * 128 + c4) = t;
+    }
+    __syncthreads();
+  }
+}
+
 int main(int argc, char** argv) {
   const int mode = argc > 1 ? atoi(argv[1]) : 0, wps = argc > 2 ? atoi(argv[2]) : 1;
   int iters = argc > 3 ? atoi(argv[3]) : 2000;
@@ -204,7 +290,18 @@ int main(int argc, char** argv) {
   float *src, *cbuf;
   hipMalloc(&out, blocks * 256 * sizeof(float));
   hipMalloc(&src, (size_t)(197 + 9) * 128 * 384 * sizeof(float));
-  hipMemset(src, 0, (size_t)(197 + 9) * 128 * 384 * sizeof(float));
+  {  // random operands: zero-filled inputs inflate MFMA benchmarks (guide 5.4 rule 25)
+    const size_t n = (size_t)(197 + 9) * 128 * 384;
+    float* hbuf = (float*)malloc(n * sizeof(float));
+    unsigned s = 12345u;
+    for (size_t i = 0; i < n; ++i) {
+      s = s * 1664525u + 1013904223u;
+      hbuf[i] = ((int)(s >> 8) % 20001 - 10000) * 1e-4f;
+    }
+    if (getenv("TT_ZERO")) memset(hbuf, 0, n * sizeof(float));
+    hipMemcpy(src, hbuf, n * sizeof(float), hipMemcpyHostToDevice);
+    free(hbuf);
+  }
   hipMalloc(&cbuf, (size_t)(blocks > 4096 ? 4096 : blocks) * 128 * 128 * sizeof(float));
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
@@ -218,7 +315,8 @@ int main(int argc, char** argv) {
       case 4: hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
       case 5: hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
       case 6: case 7: hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
-      default: hipLaunchKernelGGL(k8, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
+      case 8: hipLaunchKernelGGL(k8, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
+      default: hipLaunchKernelGGL(k9, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
     }
   };
   launch();
