@@ -366,13 +366,18 @@ static int launch_mode(const GemmArgs& g, int batch, int tile, hipStream_t s) {
 
 // Split-K plan for a product whose output is too small to fill the chip: returns the number of K slices (1 = none).
 int gemm_splitk_choice(int M, int N, int K, int* tile_out) {
-  const int tile = gemm_tile_choice(M, N, 1);
-  const int bm = (tile == 0 || tile == 2) ? 128 : 64, bn = (tile == 0 || tile == 1) ? 128 : 64;
-  const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  // Measured on the block / head weight-gradient shapes (tools/bench_kernels.py, tile x target sweep): 64x64 output tiles
+  // with about one resident wave of workgroups (~1024) win over larger tiles with more, shorter K slices
+  // (fc2 110 vs 140 us, qkv 96 vs 117, head 157 vs 187).  The launcher must use the tile this plan was made for.
+  const int tile = 3;
+  const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
   if (tile_out) *tile_out = tile;
-  if (tiles >= 384 || K < 1024) return 1;
-  int s = (int)((768 + tiles - 1) / tiles);          // aim at >= 3 workgroups per CU
-  const int smax = K / 256;                          // keep >= 256 of K per slice
+  if (tiles >= 768 || K < 1024) return 1;
+  static const int target_env = [] { const char* e = getenv("TT_SPLIT_TARGET"); return e ? atoi(e) : 0; }();  // tuning aids
+  static const int mink = [] { const char* e = getenv("TT_SPLIT_MINK"); return e ? atoi(e) : 256; }();
+  const int target = target_env ? target_env : 1024;
+  int s = (int)((target + tiles - 1) / tiles);
+  const int smax = K / mink;                         // keep >= mink of K per slice
   if (s > smax) s = smax;
   if (s > 32) s = 32;
   return s < 1 ? 1 : s;
@@ -429,6 +434,8 @@ using tt::base_args;
 namespace tt {
 int try_launch_gemm_nt_fast(const float* A, const float* B, float* C, int M, int N, int K, const float* bias,
                             const float* residual, float* pre_out, int act, hipStream_t s);
+int try_launch_dgrad_fast(const float* dy, const float* w, const float* gelu_pre, float* dx, int M, int N, int K, hipStream_t s);
+int try_launch_wgrad_fast(const float* dy, const float* x, float* out, int M, int N, int K, int splits, int kchunk, hipStream_t s);
 }
 
 extern "C" int tt_gemm_tile_choice(int M, int N, int batch) { return tt::gemm_tile_choice(M, N, batch); }
@@ -456,6 +463,10 @@ extern "C" int tt_linear_fwd(const float* x, const float* w, const float* bias, 
 extern "C" int tt_linear_bwd_data(const float* dy, const float* w, const float* gelu_pre, float* dx, int M, int N,
                                   int K, tt_stream_t stream) {
   // dx[M,K] = dy[M,N] @ w[N,K]: reduction over N; w is "n-major" for this product (stored [N_red][K_out]).
+  if (dy && w && dx && M > 0 && N > 0 && K > 0) {  // lean instance for whole-tile output columns (gemm_bwd_fast.hip)
+    const int rc = tt::try_launch_dgrad_fast(dy, w, gelu_pre, dx, M, N, K, tt::as_stream(stream));
+    if (rc <= 0) return rc;
+  }
   GemmArgs g = base_args(dy, w, dx, M, K, N, N, K, K);
   g.gelu_pre = gelu_pre;
   return tt::launch_gemm(g, 0, 1, 1, tt::as_stream(stream));
@@ -480,7 +491,8 @@ extern "C" int tt_linear_bwd_weight(const float* dy, const float* x, float* dw, 
     g.splits = s;
     g.kchunk = ((M + s - 1) / s + tt::kBK - 1) / tt::kBK * tt::kBK;
     g.strideS = (long long)N * K;
-    rc = tt::launch_gemm(g, 1, 1, 1, tt::as_stream(stream));
+    rc = tt::try_launch_wgrad_fast(dy, x, g.C, M, N, K, s, g.kchunk, tt::as_stream(stream));
+    if (rc > 0) rc = tt::launch_gemm(g, 1, 1, 1, tt::as_stream(stream));
     if (rc != TT_OK) return rc;
     const long long n = (long long)N * K;
     TT_REQUIRE(n % 4 == 0, "linear_bwd_weight: N*K must be a multiple of 4");
@@ -490,7 +502,8 @@ extern "C" int tt_linear_bwd_weight(const float* dy, const float* x, float* dw, 
                        static_cast<const float*>(workspace), dw, n, s, (long long)N * K);
     TT_CHECK_LAUNCH("splitk_reduce");
   } else {
-    rc = tt::launch_gemm(g, 1, 1, 1, tt::as_stream(stream));
+    rc = (M % 16 == 0) ? tt::try_launch_wgrad_fast(dy, x, dw, M, N, K, 1, M, tt::as_stream(stream)) : 1;
+    if (rc > 0) rc = tt::launch_gemm(g, 1, 1, 1, tt::as_stream(stream));
     if (rc != TT_OK) return rc;
   }
   if (!db) return TT_OK;

@@ -83,7 +83,7 @@ class _FusedLoss(torch.autograd.Function):
     def backward(ctx, gout):
         if ctx.grads is None:
             raise RuntimeError("the fused TimeT step was run without gradients")
-        out = [None if g is None else g for g in ctx.grads]
+        out, ctx.grads = ctx.grads, None  # hand the buffers over: with no other owner AccumulateGrad adopts them instead of cloning
         live = [g for g in out if g is not None]
         torch._foreach_mul_(live, gout)
         return (None, None, None, None, *out)
