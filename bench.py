@@ -143,11 +143,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("TT_BENCH_SHARE_DEVICE"):  # test aid: all ranks on cuda:0 of a 1-GPU box (use with TT_BENCH_BACKEND=gloo)
+        local = 0
     if a.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group(backend=os.environ.get("TT_BENCH_BACKEND", "nccl"), init_method="env://", world_size=world, rank=rank)
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", local if world > 1 else 0)
@@ -186,8 +188,9 @@ def main():
     final_loss = float(loss.item())
 
     out = None
+    # the instrumented step contains the step's collectives (score all-gather, gradient all-reduce): EVERY rank runs it
+    prof = instrumented_step(model, opt, x, a.use_teacher)
     if rank == 0:
-        prof = instrumented_step(model, opt, x, a.use_teacher)
         (dom_name, dom_tile), (cnt, flops, sec) = max(prof.items(), key=lambda kv: kv[1][2])
         all_flops = sum(v[1] for v in prof.values())
         all_sec = sum(v[2] for v in prof.values())
