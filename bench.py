@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--use_teacher", action="store_true")
     ap.add_argument("--use_queue", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the forward Linears for the TIMED region (default f32 = the headline / parity mode)")
+    ap.add_argument("--no_alt_precision", action="store_true", help="skip the secondary bf16x3 / bf16 measurements")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -156,7 +159,7 @@ def main():
 
     bs, fs, K = a.batch_size, a.num_frames, a.num_clusters
     model = build_model(a.architecture, K, device, world=world)
-    total_steps = a.steps + a.warmup + 2
+    total_steps = a.steps + a.warmup + 20
     opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, 1, total_steps), total_steps, 1)
     if a.use_teacher:
         model.init_momentum_teacher()
@@ -167,6 +170,9 @@ def main():
         model._queue_rows_pushed = model.queue.shape[0]
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1 + rank)).to(device)  # resident in HBM before timing
 
+    from timetuning_amd import hip_ops
+
+    hip_ops.set_gemm_precision(a.precision)
     for _ in range(a.warmup):
         train_step(model, opt, x, a.use_teacher)
     torch.cuda.synchronize()
@@ -190,6 +196,30 @@ def main():
     out = None
     # the instrumented step contains the step's collectives (score all-gather, gradient all-reduce): EVERY rank runs it
     prof = instrumented_step(model, opt, x, a.use_teacher)
+    # secondary, clearly-labelled measurements of the opt-in bf16 MFMA modes (same step, forward Linears only change);
+    # `value` above is always the --precision mode (f32 by default).  Every rank takes part (collectives).
+    alt = {}
+    if a.precision == "f32" and not a.no_alt_precision:
+        for mode in ("bf16x3", "bf16"):
+            hip_ops.set_gemm_precision(mode)
+            for _ in range(2):
+                train_step(model, opt, x, a.use_teacher)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            ta = time.perf_counter()
+            for _ in range(5):
+                la = train_step(model, opt, x, a.use_teacher)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt = time.perf_counter() - ta
+            if world > 1:
+                tt_ = torch.tensor([dt], device=device, dtype=torch.float64)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                dt = float(tt_.item())
+            alt[mode] = {"clip_frames_per_sec": round(world * bs * fs * 5 / dt, 1), "ms_per_step": round(dt / 5 * 1e3, 3), "loss": round(float(la.item()), 5)}
+        hip_ops.set_gemm_precision("f32")
     if rank == 0:
         (dom_name, dom_tile), (cnt, flops, sec) = max(prof.items(), key=lambda kv: kv[1][2])
         all_flops = sum(v[1] for v in prof.values())
@@ -202,7 +232,7 @@ def main():
         out = {
             "metric": "clip-frames/sec", "value": round(world * bs * fs * a.steps / elapsed, 2), "unit": "clip-frames/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": ("C2: " if (a.architecture, bs, fs, K) == ("dino-s16", 32, 4, 200) else "") +
                                    f"{a.architecture} full TimeT training step (fwd+bwd+AdamW), {fs}-frame 224x224 clips, {bs} clips/GPU, "
                                    f"{K} prototypes" + (", EMA teacher" if a.use_teacher else "") + (", queue" if a.use_queue else ""),
@@ -217,6 +247,7 @@ def main():
                          "avg_launch_us": round(sec / cnt * 1e6, 2),
                          "all_gemm_tflops": round(all_flops / all_sec / 1e12, 2),
                          "gemm_share_of_step": round(all_sec / (elapsed / a.steps), 3)},
+            "alt_precision": alt or None,
             "sinkhorn": None if sk_rate is None else {"iters_per_sec": round(sk_rate, 1), "algorithmic_GBps": round(sk_gbs, 1),
                                                       "shape": "K=200 x B=6272, 10 iterations"},
         }

@@ -73,6 +73,14 @@ int tt_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
  * 3 = 64x64 (block tile; 4 waves each).  Exposed so that profilers can attribute launches to instantiations. */
 int tt_gemm_tile_choice(int M, int N, int batch);
 
+/* Arithmetic of the forward nn.Linear products (tt_linear_fwd), process-wide:
+ *   0 = f32 MFMA (default; exact fmaf chain, the mode every parity claim and the headline benchmark refer to)
+ *   1 = "bf16x3": operands split into bf16 hi + lo, three bf16 MFMAs per product term (~2^-16 relative per product)
+ *   2 = "bf16":   operands rounded to bf16 (BASELINE config C4's "MFMA bf16 path"; does not meet the 1e-3 fp32 contract)
+ * Inputs/outputs stay fp32 in memory in every mode.  Backward products always run in f32. */
+int tt_set_gemm_precision(int mode);
+int tt_get_gemm_precision(void);
+
 /* ---- k1,k2: PatchEmbed conv (kernel = stride = P) + cls token + pos-embed
  *      (dino_vision_transformer.py:166-171, 236-247)
  *   img [F_src,C,H,W]; frame_map (optional int32[F]): output frame f reads img[frame_map[f]];

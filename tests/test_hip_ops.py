@@ -246,3 +246,23 @@ def test_adamw_ema_queue(ops):
     ref_q[:20] = feats[idx]
     qd = ops.queue_push_(dev(queue), dev(feats), dev(idx))
     assert torch.equal(qd.cpu(), ref_q)
+
+
+@pytest.mark.parametrize("M,N,K", [(1280, 384, 384), (6272, 1024, 1024), (640, 1536, 384)])
+def test_linear_precision_modes(ops, M, N, K):
+    """Opt-in bf16 MFMA instances of the forward Linear: "bf16x3" (split precision) and "bf16" (BASELINE C4), against fp64.
+    The default f32 mode is restored afterwards; every other test in this suite runs in f32."""
+    x, w, b, r = rnd("px", M, K), rnd("pw", N, K, std=0.05), rnd("pb", N), rnd("pr", M, N)
+    ref = F.gelu(F.linear(x.double(), w.double(), b.double())) + r.double()
+    errs = {}
+    try:
+        for mode in ("f32", "bf16x3", "bf16"):
+            ops.set_gemm_precision(mode)
+            assert ops.get_gemm_precision() == mode
+            y = ops.linear_fwd(dev(x), dev(w), dev(b), residual=dev(r), act=1)
+            errs[mode] = rel_err(y.cpu(), ref)
+    finally:
+        ops.set_gemm_precision("f32")
+    assert errs["f32"] < TOL
+    assert errs["bf16x3"] < 1e-4, errs     # ~2^-16 per product, averaged over K
+    assert errs["f32"] < errs["bf16x3"] < errs["bf16"] < 2e-2, errs

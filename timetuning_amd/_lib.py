@@ -41,6 +41,8 @@ SIGNATURES = {
     "tt_colsum": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_gemm_f32": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_ll, c_ll, c_ll, c_vp]),
     "tt_gemm_tile_choice": (c_i, [c_i, c_i, c_i]),
+    "tt_set_gemm_precision": (c_i, [c_i]),
+    "tt_get_gemm_precision": (c_i, []),
     "tt_patch_embed_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "tt_layernorm_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_i, c_vp]),
     "tt_layernorm_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),

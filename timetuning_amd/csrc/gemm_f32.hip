@@ -434,11 +434,24 @@ using tt::base_args;
 namespace tt {
 int try_launch_gemm_nt_fast(const float* A, const float* B, float* C, int M, int N, int K, const float* bias,
                             const float* residual, float* pre_out, int act, hipStream_t s);
+int try_launch_gemm_nt_bf16(const float* A, const float* B, float* C, int M, int N, int K, const float* bias, const float* residual,
+                            float* pre_out, int act, int npass, hipStream_t s);
+int g_gemm_precision = 0;  // 0 = f32 MFMA (default, exact), 1 = bf16x3 split, 2 = bf16; forward nn.Linear only
 int try_launch_dgrad_fast(const float* dy, const float* w, const float* gelu_pre, float* dx, int M, int N, int K, hipStream_t s);
 int try_launch_wgrad_fast(const float* dy, const float* x, float* out, int M, int N, int K, int splits, int kchunk, hipStream_t s);
 }
 
 extern "C" int tt_gemm_tile_choice(int M, int N, int batch) { return tt::gemm_tile_choice(M, N, batch); }
+
+extern "C" int tt_set_gemm_precision(int mode) {
+  if (mode < 0 || mode > 2) {
+    tt::set_error("set_gemm_precision: mode must be 0 (f32), 1 (bf16x3) or 2 (bf16), got %d", mode);
+    return TT_EINVAL;
+  }
+  tt::g_gemm_precision = mode;
+  return TT_OK;
+}
+extern "C" int tt_get_gemm_precision(void) { return tt::g_gemm_precision; }
 
 extern "C" int tt_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                            int a_mmajor, int b_nmajor, float alpha, int batch, long long strideA, long long strideB,
@@ -451,7 +464,13 @@ extern "C" int tt_gemm_f32(const float* A, const float* B, float* C, int M, int 
 
 extern "C" int tt_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                              float* pre_act, int M, int N, int K, int act, tt_stream_t stream) {
-  if (x && w && y && M > 0 && N > 0 && K > 0) {  // whole-tile, aligned shapes take the lean kernel (gemm_nt_fast.hip)
+  if (x && w && y && M > 0 && N > 0 && K > 0) {
+    if (tt::g_gemm_precision != 0) {  // opt-in bf16 / split-bf16 MFMA instances (gemm_nt_bf16.hip)
+      const int rc = tt::try_launch_gemm_nt_bf16(x, w, y, M, N, K, bias, residual, pre_act, act, tt::g_gemm_precision == 1 ? 3 : 1,
+                                                 tt::as_stream(stream));
+      if (rc <= 0) return rc;
+    }
+    // whole-tile, aligned shapes take the lean f32 kernel (gemm_nt_fast.hip)
     const int rc = tt::try_launch_gemm_nt_fast(x, w, y, M, N, K, bias, residual, pre_act, act, tt::as_stream(stream));
     if (rc <= 0) return rc;
   }

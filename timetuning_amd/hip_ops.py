@@ -38,6 +38,22 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+_PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
+
+
+def set_gemm_precision(mode: str) -> None:
+    """Arithmetic of the forward nn.Linear products: "f32" (default, exact), "bf16x3" (split-bf16, ~2^-16 per product) or
+    "bf16" (BASELINE C4's MFMA bf16 path).  Process-wide; see tt_set_gemm_precision in include/timetuning_hip.h."""
+    if mode not in _PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+    _lib.check(_lib.load().tt_set_gemm_precision(_PRECISIONS[mode]), "tt_set_gemm_precision")
+
+
+def get_gemm_precision() -> str:
+    v = _lib.load().tt_get_gemm_precision()
+    return {n: k for k, n in _PRECISIONS.items()}[v]
+
+
 # bench.py sets PROFILE to a list to get (layout, tile_choice, flops, start_event, end_event) per GEMM launch,
 # recorded with HIP events on the stream the kernel is launched on.
 PROFILE = None

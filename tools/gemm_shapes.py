@@ -4,6 +4,7 @@ import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from timetuning_amd import hip_ops as ops
+if os.environ.get('TT_PRECISION'): ops.set_gemm_precision(os.environ['TT_PRECISION'])
 for arg in sys.argv[1:]:
     p = [int(v) for v in arg.split(",")]
     M, N, K = p[:3]; act = p[3] if len(p) > 3 else 0
