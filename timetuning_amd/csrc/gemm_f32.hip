@@ -11,10 +11,12 @@
 //
 // Operand staging.  The MFMA wants, per lane l, A[row = l & 31][k = l >> 5] and B[k = l >> 5][col = l & 31]; WHICH two k
 // values the two half-waves supply is free as long as A and B agree, so MFMA number i of k-group j uses
-// k = 8 j + 4 (l >> 5) + i.  That makes the operand of a k-contiguous source (activations [M][K], nn.Linear weights
-// [N][K] - every forward GEMM) four consecutive floats of one LDS row: ONE ds_read_b128 feeds four MFMAs, and the
-// global float4 goes to LDS unchanged with one ds_write_b128 (row stride BK + 4 floats: conflict-free for b128).
-// An m/n-contiguous source (dgrad / wgrad operands) keeps a k-major image ([k][m], stride BM + 4) read with ds_read_b32.
+// k = 8 j + 4 (l >> 5) + i.  The LDS image is k-major ([k][m], stride BM + 4) for every operand and a fragment is one
+// ds_read_b32 per MFMA operand: an m/n-contiguous source (dgrad / wgrad operands) is copied with 16-byte LDS writes, a
+// k-contiguous source (activations [M][K], nn.Linear weights [N][K]) is transposed on the way in (four scalar writes per
+// float4).  The alternative [row][k] image with ds_read_b128 fragments (TT_KLAYOUT) measured slower and is off.
+// This is the GENERAL kernel (any extents, alignments and layouts); whole-tile products take the lean instances in
+// gemm_nt_fast.hip / gemm_bwd_fast.hip / gemm_nt_bf16.hip.
 //
 // Epilogue (fused): alpha, bias, pre-activation store, exact GELU, row scale,
 // GELU-derivative multiply (dgrad through fc1 / head activations), residual add, and for the patch-embed instance the
