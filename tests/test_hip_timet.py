@@ -222,3 +222,45 @@ def test_precision_modes_end_to_end(golden, mode, feat_tol):
         assert abs(loss.item() - float(g["loss0"])) < 1e-3 * float(g["loss0"])
     else:
         assert abs(loss.item() - float(g["loss0"])) < 0.1
+
+
+@pytest.mark.parametrize("bs,fs,K,teacher,queue", [(1, 2, 8, False, 0), (3, 5, 30, False, 0), (5, 3, 21, True, 0), (2, 9, 12, False, 30),
+                                                   (4, 2, 200, True, 64)])
+def test_ragged_configurations_vs_oracle(bs, fs, K, teacher, queue):
+    """Odd batch sizes, clip lengths (fs = 9 exercises the 7-frame context ring of propagate_labels), prototype counts that
+    are not multiples of 4 (element-load GEMM path), teacher and queue: loss, labels and gradients against the oracle."""
+    from oracle import timet_oracle as O
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    cfg, head = synth.ARCHS["tiny-s16"], (128, 128, 64, 32)
+    fe = FeatureExtractor("dino-s16", "", list(head), unfreeze_layers=["blocks.11", "blocks.10"], vit_cfg=cfg, init="stress", return_attention=False)
+    model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, fe.feature_dim))).cuda()
+    om = O.build_oracle("dino-s16", K, head, mode="stress", vit_cfg=cfg)
+    if teacher:
+        model.init_momentum_teacher()
+        om.init_momentum_teacher()
+    if queue:
+        model.init_queue(queue)
+        om.init_queue(queue)
+        fill = torch.from_numpy(synth.normal("ragged.queue", (queue, 32)))
+        model.queue.copy_(fill)
+        model._queue_rows_pushed = queue
+        om.queue.copy_(fill)
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=7))
+    perm = torch.randperm(bs * 196)
+    loss = model.get_loss(x.cuda(), queue_perm=perm)
+    loss.backward()
+    oloss, aux = om.get_loss(x, faithful=False, return_aux=True, queue_perm=perm)
+    oloss.backward()
+    assert rel_err(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL
+    mism = (model.last_aux["labels"].cpu() != aux["labels"].reshape(bs, -1)).float().mean().item()
+    assert mism <= 0.01
+    if mism == 0:
+        assert abs(loss.item() - oloss.item()) < 2e-4
+        og, mg = dict(om.named_parameters()), dict(model.named_parameters())
+        for name in ("prototypes", "feature_extractor.head.0.weight", "feature_extractor.backbone.blocks.11.mlp.fc2.weight",
+                     "feature_extractor.backbone.blocks.10.norm1.weight"):
+            assert rel_err(mg[name].grad.cpu(), og[name].grad) < TOL, name
+    if queue:
+        assert rel_err(model.queue.cpu(), om.queue) < 1e-4
