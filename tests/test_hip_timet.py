@@ -264,3 +264,24 @@ def test_ragged_configurations_vs_oracle(bs, fs, K, teacher, queue):
             assert rel_err(mg[name].grad.cpu(), og[name].grad) < TOL, name
     if queue:
         assert rel_err(model.queue.cpu(), om.queue) < 1e-4
+
+
+def test_bf16x3_full_size_c1(golden):
+    """Split-bf16 forward Linears on the full-size ViT-S/16 C1 fixture: patch embeddings, head features and loss stay inside
+    the north-star 1e-3 bound against the reference's own numbers."""
+    from timetuning_amd import hip_ops
+
+    g = golden("timet_c1")
+    model, _ = _build(g)
+    bs, fs = int(g["cfg"][0]), int(g["cfg"][1])
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1)).cuda()
+    try:
+        hip_ops.set_gemm_precision("bf16x3")
+        f, _ = model.feature_extractor(x.view(bs * fs, 3, 224, 224))
+        bf, _ = model.feature_extractor(x.view(bs * fs, 3, 224, 224), use_head=False)
+        loss = model.get_loss(x)
+    finally:
+        hip_ops.set_gemm_precision("f32")
+    assert rel_err(f[:, ::49, ::16].cpu(), g["features_slice"]) < TOL
+    assert rel_err(bf[:, ::49, ::16].cpu(), g["backbone_features_slice"]) < TOL
+    assert abs(loss.item() - float(g["loss0"])) < 1e-3 * float(g["loss0"])
