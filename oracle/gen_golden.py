@@ -101,6 +101,21 @@ def import_reference():
             pass
 
     tt.writer = _W()
+
+    # --use_mask branch: models.process_attentions calls torchvision's GaussianBlur and skimage's label, neither of
+    # which is installed here.  The oracle's restatements of their published algorithms stand in for them (and are
+    # declared "parity unpinned" there); the reference's own code around them then runs unchanged.
+    import timet_oracle as orc
+
+    class _GaussianBlurStandIn:
+        def __init__(self, kernel_size, sigma):
+            self.kernel_size, self.sigma = kernel_size, sigma
+
+        def __call__(self, img):
+            return orc.gaussian_blur(img, self.kernel_size, self.sigma)
+
+    models.GaussianBlur = _GaussianBlurStandIn
+    models.label = orc.label_components
     return dict(tt=tt, my_utils=my_utils, mp=mp, models=models, state=state, writer=_W())
 
 
@@ -245,7 +260,22 @@ def _grad_dict(model, names):
     return {n: t2n(g[n]) for n in names}, {n: float(v.double().norm()) for n, v in g.items()}
 
 
-def gen_timet(ref, tag, arch, cfg, K, head_list, bs, fs, mode, teacher, queue, steps, full_tensors):
+def gen_timet_masked(ref, tag, *args):
+    """--use_mask fixtures: smooth clips, and a search over clip seeds for a run in which the reference does not hit
+    its IndexError on small mask components (models.py:127-130) in any frame of any step."""
+    for seed0 in range(0, 400, 10):
+        try:
+            gen_timet(ref, tag, *args, use_mask=True, clip_seed0=seed0)
+            print(f"  {tag}: reference survived with clip seed base {seed0}")
+            return
+        except IndexError as e:
+            if "mask" not in str(e):
+                raise
+            print(f"  {tag}: clip seed base {seed0} trips the reference's small-component IndexError, trying the next")
+    raise RuntimeError("no surviving seed found")
+
+
+def gen_timet(ref, tag, arch, cfg, K, head_list, bs, fs, mode, teacher, queue, steps, full_tensors, use_mask=False, clip_seed0=0):
     """One or more reference training iterations; saves loss, labels, grads, post-step parameters."""
     import torch
 
@@ -264,13 +294,18 @@ def gen_timet(ref, tag, arch, cfg, K, head_list, bs, fs, mode, teacher, queue, s
                head_list=np.array(head_list, np.int64))
     out["arch"] = np.array(arch)
     out["mode"] = np.array(mode)
+    out["use_mask"] = np.int64(use_mask)
+    out["clip_seed0"] = np.int64(clip_seed0)
     out["vit_cfg"] = np.array([cfg["embed_dim"], cfg["depth"], cfg["num_heads"], cfg["patch_size"]], np.int64)
     watch = ["prototypes", "feature_extractor.head.6.weight", "feature_extractor.head.0.bias",
              "feature_extractor.backbone.blocks.11.mlp.fc2.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight",
              "feature_extractor.backbone.blocks.10.norm1.weight", "feature_extractor.backbone.blocks.11.attn.proj.bias"]
     n_tok = (224 // cfg["patch_size"]) ** 2
     for s in range(steps):
-        x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1 + s, coherent=True))
+        if use_mask:
+            x = torch.from_numpy(synth.make_smooth_clips(bs, fs, 224, seed=clip_seed0 + 1 + s))
+        else:
+            x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1 + s, coherent=True))
         torch.manual_seed(100 + s)
         perm = torch.randperm(bs * n_tok)
         torch.manual_seed(100 + s)
@@ -291,7 +326,12 @@ def gen_timet(ref, tag, arch, cfg, K, head_list, bs, fs, mode, teacher, queue, s
             torch.manual_seed(100 + s)
         out[f"perm{s}"] = t2n(perm)
         # replay get_loss's internals we want to pin (labels, q) without touching the model state:
-        loss = model(x, None, True, False)
+        if use_mask and s == 0:  # the masks get_loss is about to build, for diagnosis of a mismatch
+            with torch.no_grad():
+                _, attn_s = model.feature_extractor(x.view(bs * fs, 3, 224, 224))
+                out["student_mask0"] = t2n(ref["models"].process_attentions(attn_s, model.feature_extractor.spatial_resolution))
+            torch.manual_seed(100 + s)
+        loss = model(x, None, True, use_mask)
         out[f"loss{s}"] = np.float64(loss.item())
         swav.optimizer.zero_grad()
         loss.backward()
@@ -361,6 +401,44 @@ def gen_aux(ref, tag, arch, cfg, K, head_list, bs, fs, mode):
     print(f"aux_{tag}.npz written")
 
 
+def gen_mask(ref):
+    """models.process_attentions (with the blur / component-labelling stand-ins) on synthetic attention maps:
+    peaked random maps at g = 14 and 28, plus hand-made cases for the small-component rule."""
+    import torch
+
+    out = {}
+    for g, F_, H in ((14, 8, 6), (28, 6, 6), (7, 6, 2)):
+        n = g * g
+        gen = torch.Generator().manual_seed(7 + g)
+        # speckle amplitude grows with the frame index: smooth maps (no small components, the reference survives) first
+        amp = torch.tensor([0.02, 0.05, 0.1, 0.2, 0.4, 0.8, 1.5, 2.5])[:F_].view(F_, 1, 1, 1)
+        logits = amp * torch.randn(F_, H, n + 1, n + 1, generator=gen)
+        yy, xx = torch.meshgrid(torch.arange(g), torch.arange(g), indexing="ij")
+        for f in range(F_):  # a blob per frame so that the kept mass is spatially coherent, plus speckle
+            cy, cx = float(2 + 3 * f % g), float(g - 3 - 2 * f % g)
+            blob = 3.0 * torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2.0 * (g / 5.0) ** 2))
+            logits[f, :, 0, 1:] += blob.reshape(-1)
+        attn = logits.softmax(dim=-1)
+        # The reference indexes a [g,g] tensor with the [1,g,g] component mask (models.py:127-130), which raises
+        # IndexError as soon as a frame HAS a component of <= 2 pixels.  Frames are therefore run one at a time: where
+        # the reference survives its mask is the expected value (ref_ok = 1); where it raises, the fixture only records
+        # that fact and the intended behaviour (drop the small components) is checked oracle-vs-HIP in the tests.
+        masks, ok = [], []
+        for f in range(F_):
+            try:
+                masks.append(t2n(ref["models"].process_attentions(attn[f:f + 1], g))[0])
+                ok.append(1)
+            except IndexError:
+                masks.append(np.zeros((1, g, g), np.float32))
+                ok.append(0)
+        out[f"attn_cls_g{g}"] = t2n(attn[:, :, 0, :])
+        out[f"mask_g{g}"] = np.stack(masks)
+        out[f"ref_ok_g{g}"] = np.array(ok, np.int64)
+        print(f"  g={g}: reference survived {sum(ok)}/{F_} frames")
+    np.savez_compressed(os.path.join(OUT, "attention_mask.npz"), **out)
+    print("attention_mask.npz written")
+
+
 def gen_sched(ref):
     cs = ref["my_utils"].cosine_scheduler
     np.savez_compressed(os.path.join(OUT, "schedules.npz"), wd_1_4=cs(0.04, 0.4, 1, 4), ema_2_5=cs(0.995, 1.0, 2, 5),
@@ -386,6 +464,10 @@ def main():
         "aux_tiny": lambda: gen_aux(ref, "tiny", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "stress"),
         "timet_tiny": lambda: gen_timet(ref, "tiny", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "stress", False, 0, 3, True),
         "timet_tiny_tq": lambda: gen_timet(ref, "tiny_tq", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 2, "stress", True, 40, 3, True),
+        "mask": lambda: gen_mask(ref),
+        "timet_tiny_mask": lambda: gen_timet_masked(ref, "tiny_mask", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "dino", False, 0, 2, True),
+        "timet_tiny_mask_tq": lambda: gen_timet_masked(ref, "tiny_mask_tq", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 2, "dino", True, 40, 2,
+                                                       True),
     }
     if a.full:
         s16 = synth.ARCHS["dino-s16"]

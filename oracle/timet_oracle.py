@@ -265,6 +265,91 @@ def propagate_labels(n_last_frames, size_mask_neighborhood, topk, spatial_resolu
 
 
 # --------------------------------------------------------------------------------------
+# attention foreground mask  (models.py:93-144, the --use_mask branch)
+#
+# PARITY OF THIS SECTION: the reference calls two third-party functions that are not installed
+# in the build image and whose sources are not under /root/reference:
+#   torchvision.transforms.GaussianBlur (torchvision==0.15.x per requirements) and
+#   skimage.measure.label (scikit-image).
+# ``gaussian_blur`` and ``label_components`` restate their PUBLISHED algorithms and are therefore
+# "parity unpinned".  Everything around them (head mean, mass threshold, small-component removal,
+# feature masking, masked cross-entropy) IS pinned: gen_golden.py runs the reference's own
+# process_attentions / apply_attention_mask / get_loss with these two functions injected as the
+# stand-ins for the missing imports.
+# --------------------------------------------------------------------------------------
+
+
+def gaussian_kernel1d(kernel_size: int, sigma: float) -> torch.Tensor:
+    """torchvision.transforms.functional._get_gaussian_kernel1d: pdf on linspace(-h, h, k), normalised."""
+    half = (kernel_size - 1) * 0.5
+    x = torch.linspace(-half, half, steps=kernel_size)
+    pdf = torch.exp(-0.5 * (x / sigma).pow(2))
+    return pdf / pdf.sum()
+
+
+def gaussian_blur(img: torch.Tensor, kernel_size: int = 7, sigma: float = 0.6) -> torch.Tensor:
+    """torchvision GaussianBlur(kernel_size, sigma) on [B,C,H,W]: reflect padding, depthwise conv with the outer
+    product kernel.  GaussianBlur draws sigma from uniform_(s, s) in fp32, i.e. float32(sigma)."""
+    sigma = float(torch.tensor(sigma, dtype=torch.float32))
+    k1 = gaussian_kernel1d(kernel_size, sigma)
+    k2 = torch.mm(k1[:, None], k1[None, :])
+    C = img.shape[1]
+    pad = kernel_size // 2
+    x = F.pad(img, [pad, pad, pad, pad], mode="reflect")
+    return F.conv2d(x, k2.expand(C, 1, kernel_size, kernel_size), groups=C)
+
+
+def label_components(binary: np.ndarray) -> np.ndarray:
+    """skimage.measure.label(arr) with its defaults: background 0, full connectivity (arr.ndim); here through
+    scipy.ndimage.label with an all-ones structuring element.  Label numbering is not relied upon."""
+    from scipy import ndimage
+
+    lab, _ = ndimage.label(binary != 0, structure=np.ones((3,) * binary.ndim))
+    return lab
+
+
+def process_attentions(attentions: torch.Tensor, spatial_res: int, threshold: float = 0.65, blur_sigma: float = 0.6,
+                       return_blurred: bool = False):
+    """models.py:93-131.  attentions [F,h,N,N] -> {0,1} mask [F,1,g,g]."""
+    attention = attentions[:, :, 0, 1:]
+    bs, num_heads, _ = attention.shape
+    attention = attention.reshape(bs, num_heads, spatial_res, spatial_res)
+    attention = sum(attention[:, i] * 1 / num_heads for i in range(num_heads))  # :111-112
+    attention = attention.reshape(bs, 1, spatial_res, spatial_res)
+    attention = gaussian_blur(attention, 7, blur_sigma)
+    blurred = attention.reshape(bs, spatial_res ** 2).clone()
+    attention = attention.reshape(bs, 1, spatial_res ** 2)
+    val, idx = torch.sort(attention)  # keep `threshold` of the mass (:117-123)
+    val = val / torch.sum(val, dim=-1, keepdim=True)
+    cumval = torch.cumsum(val, dim=-1)
+    th_attn = cumval > (1 - threshold)
+    idx2 = torch.argsort(idx)
+    th_attn[:, 0] = torch.gather(th_attn[:, 0], dim=1, index=idx2[:, 0])
+    th_attn = th_attn.reshape(bs, 1, spatial_res, spatial_res).float()
+    for j in range(bs):  # components of <= 2 pixels are dropped (:125-130)
+        labelled = label_components(th_attn[j].numpy())
+        for k in range(1, int(labelled.max()) + 1):
+            comp = labelled == k
+            if comp.sum() <= 2:
+                th_attn[j, 0][torch.from_numpy(comp[0])] = 0
+    th_attn = th_attn.detach()
+    if return_blurred:
+        # distance of the sorted cumulative mass to the cut, per pixel: tests use it to excuse pixels whose side of the
+        # threshold depends on the last bits of the attention values
+        margin = torch.gather((cumval - (1 - threshold)).abs()[:, 0], 1, idx2[:, 0])
+        return th_attn, blurred, margin
+    return th_attn
+
+
+def apply_attention_mask(features: torch.Tensor, attentions: torch.Tensor, spatial_resolution: int):
+    """models.py:133-144.  features [bs,fs,n,dim], attentions [bs*fs,h,N,N] -> (masked features, mask [bs,fs,n])."""
+    mask = process_attentions(attentions, spatial_resolution)
+    bs, fs, n, dim = features.shape
+    mask = mask.view(bs, fs, n, 1)
+    return features * mask, mask.squeeze()
+
+
+# --------------------------------------------------------------------------------------
 # TimeT objective  (time_tuning.py:80-302)
 # --------------------------------------------------------------------------------------
 
@@ -346,8 +431,8 @@ class TimeTOracle:
         return torch.stack(propagate_labels(n_last_frames, size_mask_neighborhood, topk, g, feats_i, seed))
 
     def get_loss(self, x, n_last_frames=7, size_mask_neighborhood=6, topk=5, epsilon=0.05,
-                 sinkhorn_iterations=10, queue_perm=None, faithful=True, return_aux=False):
-        """time_tuning.py:224-302 (``mask_features=False`` branch).
+                 sinkhorn_iterations=10, queue_perm=None, faithful=True, return_aux=False, mask_features=False):
+        """time_tuning.py:224-302; ``mask_features`` is the --use_mask branch (:226-227,235-236,244-246,282-283,298-299).
 
         ``queue_perm``: the permutation ``torch.randperm(bs*n)`` draws at :259; passing it makes the
         queue update reproducible.  ``faithful`` keeps the reference's redundant passes."""
@@ -355,11 +440,14 @@ class TimeTOracle:
         g = fe.spatial_resolution
         bs, fs, c, h, w = x.shape
         flat = x.view(bs * fs, c, h, w)
+        faithful = faithful or mask_features  # the masks need the last block's attention
         if self.teacher is not None:
             with torch.no_grad():
-                teacher_features, _ = self.teacher(flat, faithful=faithful)
+                teacher_features, teacher_attentions = self.teacher(flat, faithful=faithful)
             teacher_features = teacher_features.view(bs, fs, *teacher_features.shape[1:])
-        features, _ = fe(flat, faithful=faithful)
+            if mask_features:
+                teacher_features, _ = apply_attention_mask(teacher_features, teacher_attentions, g)
+        features, attentions = fe(flat, faithful=faithful)
         with torch.no_grad():
             if faithful:
                 backbone_features, _ = fe(flat, use_head=False, faithful=True)
@@ -368,6 +456,10 @@ class TimeTOracle:
         npatch, dim = features.shape[1:]
         features = features.view(bs, fs, npatch, dim)
         backbone_features = backbone_features.view(bs, fs, npatch, -1)
+        masks = None
+        if mask_features:
+            features, masks = apply_attention_mask(features, attentions, g)
+            masks = masks.view(bs, fs, g, g)
         source_features = features[:, 0]
 
         if self.queue is not None:  # :250-261
@@ -395,14 +487,17 @@ class TimeTOracle:
             p_map = maps[-1]
             target_scores = target_batch_scores[i].view(g, g, -1).permute(2, 0, 1)
             labels = p_map.unsqueeze(0).argmax(dim=1).long()
-            loss = F.cross_entropy(target_scores.unsqueeze(0) / 0.1, labels)
+            if mask_features:  # reduction='none', weighted by the target frame's mask, mean over ALL g*g patches
+                loss = F.cross_entropy(target_scores.unsqueeze(0) / 0.1, labels, reduction="none") * masks[i, -1].unsqueeze(0)
+            else:
+                loss = F.cross_entropy(target_scores.unsqueeze(0) / 0.1, labels)
             batch_loss = batch_loss + loss.mean()
             labels_all.append(labels[0])
             pmaps.append(p_map)
         loss = batch_loss / bs
         if return_aux:
             return loss, dict(batch_q=batch_q, target_scores=target_batch_scores, labels=torch.stack(labels_all),
-                              p_map=torch.stack(pmaps), features=features, backbone_features=backbone_features)
+                              p_map=torch.stack(pmaps), features=features, backbone_features=backbone_features, masks=masks)
         return loss
 
 

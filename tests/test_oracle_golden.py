@@ -113,9 +113,18 @@ def _run_steps(g, teacher, queue):
         m.set_momentum_teacher_schedular_params(0.995, 1.0, E, I)
     params = dict(m.named_parameters())
     assert [len(gr["params"]) for gr in opt.groups] == list(g["group_sizes"])
+    use_mask = bool(int(g["use_mask"])) if "use_mask" in g.files else False
     for s in range(steps):
-        x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1 + s))
-        loss = m.get_loss(x, queue_perm=g[f"perm{s}"])
+        if use_mask:
+            x = torch.from_numpy(synth.make_smooth_clips(bs, fs, 224, seed=int(g["clip_seed0"]) + 1 + s))
+        else:
+            x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1 + s))
+        if use_mask and s == 0:
+            with torch.no_grad():
+                _, attn = m.feature_extractor(x.view(bs * fs, 3, 224, 224))
+            mask0 = O.process_attentions(attn, m.feature_extractor.spatial_resolution).numpy()
+            assert (mask0 == g["student_mask0"]).all() and 0 < mask0.mean() < 1
+        loss = m.get_loss(x, queue_perm=g[f"perm{s}"], mask_features=use_mask)
         assert abs(loss.item() - float(g[f"loss{s}"])) < 2e-5, (s, loss.item(), float(g[f"loss{s}"]))
         opt.zero_grad()
         loss.backward()
@@ -149,6 +158,61 @@ def test_training_steps_tiny(golden):
 
 def test_training_steps_tiny_teacher_queue(golden):
     _run_steps(golden("timet_tiny_tq"), True, 40)
+
+
+def test_training_steps_tiny_use_mask(golden):
+    """--use_mask branch of get_loss (time_tuning.py:226-227,235-236,244-246,282-283,298-299)."""
+    _run_steps(golden("timet_tiny_mask"), False, 0)
+
+
+def test_training_steps_tiny_use_mask_teacher_queue(golden):
+    _run_steps(golden("timet_tiny_mask_tq"), True, 40)
+
+
+def _attn_from_cls_rows(cls):
+    F_, H, N = cls.shape
+    attn = torch.zeros(F_, H, N, N)
+    attn[:, :, 0, :] = torch.from_numpy(cls)
+    return attn
+
+
+@pytest.mark.parametrize("g_", [14, 28, 7])
+def test_process_attentions(golden, g_):
+    """models.process_attentions (models.py:93-131) on the frames the reference itself survives (it raises IndexError
+    on any frame that HAS a <= 2-pixel component, models.py:127-130: a [1,g,g] numpy mask indexes a [g,g] tensor)."""
+    d = golden("attention_mask")
+    ok = d[f"ref_ok_g{g_}"].astype(bool)
+    assert ok.sum() >= 4
+    mask = O.process_attentions(_attn_from_cls_rows(d[f"attn_cls_g{g_}"]), g_).numpy()
+    assert (mask[ok] == d[f"mask_g{g_}"][ok]).all()
+    assert set(np.unique(mask)) <= {0.0, 1.0}
+
+
+def test_process_attentions_small_components():
+    """The intended behaviour on the frames the reference cannot process: components of 1 or 2 pixels (8-connected)
+    disappear, 3-pixel components and everything else stay."""
+    g_ = 7
+    th = np.zeros((g_, g_), np.float32)
+    th[0, 0] = 1                      # single pixel
+    th[0, 3] = th[1, 4] = 1           # diagonal pair
+    th[3, 0] = th[4, 0] = th[5, 1] = 1  # 3 pixels, one diagonal link -> stays
+    th[4:7, 4:7] = 1                  # block
+    lab = O.label_components(th[None])
+    sizes = sorted((lab == k).sum() for k in range(1, lab.max() + 1))
+    assert sizes == [1, 2, 3, 9]
+
+
+def test_gaussian_blur_properties():
+    """Restated torchvision GaussianBlur(7, 0.6): normalised symmetric kernel, reflect padding keeps constants."""
+    k = O.gaussian_kernel1d(7, 0.6)
+    assert abs(k.sum().item() - 1) < 1e-6 and torch.allclose(k, k.flip(0)) and k.argmax().item() == 3
+    np.testing.assert_allclose(k[3].item() / k[2].item(), np.exp(0.5 / 0.36), rtol=1e-5)
+    x = torch.full((2, 1, 14, 14), 0.37)
+    assert torch.allclose(O.gaussian_blur(x), x, atol=1e-6)
+    imp = torch.zeros(1, 1, 14, 14)
+    imp[0, 0, 7, 7] = 1.0
+    out = O.gaussian_blur(imp)
+    assert torch.allclose(out[0, 0, 4:11, 4:11], torch.outer(k, k), atol=1e-7)
 
 
 def test_state_dict_layout(golden):

@@ -151,13 +151,46 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
+#ifdef TT_DIRECT_EPI
+          for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[n][q], a[i][q], acc[i][n], 0, 0, 0);
+#else
           for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[n][q], acc[i][n], 0, 0, 0);
+#endif
     }
 #endif
     if (kt + 1 < nk) sstore(buf ^ 1);
     __syncthreads();
   }
 
+#ifdef TT_DIRECT_EPI
+  // ---- epilogue straight from the accumulators: the MFMA ran with the operands swapped (D^T = W X^T), so a lane holds
+  // ONE output row (m = lane & 31) and runs of 4 consecutive columns -> 16-byte stores, no LDS pass, no barriers.
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const size_t rowoff = (size_t)(m0 + wm * (32 * WM) + i * 32 + r) * g.N;
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * (32 * WN) + j * 32 + 8 * q + 4 * h;
+        float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        if (g.bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(g.bias + n);
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        }
+        if (g.pre_out) *reinterpret_cast<float4*>(g.pre_out + rowoff + n) = v;
+        if (g.act == 1) {
+          v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+        }
+        if (g.residual) {
+          const float4 rs = *reinterpret_cast<const float4*>(g.residual + rowoff + n);
+          v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+        }
+        *reinterpret_cast<float4*>(g.C + rowoff + n) = v;
+      }
+  }
+  return;
+#endif
   // ---- epilogue through LDS: one wave-row (32 * WM tile rows) at a time
   constexpr int CH = 32 * WM, LDCS = BN + 4, TPR = BN / 4, RPP = 256 / TPR;
   static_assert(CH * LDCS <= 2 * (ASZ + BSZ), "epilogue staging must fit the pipeline buffers");

@@ -18,17 +18,21 @@
 // the partials in a fixed order (deterministic, no atomics).  Kernel boundaries (~1.5 us) are cheaper than a grid
 // barrier (~4-7 us) on this chip, so each iteration is its own launch.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace tt {
 
 constexpr int SK_KPL = 8;      // K <= 512
-constexpr int SK_MAXWG = 64;
+constexpr int SK_MAXWG = 256;  // buffer capacity; the default policy uses up to SK_DEFWG
+constexpr int SK_DEFWG = 64;
 constexpr int SK_THREADS = 1024;
 constexpr int SK_WAVES = SK_THREADS / 64;
 
 static int sk_wgs(int B) {
   int w = (B + 2 * SK_WAVES - 1) / (2 * SK_WAVES);  // >= 2 rows per wave
-  return w > SK_MAXWG ? SK_MAXWG : (w < 1 ? 1 : w);
+  static const int cap_env = [] { const char* e = getenv("TT_SK_WGS"); return e ? atoi(e) : 0; }();  // tuning aid
+  const int cap = (cap_env > 0 && cap_env <= SK_MAXWG) ? cap_env : SK_DEFWG;
+  return w > cap ? cap : (w < 1 ? 1 : w);
 }
 
 // block-wide fold of per-wave register partials acc[SK_KPL] (lane owns k = lane + 64 i) into out[k]

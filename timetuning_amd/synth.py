@@ -147,3 +147,22 @@ def make_clips(bs: int, fs: int, img: int = 224, seed: int = 1, coherent: bool =
     noise = normal(name + ".noise", (bs, fs, 3, img, img), 0.05, 0.0, seed)
     frames = [np.roll(base[:, 0], shift=(2 * t, 2 * t), axis=(-2, -1)) for t in range(fs)]
     return (np.stack(frames, axis=1) + noise).astype(np.float32)
+
+
+def make_smooth_clips(bs: int, fs: int, img: int = 224, seed: int = 1, grid: int = 5, amplitude: float = 1.5,
+                      noise_std: float = 0.02, name: str = "smooth_clips") -> np.ndarray:
+    """Clips whose frames are LOW-FREQUENCY fields (a ``grid x grid`` normal lattice per channel, bilinearly
+    interpolated to ``img x img``) plus a little noise; frame t is a (4t, 4t)-pixel roll of frame 0.
+
+    Natural frames give the ViT spatially smooth cls-attention; white-noise frames (``make_clips``) give speckled
+    attention.  The ``--use_mask`` fixtures need the former: the reference's ``process_attentions`` raises on any
+    frame whose thresholded attention has a component of <= 2 pixels (see oracle/gen_golden.py)."""
+    lattice = normal(name + ".lattice", (bs, 3, grid, grid), amplitude, 0.0, seed).astype(np.float64)
+    pos = np.linspace(0.0, grid - 1.0, img)
+    i0 = np.minimum(np.floor(pos).astype(np.int64), grid - 2)
+    w = pos - i0
+    rows = lattice[:, :, i0, :] * (1.0 - w)[None, None, :, None] + lattice[:, :, i0 + 1, :] * w[None, None, :, None]
+    base = rows[:, :, :, i0] * (1.0 - w) + rows[:, :, :, i0 + 1] * w                       # [bs,3,img,img]
+    noise = normal(name + ".noise", (bs, fs, 3, img, img), noise_std, 0.0, seed)
+    frames = [np.roll(base, shift=(4 * t, 4 * t), axis=(-2, -1)) for t in range(fs)]
+    return (np.stack(frames, axis=1) + noise).astype(np.float32)

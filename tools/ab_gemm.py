@@ -40,6 +40,14 @@ def main():
                 torch.cuda.synchronize()
                 if rd >= 2:
                     res[p].append(e0.elapsed_time(e1) * 1e-3 / 5)
+        outs = []
+        for p, lib in libs:  # the builds must agree bit for bit unless the summation order changed
+            yo = torch.empty(M, N, device="cuda")
+            lib.tt_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, yo.data_ptr(), None, M, N, K, act, st)
+            outs.append(yo)
+        torch.cuda.synchronize()
+        diff = max((o - outs[0]).abs().max().item() for o in outs)
+        print(f"  max |diff| vs first build: {diff:.3e}")
         fl = 2.0 * M * N * K
         print(name, M, N, K, " | ".join(f"{os.path.basename(p)}: med {fl / statistics.median(v) / 1e12:6.1f} max {fl / min(v) / 1e12:6.1f} TF" for p, v in res.items()))
 

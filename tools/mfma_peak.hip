@@ -20,7 +20,15 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, const float* __r
   __shared__ float lds[2 * 16 * (132 + 132)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+#ifdef RAND_LDS  // full-entropy mantissas: the MFMA datapath's power (and so the sustained clock) depends on the operand bits
+  for (int i = tid; i < 2 * 16 * 264; i += 256) {
+    unsigned s = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+    s ^= s >> 15; s *= 2246822519u; s ^= s >> 13;
+    lds[i] = ((int)(s >> 8) % 20001 - 10000) * 1e-4f;
+  }
+#else
   for (int i = tid; i < 2 * 16 * 264; i += 256) lds[i] = (float)(i % 7) * 0.01f;
+#endif
   __syncthreads();
   f32x16 acc[2][2];
   for (int i = 0; i < 2; ++i)
