@@ -43,8 +43,11 @@ def build_model(arch, K, device, teacher=False, queue=0, world=1):
     return model
 
 
+USE_MASK = False  # --use_mask: the attention-masked variant of the objective (not the headline workload)
+
+
 def train_step(model, opt, x, use_teacher):
-    loss = model(x, None, True, False)
+    loss = model(x, None, True, USE_MASK)
     opt.step(loss)
     model.normalize_prototypes()
     if use_teacher:
@@ -107,7 +110,7 @@ def cpu_baseline(fs, K, budget_s=30.0):
     n, t_total = 0, 0.0
     while n == 0 or (t_total < 0.5 * budget_s and n < 64):  # >= ~15 s of CPU work, at least one step
         t0 = time.perf_counter()
-        loss = om.get_loss(x, faithful=True)
+        loss = om.get_loss(x, faithful=True, mask_features=USE_MASK)
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -131,11 +134,14 @@ def main():
     ap.add_argument("--architecture", default="dino-s16")
     ap.add_argument("--use_teacher", action="store_true")
     ap.add_argument("--use_queue", action="store_true")
+    ap.add_argument("--use_mask", action="store_true", help="time the --use_mask variant (attention foreground masks) instead")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the forward Linears for the TIMED region (default f32 = the headline / parity mode)")
     ap.add_argument("--no_alt_precision", action="store_true", help="skip the secondary bf16x3 / bf16 measurements")
     a = ap.parse_args()
+    global USE_MASK
+    USE_MASK = a.use_mask
 
     import torch.distributed as dist
 
@@ -235,7 +241,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": ("C2: " if (a.architecture, bs, fs, K) == ("dino-s16", 32, 4, 200) else "") +
                                    f"{a.architecture} full TimeT training step (fwd+bwd+AdamW), {fs}-frame 224x224 clips, {bs} clips/GPU, "
-                                   f"{K} prototypes" + (", EMA teacher" if a.use_teacher else "") + (", queue" if a.use_queue else ""),
+                                   f"{K} prototypes" + (", EMA teacher" if a.use_teacher else "") + (", queue" if a.use_queue else "") +
+                                   (", use_mask" if a.use_mask else ""),
                        "architecture": a.architecture, "clips_per_gpu": bs, "num_frames": fs, "num_clusters": K,
                        "global_batch": bs * world, "parallelism": f"dp{world}"},
             "loss": round(final_loss, 5),

@@ -147,9 +147,11 @@ size_t tt_label_propagate_workspace_bytes(int bs, int fs, int g, int D, int K, i
 /* ---- k15: CrossEntropyLoss(scores/temp, labels), mean over patches then batch
  *      (time_tuning.py:296-302), with its gradient w.r.t. scores.
  *   scores [rows,K]; labels int64[rows]; loss_out[1]; dscores [rows,K] (= d loss / d scores).
+ *   row_weight [rows] or NULL: the --use_mask form, CrossEntropyLoss(reduction='none') * mask followed by the
+ *   mean over ALL rows (time_tuning.py:226-227,298-300).
  *   workspace: tt_ce_workspace_bytes(rows). */
-int tt_ce_loss_fwd_bwd(const float* scores, const int64_t* labels, float* loss_out, float* dscores, int rows, int K,
-                       float temperature, void* workspace, size_t workspace_bytes, tt_stream_t stream);
+int tt_ce_loss_fwd_bwd(const float* scores, const int64_t* labels, const float* row_weight, float* loss_out, float* dscores,
+                       int rows, int K, float temperature, void* workspace, size_t workspace_bytes, tt_stream_t stream);
 size_t tt_ce_workspace_bytes(int rows);
 
 /* ---- k13: queue FIFO update (time_tuning.py:258-261): shift down by m rows, write feats[idx[i]]
@@ -177,6 +179,26 @@ int tt_ema_update(float* teacher, const float* student, long long n, double mome
 
 /* ---- misc elementwise used between the sites above */
 int tt_add_inplace(float* dst, const float* src, long long n, tt_stream_t stream);
+
+/* ---- N1: attention foreground mask, models.process_attentions (models.py:93-131), used by
+ *      apply_attention_mask (models.py:133-144) on the --use_mask branch of TimeT.get_loss.
+ *   Per frame: cls-query attention of the LAST block averaged over heads -> Gaussian blur (ksize x ksize, sigma,
+ *   reflect padding; the reference uses 7 / 0.6) -> keep `threshold` (0.65) of the mass by ascending sort +
+ *   cumulative sum -> drop 8-connected components of <= 2 pixels.  One launch, no host round trip (the
+ *   reference labels components with skimage on the CPU).
+ *   tt_foreground_mask           qkv [F,N,3*H*hd]: the last block's qkv activations (same buffer tt_attention_fwd
+ *                                reads); the cls-row probabilities softmax(q_cls k_j * scale) are recomputed in the
+ *                                kernel, so attn[F,H,N,N] is never materialised.
+ *   tt_foreground_mask_from_probs cls_probs [F,H,N]: row 0 of the attention probabilities, already computed.
+ *   mask_out [F,g*g] floats in {0,1}; blurred_out [F,g*g] optional (the blurred mean attention);
+ *   margin_out [F,g*g] optional (|cumulative mass - (1-threshold)| per pixel: how far it is from the cut). */
+int tt_foreground_mask(const float* qkv, float* mask_out, float* blurred_out, float* margin_out, int F, int N, int H, int hd, int g,
+                       float scale, float threshold, float sigma, int ksize, tt_stream_t stream);
+int tt_foreground_mask_from_probs(const float* cls_probs, float* mask_out, float* blurred_out, float* margin_out, int F, int N,
+                                  int H, int g, float threshold, float sigma, int ksize, tt_stream_t stream);
+
+/* features * mask[..., None] (models.py:142) and its backward: x[r][:] *= row_scale[r], cols % 4 == 0. */
+int tt_scale_rows_inplace(float* x, const float* row_scale, int rows, int cols, tt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -219,6 +219,109 @@ def test_ce_loss(ops):
     assert rel_err(ds.cpu(), sd.grad) < TOL
 
 
+def test_ce_loss_row_weights(ops):
+    """--use_mask loss: CrossEntropyLoss(reduction='none') * mask, mean over all rows (time_tuning.py:226-227,298-300)."""
+    rows, K = 392, 50
+    s, lab = rnd("cws", rows, K) * 0.3, torch.from_numpy(np.random.default_rng(1).integers(0, K, rows))
+    w = torch.from_numpy((np.random.default_rng(2).random(rows) < 0.6).astype(np.float32))
+    sd = s.double().requires_grad_(True)
+    ref = (F.cross_entropy(sd / 0.1, lab, reduction="none") * w.double()).mean()
+    ref.backward()
+    loss, ds = ops.ce_loss_fwd_bwd(dev(s), dev(lab), 0.1, row_weight=dev(w))
+    assert abs(loss.item() - ref.item()) < 1e-5
+    assert rel_err(ds.cpu(), sd.grad) < TOL
+    assert (ds.cpu()[w == 0] == 0).all()
+
+
+def test_scale_rows(ops):
+    x, w = rnd("srx", 392, 256), rnd("srw", 392)
+    y = ops.scale_rows_(dev(x.clone()), dev(w))
+    assert torch.equal(y.cpu(), x * w[:, None])
+
+
+def _mask_mismatch_excusable(mask, want, margin, tol=2e-6):
+    """A pixel may land on the other side of the mass cut only where its cumulative mass is within rounding of the
+    cut; such a flip can also change which neighbours form a <= 2-pixel component, so the excuse covers 3x3
+    surroundings of any near-cut pixel."""
+    mism = mask != want
+    if not mism.any():
+        return True
+    Fr, n = mask.shape
+    g = int(round(n ** 0.5))
+    near = (margin < tol).reshape(Fr, 1, g, g).float()
+    near = F.max_pool2d(near, 5, 1, 2).reshape(Fr, n).bool()   # 2 rings: the flipped pixel's neighbours' neighbours
+    return bool((~mism | near).all())
+
+
+@pytest.mark.parametrize("g_", [14, 28, 7])
+def test_foreground_mask_golden(ops, golden, g_):
+    """process_attentions (models.py:93-131): exact on the frames the reference itself can process, and against the
+    oracle's intended small-component removal on the frames where the reference raises IndexError."""
+    d = golden("attention_mask")
+    cls = d[f"attn_cls_g{g_}"]
+    ok = d[f"ref_ok_g{g_}"].astype(bool)
+    mask, blurred, margin = ops.foreground_mask_from_probs(dev(cls), g_, return_aux=True)
+    mask, margin = mask.cpu(), margin.cpu()
+    Fr, H, N = cls.shape
+    attn = torch.zeros(Fr, H, N, N)
+    attn[:, :, 0, :] = torch.from_numpy(cls)
+    want, want_blur, _ = O.process_attentions(attn, g_, return_blurred=True)
+    want = want.reshape(Fr, -1)
+    assert rel_err(blurred.cpu(), want_blur) < TOL
+    assert _mask_mismatch_excusable(mask, want, margin)
+    ref = torch.from_numpy(d[f"mask_g{g_}"]).reshape(Fr, -1)
+    assert _mask_mismatch_excusable(mask[ok], ref[ok], margin[ok])
+    assert (mask == want).float().mean() > 0.999
+    assert (~ok).any() and ok.sum() >= 4  # both kinds of frame are present in the fixture
+
+
+def test_foreground_mask_small_components(ops):
+    """Hand-made thresholded maps: 1- and 2-pixel components (8-connected) go, a 3-pixel chain and blocks stay."""
+    g_ = 9
+    n = g_ * g_
+    keep = np.zeros((g_, g_), np.float32)
+    keep[0, 0] = 1                          # single
+    keep[0, 4] = keep[1, 5] = 1             # diagonal pair
+    keep[8, 0] = keep[8, 1] = 1             # horizontal pair on the border
+    keep[3, 0] = keep[4, 0] = keep[5, 1] = 1  # 3-chain with a diagonal link
+    keep[4:8, 4:8] = 1                      # block
+    # attention whose kept mass is exactly `keep`: big values there, 1e-6 elsewhere, a 1-tap blur (identity) and a mass
+    # threshold of 99.9 % so that only the tiny values fall below the cut
+    att = np.where(keep.reshape(-1) > 0, 1.0, 1e-6).astype(np.float32)
+    att /= att.sum()
+    cls = np.zeros((1, 2, n + 1), np.float32)
+    cls[0, :, 1:] = att
+    mask = ops.foreground_mask_from_probs(dev(cls), g_, threshold=0.999, kernel_size=1).cpu().reshape(g_, g_).numpy()
+    want = keep.copy()
+    want[0, 0] = want[0, 4] = want[1, 5] = want[8, 0] = want[8, 1] = 0
+    assert (mask == want).all()
+    lab = O.label_components(keep[None])  # the oracle's component rule agrees on which components are small
+    small = [k for k in range(1, lab.max() + 1) if (lab == k).sum() <= 2]
+    assert sum((lab == k).sum() for k in small) == 5
+
+
+def test_foreground_mask_from_qkv(ops):
+    """The qkv entry point recomputes the cls-query probabilities: compare with the oracle on attention built by torch
+    from the same qkv (F=5 frames, 6 heads x 64, g=14) and with the probs entry point."""
+    Fr, H, hd, g_ = 5, 6, 64, 14
+    N, D = g_ * g_ + 1, 6 * 64
+    qkv = rnd("fmqkv", Fr, N, 3 * D) * 1.5
+    # smooth the keys over the grid so that the attention (and the mask) has spatial structure
+    kk = qkv[:, 1:, D:2 * D].reshape(Fr, g_, g_, D).permute(0, 3, 1, 2)
+    kk = F.avg_pool2d(kk, 5, 1, 2).permute(0, 2, 3, 1).reshape(Fr, N - 1, D)
+    qkv[:, 1:, D:2 * D] = 3.0 * kk
+    q = qkv[:, :, :D].reshape(Fr, N, H, hd).permute(0, 2, 1, 3).double()
+    k = qkv[:, :, D:2 * D].reshape(Fr, N, H, hd).permute(0, 2, 1, 3).double()
+    attn = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1).float()
+    want, want_blur, _ = O.process_attentions(attn, g_, return_blurred=True)
+    mask, blurred, margin = ops.foreground_mask(dev(qkv), H, g_, return_aux=True)
+    assert rel_err(blurred.cpu(), want_blur) < TOL
+    assert _mask_mismatch_excusable(mask.cpu(), want.reshape(Fr, -1), margin.cpu())
+    assert 0.2 < mask.mean().item() < 0.9
+    m2 = ops.foreground_mask_from_probs(dev(attn[:, :, 0, :]), g_)
+    assert (m2 == mask).float().mean().item() > 0.995
+
+
 def test_adamw_ema_queue(ops):
     shapes = [(200, 256), (1024,), (384, 1536), (7,)]
     ps = [torch.nn.Parameter(rnd(f"op{i}", *s)) for i, s in enumerate(shapes)]

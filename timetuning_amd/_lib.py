@@ -57,12 +57,15 @@ SIGNATURES = {
     "tt_sinkhorn_workspace_bytes": (c_sz, [c_i, c_i]),
     "tt_label_propagate": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
     "tt_label_propagate_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
-    "tt_ce_loss_fwd_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
+    "tt_ce_loss_fwd_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
     "tt_ce_workspace_bytes": (c_sz, [c_i]),
     "tt_queue_push": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp]),
     "tt_adamw_step": (c_i, [C.POINTER(AdamwTensor), c_i, c_i, c_f, c_f, c_f, c_vp]),
     "tt_ema_update": (c_i, [c_vp, c_vp, c_ll, c_d, c_vp]),
     "tt_add_inplace": (c_i, [c_vp, c_vp, c_ll, c_vp]),
+    "tt_foreground_mask": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_vp]),
+    "tt_foreground_mask_from_probs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_vp]),
+    "tt_scale_rows_inplace": (c_i, [c_vp, c_vp, c_i, c_i, c_vp]),
 }
 
 _lib = None

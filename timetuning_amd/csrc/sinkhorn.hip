@@ -147,8 +147,8 @@ __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __rest
 
 // ---- cross entropy -----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ scores, const int64_t* __restrict__ labels,
-                                                 float* __restrict__ row_loss, float* __restrict__ dscores, int rows, int K,
-                                                 float temp) {
+                                                 const float* __restrict__ row_weight, float* __restrict__ row_loss,
+                                                 float* __restrict__ dscores, int rows, int K, float temp) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -170,9 +170,11 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ score
   s = wave_sum(s);
   const int lab = (int)labels[row];
   const float zl = scores[(long long)row * K + lab] / temp;
-  if (lane == 0) row_loss[row] = (mx + logf(s)) - zl;
+  // reduction='none' * mask, then the mean over ALL rows (time_tuning.py:298-300); weight 1 without a mask
+  const float wgt = row_weight ? row_weight[row] : 1.0f;
+  if (lane == 0) row_loss[row] = ((mx + logf(s)) - zl) * wgt;
   if (dscores) {
-    const float gscale = 1.0f / (temp * (float)rows);
+    const float gscale = wgt / (temp * (float)rows);
 #pragma unroll
     for (int i = 0; i < SK_KPL; ++i) {
       const int k = lane + 64 * i;
@@ -230,14 +232,14 @@ extern "C" int tt_sinkhorn(const float* scores, float* q_out, int B_total, int K
 
 extern "C" size_t tt_ce_workspace_bytes(int rows) { return (size_t)rows * sizeof(float); }
 
-extern "C" int tt_ce_loss_fwd_bwd(const float* scores, const int64_t* labels, float* loss_out, float* dscores, int rows, int K,
-                                  float temperature, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+extern "C" int tt_ce_loss_fwd_bwd(const float* scores, const int64_t* labels, const float* row_weight, float* loss_out, float* dscores,
+                                  int rows, int K, float temperature, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
   TT_REQUIRE(scores && labels && loss_out && workspace, "ce_loss: null pointer");
   TT_REQUIRE(rows > 0 && K > 0 && K <= 64 * SK_KPL && temperature > 0.f, "ce_loss: need 0 < K <= %d", 64 * SK_KPL);
   TT_REQUIRE(workspace_bytes >= tt_ce_workspace_bytes(rows), "ce_loss: workspace too small");
   hipStream_t s = as_stream(stream);
   float* row_loss = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(ce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, scores, labels, row_loss, dscores, rows, K, temperature);
+  hipLaunchKernelGGL(ce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, scores, labels, row_weight, row_loss, dscores, rows, K, temperature);
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, row_loss, loss_out, rows);
   TT_CHECK_LAUNCH("ce_loss");
   return TT_OK;

@@ -36,9 +36,10 @@ def _frame_map_time_major(bs: int, fs: int, device) -> torch.Tensor:
 # ViT blocks
 # ------------------------------------------------------------------------------------------------
 
-def block_forward(x: torch.Tensor, blk, num_heads: int, save: Optional[dict] = None) -> torch.Tensor:
+def block_forward(x: torch.Tensor, blk, num_heads: int, save: Optional[dict] = None, aux: Optional[dict] = None) -> torch.Tensor:
     """One transformer block (dino_vision_transformer.py:147-153) on x [F,N,D].  With ``save`` the
-    activations backward needs are kept there; otherwise the residual stream is updated in place."""
+    activations backward needs are kept there; otherwise the residual stream is updated in place.
+    ``aux`` (a dict) receives the block's qkv activations [F,N,3D] - what the attention foreground mask reads."""
     Fr, N, D = x.shape
     M = Fr * N
     x2d = x.view(M, D)
@@ -47,6 +48,8 @@ def block_forward(x: torch.Tensor, blk, num_heads: int, save: Optional[dict] = N
     else:
         h1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias)
     qkv = ops.linear_fwd(h1.view(M, D), blk.attn.qkv.weight, blk.attn.qkv.bias)
+    if aux is not None:
+        aux["qkv"] = qkv.view(Fr, N, 3 * D)
     att, lse, _ = ops.attention_fwd(qkv.view(Fr, N, 3 * D), num_heads, save_lse=save is not None)
     x_mid = ops.linear_fwd(att.view(M, D), blk.attn.proj.weight, blk.attn.proj.bias, residual=x2d,
                            out=None if save is not None else x2d)
@@ -93,9 +96,9 @@ def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int,
 
 
 def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None, save_blocks: Optional[Dict[int, dict]] = None,
-               last_block_probs: bool = False):
+               last_block_probs: bool = False, last_block_aux: Optional[dict] = None):
     """prepare_tokens + all blocks (dino_vision_transformer.py:236-252).  Returns (tokens [F,N,D] before the final
-    norm, attention probabilities of the last block or None)."""
+    norm, attention probabilities of the last block or None).  ``last_block_aux`` receives the last block's qkv."""
     pe = vit.patch_embed.proj
     D = pe.weight.shape[0]
     x = ops.patch_embed_fwd(img, pe.weight.view(D, -1), pe.bias, vit.cls_token.view(D), vit.pos_embed.view(-1, D),
@@ -106,7 +109,7 @@ def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None,
         sv = save_blocks.get(i) if save_blocks is not None else None
         if last_block_probs and i == depth - 1:
             probs = last_block_attention(x, blk, vit.num_heads)
-        x = block_forward(x, blk, vit.num_heads, sv)
+        x = block_forward(x, blk, vit.num_heads, sv, last_block_aux if i == depth - 1 else None)
     return x, probs
 
 

@@ -319,18 +319,64 @@ def label_propagate(xn, seg0, n_last_frames=7, radius=6, topk=5, temperature=0.1
     return (labels, pmap) if return_pmap else labels
 
 
-def ce_loss_fwd_bwd(scores, labels, temperature=0.1, need_grad=True):
-    """mean CE of scores/temperature vs labels; returns (loss[1], dscores or None)."""
+def ce_loss_fwd_bwd(scores, labels, temperature=0.1, need_grad=True, row_weight=None):
+    """mean CE of scores/temperature vs labels (per-row weights = the --use_mask loss mask); returns (loss[1], dscores or None)."""
     lib = _lib.load()
     _chk(scores, "scores"); _chk(labels, "labels", torch.int64)
+    if row_weight is not None:
+        _chk(row_weight, "row_weight")
+        if row_weight.numel() != scores.shape[0]:
+            raise ValueError("row_weight needs one entry per score row")
     rows, K = scores.shape
     loss = torch.empty((1,), dtype=f32, device=scores.device)
     ds = torch.empty_like(scores) if need_grad else None
     nb = lib.tt_ce_workspace_bytes(rows)
     ws = _ws(nb, scores.device)
-    _lib.check(lib.tt_ce_loss_fwd_bwd(_p(scores), _p(labels), _p(loss), _p(ds), rows, K, float(temperature), _p(ws), nb, _stream()),
-               "tt_ce_loss_fwd_bwd")
+    _lib.check(lib.tt_ce_loss_fwd_bwd(_p(scores), _p(labels), _p(row_weight), _p(loss), _p(ds), rows, K, float(temperature), _p(ws), nb,
+                                      _stream()), "tt_ce_loss_fwd_bwd")
     return loss, ds
+
+
+def foreground_mask(qkv, num_heads: int, spatial_res: int, threshold: float = 0.65, blur_sigma: float = 0.6, kernel_size: int = 7,
+                    return_aux: bool = False):
+    """process_attentions (models.py:93-131) from the last block's qkv activations [F, N, 3*D] -> mask [F, g*g] in {0,1}
+    (and, with ``return_aux``, the blurred head-mean attention and each pixel's distance to the mass cut)."""
+    lib = _lib.load()
+    _chk(qkv, "qkv")
+    Fr, N, D3 = qkv.shape
+    hd = D3 // 3 // num_heads
+    n = N - 1
+    mask = torch.empty((Fr, n), dtype=f32, device=qkv.device)
+    blurred = torch.empty_like(mask) if return_aux else None
+    margin = torch.empty_like(mask) if return_aux else None
+    _lib.check(lib.tt_foreground_mask(_p(qkv), _p(mask), _p(blurred), _p(margin), Fr, N, num_heads, hd, spatial_res, float(hd) ** -0.5,
+                                      float(threshold), float(blur_sigma), int(kernel_size), _stream()), "tt_foreground_mask")
+    return (mask, blurred, margin) if return_aux else mask
+
+
+def foreground_mask_from_probs(cls_probs, spatial_res: int, threshold: float = 0.65, blur_sigma: float = 0.6, kernel_size: int = 7,
+                               return_aux: bool = False):
+    """Same from row 0 of the attention probabilities, cls_probs [F, H, N]."""
+    lib = _lib.load()
+    _chk(cls_probs, "cls_probs")
+    Fr, H, N = cls_probs.shape
+    mask = torch.empty((Fr, N - 1), dtype=f32, device=cls_probs.device)
+    blurred = torch.empty_like(mask) if return_aux else None
+    margin = torch.empty_like(mask) if return_aux else None
+    _lib.check(lib.tt_foreground_mask_from_probs(_p(cls_probs), _p(mask), _p(blurred), _p(margin), Fr, N, H, spatial_res, float(threshold),
+                                                 float(blur_sigma), int(kernel_size), _stream()), "tt_foreground_mask_from_probs")
+    return (mask, blurred, margin) if return_aux else mask
+
+
+def scale_rows_(x, row_scale):
+    """x[r, :] *= row_scale[r] in place (features * mask, models.py:142)."""
+    lib = _lib.load()
+    _chk(x, "x"); _chk(row_scale, "row_scale")
+    rows, cols = x.shape
+    if row_scale.numel() != rows:
+        raise ValueError("row_scale needs one entry per row")
+    _lib.check(lib.tt_scale_rows_inplace(_p(x), _p(row_scale), rows, cols, _stream()), "tt_scale_rows_inplace")
+    return x
 
 
 def queue_push_(queue, feats, idx):

@@ -215,11 +215,8 @@ class TimeT(nn.Module):
                  sinkhorn_iterations=10, mask_features=False, queue_perm=None):
         """``time_tuning.py:224-302``.  ``queue_perm`` (not in the reference) injects the permutation that
         ``torch.randperm`` draws at :259 so that runs can be reproduced exactly."""
-        if mask_features:
-            raise NotImplementedError("--use_mask (attention-masked loss, models.py:93-144) is the next row of the scope "
-                                      "table (SURVEY.md 8(f) N1) and is not built yet")
         hp = dict(n_last_frames=n_last_frames, radius=size_mask_neighborhood, topk=topk, epsilon=epsilon,
-                  iters=int(sinkhorn_iterations), queue_perm=queue_perm)
+                  iters=int(sinkhorn_iterations), queue_perm=queue_perm, mask_features=bool(mask_features))
         params = [p for p in self.parameters() if p.requires_grad]
         need_grad = torch.is_grad_enabled() and len(params) > 0
         return _FusedLoss.apply(self, x, hp, need_grad, *params)
@@ -246,9 +243,15 @@ class TimeT(nn.Module):
         save = {i: {} for i in range(first, len(vit.blocks))} if first is not None else None
 
         # ---- student: one pass over all frames, time-major
-        tok, _ = engine.vit_tokens(vit, xf, self._frame_map(bs, fs, dev), save)
+        use_mask = hp.get("mask_features", False)
+        g = fe.spatial_resolution
+        s_aux: Optional[dict] = {} if use_mask else None
+        tok, _ = engine.vit_tokens(vit, xf, self._frame_map(bs, fs, dev), save, last_block_aux=s_aux)
         N, D = tok.shape[1], tok.shape[2]
         n = N - 1
+        # --use_mask (time_tuning.py:244-246 -> models.py:93-144): foreground masks from the last block's cls attention.
+        # Only the frames whose head features are consumed need one: the target frames and, without a teacher, frame 0.
+        mask_tgt = ops.foreground_mask(s_aux["qkv"][(fs - 1) * bs:], vit.num_heads, g).view(-1) if use_mask else None
         if need_grad:
             feats, mean_f, rstd_f = ops.layernorm_fwd(tok, vit.norm.weight, vit.norm.bias, save_stats=True, drop_first_token=True)
         else:
@@ -257,17 +260,26 @@ class TimeT(nn.Module):
         src_rows, tgt_rows = feats[: bs * n], feats[(fs - 1) * bs * n:]
         sv_head: Optional[dict] = {} if need_grad else None
         z_tgt = engine.head_forward(tgt_rows, fe.head, sv_head) if fe.head is not None else tgt_rows
+        if use_mask:
+            z_tgt = ops.scale_rows_(z_tgt if fe.head is not None else z_tgt.clone(), mask_tgt)  # features * mask (models.py:142)
 
         # ---- assignment source: teacher on frame 0 if present, else the student's frame 0 (no grad either way)
         if self.teacher is not None:
             tvit = self.teacher.backbone
-            t_tok, _ = engine.vit_tokens(tvit, xf, self._frame_map(bs, fs, dev, only_t=0))
+            t_aux: Optional[dict] = {} if use_mask else None
+            t_tok, _ = engine.vit_tokens(tvit, xf, self._frame_map(bs, fs, dev, only_t=0), last_block_aux=t_aux)
             t_feats = ops.layernorm_fwd(t_tok, tvit.norm.weight, tvit.norm.bias, drop_first_token=True)
             z_q = engine.head_forward(t_feats, self.teacher.head) if self.teacher.head is not None else t_feats
             protos_q = self.teacher_prototypes.data
+            mask_q = ops.foreground_mask(t_aux["qkv"], tvit.num_heads, g).view(-1) if use_mask else None  # time_tuning.py:235-236
         else:
             z_q = engine.head_forward(src_rows, fe.head) if fe.head is not None else src_rows
             protos_q = self.prototypes.data
+            mask_q = ops.foreground_mask(s_aux["qkv"][:bs], vit.num_heads, g).view(-1) if use_mask else None
+            if use_mask and fe.head is None:
+                z_q = z_q.clone()  # src_rows is a view of the propagation features, which stay unmasked (time_tuning.py:285)
+        if use_mask:
+            ops.scale_rows_(z_q, mask_q)
 
         if self.queue is not None:  # time_tuning.py:250-261 (before scoring, so the batch is also in the queue)
             m = min(bs * 10, self.queue.shape[0])
@@ -285,8 +297,10 @@ class TimeT(nn.Module):
         scores_t = engine.prototype_scores(z_tgt, self.prototypes.data, sv_sc)                 # [bs*n, K]
         K = scores_t.shape[1]
         labels = ops.label_propagate(xn_bb, q.view(bs, n, K), hp["n_last_frames"], hp["radius"], hp["topk"], 0.1)
-        loss, dscores = ops.ce_loss_fwd_bwd(scores_t, labels.view(-1), 0.1, need_grad)
+        loss, dscores = ops.ce_loss_fwd_bwd(scores_t, labels.view(-1), 0.1, need_grad, row_weight=mask_tgt)  # :296-300
         self.last_aux = dict(q=q.view(bs, n, K), target_scores=scores_t.view(bs, n, K), labels=labels)
+        if use_mask:
+            self.last_aux.update(target_mask=mask_tgt.view(bs, n), source_mask=mask_q.view(bs, n))
         if not need_grad:
             return loss, {}
 
@@ -294,6 +308,8 @@ class TimeT(nn.Module):
         grads: Dict[nn.Parameter, torch.Tensor] = {}
         grads[self.prototypes], _ = ops.linear_bwd_weight(dscores, sv_sc["zn"], need_bias=False)
         dz = ops.l2norm_bwd(ops.linear_bwd_data(dscores, self.prototypes.data), sv_sc["zn"], sv_sc["inv"])
+        if use_mask:
+            ops.scale_rows_(dz, mask_tgt)  # backward of features * mask
         d_feats = engine.head_backward(dz, fe.head, sv_head, grads) if fe.head is not None else dz
         if train_ids:
             f0 = (fs - 1) * bs
