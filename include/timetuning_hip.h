@@ -144,6 +144,22 @@ int tt_label_propagate(const float* xn, const float* seg0, int64_t* labels, doub
                        size_t workspace_bytes, tt_stream_t stream);
 size_t tt_label_propagate_workspace_bytes(int bs, int fs, int g, int D, int K, int n_last_frames);
 
+/* ---- N4: label-propagation EVALUATION (mask_propagation.py:816-833, DAVIS protocol
+ *      n_last_frames 4, size_mask_neighborhood 12, topk 5), reusing k14.
+ *   tt_label_propagate_maps  same propagation, but ALL fs-1 maps are returned, as propagate_labels does
+ *                            (mask_propagation.py:448-496): pmap_all [fs-1, bs, n, K] fp64.  Workspace as above.
+ *   tt_upsample_argmax       nn.functional.interpolate(maps, (R,R), mode="bilinear", align_corners=False) followed by
+ *                            torch.max(dim=1) (mask_propagation.py:828-829), fused: maps [M, n, K] fp64 ->
+ *                            labels_out [M, R, R] int64; the upsampled fp64 tensor is never written.
+ *   tt_confusion_counts      counts[gt*C + pred] += 1 over n pixels (labels outside [0,C) ignored), uint64 [C,C]:
+ *                            the confusion matrix from which the Jaccard index (J) of the propagated masks follows. */
+int tt_label_propagate_maps(const float* xn, const float* seg0, double* pmap_all, int bs, int fs, int g, int D, int K,
+                            int n_last_frames, int radius, int topk, float temperature, void* workspace,
+                            size_t workspace_bytes, tt_stream_t stream);
+int tt_upsample_argmax(const double* maps, int64_t* labels_out, int M, int g, int K, int R, tt_stream_t stream);
+int tt_confusion_counts(const int64_t* pred, const int64_t* gt, long long n, int C, unsigned long long* counts,
+                        tt_stream_t stream);
+
 /* ---- k15: CrossEntropyLoss(scores/temp, labels), mean over patches then batch
  *      (time_tuning.py:296-302), with its gradient w.r.t. scores.
  *   scores [rows,K]; labels int64[rows]; loss_out[1]; dscores [rows,K] (= d loss / d scores).

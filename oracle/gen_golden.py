@@ -401,6 +401,55 @@ def gen_aux(ref, tag, arch, cfg, K, head_list, bs, fs, mode):
     print(f"aux_{tag}.npz written")
 
 
+def gen_davis_protocol(ref):
+    """The evaluation protocol of mask_propagation.py:821-830 (n_last_frames 4, neighbourhood 12, top-5, bilinear
+    upsampling to the input resolution, arg-max) driven through the reference's own propagate_labels / to_one_hot and
+    torch ops, on synthetic token features that follow a drifting annotation."""
+    import torch
+
+    from timetuning_amd import synth
+
+    mp = ref["mp"]
+
+    class _M:
+        def __init__(self, g):
+            self.spatial_resolution = g
+
+    out = {}
+    for tag, (g, fs, D, C, R) in dict(a=(14, 8, 64, 3, 112), b=(28, 7, 32, 4, 112), c=(14, 3, 16, 2, 56)).items():
+        n = g * g
+        yy, xx = np.mgrid[0:R, 0:R]
+        ann = np.zeros((R, R), np.int64)
+        for o in range(1, C):  # C-1 discs on a background
+            cy, cx, rad = R * (0.25 + 0.5 * (o - 1) / max(C - 2, 1)), R * (0.3 + 0.15 * o), R * 0.16
+            ann[(yy - cy) ** 2 + (xx - cx) ** 2 < rad ** 2] = o
+        proto = synth.normal(f"dv.proto.{tag}", (C, D))
+        frames = []
+        for t in range(fs):  # token features = prototype of the (shifted) label under the token centre + noise
+            sh = np.roll(ann, (2 * t * R // 112, 3 * t * R // 112), axis=(0, 1))
+            centres = ((np.arange(g) + 0.5) * R / g).astype(np.int64)
+            lab = sh[np.ix_(centres, centres)].reshape(n)
+            frames.append(proto[lab] + 0.6 * synth.normal(f"dv.noise.{tag}.{t}", (n, D)))
+        feats = torch.from_numpy(np.stack(frames).astype(np.float32))
+        first = torch.from_numpy(ann)
+        mp.mask_neighborhood = None
+        pred = mp.propagate_labels(4, 12, 5, _M(g), feats, mp.to_one_hot(first.unsqueeze(0)).unsqueeze(0), features_exist=True)
+        maps = torch.stack(pred, dim=0)
+        up = torch.nn.functional.interpolate(maps, size=(R, R), mode="bilinear", align_corners=False)
+        _, labels = torch.max(up, dim=1)
+        top2 = up.topk(2, dim=1).values
+        out[f"{tag}_cfg"] = np.array([g, fs, D, C, R], np.int64)
+        out[f"{tag}_feats"] = t2n(feats)
+        out[f"{tag}_annotation"] = ann.astype(np.uint8)
+        out[f"{tag}_maps"] = t2n(maps)
+        out[f"{tag}_pred"] = t2n(labels).astype(np.uint8)
+        out[f"{tag}_near_tie"] = t2n((top2[:, 0] - top2[:, 1]) < 1e-9)
+        print(f"  {tag}: label histogram of the last frame {np.bincount(t2n(labels)[-1].reshape(-1), minlength=C)}")
+    mp.mask_neighborhood = None
+    np.savez_compressed(os.path.join(OUT, "davis_protocol.npz"), **out)
+    print("davis_protocol.npz written")
+
+
 def gen_mask(ref):
     """models.process_attentions (with the blur / component-labelling stand-ins) on synthetic attention maps:
     peaked random maps at g = 14 and 28, plus hand-made cases for the small-component rule."""
@@ -465,6 +514,7 @@ def main():
         "timet_tiny": lambda: gen_timet(ref, "tiny", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "stress", False, 0, 3, True),
         "timet_tiny_tq": lambda: gen_timet(ref, "tiny_tq", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 2, "stress", True, 40, 3, True),
         "mask": lambda: gen_mask(ref),
+        "davis_protocol": lambda: gen_davis_protocol(ref),
         "timet_tiny_mask": lambda: gen_timet_masked(ref, "tiny_mask", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "dino", False, 0, 2, True),
         "timet_tiny_mask_tq": lambda: gen_timet_masked(ref, "tiny_mask_tq", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 2, "dino", True, 40, 2,
                                                        True),

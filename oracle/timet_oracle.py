@@ -247,7 +247,9 @@ def propagate_labels(n_last_frames, size_mask_neighborhood, topk, spatial_resolu
     """mask_propagation.py:448-496 with ``features_exist=True``.
 
     frame_list: [fs, n, D]; first_seg: [1, C, g, g].  Returns the list of fs-1 maps [C,g,g] fp64."""
-    first_seg = first_seg.double()  # (:456) nearest-resize to (g, g) is the identity here
+    # (:456) nearest-resize of the seed to the token grid: the identity on the training path, a real downsampling of
+    # the first-frame annotation on the evaluation path
+    first_seg = F.interpolate(first_seg.double(), size=(spatial_resolution, spatial_resolution), mode="nearest")
     mask = restrict_neighborhood(spatial_resolution, spatial_resolution, size_mask_neighborhood)
     frame1_feat = frame_list[0].T
     que = []
@@ -262,6 +264,41 @@ def propagate_labels(n_last_frames, size_mask_neighborhood, topk, spatial_resolu
         que.append([feat_tar, seg])
         out.append(seg.squeeze(0))
     return out
+
+
+def to_one_hot(y_tensor, n_dims=None):
+    """mask_propagation.py:349-361: integer map [1,h,w] -> one-hot [n_dims,h,w]."""
+    if n_dims is None:
+        n_dims = int(y_tensor.max() + 1)
+    _, h, w = y_tensor.size()
+    y = y_tensor.long().view(-1, 1)
+    return torch.zeros(y.size(0), n_dims).scatter_(1, y, 1).view(h, w, n_dims).permute(2, 0, 1)
+
+
+def propagate_clip_predictions(n_last_frames, size_mask_neighborhood, topk, spatial_resolution, features, first_annotation,
+                               input_resolution, n_classes=None, return_margin=False):
+    """The per-clip body of the evaluation loop, mask_propagation.py:825-830: features [fs,n,D] (extractor without head),
+    first_annotation [H,W] integer labels -> predictions [fs-1,R,R] (bilinear upsampling of the fp64 maps, arg-max)."""
+    seed = to_one_hot(first_annotation.unsqueeze(0), n_classes).unsqueeze(0)
+    maps = torch.stack(propagate_labels(n_last_frames, size_mask_neighborhood, topk, spatial_resolution, features, seed), dim=0)
+    up = F.interpolate(maps, size=(input_resolution, input_resolution), mode="bilinear", align_corners=False)
+    _, pred = torch.max(up, dim=1)
+    if return_margin:
+        top2 = up.topk(min(2, up.shape[1]), dim=1).values
+        return pred, (top2[:, 0] - top2[:, -1]), maps
+    return pred
+
+
+def jaccard(pred, gt, num_classes, involve_bg=False):
+    """Mean Jaccard index with identity label matching; classes absent from both maps are skipped, the background
+    (class 0) is excluded unless ``involve_bg`` (PredsmIoU(..., involve_bg=False), mask_propagation.py:746)."""
+    ious = []
+    for c in range(0 if involve_bg else 1, num_classes):
+        p, t = pred == c, gt == c
+        union = (p | t).sum().item()
+        if union:
+            ious.append((p & t).sum().item() / union)
+    return float(np.mean(ious)) if ious else float("nan")
 
 
 # --------------------------------------------------------------------------------------

@@ -208,6 +208,55 @@ def test_label_propagation_batch(ops):
         assert (labels[b].cpu().numpy() != ref.argmax(1)).mean() <= 0.01
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_davis_protocol_golden(ops, golden, tag):
+    """N4: evaluation-protocol propagation (4 context frames, 25x25 window - 16 candidates per thread on the 28x28 grid -,
+    all maps returned), fused bilinear upsampling + arg-max, confusion counts / Jaccard; against the reference's outputs."""
+    from timetuning_amd import mask_propagation as MP
+
+    d = golden("davis_protocol")
+    g_, fs, D, C, R = [int(v) for v in d[f"{tag}_cfg"]]
+    feats = dev(d[f"{tag}_feats"])
+    ann = dev(d[f"{tag}_annotation"].astype(np.int64))
+
+    class _FE:  # propagate_labels only reads spatial_resolution when the features exist
+        spatial_resolution = g_
+
+    maps = MP.propagate_labels(4, 12, 5, _FE(), feats, MP.to_one_hot(ann.unsqueeze(0)).unsqueeze(0), features_exist=True)
+    assert len(maps) == fs - 1 and maps[0].shape == (C, g_, g_) and maps[0].dtype == torch.float64
+    got = torch.stack(maps).cpu().numpy()
+    ref = d[f"{tag}_maps"]
+    bad = np.abs(got - ref).max(1) > 1e-5 * np.abs(ref).max()
+    assert bad.mean() <= 0.01
+    # upsample + argmax on the REFERENCE maps (isolates the fused kernel from top-k near-ties upstream)
+    ref_nk = torch.from_numpy(ref).reshape(fs - 1, C, g_ * g_).transpose(1, 2).contiguous()
+    pred = ops.upsample_argmax(dev(ref_nk), R).cpu().numpy()
+    mism = pred != d[f"{tag}_pred"]
+    assert not (mism & ~d[f"{tag}_near_tie"]).any()
+    # confusion counts / Jaccard against the oracle
+    gt = torch.from_numpy(np.roll(d[f"{tag}_annotation"].astype(np.int64), (2 * (fs - 1) * R // 112, 3 * (fs - 1) * R // 112), (0, 1)))
+    last = torch.from_numpy(pred[-1].astype(np.int64))
+    counts = ops.confusion_counts(dev(last), dev(gt), C).cpu()
+    want = torch.zeros(C, C, dtype=torch.int64)
+    want.index_put_((gt.reshape(-1), last.reshape(-1)), torch.ones(R * R, dtype=torch.int64), accumulate=True)
+    assert torch.equal(counts, want)
+    j, per_class = MP.jaccard(dev(last), dev(gt), C)
+    assert abs(j - O.jaccard(last, gt, C)) < 1e-12 and j > 0.5
+
+
+def test_upsample_argmax_vs_torch(ops):
+    """Random fp64 maps, K = 21 channels, 14x14 -> 224x224 and 28x28 -> 100x100 (non-integer scale)."""
+    for g_, R, K in ((14, 224, 21), (28, 100, 5), (3, 7, 2)):
+        maps = torch.from_numpy(np.random.default_rng(g_).random((3, g_ * g_, K)))
+        up = F.interpolate(maps.transpose(1, 2).reshape(3, K, g_, g_), size=(R, R), mode="bilinear", align_corners=False)
+        want = up.argmax(1)
+        top2 = up.topk(2, dim=1).values
+        got = ops.upsample_argmax(dev(maps), R).cpu()
+        mism = got != want
+        assert not (mism & ((top2[:, 0] - top2[:, 1]) > 1e-12)).any()
+        assert mism.float().mean() < 1e-3
+
+
 def test_ce_loss(ops):
     rows, K = 392, 200
     s, lab = rnd("ces", rows, K) * 0.3, torch.from_numpy(np.random.default_rng(0).integers(0, K, rows))

@@ -226,6 +226,33 @@ def test_use_mask_full_size_vs_oracle():
                 assert rel_err(p.grad.cpu(), op[name].grad) < TOL, name
 
 
+def test_mask_propagation_evaluation_vs_oracle():
+    """N4: the evaluation loop body (extractor without head -> propagate_labels(4, 12, 5) -> upsample -> arg-max -> J) on a
+    synthetic tracking clip, against the oracle fed with the same features; and the command-line driver."""
+    from oracle import timet_oracle as O
+    from timetuning_amd import mask_propagation as MP
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    fe = FeatureExtractor("dino-s16", "", [1024, 1024, 512, 256], init="stress", return_attention=False)
+    model = TimeT(fe, 10).cuda().eval()
+    fs, R, C = 7, 224, 3
+    clip, masks = MP.synthetic_tracking_clip(fs, R, seed=1)
+    pred = MP.propagate_clip(model, clip.cuda(), masks[0].cuda(), 4, 12, 5, R, C)
+    assert pred.shape == (fs - 1, R, R) and pred.dtype == torch.int64
+    feats, _ = model(clip.cuda(), use_head=False)
+    want, margin, _ = O.propagate_clip_predictions(4, 12, 5, 14, feats.cpu(), masks[0], R, C, return_margin=True)
+    mism = pred.cpu() != want
+    assert mism.float().mean().item() <= 0.005
+    assert (margin[mism] < 1e-3).all()       # flips only where the top-2 upsampled scores are close (a top-k near-tie upstream)
+    j_gpu, _ = MP.jaccard(pred, masks[1:].cuda(), C)
+    j_cpu = O.jaccard(want, masks[1:], C)
+    assert abs(j_gpu - j_cpu) < 0.01 and j_gpu > 0.3
+    args = MP.build_parser().parse_args(["--dataset", "synthetic", "--model_path", "", "--num_frames", "5", "--num_clips", "2"])
+    assert args.n_last_frames == 4 and args.size_mask_neighborhood == 12 and args.topk == 5   # the reference's defaults
+    assert np.isfinite(MP.mask_propagation(args))
+
+
 @pytest.mark.parametrize("arch", ["dino-b16", "dino-s8"])
 def test_other_architectures_vs_oracle(arch):
     """ViT-B/16 (D=768, 12 heads) and ViT-S/8 (785 tokens: KV-tiled attention, 28x28 propagation grid) against the oracle:

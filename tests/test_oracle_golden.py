@@ -215,6 +215,33 @@ def test_gaussian_blur_properties():
     assert torch.allclose(out[0, 0, 4:11, 4:11], torch.outer(k, k), atol=1e-7)
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_davis_protocol(golden, tag):
+    """Evaluation protocol (mask_propagation.py:821-830): 4 context frames, neighbourhood 12, top-5, bilinear upsampling +
+    arg-max, from the first frame's integer annotation."""
+    d = golden("davis_protocol")
+    g_, fs, D, C, R = [int(v) for v in d[f"{tag}_cfg"]]
+    feats = torch.from_numpy(d[f"{tag}_feats"])
+    ann = torch.from_numpy(d[f"{tag}_annotation"].astype(np.int64))
+    pred, margin, maps = O.propagate_clip_predictions(4, 12, 5, g_, feats, ann, R, return_margin=True)
+    assert rel_err(maps.numpy(), d[f"{tag}_maps"]) < 1e-12
+    mism = pred.numpy() != d[f"{tag}_pred"]
+    assert not (mism & ~d[f"{tag}_near_tie"]).any()
+    j = O.jaccard(pred[-1], torch.from_numpy(np.roll(d[f"{tag}_annotation"].astype(np.int64), (2 * (fs - 1) * R // 112, 3 * (fs - 1) * R // 112), (0, 1))), C)
+    assert j > 0.5  # the propagated masks follow the drifting discs
+
+
+def test_to_one_hot_and_jaccard():
+    y = torch.tensor([[[0, 2], [1, 2]]])
+    oh = O.to_one_hot(y)
+    assert oh.shape == (3, 2, 2) and oh.sum(0).eq(1).all() and oh[2, 0, 1] == 1 and oh[1, 1, 0] == 1
+    a = torch.tensor([[0, 1, 1], [2, 2, 0]])
+    b = torch.tensor([[0, 1, 2], [2, 2, 2]])
+    # class 1: inter 1, union 2; class 2: inter 2, union 4
+    assert abs(O.jaccard(a, b, 3) - 0.5) < 1e-12
+    assert abs(O.jaccard(a, b, 3, involve_bg=True) - (0.5 + 0.5 + 0.5) / 3) < 1e-12
+
+
 def test_state_dict_layout(golden):
     """SURVEY section 5 checkpoint layout: key names the build must reproduce."""
     keys = [str(k) for k in golden("timet_tiny_tq")["state_dict_keys"]]

@@ -18,7 +18,9 @@ int launch_gemm_plain(const float* A, const float* B, float* C, int M, int N, in
                       long long sA, long long sB, long long sC, hipStream_t s);
 
 constexpr int LP_MAXC = 8;      // context frames (frame 0 + n_last_frames <= 7)
-constexpr int LP_CAND = 8;      // candidates per thread: ceil(8 * 25^2 / 256) would need r <= 12 ... see host check
+// candidates per thread (template parameter of the kernel): 8 covers the training protocol (13x13 window x 8 context
+// frames = 1352 <= 2048); 16 covers the DAVIS evaluation protocol on the 28x28 grid (25x25 window x 5 frames = 3125)
+constexpr int LP_CAND_MAX = 16;
 constexpr int LP_MAXKEEP = 64;  // kept sources per query (top-k plus ties)
 
 struct LpArgs {
@@ -32,10 +34,10 @@ struct LpArgs {
   float temp;
 };
 
+template <int LP_CAND>
 __global__ __launch_bounds__(256) void label_prop_kernel(LpArgs a) {
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
-  __shared__ float s_thr;
   __shared__ int s_cnt[4];
   __shared__ float s_sum[4];
   __shared__ int keep_src[LP_MAXKEEP];   // ctx * n + source patch
@@ -224,25 +226,26 @@ extern "C" size_t tt_label_propagate_workspace_bytes(int bs, int fs, int g, int 
   return ((sims + 255) / 256) * 256 + segs;
 }
 
-extern "C" int tt_label_propagate(const float* xn, const float* seg0, int64_t* labels, double* pmap_last, int bs, int fs, int g,
-                                  int D, int K, int n_last_frames, int radius, int topk, float temperature, void* workspace,
-                                  size_t workspace_bytes, tt_stream_t stream) {
-  TT_REQUIRE(xn && seg0 && labels && workspace, "label_propagate: null pointer");
-  TT_REQUIRE(bs > 0 && fs >= 2 && g > 0 && D > 0 && K > 0, "label_propagate: need fs >= 2 and positive sizes");
-  TT_REQUIRE(n_last_frames >= 0 && n_last_frames + 1 <= LP_MAXC, "label_propagate: n_last_frames must be <= %d", LP_MAXC - 1);
-  TT_REQUIRE(radius > 0, "label_propagate: size_mask_neighborhood must be > 0 (the unrestricted variant is not on the training path)");
-  TT_REQUIRE(topk >= 1, "label_propagate: topk >= 1");
+static int lp_run(const char* who, const float* xn, const float* seg0, int64_t* labels, double* pmap_last, double* pmap_all, int bs,
+                  int fs, int g, int D, int K, int n_last_frames, int radius, int topk, float temperature, void* workspace,
+                  size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(xn && seg0 && workspace, "%s: null pointer", who);
+  TT_REQUIRE(bs > 0 && fs >= 2 && g > 0 && D > 0 && K > 0, "%s: need fs >= 2 and positive sizes", who);
+  TT_REQUIRE(n_last_frames >= 0 && n_last_frames + 1 <= LP_MAXC, "%s: n_last_frames must be <= %d", who, LP_MAXC - 1);
+  TT_REQUIRE(radius > 0, "%s: size_mask_neighborhood must be > 0 (the unrestricted variant is not built)", who);
+  TT_REQUIRE(topk >= 1, "%s: topk >= 1", who);
   const int win = (2 * radius + 1 < g ? 2 * radius + 1 : g);
-  TT_REQUIRE((long long)win * win * lp_cmax(fs, n_last_frames) <= 256LL * LP_CAND,
-             "label_propagate: window %dx%d with %d context frames exceeds %d candidates per query", win, win,
-             lp_cmax(fs, n_last_frames), 256 * LP_CAND);
-  TT_REQUIRE(D % 4 == 0, "label_propagate: feature dim must be a multiple of 4");
-  TT_REQUIRE(workspace_bytes >= tt_label_propagate_workspace_bytes(bs, fs, g, D, K, n_last_frames), "label_propagate: workspace too small");
+  const long long cand_max = (long long)win * win * lp_cmax(fs, n_last_frames);
+  TT_REQUIRE(cand_max <= 256LL * LP_CAND_MAX, "%s: window %dx%d with %d context frames exceeds %d candidates per query", who, win, win,
+             lp_cmax(fs, n_last_frames), 256 * LP_CAND_MAX);
+  TT_REQUIRE(D % 4 == 0, "%s: feature dim must be a multiple of 4", who);
+  TT_REQUIRE(workspace_bytes >= tt_label_propagate_workspace_bytes(bs, fs, g, D, K, n_last_frames), "%s: workspace too small", who);
   hipStream_t s = as_stream(stream);
   const int n = g * g;
   const size_t sims_bytes = (((size_t)bs * lp_cmax(fs, n_last_frames) * n * n * sizeof(float)) + 255) / 256 * 256;
   float* sims = static_cast<float*>(workspace);
-  double* segs = reinterpret_cast<double*>(static_cast<char*>(workspace) + sims_bytes);
+  // the fp64 maps of frames 1..fs-1: the caller's buffer when all of them are wanted, the workspace otherwise
+  double* segs = pmap_all ? pmap_all : reinterpret_cast<double*>(static_cast<char*>(workspace) + sims_bytes);
   const long long fstride = (long long)bs * n * K;
   for (int t = 1; t < fs; ++t) {
     LpArgs a{};
@@ -262,13 +265,107 @@ extern "C" int tt_label_propagate(const float* xn, const float* seg0, int64_t* l
     a.seg_out = segs + (long long)(t - 1) * fstride;
     a.labels = (t == fs - 1) ? labels : nullptr;
     a.c = c; a.bs = bs; a.g = g; a.K = K; a.radius = radius; a.topk = topk; a.temp = temperature;
-    hipLaunchKernelGGL(label_prop_kernel, dim3(n, bs), dim3(256), 0, s, a);
-    TT_CHECK_LAUNCH("label_propagate");
+    if (cand_max <= 256LL * 8)
+      hipLaunchKernelGGL((label_prop_kernel<8>), dim3(n, bs), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((label_prop_kernel<LP_CAND_MAX>), dim3(n, bs), dim3(256), 0, s, a);
+    TT_CHECK_LAUNCH(who);
   }
   if (pmap_last) {
     const long long cnt = fstride;
     hipLaunchKernelGGL(f64_copy_kernel, dim3(1024), dim3(256), 0, s, segs + (long long)(fs - 2) * fstride, pmap_last, cnt);
-    TT_CHECK_LAUNCH("label_propagate.copy");
+    TT_CHECK_LAUNCH(who);
   }
+  return TT_OK;
+}
+
+extern "C" int tt_label_propagate(const float* xn, const float* seg0, int64_t* labels, double* pmap_last, int bs, int fs, int g,
+                                  int D, int K, int n_last_frames, int radius, int topk, float temperature, void* workspace,
+                                  size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(labels, "label_propagate: null pointer");
+  return lp_run("label_propagate", xn, seg0, labels, pmap_last, nullptr, bs, fs, g, D, K, n_last_frames, radius, topk, temperature,
+                workspace, workspace_bytes, stream);
+}
+
+extern "C" int tt_label_propagate_maps(const float* xn, const float* seg0, double* pmap_all, int bs, int fs, int g, int D, int K,
+                                       int n_last_frames, int radius, int topk, float temperature, void* workspace,
+                                       size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(pmap_all, "label_propagate_maps: null pointer");
+  return lp_run("label_propagate_maps", xn, seg0, nullptr, nullptr, pmap_all, bs, fs, g, D, K, n_last_frames, radius, topk, temperature,
+                workspace, workspace_bytes, stream);
+}
+
+// ---- evaluation tail of mask_propagation.py:826-829: bilinear upsample (align_corners=False) of the fp64 maps to the
+// input resolution, then argmax over the label channel - fused, so the [M, K, R, R] fp64 tensor (77 MB per 25-frame clip
+// at K = 8) is never written.
+namespace tt {
+__global__ __launch_bounds__(256) void upsample_argmax_kernel(const double* __restrict__ maps, int64_t* __restrict__ out, int g, int K,
+                                                              int R) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= R * R) return;
+  const int m = blockIdx.y, oy = pix / R, ox = pix - oy * R;
+  const double scale = (double)g / (double)R;  // area_pixel_compute_scale, align_corners = False
+  double sy = scale * (oy + 0.5) - 0.5, sx = scale * (ox + 0.5) - 0.5;
+  sy = sy < 0.0 ? 0.0 : sy;
+  sx = sx < 0.0 ? 0.0 : sx;
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < g - 1 ? 1 : 0), x1 = x0 + (x0 < g - 1 ? 1 : 0);
+  const double ly = sy - y0, lx = sx - x0, hy = 1.0 - ly, hx = 1.0 - lx;
+  const double* base = maps + (long long)m * g * g * K;
+  const double* p00 = base + (long long)(y0 * g + x0) * K;
+  const double* p01 = base + (long long)(y0 * g + x1) * K;
+  const double* p10 = base + (long long)(y1 * g + x0) * K;
+  const double* p11 = base + (long long)(y1 * g + x1) * K;
+  double best = -INFINITY;
+  int besti = 0;
+  for (int k = 0; k < K; ++k) {
+    const double v = hy * (hx * p00[k] + lx * p01[k]) + ly * (hx * p10[k] + lx * p11[k]);
+    if (v > best) {  // torch.max: first index of the maximum
+      best = v;
+      besti = k;
+    }
+  }
+  out[(long long)m * R * R + pix] = besti;
+}
+
+// counts[gt * C + pred] += 1 over n pixels (labels outside [0, C) are ignored): the confusion matrix behind the
+// Jaccard index of the propagated masks
+__global__ __launch_bounds__(256) void confusion_kernel(const int64_t* __restrict__ pred, const int64_t* __restrict__ gt, long long n,
+                                                        int C, unsigned long long* __restrict__ counts) {
+  extern __shared__ unsigned int hist[];
+  const int cells = C * C;
+  for (int i = threadIdx.x; i < cells; i += 256) hist[i] = 0;
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const long long p = pred[i], t = gt[i];
+    if (p >= 0 && p < C && t >= 0 && t < C) atomicAdd(&hist[(int)t * C + (int)p], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cells; i += 256)
+    if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+}  // namespace tt
+
+extern "C" int tt_upsample_argmax(const double* maps, int64_t* labels_out, int M, int g, int K, int R, tt_stream_t stream) {
+  TT_REQUIRE(maps && labels_out && M > 0 && g > 0 && K > 0 && R > 0, "upsample_argmax: bad arguments");
+  hipLaunchKernelGGL(upsample_argmax_kernel, dim3((R * R + 255) / 256, M), dim3(256), 0, as_stream(stream), maps, labels_out, g, K, R);
+  TT_CHECK_LAUNCH("upsample_argmax");
+  return TT_OK;
+}
+
+extern "C" int tt_confusion_counts(const int64_t* pred, const int64_t* gt, long long n, int C, unsigned long long* counts,
+                                   tt_stream_t stream) {
+  TT_REQUIRE(pred && gt && counts && n > 0, "confusion_counts: bad arguments");
+  TT_REQUIRE(C > 0 && C <= 96, "confusion_counts: need 0 < classes <= 96 (got %d)", C);
+  hipStream_t s = as_stream(stream);
+  if (hipMemsetAsync(counts, 0, sizeof(unsigned long long) * C * C, s) != hipSuccess) {
+    set_error("confusion_counts: memset failed");
+    return TT_ELAUNCH;
+  }
+  long long blocks = (n + 256 * 16 - 1) / (256 * 16);
+  blocks = blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks);
+  hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)blocks), dim3(256), sizeof(unsigned int) * C * C, s, pred, gt, n, C, counts);
+  TT_CHECK_LAUNCH("confusion_counts");
   return TT_OK;
 }

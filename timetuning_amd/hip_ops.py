@@ -319,6 +319,45 @@ def label_propagate(xn, seg0, n_last_frames=7, radius=6, topk=5, temperature=0.1
     return (labels, pmap) if return_pmap else labels
 
 
+def label_propagate_maps(xn, seg0, n_last_frames=7, radius=6, topk=5, temperature=0.1):
+    """As ``label_propagate`` but returns ALL propagated maps [fs-1, bs, n, K] fp64 (mask_propagation.py:448-496)."""
+    lib = _lib.load()
+    _chk(xn, "xn"); _chk(seg0, "seg0")
+    fs, bs, n, D = xn.shape
+    K = seg0.shape[-1]
+    g = int(round(n ** 0.5))
+    assert g * g == n
+    maps = torch.empty((fs - 1, bs, n, K), dtype=torch.float64, device=xn.device)
+    nb = lib.tt_label_propagate_workspace_bytes(bs, fs, g, D, K, n_last_frames)
+    ws = _ws(nb, xn.device)
+    _lib.check(lib.tt_label_propagate_maps(_p(xn), _p(seg0), _p(maps), bs, fs, g, D, K, n_last_frames, radius, topk, float(temperature),
+                                           _p(ws), nb, _stream()), "tt_label_propagate_maps")
+    return maps
+
+
+def upsample_argmax(maps, resolution: int):
+    """maps [M, n, K] fp64 -> labels [M, R, R] int64 = argmax_K of the bilinear (align_corners=False) upsampling."""
+    lib = _lib.load()
+    _chk(maps, "maps", torch.float64)
+    M, n, K = maps.shape
+    g = int(round(n ** 0.5))
+    assert g * g == n
+    out = torch.empty((M, resolution, resolution), dtype=torch.int64, device=maps.device)
+    _lib.check(lib.tt_upsample_argmax(_p(maps), _p(out), M, g, K, int(resolution), _stream()), "tt_upsample_argmax")
+    return out
+
+
+def confusion_counts(pred, gt, num_classes: int):
+    """counts[gt, pred] over all elements, int64 [C, C] (labels outside [0, C) are ignored)."""
+    lib = _lib.load()
+    _chk(pred, "pred", torch.int64); _chk(gt, "gt", torch.int64)
+    if pred.numel() != gt.numel():
+        raise ValueError("pred and gt need the same number of elements")
+    counts = torch.empty((num_classes, num_classes), dtype=torch.int64, device=pred.device)
+    _lib.check(lib.tt_confusion_counts(_p(pred), _p(gt), pred.numel(), int(num_classes), _p(counts), _stream()), "tt_confusion_counts")
+    return counts
+
+
 def ce_loss_fwd_bwd(scores, labels, temperature=0.1, need_grad=True, row_weight=None):
     """mean CE of scores/temperature vs labels (per-row weights = the --use_mask loss mask); returns (loss[1], dscores or None)."""
     lib = _lib.load()

@@ -57,6 +57,23 @@ def main():
     sc = torch.nn.functional.normalize(torch.randn(6272, 256, device=dev), dim=1) @ torch.nn.functional.normalize(torch.randn(200, 256, device=dev), dim=1).t()
     t = timeit(lambda: ops.sinkhorn(sc, 10))
     print(f"sinkhorn K=200 B=6272 10 it                {t * 1e6:8.1f} {10 / t:8.0f} it/s")
+    # training-protocol propagation (C2: 32 clips x 4 frames, K=200, 7 context frames, radius 6)
+    xn = torch.nn.functional.normalize(torch.randn(4, 32, 196, 384, device=dev), dim=-1)
+    q0 = torch.softmax(torch.randn(32, 196, 200, device=dev), -1)
+    t = timeit(lambda: ops.label_propagate(xn, q0))
+    print(f"label_propagate C2 (32x4 fr, K=200)        {t * 1e6:8.1f} {32 * 3 / t:8.0f} frames/s")
+    # --use_mask: foreground masks of 64 frames from the last block's qkv
+    qkv64 = torch.randn(64, 197, 1152, device=dev)
+    t = timeit(lambda: ops.foreground_mask(qkv64, 6, 14))
+    print(f"foreground_mask 64 frames g=14             {t * 1e6:8.1f} {64 / t:8.0f} frames/s")
+    # evaluation protocol (N4): one 25-frame clip, 4 context frames, radius 12, 8 classes, + upsample/argmax to 224
+    for g_ in (14, 28):
+        xn = torch.nn.functional.normalize(torch.randn(25, 1, g_ * g_, 384, device=dev), dim=-1)
+        seed = torch.nn.functional.one_hot(torch.randint(0, 8, (1, g_ * g_), device=dev), 8).float()
+        t = timeit(lambda: ops.label_propagate_maps(xn, seed, 4, 12, 5))
+        maps = ops.label_propagate_maps(xn, seed, 4, 12, 5).view(24, g_ * g_, 8)
+        t2 = timeit(lambda: ops.upsample_argmax(maps, 224))
+        print(f"eval propagate 25 fr g={g_:2d} r=12 + upsample   {t * 1e6:8.1f} {24 / (t + t2):8.0f} frames/s (upsample+argmax {t2 * 1e6:.1f} us)")
 
 
 if __name__ == "__main__":
