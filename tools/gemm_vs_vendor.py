@@ -15,18 +15,20 @@ SHAPES = [("qkv", 25216, 1152, 384, 0), ("proj", 25216, 384, 384, 0), ("fc1", 25
           ("head2", 6272, 1024, 1024, 1)]
 
 
-def timed(fn, reps=5, rounds=10):
-    ts = []
+def timed_pair(fa, fb, reps=5, rounds=12):
+    """Interleaved rounds (clock / thermal state is shared), median of each."""
+    ta, tb = [], []
     for rd in range(rounds):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        if rd >= 2:
-            ts.append(e0.elapsed_time(e1) * 1e-3 / reps)
-    return statistics.median(ts)
+        for fn, acc in ((fa, ta), (fb, tb)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            if rd >= 2:
+                acc.append(e0.elapsed_time(e1) * 1e-3 / reps)
+    return statistics.median(ta), statistics.median(tb)
 
 
 def main():
@@ -37,8 +39,7 @@ def main():
         w = torch.randn(N, K, device="cuda") * 0.02
         b = torch.randn(N, device="cuda")
         y = torch.empty(M, N, device="cuda")
-        t_ours = timed(lambda: ops.linear_fwd(x, w, b, act=act, out=y))
-        t_vendor = timed(lambda: torch.nn.functional.linear(x, w, b))
+        t_ours, t_vendor = timed_pair(lambda: ops.linear_fwd(x, w, b, act=act, out=y), lambda: torch.nn.functional.linear(x, w, b))
         ref = torch.nn.functional.linear(x, w, b)
         if act:
             ref = torch.nn.functional.gelu(ref)
