@@ -5,13 +5,18 @@
 // switches, row pointers advanced instead of recomputed, and - the part that matters - the tile leaves through the
 // idle LDS as 16-byte, fully coalesced row-major stores.  tools/mfma_peak.hip measures the inner loop at
 // 133 TFLOP/s, 105 with the natural 64-scalar-stores-per-lane epilogue (store-issue bound) and 121-125 with this one.
+//
+// Measured dead ends, kept out of the source (DESIGN.md section 5 has the numbers, git history the code):
+//   * operands swapped (D^T = W X^T) so that a lane owns 4 consecutive output columns and stores 16 bytes straight from
+//     the accumulators, no LDS pass: bit-identical, 1-2 % slower (32 rows x 32 B per store instruction);
+//   * [row][k] LDS image with ds_write_b128 / ds_read_b128 (k-permuted fragments): bit-identical, -9 ... +2 % by shape;
+//   * capping the workgroups per CU: flat from 6 down to 3, -10 % at 2, -26 % at 1 - the loop is not latency-bound.
 #include "common.hpp"
 #include <cstdlib>
 
 namespace tt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct FastArgs {
   const float* A;   // [M][K]
@@ -37,27 +42,12 @@ extern "C" int tt_debug_read_clock_stamps(unsigned long long* host, int count) {
 template <int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
   constexpr int BM = 64 * WM, BN = 64 * WN, BK = 16;
-#ifdef TT_KLAYOUT
-  // [row][k] image, row stride 20 floats (16 k + 4 pad): one ds_write_b128 per staged float4 and one ds_read_b128 per
-  // fragment quad.  Lane (r, h) reads k = 8 jj + 4 h + {0..3} of its row and feeds element q to MFMA q, i.e. the k-pair of
-  // MFMA (jj, q) is (8 jj + q, 8 jj + 4 + q) for BOTH operands - the sum over k does not care.  Stride 20 makes both the
-  // 4 x 16-lane groups of the read and the 8 x 8-lane groups of the write hit distinct banks.
-  constexpr int KS = BK + 4;
-  constexpr int LDA = KS, LDB = KS;  // (row strides here; ASZ / BSZ below are set from them)
-#elif defined(TT_LDS_PAD4)
-  constexpr int LDA = BM + 4, LDB = BN + 4;
-#else
   // k-row stride = tile extent + 2: the transposing staging writes (lane -> k-rows 4 (tid & 3) + e, column tid >> 2) then
   // spread over all 32 banks of a ds_write_b32 lane group (4 * stride = 8 mod 32); with + 4 (= 16 mod 32) they collide
   // two-way on every write (SQ_LDS_BANK_CONFLICT was 24 % of the LDS-active cycles).  Fragment reads walk consecutive
   // columns of one k-row and are conflict-free for any stride.
   constexpr int LDA = BM + 2, LDB = BN + 2;
-#endif
-#ifdef TT_KLAYOUT
-  constexpr int ASZ = BM * KS, BSZ = BN * KS;
-#else
   constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
-#endif
   constexpr int PIPE_FLOATS = 2 * (ASZ + BSZ), EPI_FLOATS = 32 * WM * (BN + 4);
   __shared__ __attribute__((aligned(16))) float lds[PIPE_FLOATS > EPI_FLOATS ? PIPE_FLOATS : EPI_FLOATS];
 
@@ -76,17 +66,6 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
   const float* pa = g.A + (size_t)(m0 + srow) * K + skc;
   const float* pb = g.B + (size_t)(n0 + srow) * K + skc;
   const size_t step64 = (size_t)64 * K;
-#ifdef TT_KLAYOUT
-  f32x4 ra[WM], rb[WN];  // native vectors: HIP's float4 struct copied whole through a lambda capture lands in scratch memory
-  auto gload = [&]() {
-#pragma unroll
-    for (int i = 0; i < WM; ++i) ra[i] = *reinterpret_cast<const f32x4*>(pa + i * step64);
-#pragma unroll
-    for (int i = 0; i < WN; ++i) rb[i] = *reinterpret_cast<const f32x4*>(pb + i * step64);
-    pa += BK;
-    pb += BK;
-  };
-#else
   float4 ra[WM], rb[WN];
   auto gload = [&]() {
 #pragma unroll
@@ -96,17 +75,6 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
     pa += BK;
     pb += BK;
   };
-#endif
-#ifdef TT_KLAYOUT
-  auto sstore = [&](int buf) {
-    float* da = lds + buf * ASZ + srow * KS + skc;
-    float* db = lds + 2 * ASZ + buf * BSZ + srow * KS + skc;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) *reinterpret_cast<f32x4*>(da + 64 * i * KS) = ra[i];
-#pragma unroll
-    for (int i = 0; i < WN; ++i) *reinterpret_cast<f32x4*>(db + 64 * i * KS) = rb[i];
-  };
-#else
   auto sstore = [&](int buf) {
     float* da = lds + buf * ASZ + skc * LDA + srow;
     float* db = lds + 2 * ASZ + buf * BSZ + skc * LDB + srow;
@@ -125,7 +93,6 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
       db[3 * LDB + 64 * i] = rb[i].w;
     }
   };
-#endif
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -145,24 +112,6 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload();
-#ifdef TT_KLAYOUT
-    const float* fa = lds + buf * ASZ + (wm * (32 * WM) + r) * KS + 4 * h;
-    const float* fb = lds + 2 * ASZ + buf * BSZ + (wn * (32 * WN) + r) * KS + 4 * h;
-#pragma unroll
-    for (int j = 0; j < BK / 8; ++j) {
-      f32x4 a4[WM], b4[WN];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) a4[i] = *reinterpret_cast<const f32x4*>(fa + i * 32 * KS + 8 * j);
-#pragma unroll
-      for (int n = 0; n < WN; ++n) b4[n] = *reinterpret_cast<const f32x4*>(fb + n * 32 * KS + 8 * j);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][q], b4[n][q], acc[i][n], 0, 0, 0);
-    }
-#else
     const float* fa = lds + buf * ASZ + (4 * h) * LDA + wm * (32 * WM) + r;
     const float* fb = lds + 2 * ASZ + buf * BSZ + (4 * h) * LDB + wn * (32 * WN) + r;
 #ifdef TT_ASM_PIPELINED_FRAGS
@@ -230,14 +179,9 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-#ifdef TT_DIRECT_EPI
-          for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[n][q], a[i][q], acc[i][n], 0, 0, 0);
-#else
           for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[n][q], acc[i][n], 0, 0, 0);
-#endif
     }
 #endif
-#endif  // TT_KLAYOUT
     if (kt + 1 < nk) sstore(buf ^ 1);
     __syncthreads();
   }
@@ -248,37 +192,6 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
     st[0] = st_c0; st[1] = st_r0; st[2] = __builtin_amdgcn_s_memtime(); st[3] = __builtin_amdgcn_s_memrealtime();
     st[4] = st_entry;
   }
-#endif
-#ifdef TT_DIRECT_EPI
-  // ---- epilogue straight from the accumulators (experiment, OFF by default: measured 1-2 % SLOWER than the LDS-staged
-  // epilogue below on every forward shape (tools/ab_gemm.py) - each store instruction touches 32 rows x 32 bytes, so the
-  // write path sees 4x the cache-line transactions; outputs are bit-identical): the MFMA ran with the operands swapped (D^T = W X^T), so a lane holds
-  // ONE output row (m = lane & 31) and runs of 4 consecutive columns -> 16-byte stores, no LDS pass, no barriers.
-#pragma unroll
-  for (int i = 0; i < WM; ++i) {
-    const size_t rowoff = (size_t)(m0 + wm * (32 * WM) + i * 32 + r) * g.N;
-#pragma unroll
-    for (int j = 0; j < WN; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * (32 * WN) + j * 32 + 8 * q + 4 * h;
-        float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-        if (g.bias) {
-          const float4 b4 = *reinterpret_cast<const float4*>(g.bias + n);
-          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-        }
-        if (g.pre_out) *reinterpret_cast<float4*>(g.pre_out + rowoff + n) = v;
-        if (g.act == 1) {
-          v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
-        }
-        if (g.residual) {
-          const float4 rs = *reinterpret_cast<const float4*>(g.residual + rowoff + n);
-          v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
-        }
-        *reinterpret_cast<float4*>(g.C + rowoff + n) = v;
-      }
-  }
-  return;
 #endif
   // ---- epilogue through LDS: one wave-row (32 * WM tile rows) at a time
   constexpr int CH = 32 * WM, LDCS = BN + 4, TPR = BN / 4, RPP = 256 / TPR;
