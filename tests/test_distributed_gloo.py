@@ -66,6 +66,17 @@ def _worker(rank, W, port, ret):
     expect = [sum(torch.from_numpy(synth.normal(f"ddp.g{i}.r{r}", tuple(p.shape))) for r in range(W)) / W for i, p in enumerate(params)]
     red = engine.allreduce_mean_(dict(grads))
     out["grad_err"] = max(float((red[p] - e).abs().max()) for p, e in zip(params, expect))
+    # (2b) the bucketed, asynchronous form the fused step uses: gradients are pushed as backward produces them
+    ex = engine.GradExchange()
+    staged = {params[0]: grads[params[0]].clone()}
+    ex.push(staged)
+    staged[params[1]] = grads[params[1]].clone()
+    ex.push(staged)
+    ex.push(staged)                       # nothing new: no bucket
+    staged[params[2]] = grads[params[2]].clone()
+    fin = ex.finish(staged)
+    out["bucket_err"] = max(float((fin[p] - e).abs().max()) for p, e in zip(params, expect))
+    out["bucket_count_ok"] = bool(len(ex.sent) == 3)
 
     # (3) the wrapper broadcasts rank 0's parameters and passes attribute access through
     cfg = synth.ARCHS["tiny-s16"]
@@ -96,6 +107,7 @@ def test_world_size_2_gloo():
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     for r in range(W):
         o = ret[r]
+        assert o["bucket_err"] < 1e-6 and o["bucket_count_ok"], o
         assert o["q_err_vs_reference"] < 2e-6, o
         assert o["q_err_vs_allreduce_form"] < 2e-6, o
         assert o["grad_err"] < 1e-6, o

@@ -23,15 +23,21 @@
 namespace tt {
 
 constexpr int SK_KPL = 8;      // K <= 512
-constexpr int SK_MAXWG = 256;  // buffer capacity; the default policy uses up to SK_DEFWG
-constexpr int SK_DEFWG = 64;
+constexpr int SK_MAXWG = 256;  // buffer capacity
+// Workgroup-count policy, measured (tools/sk_sweep.py, K = 200): the best count grows with the problem - 64-96 at B = 6272
+// (one rank), 128 at 12544, 192 at 25088, 192-256 at 50176 (the 8-rank global problem, 337 -> 193 us) - because the
+// per-launch fold of the partial sums costs O(workgroups) while the sweep over E shrinks as 1/workgroups.
+static int sk_default_cap(int B) {
+  const int c = B / 98;
+  return c < 64 ? 64 : (c > SK_MAXWG ? SK_MAXWG : c);
+}
 constexpr int SK_THREADS = 1024;
 constexpr int SK_WAVES = SK_THREADS / 64;
 
 static int sk_wgs(int B) {
   int w = (B + 2 * SK_WAVES - 1) / (2 * SK_WAVES);  // >= 2 rows per wave
   static const int cap_env = [] { const char* e = getenv("TT_SK_WGS"); return e ? atoi(e) : 0; }();  // tuning aid
-  const int cap = (cap_env > 0 && cap_env <= SK_MAXWG) ? cap_env : SK_DEFWG;
+  const int cap = (cap_env > 0 && cap_env <= SK_MAXWG) ? cap_env : sk_default_cap(B);
   return w > cap ? cap : (w < 1 ? 1 : w);
 }
 

@@ -195,6 +195,49 @@ def global_sinkhorn(scores_local: torch.Tensor, rows_out: int, eps: float, iters
     return solver(scores_local, iters, eps, row0=0, rows_out=rows_out)
 
 
+class GradExchange:
+    """The data-parallel gradient exchange, bucketed in the order the fused backward produces gradients (what DDP's
+    bucketed all-reduce does in the reference, models.py:1295).  ``push(grads)`` flattens the gradients that exist so far
+    and not yet sent into one buffer and starts an asynchronous all-reduce (SUM) on it - RCCL runs it on its own stream
+    while the backward of the earlier blocks continues on the compute stream; ``finish(grads)`` sends the rest, waits for
+    every bucket and returns the averaged gradients as views into the flat buffers.  Without an initialised process group
+    (or with one rank) both are no-ops.  At C2 sizes the three buckets are prototypes + head (2.2 M floats), final norm +
+    blocks.11 (1.8 M) and blocks.10 (1.8 M): only the last one is exposed."""
+
+    def __init__(self):
+        import torch.distributed as dist
+
+        self.dist = dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.sent = set()
+        self.buckets = []  # (keys, flat, work)
+
+    def push(self, grads: Dict[torch.nn.Parameter, torch.Tensor]) -> None:
+        if self.dist is None:
+            return
+        keys = [k for k in grads if k not in self.sent and k.requires_grad]
+        if not keys:
+            return
+        flat = torch.cat([grads[k].reshape(-1) for k in keys])
+        work = self.dist.all_reduce(flat, async_op=True)
+        self.sent.update(keys)
+        self.buckets.append((keys, flat, work))
+
+    def finish(self, grads: Dict[torch.nn.Parameter, torch.Tensor]) -> Dict[torch.nn.Parameter, torch.Tensor]:
+        if self.dist is None:
+            return grads
+        self.push(grads)
+        inv = 1.0 / self.dist.get_world_size()
+        for keys, flat, work in self.buckets:
+            work.wait()
+            flat *= inv
+            off = 0
+            for k in keys:
+                grads[k] = flat[off:off + k.numel()].view(k.shape)
+                off += k.numel()
+        self.buckets = []
+        return grads
+
+
 def allreduce_mean_(grads: Dict[torch.nn.Parameter, torch.Tensor]) -> Dict[torch.nn.Parameter, torch.Tensor]:
     """The data-parallel gradient exchange (what DDP's bucketed all-reduce does in the reference, models.py:1295):
     ONE flat all-reduce (SUM) over RCCL followed by the 1/W scale; the returned tensors are views into the flat

@@ -306,11 +306,13 @@ class TimeT(nn.Module):
 
         # ---- backward on the target frames only
         grads: Dict[nn.Parameter, torch.Tensor] = {}
+        exchange = engine.GradExchange()  # the data-parallel exchange: bucketed all-reduce (mean) over RCCL, overlapped with backward
         grads[self.prototypes], _ = ops.linear_bwd_weight(dscores, sv_sc["zn"], need_bias=False)
         dz = ops.l2norm_bwd(ops.linear_bwd_data(dscores, self.prototypes.data), sv_sc["zn"], sv_sc["inv"])
         if use_mask:
             ops.scale_rows_(dz, mask_tgt)  # backward of features * mask
         d_feats = engine.head_backward(dz, fe.head, sv_head, grads) if fe.head is not None else dz
+        exchange.push(grads)  # prototypes + head
         if train_ids:
             f0 = (fs - 1) * bs
             wg = vit.norm.weight.requires_grad
@@ -321,9 +323,10 @@ class TimeT(nn.Module):
             dx = dx.view(bs * N, D)
             for i in range(len(vit.blocks) - 1, first - 1, -1):
                 dx = engine.block_backward(dx, vit.blocks[i], vit.num_heads, save[i], f0, Fr, grads, need_dx=i > first)
+                if i > first:
+                    exchange.push(grads)  # this block's gradients travel while the next block's backward runs
         grads = {p: g for p, g in grads.items() if p.requires_grad}
-
-        return loss, engine.allreduce_mean_(grads)  # the data-parallel exchange: ONE flat all-reduce (mean) over RCCL
+        return loss, exchange.finish(grads)
 
 
 # ------------------------------------------------------------------------------------------------
