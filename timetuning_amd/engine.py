@@ -171,6 +171,34 @@ def prototype_scores(z: torch.Tensor, prototypes: torch.Tensor, save: Optional[d
     return ops.linear_fwd(zn, prototypes)
 
 
+def global_sinkhorn_begin(scores_local: torch.Tensor):
+    """Starts the all-gather of the local score rows (asynchronous: RCCL moves them on its own stream while the caller
+    keeps launching work that does not need the assignment) and returns the context ``global_sinkhorn_end`` consumes."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return (scores_local, None, None)
+    W = dist.get_world_size()
+    local = scores_local.contiguous()
+    gathered = torch.empty((W * local.shape[0], local.shape[1]), dtype=f32, device=local.device)
+    try:
+        work = dist.all_gather_into_tensor(gathered, local, async_op=True)
+    except RuntimeError:  # backends without the flat all-gather (gloo on device tensors, used by the 1-GPU 2-rank test)
+        work = dist.all_gather(list(gathered.chunk(W, dim=0)), local, async_op=True)
+    return (local, gathered, work)
+
+
+def global_sinkhorn_end(ctx, rows_out: int, eps: float, iters: int, solver=None) -> torch.Tensor:
+    import torch.distributed as dist
+
+    solver = ops.sinkhorn if solver is None else solver
+    local, gathered, work = ctx
+    if gathered is None:
+        return solver(local, iters, eps, row0=0, rows_out=rows_out)
+    work.wait()
+    return solver(gathered, iters, eps, row0=dist.get_rank() * local.shape[0], rows_out=rows_out)
+
+
 def global_sinkhorn(scores_local: torch.Tensor, rows_out: int, eps: float, iters: int, solver=None) -> torch.Tensor:
     """find_optimal_assignment (time_tuning.py:157-168) with the reference's cross-rank semantics
     (my_utils.py:250-272): ONE all-gather of the local score rows over RCCL, then every rank solves the global
@@ -180,19 +208,7 @@ def global_sinkhorn(scores_local: torch.Tensor, rows_out: int, eps: float, iters
 
     ``solver(scores, iters, eps, row0=, rows_out=)`` defaults to the HIP kernel; the CPU gloo tests inject the oracle
     to exercise the collective logic without a GPU."""
-    import torch.distributed as dist
-
-    solver = ops.sinkhorn if solver is None else solver
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        W, rank = dist.get_world_size(), dist.get_rank()
-        B_loc = scores_local.shape[0]
-        gathered = torch.empty((W * B_loc, scores_local.shape[1]), dtype=f32, device=scores_local.device)
-        try:
-            dist.all_gather_into_tensor(gathered, scores_local.contiguous())
-        except RuntimeError:  # backends without the flat all-gather (gloo on device tensors, used by the 1-GPU 2-rank test)
-            dist.all_gather(list(gathered.chunk(W, dim=0)), scores_local.contiguous())
-        return solver(gathered, iters, eps, row0=rank * B_loc, rows_out=rows_out)
-    return solver(scores_local, iters, eps, row0=0, rows_out=rows_out)
+    return global_sinkhorn_end(global_sinkhorn_begin(scores_local), rows_out, eps, iters, solver)
 
 
 class GradExchange:

@@ -258,10 +258,6 @@ class TimeT(nn.Module):
             feats = ops.layernorm_fwd(tok, vit.norm.weight, vit.norm.bias, drop_first_token=True)
         xn_bb = ops.l2norm_fwd(feats).view(fs, bs, n, D)           # label-propagation features (pre-head tokens)
         src_rows, tgt_rows = feats[: bs * n], feats[(fs - 1) * bs * n:]
-        sv_head: Optional[dict] = {} if need_grad else None
-        z_tgt = engine.head_forward(tgt_rows, fe.head, sv_head) if fe.head is not None else tgt_rows
-        if use_mask:
-            z_tgt = ops.scale_rows_(z_tgt if fe.head is not None else z_tgt.clone(), mask_tgt)  # features * mask (models.py:142)
 
         # ---- assignment source: teacher on frame 0 if present, else the student's frame 0 (no grad either way)
         if self.teacher is not None:
@@ -291,11 +287,17 @@ class TimeT(nn.Module):
         scores_q = engine.prototype_scores(z_q, protos_q)
         if self.queue_is_full():
             scores_q = torch.cat([scores_q, engine.prototype_scores(self.queue, protos_q)], dim=0)
-        q = engine.global_sinkhorn(scores_q, bs * n, hp["epsilon"], hp["iters"])                 # [bs*n, K]
+        gather = engine.global_sinkhorn_begin(scores_q)  # W > 1: the score rows travel while the target head runs
 
+        # ---- target frames: head + scores (with grad)
+        sv_head: Optional[dict] = {} if need_grad else None
+        z_tgt = engine.head_forward(tgt_rows, fe.head, sv_head) if fe.head is not None else tgt_rows
+        if use_mask:
+            z_tgt = ops.scale_rows_(z_tgt if fe.head is not None else z_tgt.clone(), mask_tgt)  # features * mask (models.py:142)
         sv_sc: Optional[dict] = {} if need_grad else None
         scores_t = engine.prototype_scores(z_tgt, self.prototypes.data, sv_sc)                 # [bs*n, K]
         K = scores_t.shape[1]
+        q = engine.global_sinkhorn_end(gather, bs * n, hp["epsilon"], hp["iters"])              # [bs*n, K]
         labels = ops.label_propagate(xn_bb, q.view(bs, n, K), hp["n_last_frames"], hp["radius"], hp["topk"], 0.1)
         loss, dscores = ops.ce_loss_fwd_bwd(scores_t, labels.view(-1), 0.1, need_grad, row_weight=mask_tgt)  # :296-300
         self.last_aux = dict(q=q.view(bs, n, K), target_scores=scores_t.view(bs, n, K), labels=labels)
