@@ -73,6 +73,14 @@ int tt_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
  * 3 = 64x64 (block tile; 4 waves each).  Exposed so that profilers can attribute launches to instantiations. */
 int tt_gemm_tile_choice(int M, int N, int batch);
 
+/* ---- k1b: interpolate_pos_encoding for inputs whose token grid differs from the stored one
+ *      (dino_vision_transformer.py:214-234): bicubic resampling of the patch position table, as
+ *      nn.functional.interpolate(..., scale_factor=(scale_h, scale_w), mode="bicubic") computes it (align_corners False,
+ *      coordinate scale 1/scale_factor, A = -0.75, border-clamped taps); the class row is copied.
+ *   pos [1 + g*g, D] -> out [1 + gh*gw, D].  The reference passes scale = (rows + 0.1) / g, (cols + 0.1) / g. */
+int tt_pos_embed_interpolate(const float* pos, float* out, int g, int gh, int gw, int D, float scale_h, float scale_w,
+                             tt_stream_t stream);
+
 /* Arithmetic of the forward nn.Linear products (tt_linear_fwd), process-wide:
  *   0 = f32 MFMA (default; exact fmaf chain, the mode every parity claim and the headline benchmark refer to)
  *   1 = "bf16x3": operands split into bf16 hi + lo, three bf16 MFMAs per product term (~2^-16 relative per product)

@@ -450,6 +450,33 @@ def gen_davis_protocol(ref):
     print("davis_protocol.npz written")
 
 
+def gen_extractor_sizes(ref):
+    """FeatureExtractor on inputs that are NOT 224x224: interpolate_pos_encoding's bicubic branch
+    (dino_vision_transformer.py:219-234), non-square token grids, token counts other than 197."""
+    import torch
+
+    from timetuning_amd import synth
+
+    cfg = synth.ARCHS["tiny-s16"]
+    model = build_reference_model(ref, "dino-s16", cfg, 20, (128, 128, 64, 32), "stress", 1)
+    fe = model.feature_extractor
+    out = dict(vit_cfg=np.array([cfg["embed_dim"], cfg["depth"], cfg["num_heads"], cfg["patch_size"]], np.int64),
+               head_list=np.array((128, 128, 64, 32), np.int64))
+    for tag, (H, W) in dict(a=(160, 192), b=(256, 256), c=(96, 64)).items():
+        x = torch.from_numpy(synth.normal(f"sizes.x.{tag}", (2, 3, H, W)))
+        with torch.no_grad():
+            feats, attn = fe(x)
+            bfeats, _ = fe(x, use_head=False)
+            pos = fe.backbone.interpolate_pos_encoding(torch.zeros(1, 1 + (H // 16) * (W // 16), cfg["embed_dim"]), H, W)
+        out[f"{tag}_hw"] = np.array([H, W], np.int64)
+        out[f"{tag}_pos"] = t2n(pos[0])
+        out[f"{tag}_features"] = t2n(feats)
+        out[f"{tag}_backbone_features"] = t2n(bfeats)
+        out[f"{tag}_attn_cls_row"] = t2n(attn[:, :, 0, :])
+    np.savez_compressed(os.path.join(OUT, "extractor_sizes.npz"), **out)
+    print("extractor_sizes.npz", {k: v.shape for k, v in out.items()})
+
+
 def gen_mask(ref):
     """models.process_attentions (with the blur / component-labelling stand-ins) on synthetic attention maps:
     peaked random maps at g = 14 and 28, plus hand-made cases for the small-component rule."""
@@ -514,6 +541,7 @@ def main():
         "timet_tiny": lambda: gen_timet(ref, "tiny", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "stress", False, 0, 3, True),
         "timet_tiny_tq": lambda: gen_timet(ref, "tiny_tq", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 2, "stress", True, 40, 3, True),
         "mask": lambda: gen_mask(ref),
+        "extractor_sizes": lambda: gen_extractor_sizes(ref),
         "davis_protocol": lambda: gen_davis_protocol(ref),
         "timet_tiny_mask": lambda: gen_timet_masked(ref, "tiny_mask", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "dino", False, 0, 2, True),
         "timet_tiny_mask_tq": lambda: gen_timet_masked(ref, "tiny_mask_tq", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 2, "dino", True, 40, 2,

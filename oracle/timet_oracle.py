@@ -45,9 +45,21 @@ def prepare_tokens(p, x, patch_size):
     t = t.flatten(2).transpose(1, 2)
     cls = p["cls_token"].expand(B, -1, -1)
     t = torch.cat((cls, t), dim=1)
-    if t.shape[1] != p["pos_embed"].shape[1]:
-        raise ValueError("oracle only restates the identity pos-embed branch (npatch == N, w == h)")
-    return t + p["pos_embed"]
+    return t + interpolate_pos_encoding(p["pos_embed"], t.shape[1] - 1, x.shape[2], x.shape[3], patch_size)
+
+
+def interpolate_pos_encoding(pos_embed, npatch, w, h, patch_size):
+    """dino_vision_transformer.py:214-234 (``w``/``h`` are the reference's names for the input's dims 2 and 3)."""
+    N = pos_embed.shape[1] - 1
+    if npatch == N and w == h:
+        return pos_embed
+    dim = pos_embed.shape[-1]
+    w0, h0 = w // patch_size + 0.1, h // patch_size + 0.1
+    g = int(math.sqrt(N))
+    patch_pos = F.interpolate(pos_embed[:, 1:].reshape(1, g, g, dim).permute(0, 3, 1, 2), scale_factor=(w0 / math.sqrt(N), h0 / math.sqrt(N)),
+                              mode="bicubic")
+    assert int(w0) == patch_pos.shape[-2] and int(h0) == patch_pos.shape[-1]
+    return torch.cat((pos_embed[:, 0].unsqueeze(0), patch_pos.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
 
 
 def attention(p, pre, x, num_heads):

@@ -122,11 +122,10 @@ def test_attention_fwd_bwd(ops, Fr, N, H):
     qd = qkv.double().requires_grad_(True)
     ref, lse_ref, p_ref = _attn_ref(qd, H)
     ref.backward(do.double())
-    out, lse, probs = ops.attention_fwd(dev(qkv), H, save_lse=True, return_probs=N <= 256)
+    out, lse, probs = ops.attention_fwd(dev(qkv), H, save_lse=True, return_probs=True)
     assert rel_err(out.cpu(), ref.detach()) < TOL
     assert rel_err(lse.cpu(), lse_ref.detach()) < TOL
-    if N <= 256:
-        assert rel_err(probs.cpu(), p_ref.detach()) < TOL
+    assert rel_err(probs.cpu(), p_ref.detach()) < TOL   # N > 256: the row-per-wave probabilities kernel
     dqkv = ops.attention_bwd(dev(qkv), out, dev(do), lse, H)
     assert rel_err(dqkv.cpu(), qd.grad) < 5e-5
 

@@ -52,6 +52,31 @@ def test_extractor_tiny(golden):
     assert torch.equal(f2, f)
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_extractor_other_input_sizes(golden, tag):
+    """Inputs that are not 224x224: bicubic pos-embed resampling (tt_pos_embed_interpolate), non-square token grids,
+    token counts 121 / 257 / 25 through the attention kernels; against the reference's outputs."""
+    from timetuning_amd import hip_ops as ops
+    from timetuning_amd.models import FeatureExtractor
+
+    g = golden("extractor_sizes")
+    D, depth, heads, patch = [int(v) for v in g["vit_cfg"]]
+    fe = FeatureExtractor("dino-s16", "", [int(v) for v in g["head_list"]], vit_cfg=dict(embed_dim=D, depth=depth, num_heads=heads, patch_size=patch),
+                          init="stress").cuda()
+    H, W = [int(v) for v in g[f"{tag}_hw"]]
+    x = torch.from_numpy(synth.normal(f"sizes.x.{tag}", (2, 3, H, W))).cuda()
+    pos = fe.backbone.pos_table(H, W)
+    assert rel_err(pos.cpu(), g[f"{tag}_pos"]) < 1e-5
+    assert fe.backbone.pos_table(H, W) is pos            # cached per input size
+    f, attn = fe(x)
+    bf, _ = fe(x, use_head=False)
+    assert rel_err(f.cpu(), g[f"{tag}_features"]) < 1e-4
+    assert rel_err(bf.cpu(), g[f"{tag}_backbone_features"]) < 1e-4
+    assert rel_err(attn[:, :, 0, :].cpu(), g[f"{tag}_attn_cls_row"]) < 1e-4
+    with pytest.raises(ValueError):
+        fe(torch.zeros(1, 3, 100, 224, device="cuda"))    # not a multiple of the patch size
+
+
 def test_loss_internals_tiny(golden):
     g, t = golden("aux_tiny"), golden("timet_tiny")
     model, _ = _build(t)

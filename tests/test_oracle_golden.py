@@ -89,6 +89,26 @@ def test_extractor_tiny(golden):
     assert rel_err(attn[:, :, 0, :].numpy(), g["attn_cls_row"]) < 1e-5
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_extractor_other_input_sizes(golden, tag):
+    """interpolate_pos_encoding's bicubic branch (dino_vision_transformer.py:219-234): 160x192 (non-square grid 10x12),
+    256x256 (16x16) and 96x64 (6x4) inputs."""
+    g = golden("extractor_sizes")
+    D, depth, heads, patch = [int(v) for v in g["vit_cfg"]]
+    cfg = dict(embed_dim=D, depth=depth, num_heads=heads, patch_size=patch)
+    m = O.build_oracle("dino-s16", 20, tuple(int(v) for v in g["head_list"]), mode="stress", vit_cfg=cfg)
+    H, W = [int(v) for v in g[f"{tag}_hw"]]
+    x = torch.from_numpy(synth.normal(f"sizes.x.{tag}", (2, 3, H, W)))
+    pos = O.interpolate_pos_encoding(m.feature_extractor.backbone["pos_embed"], (H // patch) * (W // patch), H, W, patch)
+    assert rel_err(pos[0].numpy(), g[f"{tag}_pos"]) < 1e-6
+    with torch.no_grad():
+        f, attn = m.feature_extractor(x)
+        bf, _ = m.feature_extractor(x, use_head=False)
+    assert rel_err(f.numpy(), g[f"{tag}_features"]) < 1e-5
+    assert rel_err(bf.numpy(), g[f"{tag}_backbone_features"]) < 1e-5
+    assert rel_err(attn[:, :, 0, :].numpy(), g[f"{tag}_attn_cls_row"]) < 1e-5
+
+
 def test_get_loss_internals_tiny(golden):
     g = golden("aux_tiny")
     t = golden("timet_tiny")

@@ -66,6 +66,7 @@ SIGNATURES = {
     "tt_foreground_mask": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_vp]),
     "tt_foreground_mask_from_probs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_vp]),
     "tt_scale_rows_inplace": (c_i, [c_vp, c_vp, c_i, c_i, c_vp]),
+    "tt_pos_embed_interpolate": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_f, c_vp]),
     "tt_label_propagate_maps": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
     "tt_upsample_argmax": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "tt_confusion_counts": (c_i, [c_vp, c_vp, c_ll, c_i, c_vp, c_vp]),

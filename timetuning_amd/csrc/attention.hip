@@ -327,6 +327,45 @@ __global__ __launch_bounds__(256) void attention_fwd_flash_kernel(const float* _
 
 int launch_attention_fwd_q2(const float* qkv, float* out, float* lse, int F, int N, int H, float scale, hipStream_t s);  // attention_q2.hip
 
+// Attention probabilities for sequences the register-resident kernel does not cover (N > 256, e.g. ViT-S/8's 785 tokens or
+// 256x256 inputs at patch 16): only callers that ask for the reference's attn[F,h,N,N] pay for it (FeatureExtractor with
+// return_attention=True; the training step never does).  One wave per query row, lane j handles keys j, j+64, ...: the
+// logits go straight into the output row, are reduced to max / sum across the wave and normalised in place.
+__global__ __launch_bounds__(256) void attention_probs_rows_kernel(const float* __restrict__ qkv, float* __restrict__ probs, int N, int H,
+                                                                  float scale) {
+  __shared__ float qs[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave, fh = blockIdx.y, f = fh / H, h = fh - f * H;
+  if (row >= N) return;
+  const int D3 = 3 * H * 64;
+  const float* base = qkv + (size_t)f * N * D3;
+  qs[wave][lane] = base[(size_t)row * D3 + h * 64 + lane];
+  __builtin_amdgcn_wave_barrier();
+  float* prow = probs + ((size_t)fh * N + row) * N;
+  float mx = -INFINITY;
+  for (int j = lane; j < N; j += 64) {
+    const float4* kr = reinterpret_cast<const float4*>(base + (size_t)j * D3 + H * 64 + h * 64);
+    float sdot = 0.f;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+      const float4 kv = kr[d];
+      sdot += qs[wave][4 * d] * kv.x + qs[wave][4 * d + 1] * kv.y + qs[wave][4 * d + 2] * kv.z + qs[wave][4 * d + 3] * kv.w;
+    }
+    sdot *= scale;
+    prow[j] = sdot;
+    mx = fmaxf(mx, sdot);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    const float e = expf(prow[j] - mx);
+    prow[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  for (int j = lane; j < N; j += 64) prow[j] = prow[j] / sum;
+}
+
 template <int NT>
 static int launch_fwd(const float* qkv, float* out, float* lse, float* probs, int F, int N, int H, float scale, hipStream_t s) {
   // 1-D over (frame*head, q-tile), ordered so that the q-tiles sharing K/V sit on one XCD (common.hpp xcd_group_decode)
@@ -347,10 +386,13 @@ extern "C" int tt_attention_fwd(const float* qkv, float* out, float* lse, float*
   TT_REQUIRE(aligned16(qkv) && aligned16(out), "attention_fwd: buffers must be 16-byte aligned");
   hipStream_t s = as_stream(stream);
   if (N > 256) {  // KV-tiled online-softmax kernel (ViT-S/8: 785 tokens)
-    TT_REQUIRE(probs == nullptr, "attention_fwd: attention probabilities are only produced for N <= 256 (got %d)", N);
     hipLaunchKernelGGL(attention_fwd_flash_kernel, dim3(xcd_group_grid(F * H, (N + 63) / 64)), dim3(256), 0, s, qkv, out, lse, N, H,
                        F * H, scale);
     TT_CHECK_LAUNCH("attention_fwd_flash");
+    if (probs) {
+      hipLaunchKernelGGL(attention_probs_rows_kernel, dim3((N + 3) / 4, F * H), dim3(256), 0, s, qkv, probs, N, H, scale);
+      TT_CHECK_LAUNCH("attention_probs_rows");
+    }
     return TT_OK;
   }
   const int nt = (N + 15) / 16;

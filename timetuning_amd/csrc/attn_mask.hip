@@ -195,9 +195,67 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ x, 
   reinterpret_cast<float4*>(x)[i] = v;
 }
 
+// interpolate_pos_encoding (dino_vision_transformer.py:214-234) for inputs whose token grid is not the stored one:
+// nn.functional.interpolate(patch_pos_embed [1,D,g,g], scale_factor=(sh, sw), mode="bicubic") - align_corners False, the
+// coordinate scale is 1 / scale_factor (scale_factor given, not recomputed), cubic convolution with A = -0.75, taps
+// clamped to the border - then the class row in front.  pos [1+g*g, D] -> out [1+gh*gw, D]; one thread per (token, 4 d's).
+__device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.f, x3 = 2.f - t, u = 1.f - t;
+  w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+  w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+  w[2] = ((A + 2.f) * u - (A + 3.f)) * u * u + 1.f;
+  w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+__global__ __launch_bounds__(256) void pos_embed_bicubic_kernel(const float* __restrict__ pos, float* __restrict__ out, int g, int gh,
+                                                                int gw, int D, float rscale_h, float rscale_w) {
+  const int d4 = D / 4;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)(1 + gh * gw) * d4;
+  if (idx >= total) return;
+  const int tok = (int)(idx / d4), d = (int)(idx - (long long)tok * d4) * 4;
+  if (tok == 0) {  // class position: copied
+    *reinterpret_cast<float4*>(out + d) = *reinterpret_cast<const float4*>(pos + d);
+    return;
+  }
+  const int oy = (tok - 1) / gw, ox = (tok - 1) - oy * gw;
+  const float ry = rscale_h * (oy + 0.5f) - 0.5f, rx = rscale_w * (ox + 0.5f) - 0.5f;
+  const float fy = floorf(ry), fx = floorf(rx);
+  float wy[4], wx[4];
+  cubic_coeffs(ry - fy, wy);
+  cubic_coeffs(rx - fx, wx);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int yy = min(max((int)fy - 1 + i, 0), g - 1);
+    float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xx = min(max((int)fx - 1 + j, 0), g - 1);
+      const float4 v = *reinterpret_cast<const float4*>(pos + (size_t)(1 + yy * g + xx) * D + d);
+      row.x += wx[j] * v.x; row.y += wx[j] * v.y; row.z += wx[j] * v.z; row.w += wx[j] * v.w;
+    }
+    acc.x += wy[i] * row.x; acc.y += wy[i] * row.y; acc.z += wy[i] * row.z; acc.w += wy[i] * row.w;
+  }
+  *reinterpret_cast<float4*>(out + (size_t)tok * D + d) = acc;
+}
+
 }  // namespace tt
 
 using namespace tt;
+
+extern "C" int tt_pos_embed_interpolate(const float* pos, float* out, int g, int gh, int gw, int D, float scale_h, float scale_w,
+                                        tt_stream_t stream) {
+  TT_REQUIRE(pos && out && g > 0 && gh > 0 && gw > 0, "pos_embed_interpolate: bad arguments");
+  TT_REQUIRE(D % 4 == 0 && aligned16(pos) && aligned16(out), "pos_embed_interpolate: D must be a multiple of 4, buffers 16-byte aligned");
+  TT_REQUIRE(scale_h > 0.f && scale_w > 0.f, "pos_embed_interpolate: scale factors must be positive");
+  const long long total = (long long)(1 + gh * gw) * (D / 4);
+  hipLaunchKernelGGL(pos_embed_bicubic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), pos, out, g, gh, gw,
+                     D, 1.0f / scale_h, 1.0f / scale_w);
+  TT_CHECK_LAUNCH("pos_embed_interpolate");
+  return TT_OK;
+}
 
 static int launch_foreground_mask(const FmArgs& a, tt_stream_t stream, const char* who) {
   TT_REQUIRE(a.mask && a.F > 0, "%s: null pointer / no frames", who);

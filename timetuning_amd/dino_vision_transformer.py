@@ -86,16 +86,32 @@ class VisionTransformer(nn.Module):
 
     # -- the reference's public methods ---------------------------------------------------------
     def _check(self, x: torch.Tensor):
-        n_side = x.shape[-1] // self.patch_embed.patch_size
-        if x.shape[-1] != x.shape[-2] or n_side * n_side != self.patch_embed.num_patches:
-            raise ValueError("only the identity branch of interpolate_pos_encoding is built: input must be "
-                             f"{self.patch_embed.img_size}x{self.patch_embed.img_size} (got {tuple(x.shape[-2:])})")
+        P = self.patch_embed.patch_size
+        if x.shape[-1] % P or x.shape[-2] % P or x.shape[-1] < P or x.shape[-2] < P:
+            raise ValueError(f"input height and width must be positive multiples of the patch size {P} (got {tuple(x.shape[-2:])})")
         return x.contiguous().float()
+
+    def pos_table(self, H: int, W: int) -> torch.Tensor:
+        """``interpolate_pos_encoding`` (dino_vision_transformer.py:214-234) as a [1 + rows*cols, D] table: the stored
+        ``pos_embed`` when the token grid is the stored square one, else its bicubic resampling (computed once per input size
+        and parameter version)."""
+        P, D = self.patch_embed.patch_size, self.embed_dim
+        rows, cols = H // P, W // P
+        if rows * cols == self.pos_embed.shape[1] - 1 and rows == cols:
+            return self.pos_embed.view(-1, D)
+        key = (rows, cols, self.pos_embed.data_ptr(), self.pos_embed._version)
+        cache = self.__dict__.setdefault("_pos_cache", {})
+        if key not in cache:
+            cache.clear()
+            with torch.no_grad():
+                cache[key] = ops.pos_embed_interpolate(self.pos_embed.detach().view(-1, D).contiguous(), rows, cols)
+        return cache[key]
 
     def prepare_tokens(self, x: torch.Tensor) -> torch.Tensor:
         pe = self.patch_embed.proj
         D = self.embed_dim
-        return ops.patch_embed_fwd(self._check(x), pe.weight.view(D, -1), pe.bias, self.cls_token.view(D), self.pos_embed.view(-1, D),
+        x = self._check(x)
+        return ops.patch_embed_fwd(x, pe.weight.view(D, -1), pe.bias, self.cls_token.view(D), self.pos_table(x.shape[-2], x.shape[-1]),
                                    self.patch_embed.patch_size)
 
     @torch.no_grad()

@@ -101,7 +101,7 @@ def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None,
     norm, attention probabilities of the last block or None).  ``last_block_aux`` receives the last block's qkv."""
     pe = vit.patch_embed.proj
     D = pe.weight.shape[0]
-    x = ops.patch_embed_fwd(img, pe.weight.view(D, -1), pe.bias, vit.cls_token.view(D), vit.pos_embed.view(-1, D),
+    x = ops.patch_embed_fwd(img, pe.weight.view(D, -1), pe.bias, vit.cls_token.view(D), vit.pos_table(img.shape[-2], img.shape[-1]),
                             vit.patch_embed.patch_size, frame_map)
     probs = None
     depth = len(vit.blocks)

@@ -180,13 +180,26 @@ def patch_embed_fwd(img, w, bias, cls, pos, patch: int, frame_map=None):
     if frame_map is not None: _chk(frame_map, "frame_map", torch.int32)
     n = (H // patch) * (W // patch)
     if pos.numel() != (n + 1) * D:
-        raise ValueError("pos_embed does not match the token grid (only the identity branch of interpolate_pos_encoding is built)")
+        raise ValueError("pos_embed does not match the token grid: pass VisionTransformer.pos_table(H, W)")
     tokens = torch.empty((F, n + 1, D), dtype=f32, device=img.device)
     e0 = _prof_begin()
     _lib.check(lib.tt_patch_embed_fwd(_p(img), _p(frame_map), _p(w), _p(bias), _p(cls), _p(pos), _p(tokens), F, Cc, H, W, patch, D,
                                       _stream()), "tt_patch_embed_fwd")
     _prof_end(e0, "patch", F * n, D, Cc * patch * patch)
     return tokens
+
+
+def pos_embed_interpolate(pos, grid_h: int, grid_w: int):
+    """interpolate_pos_encoding's bicubic branch (dino_vision_transformer.py:219-234): pos [1+g*g, D] -> [1+grid_h*grid_w, D]."""
+    lib = _lib.load()
+    _chk(pos, "pos")
+    D = pos.shape[-1]
+    g = int(round((pos.shape[0] - 1) ** 0.5))
+    out = torch.empty((1 + grid_h * grid_w, D), dtype=f32, device=pos.device)
+    # the reference adds 0.1 to the target grid before dividing ("to avoid floating point error in the interpolation")
+    _lib.check(lib.tt_pos_embed_interpolate(_p(pos), _p(out), g, grid_h, grid_w, D, (grid_h + 0.1) / g, (grid_w + 0.1) / g, _stream()),
+               "tt_pos_embed_interpolate")
+    return out
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-6, save_stats=False, out=None, drop_first_token=False):
