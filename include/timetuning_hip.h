@@ -159,8 +159,9 @@ size_t tt_label_propagate_workspace_bytes(int bs, int fs, int g, int D, int K, i
  *   tt_upsample_argmax       nn.functional.interpolate(maps, (R,R), mode="bilinear", align_corners=False) followed by
  *                            torch.max(dim=1) (mask_propagation.py:828-829), fused: maps [M, n, K] fp64 ->
  *                            labels_out [M, R, R] int64; the upsampled fp64 tensor is never written.
- *   tt_confusion_counts      counts[gt*C + pred] += 1 over n pixels (labels outside [0,C) ignored), uint64 [C,C]:
- *                            the confusion matrix from which the Jaccard index (J) of the propagated masks follows. */
+ *   tt_confusion_counts      counts[gt*C + pred] += 1 over n pixels (labels outside [0,C) ignored), uint64 [C,C],
+ *                            C <= 4096: the confusion matrix from which the Jaccard index (J) of the propagated masks and
+ *                            the evaluator's matched mIoU (metrics.py:357-432) follow. */
 int tt_label_propagate_maps(const float* xn, const float* seg0, double* pmap_all, int bs, int fs, int g, int D, int K,
                             int n_last_frames, int radius, int topk, float temperature, void* workspace,
                             size_t workspace_bytes, tt_stream_t stream);
@@ -220,6 +221,28 @@ int tt_foreground_mask(const float* qkv, float* mask_out, float* blurred_out, fl
                        float scale, float threshold, float sigma, int ksize, tt_stream_t stream);
 int tt_foreground_mask_from_probs(const float* cls_probs, float* mask_out, float* blurred_out, float* margin_out, int F, int N,
                                   int H, int g, float threshold, float sigma, int ksize, tt_stream_t stream);
+
+/* ---- N2: evaluator clustering - the device side of clustering.cluster_features / proto_clustering
+ *      (clustering.py:20-117), my_utils.normalize_and_transform (my_utils.py:19-37) and of the Lloyd iterations the
+ *      reference delegates to faiss.Kmeans(d, k, niter=50, nredo=5, seed=1).
+ *   tt_col_moments              per-column mean and population variance (StandardScaler, my_utils.py:24-30), fp64.
+ *   tt_upsample_bilinear_tokens token maps [M, g*g, C] -> [M, R*R, C] as nn.functional.interpolate(x.double(), (R,R),
+ *                               mode="bilinear").float() (clustering.py:34-36).
+ *   tt_upsample_argmax_f32      fp32 twin of tt_upsample_argmax for proto_clustering's prototype scores (clustering.py:101-104).
+ *   tt_kmeans_assign            labels[p] = argmin_j |x_p - c_j|^2 (first minimum) over centroids [k, d]; dist2 optional.
+ *   tt_kmeans_accumulate        sums[k, d] (fp64) and counts[k] of the points per label, deterministic (no atomics). */
+int tt_affine_cols_inplace(float* x, const float* scale, const float* shift, long long rows, int cols,
+                           tt_stream_t stream); /* x[r][c] = x[r][c] * scale[c] + shift[c] (StandardScaler.transform) */
+size_t tt_col_moments_workspace_bytes(long long rows, int cols);
+int tt_col_moments(const float* x, double* mean, double* var, long long rows, int cols, void* workspace, size_t workspace_bytes,
+                   tt_stream_t stream);
+int tt_upsample_bilinear_tokens(const float* x, float* out, int M, int g, int C, int R, tt_stream_t stream);
+int tt_upsample_argmax_f32(const float* maps, int64_t* labels_out, int M, int g, int K, int R, tt_stream_t stream);
+int tt_kmeans_assign(const float* x, const float* centroids, int32_t* labels, float* dist2, long long P, int d, int k,
+                     tt_stream_t stream);
+size_t tt_kmeans_accumulate_workspace_bytes(long long P, int d, int k);
+int tt_kmeans_accumulate(const float* x, const int32_t* labels, double* sums, long long* counts, long long P, int d, int k,
+                         void* workspace, size_t workspace_bytes, tt_stream_t stream);
 
 /* features * mask[..., None] (models.py:142) and its backward: x[r][:] *= row_scale[r], cols % 4 == 0. */
 int tt_scale_rows_inplace(float* x, const float* row_scale, int rows, int cols, tt_stream_t stream);

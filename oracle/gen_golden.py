@@ -477,6 +477,60 @@ def gen_extractor_sizes(ref):
     print("extractor_sizes.npz", {k: v.shape for k, v in out.items()})
 
 
+def gen_metric(ref):
+    """metrics.PredsmIoU.compute (metrics.py:246-432): Hungarian / many-to-one / precision-based matching, with and without the
+    background class, on label maps whose clusters are noisy refinements of the ground truth; and clustering.proto_clustering
+    without the k-means merge (clustering.py:82-104; the merge needs faiss)."""
+    import importlib
+
+    import torch
+
+    metrics = importlib.import_module("metrics")
+    clustering = importlib.import_module("clustering")
+    out = {}
+    rng = np.random.default_rng(5)
+    cases = dict(a=(6, 6, 4000), b=(4, 9, 6000), c=(3, 3, 500), d=(5, 2, 3000))
+    for tag, (n_gt, n_pred, n) in cases.items():
+        gt = rng.integers(0, n_gt, n)
+        if tag == "b":
+            gt = gt * 3                                   # non-contiguous label values
+        pred = (gt // (3 if tag == "b" else 1)) % n_pred
+        split = rng.random(n) < 0.5                        # over-segmentation: half of every class moves to another cluster id
+        pred = np.where(split, (pred + n_gt) % n_pred, pred)
+        noise = rng.random(n) < 0.15
+        pred = np.where(noise, rng.integers(0, n_pred, n), pred) + (7 if tag == "c" else 0)
+        out[f"{tag}_gt"], out[f"{tag}_pred"] = gt.astype(np.int16), pred.astype(np.int16)
+        for involve_bg in (False, True):
+            for mode, kw in dict(hungarian=dict(), many=dict(many_to_one=True), many_prec=dict(many_to_one=True, precision_based=True)).items():
+                m = metrics.PredsmIoU(n_pred, n_gt, involve_bg=involve_bg)
+                m.n_jobs = 1
+                m.update(torch.from_numpy(gt), torch.from_numpy(pred))
+                score, tp, fp, fn, reordered, bg = m.compute(True, **kw)
+                key = f"{tag}_{mode}_{int(involve_bg)}"
+                out[key + "_score"] = np.float64(score)
+                ks = sorted(tp)
+                out[key + "_classes"] = np.array(ks, np.int64)
+                out[key + "_tp"] = np.array([tp[k] for k in ks], np.int64)
+                out[key + "_fp"] = np.array([fp[k] for k in ks], np.int64)
+                out[key + "_fn"] = np.array([fn[k] for k in ks], np.int64)
+                out[key + "_reordered"] = np.asarray(reordered).astype(np.int16)
+                out[key + "_bg"] = np.float64(bg)
+    # proto_clustering (no merge)
+    from timetuning_amd import synth
+    x = torch.from_numpy(synth.normal("pc.x", (3, 196, 64)))
+    protos = torch.from_numpy(synth.normal("pc.p", (12, 64)))
+    assign = clustering.proto_clustering(x, protos, input_size=14, output_size=56)
+    with torch.no_grad():
+        xn, pn = torch.nn.functional.normalize(x, dim=-1), torch.nn.functional.normalize(protos, dim=-1)
+        sc = torch.einsum("klm,nm->kln", xn, pn).permute(0, 2, 1).reshape(3, 12, 14, 14)
+        up = torch.nn.functional.interpolate(sc, size=(56, 56), mode="bilinear", align_corners=False)
+        top2 = up.topk(2, dim=1).values
+    out["pc_assign"] = t2n(assign).astype(np.int16)
+    out["pc_near_tie"] = t2n((top2[:, 0] - top2[:, 1]) < 1e-6)
+    np.savez_compressed(os.path.join(OUT, "evaluator.npz"), **out)
+    print("evaluator.npz written", len(out), "arrays")
+
+
 def gen_mask(ref):
     """models.process_attentions (with the blur / component-labelling stand-ins) on synthetic attention maps:
     peaked random maps at g = 14 and 28, plus hand-made cases for the small-component rule."""
@@ -541,6 +595,7 @@ def main():
         "timet_tiny": lambda: gen_timet(ref, "tiny", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "stress", False, 0, 3, True),
         "timet_tiny_tq": lambda: gen_timet(ref, "tiny_tq", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 2, "stress", True, 40, 3, True),
         "mask": lambda: gen_mask(ref),
+        "metric": lambda: gen_metric(ref),
         "extractor_sizes": lambda: gen_extractor_sizes(ref),
         "davis_protocol": lambda: gen_davis_protocol(ref),
         "timet_tiny_mask": lambda: gen_timet_masked(ref, "tiny_mask", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "dino", False, 0, 2, True),

@@ -314,6 +314,99 @@ def jaccard(pred, gt, num_classes, involve_bg=False):
 
 
 # --------------------------------------------------------------------------------------
+# evaluator: matched mIoU (metrics.py:246-505), proto_clustering (clustering.py:82-104), and NumPy restatements of the
+# third-party pieces the evaluator delegates to (StandardScaler, faiss PCAMatrix, faiss Kmeans' Lloyd iteration) - the
+# latter are "parity unpinned": faiss is not installed and its RNG stream / LAPACK sign choices are not reproducible.
+# --------------------------------------------------------------------------------------
+
+
+def miou(gt, pred, many_to_one=False, precision_based=False, involve_bg=False):
+    """PredsmIoU.compute -> compute_miou (metrics.py:246-432) from flat integer label arrays.
+    Returns (score, tp, fp, fn, reordered_preds, matched_bg_clusters)."""
+    from scipy.optimize import linear_sum_assignment
+
+    gt, pred = np.asarray(gt).astype(int), np.asarray(pred).astype(int)
+    pred_unique, gt_unique = np.unique(pred), np.unique(gt)
+    num_pred, num_gt = len(pred_unique), len(gt_unique)
+
+    def score(c1, c2):  # get_score :435-455
+        a, b = gt == c1, pred == c2
+        tp_, fp_ = np.sum(a & b), np.sum(~a & b)
+        if precision_based:
+            return float(tp_) / max(float(tp_ + fp_), 1e-8)
+        return float(tp_) / max(float(tp_ + fp_ + np.sum(a & ~b)), 1e-8)
+
+    reordered = np.zeros(len(pred))
+    if many_to_one:
+        mat = np.array([score(c1, c2) for c2 in pred_unique for c1 in gt_unique]).reshape(num_pred, num_gt).T
+        best = {}
+        for pc in range(num_pred):
+            for gc in range(num_gt):
+                if pc not in best or mat[gc, pc] > best[pc][1]:
+                    best[pc] = (gc, mat[gc, pc])
+        for pc, (gc, _) in best.items():
+            reordered[pred == pred_unique[pc]] = gt_unique[gc]
+        bg = sum(1 for gc, _ in best.values() if gc == 0) / num_pred
+    else:
+        precision_based_saved, precision_based = precision_based, False   # _hungarian_match always matches on IoU (:476-483)
+        mat = np.array([score(c1, c2) for c2 in pred_unique for c1 in gt_unique]).reshape(num_pred, num_gt).T
+        precision_based = precision_based_saved
+        rows, cols = linear_sum_assignment(1 - mat)
+        for r, c in zip(rows, cols):
+            reordered[pred == pred_unique[c]] = gt_unique[r]
+        bg = 1 / num_gt
+    tp, fp, fn, jac = {}, {}, {}, {}
+    for g_ in gt_unique:
+        a, b = gt == g_, reordered == g_
+        tp[int(g_)], fp[int(g_)], fn[int(g_)] = int(np.sum(a & b)), int(np.sum(~a & b)), int(np.sum(a & ~b))
+        jac[int(g_)] = float(tp[int(g_)]) / max(float(tp[int(g_)] + fp[int(g_)] + fn[int(g_)]), 1e-8)
+    if not involve_bg:
+        jac.pop(0, None)
+        if len(jac) == 0:
+            jac[0] = 0
+    return float(np.mean(list(jac.values()))), tp, fp, fn, reordered.astype(int), bg
+
+
+def proto_clustering(x, prototypes, input_size=14, output_size=224):
+    """clustering.py:82-104 without the k-means merge of the prototypes (``num_classes=None``)."""
+    n, num_patches, dim = x.shape
+    xn, pn = F.normalize(x, dim=-1, p=2), F.normalize(prototypes, dim=-1, p=2)
+    scores = torch.einsum("klm,nm->kln", xn, pn).permute(0, 2, 1).reshape(n, prototypes.shape[0], input_size, input_size)
+    scores = F.interpolate(scores, size=(output_size, output_size), mode="bilinear", align_corners=False)
+    return scores.permute(0, 2, 3, 1).argmax(dim=-1)
+
+
+def standard_scale_pca(x: np.ndarray, pca_dim: int):
+    """StandardScaler (population variance, zero scales -> 1) followed by PCA onto the top ``pca_dim`` eigenvectors of the
+    covariance of the standardised data (faiss.PCAMatrix with eigen_power 0); rows oriented so that their largest-magnitude
+    entry is positive.  Returns (transformed [n, pca_dim], basis [pca_dim, dim])."""
+    x = x.astype(np.float64)
+    mean, std = x.mean(0), x.std(0)
+    std[std < 10 * np.finfo(np.float64).eps] = 1.0
+    z = (x - mean) / std
+    zc = z - z.mean(0)
+    evals, evecs = np.linalg.eigh(zc.T @ zc / len(z))
+    basis = evecs[:, np.argsort(evals)[::-1][:pca_dim]].T
+    basis = basis * np.sign(basis[np.arange(len(basis)), np.abs(basis).argmax(1)])[:, None]
+    return zc @ basis.T, basis
+
+
+def kmeans_lloyd(x: np.ndarray, init_idx, niter: int):
+    """Lloyd iterations from x[init_idx] (assignment to the nearest centroid, first minimum; means; empty clusters keep their
+    centroid).  Returns (centroids, labels of the last assignment, objective of the last assignment)."""
+    x = x.astype(np.float64)
+    cent = x[np.asarray(init_idx)].copy()
+    for _ in range(niter):
+        d2 = ((x[:, None, :] - cent[None, :, :]) ** 2).sum(-1)
+        lab = d2.argmin(1)
+        obj = d2[np.arange(len(x)), lab].sum()
+        for j in range(len(cent)):
+            if (lab == j).any():
+                cent[j] = x[lab == j].mean(0)
+    return cent, lab, obj
+
+
+# --------------------------------------------------------------------------------------
 # attention foreground mask  (models.py:93-144, the --use_mask branch)
 #
 # PARITY OF THIS SECTION: the reference calls two third-party functions that are not installed

@@ -1,0 +1,189 @@
+"""GPU parity of the evaluator path: column moments / scaler / PCA, bilinear token upsampling, k-means
+assignment and accumulation, the faiss-style Kmeans driver, cluster_features, proto_clustering and the matched mIoU, against
+the golden vectors generated from the reference (metric, proto_clustering) and the oracle's NumPy restatements of the
+third-party pieces (StandardScaler / PCA / Lloyd, "parity unpinned")."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from oracle import timet_oracle as O
+from timetuning_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from timetuning_amd import hip_ops
+
+    return hip_ops
+
+
+def dev(a):
+    return torch.as_tensor(a).cuda().contiguous()
+
+
+def test_col_moments_and_affine(ops):
+    x = synth.normal("ev.x", (5000, 384)) * np.linspace(0.1, 3.0, 384, dtype=np.float32) + np.linspace(-2, 2, 384, dtype=np.float32)
+    mean, var = ops.col_moments(dev(x))
+    assert rel_err(mean.cpu(), x.astype(np.float64).mean(0)) < 1e-10
+    assert rel_err(var.cpu(), x.astype(np.float64).var(0)) < 1e-9
+    sc, sh = synth.normal("ev.sc", (384,)), synth.normal("ev.sh", (384,))
+    y = ops.affine_cols_(dev(x.copy()), dev(sc), dev(sh))
+    assert rel_err(y.cpu(), x * sc + sh) < 1e-6
+
+
+def test_upsample_bilinear_tokens(ops):
+    for g_, R, C in ((14, 56, 50), (28, 60, 7), (3, 8, 300)):
+        x = torch.from_numpy(synth.normal(f"ev.up.{g_}", (2, g_ * g_, C)))
+        want = F.interpolate(x.double().transpose(1, 2).reshape(2, C, g_, g_), size=(R, R), mode="bilinear").float()
+        want = want.reshape(2, C, R * R).transpose(1, 2)
+        got = ops.upsample_bilinear_tokens(dev(x), R).cpu()
+        assert rel_err(got, want) < 1e-6
+
+
+def test_kmeans_kernels(ops):
+    P, d, k = 7001, 50, 21
+    x = synth.normal("ev.km.x", (P, d))
+    c = x[:k] * 0.5
+    labels, dist2 = ops.kmeans_assign(dev(x), dev(c), return_dist=True)
+    d2 = ((x[:, None, :].astype(np.float64) - c[None].astype(np.float64)) ** 2).sum(-1)
+    want = d2.argmin(1)
+    mism = labels.cpu().numpy() != want
+    srt = np.sort(d2, 1)
+    assert (srt[mism, 1] - srt[mism, 0] < 1e-4 * srt[mism, 0]).all()        # only near-ties may differ
+    assert rel_err(dist2.cpu(), d2.min(1)) < 1e-5
+    sums, counts = ops.kmeans_accumulate(dev(x), labels, k)
+    lab = labels.cpu().numpy()
+    assert (counts.cpu().numpy() == np.bincount(lab, minlength=k)).all()
+    want_sums = np.stack([x[lab == j].astype(np.float64).sum(0) for j in range(k)])
+    assert rel_err(sums.cpu(), want_sums) < 1e-5
+    s2, c2 = ops.kmeans_accumulate(dev(x), labels, k)
+    assert torch.equal(s2, sums) and torch.equal(c2, counts)               # deterministic
+
+
+def test_normalize_and_transform_vs_oracle():
+    from timetuning_amd.clustering import normalize_and_transform
+
+    n, dim, p = 6000, 96, 20
+    basis = synth.normal("ev.pca.b", (dim, dim))
+    x = (synth.normal("ev.pca.x", (n, dim)) * np.linspace(3.0, 0.05, dim, dtype=np.float32)) @ basis + 0.7
+    got = normalize_and_transform(dev(x.astype(np.float32)), p).cpu().numpy()
+    want, _ = O.standard_scale_pca(x.astype(np.float32), p)
+    # eigen-directions with well separated eigenvalues agree up to fp32 Gram-matrix rounding
+    for j in range(8):
+        assert rel_err(got[:, j], want[:, j]) < 2e-3, j
+    # the retained subspace agrees as a whole: same pairwise distances
+    i = np.arange(0, 200)
+    dg = ((got[i, None] - got[None, i]) ** 2).sum(-1)
+    dw = ((want[i, None] - want[None, i]) ** 2).sum(-1)
+    assert rel_err(dg, dw) < 1e-3
+
+
+def test_kmeans_driver_vs_oracle_lloyd():
+    from timetuning_amd.clustering import Kmeans
+
+    k, d = 5, 8
+    centres = synth.normal("ev.kd.c", (k, d)) * 6
+    x = np.concatenate([centres[j] + synth.normal(f"ev.kd.{j}", (300, d)) for j in range(k)]).astype(np.float32)
+    init = [[0, 300, 600, 900, 1200], [1, 2, 3, 4, 5]]
+    km = Kmeans(d, k, niter=10, nredo=2, seed=1, max_points_per_centroid=10 ** 6)   # no subsampling: the init rows index x itself
+    best = km.train(dev(x), init_indices=init)
+    objs = []
+    for idx in init:
+        cent, lab, obj = O.kmeans_lloyd(x, idx, 10)
+        objs.append(obj)
+    assert np.allclose(km.obj, objs, rtol=1e-4)
+    assert abs(best - min(objs)) < 1e-4 * min(objs)
+    cent, lab, _ = O.kmeans_lloyd(x, init[int(np.argmin(objs))], 10)
+    assert rel_err(km.centroids, cent) < 1e-4
+    _, labels = km.assign(dev(x))
+    assert (labels.cpu().numpy() == ((x[:, None] - km.centroids[None]) ** 2).sum(-1).argmin(1)).mean() > 0.999
+    # default seeding: well separated blobs are recovered whatever the random draws are
+    km2 = Kmeans(d, k)
+    km2.train(dev(x))
+    lab2 = km2.assign(dev(x))[1].cpu().numpy()
+    truth = np.repeat(np.arange(k), 300)
+    assert O.miou(truth + 1, lab2, involve_bg=True)[0] > 0.99
+    # an empty cluster is re-seeded by splitting a populated one
+    km3 = Kmeans(d, 3, niter=3, nredo=1)
+    far = np.concatenate([x[:600], np.full((1, d), 1e3, np.float32)])
+    km3.train(dev(far), init_indices=[[0, 1, 600]])
+    assert np.isfinite(km3.centroids).all()
+
+
+def test_cluster_features_recovers_planted_segments():
+    """cluster_features on token features made of K planted segment prototypes + noise, all three protocols: after Hungarian
+    matching the clusters reproduce the planted segmentation."""
+    from timetuning_amd.clustering import cluster_features
+    from timetuning_amd.evaluation import evaluate_localizations
+    from timetuning_amd.metrics import PredsmIoU
+
+    bs, fs, g_, dim, K, R = 2, 2, 14, 64, 4, 28
+    protos = synth.normal("ev.cf.p", (K, dim)) * 3
+    yy, xx = np.mgrid[0:g_, 0:g_]
+    seg = ((yy >= 7).astype(int) * 2 + (xx >= 7).astype(int)).reshape(-1)              # 4 quadrants
+    feats = np.stack([[protos[seg] + 0.3 * synth.normal(f"ev.cf.n{b}{f}", (g_ * g_, dim)) for f in range(fs)] for b in range(bs)])
+    gt = torch.from_numpy(np.kron(seg.reshape(g_, g_), np.ones((R // g_, R // g_), int))).cuda()
+    gts = gt[None, None].expand(bs, fs, R, R).contiguous() + 1                           # labels 1..4 (0 = background, unused)
+    for protocol in ("frame-wise", "sample-wise", "dataset-wise"):
+        maps = cluster_features(dev(feats.astype(np.float32)), K, g_, R, protocol)
+        assert maps.shape == (bs, fs, R, R) and maps.dtype == torch.int16
+        score = evaluate_localizations(PredsmIoU(K, K), gts, maps.long(), protocol)
+        assert score > 0.9, (protocol, score)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_matched_miou_golden(golden, tag):
+    from timetuning_amd.metrics import PredsmIoU
+
+    d = golden("evaluator")
+    gt, pred = torch.from_numpy(d[f"{tag}_gt"].astype(np.int64)), torch.from_numpy(d[f"{tag}_pred"].astype(np.int64))
+    for involve_bg in (0, 1):
+        for mode, kw in dict(hungarian={}, many=dict(many_to_one=True), many_prec=dict(many_to_one=True, precision_based=True)).items():
+            key = f"{tag}_{mode}_{involve_bg}"
+            m = PredsmIoU(3, 3, involve_bg=bool(involve_bg))
+            m.update(gt[:1000].cuda(), pred[:1000].cuda())
+            m.update(gt[1000:].cuda(), pred[1000:].cuda())
+            score, tp, fp, fn, reordered, bg = m.compute(True, **kw)
+            assert abs(score - float(d[key + "_score"])) < 1e-12, key
+            ks = [int(k) for k in d[key + "_classes"]]
+            assert [tp[k] for k in ks] == list(d[key + "_tp"]) and [fp[k] for k in ks] == list(d[key + "_fp"]) and [fn[k] for k in ks] == list(d[key + "_fn"])
+            assert (reordered.cpu().numpy() == d[key + "_reordered"]).all() and abs(bg - float(d[key + "_bg"])) < 1e-12
+
+
+def test_proto_clustering_golden(golden):
+    from timetuning_amd.clustering import proto_clustering
+
+    d = golden("evaluator")
+    x = dev(synth.normal("pc.x", (3, 196, 64)))
+    protos = dev(synth.normal("pc.p", (12, 64)))
+    got = proto_clustering(x, protos, input_size=14, output_size=56).cpu().numpy()
+    assert got.shape == (3, 56, 56)
+    assert not ((got != d["pc_assign"]) & ~d["pc_near_tie"]).any()
+    merged = proto_clustering(x, protos, input_size=14, output_size=56, num_classes=4)
+    assert merged.shape == (3, 56, 56) and int(merged.max()) <= 3
+
+
+def test_evaluator_end_to_end():
+    """Evaluator.evaluate on a synthetic loader (tracking clips with masks), k-means and prototype clustering."""
+    from timetuning_amd import mask_propagation as MP
+    from timetuning_amd.evaluation import Evaluator
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    # (prototype clustering scores the HEADLESS features against the prototypes - evaluation.py:433,468 - so it needs a model
+    # whose prototypes live in the backbone's feature space, i.e. one built without a projection head)
+    models = {"k-means": TimeT(FeatureExtractor("dino-s16", "", [1024, 1024, 512, 256], init="stress", return_attention=False), 20).cuda(),
+              "prototypes": TimeT(FeatureExtractor("dino-s16", "", [], init="stress", return_attention=False), 20).cuda()}
+    loader = []
+    for i in range(2):
+        clip, masks = MP.synthetic_tracking_clip(2, 224, seed=10 + i)
+        loader.append((clip[None, None], masks[None, None].float(), torch.zeros(1)))
+    for algo in ("k-means", "prototypes"):
+        ev = Evaluator(models[algo], loader, num_prototypes=3, clustering_algorithm=algo, involve_bg=True)
+        for protocol in ("frame-wise", "dataset-wise"):
+            s = ev.evaluate(evaluation_protocol=protocol, eval_resolution=56, num_clusters=3)
+            assert 0.0 <= s <= 1.0

@@ -262,6 +262,29 @@ def test_to_one_hot_and_jaccard():
     assert abs(O.jaccard(a, b, 3, involve_bg=True) - (0.5 + 0.5 + 0.5) / 3) < 1e-12
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_matched_miou(golden, tag):
+    """PredsmIoU.compute (metrics.py:246-432): Hungarian, many-to-one and precision-based matching, background in / out."""
+    d = golden("evaluator")
+    gt, pred = d[f"{tag}_gt"].astype(int), d[f"{tag}_pred"].astype(int)
+    for involve_bg in (0, 1):
+        for mode, kw in dict(hungarian={}, many=dict(many_to_one=True), many_prec=dict(many_to_one=True, precision_based=True)).items():
+            key = f"{tag}_{mode}_{involve_bg}"
+            score, tp, fp, fn, reordered, bg = O.miou(gt, pred, involve_bg=bool(involve_bg), **kw)
+            assert abs(score - float(d[key + "_score"])) < 1e-12, key
+            ks = [int(k) for k in d[key + "_classes"]]
+            assert [tp[k] for k in ks] == list(d[key + "_tp"]) and [fp[k] for k in ks] == list(d[key + "_fp"]) and [fn[k] for k in ks] == list(d[key + "_fn"])
+            assert (reordered == d[key + "_reordered"]).all() and abs(bg - float(d[key + "_bg"])) < 1e-12
+
+
+def test_proto_clustering(golden):
+    d = golden("evaluator")
+    x = torch.from_numpy(synth.normal("pc.x", (3, 196, 64)))
+    protos = torch.from_numpy(synth.normal("pc.p", (12, 64)))
+    got = O.proto_clustering(x, protos, 14, 56).numpy()
+    assert not ((got != d["pc_assign"]) & ~d["pc_near_tie"]).any()
+
+
 def test_state_dict_layout(golden):
     """SURVEY section 5 checkpoint layout: key names the build must reproduce."""
     keys = [str(k) for k in golden("timet_tiny_tq")["state_dict_keys"]]

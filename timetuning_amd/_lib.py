@@ -67,6 +67,14 @@ SIGNATURES = {
     "tt_foreground_mask_from_probs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_vp]),
     "tt_scale_rows_inplace": (c_i, [c_vp, c_vp, c_i, c_i, c_vp]),
     "tt_pos_embed_interpolate": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_f, c_vp]),
+    "tt_affine_cols_inplace": (c_i, [c_vp, c_vp, c_vp, c_ll, c_i, c_vp]),
+    "tt_col_moments_workspace_bytes": (c_sz, [c_ll, c_i]),
+    "tt_col_moments": (c_i, [c_vp, c_vp, c_vp, c_ll, c_i, c_vp, c_sz, c_vp]),
+    "tt_upsample_bilinear_tokens": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
+    "tt_upsample_argmax_f32": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
+    "tt_kmeans_assign": (c_i, [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_vp]),
+    "tt_kmeans_accumulate_workspace_bytes": (c_sz, [c_ll, c_i, c_i]),
+    "tt_kmeans_accumulate": (c_i, [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_label_propagate_maps": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
     "tt_upsample_argmax": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "tt_confusion_counts": (c_i, [c_vp, c_vp, c_ll, c_i, c_vp, c_vp]),

@@ -345,6 +345,16 @@ __global__ __launch_bounds__(256) void confusion_kernel(const int64_t* __restric
   for (int i = threadIdx.x; i < cells; i += 256)
     if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
 }
+
+// more classes than an LDS histogram holds (many-to-one evaluation with hundreds of clusters): global integer atomics
+__global__ __launch_bounds__(256) void confusion_global_kernel(const int64_t* __restrict__ pred, const int64_t* __restrict__ gt, long long n,
+                                                               int C, unsigned long long* __restrict__ counts) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const long long p = pred[i], t = gt[i];
+    if (p >= 0 && p < C && t >= 0 && t < C) atomicAdd(&counts[t * C + p], 1ull);
+  }
+}
 }  // namespace tt
 
 extern "C" int tt_upsample_argmax(const double* maps, int64_t* labels_out, int M, int g, int K, int R, tt_stream_t stream) {
@@ -357,7 +367,7 @@ extern "C" int tt_upsample_argmax(const double* maps, int64_t* labels_out, int M
 extern "C" int tt_confusion_counts(const int64_t* pred, const int64_t* gt, long long n, int C, unsigned long long* counts,
                                    tt_stream_t stream) {
   TT_REQUIRE(pred && gt && counts && n > 0, "confusion_counts: bad arguments");
-  TT_REQUIRE(C > 0 && C <= 96, "confusion_counts: need 0 < classes <= 96 (got %d)", C);
+  TT_REQUIRE(C > 0 && C <= 4096, "confusion_counts: need 0 < classes <= 4096 (got %d)", C);
   hipStream_t s = as_stream(stream);
   if (hipMemsetAsync(counts, 0, sizeof(unsigned long long) * C * C, s) != hipSuccess) {
     set_error("confusion_counts: memset failed");
@@ -365,7 +375,10 @@ extern "C" int tt_confusion_counts(const int64_t* pred, const int64_t* gt, long 
   }
   long long blocks = (n + 256 * 16 - 1) / (256 * 16);
   blocks = blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks);
-  hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)blocks), dim3(256), sizeof(unsigned int) * C * C, s, pred, gt, n, C, counts);
+  if (C <= 96)
+    hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)blocks), dim3(256), sizeof(unsigned int) * C * C, s, pred, gt, n, C, counts);
+  else
+    hipLaunchKernelGGL(confusion_global_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pred, gt, n, C, counts);
   TT_CHECK_LAUNCH("confusion_counts");
   return TT_OK;
 }

@@ -371,6 +371,77 @@ def confusion_counts(pred, gt, num_classes: int):
     return counts
 
 
+def col_moments(x):
+    """Per-column mean and population variance of x [rows, cols] (fp64 tensors)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    rows, cols = x.shape
+    mean = torch.empty(cols, dtype=torch.float64, device=x.device)
+    var = torch.empty_like(mean)
+    nb = lib.tt_col_moments_workspace_bytes(rows, cols)
+    ws = _ws(nb, x.device)
+    _lib.check(lib.tt_col_moments(_p(x), _p(mean), _p(var), rows, cols, _p(ws), nb, _stream()), "tt_col_moments")
+    return mean, var
+
+
+def affine_cols_(x, scale, shift):
+    """x[r, c] = x[r, c] * scale[c] + shift[c] in place."""
+    lib = _lib.load()
+    _chk(x, "x"); _chk(scale, "scale"); _chk(shift, "shift")
+    rows, cols = x.shape
+    _lib.check(lib.tt_affine_cols_inplace(_p(x), _p(scale), _p(shift), rows, cols, _stream()), "tt_affine_cols_inplace")
+    return x
+
+
+def upsample_bilinear_tokens(x, resolution: int):
+    """x [M, g*g, C] fp32 -> [M, R*R, C] fp32 (bilinear, align_corners=False, fp64 arithmetic)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    M, n, Cc = x.shape
+    g = int(round(n ** 0.5))
+    assert g * g == n
+    out = torch.empty((M, resolution * resolution, Cc), dtype=f32, device=x.device)
+    _lib.check(lib.tt_upsample_bilinear_tokens(_p(x), _p(out), M, g, Cc, int(resolution), _stream()), "tt_upsample_bilinear_tokens")
+    return out
+
+
+def upsample_argmax_f32(maps, resolution: int):
+    """maps [M, n, K] fp32 -> labels [M, R, R] int64 (fp32 bilinear interpolation, first maximum)."""
+    lib = _lib.load()
+    _chk(maps, "maps")
+    M, n, K = maps.shape
+    g = int(round(n ** 0.5))
+    assert g * g == n
+    out = torch.empty((M, resolution, resolution), dtype=torch.int64, device=maps.device)
+    _lib.check(lib.tt_upsample_argmax_f32(_p(maps), _p(out), M, g, K, int(resolution), _stream()), "tt_upsample_argmax_f32")
+    return out
+
+
+def kmeans_assign(x, centroids, return_dist=False):
+    """x [P, d], centroids [k, d] -> labels int32 [P] (+ squared distances)."""
+    lib = _lib.load()
+    _chk(x, "x"); _chk(centroids, "centroids")
+    P, d = x.shape
+    k = centroids.shape[0]
+    labels = torch.empty(P, dtype=torch.int32, device=x.device)
+    dist2 = torch.empty(P, dtype=f32, device=x.device) if return_dist else None
+    _lib.check(lib.tt_kmeans_assign(_p(x), _p(centroids), _p(labels), _p(dist2), P, d, k, _stream()), "tt_kmeans_assign")
+    return (labels, dist2) if return_dist else labels
+
+
+def kmeans_accumulate(x, labels, k: int):
+    """Sums [k, d] (fp64) and counts [k] (int64) of the points of each label."""
+    lib = _lib.load()
+    _chk(x, "x"); _chk(labels, "labels", torch.int32)
+    P, d = x.shape
+    sums = torch.empty((k, d), dtype=torch.float64, device=x.device)
+    counts = torch.empty(k, dtype=torch.int64, device=x.device)
+    nb = lib.tt_kmeans_accumulate_workspace_bytes(P, d, k)
+    ws = _ws(nb, x.device)
+    _lib.check(lib.tt_kmeans_accumulate(_p(x), _p(labels), _p(sums), _p(counts), P, d, k, _p(ws), nb, _stream()), "tt_kmeans_accumulate")
+    return sums, counts
+
+
 def ce_loss_fwd_bwd(scores, labels, temperature=0.1, need_grad=True, row_weight=None):
     """mean CE of scores/temperature vs labels (per-row weights = the --use_mask loss mask); returns (loss[1], dscores or None)."""
     lib = _lib.load()

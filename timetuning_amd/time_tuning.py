@@ -518,8 +518,9 @@ class SyntheticClips:
 
 
 def time_tuning(gpu=0, args=None):
-    """One process per GPU (``time_tuning.py:508-666``): model, optimiser, epoch loop.  Evaluation every 4 epochs
-    (faiss k-means + Hungarian mIoU on Pascal VOC, :634-646) is out of scope."""
+    """One process per GPU (``time_tuning.py:508-666``): model, optimiser, epoch loop.  The evaluation the reference runs
+    every 4 epochs on Pascal VOC (:634-646) is available as ``timetuning_amd.evaluation.Evaluator`` but not wired in here:
+    the dataset readers are out of scope."""
     import torch.distributed as dist
 
     global world_size

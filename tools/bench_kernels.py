@@ -66,6 +66,17 @@ def main():
     qkv64 = torch.randn(64, 197, 1152, device=dev)
     t = timeit(lambda: ops.foreground_mask(qkv64, 6, 14))
     print(f"foreground_mask 64 frames g=14             {t * 1e6:8.1f} {64 / t:8.0f} frames/s")
+    # evaluator clustering (N2): 64 frames of 196 x 50 PCA features -> 224 x 224, then one k-means assignment scan (k = 21)
+    f50 = torch.randn(64, 196, 50, device=dev)
+    t = timeit(lambda: ops.upsample_bilinear_tokens(f50, 224))
+    up = ops.upsample_bilinear_tokens(f50, 224).view(-1, 50)
+    print(f"upsample tokens 64 x 14^2 -> 224^2 x 50     {t * 1e6:8.1f} {up.numel() * 4 / t / 1e9:8.0f} GB/s written")
+    cent = up[:21].clone()
+    t = timeit(lambda: ops.kmeans_assign(up, cent))
+    print(f"kmeans_assign {up.shape[0]} pts d=50 k=21        {t * 1e6:8.1f} {up.numel() * 4 / t / 1e9:8.0f} GB/s read")
+    lab = ops.kmeans_assign(up, cent)
+    t = timeit(lambda: ops.kmeans_accumulate(up, lab, 21))
+    print(f"kmeans_accumulate (deterministic)          {t * 1e6:8.1f} {up.numel() * 4 / t / 1e9:8.0f} GB/s read")
     # evaluation protocol (N4): one 25-frame clip, 4 context frames, radius 12, 8 classes, + upsample/argmax to 224
     for g_ in (14, 28):
         xn = torch.nn.functional.normalize(torch.randn(25, 1, g_ * g_, 384, device=dev), dim=-1)
