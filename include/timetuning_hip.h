@@ -244,6 +244,29 @@ size_t tt_kmeans_accumulate_workspace_bytes(long long P, int d, int k);
 int tt_kmeans_accumulate(const float* x, const int32_t* labels, double* sums, long long* counts, long long P, int d, int k,
                          void* workspace, size_t workspace_bytes, tt_stream_t stream);
 
+/* ---- N3: the clip input pipeline - the pixel work of video_transformations.py as wired at
+ *      time_tuning.py:588-593, bit-exact with Pillow (which the reference calls per frame on the host).
+ *   Frames are interleaved uint8 RGB [F, H, W, 3] in device memory.
+ *   tt_img_resample_h   horizontal pass of Image.resize(BILINEAR) (Resample.c) over the crop rows y0..y0+h, columns starting
+ *                       at x0: out [F, h, OW, 3].  coeffs int32 [OW, ksize] / bounds int32 [OW, 2] are Resample.c's 22-bit taps
+ *                       (device memory; timetuning_amd.video_transformations.resample_coeffs builds them on the host).
+ *   tt_img_resample_v   vertical pass over in [F, Hin, W, 3] starting at row y0: either out_u8 [F, OH, W, 3] or out_f32
+ *                       [F, 3, OH, W] = ClipToTensor(mean, std) of the (optionally horizontally flipped) result
+ *                       (video_transformations.py:168-179,262-276); mean3 / std3 are HOST pointers to 3 floats.
+ *   tt_img_color        in place: mode 0 RandomGrayscale's convert("L") replicated to 3 channels; 1 / 2 / 3 torchvision
+ *                       adjust_brightness / adjust_contrast / adjust_saturation (ImageEnhance = Blend.c); 4 adjust_hue
+ *                       (hue_shift = uint8(hue_factor * 255)).  gray_sums: F uint64 of workspace for mode 2.
+ *   tt_img_box_blur     one pass of BoxBlur.c along x (direction 0) or y (1); ImageFilter.GaussianBlur(radius) is three x
+ *                       passes then three y passes with (radius, ww, fw) from the box radius (video_transformations.py:604-647). */
+int tt_img_resample_h(const unsigned char* in, unsigned char* out, const int* coeffs, const int* bounds, int F, int H, int W, int y0, int x0,
+                      int h, int OW, int ksize, tt_stream_t stream);
+int tt_img_resample_v(const unsigned char* in, unsigned char* out_u8, float* out_f32, const int* coeffs, const int* bounds, int F, int Hin,
+                      int W, int y0, int OH, int ksize, int flip, const float* mean3, const float* std3, tt_stream_t stream);
+int tt_img_color(unsigned char* img, int F, int H, int W, int mode, float factor, int hue_shift, unsigned long long* gray_sums,
+                 tt_stream_t stream);
+int tt_img_box_blur(const unsigned char* in, unsigned char* out, int F, int H, int W, int direction, int radius, unsigned ww, unsigned fw,
+                    tt_stream_t stream);
+
 /* features * mask[..., None] (models.py:142) and its backward: x[r][:] *= row_scale[r], cols % 4 == 0. */
 int tt_scale_rows_inplace(float* x, const float* row_scale, int rows, int cols, tt_stream_t stream);
 

@@ -531,6 +531,60 @@ def gen_metric(ref):
     print("evaluator.npz written", len(out), "arrays")
 
 
+def gen_transforms(ref):
+    """The reference's training transforms (time_tuning.py:588-593) run on PIL clips with seeded generators.
+    video_transformations.py reaches torchvision for ToTensor and the adjust_* functions; torchvision is not installed, so
+    the published PIL-backend implementations of those five functions (they only call Pillow, which IS installed) stand in."""
+    import importlib
+    import random
+    import types
+
+    import torch
+    from PIL import Image, ImageEnhance
+
+    vt = importlib.import_module("video_transformations")
+
+    def to_tensor(pic):
+        a = np.array(pic, copy=True)
+        return torch.from_numpy(a).view(pic.size[1], pic.size[0], 3).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+    def adjust_hue(img, hue_factor):
+        h, s_, v = img.convert("HSV").split()
+        nh = (np.array(h, dtype=np.int32) + int(hue_factor * 255) % 256) % 256    # np_h += np.uint8(hue_factor * 255), wrapping
+        return Image.merge("HSV", (Image.fromarray(nh.astype(np.uint8), "L"), s_, v)).convert("RGB")
+
+    functional = types.SimpleNamespace(adjust_brightness=lambda img, f: ImageEnhance.Brightness(img).enhance(f),
+                                       adjust_contrast=lambda img, f: ImageEnhance.Contrast(img).enhance(f),
+                                       adjust_saturation=lambda img, f: ImageEnhance.Color(img).enhance(f), adjust_hue=adjust_hue)
+    vt.torchvision = types.SimpleNamespace(transforms=types.SimpleNamespace(ToTensor=lambda: to_tensor, functional=functional))
+
+    R = 64
+    rand_color_jitter = vt.RandomApply([vt.ColorJitter(brightness=0.8, contrast=0.8, saturation=0.8, hue=0.2)], p=0.8)
+    data_transform = vt.Compose([rand_color_jitter, vt.RandomGrayscale(), vt.RandomGaussianBlur()])
+    video_transform = vt.Compose([vt.Resize(R), vt.RandomResizedCrop((R, R)), vt.RandomHorizontalFlip(),
+                                  vt.ClipToTensor(mean=[0.485, 0.456, 0.406], std=[0.228, 0.224, 0.225])])
+    rng = np.random.default_rng(3)
+    out = {}
+    for tag, (H, W) in dict(a=(96, 128), b=(150, 100)).items():
+        yy, xx = np.mgrid[0:H, 0:W]
+        frames = []
+        for t in range(3):
+            base = np.stack([127 + 100 * np.sin((xx + 5 * t) / 9.0 + c) * np.cos((yy - 3 * t) / 7.0 + 2 * c) for c in range(3)], -1)
+            frames.append(np.clip(base + rng.normal(0, 12, (H, W, 3)), 0, 255).astype(np.uint8))
+        frames = np.stack(frames)
+        out[f"{tag}_frames"] = frames
+        for seed in range(7 if tag == "a" else 3):
+            random.seed(seed)
+            torch.manual_seed(seed)
+            clip = [Image.fromarray(f) for f in frames]
+            clip = data_transform(clip)
+            if tag == "a":
+                out[f"{tag}_seed{seed}_after_frame_transform"] = np.stack([np.array(im) for im in clip])
+            out[f"{tag}_seed{seed}"] = t2n(video_transform(clip))
+    np.savez_compressed(os.path.join(OUT, "transforms.npz"), **out)
+    print("transforms.npz written", len(out), "arrays")
+
+
 def gen_mask(ref):
     """models.process_attentions (with the blur / component-labelling stand-ins) on synthetic attention maps:
     peaked random maps at g = 14 and 28, plus hand-made cases for the small-component rule."""
@@ -595,6 +649,7 @@ def main():
         "timet_tiny": lambda: gen_timet(ref, "tiny", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "stress", False, 0, 3, True),
         "timet_tiny_tq": lambda: gen_timet(ref, "tiny_tq", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 2, "stress", True, 40, 3, True),
         "mask": lambda: gen_mask(ref),
+        "transforms": lambda: gen_transforms(ref),
         "metric": lambda: gen_metric(ref),
         "extractor_sizes": lambda: gen_extractor_sizes(ref),
         "davis_protocol": lambda: gen_davis_protocol(ref),

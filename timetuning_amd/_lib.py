@@ -67,6 +67,10 @@ SIGNATURES = {
     "tt_foreground_mask_from_probs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_vp]),
     "tt_scale_rows_inplace": (c_i, [c_vp, c_vp, c_i, c_i, c_vp]),
     "tt_pos_embed_interpolate": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_f, c_vp]),
+    "tt_img_resample_h": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "tt_img_resample_v": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.POINTER(C.c_float), C.POINTER(C.c_float), c_vp]),
+    "tt_img_color": (c_i, [c_vp, c_i, c_i, c_i, c_i, c_f, c_i, c_vp, c_vp]),
+    "tt_img_box_blur": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, C.c_uint, C.c_uint, c_vp]),
     "tt_affine_cols_inplace": (c_i, [c_vp, c_vp, c_vp, c_ll, c_i, c_vp]),
     "tt_col_moments_workspace_bytes": (c_sz, [c_ll, c_i]),
     "tt_col_moments": (c_i, [c_vp, c_vp, c_vp, c_ll, c_i, c_vp, c_sz, c_vp]),

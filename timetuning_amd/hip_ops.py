@@ -371,6 +371,62 @@ def confusion_counts(pred, gt, num_classes: int):
     return counts
 
 
+# ---- clip input pipeline (uint8 frames [F, H, W, 3]) ------------------------------------------------------------------
+
+def img_resample_h(frames, coeffs, bounds, y0: int, x0: int, h: int):
+    """Horizontal pass of Pillow's bilinear resize over rows y0..y0+h, columns from x0: -> uint8 [F, h, OW, 3]."""
+    lib = _lib.load()
+    _chk(frames, "frames", torch.uint8); _chk(coeffs, "coeffs", torch.int32); _chk(bounds, "bounds", torch.int32)
+    Fr, H, W, _ = frames.shape
+    OW, ksize = coeffs.shape
+    out = torch.empty((Fr, h, OW, 3), dtype=torch.uint8, device=frames.device)
+    _lib.check(lib.tt_img_resample_h(_p(frames), _p(out), _p(coeffs), _p(bounds), Fr, H, W, y0, x0, h, OW, ksize, _stream()), "tt_img_resample_h")
+    return out
+
+
+def img_resample_v(frames, coeffs, bounds, y0: int = 0, to_tensor=None, flip: bool = False):
+    """Vertical pass: -> uint8 [F, OH, W, 3], or with ``to_tensor=(mean, std)`` the finished float32 [F, 3, OH, W]."""
+    import ctypes as C
+
+    lib = _lib.load()
+    _chk(frames, "frames", torch.uint8); _chk(coeffs, "coeffs", torch.int32); _chk(bounds, "bounds", torch.int32)
+    Fr, Hin, W, _ = frames.shape
+    OH, ksize = coeffs.shape
+    if to_tensor is None:
+        out = torch.empty((Fr, OH, W, 3), dtype=torch.uint8, device=frames.device)
+        _lib.check(lib.tt_img_resample_v(_p(frames), _p(out), None, _p(coeffs), _p(bounds), Fr, Hin, W, y0, OH, ksize, 0, None, None, _stream()),
+                   "tt_img_resample_v")
+        return out
+    mean, std = to_tensor
+    out = torch.empty((Fr, 3, OH, W), dtype=f32, device=frames.device)
+    m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    _lib.check(lib.tt_img_resample_v(_p(frames), None, _p(out), _p(coeffs), _p(bounds), Fr, Hin, W, y0, OH, ksize, int(bool(flip)), m3, s3,
+                                     _stream()), "tt_img_resample_v")
+    return out
+
+
+IMG_GRAYSCALE, IMG_BRIGHTNESS, IMG_CONTRAST, IMG_SATURATION, IMG_HUE = range(5)
+
+
+def img_color_(frames, mode: int, factor: float = 1.0, hue_shift: int = 0):
+    """In-place colour operation on uint8 [F, H, W, 3] (modes above)."""
+    lib = _lib.load()
+    _chk(frames, "frames", torch.uint8)
+    Fr, H, W, _ = frames.shape
+    ws = torch.empty(Fr, dtype=torch.int64, device=frames.device) if mode == IMG_CONTRAST else None
+    _lib.check(lib.tt_img_color(_p(frames), Fr, H, W, int(mode), float(factor), int(hue_shift), _p(ws), _stream()), "tt_img_color")
+    return frames
+
+
+def img_box_blur(frames, direction: int, radius: int, ww: int, fw: int):
+    lib = _lib.load()
+    _chk(frames, "frames", torch.uint8)
+    Fr, H, W, _ = frames.shape
+    out = torch.empty_like(frames)
+    _lib.check(lib.tt_img_box_blur(_p(frames), _p(out), Fr, H, W, int(direction), int(radius), int(ww), int(fw), _stream()), "tt_img_box_blur")
+    return out
+
+
 def col_moments(x):
     """Per-column mean and population variance of x [rows, cols] (fp64 tensors)."""
     lib = _lib.load()

@@ -517,6 +517,29 @@ class SyntheticClips:
             yield data, torch.zeros(self.bs, 1, self.fs, 1), torch.zeros(self.bs)
 
 
+class SyntheticFrameClips(SyntheticClips):
+    """As ``SyntheticClips`` but starting from raw uint8 frames ``[fs, H, W, 3]`` that go through the GPU input pipeline
+    (``video_transformations.training_transforms``: colour jitter / grayscale / blur, Resize, RandomResizedCrop, ClipToTensor) -
+    the work the reference's DataLoader workers do with Pillow on the host (``time_tuning.py:588-593``)."""
+
+    def __init__(self, batch_size, num_frames, resolution, steps, device, rank=0, raw_size=(360, 480)):
+        super().__init__(batch_size, num_frames, resolution, steps, device, rank)
+        from . import video_transformations as VT
+
+        self.raw_size = raw_size
+        self.frame_transform, self.video_transform = VT.training_transforms(resolution)
+
+    def __iter__(self):
+        H, W = self.raw_size
+        for i in range(self.steps):
+            clips = []
+            for b in range(self.bs):
+                z = self._synth.normal(f"raw.{self.rank}.{i}.{b}", (self.fs, H // 8, W // 8, 3), 60.0, 127.0)
+                raw = torch.from_numpy(np.clip(np.kron(z, np.ones((1, 8, 8, 1), np.float32)), 0, 255).astype(np.uint8)).to(self.device)
+                clips.append(self.video_transform(self.frame_transform(raw)))
+            yield torch.stack(clips).unsqueeze(1), torch.zeros(self.bs, 1, self.fs, 1), torch.zeros(self.bs)
+
+
 def time_tuning(gpu=0, args=None):
     """One process per GPU (``time_tuning.py:508-666``): model, optimiser, epoch loop.  The evaluation the reference runs
     every 4 epochs on Pascal VOC (:634-646) is available as ``timetuning_amd.evaluation.Evaluator`` but not wired in here:
@@ -538,10 +561,13 @@ def time_tuning(gpu=0, args=None):
     model = TimeT(fe, args.num_clusters).to(device)
     if world_size > 1:
         model = DistributedDataParallelModel(model, gpu)
-    if args.dataset != "synthetic":
-        raise NotImplementedError("dataset loaders (data_loader.py / video_transformations.py) are out of scope for this build "
-                                  "(SURVEY.md 8(f) N3); run with --dataset synthetic")
-    loader = SyntheticClips(args.batch_size, args.num_frames, args.input_resolution, args.steps_per_epoch, device, rank)
+    if args.dataset == "synthetic":
+        loader = SyntheticClips(args.batch_size, args.num_frames, args.input_resolution, args.steps_per_epoch, device, rank)
+    elif args.dataset == "synthetic_frames":  # raw uint8 frames through the GPU input pipeline
+        loader = SyntheticFrameClips(args.batch_size, args.num_frames, args.input_resolution, args.steps_per_epoch, device, rank)
+    else:
+        raise NotImplementedError("the dataset readers (data_loader.py: directory scanning, JPEG decoding) are out of scope for this "
+                                  "build; run with --dataset synthetic or --dataset synthetic_frames")
     num_itr = len(loader)
     opt = SwavOptimizer(model, "AdamW", args.use_projection_head, args.head_lr / 10, args.head_lr, args.lr_scheduler,
                         cosine_scheduler(0.04, 0.4, args.num_epochs, num_itr), num_itr, args.num_epochs)

@@ -77,6 +77,16 @@ def main():
     lab = ops.kmeans_assign(up, cent)
     t = timeit(lambda: ops.kmeans_accumulate(up, lab, 21))
     print(f"kmeans_accumulate (deterministic)          {t * 1e6:8.1f} {up.numel() * 4 / t / 1e9:8.0f} GB/s read")
+    # input pipeline (N3): 4-frame 480x854 uint8 clips -> jitter/blur at full size -> Resize(224) -> RandomResizedCrop -> tensor
+    import random
+    from timetuning_amd import video_transformations as VT
+    frames = torch.randint(0, 256, (4, 480, 854, 3), dtype=torch.uint8, device=dev)
+    dt, vt_ = VT.training_transforms(224)
+    random.seed(0); torch.manual_seed(0)
+    t = timeit(lambda: vt_(dt(frames)), reps=30)
+    print(f"input pipeline, one 4-frame 480x854 clip   {t * 1e6:8.1f} {4 / t:8.0f} frames/s (random branches, mean of 30 draws)")
+    t = timeit(lambda: vt_(frames), reps=30)
+    print(f"  video_transform only (resize+crop+tensor)  {t * 1e6:8.1f} {4 / t:8.0f} frames/s")
     # evaluation protocol (N4): one 25-frame clip, 4 context frames, radius 12, 8 classes, + upsample/argmax to 224
     for g_ in (14, 28):
         xn = torch.nn.functional.normalize(torch.randn(25, 1, g_ * g_, 384, device=dev), dim=-1)
