@@ -278,15 +278,15 @@ def test_mask_propagation_evaluation_vs_oracle():
     assert np.isfinite(MP.mask_propagation(args))
 
 
-@pytest.mark.parametrize("arch", ["dino-b16", "dino-s8"])
-def test_other_architectures_vs_oracle(arch):
+@pytest.mark.parametrize("arch,K,bs,fs", [("dino-b16", 40, 1, 2), ("dino-s8", 40, 1, 2), ("dino-b16", 400, 1, 8), ("dino-s8", 200, 1, 4)])
+def test_other_architectures_vs_oracle(arch, K, bs, fs):
     """ViT-B/16 (D=768, 12 heads) and ViT-S/8 (785 tokens: KV-tiled attention, 28x28 propagation grid) against the oracle:
-    extractor outputs and one full loss + gradient."""
+    extractor outputs and one full loss + gradient - at a small shape and at the clip length / prototype count of BASELINE's
+    configs C4 (ViT-B/16, 8 frames, 400 prototypes) and C5 (ViT-S/8, 4 frames, 200 prototypes), one clip each."""
     from oracle import timet_oracle as O
     from timetuning_amd.models import FeatureExtractor
     from timetuning_amd.time_tuning import TimeT
 
-    K, bs, fs = 40, 1, 2
     fe = FeatureExtractor(arch, "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="stress", return_attention=False)
     assert fe.spatial_resolution == (28 if arch == "dino-s8" else 14)
     model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, 256))).cuda()
