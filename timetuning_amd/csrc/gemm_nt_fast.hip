@@ -7,6 +7,9 @@
 // 133 TFLOP/s, 105 with the natural 64-scalar-stores-per-lane epilogue (store-issue bound) and 121-125 with this one.
 //
 // Measured dead ends, kept out of the source (DESIGN.md section 5 has the numbers, git history the code):
+//   * fragment reads hand-pipelined with inline-asm ds_read_b32 into a register double buffer and counted lgkmcnt waits
+//     (hipcc folds any source-level double buffer back into "reads -> wait -> MFMAs"): +8 % on ZERO-filled operands,
+//     nothing on random operands - the loop is not latency-limited;
 //   * operands swapped (D^T = W X^T) so that a lane owns 4 consecutive output columns and stores 16 bytes straight from
 //     the accumulators, no LDS pass: bit-identical, 1-2 % slower (32 rows x 32 B per store instruction);
 //   * [row][k] LDS image with ds_write_b128 / ds_read_b128 (k-permuted fragments): bit-identical, -9 ... +2 % by shape;
@@ -114,56 +117,6 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
     if (kt + 1 < nk) gload();
     const float* fa = lds + buf * ASZ + (4 * h) * LDA + wm * (32 * WM) + r;
     const float* fb = lds + 2 * ASZ + buf * BSZ + (4 * h) * LDB + wn * (32 * WN) + r;
-#ifdef TT_ASM_PIPELINED_FRAGS
-    // Hand-pipelined fragment reads (opt-in, OFF by default).  hipcc schedules "ds_read x2 -> s_waitcnt lgkmcnt(0) ->
-    // 4 MFMA" per k-pair and folds any source-level register double buffer back into that shape.  Here the reads of
-    // k-pair step+1 are issued by inline asm into the other register set BEFORE the MFMAs of k-pair step, with a counted
-    // lgkmcnt that leaves exactly those reads in flight.  Measured (tools/mfma_peak.hip mode 9 vs 7, tools/ab_gemm.py):
-    // +8 % on ZERO-filled operands (131 vs 121 TFLOP/s) but nothing on random operands (120 vs 119; the real kernel
-    // 111 vs 111): with real data the loop is not latency-limited, so the compiler-scheduled form ships and this stays
-    // as a documented experiment.  The asm loads are invisible
-    // to hipcc's wait bookkeeping (guide 5.7): every one is retired by our own s_waitcnt before its first use, the
-    // sched_barrier keeps the MFMAs below that wait, and lgkmcnt(0) precedes the last quad, so no asm read is
-    // outstanding when compiler-generated LDS traffic (staging writes, epilogue) resumes.
-    const unsigned la = (unsigned)(unsigned long long)fa, lb = (unsigned)(unsigned long long)fb;
-    float a0[WM], b0[WN], a1[WM], b1[WN];
-#define TT_RD(step, A, B)                                                                                                         \
-  do {                                                                                                                              \
-    constexpr int kq_ = 8 * ((step) >> 2) + ((step)&3);                                                                              \
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(A[0]) : "v"(la), "i"(4 * (kq_ * LDA)));                                     \
-    if constexpr (WM == 2) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(A[WM - 1]) : "v"(la), "i"(4 * (kq_ * LDA + 32)));    \
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(B[0]) : "v"(lb), "i"(4 * (kq_ * LDB)));                                     \
-    if constexpr (WN == 2) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(B[WN - 1]) : "v"(lb), "i"(4 * (kq_ * LDB + 32)));    \
-  } while (0)
-#define TT_WAIT_INFLIGHT()                                                          \
-  do {                                                                              \
-    if constexpr (WM + WN == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  \
-    else if constexpr (WM + WN == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); \
-    else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                         \
-    __builtin_amdgcn_sched_barrier(0);                                              \
-  } while (0)
-#define TT_MM(A, B)                                                                                              \
-  do {                                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int n = 0; n < WN; ++n)                \
-        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i], B[n], acc[i][n], 0, 0, 0);                       \
-  } while (0)
-    TT_RD(0, a0, b0);
-    TT_RD(1, a1, b1); TT_WAIT_INFLIGHT(); TT_MM(a0, b0);
-    TT_RD(2, a0, b0); TT_WAIT_INFLIGHT(); TT_MM(a1, b1);
-    TT_RD(3, a1, b1); TT_WAIT_INFLIGHT(); TT_MM(a0, b0);
-    TT_RD(4, a0, b0); TT_WAIT_INFLIGHT(); TT_MM(a1, b1);
-    TT_RD(5, a1, b1); TT_WAIT_INFLIGHT(); TT_MM(a0, b0);
-    TT_RD(6, a0, b0); TT_WAIT_INFLIGHT(); TT_MM(a1, b1);
-    TT_RD(7, a1, b1); TT_WAIT_INFLIGHT(); TT_MM(a0, b0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    TT_MM(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-#undef TT_RD
-#undef TT_WAIT_INFLIGHT
-#undef TT_MM
-    static_assert(BK == 16, "the hand-unrolled pipeline covers 8 k-pairs");
-#else
 #pragma unroll
     for (int j = 0; j < BK / 8; ++j) {
       float a[WM][4], b[WN][4];
@@ -181,7 +134,6 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
 #pragma unroll
           for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[n][q], acc[i][n], 0, 0, 0);
     }
-#endif
     if (kt + 1 < nk) sstore(buf ^ 1);
     __syncthreads();
   }
