@@ -251,6 +251,53 @@ def test_use_mask_full_size_vs_oracle():
                 assert rel_err(p.grad.cpu(), op[name].grad) < TOL, name
 
 
+def test_ten_training_steps_track_the_oracle():
+    """Ten consecutive iterations (teacher + queue, which fills after two steps so the queue branch of the Sinkhorn is live from
+    step 3) on the tiny ViT, GPU vs CPU oracle fed the same clips and queue permutations: the loss trajectories stay together
+    and the final parameters agree - no drift from accumulated rounding, stale buffers or state that only shows after step 3."""
+    from oracle import timet_oracle as O
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.my_utils import cosine_scheduler
+    from timetuning_amd.time_tuning import SwavOptimizer, TimeT
+
+    cfg = synth.ARCHS["tiny-s16"]
+    K, head, bs, fs, steps, E, I = 20, (128, 128, 64, 32), 2, 3, 10, 1, 12
+    fe = FeatureExtractor("dino-s16", "", list(head), unfreeze_layers=["blocks.11", "blocks.10"], vit_cfg=cfg, init="stress", return_attention=False)
+    model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, fe.feature_dim))).cuda()
+    opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, E, I), I, E)
+    model.init_momentum_teacher()
+    model.set_momentum_teacher_schedular_params(0.995, 1.0, E, I)
+    model.init_queue(40)
+    om = O.build_oracle("dino-s16", K, head, mode="stress", vit_cfg=cfg)
+    oopt = O.SwavOptimizerOracle(om, 1e-5, 1e-4, O.cosine_scheduler(0.04, 0.4, E, I), I, E)
+    om.init_momentum_teacher()
+    om.set_momentum_teacher_schedular_params(0.995, 1.0, E, I)
+    om.init_queue(40)
+    gpu_losses, cpu_losses = [], []
+    for s in range(steps):
+        x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=50 + s))
+        perm = torch.randperm(bs * 196, generator=torch.Generator().manual_seed(s)).numpy()
+        loss = model.get_loss(x.cuda(), queue_perm=perm)
+        opt.step(loss)
+        model.normalize_prototypes()
+        model.update_momentum_teacher(opt.global_step)
+        oloss = om.get_loss(x, queue_perm=perm, faithful=False)
+        oopt.zero_grad()
+        oloss.backward()
+        oopt.step()
+        om.normalize_prototypes()
+        om.update_momentum_teacher(oopt.global_step)
+        gpu_losses.append(loss.item())
+        cpu_losses.append(oloss.item())
+    assert model.queue_is_full()
+    np.testing.assert_allclose(gpu_losses, cpu_losses, rtol=5e-3)
+    assert rel_err(model.prototypes.detach().cpu(), om.prototypes.detach()) < 1e-3
+    assert rel_err(model.teacher_prototypes.detach().cpu(), om.teacher_prototypes) < 1e-3
+    assert rel_err(model.queue.cpu(), om.queue) < 1e-3
+    w = dict(model.named_parameters())["feature_extractor.backbone.blocks.11.mlp.fc2.weight"].detach().cpu()
+    assert rel_err(w, om.feature_extractor.backbone["blocks.11.mlp.fc2.weight"].detach()) < 1e-4
+
+
 def test_mask_propagation_evaluation_vs_oracle():
     """N4: the evaluation loop body (extractor without head -> propagate_labels(4, 12, 5) -> upsample -> arg-max -> J) on a
     synthetic tracking clip, against the oracle fed with the same features; and the command-line driver."""
