@@ -243,7 +243,7 @@ def main():
                                    f"{a.architecture} full TimeT training step (fwd+bwd+AdamW), {fs}-frame 224x224 clips, {bs} clips/GPU, "
                                    f"{K} prototypes" + (", EMA teacher" if a.use_teacher else "") + (", queue" if a.use_queue else "") +
                                    (", use_mask" if a.use_mask else ""),
-                       "architecture": a.architecture, "clips_per_gpu": bs, "num_frames": fs, "num_clusters": K,
+                       "clips_per_gpu": bs, "num_frames": fs, "num_clusters": K,
                        "global_batch": bs * world, "parallelism": f"dp{world}"},
             "loss": round(final_loss, 5),
             "roofline": {"bound": "mfma",
