@@ -19,11 +19,15 @@ struct BwdArgs {
   const float* gelu_pre; // dgrad only: [M][N]
   int kchunk;            // wgrad: reduction slice per grid.z
   long long strideS;     // wgrad: elements between split-K partial outputs
+  float* colpart;        // wgrad, optional: [grid.z][M] partial column sums of A (= the bias gradient of the same nn.Linear)
 };
 
 // Shared main loop.  A_MMAJOR: A stored [K][lda] (else [M][lda], k contiguous).  B is always stored [K][ldb].
-template <int WM, int WN, bool A_MMAJOR, bool GUARD_M>
-__device__ __forceinline__ void bwd_mainloop(const BwdArgs& g, float* lds, int m0, int n0, int kbeg, int kend, f32x16 (&acc)[WM][WN]) {
+// COLSUM (wgrad): the workgroup also sums the A rows it stages (A = dy [reduction][M], so these are column sums of dy over
+// the slice) into csum - the bias gradient rides on loads the weight gradient needs anyway, instead of a second pass over dy.
+template <int WM, int WN, bool A_MMAJOR, bool GUARD_M, bool COLSUM = false>
+__device__ __forceinline__ void bwd_mainloop(const BwdArgs& g, float* lds, int m0, int n0, int kbeg, int kend, f32x16 (&acc)[WM][WN],
+                                             float4* csum = nullptr) {
   constexpr int BM = 64 * WM, BN = 64 * WN, BK = 16;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
@@ -61,6 +65,9 @@ __device__ __forceinline__ void bwd_mainloop(const BwdArgs& g, float* lds, int m
       if (A_MMAJOR) {
         const int kr = u / (BM / 4), mc = (u % (BM / 4)) * 4;
         *reinterpret_cast<float4*>(da + kr * LDA + mc) = ra[i];
+        if (COLSUM && csum) {
+          csum->x += ra[i].x; csum->y += ra[i].y; csum->z += ra[i].z; csum->w += ra[i].w;
+        }
       } else {
         const int row = u >> 2, kc = (u & 3) * 4;
         da[(kc + 0) * LDA + row] = ra[i].x;
@@ -170,7 +177,24 @@ __global__ __launch_bounds__(256) void gemm_wgrad_fast_kernel(BwdArgs g) {
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
   const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
   f32x16 acc[WM][WN];
-  bwd_mainloop<WM, WN, true, false>(g, lds, m0, n0, kbeg, kend, acc);
+  const bool do_cs = g.colpart != nullptr && n0 == 0;   // one workgroup per row-block of the output carries the column sums
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  bwd_mainloop<WM, WN, true, false, true>(g, lds, m0, n0, kbeg, kend, acc, do_cs ? &cs : nullptr);
+  if (do_cs) {
+    // thread tid staged columns 4 (tid % (BM/4)) .. +3 of reduction rows tid / (BM/4) (+ 256 i / (BM/4)): fold the row groups
+    constexpr int G = BM / 4, R = 256 / G;
+    float* red = lds;  // the pipeline buffers are idle between the main loop and the epilogue
+    const int tid = threadIdx.x;
+    *reinterpret_cast<float4*>(red + (tid / G) * BM + (tid % G) * 4) = cs;
+    __syncthreads();
+    if (tid < BM) {
+      float sum = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) sum += red[rr * BM + tid];
+      g.colpart[(size_t)blockIdx.z * g.M + m0 + tid] = sum;
+    }
+    __syncthreads();
+  }
   bwd_epilogue<WM, WN, false>(lds, acc, g.C + (long long)blockIdx.z * g.strideS, g.N, m0, n0, g.M, nullptr);
 }
 
@@ -180,7 +204,7 @@ int gemm_tile_choice(int M, int N, int batch);
 int try_launch_dgrad_fast(const float* dy, const float* w, const float* gelu_pre, float* dx, int M, int N, int K, hipStream_t s) {
   auto ok16 = [](const void* p) { return p == nullptr || aligned16(p); };
   if (N % 16 != 0 || N < 16 || K % 64 != 0 || !aligned16(dy) || !aligned16(w) || !aligned16(dx) || !ok16(gelu_pre)) return 1;
-  BwdArgs g{dy, w, dx, M, K, N, N, K, gelu_pre, N, 0};
+  BwdArgs g{dy, w, dx, M, K, N, N, K, gelu_pre, N, 0, nullptr};
   const int tile = gemm_tile_choice(M, K, 1);
   const bool bn128 = (tile == 0 || tile == 1) && K % 128 == 0;
   const bool bm128 = (tile == 0 || tile == 2);
@@ -195,9 +219,11 @@ int try_launch_dgrad_fast(const float* dy, const float* w, const float* gelu_pre
 }
 
 // partial[z][N][K] = dy[zslice,N]^T @ x[zslice,K]: output [N][K], reduction M (split `splits` ways, kchunk % 16 == 0).
-int try_launch_wgrad_fast(const float* dy, const float* x, float* out, int M, int N, int K, int splits, int kchunk, hipStream_t s) {
+// colpart (optional): [splits][N] partial column sums of dy, written by the same launch (the caller folds them into db).
+int try_launch_wgrad_fast(const float* dy, const float* x, float* out, int M, int N, int K, int splits, int kchunk, float* colpart,
+                          hipStream_t s) {
   if (M % 16 != 0 || kchunk % 16 != 0 || N % 64 != 0 || K % 64 != 0 || !aligned16(dy) || !aligned16(x) || !aligned16(out)) return 1;
-  BwdArgs g{dy, x, out, N, K, M, N, K, nullptr, kchunk, (long long)N * K};
+  BwdArgs g{dy, x, out, N, K, M, N, K, nullptr, kchunk, (long long)N * K, colpart};
   const int tile = splits > 1 ? 3 : gemm_tile_choice(N, K, 1);  // split plans are made for 64x64 tiles (gemm_splitk_choice)
   const bool bm128 = (tile == 0 || tile == 2) && N % 128 == 0;
   const bool bn128 = (tile == 0 || tile == 1) && K % 128 == 0;

@@ -151,6 +151,13 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ p
   if (w == 0 && n < N) out[n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// fold of partial[chunks][N] into out[N] for other translation units (the weight-gradient GEMM's fused bias gradient)
+int launch_colsum_fold(const float* partial, float* out, int chunks, int N, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_stage2, dim3((N + 63) / 64), dim3(256), 0, s, partial, out, chunks, N, N, 0);
+  TT_CHECK_LAUNCH("colsum_fold");
+  return TT_OK;
+}
+
 static int colsum_chunks(int M) {
   int chunks = (M + 255) / 256;
   return chunks > 128 ? 128 : (chunks < 1 ? 1 : chunks);
