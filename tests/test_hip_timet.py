@@ -359,6 +359,35 @@ def test_other_architectures_vs_oracle(arch, K, bs, fs):
             assert rel_err(dict(model.named_parameters())[name].grad.cpu(), og[name].grad) < TOL, name
 
 
+def test_c4_shape_in_bf16_mode():
+    """BASELINE config C4 names the "MFMA bf16 path": ViT-B/16, 8-frame clips, 400 prototypes.  One clip of that shape in the
+    opt-in "bf16" mode of the forward Linears against the fp32 oracle, held to a bf16-sized bound (the mode cannot meet the
+    1e-3 fp32 contract and is never the default); "bf16x3" on the same shape stays inside the fp32 contract."""
+    from oracle import timet_oracle as O
+    from timetuning_amd import hip_ops
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    K, bs, fs = 400, 1, 8
+    fe = FeatureExtractor("dino-b16", "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="stress", return_attention=False)
+    model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, 256))).cuda()
+    om = O.build_oracle("dino-b16", K, (1024, 1024, 512, 256), mode="stress")
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=5))
+    with torch.no_grad():
+        of, _ = om.feature_extractor(x.view(bs * fs, 3, 224, 224), faithful=False)
+        oloss = om.get_loss(x, faithful=False)
+    try:
+        for mode, ftol, ltol in (("bf16x3", 1e-3, 2e-3), ("bf16", 8e-2, 0.15)):
+            hip_ops.set_gemm_precision(mode)
+            f, _ = model.feature_extractor(x.view(bs * fs, 3, 224, 224).cuda())
+            assert rel_err(f.cpu(), of) < ftol, mode
+            with torch.no_grad():
+                loss = model.get_loss(x.cuda())
+            assert abs(loss.item() - oloss.item()) < ltol * abs(oloss.item()), (mode, loss.item(), oloss.item())
+    finally:
+        hip_ops.set_gemm_precision("f32")
+
+
 @pytest.mark.parametrize("mode,feat_tol", [("bf16x3", 1e-3), ("bf16", 6e-2)])
 def test_precision_modes_end_to_end(golden, mode, feat_tol):
     """The opt-in bf16 MFMA modes of the forward Linears against the reference's numbers (tiny ViT golden fixture):
