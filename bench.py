@@ -107,6 +107,25 @@ def cpu_baseline(fs, K, budget_s=30.0):
     om = O.build_oracle("dino-s16", K, (1024, 1024, 512, 256), mode="dino")
     opt = O.SwavOptimizerOracle(om, 1e-5, 1e-4, O.cosine_scheduler(0.04, 0.4, 1, 128), 128, 1)
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1))
+    # parity of the two paths on this very sample, before either is trained (same portable weights): patch embeddings
+    # (head outputs) and assignment logits (patch x prototype scores) - the north-star quantities, bound 1e-3 relative
+    with torch.no_grad():
+        flat = x.view(bs * fs, 3, 224, 224)
+        of, _ = om.feature_extractor(flat, faithful=False)
+        osc = om.get_feature_prototype_similarity(of.reshape(-1, of.shape[-1]))
+        gm = build_model("dino-s16", K, torch.device("cuda", 0))
+        gf, _ = gm.feature_extractor(flat.cuda())
+        gsc = gm.get_feature_prototype_similarity(gf.reshape(-1, gf.shape[-1]))
+        rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        parity = {"patch_embeddings_rel_err": rel(gf.cpu(), of), "assignment_logits_rel_err": rel(gsc.cpu(), osc), "bound": 1e-3}
+        del gm, gf, gsc
+        # the second half of the metric on the host: the reference's Sinkhorn (my_utils.py:246-274) at the C2 shape
+        sk_in = torch.exp(torch.nn.functional.normalize(torch.randn(6272, 256), dim=1) @ torch.nn.functional.normalize(torch.randn(K, 256), dim=1).t() / 0.05).t()
+        O.sinkhorn(sk_in.clone(), 10)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            O.sinkhorn(sk_in.clone(), 10)
+        sk_cpu = 30.0 / (time.perf_counter() - t0)
     n, t_total = 0, 0.0
     while n == 0 or (t_total < 0.5 * budget_s and n < 64):  # >= ~15 s of CPU work, at least one step
         t0 = time.perf_counter()
@@ -120,7 +139,7 @@ def cpu_baseline(fs, K, budget_s=30.0):
     return {"value": round(bs * fs * n / t_total, 4), "unit": "clip-frames/sec", "cores": cores, "kind": "port",
             "sample": f"{n} training step(s) of {bs} clips x {fs} frames (C2 step = 32 clips; per-clip work identical), torch-CPU fp32, "
                       "reference-faithful structure (4 ViT passes per frame, per-sample host label propagation)",
-            "seconds_per_step": round(t_total / n, 3)}
+            "seconds_per_step": round(t_total / n, 3), "sinkhorn_iters_per_sec": round(sk_cpu, 1), "parity_vs_gpu": parity}
 
 
 def main():
