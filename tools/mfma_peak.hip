@@ -289,6 +289,69 @@ __global__ __launch_bounds__(256) void k9(float* out, int iters, const float* __
   }
 }
 
+// mode 10: MFMA 32x32x2 + fragment reads only (like mode 1) but from a [row][k] image with ds_read_b128 (k-permuted fragments)
+// mode 11: MFMA 16x16x4, wave tile 64x64 = 4x4 blocks, ds_read_b128 fragments from a [row][k] image (the vendor kernels' shape)
+// both: no staging writes, no barriers - they isolate what the fragment-read instruction mix costs next to the MFMAs.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int MODE, int STRIDE>
+__global__ __launch_bounds__(256) void kread(float* out, int iters) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 128 * STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  for (int i = tid; i < 2 * 128 * STRIDE; i += 256) {
+    unsigned s = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+    s ^= s >> 15; s *= 2246822519u; s ^= s >> 13;
+    lds[i] = ((int)(s >> 8) % 20001 - 10000) * 1e-4f;
+  }
+  __syncthreads();
+  float sink = 0.f;
+  if (MODE == 10) {
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const float* pa = lds + (wm * 64 + r) * STRIDE + 4 * h;
+    const float* pb = lds + 128 * STRIDE + (wn * 64 + r) * STRIDE + 4 * h;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4v a[2], b[2];
+        a[0] = *reinterpret_cast<const f32x4v*>(pa + 8 * j);
+        a[1] = *reinterpret_cast<const f32x4v*>(pa + 32 * STRIDE + 8 * j);
+        b[0] = *reinterpret_cast<const f32x4v*>(pb + 8 * j);
+        b[1] = *reinterpret_cast<const f32x4v*>(pb + 32 * STRIDE + 8 * j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[n][q], acc[i][n], 0, 0, 0);
+      }
+    }
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sink += acc[i][j][e];
+  } else {
+    const int r = lane & 15, g = lane >> 4;
+    f32x4v acc[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    const float* pa = lds + (wm * 64 + r) * STRIDE + 4 * g;
+    const float* pb = lds + 128 * STRIDE + (wn * 64 + r) * STRIDE + 4 * g;
+    for (int it = 0; it < iters; ++it) {
+      f32x4v a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = *reinterpret_cast<const f32x4v*>(pa + 16 * i * STRIDE);
+        b[i] = *reinterpret_cast<const f32x4v*>(pb + 16 * i * STRIDE);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], b[n][q], acc[i][n], 0, 0, 0);
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 4; ++e) sink += acc[i][j][e];
+  }
+  out[blockIdx.x * 256 + tid] = sink;
+}
+
 int main(int argc, char** argv) {
   const int mode = argc > 1 ? atoi(argv[1]) : 0, wps = argc > 2 ? atoi(argv[2]) : 1;
   int iters = argc > 3 ? atoi(argv[3]) : 2000;
@@ -327,6 +390,26 @@ int main(int argc, char** argv) {
       default: hipLaunchKernelGGL(k9, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
     }
   };
+  if (mode >= 10) {  // fragment-read studies: flops per iteration = 4 waves x 32 MFMA-equivalents x 4096 (mode 10: 2 j x 16; mode 11: 64 x 2048)
+    const int stride = argc > 4 ? atoi(argv[4]) : 20;
+    auto go = [&]() {
+      if (mode == 10 && stride == 20) hipLaunchKernelGGL((kread<10, 20>), dim3(blocks), dim3(256), 0, 0, out, iters);
+      else if (mode == 10) hipLaunchKernelGGL((kread<10, 24>), dim3(blocks), dim3(256), 0, 0, out, iters);
+      else if (stride == 20) hipLaunchKernelGGL((kread<11, 20>), dim3(blocks), dim3(256), 0, 0, out, iters);
+      else hipLaunchKernelGGL((kread<11, 24>), dim3(blocks), dim3(256), 0, 0, out, iters);
+    };
+    go();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) go();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms2;
+    hipEventElapsedTime(&ms2, e0, e1);
+    const double fl = 5.0 * blocks * 4.0 * iters * 32.0 * 4096.0;
+    printf("mode %d stride %d waves/SIMD %d: %.1f TFLOP/s\n", mode, stride, wps, fl / (ms2 * 1e-3) / 1e12);
+    return 0;
+  }
   launch();
   hipDeviceSynchronize();
   hipEventRecord(e0);
