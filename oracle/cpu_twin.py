@@ -1,0 +1,37 @@
+"""Loader for oracle/tt_cpu.c (the plain-C CPU twins of a subset of the C ABI).  TEST INFRASTRUCTURE ONLY.
+
+``load()`` compiles the file with gcc when the shared object is missing or older than the source and returns a ctypes handle
+whose functions carry the SAME prototypes as their ``tt_*`` counterparts (taken from ``timetuning_amd._lib.SIGNATURES``), so a
+test can drive the HIP library and the twin through one call site, with host pointers on this side."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "tt_cpu.c")
+OUT = os.path.join(HERE, "_build", "libtt_cpu.so")
+TWINS = ["sinkhorn", "ce_loss_fwd_bwd", "img_resample_h", "img_resample_v", "img_color", "img_box_blur", "confusion_counts",
+         "upsample_argmax", "kmeans_assign", "col_moments"]
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.isfile(OUT) or os.path.getmtime(OUT) < os.path.getmtime(SRC):
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-Wno-unused-parameter", SRC, "-o", OUT, "-lm"], check=True)
+    return OUT
+
+
+def load():
+    global _lib
+    if _lib is None:
+        from timetuning_amd._lib import SIGNATURES
+
+        lib = C.CDLL(build())
+        for name in TWINS:
+            fn = getattr(lib, "tt_cpu_" + name)
+            fn.restype, fn.argtypes = SIGNATURES["tt_" + name]
+        _lib = lib
+    return _lib

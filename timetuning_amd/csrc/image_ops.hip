@@ -11,6 +11,10 @@
 // All of these are byte work bound by HBM: one thread per output pixel (3 channels), coalesced along the row.
 #include "common.hpp"
 
+// Pillow's C code runs as separate multiplies and adds; a fused multiply-add rounds once and can land on the other side of a
+// uint8 truncation, so contraction is off for this whole file (bit-exactness is the contract here, not speed).
+#pragma clang fp contract(off)
+
 namespace tt {
 
 constexpr int IM_THREADS = 256;
