@@ -145,3 +145,60 @@ def test_schedules_match_reference(golden):
     g = golden("schedules")
     np.testing.assert_allclose(cosine_scheduler(0.04, 0.4, 1, 4), g["wd_1_4"], rtol=0, atol=1e-15)
     np.testing.assert_allclose(cosine_scheduler(0.995, 1.0, 2, 5), g["ema_2_5"], rtol=0, atol=1e-15)
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """save_checkpoint / load_checkpoint (time_tuning.py:460-505): model (student, teacher, prototypes, queue-free state_dict),
+    optimizer state, scheduler and global_step survive a round trip; a missing file resumes from epoch 0."""
+    import torch
+
+    from timetuning_amd import synth
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.my_utils import cosine_scheduler
+    from timetuning_amd.time_tuning import SwavOptimizer, TimeT, load_checkpoint, save_checkpoint
+
+    def make(seed):
+        cfg = synth.ARCHS["tiny-s16"]
+        fe = FeatureExtractor("dino-s16", "", [128, 128, 64, 32], unfreeze_layers=["blocks.11", "blocks.10"], vit_cfg=cfg, init="stress", seed=seed)
+        model = TimeT(fe, 20, prototype_init=torch.from_numpy(synth.make_prototypes(20, 32, seed=seed)))
+        model.init_momentum_teacher()
+        opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, 2, 4), 4, 2)
+        return model, opt
+
+    a, oa = make(1)
+    for p in a.parameters():           # optimizer state as after one step, without needing the GPU
+        if p.requires_grad:
+            oa.optimizer.state[p] = dict(step=torch.tensor(1.0), exp_avg=torch.full_like(p, 0.5), exp_avg_sq=torch.full_like(p, 0.25))
+    oa.global_step = 3
+    oa.lr_scheduler.step()
+    path = str(tmp_path / "checkpoint.pth")
+    save_checkpoint(a, oa, 1, path)
+    b, ob = make(2)
+    assert not torch.equal(a.prototypes, b.prototypes)
+    assert load_checkpoint(b, ob, path) == 1
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+    assert ob.global_step == 3 and ob.lr_scheduler.last_epoch == oa.lr_scheduler.last_epoch
+    sa, sb = oa.optimizer.state_dict()["state"], ob.optimizer.state_dict()["state"]
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) for k in sa)
+    assert load_checkpoint(b, ob, str(tmp_path / "missing.pth")) == 0
+
+
+def test_backbone_loads_dino_style_checkpoints(tmp_path):
+    """--model_path: a plain state_dict, and a DINO training checkpoint ({"teacher": {"module.backbone.<name>": ...}, "args":
+    Namespace}) both fill the backbone."""
+    import argparse
+
+    import torch
+
+    from timetuning_amd import synth
+    from timetuning_amd.models import get_backbone
+
+    cfg = synth.ARCHS["tiny-s16"]
+    w = {k: torch.from_numpy(v) for k, v in synth.make_vit_weights(mode="stress", seed=7, **cfg).items()}
+    p1, p2 = str(tmp_path / "plain.pth"), str(tmp_path / "dino_full.pth")
+    torch.save(w, p1)
+    torch.save({"teacher": {"module.backbone." + k: v for k, v in w.items()}, "args": argparse.Namespace(arch="vit_small"), "epoch": 3}, p2)
+    for path in (p1, p2):
+        m = get_backbone("dino-s16", path, vit_cfg=cfg)
+        assert torch.equal(m.blocks[5].mlp.fc1.weight, w["blocks.5.mlp.fc1.weight"]) and torch.equal(m.pos_embed, w["pos_embed"])

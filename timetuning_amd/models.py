@@ -35,7 +35,8 @@ def get_backbone(name: str, model_path: str = "", vit_cfg: Optional[dict] = None
     import os
 
     if model_path and os.path.isfile(model_path):
-        sd = torch.load(model_path, map_location="cpu")
+        # full DINO training checkpoints carry an argparse.Namespace next to the "teacher" / "student" dicts
+        sd = torch.load(model_path, map_location="cpu", weights_only=False)
         for key in ("model", "state_dict", "teacher", "student"):
             if isinstance(sd, dict) and key in sd and isinstance(sd[key], dict):
                 sd = sd[key]

@@ -434,7 +434,8 @@ def load_checkpoint(model, swav_optimizer: SwavOptimizer, filename: str) -> int:
     if not os.path.isfile(filename):
         print(f"No checkpoint found at {filename}")
         return 0
-    state = torch.load(filename, map_location="cpu")
+    # (the optimizer / scheduler state holds plain Python and NumPy scalars: the reference's torch.load predates weights_only)
+    state = torch.load(filename, map_location="cpu", weights_only=False)
     model.load_state_dict(state["model"])
     swav_optimizer.optimizer.load_state_dict(state["optimizer"])
     swav_optimizer.global_step = state["global_step"]
