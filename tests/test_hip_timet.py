@@ -251,6 +251,58 @@ def test_use_mask_full_size_vs_oracle():
                 assert rel_err(p.grad.cpu(), op[name].grad) < TOL, name
 
 
+def test_reference_named_methods_vs_oracle(golden):
+    """The delegating methods a caller of the reference would use directly - get_feature_prototype_similarity, get_scores (with
+    and without a full queue, student and teacher prototypes), find_optimal_assignment, make_seg_maps, the
+    PatchPrototypeSimilarity module, reshape_to_spatial_resolution - against the oracle's restatements."""
+    from oracle import timet_oracle as O
+
+    g = golden("timet_tiny_tq")
+    model, _ = _build(g, True, 40)
+    D, depth, heads, patch = [int(v) for v in g["vit_cfg"]]
+    om = O.build_oracle("dino-s16", int(g["cfg"][2]), tuple(int(v) for v in g["head_list"]), mode=str(g["mode"]),
+                        vit_cfg=dict(embed_dim=D, depth=depth, num_heads=heads, patch_size=patch))
+    om.init_momentum_teacher()
+    om.init_queue(40)
+    bs, fs = int(g["cfg"][0]), int(g["cfg"][1])
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1)).view(bs * fs, 3, 224, 224)
+    with torch.no_grad():
+        of, _ = om.feature_extractor(x, faithful=False)
+        obf, _ = om.feature_extractor(x, use_head=False, faithful=False)
+    f, _ = model.feature_extractor(x.cuda())
+    with torch.no_grad():
+        n, dim = f.shape[1], f.shape[2]
+        feats, ofeats = f.view(bs, fs, n, dim)[:, 0].contiguous(), of.view(bs, fs, n, dim)[:, 0].contiguous()
+        # similarity (student / teacher prototypes)
+        for use_teacher in (False, True):
+            sc = model.get_feature_prototype_similarity(feats.reshape(-1, dim), use_teacher)
+            assert rel_err(sc.cpu(), om.get_feature_prototype_similarity(ofeats.reshape(-1, dim), use_teacher)) < TOL
+        # get_scores without a full queue, then with one (the queue rows join the Sinkhorn problem, :207-211)
+        q, sc = model.get_scores(feats, 0.05, 10)
+        oq, osc = om.get_scores(ofeats, 0.05, 10)
+        assert q.shape == (bs, n, om.prototypes.shape[0]) and rel_err(q.cpu(), oq) < TOL and rel_err(sc.cpu(), osc) < TOL
+        fill = torch.from_numpy(synth.normal("rnm.queue", (40, dim)))
+        model.queue.copy_(fill)
+        model._queue_rows_pushed = 40
+        om.queue.copy_(fill)
+        q2, _ = model.get_scores(feats, 0.05, 10, use_teacher=True)
+        oq2, _ = om.get_scores(ofeats, 0.05, 10, use_teacher=True)
+        assert rel_err(q2.cpu(), oq2) < TOL and rel_err(q2.cpu(), oq) > 1e-3       # the queue changed the assignment
+        q3, sc3 = model.similarity(feats, use_teacher=True)                          # the PatchPrototypeSimilarity module itself
+        assert torch.equal(q3, q2)
+        # find_optimal_assignment and make_seg_maps
+        qa = model.find_optimal_assignment(sc.reshape(-1, sc.shape[-1]), 0.05, 3)
+        assert rel_err(qa.cpu(), om.find_optimal_assignment(osc.reshape(-1, osc.shape[-1]), 0.05, 3)) < TOL
+        bf, _ = model.feature_extractor(x.cuda(), use_head=False)
+        maps = model.make_seg_maps(q[0], bf.view(bs, fs, n, -1)[0], 7, 6, 5, features_exist=True)
+        omaps = om.make_seg_maps(oq[0], obf.view(bs, fs, n, -1)[0], 7, 6, 5)
+        got, want = maps[-1].cpu().numpy(), omaps[-1].numpy()
+        bad = np.abs(got - want).reshape(got.shape[0], -1).max(0) > 1e-4 * np.abs(want).max()
+        assert bad.mean() <= 0.01
+        r = model.reshape_to_spatial_resolution(q[0], 14)
+        assert r.shape == (q.shape[-1], 14, 14) and torch.equal(r[:, 3, 5], q[0][3 * 14 + 5])
+
+
 def test_ten_training_steps_track_the_oracle():
     """Ten consecutive iterations (teacher + queue, which fills after two steps so the queue branch of the Sinkhorn is live from
     step 3) on the tiny ViT, GPU vs CPU oracle fed the same clips and queue permutations: the loss trajectories stay together
