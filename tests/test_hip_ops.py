@@ -148,6 +148,18 @@ def test_l2norm(ops):
     assert rel_err(w.cpu(), ref_w) < TOL
 
 
+def test_my_utils_sinkhorn_signature(golden):
+    """``my_utils.sinkhorn(Q, nmb_iters, world_size)`` as the reference calls it (Q = exp(scores / eps).T, my_utils.py:246-274)."""
+    from timetuning_amd.my_utils import sinkhorn
+
+    g = golden("sinkhorn")
+    assert rel_err(sinkhorn(dev(g["kat_in"]), 3).cpu(), g["kat_it3"]) < 1e-5
+    assert rel_err(sinkhorn(dev(g["kat_in"]), 0).cpu(), g["kat_it0"]) < 1e-5
+    for tag in "ac":
+        Q = torch.exp(torch.from_numpy(g[f"{tag}_scores"]) / 0.05).t().contiguous()
+        assert rel_err(sinkhorn(Q.cuda(), int(g[f"{tag}_iters"])).cpu(), g[f"{tag}_q"]) < 1e-4, tag
+
+
 def test_sinkhorn_golden(ops, golden):
     g = golden("sinkhorn")
     kat = torch.log(torch.from_numpy(g["kat_in"]).t().contiguous()) * 0.05  # scores whose exp(./eps)^T is the KAT matrix

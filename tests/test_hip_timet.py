@@ -303,6 +303,21 @@ def test_reference_named_methods_vs_oracle(golden):
         assert r.shape == (q.shape[-1], 14, 14) and torch.equal(r[:, 3, 5], q[0][3 * 14 + 5])
 
 
+def test_propagate_labels_from_frames(golden):
+    """mask_propagation.propagate_labels with features_exist=False: the frames go through the extractor first (:462-466), and
+    the result equals the features_exist=True call on those features."""
+    from timetuning_amd import mask_propagation as MP
+
+    g = golden("timet_tiny")
+    model, _ = _build(g)
+    frames = torch.from_numpy(synth.make_clips(1, 3, 224, seed=9))[0].cuda()
+    seed = torch.softmax(torch.from_numpy(synth.normal("plf.seed", (1, 6, 14, 14))) * 2, dim=1).cuda()
+    a = MP.propagate_labels(7, 6, 5, model, frames, seed, features_exist=False)
+    feats, _ = model.feature_extractor(frames, use_head=False)
+    b = MP.propagate_labels(7, 6, 5, model, feats, seed, features_exist=True)
+    assert len(a) == len(b) == 2 and all(torch.equal(u, v) for u, v in zip(a, b)) and a[0].shape == (6, 14, 14)
+
+
 def test_ten_training_steps_track_the_oracle():
     """Ten consecutive iterations (teacher + queue, which fills after two steps so the queue branch of the Sinkhorn is live from
     step 3) on the tiny ViT, GPU vs CPU oracle fed the same clips and queue permutations: the loss trajectories stay together
