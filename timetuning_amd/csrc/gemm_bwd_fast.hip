@@ -27,7 +27,7 @@ struct BwdArgs {
 // the slice) into csum - the bias gradient rides on loads the weight gradient needs anyway, instead of a second pass over dy.
 template <int WM, int WN, bool A_MMAJOR, bool GUARD_M, bool COLSUM = false>
 __device__ __forceinline__ void bwd_mainloop(const BwdArgs& g, float* lds, int m0, int n0, int kbeg, int kend, f32x16 (&acc)[WM][WN],
-                                             float4* csum = nullptr) {
+                                             float4* csum = nullptr, int cs_mod = 1, int cs_sel = 0) {
   constexpr int BM = 64 * WM, BN = 64 * WN, BK = 16;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
@@ -56,7 +56,10 @@ __device__ __forceinline__ void bwd_mainloop(const BwdArgs& g, float* lds, int m
       rb[i] = *reinterpret_cast<const float4*>(g.B + (size_t)(k0 + kr) * g.ldb + n0 + nc);
     }
   };
+  int cs_phase = 0;  // COLSUM: the column tiles of one row block share the sums - slab s belongs to tile s % cs_mod
   auto sstore = [&](int buf) {
+    const bool cs_now = COLSUM && csum && (cs_phase % cs_mod) == cs_sel;
+    ++cs_phase;
     float* da = lds + buf * ASZ;
     float* db = lds + 2 * ASZ + buf * BSZ;
 #pragma unroll
@@ -65,7 +68,7 @@ __device__ __forceinline__ void bwd_mainloop(const BwdArgs& g, float* lds, int m
       if (A_MMAJOR) {
         const int kr = u / (BM / 4), mc = (u % (BM / 4)) * 4;
         *reinterpret_cast<float4*>(da + kr * LDA + mc) = ra[i];
-        if (COLSUM && csum) {
+        if (cs_now) {
           csum->x += ra[i].x; csum->y += ra[i].y; csum->z += ra[i].z; csum->w += ra[i].w;
         }
       } else {
@@ -177,9 +180,11 @@ __global__ __launch_bounds__(256) void gemm_wgrad_fast_kernel(BwdArgs g) {
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
   const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
   f32x16 acc[WM][WN];
-  const bool do_cs = g.colpart != nullptr && n0 == 0;   // one workgroup per row-block of the output carries the column sums
+  // the ntn workgroups of a row block each sum the slabs s with s % ntn == their column-tile index: the bias gradient's
+  // extra adds are spread evenly instead of making one workgroup per row block the straggler
+  const bool do_cs = g.colpart != nullptr;
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-  bwd_mainloop<WM, WN, true, false, true>(g, lds, m0, n0, kbeg, kend, acc, do_cs ? &cs : nullptr);
+  bwd_mainloop<WM, WN, true, false, true>(g, lds, m0, n0, kbeg, kend, acc, do_cs ? &cs : nullptr, ntn, n0 / BN);
   if (do_cs) {
     // thread tid staged columns 4 (tid % (BM/4)) .. +3 of reduction rows tid / (BM/4) (+ 256 i / (BM/4)): fold the row groups
     constexpr int G = BM / 4, R = 256 / G;
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_fast_kernel(BwdArgs g) {
       float sum = 0.f;
 #pragma unroll
       for (int rr = 0; rr < R; ++rr) sum += red[rr * BM + tid];
-      g.colpart[(size_t)blockIdx.z * g.M + m0 + tid] = sum;
+      g.colpart[((size_t)blockIdx.z * ntn + n0 / BN) * g.M + m0 + tid] = sum;
     }
     __syncthreads();
   }
@@ -219,9 +224,10 @@ int try_launch_dgrad_fast(const float* dy, const float* w, const float* gelu_pre
 }
 
 // partial[z][N][K] = dy[zslice,N]^T @ x[zslice,K]: output [N][K], reduction M (split `splits` ways, kchunk % 16 == 0).
-// colpart (optional): [splits][N] partial column sums of dy, written by the same launch (the caller folds them into db).
+// colpart (optional): [splits * (K / tile columns)][N] partial column sums of dy, written by the same launch (the caller folds
+// them into db); *colparts receives that leading extent.
 int try_launch_wgrad_fast(const float* dy, const float* x, float* out, int M, int N, int K, int splits, int kchunk, float* colpart,
-                          hipStream_t s) {
+                          int* colparts, hipStream_t s) {
   if (M % 16 != 0 || kchunk % 16 != 0 || N % 64 != 0 || K % 64 != 0 || !aligned16(dy) || !aligned16(x) || !aligned16(out)) return 1;
   BwdArgs g{dy, x, out, N, K, M, N, K, nullptr, kchunk, (long long)N * K, colpart};
   const int tile = splits > 1 ? 3 : gemm_tile_choice(N, K, 1);  // split plans are made for 64x64 tiles (gemm_splitk_choice)
@@ -229,6 +235,7 @@ int try_launch_wgrad_fast(const float* dy, const float* x, float* out, int M, in
   const bool bn128 = (tile == 0 || tile == 1) && K % 128 == 0;
   const int bm = bm128 ? 128 : 64, bn = bn128 ? 128 : 64;
   dim3 grid((N / bm) * (K / bn), 1, splits);
+  if (colparts) *colparts = splits * (K / bn);
   if (bm128 && bn128) hipLaunchKernelGGL((gemm_wgrad_fast_kernel<2, 2>), grid, dim3(256), 0, s, g);
   else if (bm128) hipLaunchKernelGGL((gemm_wgrad_fast_kernel<2, 1>), grid, dim3(256), 0, s, g);
   else if (bn128) hipLaunchKernelGGL((gemm_wgrad_fast_kernel<1, 2>), grid, dim3(256), 0, s, g);

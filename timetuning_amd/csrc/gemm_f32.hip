@@ -441,7 +441,7 @@ int try_launch_gemm_nt_bf16(const float* A, const float* B, float* C, int M, int
 int g_gemm_precision = 0;  // 0 = f32 MFMA (default, exact), 1 = bf16x3 split, 2 = bf16; forward nn.Linear only
 int try_launch_dgrad_fast(const float* dy, const float* w, const float* gelu_pre, float* dx, int M, int N, int K, hipStream_t s);
 int try_launch_wgrad_fast(const float* dy, const float* x, float* out, int M, int N, int K, int splits, int kchunk, float* colpart,
-                          hipStream_t s);
+                          int* colparts, hipStream_t s);
 int launch_colsum_fold(const float* partial, float* out, int chunks, int N, hipStream_t s);  // rowops.hip
 }
 
@@ -497,8 +497,8 @@ extern "C" int tt_linear_bwd_data(const float* dy, const float* w, const float* 
 
 extern "C" size_t tt_linear_bwd_weight_workspace_bytes(int M, int N, int K) {
   const int s = (((long long)N * K) % 4 == 0) ? tt::gemm_splitk_choice(N, K, M, nullptr) : 1;
-  // split-K partials of dw, then the [s][N] partial column sums of dy that the same launch produces for db
-  const size_t split = (s > 1 ? (size_t)s * N * K * sizeof(float) : 0) + (size_t)s * N * sizeof(float);
+  // split-K partials of dw, then the [s * K / 64][N] partial column sums of dy that the same launch produces for db
+  const size_t split = (s > 1 ? (size_t)s * N * K * sizeof(float) : 0) + (size_t)s * ((K + 63) / 64) * N * sizeof(float);
   const size_t cs = tt_colsum_workspace_bytes(M, N);
   return split > cs ? split : cs;
 }
@@ -514,13 +514,14 @@ extern "C" int tt_linear_bwd_weight(const float* dy, const float* x, float* dw, 
   // behind the split-K area, folded below; otherwise tt_colsum makes its own pass over dy
   float* colpart = db ? static_cast<float*>(workspace) + (s > 1 ? (size_t)s * N * K : 0) : nullptr;
   bool bias_fused = false;
+  int colparts = 0;
   if (s > 1) {
     TT_REQUIRE(workspace && workspace_bytes >= (size_t)s * N * K * sizeof(float), "linear_bwd_weight: workspace too small for split-K");
     g.C = static_cast<float*>(workspace);
     g.splits = s;
     g.kchunk = ((M + s - 1) / s + tt::kBK - 1) / tt::kBK * tt::kBK;
     g.strideS = (long long)N * K;
-    rc = tt::try_launch_wgrad_fast(dy, x, g.C, M, N, K, s, g.kchunk, colpart, tt::as_stream(stream));
+    rc = tt::try_launch_wgrad_fast(dy, x, g.C, M, N, K, s, g.kchunk, colpart, &colparts, tt::as_stream(stream));
     bias_fused = rc == TT_OK && colpart != nullptr;
     if (rc > 0) rc = tt::launch_gemm(g, 1, 1, 1, tt::as_stream(stream));
     if (rc != TT_OK) return rc;
@@ -532,13 +533,13 @@ extern "C" int tt_linear_bwd_weight(const float* dy, const float* x, float* dw, 
                        static_cast<const float*>(workspace), dw, n, s, (long long)N * K);
     TT_CHECK_LAUNCH("splitk_reduce");
   } else {
-    rc = (M % 16 == 0) ? tt::try_launch_wgrad_fast(dy, x, dw, M, N, K, 1, M, colpart, tt::as_stream(stream)) : 1;
+    rc = (M % 16 == 0) ? tt::try_launch_wgrad_fast(dy, x, dw, M, N, K, 1, M, colpart, &colparts, tt::as_stream(stream)) : 1;
     bias_fused = rc == TT_OK && colpart != nullptr;
     if (rc > 0) rc = tt::launch_gemm(g, 1, 1, 1, tt::as_stream(stream));
     if (rc != TT_OK) return rc;
   }
   if (!db) return TT_OK;
-  if (bias_fused) return tt::launch_colsum_fold(colpart, db, s, N, tt::as_stream(stream));
+  if (bias_fused) return tt::launch_colsum_fold(colpart, db, colparts, N, tt::as_stream(stream));
   return tt_colsum(dy, db, M, N, workspace, workspace_bytes, stream);
 }
 
