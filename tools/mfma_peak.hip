@@ -352,6 +352,79 @@ __global__ __launch_bounds__(256) void kread(float* out, int iters) {
   out[blockIdx.x * 256 + tid] = sink;
 }
 
+// mode 12 / 13: the full main loop (global loads -> transposing LDS writes -> barrier -> fragment reads -> MFMAs) with BK = 32
+// slabs (half the barriers per k) and, in 13, the fragment groups software-pipelined INSIDE the slab: the reads of group
+// j + 1 are issued before the MFMAs of group j (the fragment wait is what every read form pays >= 5 % for).  128x128 tile.
+template <bool PIPE>
+__global__ __launch_bounds__(256) void kbk32(float* out, int iters, const float* __restrict__ src) {
+  constexpr int LD = 132, BK = 32;
+  __shared__ float lds[2 * BK * 2 * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  for (int i = tid; i < 2 * BK * 2 * LD; i += 256) lds[i] = 0.01f * (float)(i % 13);
+  __syncthreads();
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const float* ga = src + (size_t)(blockIdx.x % 197) * 128 * 384;
+  const float* gb = src + (size_t)(197 * 128 * 384) + (size_t)(blockIdx.x % 9) * 128 * 384;
+  float4 st[8];
+  for (int it = 0; it < iters; ++it) {
+    const int buf = it & 1, k0 = (it % 12) * 32;
+    // 256 threads x 8 float4 = (128 + 128) rows x 32 k
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = tid + 256 * i, row = u >> 3, kc = (u & 7) * 4;
+      st[i] = *reinterpret_cast<const float4*>(ga + (size_t)row * 384 + k0 + kc);
+      st[4 + i] = *reinterpret_cast<const float4*>(gb + (size_t)row * 384 + k0 + kc);
+    }
+    const float* pa = lds + buf * BK * 2 * LD + (4 * h) * LD + wm * 64 + r;
+    const float* pb = pa + BK * LD - wm * 64 + wn * 64;
+    auto rd = [&](int j, float (&a)[2][4], float (&b)[2][4]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[0][q] = pa[(8 * j + q) * LD]; a[1][q] = pa[(8 * j + q) * LD + 32];
+        b[0][q] = pb[(8 * j + q) * LD]; b[1][q] = pb[(8 * j + q) * LD + 32];
+      }
+    };
+    auto mm = [&](float (&a)[2][4], float (&b)[2][4]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[n][q], acc[i][n], 0, 0, 0);
+    };
+    if (PIPE) {
+      float a0[2][4], b0[2][4], a1[2][4], b1[2][4];
+      rd(0, a0, b0);
+      rd(1, a1, b1); mm(a0, b0);
+      rd(2, a0, b0); mm(a1, b1);
+      rd(3, a1, b1); mm(a0, b0);
+      mm(a1, b1);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a[2][4], b[2][4];
+        rd(j, a, b);
+        mm(a, b);
+      }
+    }
+    float* dst = lds + (buf ^ 1) * BK * 2 * LD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = tid + 256 * i, row = u >> 3, kc = (u & 7) * 4;
+      dst[(kc + 0) * LD + row] = st[i].x; dst[(kc + 1) * LD + row] = st[i].y;
+      dst[(kc + 2) * LD + row] = st[i].z; dst[(kc + 3) * LD + row] = st[i].w;
+      dst[BK * LD + (kc + 0) * LD + row] = st[4 + i].x; dst[BK * LD + (kc + 1) * LD + row] = st[4 + i].y;
+      dst[BK * LD + (kc + 2) * LD + row] = st[4 + i].z; dst[BK * LD + (kc + 3) * LD + row] = st[4 + i].w;
+    }
+    __syncthreads();
+  }
+  float sink = 0.f;
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sink += acc[i][j][e];
+  out[blockIdx.x * 256 + tid] = sink;
+}
+
 int main(int argc, char** argv) {
   const int mode = argc > 1 ? atoi(argv[1]) : 0, wps = argc > 2 ? atoi(argv[2]) : 1;
   int iters = argc > 3 ? atoi(argv[3]) : 2000;
@@ -390,6 +463,23 @@ int main(int argc, char** argv) {
       default: hipLaunchKernelGGL(k9, dim3(blocks), dim3(256), 0, 0, out, iters, src, cbuf); break;
     }
   };
+  if (mode == 12 || mode == 13) {
+    auto go = [&]() {
+      if (mode == 12) hipLaunchKernelGGL((kbk32<false>), dim3(blocks), dim3(256), 0, 0, out, iters, src);
+      else hipLaunchKernelGGL((kbk32<true>), dim3(blocks), dim3(256), 0, 0, out, iters, src);
+    };
+    go();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) go();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms3;
+    hipEventElapsedTime(&ms3, e0, e1);
+    const double fl = 5.0 * blocks * 4.0 * iters * 64.0 * 4096.0;  // 64 MFMAs per wave per 32-deep slab
+    printf("mode %d (BK=32%s) waves/SIMD %d: %.1f TFLOP/s\n", mode, mode == 13 ? ", pipelined fragments" : "", wps, fl / (ms3 * 1e-3) / 1e12);
+    return 0;
+  }
   if (mode >= 10) {  // fragment-read studies: flops per iteration = 4 waves x 32 MFMA-equivalents x 4096 (mode 10: 2 j x 16; mode 11: 64 x 2048)
     const int stride = argc > 4 ? atoi(argv[4]) : 20;
     auto go = [&]() {
