@@ -3,6 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W
 
+With N > 1 and no external launcher (no WORLD_SIZE in the environment) the script starts the N rank processes itself, one
+per GPU, over RCCL (``launch_ranks``); under ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` it is
+one of the ranks.  Either way rank 0 prints the line, with ``n_gpus: N`` and ``rccl: {world_size, backend}``.
+
 A step = one full training iteration of BASELINE.json configs[1] (C2): ViT-S/16, 4-frame 224x224 clips,
 32 clips per GPU, 200 prototypes, no queue / teacher - ``TimeT.get_loss`` forward + backward, AdamW step,
 prototype renormalisation.  Synthetic clips and random-init weights (portable generator), resident in HBM before the
@@ -142,6 +146,80 @@ def cpu_baseline(fs, K, budget_s=30.0):
             "seconds_per_step": round(t_total / n, 3), "sinkhorn_iters_per_sec": round(sk_cpu, 1), "parity_vs_gpu": parity}
 
 
+def _free_port() -> int:
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv) -> int:
+    """``python bench.py --gpus N`` without an external launcher: start N rank processes of this script (one per GPU, the
+    reference's ``mp.spawn(time_tuning, nprocs=args.gpus)``, time_tuning.py:714-717) and wait for them.  The parent never touches
+    the GPU - no ``torch.cuda`` / HIP call happens before or after the children are started - and the children are fresh
+    interpreters (``subprocess``, no fork of an initialised runtime, no re-exec).  Rank 0's JSON line passes straight through
+    on the inherited stdout.  Returns the exit code (non-zero as soon as any rank fails; the others are then terminated so
+    that nobody hangs in a collective)."""
+    import signal
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, TT_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank process {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    for q in live:
+                        q.send_signal(signal.SIGTERM)
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None:
+                q.send_signal(signal.SIGTERM)
+        rc = 130
+    for q in procs:
+        try:
+            q.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            q.kill()
+    return rc
+
+
+def dry_rank(a, world: int, rank: int) -> None:
+    """TT_BENCH_DRY=1 (launcher self-test, runs without a GPU): the rank joins the process group, proves through an all-gather
+    that ``world`` distinct ranks are present and rank 0 prints a JSON line in the bench's shape - no kernels, no timing."""
+    import torch.distributed as dist
+
+    if os.environ.get("TT_BENCH_DRY_FAIL_RANK") == str(rank):  # launcher self-test: a rank that dies must fail the whole run
+        sys.exit(3)
+    dist.init_process_group(backend=os.environ.get("TT_BENCH_BACKEND", "gloo"), init_method="env://", world_size=world, rank=rank)
+    seen = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(seen, torch.tensor([rank, os.getpid()], dtype=torch.int64))
+    if rank == 0:
+        print(json.dumps({"metric": "clip-frames/sec", "value": None, "dry": True, "n_gpus": world,
+                          "ranks": [int(t[0]) for t in seen], "pids": [int(t[1]) for t in seen],
+                          "config": {"global_batch": a.batch_size * world, "parallelism": f"dp{world}"},
+                          "rccl": {"world_size": dist.get_world_size(), "backend": dist.get_backend()}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +240,10 @@ def main():
     global USE_MASK
     USE_MASK = a.use_mask
 
+    # ---- N > 1 without an external launcher: this process only starts the N rank processes (before any GPU call)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+
     import torch.distributed as dist
 
     from timetuning_amd import synth
@@ -171,13 +253,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(a.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
+    if os.environ.get("TT_BENCH_DRY"):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        return dry_rank(a, world, rank)
     if os.environ.get("TT_BENCH_SHARE_DEVICE"):  # test aid: all ranks on cuda:0 of a 1-GPU box (use with TT_BENCH_BACKEND=gloo)
         local = 0
-    if a.gpus > 1 or world > 1:
+    elif world > 1 and torch.cuda.device_count() < world:  # (device_count does not initialise the runtime)
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local)
-        dist.init_process_group(backend=os.environ.get("TT_BENCH_BACKEND", "nccl"), init_method="env://", world_size=world, rank=rank)
+        backend = os.environ.get("TT_BENCH_BACKEND", "nccl")
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank, **kw)
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", local if world > 1 else 0)
@@ -265,6 +357,8 @@ def main():
                        "clips_per_gpu": bs, "num_frames": fs, "num_clusters": K,
                        "global_batch": bs * world, "parallelism": f"dp{world}"},
             "loss": round(final_loss, 5),
+            # proof of what carried the exchange: RCCL ("nccl") saw this many ranks (None for the single-process run)
+            "rccl": {"world_size": dist.get_world_size(), "backend": dist.get_backend()} if world > 1 else None,
             "roofline": {"bound": "mfma",
                          "kernel": (f"gemm_nt_fast_kernel<{TILE_NAMES[dom_tile]}> (forward nn.Linear, whole tiles)" if dom_name == "NT"
                                     else f"gemm_f32_kernel<{TILE_NAMES[dom_tile]},{dom_name}>"), "launches_per_step": cnt,

@@ -573,11 +573,16 @@ class TimeTOracle:
         return torch.stack(propagate_labels(n_last_frames, size_mask_neighborhood, topk, g, feats_i, seed))
 
     def get_loss(self, x, n_last_frames=7, size_mask_neighborhood=6, topk=5, epsilon=0.05,
-                 sinkhorn_iterations=10, queue_perm=None, faithful=True, return_aux=False, mask_features=False):
+                 sinkhorn_iterations=10, queue_perm=None, faithful=True, return_aux=False, mask_features=False,
+                 labels_override=None, masks_override=None):
         """time_tuning.py:224-302; ``mask_features`` is the --use_mask branch (:226-227,235-236,244-246,282-283,298-299).
 
         ``queue_perm``: the permutation ``torch.randperm(bs*n)`` draws at :259; passing it makes the
-        queue update reproducible.  ``faithful`` keeps the reference's redundant passes."""
+        queue update reproducible.  ``faithful`` keeps the reference's redundant passes.
+        Checker aids (the two discontinuous decisions of the objective, pinned so that everything continuous around them can be
+        compared unconditionally): ``labels_override`` [bs, g*g] replaces the arg-max labels in the cross entropy;
+        ``masks_override = (source_mask [bs, n], target_mask [bs, n])`` replaces the foreground masks of the source frame
+        (the teacher's when there is one) and of the target frame."""
         fe = self.feature_extractor
         g = fe.spatial_resolution
         bs, fs, c, h, w = x.shape
@@ -588,7 +593,12 @@ class TimeTOracle:
                 teacher_features, teacher_attentions = self.teacher(flat, faithful=faithful)
             teacher_features = teacher_features.view(bs, fs, *teacher_features.shape[1:])
             if mask_features:
-                teacher_features, _ = apply_attention_mask(teacher_features, teacher_attentions, g)
+                if masks_override is not None:
+                    tm = process_attentions(teacher_attentions, g).view(bs, fs, -1).clone()
+                    tm[:, 0] = torch.as_tensor(masks_override[0]).float().view(bs, -1)
+                    teacher_features = teacher_features * tm.unsqueeze(-1)
+                else:
+                    teacher_features, _ = apply_attention_mask(teacher_features, teacher_attentions, g)
         features, attentions = fe(flat, faithful=faithful)
         with torch.no_grad():
             if faithful:
@@ -600,7 +610,14 @@ class TimeTOracle:
         backbone_features = backbone_features.view(bs, fs, npatch, -1)
         masks = None
         if mask_features:
-            features, masks = apply_attention_mask(features, attentions, g)
+            if masks_override is not None:
+                masks = process_attentions(attentions, g).view(bs, fs, -1).clone()
+                if self.teacher is None:
+                    masks[:, 0] = torch.as_tensor(masks_override[0]).float().view(bs, -1)
+                masks[:, -1] = torch.as_tensor(masks_override[1]).float().view(bs, -1)
+                features = features * masks.unsqueeze(-1)
+            else:
+                features, masks = apply_attention_mask(features, attentions, g)
             masks = masks.view(bs, fs, g, g)
         source_features = features[:, 0]
 
@@ -629,12 +646,14 @@ class TimeTOracle:
             p_map = maps[-1]
             target_scores = target_batch_scores[i].view(g, g, -1).permute(2, 0, 1)
             labels = p_map.unsqueeze(0).argmax(dim=1).long()
+            labels_all.append(labels[0])
+            if labels_override is not None:
+                labels = torch.as_tensor(labels_override)[i].long().view(1, g, g)
             if mask_features:  # reduction='none', weighted by the target frame's mask, mean over ALL g*g patches
                 loss = F.cross_entropy(target_scores.unsqueeze(0) / 0.1, labels, reduction="none") * masks[i, -1].unsqueeze(0)
             else:
                 loss = F.cross_entropy(target_scores.unsqueeze(0) / 0.1, labels)
             batch_loss = batch_loss + loss.mean()
-            labels_all.append(labels[0])
             pmaps.append(p_map)
         loss = batch_loss / bs
         if return_aux:

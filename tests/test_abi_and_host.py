@@ -202,3 +202,46 @@ def test_backbone_loads_dino_style_checkpoints(tmp_path):
     for path in (p1, p2):
         m = get_backbone("dino-s16", path, vit_cfg=cfg)
         assert torch.equal(m.blocks[5].mlp.fc1.weight, w["blocks.5.mlp.fc1.weight"]) and torch.equal(m.pos_embed, w["pos_embed"])
+
+
+def test_missing_model_path_raises_instead_of_training_from_random_weights():
+    """only an EMPTY model path opts into synthetic weights; the CLI default / a typo must not silently do so."""
+    from timetuning_amd import synth
+    from timetuning_amd.models import FeatureExtractor, get_backbone
+
+    cfg = synth.ARCHS["tiny-s16"]
+    with pytest.raises(FileNotFoundError):
+        get_backbone("dino-s16", "vits16_800ep.pth.tar", vit_cfg=cfg)
+    with pytest.raises(FileNotFoundError):
+        FeatureExtractor("dino-s16", "/nonexistent/typo.pth", [32, 16], vit_cfg=cfg)
+    assert get_backbone("dino-s16", "", vit_cfg=cfg) is not None
+
+
+def test_ddp_wrapper_checkpoint_keys_match_the_reference(tmp_path):
+    """The reference wraps nn.parallel.DistributedDataParallel (models.py:1292-1295), so its multi-GPU checkpoints carry
+    ``model.module.<name>`` keys: the wrapper here writes the same keys and loads such a checkpoint strictly."""
+    import torch
+
+    from timetuning_amd import synth
+    from timetuning_amd.models import DistributedDataParallelModel, FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    def make(seed):
+        fe = FeatureExtractor("dino-s16", "", [64, 32], unfreeze_layers=["blocks.11"], vit_cfg=synth.ARCHS["tiny-s16"], init="stress", seed=seed)
+        m = TimeT(fe, 12, prototype_init=torch.from_numpy(synth.make_prototypes(12, 32, seed=seed)))
+        m.init_momentum_teacher()
+        return m
+
+    inner = make(1)
+    ddp = DistributedDataParallelModel(inner, 0)
+    keys = list(ddp.state_dict().keys())
+    assert keys and all(k.startswith("model.module.") for k in keys)
+    assert {k[len("model.module."):] for k in keys} == set(inner.state_dict().keys())
+    assert "model.module.teacher.backbone.blocks.3.attn.qkv.weight" in keys and "model.module.teacher_prototypes" in keys
+    # a reference-style DDP checkpoint: {"model": {"model.module.<name>": tensor}}
+    ref_style = {"model.module." + k: v.clone() + 1.0 for k, v in make(2).state_dict().items()}
+    path = str(tmp_path / "ddp.pth")
+    torch.save({"model": ref_style}, path)
+    ddp.load_state_dict(torch.load(path)["model"])                      # strict
+    assert torch.equal(inner.prototypes.detach(), ref_style["model.module.prototypes"])
+    assert ddp.get_non_ddp_model() is inner and ddp.prototypes is inner.prototypes

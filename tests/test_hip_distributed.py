@@ -1,7 +1,12 @@
-"""The N>1 path on real kernels with ONE GPU: two ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
-device), each runs the fused training step on its own clips.  The data-parallel result must equal a single process on
-the concatenated batch: the global Sinkhorn couples all columns, the loss is the mean over all clips, and the
-all-reduced gradient is the gradient of that mean."""
+"""The N>1 path on real kernels.  Two ranks run the fused training step on their own clips; the data-parallel result must
+equal a single process on the concatenated batch: the global Sinkhorn couples all columns, the loss is the mean over all clips,
+and the all-reduced gradient is the gradient of that mean.
+
+* ``gloo``: both ranks share cuda:0 (RCCL refuses two ranks on one device) - runs on the 1-GPU box.
+* ``nccl`` (= RCCL): one rank per GPU, needs >= 2 visible GPUs (skipped otherwise).
+* the RCCL calls themselves (async all_gather_into_tensor + bucketed async all_reduce on side streams) are also executed on
+  the 1-GPU box through a ONE-rank ``nccl`` group with ``TT_EXCHANGE_SINGLE_RANK=1`` (engine.exchange_group).
+* ``bench.py --gpus 2`` is run through its own launcher (two ranks on cuda:0 over gloo)."""
 import os
 import socket
 
@@ -34,7 +39,7 @@ def _model():
     return TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, fe.feature_dim))).cuda()
 
 
-def _worker(rank, W, port, ret):
+def _worker(rank, W, port, ret, backend="gloo"):
     import sys
 
     sys.path.insert(0, REPO)
@@ -45,9 +50,11 @@ def _worker(rank, W, port, ret):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=W)
-    model = DistributedDataParallelModel(_model(), 0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=W)
+    model = DistributedDataParallelModel(_model(), dev)
     x = torch.from_numpy(synth.make_clips(BS, FS, 224, seed=11 + rank)).cuda()
     loss = model(x, None, True, False)
     loss.backward()
@@ -59,17 +66,20 @@ def _worker(rank, W, port, ret):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_equal_single_process_on_concatenated_batch():
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_equal_single_process_on_concatenated_batch(backend):
     import torch.multiprocessing as mp
 
     from timetuning_amd import synth
 
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("the RCCL two-rank run needs two GPUs (one rank per device)")
     W = 2
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     ret = mgr.dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, W, port, ret)) for r in range(W)]
+    procs = [ctx.Process(target=_worker, args=(r, W, port, ret, backend)) for r in range(W)]
     [p.start() for p in procs]
     [p.join(500) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
@@ -88,3 +98,104 @@ def test_two_ranks_equal_single_process_on_concatenated_batch():
         for r in range(W):
             err = np.abs(ret[r]["grads"][n] - ref).max() / np.abs(ref).max()
             assert err < 1e-4, (n, r, err)
+
+
+def _single_rank_nccl_worker(port, ret):
+    """ONE rank, backend nccl: with TT_EXCHANGE_SINGLE_RANK=1 the step issues the same RCCL calls as on N GPUs."""
+    import sys
+
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+
+    from timetuning_amd import engine, synth
+    from timetuning_amd.models import DistributedDataParallelModel
+    from timetuning_amd.my_utils import cosine_scheduler
+    from timetuning_amd.time_tuning import SwavOptimizer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TT_EXCHANGE_SINGLE_RANK="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    assert engine.exchange_group() is not None and dist.get_backend() == "nccl"
+    calls = {"all_gather": 0, "all_reduce": 0}
+    ag, ar = dist.all_gather_into_tensor, dist.all_reduce
+
+    def count_ag(*a, **k):
+        calls["all_gather"] += 1
+        return ag(*a, **k)
+
+    def count_ar(*a, **k):
+        calls["all_reduce"] += 1
+        return ar(*a, **k)
+
+    dist.all_gather_into_tensor, dist.all_reduce = count_ag, count_ar
+    model = DistributedDataParallelModel(_model(), 0)
+    opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, 1, 4), 4, 1)
+    losses = []
+    for s_ in range(2):
+        x = torch.from_numpy(synth.make_clips(BS, FS, 224, seed=21 + s_)).cuda()
+        loss = model(x, None, True, False)
+        opt.step(loss)
+        model.normalize_prototypes()
+        losses.append(float(loss.item()))
+    params = dict(model.get_non_ddp_model().named_parameters())
+    ret["out"] = dict(losses=losses, calls=dict(calls), params={n: params[n].detach().cpu().numpy() for n in WATCH})
+    dist.barrier(device_ids=[0])
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_calls_execute_on_one_gpu():
+    """The nccl / RCCL code path on the 1-GPU box: a one-rank communicator carries the score all-gather and the three gradient
+    buckets of every step (asynchronously, on RCCL's streams); two optimizer steps must reproduce the plain single-process run
+    bit for bit (mean over one rank = identity)."""
+    import torch.multiprocessing as mp
+
+    from timetuning_amd import synth
+    from timetuning_amd.my_utils import cosine_scheduler
+    from timetuning_amd.time_tuning import SwavOptimizer
+
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    p = ctx.Process(target=_single_rank_nccl_worker, args=(_free_port(), ret))
+    p.start()
+    p.join(500)
+    assert p.exitcode == 0, p.exitcode
+    out = ret["out"]
+    assert out["calls"]["all_gather"] == 2 and out["calls"]["all_reduce"] == 6, out["calls"]   # per step: 1 gather + 3 buckets
+
+    model = _model()
+    opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, 1, 4), 4, 1)
+    for s_ in range(2):
+        x = torch.from_numpy(synth.make_clips(BS, FS, 224, seed=21 + s_)).cuda()
+        loss = model.get_loss(x)
+        opt.step(loss)
+        model.normalize_prototypes()
+        assert loss.item() == out["losses"][s_]
+    params = dict(model.named_parameters())
+    for n in WATCH:
+        assert np.array_equal(params[n].detach().cpu().numpy(), out["params"][n]), n
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_through_its_own_launcher():
+    """`python bench.py --gpus 2` with no external launcher: the parent starts two ranks (here both on cuda:0, over gloo,
+    because the box has one GPU), rank 0 prints ONE line with n_gpus 2, twice the global batch and the process-group record."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, TT_BENCH_SHARE_DEVICE="1", TT_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch_size", "2",
+                        "--num_frames", "2", "--num_clusters", "50", "--no_cpu_baseline", "--no_alt_precision"],
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["rccl"] == {"world_size": 2, "backend": "gloo"}
+    assert out["value"] > 0 and out["scaling"] == "weak" and np.isfinite(out["loss"])

@@ -83,14 +83,15 @@ def test_loss_internals_tiny(golden):
     bs, fs, K = [int(v) for v in g["cfg"]]
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1)).cuda()
     with torch.no_grad():
-        loss = model.get_loss(x)
+        # the reference's own hard labels feed the cross entropy, so the loss is compared whether or not a top-k near-tie
+        # flipped one of ours; the propagation's labels are compared separately
+        loss = model.get_loss(x, target_labels=g["labels"].reshape(bs, -1))
     aux = model.last_aux
     assert rel_err(aux["q"].cpu(), g["q"]) < TOL
     assert rel_err(aux["target_scores"].cpu(), g["target_scores"]) < TOL
     mism = aux["labels"].cpu().numpy() != g["labels"].reshape(bs, -1)
     assert mism.mean() <= 0.01
-    if not mism.any():
-        assert abs(loss.item() - float(t["loss0"])) < 1e-4
+    assert abs(loss.item() - float(t["loss0"])) < 1e-4
 
 
 def _run_steps(g, teacher, queue):
@@ -211,6 +212,92 @@ def test_c2_size_properties():
     assert torch.isfinite(g).all() and g.abs().max() > 0
 
 
+@pytest.mark.timeout(900)
+def test_c2_full_step_vs_oracle():
+    """BASELINE C2 at FULL size (ViT-S/16, 32 clips x 4 frames, 200 prototypes): the whole training step against the CPU oracle
+    (one pass per frame, ``faithful=False``: same arithmetic as the reference's four) - Sinkhorn assignment of all 6272 source
+    patches, hard labels, loss, and the gradients of the prototypes, a head weight and a blocks.10 weight."""
+    from oracle import timet_oracle as O
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    bs, fs, K = 32, 4, 200
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    fe = FeatureExtractor("dino-s16", "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="stress",
+                          return_attention=False)
+    model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, 256))).cuda()
+    om = O.build_oracle("dino-s16", K, (1024, 1024, 512, 256), mode="stress")
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=3))
+    oloss, aux = om.get_loss(x, faithful=False, return_aux=True)
+    oloss.backward()
+    loss = model.get_loss(x.cuda(), target_labels=aux["labels"].reshape(bs, -1))
+    loss.backward()
+    assert rel_err(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL
+    assert rel_err(model.last_aux["target_scores"].cpu(), aux["target_scores"].detach()) < TOL
+    mism = (model.last_aux["labels"].cpu() != aux["labels"].reshape(bs, -1)).float().mean().item()
+    assert mism <= 0.01, mism
+    assert abs(loss.item() - oloss.item()) < 2e-4, (loss.item(), oloss.item())
+    og, mg = dict(om.named_parameters()), dict(model.named_parameters())
+    for name in ("prototypes", "feature_extractor.head.6.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight"):
+        assert rel_err(mg[name].grad.cpu(), og[name].grad) < TOL, name
+
+
+@pytest.mark.timeout(900)
+def test_c3_per_rank_workload_vs_oracle():
+    """BASELINE C3's per-rank work at ViT-S/16 size: EMA teacher + a pre-filled 2048-row queue (16384 // 8 ranks,
+    time_tuning.py:618) + 200 prototypes, TWO optimizer steps (so the teacher used by step 2 is an EMA product and the queue has
+    been shifted once) against the oracle: assignment, labels, loss, gradients, updated parameters, teacher and queue."""
+    from oracle import timet_oracle as O
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.my_utils import cosine_scheduler
+    from timetuning_amd.time_tuning import SwavOptimizer, TimeT
+
+    bs, fs, K, Q, E, I = 4, 4, 200, 2048, 1, 4
+    fe = FeatureExtractor("dino-s16", "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="stress",
+                          return_attention=False)
+    model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, 256))).cuda()
+    opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, E, I), I, E)
+    om = O.build_oracle("dino-s16", K, (1024, 1024, 512, 256), mode="stress")
+    oopt = O.SwavOptimizerOracle(om, 1e-5, 1e-4, O.cosine_scheduler(0.04, 0.4, E, I), I, E)
+    for m_ in (model, om):
+        m_.init_momentum_teacher()
+        m_.set_momentum_teacher_schedular_params(0.995, 1.0, E, I)
+        m_.init_queue(Q)
+    fill = torch.nn.functional.normalize(torch.from_numpy(synth.normal("c3.queue", (Q, 256))), dim=1) * 3.0
+    model.queue.copy_(fill)
+    model._queue_rows_pushed = Q
+    om.queue.copy_(fill)
+    assert model.queue_is_full()
+    watch = ("prototypes", "feature_extractor.head.6.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight",
+             "feature_extractor.backbone.blocks.11.mlp.fc2.weight")
+    for s_ in range(2):
+        x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=70 + s_))
+        perm = torch.randperm(bs * 196, generator=torch.Generator().manual_seed(s_)).numpy()
+        oloss, aux = om.get_loss(x, faithful=False, return_aux=True, queue_perm=perm)
+        oopt.zero_grad()
+        oloss.backward()
+        loss = model.get_loss(x.cuda(), queue_perm=perm, target_labels=aux["labels"].reshape(bs, -1))
+        assert rel_err(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL, s_
+        mism = (model.last_aux["labels"].cpu() != aux["labels"].reshape(bs, -1)).float().mean().item()
+        assert mism <= 0.01, (s_, mism)
+        opt.step(loss)
+        assert abs(loss.item() - oloss.item()) < 2e-4, (s_, loss.item(), oloss.item())
+        og, mg = dict(om.named_parameters()), dict(model.named_parameters())
+        for name in watch:
+            assert rel_err(mg[name].grad.cpu(), og[name].grad) < TOL, (s_, name)
+        oopt.step()
+        model.normalize_prototypes()
+        om.normalize_prototypes()
+        model.update_momentum_teacher(opt.global_step)
+        om.update_momentum_teacher(oopt.global_step)
+        for name in watch:
+            assert rel_err(mg[name].detach().cpu(), og[name].detach()) < 1e-4, (s_, name)
+        assert rel_err(model.queue.cpu(), om.queue) < 1e-4
+        assert rel_err(model.teacher_prototypes.detach().cpu(), om.teacher_prototypes) < 1e-4
+        tw = dict(model.teacher.named_parameters())["backbone.blocks.11.mlp.fc2.weight"].detach().cpu()
+        assert rel_err(tw, om.teacher.backbone["blocks.11.mlp.fc2.weight"]) < 1e-4
+
+
 def test_use_mask_full_size_vs_oracle():
     """--use_mask at ViT-S/16 size with the "stress" weights and white-noise clips: speckled attention, so the masks DO
     contain 1- and 2-pixel components (the case the reference cannot process, models.py:127-130) and their removal is
@@ -227,8 +314,8 @@ def test_use_mask_full_size_vs_oracle():
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=11))
     loss = model.get_loss(x.cuda(), mask_features=True)
     loss.backward()
-    oloss, aux = om.get_loss(x, return_aux=True, mask_features=True)
-    oloss.backward()
+    with torch.no_grad():
+        _, aux = om.get_loss(x, return_aux=True, mask_features=True)
     om_masks = aux["masks"].reshape(bs, fs, -1)
     # the oracle's thresholded maps before component removal would differ from these where small components existed
     with torch.no_grad():
@@ -242,13 +329,18 @@ def test_use_mask_full_size_vs_oracle():
     tm, sm = model.last_aux["target_mask"].cpu(), model.last_aux["source_mask"].cpu()
     mism = ((tm != om_masks[:, -1]).float().mean() + (sm != om_masks[:, 0]).float().mean()).item() / 2
     assert mism <= 0.005
-    if mism == 0:
-        assert abs(loss.item() - oloss.item()) < 2e-4
-        op = dict(om.named_parameters())
-        for name, p in model.named_parameters():
-            if p.grad is not None and name in ("prototypes", "feature_extractor.head.6.weight",
-                                               "feature_extractor.backbone.blocks.10.attn.qkv.weight"):
-                assert rel_err(p.grad.cpu(), op[name].grad) < TOL, name
+    lab_mism = (model.last_aux["labels"].cpu() != aux["labels"].reshape(bs, -1)).float().mean().item()
+    assert lab_mism <= 0.01 or mism > 0
+    # loss and gradients, unconditionally: the oracle is re-run with the two discontinuous decisions (foreground masks, hard
+    # labels) pinned to the GPU's, so a flipped mask pixel or label cannot switch the comparison off
+    oloss = om.get_loss(x, mask_features=True, masks_override=(sm, tm), labels_override=model.last_aux["labels"].cpu())
+    oloss.backward()
+    assert abs(loss.item() - oloss.item()) < 2e-4
+    op = dict(om.named_parameters())
+    for name, p in model.named_parameters():
+        if p.grad is not None and name in ("prototypes", "feature_extractor.head.6.weight",
+                                           "feature_extractor.backbone.blocks.10.attn.qkv.weight"):
+            assert rel_err(p.grad.cpu(), op[name].grad) < TOL, name
 
 
 def test_reference_named_methods_vs_oracle(golden):
@@ -413,17 +505,17 @@ def test_other_architectures_vs_oracle(arch, K, bs, fs):
     bf, _ = model.feature_extractor(x.view(bs * fs, 3, 224, 224).cuda(), use_head=False)
     assert rel_err(f.cpu(), of) < TOL
     assert rel_err(bf.cpu(), obf) < TOL
-    loss = model.get_loss(x.cuda())
-    loss.backward()
     oloss, aux = om.get_loss(x, faithful=False, return_aux=True)
     oloss.backward()
+    loss = model.get_loss(x.cuda(), target_labels=aux["labels"].reshape(bs, -1))   # the oracle's hard labels feed the CE
+    loss.backward()
     mism = (model.last_aux["labels"].cpu() != aux["labels"].reshape(bs, -1)).float().mean().item()
     assert mism <= 0.01
-    if mism == 0:
-        assert abs(loss.item() - oloss.item()) < 2e-4
-        og = dict(om.named_parameters())
-        for name in ("prototypes", "feature_extractor.head.0.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight"):
-            assert rel_err(dict(model.named_parameters())[name].grad.cpu(), og[name].grad) < TOL, name
+    assert rel_err(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL
+    assert abs(loss.item() - oloss.item()) < 2e-4
+    og = dict(om.named_parameters())
+    for name in ("prototypes", "feature_extractor.head.0.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight"):
+        assert rel_err(dict(model.named_parameters())[name].grad.cpu(), og[name].grad) < TOL, name
 
 
 def test_c4_shape_in_bf16_mode():
@@ -508,19 +600,18 @@ def test_ragged_configurations_vs_oracle(bs, fs, K, teacher, queue):
         om.queue.copy_(fill)
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=7))
     perm = torch.randperm(bs * 196)
-    loss = model.get_loss(x.cuda(), queue_perm=perm)
-    loss.backward()
     oloss, aux = om.get_loss(x, faithful=False, return_aux=True, queue_perm=perm)
     oloss.backward()
+    loss = model.get_loss(x.cuda(), queue_perm=perm, target_labels=aux["labels"].reshape(bs, -1))
+    loss.backward()
     assert rel_err(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL
     mism = (model.last_aux["labels"].cpu() != aux["labels"].reshape(bs, -1)).float().mean().item()
     assert mism <= 0.01
-    if mism == 0:
-        assert abs(loss.item() - oloss.item()) < 2e-4
-        og, mg = dict(om.named_parameters()), dict(model.named_parameters())
-        for name in ("prototypes", "feature_extractor.head.0.weight", "feature_extractor.backbone.blocks.11.mlp.fc2.weight",
-                     "feature_extractor.backbone.blocks.10.norm1.weight"):
-            assert rel_err(mg[name].grad.cpu(), og[name].grad) < TOL, name
+    assert abs(loss.item() - oloss.item()) < 2e-4
+    og, mg = dict(om.named_parameters()), dict(model.named_parameters())
+    for name in ("prototypes", "feature_extractor.head.0.weight", "feature_extractor.backbone.blocks.11.mlp.fc2.weight",
+                 "feature_extractor.backbone.blocks.10.norm1.weight"):
+        assert rel_err(mg[name].grad.cpu(), og[name].grad) < TOL, name
     if queue:
         assert rel_err(model.queue.cpu(), om.queue) < 1e-4
 

@@ -5,7 +5,7 @@ keeps the device buffers alive.  Three sequences:
 
 ``vit_tokens``       patch-embed + 12 blocks (blocks flagged trainable keep their activations)
 ``extractor``        + final LayerNorm with the cls row dropped (+ projection head)
-``TimeTStep``        the whole objective of ``TimeT.get_loss`` (time_tuning.py:224-302) with ONE
+``TimeT._run_step``  (time_tuning.py of this package) the whole objective of ``TimeT.get_loss`` (time_tuning.py:224-302) with ONE
                      student pass per frame instead of the reference's four, the head only on the
                      source/target frames, one Sinkhorn solve instead of two (or four with a teacher),
                      batched label propagation without host round trips, fused CE forward/backward and
@@ -24,12 +24,6 @@ import torch
 from . import hip_ops as ops
 
 f32 = torch.float32
-
-
-def _frame_map_time_major(bs: int, fs: int, device) -> torch.Tensor:
-    # output frame t*bs + b reads input frame b*fs + t
-    m = torch.arange(bs * fs, dtype=torch.int32).view(bs, fs).t().contiguous().view(-1)
-    return m.to(device)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -171,12 +165,27 @@ def prototype_scores(z: torch.Tensor, prototypes: torch.Tensor, save: Optional[d
     return ops.linear_fwd(zn, prototypes)
 
 
+def exchange_group():
+    """``torch.distributed`` when the step has to exchange data, else None: an initialised process group with more than one
+    rank - or with ONE rank when ``TT_EXCHANGE_SINGLE_RANK=1``, which issues the very same RCCL calls (async all-gather of the
+    score rows, bucketed async all-reduce of the gradients) on a one-rank communicator: how the ``nccl`` code path is executed
+    on a 1-GPU box, where RCCL refuses two ranks on one device."""
+    import os
+
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_world_size() > 1 or os.environ.get("TT_EXCHANGE_SINGLE_RANK") == "1":
+        return dist
+    return None
+
+
 def global_sinkhorn_begin(scores_local: torch.Tensor):
     """Starts the all-gather of the local score rows (asynchronous: RCCL moves them on its own stream while the caller
     keeps launching work that does not need the assignment) and returns the context ``global_sinkhorn_end`` consumes."""
-    import torch.distributed as dist
-
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    dist = exchange_group()
+    if dist is None:
         return (scores_local, None, None)
     W = dist.get_world_size()
     local = scores_local.contiguous()
@@ -221,9 +230,7 @@ class GradExchange:
     blocks.11 (1.8 M) and blocks.10 (1.8 M): only the last one is exposed."""
 
     def __init__(self):
-        import torch.distributed as dist
-
-        self.dist = dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.dist = exchange_group()
         self.sent = set()
         self.buckets = []  # (keys, flat, work)
 
@@ -252,22 +259,3 @@ class GradExchange:
                 off += k.numel()
         self.buckets = []
         return grads
-
-
-def allreduce_mean_(grads: Dict[torch.nn.Parameter, torch.Tensor]) -> Dict[torch.nn.Parameter, torch.Tensor]:
-    """The data-parallel gradient exchange (what DDP's bucketed all-reduce does in the reference, models.py:1295):
-    ONE flat all-reduce (SUM) over RCCL followed by the 1/W scale; the returned tensors are views into the flat
-    buffer.  No-op without an initialised process group."""
-    import torch.distributed as dist
-
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-        return grads
-    keys = list(grads)
-    flat = torch.cat([grads[k].reshape(-1) for k in keys])
-    dist.all_reduce(flat)
-    flat /= dist.get_world_size()
-    off = 0
-    for k in keys:
-        grads[k] = flat[off:off + k.numel()].view(k.shape)
-        off += k.numel()
-    return grads

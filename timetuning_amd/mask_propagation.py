@@ -145,8 +145,7 @@ def mask_propagation(args) -> float:
     if args.use_optical_flow:
         raise NotImplementedError("the optical-flow baseline (cv2 Farneback, mask_propagation.py:803-815) is not part of this build")
     device = torch.device("cuda", 0)
-    fe = FeatureExtractor(args.architecture, args.model_path if args.model_path and args.model_path != "../models/leopart_vits16.ckpt" else "",
-                          [1024, 1024, 512, 256], return_attention=False)
+    fe = FeatureExtractor(args.architecture, args.model_path, [1024, 1024, 512, 256], return_attention=False)  # "" = synthetic weights
     model = TimeT(fe, 200).to(device).eval()
     scores = []
     for i in range(args.num_clips):

@@ -22,9 +22,10 @@ spatial_resolutions = {"dino-s16": 14, "dino-b16": 14, "dino-s8": 28}
 def get_backbone(name: str, model_path: str = "", vit_cfg: Optional[dict] = None, init: str = "dino", seed: int = 1):
     """models.py:773-900 for the DINO entries.  The reference downloads pretrained weights through
     ``torch.hub`` (:780-785); there is no network here, so the same architecture is built locally and
-    filled from ``model_path`` (a state_dict or a checkpoint with a ``"model"``/``"state_dict"`` entry) or, when the
-    path is empty or missing, from the portable synthetic generator.  Unknown names raise (the reference prints
-    the error and then fails on ``None.eval()``, :897-900)."""
+    filled from ``model_path`` (a state_dict or a checkpoint with a ``"model"``/``"state_dict"`` entry).  ONLY an empty
+    ``model_path`` selects the portable synthetic generator (non-pretrained weights: benchmarks and parity tests); a
+    non-empty path that does not exist raises ``FileNotFoundError`` instead of silently training from random weights.
+    Unknown names raise (the reference prints the error and then fails on ``None.eval()``, :897-900)."""
     if vit_cfg is None:
         if name not in synth.ARCHS or name not in spatial_resolutions:
             raise ValueError(f"unknown architecture {name!r}; built: {sorted(spatial_resolutions)}")
@@ -34,7 +35,11 @@ def get_backbone(name: str, model_path: str = "", vit_cfg: Optional[dict] = None
                                   num_heads=cfg["num_heads"], mlp_ratio=4, qkv_bias=True)
     import os
 
-    if model_path and os.path.isfile(model_path):
+    if model_path and not os.path.isfile(model_path):
+        raise FileNotFoundError(f"--model_path {model_path!r} does not exist.  The reference downloads the pretrained DINO weights "
+                                "through torch.hub (models.py:780-785); there is no network here, so pass a local DINO checkpoint, "
+                                "or pass an EMPTY model path (--model_path \"\") to opt into synthetic, non-pretrained weights.")
+    if model_path:
         # full DINO training checkpoints carry an argparse.Namespace next to the "teacher" / "student" dicts
         sd = torch.load(model_path, map_location="cpu", weights_only=False)
         for key in ("model", "state_dict", "teacher", "student"):
@@ -79,7 +84,7 @@ class FeatureExtractor(nn.Module):
                 if i != len(head_layer_list) - 1:
                     layers.append(nn.GELU())
             self.head = nn.Sequential(*layers)
-            if not (model_path and __import__("os").path.isfile(model_path)):
+            if not model_path:  # synthetic run: portable head weights too (with a checkpoint: torch's default init, as :915-926)
                 hw = synth.make_head_weights(self.feature_dim, head_layer_list, mode=init, seed=seed)
                 self.head.load_state_dict({k: torch.from_numpy(v) for k, v in hw.items()}, strict=True)
             self.feature_dim = head_layer_list[-1]
@@ -119,16 +124,28 @@ class FeatureExtractor(nn.Module):
         return feats, attn
 
 
+class _DDPStandIn(nn.Module):
+    """Stands where ``torch.nn.parallel.DistributedDataParallel`` stands in the reference: one attribute, ``module``, so
+    that the wrapper's state_dict keys read ``model.module.<...>`` exactly as the reference's multi-GPU checkpoints do."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *input):
+        return self.module(*input)
+
+
 class DistributedDataParallelModel(nn.Module):
-    """``models.py:1292-1306`` surface (``forward``, ``get_non_ddp_model``, attribute fall-through) without
-    ``torch.nn.parallel.DistributedDataParallel``: the step's backward already produces every gradient in one
-    shot, so the exchange is a single flat RCCL all-reduce issued by ``TimeT`` itself (time_tuning.py), and the
-    Sinkhorn solve all-gathers the score rows (engine.global_sinkhorn).  Parameters are broadcast from rank 0 at
-    construction, as DDP does."""
+    """``models.py:1292-1306`` surface (``forward``, ``get_non_ddp_model``, attribute fall-through, state_dict keys
+    ``model.module.*``) without ``torch.nn.parallel.DistributedDataParallel``: the step's backward already produces every
+    gradient in one shot, so the exchange is the bucketed RCCL all-reduce issued by ``TimeT`` itself (engine.GradExchange), and
+    the Sinkhorn solve all-gathers the score rows (engine.global_sinkhorn).  Parameters and buffers are broadcast from rank 0
+    at construction, as DDP does."""
 
     def __init__(self, model, gpu):
         super().__init__()
-        self.model = model
+        self.model = _DDPStandIn(model)
         self.gpu = gpu
         import torch.distributed as dist
 
@@ -142,10 +159,10 @@ class DistributedDataParallelModel(nn.Module):
         return self.model(*input)
 
     def get_non_ddp_model(self):
-        return self.model
+        return self.model.module
 
     def __getattr__(self, name):
         try:
             return super().__getattr__(name)
         except AttributeError:
-            return getattr(super().__getattr__("model"), name)
+            return getattr(super().__getattr__("model").module, name)

@@ -28,12 +28,6 @@ from .my_utils import cosine_scheduler
 world_size = 1  # module global, as in the reference (time_tuning.py:75,511-512)
 
 
-def _dist():
-    import torch.distributed as dist
-
-    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
-
-
 class PatchPrototypeSimilarity(nn.Module):
     """Patch-token x prototype scores + Sinkhorn-Knopp assignment: the north-star's name for what the
     reference spreads over ``get_feature_prototype_similarity`` / ``find_optimal_assignment`` / ``get_scores``
@@ -212,11 +206,14 @@ class TimeT(nn.Module):
 
     # -- the objective -----------------------------------------------------------------------------
     def get_loss(self, x, annotations=None, n_last_frames=7, size_mask_neighborhood=6, topk=5, epsilon=0.05,
-                 sinkhorn_iterations=10, mask_features=False, queue_perm=None):
-        """``time_tuning.py:224-302``.  ``queue_perm`` (not in the reference) injects the permutation that
-        ``torch.randperm`` draws at :259 so that runs can be reproduced exactly."""
+                 sinkhorn_iterations=10, mask_features=False, queue_perm=None, target_labels=None):
+        """``time_tuning.py:224-302``.  Two arguments that are not in the reference pin its two discrete decisions so that
+        runs can be reproduced exactly: ``queue_perm`` injects the permutation ``torch.randperm`` draws at :259, and
+        ``target_labels`` (int64 [bs, n]) replaces the hard labels ``argmax_K`` of the propagated map (:294-295) in the
+        cross entropy - the propagation still runs and ``last_aux["labels"]`` still reports its own result."""
         hp = dict(n_last_frames=n_last_frames, radius=size_mask_neighborhood, topk=topk, epsilon=epsilon,
-                  iters=int(sinkhorn_iterations), queue_perm=queue_perm, mask_features=bool(mask_features))
+                  iters=int(sinkhorn_iterations), queue_perm=queue_perm, mask_features=bool(mask_features),
+                  target_labels=target_labels)
         params = [p for p in self.parameters() if p.requires_grad]
         need_grad = torch.is_grad_enabled() and len(params) > 0
         return _FusedLoss.apply(self, x, hp, need_grad, *params)
@@ -299,7 +296,10 @@ class TimeT(nn.Module):
         K = scores_t.shape[1]
         q = engine.global_sinkhorn_end(gather, bs * n, hp["epsilon"], hp["iters"])              # [bs*n, K]
         labels = ops.label_propagate(xn_bb, q.view(bs, n, K), hp["n_last_frames"], hp["radius"], hp["topk"], 0.1)
-        loss, dscores = ops.ce_loss_fwd_bwd(scores_t, labels.view(-1), 0.1, need_grad, row_weight=mask_tgt)  # :296-300
+        ce_labels = labels
+        if hp.get("target_labels") is not None:
+            ce_labels = torch.as_tensor(hp["target_labels"]).to(device=dev, dtype=torch.int64).reshape(bs, n).contiguous()
+        loss, dscores = ops.ce_loss_fwd_bwd(scores_t, ce_labels.view(-1), 0.1, need_grad, row_weight=mask_tgt)  # :296-300
         self.last_aux = dict(q=q.view(bs, n, K), target_scores=scores_t.view(bs, n, K), labels=labels)
         if use_mask:
             self.last_aux.update(target_mask=mask_tgt.view(bs, n), source_mask=mask_q.view(bs, n))
