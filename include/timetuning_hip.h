@@ -204,6 +204,10 @@ int tt_ema_update(float* teacher, const float* student, long long n, double mome
 
 /* ---- misc elementwise used between the sites above */
 int tt_add_inplace(float* dst, const float* src, long long n, tt_stream_t stream);
+/* Number of positions where two fp32 buffers differ BITWISE.  Decides, once, whether the EMA teacher's frozen tensors still equal the student's
+ * (time_tuning.py:113-114 blends identical tensors for every frozen parameter), i.e. whether the teacher pass may reuse the
+ * student's frozen-block activations.  count_out: device int64. */
+int tt_count_mismatch(const float* a, const float* b, long long n, long long* count_out, tt_stream_t stream);
 
 /* ---- N1: attention foreground mask, models.process_attentions (models.py:93-131), used by
  *      apply_attention_mask (models.py:133-144) on the --use_mask branch of TimeT.get_loss.

@@ -457,6 +457,46 @@ def test_ten_training_steps_track_the_oracle():
     assert rel_err(w, om.feature_extractor.backbone["blocks.11.mlp.fc2.weight"].detach()) < 1e-4
 
 
+def test_teacher_reuses_student_frozen_blocks_only_when_they_are_equal():
+    """The EMA teacher pass continues from the student's activations at the first trainable block when - and only when - the
+    teacher's frozen tensors equal the student's bit for bit (the reference's deepcopy teacher, time_tuning.py:96); a teacher
+    whose frozen weights differ takes the full pass and the full EMA.  Both against the oracle."""
+    from oracle import timet_oracle as O
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    cfg, head, K, bs, fs = synth.ARCHS["tiny-s16"], (128, 128, 64, 32), 20, 2, 3
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=31))
+    delta = torch.from_numpy(synth.normal("teacher.delta", (4 * cfg["embed_dim"], cfg["embed_dim"]), 0.05))
+    for perturbed in (False, True):
+        fe = FeatureExtractor("dino-s16", "", list(head), unfreeze_layers=["blocks.11", "blocks.10"], vit_cfg=cfg, init="stress", return_attention=False)
+        model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, fe.feature_dim))).cuda()
+        om = O.build_oracle("dino-s16", K, head, mode="stress", vit_cfg=cfg)
+        for m_ in (model, om):
+            m_.init_momentum_teacher()
+            m_.set_momentum_teacher_schedular_params(0.9, 1.0, 1, 4)
+        if perturbed:
+            with torch.no_grad():
+                model.teacher.backbone.blocks[3].mlp.fc1.weight.add_(delta.cuda())
+                om.teacher.backbone["blocks.3.mlp.fc1.weight"].add_(delta)
+            model.invalidate_teacher_cache()
+        assert model.teacher_shares_frozen_blocks() == (not perturbed)
+        oloss, aux = om.get_loss(x, faithful=False, return_aux=True)
+        oloss.backward()
+        loss = model.get_loss(x.cuda(), target_labels=aux["labels"].reshape(bs, -1))
+        loss.backward()
+        assert rel_err(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL, perturbed
+        assert abs(loss.item() - oloss.item()) < 2e-4, perturbed
+        model.update_momentum_teacher(1)
+        om.update_momentum_teacher(1)
+        tw = model.teacher.backbone.blocks[3].mlp.fc1.weight.detach().cpu()
+        sw = model.feature_extractor.backbone.blocks[3].mlp.fc1.weight.detach().cpu()
+        assert rel_err(tw, om.teacher.backbone["blocks.3.mlp.fc1.weight"]) < 1e-6
+        assert torch.equal(tw, sw) == (not perturbed)      # shared: untouched and identical; else blended towards the student
+        t11 = model.teacher.backbone.blocks[11].mlp.fc2.weight.detach().cpu()
+        assert rel_err(t11, om.teacher.backbone["blocks.11.mlp.fc2.weight"]) < 1e-6
+
+
 def test_mask_propagation_evaluation_vs_oracle():
     """N4: the evaluation loop body (extractor without head -> propagate_labels(4, 12, 5) -> upsample -> arg-max -> J) on a
     synthetic tracking clip, against the oracle fed with the same features; and the command-line driver."""

@@ -63,6 +63,7 @@ SIGNATURES = {
     "tt_adamw_step": (c_i, [C.POINTER(AdamwTensor), c_i, c_i, c_f, c_f, c_f, c_vp]),
     "tt_ema_update": (c_i, [c_vp, c_vp, c_ll, c_d, c_vp]),
     "tt_add_inplace": (c_i, [c_vp, c_vp, c_ll, c_vp]),
+    "tt_count_mismatch": (c_i, [c_vp, c_vp, c_ll, c_vp, c_vp]),
     "tt_foreground_mask": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_vp]),
     "tt_foreground_mask_from_probs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_vp]),
     "tt_scale_rows_inplace": (c_i, [c_vp, c_vp, c_i, c_i, c_vp]),

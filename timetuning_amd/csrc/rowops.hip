@@ -384,6 +384,31 @@ extern "C" int tt_add_inplace(float* dst, const float* src, long long n, tt_stre
   return TT_OK;
 }
 
+__global__ __launch_bounds__(256) void count_mismatch_kernel(const unsigned* __restrict__ a, const unsigned* __restrict__ b, long long n,
+                                                              unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) c += a[i] != b[i];
+  unsigned lo = (unsigned)c;  // per-thread count < 2^32 for any n this is used on
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lo += __shfl_xor(lo, o, 64);
+  if ((threadIdx.x & 63) == 0 && lo) atomicAdd(out, (unsigned long long)lo);
+}
+
+extern "C" int tt_count_mismatch(const float* a, const float* b, long long n, long long* count_out, tt_stream_t stream) {
+  TT_REQUIRE(a && b && count_out && n > 0, "count_mismatch: bad arguments");
+  hipError_t e = hipMemsetAsync(count_out, 0, sizeof(long long), as_stream(stream));
+  if (e != hipSuccess) {
+    set_error("count_mismatch: memset failed: %s", hipGetErrorString(e));
+    return TT_ELAUNCH;
+  }
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(count_mismatch_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<const unsigned*>(a),
+                     reinterpret_cast<const unsigned*>(b), n, reinterpret_cast<unsigned long long*>(count_out));
+  TT_CHECK_LAUNCH("count_mismatch");
+  return TT_OK;
+}
+
 extern "C" int tt_adamw_step(const tt_adamw_tensor* tensors, int count, int step, float beta1, float beta2, float eps,
                              tt_stream_t stream) {
   TT_REQUIRE(tensors && count > 0 && count <= TT_MAX_TENSORS && step >= 1, "adamw: need 1..%d tensors and step >= 1", TT_MAX_TENSORS);

@@ -90,9 +90,11 @@ def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int,
 
 
 def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None, save_blocks: Optional[Dict[int, dict]] = None,
-               last_block_probs: bool = False, last_block_aux: Optional[dict] = None):
+               last_block_probs: bool = False, last_block_aux: Optional[dict] = None, tap: Optional[dict] = None):
     """prepare_tokens + all blocks (dino_vision_transformer.py:236-252).  Returns (tokens [F,N,D] before the final
-    norm, attention probabilities of the last block or None).  ``last_block_aux`` receives the last block's qkv."""
+    norm, attention probabilities of the last block or None).  ``last_block_aux`` receives the last block's qkv.
+    ``tap = {"block": i, "rows": r}`` receives under ``"x"`` a private copy of the first ``r`` frames' residual stream as it
+    ENTERS block ``i`` (``i == depth``: as it leaves the last block) - what an EMA teacher sharing blocks [0, i) continues from."""
     pe = vit.patch_embed.proj
     D = pe.weight.shape[0]
     x = ops.patch_embed_fwd(img, pe.weight.view(D, -1), pe.bias, vit.cls_token.view(D), vit.pos_table(img.shape[-2], img.shape[-1]),
@@ -100,11 +102,23 @@ def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None,
     probs = None
     depth = len(vit.blocks)
     for i, blk in enumerate(vit.blocks):
+        if tap is not None and tap["block"] == i:
+            tap["x"] = x[: tap["rows"]].clone()
         sv = save_blocks.get(i) if save_blocks is not None else None
         if last_block_probs and i == depth - 1:
             probs = last_block_attention(x, blk, vit.num_heads)
         x = block_forward(x, blk, vit.num_heads, sv, last_block_aux if i == depth - 1 else None)
+    if tap is not None and tap["block"] == depth:
+        tap["x"] = x[: tap["rows"]].clone()
     return x, probs
+
+
+def vit_blocks(vit, x: torch.Tensor, first: int, last_block_aux: Optional[dict] = None) -> torch.Tensor:
+    """Blocks [first, depth) of ``vit`` on a residual stream x [F,N,D] that is the caller's to overwrite."""
+    depth = len(vit.blocks)
+    for i in range(first, depth):
+        x = block_forward(x, vit.blocks[i], vit.num_heads, None, last_block_aux if i == depth - 1 else None)
+    return x
 
 
 def last_block_attention(x: torch.Tensor, blk, num_heads: int) -> torch.Tensor:

@@ -598,3 +598,13 @@ def add_(dst, src):
     _chk(dst, "dst"); _chk(src, "src")
     _lib.check(lib.tt_add_inplace(_p(dst), _p(src), dst.numel(), _stream()), "tt_add_inplace")
     return dst
+
+
+def count_mismatch(a, b) -> int:
+    """Number of positions where two fp32 buffers differ bitwise; synchronises (a one-off check, not a step op)."""
+    lib = _lib.load()
+    _chk(a, "a"); _chk(b, "b")
+    assert a.numel() == b.numel()
+    out = torch.empty((1,), dtype=torch.int64, device=a.device)
+    _lib.check(lib.tt_count_mismatch(_p(a), _p(b), a.numel(), _p(out), _stream()), "tt_count_mismatch")
+    return int(out.item())

@@ -97,6 +97,7 @@ class TimeT(nn.Module):
         self.momentum_schedule = None
         self.data_parallel = False
         self._queue_rows_pushed = 0
+        self._ema_flat = None
         self._frame_maps: Dict[tuple, torch.Tensor] = {}
         if prototype_init is None:
             prototype_init = F.normalize(torch.randn((prototype_number, feature_extractor.feature_dim)), dim=-1, p=2)
@@ -129,29 +130,54 @@ class TimeT(nn.Module):
         self.momentum_schedule = cosine_scheduler(momentum_teacher, momentum_teacher_end, max_epochs, train_iter_per_epoch)
 
     def _flatten_for_ema(self):
-        """Re-homes student and teacher extractor parameters into two flat buffers (same order) so that the EMA
-        of 23.8 M parameters is one launch instead of ~150."""
+        """Re-homes student and teacher extractor parameters into two flat buffers (same order: trainable tensors first, frozen
+        ones after) so that the EMA is one launch instead of ~150, and decides ONCE whether the teacher's frozen tensors still
+        equal the student's bit for bit (``shared``).  They do whenever the teacher is the reference's ``deepcopy`` of the
+        student (time_tuning.py:96): a frozen parameter never changes, and its EMA ``t*(1-m) + s*m`` blends two identical
+        tensors (:113-114) - mathematically the identity.  With ``shared`` the EMA therefore runs over the trainable tensors
+        only (5.7 M of 23.8 M floats at ViT-S/16) and the teacher pass reuses the student's frozen-block activations
+        (``_run_step``).  A teacher passed in from outside, or loaded from a checkpoint whose frozen tensors differ, is
+        ``shared = False`` and takes the full pass and the full EMA."""
         sp, tp = list(self.feature_extractor.parameters()), list(self.teacher.parameters())
-        ok = self._ema_flat is not None
+        order = [i for i, p in enumerate(sp) if p.requires_grad] + [i for i, p in enumerate(sp) if not p.requires_grad]
+        sig = tuple(p.requires_grad for p in sp)
+        ok = self._ema_flat is not None and self._ema_flat["sig"] == sig
         if ok:
-            fs_, ft_, offs = self._ema_flat
-            ok = all(p.data_ptr() == fs_.data_ptr() + 4 * o for p, o in zip(sp, offs)) and \
-                all(p.data_ptr() == ft_.data_ptr() + 4 * o for p, o in zip(tp, offs))
+            c = self._ema_flat   # still re-homed?  (.to() / .cuda() re-allocate every tensor: the two ends tell)
+            ends = ((order[0], c["offs"][0]), (order[-1], c["offs"][-1]))
+            ok = all(sp[i].data_ptr() == c["s"].data_ptr() + 4 * o and tp[i].data_ptr() == c["t"].data_ptr() + 4 * o for i, o in ends)
         if ok:
             return self._ema_flat
-        offs, total = [], 0
-        for p in sp:
+        offs, total, n_train = [], 0, 0
+        for i in order:
             offs.append(total)
-            total += (p.numel() + 3) // 4 * 4
+            total += (sp[i].numel() + 3) // 4 * 4
+            if sp[i].requires_grad:
+                n_train = total
         dev = self.prototypes.device
         fs_, ft_ = torch.zeros(total, device=dev), torch.zeros(total, device=dev)
         for plist, flat in ((sp, fs_), (tp, ft_)):
-            for p, o in zip(plist, offs):
+            for i, o in zip(order, offs):
+                p = plist[i]
                 view = flat[o:o + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
-        self._ema_flat = (fs_, ft_, offs)
+        shared = total == n_train or ops.count_mismatch(fs_[n_train:], ft_[n_train:]) == 0
+        self._ema_flat = dict(s=fs_, t=ft_, offs=offs, n_train=n_train, shared=shared, sig=sig)
         return self._ema_flat
+
+    def invalidate_teacher_cache(self):
+        """Call after changing teacher or student FROZEN tensors by hand (``load_state_dict`` does it by itself): the next
+        step re-checks whether the teacher may share the student's frozen-block activations."""
+        self._ema_flat = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._ema_flat = None
+        return out
+
+    def teacher_shares_frozen_blocks(self) -> bool:
+        return self.teacher is not None and self.prototypes.is_cuda and self._flatten_for_ema()["shared"]
 
     def update_momentum_teacher(self, step, writer=None):
         """teacher <- teacher * (1 - m) + student * m with m = momentum_schedule[step] (time_tuning.py:109-118;
@@ -160,8 +186,10 @@ class TimeT(nn.Module):
             momentum = float(self.momentum_schedule[step])
             if writer is not None:
                 writer.add_scalar("momentum", momentum, step)
-            fs_, ft_, _ = self._flatten_for_ema()
-            ops.ema_update_(ft_, fs_, momentum)
+            c = self._flatten_for_ema()
+            n = c["n_train"] if c["shared"] else c["s"].numel()
+            if n:
+                ops.ema_update_(c["t"][:n], c["s"][:n], momentum)
             ops.ema_update_(self.teacher_prototypes.data, self.prototypes.data, momentum)
             ops.normalize_rows_(self.teacher_prototypes.data)
 
@@ -235,15 +263,21 @@ class TimeT(nn.Module):
         Fr = bs * fs
         xf = vit._check(x.reshape(Fr, c, h, w))
         dev = xf.device
-        train_ids = fe.trainable_block_ids() if need_grad else []
+        depth = len(vit.blocks)
+        all_train_ids = fe.trainable_block_ids()
+        train_ids = all_train_ids if need_grad else []
         first = min(train_ids) if train_ids else None
-        save = {i: {} for i in range(first, len(vit.blocks))} if first is not None else None
+        save = {i: {} for i in range(first, depth)} if first is not None else None
+        # EMA teacher that still shares the student's frozen tensors: its blocks [0, t_first) would reproduce the student's
+        # activations of frame 0, so they are tapped from the student's pass instead of recomputed
+        t_first = (min(all_train_ids) if all_train_ids else depth) if self.teacher_shares_frozen_blocks() else 0
+        tap: Optional[dict] = {"block": t_first, "rows": bs} if t_first > 0 else None
 
         # ---- student: one pass over all frames, time-major
         use_mask = hp.get("mask_features", False)
         g = fe.spatial_resolution
         s_aux: Optional[dict] = {} if use_mask else None
-        tok, _ = engine.vit_tokens(vit, xf, self._frame_map(bs, fs, dev), save, last_block_aux=s_aux)
+        tok, _ = engine.vit_tokens(vit, xf, self._frame_map(bs, fs, dev), save, last_block_aux=s_aux, tap=tap)
         N, D = tok.shape[1], tok.shape[2]
         n = N - 1
         # --use_mask (time_tuning.py:244-246 -> models.py:93-144): foreground masks from the last block's cls attention.
@@ -260,7 +294,12 @@ class TimeT(nn.Module):
         if self.teacher is not None:
             tvit = self.teacher.backbone
             t_aux: Optional[dict] = {} if use_mask else None
-            t_tok, _ = engine.vit_tokens(tvit, xf, self._frame_map(bs, fs, dev, only_t=0), last_block_aux=t_aux)
+            if tap is not None:   # frame 0 = the first bs frames of the time-major pass
+                t_tok = engine.vit_blocks(tvit, tap["x"], t_first, last_block_aux=t_aux)
+                if use_mask and t_first == depth:
+                    t_aux["qkv"] = s_aux["qkv"][:bs]
+            else:
+                t_tok, _ = engine.vit_tokens(tvit, xf, self._frame_map(bs, fs, dev, only_t=0), last_block_aux=t_aux)
             t_feats = ops.layernorm_fwd(t_tok, tvit.norm.weight, tvit.norm.bias, drop_first_token=True)
             z_q = engine.head_forward(t_feats, self.teacher.head) if self.teacher.head is not None else t_feats
             protos_q = self.teacher_prototypes.data
