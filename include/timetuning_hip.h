@@ -140,6 +140,12 @@ int tt_normalize_rows_inplace(float* w, int rows, int D, tt_stream_t stream);
 int tt_sinkhorn(const float* scores, float* q_out, int B_total, int K, int row0, int rows_out, float eps,
                 int iters, void* workspace, size_t workspace_bytes, tt_stream_t stream);
 size_t tt_sinkhorn_workspace_bytes(int B_total, int K);
+/*   The reference-signature entry, my_utils.sinkhorn(Q, nmb_iters, world_size) (my_utils.py:246): takes the POSITIVE matrix
+ *   exp(scores / eps) itself (no log / exp round trip) - as Q [K, B_total] (transposed = 0: the reference's layout) or as
+ *   Q^T [B_total, K] (transposed = 1: what an all-gather of the ranks' columns yields; read in place).  Same iterations,
+ *   same workspace. */
+int tt_sinkhorn_from_q(const float* Q, int transposed, float* q_out, int B_total, int K, int row0, int rows_out, int iters,
+                       void* workspace, size_t workspace_bytes, tt_stream_t stream);
 
 /* ---- k14: temporal label propagation (time_tuning.py:143-154 -> mask_propagation.py:396-496)
  *   xn   [fs, bs, n, D]  L2-normalised backbone tokens, time-major (frame t of clip b at [t][b])

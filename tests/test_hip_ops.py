@@ -158,6 +158,13 @@ def test_my_utils_sinkhorn_signature(golden):
     for tag in "ac":
         Q = torch.exp(torch.from_numpy(g[f"{tag}_scores"]) / 0.05).t().contiguous()
         assert rel_err(sinkhorn(Q.cuda(), int(g[f"{tag}_iters"])).cpu(), g[f"{tag}_q"]) < 1e-4, tag
+    # the positive matrix in [B, K] layout (what the all-gather of the ranks' columns yields), rank 1's rows of the W = 2 problem
+    from timetuning_amd import hip_ops
+
+    g2 = golden("sinkhorn_w2")
+    E = torch.exp(torch.from_numpy(g2["scores"]) / 0.05).contiguous().cuda()
+    q = hip_ops.sinkhorn_from_q(E, int(g2["iters"]), row0=196, rows_out=196, transposed=True)
+    assert rel_err(q.cpu(), g2["q"][196:]) < 5e-5
 
 
 def test_sinkhorn_golden(ops, golden):

@@ -497,6 +497,64 @@ def test_teacher_reuses_student_frozen_blocks_only_when_they_are_equal():
         assert rel_err(t11, om.teacher.backbone["blocks.11.mlp.fc2.weight"]) < 1e-6
 
 
+@pytest.mark.parametrize("use_head", [True, False])
+def test_features_carry_grad_at_the_module_surface(use_head):
+    """models.py:1070-1078: ``FeatureExtractor.forward`` returns features WITH grad (a caller such as linear_finetune.py:59-63
+    trains through ``model(x)``); attentions never carry grad (:969).  Gradient of a random linear functional of the features
+    against the oracle's autograd, for head, unfrozen-block and frozen parameters."""
+    from oracle import timet_oracle as O
+    from timetuning_amd.models import FeatureExtractor
+
+    cfg, head = synth.ARCHS["tiny-s16"], (128, 128, 64, 32)
+    fe = FeatureExtractor("dino-s16", "", list(head), unfreeze_layers=["blocks.11", "blocks.10"], vit_cfg=cfg, init="stress").cuda()
+    om = O.build_oracle("dino-s16", 8, head, mode="stress", vit_cfg=cfg)
+    x = torch.from_numpy(synth.make_clips(1, 3, 224, seed=41)).view(3, 3, 224, 224)
+    f, attn = fe(x.cuda(), use_head=use_head)
+    assert f.requires_grad and attn is not None and not attn.requires_grad
+    of, oattn = om.feature_extractor(x, use_head=use_head, faithful=True)
+    assert rel_err(f.detach().cpu(), of.detach()) < 1e-4 and rel_err(attn.cpu(), oattn) < 1e-4
+    w = torch.from_numpy(synth.normal("surface.w", tuple(f.shape)))
+    (f * w.cuda()).sum().backward()
+    (of * w).sum().backward()
+    og = {"feature_extractor." + k: v for k, v in om.feature_extractor.named_parameters()}
+    mine = {"feature_extractor." + k: v for k, v in fe.named_parameters()}
+    names = ["feature_extractor.backbone.blocks.10.attn.qkv.weight", "feature_extractor.backbone.blocks.11.norm2.weight",
+             "feature_extractor.backbone.blocks.11.mlp.fc2.bias"]
+    if use_head:
+        names += ["feature_extractor.head.0.weight", "feature_extractor.head.6.bias"]
+    for name in names:
+        assert mine[name].grad is not None, name
+        assert rel_err(mine[name].grad.cpu(), og[name].grad) < TOL, name
+    assert mine["feature_extractor.backbone.blocks.3.mlp.fc1.weight"].grad is None          # frozen
+    if not use_head:
+        assert mine["feature_extractor.head.0.weight"].grad is None
+    with torch.no_grad():                                                                    # and nothing is kept without grad
+        f2, _ = fe(x.cuda(), use_head=use_head)
+    assert not f2.requires_grad and torch.equal(f2, f.detach())
+
+
+def test_similarity_scores_carry_grad():
+    """time_tuning.py:130-141: ``get_feature_prototype_similarity`` is differentiable in the features and the prototypes."""
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    fe = FeatureExtractor("dino-s16", "", [64, 32], vit_cfg=synth.ARCHS["tiny-s16"], init="stress", return_attention=False)
+    model = TimeT(fe, 24, prototype_init=torch.from_numpy(synth.make_prototypes(24, 32))).cuda()
+    z = torch.from_numpy(synth.normal("sim.z", (200, 32)))
+    w = torch.from_numpy(synth.normal("sim.w", (200, 24)))
+    zg = z.clone().cuda().requires_grad_(True)
+    sc = model.get_feature_prototype_similarity(zg)
+    assert sc.requires_grad
+    (sc * w.cuda()).sum().backward()
+    zc, pc = z.clone().requires_grad_(True), model.prototypes.detach().cpu().clone().requires_grad_(True)
+    ref = torch.nn.functional.normalize(zc, dim=-1) @ pc.t()
+    (ref * w).sum().backward()
+    assert rel_err(sc.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(zg.grad.cpu(), zc.grad) < 1e-4 and rel_err(model.prototypes.grad.cpu(), pc.grad) < 1e-4
+    sct = model.get_feature_prototype_similarity(zg.detach(), use_teacher=False)            # prototypes alone still require grad
+    assert sct.requires_grad
+
+
 def test_mask_propagation_evaluation_vs_oracle():
     """N4: the evaluation loop body (extractor without head -> propagate_labels(4, 12, 5) -> upsample -> arg-max -> J) on a
     synthetic tracking clip, against the oracle fed with the same features; and the command-line driver."""

@@ -110,3 +110,7 @@ def test_cli_driver_on_raw_frames(tmp_path):
     model = time_tuning(0, args)
     assert model.teacher is not None and model.queue is not None
     assert torch.isfinite(model.prototypes).all() and (tmp_path / "checkpoint.pth").exists()
+    # the periodic rank-0 evaluation (time_tuning.py:634-646) ran at epoch 0 on the synthetic evaluation set: k-means over
+    # backbone features -> matched mIoU; the best-score snapshot is written like the reference's "{score}_{epoch}.pth"
+    assert len(model.eval_scores) == 1 and model.eval_scores[0][0] == 0 and 0.0 < model.eval_scores[0][1] <= 1.0
+    assert (tmp_path / f"{model.eval_scores[0][1]}_0.pth").exists()

@@ -55,6 +55,7 @@ SIGNATURES = {
     "tt_normalize_rows_inplace": (c_i, [c_vp, c_i, c_i, c_vp]),
     "tt_sinkhorn": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_i, c_vp, c_sz, c_vp]),
     "tt_sinkhorn_workspace_bytes": (c_sz, [c_i, c_i]),
+    "tt_sinkhorn_from_q": (c_i, [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_label_propagate": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
     "tt_label_propagate_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "tt_ce_loss_fwd_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_vp, c_sz, c_vp]),

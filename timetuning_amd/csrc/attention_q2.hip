@@ -92,11 +92,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_q2_kernel(const float* _
   for (int c = 0; c < NC; ++c) {
     const int buf = c & 1;
     if (c + 1 < NC) gload(c + 1, 1);
-#ifdef ABL_NOQK
-    if (false) {
-#else
     if (wave_active) {
-#endif
       const float* kp = Ks + (buf * Q2_KCH + qi) * Q2_KSTR + g;
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
@@ -133,11 +129,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_q2_kernel(const float* _
     for (int k = 0; k < NT; ++k)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-#ifdef ABL_NOEXP  // timing ablation only (tools/ab_attn.py)
-        const float p = sacc[t][k][e] - mx;
-#else
         const float p = fast_exp(sacc[t][k][e] - mx);
-#endif
         sacc[t][k][e] = p;
         sum += p;
       }
@@ -159,11 +151,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_q2_kernel(const float* _
   for (int c = 0; c < NC; ++c) {
     const int buf = c & 1;
     if (c + 1 < NC) gload(c + 1, 2);
-#ifdef ABL_NOPV
-    if (false) {
-#else
     if (wave_active) {
-#endif
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         const int k = 2 * c + t2;

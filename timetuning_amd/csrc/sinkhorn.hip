@@ -83,6 +83,37 @@ __global__ __launch_bounds__(SK_THREADS) void sk_init_kernel(const float* __rest
   fold_waves(acc, red, partial + (long long)blockIdx.x * K, K);
 }
 
+// The same from the positive matrix itself, Q[k][b] = exp(scores[b][k] / eps) as my_utils.sinkhorn receives it ([K][B], :246):
+// E[b][k] = Q[k][b] (a transposing copy through LDS, 64 x 64 tiles), no exp / log round trip.
+__global__ __launch_bounds__(256) void sk_transpose_kernel(const float* __restrict__ Q, float* __restrict__ E, int B, int K) {
+  __shared__ float t[64][65];
+  const int b0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+  for (int r = r4; r < 64; r += 4)
+    if (k0 + r < K && b0 + c < B) t[r][c] = Q[(long long)(k0 + r) * B + b0 + c];
+  __syncthreads();
+  for (int r = r4; r < 64; r += 4)
+    if (b0 + r < B && k0 + c < K) E[(long long)(b0 + r) * K + k0 + c] = t[c][r];
+}
+
+__global__ __launch_bounds__(SK_THREADS) void sk_init_from_e_kernel(const float* __restrict__ E, float* __restrict__ partial, int B, int K,
+                                                                    int rows_per_wg) {
+  __shared__ float red[SK_WAVES][64 * SK_KPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(B, r0 + rows_per_wg);
+  float acc[SK_KPL];
+#pragma unroll
+  for (int i = 0; i < SK_KPL; ++i) acc[i] = 0.f;
+  for (int b = r0 + wave; b < r1; b += SK_WAVES) {
+#pragma unroll
+    for (int i = 0; i < SK_KPL; ++i) {
+      const int k = lane + 64 * i;
+      if (k < K) acc[i] += E[(long long)b * K + k];
+    }
+  }
+  fold_waves(acc, red, partial + (long long)blockIdx.x * K, K);
+}
+
 // One Sinkhorn iteration (row step + column step) or, with LAST, the final column normalisation + output.
 template <bool LAST>
 __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __restrict__ E, const float* __restrict__ partial_in,
@@ -211,20 +242,42 @@ extern "C" size_t tt_sinkhorn_workspace_bytes(int B_total, int K) {
   return ((size_t)B_total * K + 2ull * SK_MAXWG * K) * sizeof(float);
 }
 
+static int sinkhorn_impl(const float* scores, const float* Q, int q_rows_are_columns, float* q_out, int B_total, int K, int row0,
+                         int rows_out, float eps, int iters, void* workspace, size_t workspace_bytes, tt_stream_t stream);
+
 extern "C" int tt_sinkhorn(const float* scores, float* q_out, int B_total, int K, int row0, int rows_out, float eps,
                            int iters, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
-  TT_REQUIRE(scores && q_out && workspace, "sinkhorn: null pointer");
+  TT_REQUIRE(scores, "sinkhorn: null pointer");
+  return sinkhorn_impl(scores, nullptr, 0, q_out, B_total, K, row0, rows_out, eps, iters, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tt_sinkhorn_from_q(const float* Q, int transposed, float* q_out, int B_total, int K, int row0, int rows_out, int iters,
+                                  void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(Q, "sinkhorn_from_q: null pointer");
+  return sinkhorn_impl(nullptr, Q, transposed, q_out, B_total, K, row0, rows_out, 1.0f, iters, workspace, workspace_bytes, stream);
+}
+
+static int sinkhorn_impl(const float* scores, const float* Q, int q_rows_are_columns, float* q_out, int B_total, int K, int row0,
+                         int rows_out, float eps, int iters, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(q_out && workspace, "sinkhorn: null pointer");
   TT_REQUIRE(B_total > 0 && K > 0 && K <= 64 * SK_KPL, "sinkhorn: need 0 < K <= %d (got %d)", 64 * SK_KPL, K);
   TT_REQUIRE(row0 >= 0 && rows_out > 0 && row0 + rows_out <= B_total, "sinkhorn: output rows [%d, %d) outside [0, %d)", row0,
              row0 + rows_out, B_total);
   TT_REQUIRE(iters >= 0 && eps > 0.f, "sinkhorn: bad iters/eps");
   TT_REQUIRE(workspace_bytes >= tt_sinkhorn_workspace_bytes(B_total, K), "sinkhorn: workspace too small");
   hipStream_t s = as_stream(stream);
-  float* E = static_cast<float*>(workspace);
-  float* part[2] = {E + (size_t)B_total * K, E + (size_t)B_total * K + (size_t)SK_MAXWG * K};
+  float* Ews = static_cast<float*>(workspace);
+  float* part[2] = {Ews + (size_t)B_total * K, Ews + (size_t)B_total * K + (size_t)SK_MAXWG * K};
+  // E [B][K]: built in the workspace, or - when the caller already holds the positive matrix in that layout - read in place
+  const float* E = (Q && q_rows_are_columns) ? Q : Ews;
   const int wgs = sk_wgs(B_total);
   const int rpw = (B_total + wgs - 1) / wgs;
-  hipLaunchKernelGGL(sk_init_kernel, dim3(wgs), dim3(SK_THREADS), 0, s, scores, E, part[0], B_total, K, eps, rpw);
+  if (Q) {
+    if (!q_rows_are_columns) hipLaunchKernelGGL(sk_transpose_kernel, dim3((B_total + 63) / 64, (K + 63) / 64), dim3(256), 0, s, Q, Ews, B_total, K);
+    hipLaunchKernelGGL(sk_init_from_e_kernel, dim3(wgs), dim3(SK_THREADS), 0, s, E, part[0], B_total, K, rpw);
+  } else {
+    hipLaunchKernelGGL(sk_init_kernel, dim3(wgs), dim3(SK_THREADS), 0, s, scores, Ews, part[0], B_total, K, eps, rpw);
+  }
   int cur = 0;
   for (int it = 0; it + 1 < iters; ++it) {  // iterations 1 .. iters-1 (each prepares the next row step)
     hipLaunchKernelGGL((sk_iter_kernel<false>), dim3(wgs), dim3(SK_THREADS), 0, s, E, part[cur], part[cur ^ 1], (float*)nullptr,

@@ -315,6 +315,21 @@ def sinkhorn(scores, iters: int, eps: float = 0.05, row0: int = 0, rows_out: Opt
     return q
 
 
+def sinkhorn_from_q(Q, iters: int, row0: int = 0, rows_out: Optional[int] = None, transposed: bool = False):
+    """Q positive = exp(scores / eps): [K, B_total] as my_utils.sinkhorn receives it, or [B_total, K] with ``transposed``
+    -> q [rows_out, K]."""
+    lib = _lib.load()
+    _chk(Q, "Q")
+    B, K = Q.shape if transposed else Q.shape[::-1]
+    rows_out = B - row0 if rows_out is None else rows_out
+    q = torch.empty((rows_out, K), dtype=f32, device=Q.device)
+    nb = lib.tt_sinkhorn_workspace_bytes(B, K)
+    ws = _ws(nb, Q.device)
+    _lib.check(lib.tt_sinkhorn_from_q(_p(Q), int(transposed), _p(q), B, K, row0, rows_out, int(iters), _p(ws), nb, _stream()),
+               "tt_sinkhorn_from_q")
+    return q
+
+
 def label_propagate(xn, seg0, n_last_frames=7, radius=6, topk=5, temperature=0.1, return_pmap=False):
     """xn [fs,bs,n,D] normalised tokens (time-major), seg0 [bs,n,K] -> labels [bs,n] int64 (+ pmap [bs,n,K] fp64)."""
     lib = _lib.load()

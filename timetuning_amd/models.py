@@ -104,24 +104,94 @@ class FeatureExtractor(nn.Module):
                 ids.append(i)
         return ids
 
-    # -- inference surface -----------------------------------------------------------------------
+    # -- forward surface ---------------------------------------------------------------------------
     @torch.no_grad()
     def get_features(self, input):
-        """models.py:965-969: final-norm'd patch tokens (cls dropped) and the last block's attention."""
+        """models.py:965-969: final-norm'd patch tokens (cls dropped) and the last block's attention (always detached, :969)."""
         x = self.backbone._check(input)
         tok, probs = engine.vit_tokens(self.backbone, x, last_block_probs=self.return_attention)
         Fr, N, D = tok.shape
         feats = ops.layernorm_fwd(tok, self.backbone.norm.weight, self.backbone.norm.bias, drop_first_token=True)
         return feats.view(Fr, N - 1, D), probs
 
-    @torch.no_grad()
     def forward(self, x, use_head=True):
-        """models.py:1070-1078 (inference: no autograd graph; training goes through TimeT.get_loss)."""
-        feats, attn = self.get_features(x)
+        """models.py:1070-1078.  As in the reference the returned features carry grad whenever autograd is enabled and a
+        parameter on their path requires it (the head, the unfrozen blocks): the forward then keeps the activations of the
+        trainable part and ``features.backward(...)`` runs the HIP backward kernels (``_ExtractorFunction``).  Under
+        ``torch.no_grad()`` - every call on the training path of ``TimeT`` - nothing is kept.  ``attentions`` never carry
+        grad (:969)."""
+        params = [p for p in (self.parameters() if use_head else self.backbone.parameters()) if p.requires_grad]
+        if torch.is_grad_enabled() and params:
+            if x.requires_grad:
+                raise NotImplementedError("gradients with respect to the input frames are not built (the reference's callers never ask for them)")
+            feats, attn = _ExtractorFunction.apply(self, x, bool(use_head), *params)
+            return feats, (attn if attn.numel() else None)
+        with torch.no_grad():
+            feats, attn = self.get_features(x)
+            if self.head is not None and use_head:
+                Fr, n, D = feats.shape
+                feats = engine.head_forward(feats.view(Fr * n, D), self.head).view(Fr, n, -1)
+            return feats, attn
+
+    def _forward_saving(self, x, use_head: bool):
+        """Forward that keeps what ``_backward_saved`` needs: activations of the trainable blocks (all frames), the final
+        norm's statistics and the head's activations."""
+        vit = self.backbone
+        xi = vit._check(x)
+        ids = self.trainable_block_ids()
+        first = min(ids) if ids else None
+        save = {i: {} for i in range(first, len(vit.blocks))} if first is not None else None
+        tok, probs = engine.vit_tokens(vit, xi, None, save, last_block_probs=self.return_attention)
+        Fr, N, D = tok.shape
+        feats, mean_f, rstd_f = ops.layernorm_fwd(tok, vit.norm.weight, vit.norm.bias, save_stats=True, drop_first_token=True)
+        sv_head = None
+        out = feats
         if self.head is not None and use_head:
-            Fr, n, D = feats.shape
-            feats = engine.head_forward(feats.view(Fr * n, D), self.head).view(Fr, n, -1)
+            sv_head = {}
+            out = engine.head_forward(feats, self.head, sv_head)
+        saved = dict(first=first, blocks=save, tok=tok, mean=mean_f, rstd=rstd_f, head=sv_head, shape=(Fr, N, D))
+        return out.view(Fr, N - 1, -1), probs, saved
+
+    def _backward_saved(self, saved: dict, dfeats: torch.Tensor) -> Dict[nn.Parameter, torch.Tensor]:
+        vit = self.backbone
+        Fr, N, D = saved["shape"]
+        grads: Dict[nn.Parameter, torch.Tensor] = {}
+        d = dfeats.reshape(Fr * (N - 1), -1).contiguous()   # read-only below: autograd's buffer is never written
+        if saved["head"] is not None:
+            d = engine.head_backward(d, self.head, saved["head"], grads)
+        first = saved["first"]
+        wg = vit.norm.weight.requires_grad
+        if first is not None or wg:
+            dx, dg, db = ops.layernorm_bwd(d, saved["tok"], vit.norm.weight, saved["mean"], saved["rstd"], need_wgrad=wg, drop_first_token=True)
+            if wg:
+                grads[vit.norm.weight], grads[vit.norm.bias] = dg, db
+            if first is not None:
+                dx = dx.view(Fr * N, D)
+                for i in range(len(vit.blocks) - 1, first - 1, -1):
+                    dx = engine.block_backward(dx, vit.blocks[i], vit.num_heads, saved["blocks"][i], 0, Fr, grads, need_dx=i > first)
+        return {p: g for p, g in grads.items() if p.requires_grad}
+
+
+class _ExtractorFunction(torch.autograd.Function):
+    """``FeatureExtractor.forward`` with grad: HIP forward that keeps the trainable part's activations, HIP backward
+    (engine.head_backward / block_backward) when the features' gradient arrives."""
+
+    @staticmethod
+    def forward(ctx, fe, x, use_head, *params):
+        feats, attn, saved = fe._forward_saving(x, use_head)
+        ctx.fe, ctx.saved, ctx.params = fe, saved, params
+        if attn is None:
+            attn = x.new_empty(0)   # autograd.Function outputs must be tensors; turned back into None by the caller-facing wrapper
+        ctx.mark_non_differentiable(attn)
         return feats, attn
+
+    @staticmethod
+    def backward(ctx, dfeats, _dattn):
+        if ctx.saved is None:
+            raise RuntimeError("FeatureExtractor: backward through the same forward twice (activations are freed after the first)")
+        grads = ctx.fe._backward_saved(ctx.saved, dfeats)
+        ctx.saved = None
+        return (None, None, None, *[grads.get(p) for p in ctx.params])
 
 
 class _DDPStandIn(nn.Module):

@@ -44,9 +44,13 @@ class PatchPrototypeSimilarity(nn.Module):
         self.sinkhorn_iterations = sinkhorn_iterations
 
     def similarity(self, x: torch.Tensor, use_teacher: bool = False) -> torch.Tensor:
+        """``normalize(x, dim=-1) @ prototypes.T`` (time_tuning.py:130-141).  With autograd enabled the scores carry grad to
+        ``x`` and to the prototypes, as in the reference (``_SimilarityFunction``: HIP forward and backward)."""
         o = self._owner
         protos = o.teacher_prototypes if use_teacher else o.prototypes
-        return engine.prototype_scores(x.contiguous(), protos.detach())
+        if torch.is_grad_enabled() and (x.requires_grad or protos.requires_grad):
+            return _SimilarityFunction.apply(x, protos)
+        return engine.prototype_scores(x.detach().contiguous(), protos.detach())
 
     @torch.no_grad()
     def forward(self, features: torch.Tensor, use_teacher: bool = False, epsilon: Optional[float] = None,
@@ -61,6 +65,29 @@ class PatchPrototypeSimilarity(nn.Module):
             scores = torch.cat([batch_scores, self.similarity(o.queue, use_teacher)], dim=0)
         q = engine.global_sinkhorn(scores, bs * n, eps, int(iters))
         return q.view(bs, n, -1), batch_scores.view(bs, n, -1)
+
+
+class _SimilarityFunction(torch.autograd.Function):
+    """scores = normalize(x) @ prototypes.T with a HIP backward: d_prototypes = d_scores.T @ normalize(x),
+    d_x = l2norm_bwd(d_scores @ prototypes)."""
+
+    @staticmethod
+    def forward(ctx, x, protos):
+        sv: Dict[str, torch.Tensor] = {}
+        scores = engine.prototype_scores(x.detach().contiguous(), protos.detach(), sv)
+        ctx.save_for_backward(sv["zn"], sv["inv"], protos.detach())
+        return scores
+
+    @staticmethod
+    def backward(ctx, dscores):
+        zn, inv, protos = ctx.saved_tensors
+        ds = dscores.contiguous()
+        dprotos = dx = None
+        if ctx.needs_input_grad[1]:
+            dprotos, _ = ops.linear_bwd_weight(ds, zn, need_bias=False)
+        if ctx.needs_input_grad[0]:
+            dx = ops.l2norm_bwd(ops.linear_bwd_data(ds, protos), zn, inv)
+        return dx, dprotos
 
 
 class _FusedLoss(torch.autograd.Function):
@@ -494,8 +521,8 @@ def build_parser() -> argparse.ArgumentParser:
     queue ON, as in the reference's README command); ``--epsilon --sinkhorn_iterations --n_last_frames --topk
     --size_mask_neighborhood --epochs --dataset_path --destination_path`` are parsed but never reach ``get_loss``,
     which uses its signature defaults (eps 0.05, 10 iterations, 7 frames, radius 6, top-5).
-    Added (not in the reference): ``--dataset synthetic`` and ``--steps_per_epoch`` because the dataset loaders are
-    out of scope here."""
+    Added (not in the reference): ``--dataset synthetic`` / ``--steps_per_epoch`` / ``--eval_clips`` because the dataset
+    loaders are out of scope here, and ``--eval_every`` (the reference hard-codes 4)."""
     p = argparse.ArgumentParser()
     p.add_argument("--architecture", type=str, default="dino-s16")
     p.add_argument("--model_path", type=str, default="vits16_800ep.pth.tar")
@@ -534,6 +561,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("-nr", "--nr", default=0, type=int)
     p.add_argument("--epochs", default=3000, type=int, metavar="N")
     p.add_argument("--steps_per_epoch", default=8, type=int, help="synthetic data only")
+    p.add_argument("--eval_every", default=4, type=int, help="epochs between rank-0 evaluations (the reference hard-codes 4; 0 = never)")
+    p.add_argument("--eval_clips", default=8, type=int, help="synthetic evaluation set size")
     return p
 
 
@@ -580,13 +609,47 @@ class SyntheticFrameClips(SyntheticClips):
             yield torch.stack(clips).unsqueeze(1), torch.zeros(self.bs, 1, self.fs, 1), torch.zeros(self.bs)
 
 
+class SyntheticEvalClips:
+    """Stand-in for the reference's evaluation loader (``pascal_loader(60, ..., "val", 112, train_size=224)``, time_tuning.py:596):
+    a fixed set of synthetic frames with planted integer masks, batches ``(data [bs,1,fs,3,R,R], annotations [bs,1,fs,R,R])``."""
+
+    def __init__(self, num_clips, num_frames, resolution, batch_size, device):
+        from . import mask_propagation as MP
+
+        self.batches = []
+        for b0 in range(0, num_clips, batch_size):
+            clips = [MP.synthetic_tracking_clip(num_frames, resolution, seed=900 + i) for i in range(b0, min(num_clips, b0 + batch_size))]
+            data = torch.stack([c for c, _ in clips]).unsqueeze(1).to(device)
+            ann = torch.stack([m for _, m in clips]).unsqueeze(1).to(device)
+            self.batches.append((data, ann))
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def seed_everything(seed: int = 1) -> None:
+    """The reference seeds python / numpy / torch with 1 at import time (time_tuning.py:66-69): prototype initialisation and
+    the queue permutations (``torch.randperm``, :259) are reproducible from run to run."""
+    import random
+
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
 def time_tuning(gpu=0, args=None):
-    """One process per GPU (``time_tuning.py:508-666``): model, optimiser, epoch loop.  The evaluation the reference runs
-    every 4 epochs on Pascal VOC (:634-646) is available as ``timetuning_amd.evaluation.Evaluator`` but not wired in here:
-    the dataset readers are out of scope."""
+    """One process per GPU (``time_tuning.py:508-666``): model, optimiser, epoch loop with the rank-0 evaluation every
+    ``--eval_every`` (reference: 4) epochs and the barrier behind it (:634-648).  Datasets are synthetic (the readers are out of
+    scope): training clips from the portable generator, evaluation frames with planted masks."""
     import torch.distributed as dist
 
+    from .evaluation import Evaluator
+
     global world_size
+    seed_everything(1)
     device = torch.device("cuda", gpu)
     torch.cuda.set_device(device)
     world_size = args.gpus * args.nodes
@@ -619,12 +682,32 @@ def time_tuning(gpu=0, args=None):
     os.makedirs(args.logging_directory, exist_ok=True)
     if args.load_checkpoint:
         load_checkpoint(model, opt, os.path.join(args.logging_directory, "checkpoint.pth"))
+    # evaluation (time_tuning.py:596-604): rank 0 only, on the bare model, k-means over backbone features, matched mIoU
+    eval_model = model.get_non_ddp_model() if isinstance(model, DistributedDataParallelModel) else model
+    evaluator = None
+    if args.eval_every > 0 and rank == 0:
+        eval_loader = SyntheticEvalClips(args.eval_clips, 1, args.input_resolution, 4, device)
+        evaluator = Evaluator(eval_model, eval_loader, 21, device, clustering_algorithm="k-means", uvos_flag=bool(args.uvos))
+    eval_resolution = args.input_resolution // 2 if args.evaluation_protocol == "dataset-wise" else args.input_resolution  # :603
+    previous_score, scores = 0.0, []
     last = num_itr * args.num_epochs - 1
     for epoch in range(args.num_epochs):
         if rank == 0:
             save_checkpoint(model, opt, epoch, os.path.join(args.logging_directory, "checkpoint.pth"))
+        if evaluator is not None and epoch % args.eval_every == 0:        # :634-646
+            with torch.no_grad():
+                eval_model.eval()
+                eval_score = float(evaluator.evaluate(many_to_one=args.many_to_one, evaluation_protocol=args.evaluation_protocol,
+                                                      eval_resolution=eval_resolution, num_clusters=21, use_annotations=False,
+                                                      use_mask=False, precision_based=args.precision_based))
+                if eval_score > previous_score:
+                    previous_score = eval_score
+                    eval_model.save(os.path.join(args.logging_directory, f"{previous_score}_{epoch}.pth"))
+                scores.append((epoch, eval_score))
+                print("Epoch: {} Scores/localization {:.4f}".format(epoch, eval_score))
+            eval_model.train()
         if world_size > 1:
-            dist.barrier()
+            dist.barrier()                                                  # :647-648: the other ranks wait for rank 0
         model.train()
         for i, (data, annotations, label) in enumerate(loader):
             data = data.squeeze(1)
@@ -635,6 +718,7 @@ def time_tuning(gpu=0, args=None):
                 model.update_momentum_teacher(min(opt.global_step, last))
             if rank == 0:
                 print("Iteration: {}/{} loss {:.4f}".format(i, num_itr, loss.item()))
+    model.eval_scores = scores
     return model
 
 
