@@ -32,6 +32,24 @@ import torch  # noqa: E402
 
 F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 TILE_NAMES = {0: "128x128", 1: "64x128", 2: "128x64", 3: "64x64"}
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense v_mfma_f32_32x32x16_bf16 (MI355X_MICROARCH.md)
+ALT_NOTES = {
+    "bf16x6": "fp32-accurate split mode: operands pre-split into 3 bf16 planes, 6 bf16 MFMAs per product term (nominal peak "
+              f"{BF16_MATRIX_PEAK_TFLOPS / 6:.0f} TFLOP/s) on the blocks that keep no activations; same fp32 tolerances in the parity tests",
+    "bf16x3": "2-plane split (~2^-16 per product), fp32 in HBM converted while staging",
+    "bf16": "bf16 activations + weights in HBM, bf16 attention (BASELINE C4's MFMA bf16 path) on the blocks that keep no activations; "
+            "not within the fp32 contract",
+}
+
+
+def kernel_label(name, tile):
+    if name == "NT":
+        return f"gemm_nt_fast_kernel<{TILE_NAMES[tile]}> (forward nn.Linear, whole tiles)"
+    if name == "NTbf16":
+        return f"gemm_nt_bf16_kernel<{TILE_NAMES[tile]}> (forward nn.Linear, fp32 operands converted while staged)"
+    if name.startswith("PLANES"):
+        return f"gemm_planes_kernel<P={name[6:]}> (forward nn.Linear on bf16-plane operands)"
+    return f"gemm_f32_kernel<{TILE_NAMES[tile]},{name}>"
 
 
 def build_model(arch, K, device, teacher=False, queue=0, world=1):
@@ -98,9 +116,10 @@ def sinkhorn_rate(device, B=6272, K=200, iters=10, reps=30):
     return iters / sec, algo_bytes / sec / 1e9
 
 
-def cpu_baseline(fs, K, budget_s=30.0):
+def cpu_baseline(fs, K, budget_s=30.0, arch="dino-s16", precision="f32"):
     """The oracle in the reference's own structure (4 backbone passes per frame, per-sample host propagation) on a
-    bounded sample of the C2 step: bs=2 clips instead of 32 (per-clip work is identical)."""
+    bounded sample of the timed step: bs=2 clips instead of the full batch (per-clip work is identical).  Also the parity of the
+    GPU path IN THE TIMED PRECISION MODE against this fp32 oracle on that sample (patch embeddings, assignment logits)."""
     from oracle import timet_oracle as O
     from timetuning_amd import synth
 
@@ -108,7 +127,7 @@ def cpu_baseline(fs, K, budget_s=30.0):
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     bs = 2
-    om = O.build_oracle("dino-s16", K, (1024, 1024, 512, 256), mode="dino")
+    om = O.build_oracle(arch, K, (1024, 1024, 512, 256), mode="dino")
     opt = O.SwavOptimizerOracle(om, 1e-5, 1e-4, O.cosine_scheduler(0.04, 0.4, 1, 128), 128, 1)
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1))
     # parity of the two paths on this very sample, before either is trained (same portable weights): patch embeddings
@@ -117,11 +136,18 @@ def cpu_baseline(fs, K, budget_s=30.0):
         flat = x.view(bs * fs, 3, 224, 224)
         of, _ = om.feature_extractor(flat, faithful=False)
         osc = om.get_feature_prototype_similarity(of.reshape(-1, of.shape[-1]))
-        gm = build_model("dino-s16", K, torch.device("cuda", 0))
-        gf, _ = gm.feature_extractor(flat.cuda())
-        gsc = gm.get_feature_prototype_similarity(gf.reshape(-1, gf.shape[-1]))
+        from timetuning_amd import hip_ops
+
+        gm = build_model(arch, K, torch.device("cuda", 0))
+        hip_ops.set_gemm_precision(precision)
+        try:
+            gf, _ = gm.feature_extractor(flat.cuda())
+            gsc = gm.get_feature_prototype_similarity(gf.reshape(-1, gf.shape[-1]))
+        finally:
+            hip_ops.set_gemm_precision("f32")
         rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
-        parity = {"patch_embeddings_rel_err": rel(gf.cpu(), of), "assignment_logits_rel_err": rel(gsc.cpu(), osc), "bound": 1e-3}
+        parity = {"patch_embeddings_rel_err": rel(gf.cpu(), of), "assignment_logits_rel_err": rel(gsc.cpu(), osc), "gpu_precision": precision,
+                  "bound": 1e-3 if precision in ("f32", "bf16x6", "bf16x3") else None}
         del gm, gf, gsc
         # the second half of the metric on the host: the reference's Sinkhorn (my_utils.py:246-274) at the C2 shape
         sk_in = torch.exp(torch.nn.functional.normalize(torch.randn(6272, 256), dim=1) @ torch.nn.functional.normalize(torch.randn(K, 256), dim=1).t() / 0.05).t()
@@ -141,7 +167,7 @@ def cpu_baseline(fs, K, budget_s=30.0):
         t_total += time.perf_counter() - t0
         n += 1
     return {"value": round(bs * fs * n / t_total, 4), "unit": "clip-frames/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} training step(s) of {bs} clips x {fs} frames (C2 step = 32 clips; per-clip work identical), torch-CPU fp32, "
+            "sample": f"{n} training step(s) of {bs} clips x {fs} frames of {arch} (per-clip work identical to the timed batch), torch-CPU fp32, "
                       "reference-faithful structure (4 ViT passes per frame, per-sample host label propagation)",
             "seconds_per_step": round(t_total / n, 3), "sinkhorn_iters_per_sec": round(sk_cpu, 1), "parity_vs_gpu": parity}
 
@@ -233,8 +259,9 @@ def main():
     ap.add_argument("--use_queue", action="store_true")
     ap.add_argument("--use_mask", action="store_true", help="time the --use_mask variant (attention foreground masks) instead")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
-                    help="arithmetic of the forward Linears for the TIMED region (default f32 = the headline / parity mode)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
+                    help="arithmetic of the forward Linears for the TIMED region (default f32 = the headline / parity mode; "
+                         "hip_ops.set_gemm_precision documents the others)")
     ap.add_argument("--no_alt_precision", action="store_true", help="skip the secondary bf16x3 / bf16 measurements")
     a = ap.parse_args()
     global USE_MASK
@@ -317,7 +344,7 @@ def main():
     # `value` above is always the --precision mode (f32 by default).  Every rank takes part (collectives).
     alt = {}
     if a.precision == "f32" and not a.no_alt_precision:
-        for mode in ("bf16x3", "bf16"):
+        for mode in ("bf16x6", "bf16x3", "bf16"):
             hip_ops.set_gemm_precision(mode)
             for _ in range(2):
                 train_step(model, opt, x, a.use_teacher)
@@ -335,22 +362,31 @@ def main():
                 tt_ = torch.tensor([dt], device=device, dtype=torch.float64)
                 dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
                 dt = float(tt_.item())
-            alt[mode] = {"clip_frames_per_sec": round(world * bs * fs * 5 / dt, 1), "ms_per_step": round(dt / 5 * 1e3, 3), "loss": round(float(la.item()), 5)}
+            alt[mode] = {"clip_frames_per_sec": round(world * bs * fs * 5 / dt, 1), "ms_per_step": round(dt / 5 * 1e3, 3), "loss": round(float(la.item()), 5),
+                         "note": ALT_NOTES[mode]}
         hip_ops.set_gemm_precision("f32")
     if rank == 0:
         (dom_name, dom_tile), (cnt, flops, sec) = max(prof.items(), key=lambda kv: kv[1][2])
         all_flops = sum(v[1] for v in prof.values())
         all_sec = sum(v[2] for v in prof.values())
+        # peak the dominant kernel is priced against: dense f32 MFMA, or dense bf16 MFMA / the MFMAs it issues per product term
+        peak = {"PLANES1": BF16_MATRIX_PEAK_TFLOPS, "PLANES2": BF16_MATRIX_PEAK_TFLOPS / 3, "PLANES3": BF16_MATRIX_PEAK_TFLOPS / 6,
+                "NTbf16": BF16_MATRIX_PEAK_TFLOPS / (3 if a.precision == "bf16x3" else 1)}.get(dom_name, F32_MATRIX_PEAK_TFLOPS)
+        # HBM bytes per launch of the dominant kernel from the committed PMC pass (tools/pmc_traffic.py) - only when that pass
+        # measured THIS kernel
         traffic = None
         tpath = os.path.join(REPO, "profiles", "dominant_kernel_traffic.json")
         if os.path.isfile(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            if tj.get("kernel_label", "gemm_nt_fast_kernel<64x128>") in kernel_label(dom_name, dom_tile):
+                traffic = tj.get("hbm_bytes_per_launch")
         sk_rate, sk_gbs = sinkhorn_rate(device) if world == 1 else (None, None)
         out = {
             "metric": "clip-frames/sec", "value": round(world * bs * fs * a.steps / elapsed, 2), "unit": "clip-frames/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": ("C2: " if (a.architecture, bs, fs, K) == ("dino-s16", 32, 4, 200) else "") +
+            "config": {"workload": ("C2: " if (a.architecture, bs, fs, K) == ("dino-s16", 32, 4, 200) else
+                                    "C4 (per-GPU share): " if (a.architecture, bs, fs, K) == ("dino-b16", 16, 8, 400) else "") +
                                    f"{a.architecture} full TimeT training step (fwd+bwd+AdamW), {fs}-frame 224x224 clips, {bs} clips/GPU, "
                                    f"{K} prototypes" + (", EMA teacher" if a.use_teacher else "") + (", queue" if a.use_queue else "") +
                                    (", use_mask" if a.use_mask else ""),
@@ -359,11 +395,10 @@ def main():
             "loss": round(final_loss, 5),
             # proof of what carried the exchange: RCCL ("nccl") saw this many ranks (None for the single-process run)
             "rccl": {"world_size": dist.get_world_size(), "backend": dist.get_backend()} if world > 1 else None,
-            "roofline": {"bound": "mfma",
-                         "kernel": (f"gemm_nt_fast_kernel<{TILE_NAMES[dom_tile]}> (forward nn.Linear, whole tiles)" if dom_name == "NT"
-                                    else f"gemm_f32_kernel<{TILE_NAMES[dom_tile]},{dom_name}>"), "launches_per_step": cnt,
-                         "achieved": round(flops / sec / 1e12, 2), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(flops / sec / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "precision": a.precision,
+                         "kernel": kernel_label(dom_name, dom_tile), "launches_per_step": cnt,
+                         "achieved": round(flops / sec / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(flops / sec / 1e12 / peak, 4), "traffic": traffic,
                          "avg_launch_us": round(sec / cnt * 1e6, 2),
                          "all_gemm_tflops": round(all_flops / all_sec / 1e12, 2),
                          "gemm_share_of_step": round(all_sec / (elapsed / a.steps), 3)},
@@ -372,7 +407,7 @@ def main():
                                                       "shape": "K=200 x B=6272, 10 iterations"},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fs, K)
+            out["cpu_baseline"] = cpu_baseline(fs, K, arch=a.architecture, precision=a.precision)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

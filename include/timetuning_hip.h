@@ -72,6 +72,9 @@ int tt_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, i
 /* Which tile shape the launcher picks for an M x N (x batch) product: 0 = 128x128, 1 = 64x128, 2 = 128x64,
  * 3 = 64x64 (block tile; 4 waves each).  Exposed so that profilers can attribute launches to instantiations. */
 int tt_gemm_tile_choice(int M, int N, int batch);
+/* Which kernel an fp32 tt_linear_fwd of this shape runs: bits 0-1 tile (0 128x128, 1 64x128, 2 128x64, 3 64x64), bit 8 set = the
+ * lean whole-tile instance (gemm_nt_fast_kernel), clear = the general kernel.  For profilers' labels only. */
+int tt_linear_fwd_route(int M, int N, int K);
 
 /* ---- k1b: interpolate_pos_encoding for inputs whose token grid differs from the stored one
  *      (dino_vision_transformer.py:214-234): bicubic resampling of the patch position table, as
@@ -146,6 +149,28 @@ size_t tt_sinkhorn_workspace_bytes(int B_total, int K);
  *   same workspace. */
 int tt_sinkhorn_from_q(const float* Q, int transposed, float* q_out, int B_total, int K, int row0, int rows_out, int iters,
                        void* workspace, size_t workspace_bytes, tt_stream_t stream);
+
+/* ---- bf16-plane operands: BASELINE config C4's "MFMA bf16 path" (planes = 1) and the fp32-accurate split mode (planes = 3)
+ *   of the forward nn.Linear sites (dino_vision_transformer.py:94-103,115-130).  A tensor "in P planes" is P bf16 arrays of
+ *   the tensor's shape, `plane_stride` ELEMENTS apart, with value = plane0 + plane1 + plane2 (plane0 = bf16(x), plane1 =
+ *   bf16(x - plane0), plane2 = bf16(x - plane0 - plane1): 8 / 16 / 24 significant bits).  Producers write planes, consumers
+ *   read planes: nothing is converted on the GEMM's own path.
+ *   tt_split_planes          fp32 [n] -> planes (weights; activations produced by fp32 kernels).  n % 8 == 0.
+ *   tt_layernorm_fwd_planes  tt_layernorm_fwd with the result in planes (optional mean / rstd as there).
+ *   tt_linear_fwd_planes     y = act(x @ w^T + bias) (+ residual): x [M,K] and w [N,K] in `planes` planes each; products
+ *                            x_i w_j with i + j <= planes + 1 (1 / 3 / 6 bf16 MFMAs per term), fp32 accumulate.  Outputs, any of:
+ *                            y fp32 [M,N], pre_out fp32 (pre-activation), y_planes (y_nplanes planes of y).  residual fp32 may
+ *                            alias y.  N % 64 == 0, K % 64 == 0; any M.
+ *   tt_attention_fwd_bf16    softmax(q k^T * scale) v on bf16 qkv [F,N,3*H*64] -> bf16 out [F,N,H*64]; fp32 scores and
+ *                            accumulation, N <= 256 (dino_vision_transformer.py:122-129). */
+int tt_split_planes(const float* src, void* dst_planes, long long plane_stride, int planes, long long n, tt_stream_t stream);
+int tt_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, void* y_planes, long long plane_stride,
+                            int planes, float* mean, float* rstd, int rows, int D, float eps, int skip_group,
+                            tt_stream_t stream);
+int tt_linear_fwd_planes(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes,
+                         const float* bias, const float* residual, float* y, float* pre_out, void* y_planes,
+                         long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, tt_stream_t stream);
+int tt_attention_fwd_bf16(const void* qkv, void* out, int F, int N, int H, int head_dim, float scale, tt_stream_t stream);
 
 /* ---- k14: temporal label propagation (time_tuning.py:143-154 -> mask_propagation.py:396-496)
  *   xn   [fs, bs, n, D]  L2-normalised backbone tokens, time-major (frame t of clip b at [t][b])

@@ -37,6 +37,18 @@ def golden():
 
 def rel_err(a, b):
     """max |a-b| / max |b| - the "relative fp32" measure used throughout (north_star: <= 1e-3)."""
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    # (features returned by FeatureExtractor.forward carry grad, as in the reference: detach before converting)
+    a = np.asarray(a.detach().cpu() if hasattr(a, "detach") else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if hasattr(b, "detach") else b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.fixture(params=["f32", "bf16x6"])
+def accurate_precision(request):
+    """The two arithmetic modes that must meet the fp32 contract: exact f32 MFMA (default) and the fp32-accurate split mode
+    (three bf16 planes, six products).  Tests that take this fixture run at their UNCHANGED fp32 tolerances in both."""
+    from timetuning_amd import hip_ops
+
+    hip_ops.set_gemm_precision(request.param)
+    yield request.param
+    hip_ops.set_gemm_precision("f32")

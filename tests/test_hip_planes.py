@@ -1,0 +1,108 @@
+"""Per-op parity of the bf16-plane kernels (gemm_planes.hip, attention_bf16.hip, layernorm_fwd_planes) through the C ABI.
+
+planes = 1 is BASELINE C4's bf16 path: checked against an fp64 product of the SAME bf16-rounded operands (so only the fp32
+accumulation differs) and, loosely, against the fp32 operands.  planes = 3 is the fp32-accurate split mode: held to the SAME
+2e-5 bound as the f32-MFMA kernels (tests/test_hip_ops.py) against fp64 of the fp32 operands."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from timetuning_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL_F32 = 2e-5
+
+
+def rnd(name, *shape, scale=1.0):
+    return torch.from_numpy(synth.normal("planes." + name, shape, scale))
+
+
+def planes_to_f64(p):
+    return p.double().sum(0)
+
+
+@pytest.mark.parametrize("planes", [1, 2, 3])
+def test_split_planes(planes):
+    from timetuning_amd import hip_ops as ops
+
+    x = rnd("split", 64, 200, scale=3.0)
+    x[0, :4] = torch.tensor([0.0, 1e-30, -65504.0, 3.0e38])
+    p = ops.split_planes(x.cuda(), planes).cpu()
+    assert p.shape == (planes, 64, 200) and p.dtype == torch.bfloat16
+    assert torch.equal(p[0], x.to(torch.bfloat16))
+    err = (planes_to_f64(p) - x.double()).abs() / x.double().abs().clamp_min(1e-20)
+    bound = {1: 2.0 ** -8, 2: 2.0 ** -16, 3: 0.0}[planes]
+    assert err[:, 4:].max().item() <= bound and err[0, :4].max().item() <= max(bound, 2.0 ** -16)   # (1e-30: bf16 subnormal range)
+
+
+@pytest.mark.parametrize("planes", [1, 3])
+def test_layernorm_planes(planes):
+    from timetuning_amd import hip_ops as ops
+
+    x, g, b = rnd("ln.x", 3, 197, 384, scale=2.0), 1.0 + 0.1 * rnd("ln.g", 384), 0.1 * rnd("ln.b", 384)
+    ref = F.layer_norm(x.double(), (384,), g.double(), b.double(), 1e-6)
+    y, mean, rstd = ops.layernorm_fwd_planes(x.cuda(), g.cuda(), b.cuda(), planes, save_stats=True)
+    assert y.shape == (planes, 591, 384)
+    assert rel_err(planes_to_f64(y.cpu()).view(3, 197, 384), ref) < (TOL_F32 if planes == 3 else 5e-3)
+    assert rel_err(mean.cpu(), x.double().mean(-1).view(-1)) < 1e-5
+    yd = ops.layernorm_fwd_planes(x.cuda(), g.cuda(), b.cuda(), planes, drop_first_token=True)
+    assert yd.shape == (planes, 3 * 196, 384)
+    assert rel_err(planes_to_f64(yd.cpu()).view(3, 196, 384), ref[:, 1:]) < (TOL_F32 if planes == 3 else 5e-3)
+
+
+@pytest.mark.parametrize("planes", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(788, 384, 384), (1000, 1152, 384), (8192, 1536, 384), (394, 64, 1536), (2048, 768, 3072)])
+def test_linear_planes(planes, M, N, K):
+    from timetuning_amd import hip_ops as ops
+
+    x, w, b = rnd(f"lin.x{M}", M, K), rnd(f"lin.w{N}.{K}", N, K, scale=0.05), rnd(f"lin.b{N}", N, scale=0.1)
+    xp, wp = ops.split_planes(x.cuda(), planes), ops.split_planes(w.cuda(), planes)
+    o = ops.linear_fwd_planes(xp, wp, b.cuda())
+    ref32 = x.double() @ w.double().t() + b.double()
+    if planes == 3:
+        assert rel_err(o["y"].cpu(), ref32) < TOL_F32
+    elif planes == 2:
+        assert rel_err(o["y"].cpu(), ref32) < 2e-4
+    else:
+        ref_bf = planes_to_f64(xp.cpu()) @ planes_to_f64(wp.cpu()).t() + b.double()   # the same rounded operands, exact products
+        assert rel_err(o["y"].cpu(), ref_bf) < TOL_F32
+        assert rel_err(o["y"].cpu(), ref32) < 2e-2
+
+
+@pytest.mark.parametrize("planes", [1, 3])
+def test_linear_planes_epilogues(planes):
+    """bias + GELU + pre-activation + plane output; residual add in place; plane-only output."""
+    from timetuning_amd import hip_ops as ops
+
+    M, N, K = 591, 256, 128
+    x, w, b, res = rnd("epi.x", M, K), rnd("epi.w", N, K, scale=0.1), rnd("epi.b", N, scale=0.1), rnd("epi.r", M, N)
+    xp, wp = ops.split_planes(x.cuda(), planes), ops.split_planes(w.cuda(), planes)
+    pre_ref = planes_to_f64(xp.cpu()) @ planes_to_f64(wp.cpu()).t() + b.double()
+    tol = TOL_F32 if planes == 3 else 2e-5
+    o = ops.linear_fwd_planes(xp, wp, b.cuda(), act=1, out_planes=planes, save_pre=True)
+    assert rel_err(o["pre"].cpu(), pre_ref) < tol
+    assert rel_err(o["y"].cpu(), F.gelu(pre_ref)) < tol
+    got = planes_to_f64(o["planes"].cpu())
+    assert rel_err(got, o["y"].cpu().double()) <= (0.0 if planes == 3 else 2.0 ** -8)   # the planes ARE the fp32 result, split
+    rc = res.clone().cuda()
+    o2 = ops.linear_fwd_planes(xp, wp, b.cuda(), residual=rc, out=rc)
+    assert o2["y"].data_ptr() == rc.data_ptr() and rel_err(rc.cpu(), pre_ref + res.double()) < tol
+    o3 = ops.linear_fwd_planes(xp, wp, None, out_f32=False, out_planes=planes)
+    assert o3["y"] is None and rel_err(planes_to_f64(o3["planes"].cpu()), pre_ref - b.double()) < (tol if planes == 3 else 5e-3)
+
+
+@pytest.mark.parametrize("Fr,N,H", [(3, 197, 6), (2, 50, 2), (1, 256, 12), (2, 225, 3), (5, 17, 1)])
+def test_attention_bf16(Fr, N, H):
+    from timetuning_amd import hip_ops as ops
+
+    D = 64 * H
+    qkv = (rnd(f"att.{Fr}.{N}.{H}", Fr, N, 3 * D) * 0.7).to(torch.bfloat16)
+    out = ops.attention_fwd_bf16(qkv.cuda(), H).cpu()
+    q, k, v = qkv.double().view(Fr, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    p = torch.softmax(q @ k.transpose(-1, -2) * 64 ** -0.5, dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(Fr, N, D)
+    # P and the output are rounded to bf16 (8 significant bits each)
+    assert rel_err(out.double(), ref) < 1.5e-2
+    assert (out.double() - ref).abs().mean().item() < 2e-3 * ref.abs().mean().item() + 1e-4

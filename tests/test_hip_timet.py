@@ -38,7 +38,7 @@ def test_state_dict_keys_match_reference(golden):
     assert set(model.state_dict().keys()) == {str(k) for k in g["state_dict_keys"]}
 
 
-def test_extractor_tiny(golden):
+def test_extractor_tiny(golden, accurate_precision):
     g = golden("timet_tiny")
     model, _ = _build(g)
     bs, fs = int(g["cfg"][0]), int(g["cfg"][1])
@@ -77,7 +77,7 @@ def test_extractor_other_input_sizes(golden, tag):
         fe(torch.zeros(1, 3, 100, 224, device="cuda"))    # not a multiple of the patch size
 
 
-def test_loss_internals_tiny(golden):
+def test_loss_internals_tiny(golden, accurate_precision):
     g, t = golden("aux_tiny"), golden("timet_tiny")
     model, _ = _build(t)
     bs, fs, K = [int(v) for v in g["cfg"]]
@@ -142,11 +142,11 @@ def _run_steps(g, teacher, queue):
             assert abs(model.queue.double().sum().item() - float(g[f"queue_sum{s}"])) < 1e-2
 
 
-def test_training_steps_tiny(golden):
+def test_training_steps_tiny(golden, accurate_precision):
     _run_steps(golden("timet_tiny"), False, 0)
 
 
-def test_training_steps_tiny_teacher_queue(golden):
+def test_training_steps_tiny_teacher_queue(golden, accurate_precision):
     _run_steps(golden("timet_tiny_tq"), True, 40)
 
 
@@ -155,11 +155,11 @@ def test_training_steps_tiny_use_mask(golden):
     _run_steps(golden("timet_tiny_mask"), False, 0)
 
 
-def test_training_steps_tiny_use_mask_teacher_queue(golden):
+def test_training_steps_tiny_use_mask_teacher_queue(golden, accurate_precision):
     _run_steps(golden("timet_tiny_mask_tq"), True, 40)
 
 
-def test_full_size_c1(golden):
+def test_full_size_c1(golden, accurate_precision):
     """ViT-S/16, bs 2 x 2 frames, K=50 (BASELINE C1) against the reference's own numbers."""
     g = golden("timet_c1")
     model, opt = _build(g)
@@ -213,7 +213,7 @@ def test_c2_size_properties():
 
 
 @pytest.mark.timeout(900)
-def test_c2_full_step_vs_oracle():
+def test_c2_full_step_vs_oracle(accurate_precision):
     """BASELINE C2 at FULL size (ViT-S/16, 32 clips x 4 frames, 200 prototypes): the whole training step against the CPU oracle
     (one pass per frame, ``faithful=False``: same arithmetic as the reference's four) - Sinkhorn assignment of all 6272 source
     patches, hard labels, loss, and the gradients of the prototypes, a head weight and a blocks.10 weight."""
@@ -243,7 +243,7 @@ def test_c2_full_step_vs_oracle():
 
 
 @pytest.mark.timeout(900)
-def test_c3_per_rank_workload_vs_oracle():
+def test_c3_per_rank_workload_vs_oracle(accurate_precision):
     """BASELINE C3's per-rank work at ViT-S/16 size: EMA teacher + a pre-filled 2048-row queue (16384 // 8 ranks,
     time_tuning.py:618) + 200 prototypes, TWO optimizer steps (so the teacher used by step 2 is an EMA product and the queue has
     been shifted once) against the oracle: assignment, labels, loss, gradients, updated parameters, teacher and queue."""
@@ -634,7 +634,7 @@ def test_c4_shape_in_bf16_mode():
         of, _ = om.feature_extractor(x.view(bs * fs, 3, 224, 224), faithful=False)
         oloss = om.get_loss(x, faithful=False)
     try:
-        for mode, ftol, ltol in (("bf16x3", 1e-3, 2e-3), ("bf16", 8e-2, 0.15)):
+        for mode, ftol, ltol in (("bf16x6", 1e-4, 2e-4), ("bf16x3", 1e-3, 2e-3), ("bf16", 8e-2, 0.15)):
             hip_ops.set_gemm_precision(mode)
             f, _ = model.feature_extractor(x.view(bs * fs, 3, 224, 224).cuda())
             assert rel_err(f.cpu(), of) < ftol, mode

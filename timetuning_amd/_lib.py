@@ -41,6 +41,7 @@ SIGNATURES = {
     "tt_colsum": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_gemm_f32": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_ll, c_ll, c_ll, c_vp]),
     "tt_gemm_tile_choice": (c_i, [c_i, c_i, c_i]),
+    "tt_linear_fwd_route": (c_i, [c_i, c_i, c_i]),
     "tt_set_gemm_precision": (c_i, [c_i]),
     "tt_get_gemm_precision": (c_i, []),
     "tt_patch_embed_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
@@ -48,6 +49,10 @@ SIGNATURES = {
     "tt_layernorm_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_layernorm_bwd_workspace_bytes": (c_sz, [c_i, c_i]),
     "tt_attention_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp]),
+    "tt_split_planes": (c_i, [c_vp, c_vp, c_ll, c_i, c_ll, c_vp]),
+    "tt_layernorm_fwd_planes": (c_i, [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_vp, c_vp, c_i, c_i, c_f, c_i, c_vp]),
+    "tt_linear_fwd_planes": (c_i, [c_vp, c_ll, c_vp, c_ll, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "tt_attention_fwd_bf16": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp]),
     "tt_attention_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
     "tt_attention_bwd_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "tt_l2norm_fwd": (c_i, [c_vp, c_i, c_vp, c_vp, c_i, c_i, c_vp]),

@@ -447,6 +447,18 @@ int launch_colsum_fold(const float* partial, float* out, int chunks, int N, hipS
 
 extern "C" int tt_gemm_tile_choice(int M, int N, int batch) { return tt::gemm_tile_choice(M, N, batch); }
 
+// Which kernel an fp32 tt_linear_fwd of this shape runs (16-byte aligned operands assumed): bits 0-1 = tile
+// (0: 128x128, 1: 64x128, 2: 128x64, 3: 64x64), bit 8 set = the lean whole-tile instance gemm_nt_fast_kernel, clear = the
+// general bounds-checked gemm_f32_kernel.  Mirrors try_launch_gemm_nt_fast; profilers label launches with it.
+extern "C" int tt_linear_fwd_route(int M, int N, int K) {
+  const int tile = tt::gemm_tile_choice(M, N, 1);
+  if (K % 16 != 0 || K < 16) return tile;
+  const int bm = (tile == 0 || tile == 2) ? 128 : 64, bn = (tile == 0 || tile == 1) ? 128 : 64;
+  if (M % bm == 0 && N % bn == 0) return tile | 256;
+  if (M % 64 == 0 && N % 64 == 0) return 3 | 256;
+  return tile;
+}
+
 extern "C" int tt_set_gemm_precision(int mode) {
   if (mode < 0 || mode > 2) {
     tt::set_error("set_gemm_precision: mode must be 0 (f32), 1 (bf16x3) or 2 (bf16), got %d", mode);

@@ -1,0 +1,306 @@
+// bf16-plane GEMM for the forward nn.Linear sites (dino_vision_transformer.py:94-103,115-130; models.py:915-926):
+//     y = act(x @ w^T + bias) (+ residual)
+// with BOTH operands already resident in HBM as P planes of bf16 ("pre-split" by whoever produced them):
+//
+//   P = 1   plain bf16 operands: BASELINE config C4's "MFMA bf16 path" - bf16 activations and weights in HBM, fp32 accumulate.
+//   P = 2   x = x1 + x2 (16 significant bits), products x1w1 + x1w2 + x2w1.
+//   P = 3   x = x1 + x2 + x3 EXACTLY (3 x 8 = 24 significant bits = fp32), the six products with i + j <= 4; the dropped
+//           terms are <= 2^-24 relative, i.e. fp32-level accuracy at 6 bf16 MFMAs per product term (nominal peak = bf16 / 6).
+//
+// Unlike gemm_nt_bf16.hip (fp32 in HBM, converted while staged: HBM- and VALU-bound) nothing is converted here: a slab goes
+// HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write) and a fragment is one ds_read_b128.
+//
+// LDS image per plane and operand: [row][BK bf16] rows of BK*2 bytes, 16-byte chunks XOR-swizzled by the row so that the
+// 16 lanes a ds_read_b128 services together (lanes {0-3,12-15,20-27}, ... = rows with distinct (row / W) & (C-1), W = rows
+// per 256 B, C = chunks per row) hit 16 distinct 16-byte slots of the 64 banks.  The LDS-DMA destination is lane-linear (M0
+// base + 16 * lane), so the swizzle is applied to the per-lane SOURCE address: LDS slot s of row r receives chunk s ^ f(r).
+// v_mfma_f32_32x32x16_bf16: lane l (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j], j = 0..7 = chunk 2 ks + h of its row.
+//
+// Tile (64 WM) x (64 WN), 4 waves as 2 x 2, double-buffered LDS, ONE barrier per slab: the DMA of slab t+1 is issued before
+// the MFMAs of slab t and retired by the barrier's vmcnt(0).  Rows beyond M are clamped on load and masked on store.
+// Epilogue through LDS (8 columns per thread): bias, exact GELU, residual, and any of: fp32 y, fp32 pre-activation, bf16 planes
+// of y (so the consumer finds its operand pre-split).
+#include "common.hpp"
+
+namespace tt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+struct PlaneArgs {
+  const __bf16* A;        // [P][M][K]
+  const __bf16* B;        // [P][N][K]
+  long long a_stride, b_stride;  // plane strides in elements
+  int M, N, K;
+  const float* bias;      // [N] or null
+  const float* residual;  // [M][N] fp32 or null (may alias C)
+  float* C;               // [M][N] fp32 or null
+  float* pre_out;         // [M][N] fp32 or null
+  __bf16* Cp;             // [PO][M][N] bf16 planes or null
+  long long c_stride;
+  int po;                 // number of output planes (0..3)
+  int act;                // 1 = GELU
+};
+
+// x -> up to three bf16 planes with x = p0 + p1 + p2 (exact when 3 planes are taken and no exponent underflow)
+__device__ __forceinline__ void split3(float v, __bf16& p0, __bf16& p1, __bf16& p2) {
+  p0 = (__bf16)v;
+  const float r1 = v - (float)p0;
+  p1 = (__bf16)r1;
+  const float r2 = r1 - (float)p1;
+  p2 = (__bf16)r2;
+}
+
+template <int P, int BK, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int ROWB = BK * 2;              // bytes per LDS row
+  constexpr int CPR = ROWB / 16;            // 16-byte chunks per row
+  constexpr int WIN = 256 / ROWB;           // rows per 256-byte bank window
+  constexpr int RPI = 64 / CPR;             // rows one LDS-DMA wave-instruction fills
+  constexpr int A_PL = BM * ROWB, B_PL = BN * ROWB;
+  constexpr int BUF = P * (A_PL + B_PL);
+  constexpr int CH = 32 * WM, LDCS = BN + 4;
+  constexpr int EPI = CH * LDCS * 4;
+  constexpr int LDS_BYTES = 2 * BUF > EPI ? 2 * BUF : EPI;
+  static_assert(LDS_BYTES <= 65536, "LDS budget");
+  static_assert(BM % RPI == 0 && BN % RPI == 0, "whole DMA pieces");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  const int ntn = g.N / BN, ntm = (g.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const int K = g.K;
+
+  // ---- LDS-DMA: piece i (RPI rows) of an operand plane; lane -> (row, slot), source chunk = slot ^ f(row)
+  const int l_row = lane / CPR, l_slot = lane % CPR;
+  auto issue = [&](int kt, int buf) {
+    unsigned char* base = smem + buf * BUF;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+#pragma unroll
+      for (int i = 0; i < (BM / RPI + 3) / 4; ++i) {
+        const int piece = wave + 4 * i, row = piece * RPI + l_row;
+        if ((BM / RPI) % 4 != 0 && piece >= BM / RPI) break;   // wave-uniform
+        const int chunk = l_slot ^ ((row / WIN) & (CPR - 1));
+        int grow = m0 + row;
+        grow = grow < g.M ? grow : g.M - 1;
+        const __bf16* src = g.A + p * g.a_stride + (size_t)grow * K + kt * BK + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                         (void __attribute__((address_space(3)))*)(base + p * A_PL + piece * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < (BN / RPI + 3) / 4; ++i) {
+        const int piece = wave + 4 * i, row = piece * RPI + l_row;
+        if ((BN / RPI) % 4 != 0 && piece >= BN / RPI) break;   // wave-uniform
+        const int chunk = l_slot ^ ((row / WIN) & (CPR - 1));
+        const __bf16* src = g.B + p * g.b_stride + (size_t)(n0 + row) * K + kt * BK + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                         (void __attribute__((address_space(3)))*)(base + P * A_PL + p * B_PL + piece * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addressing: row offsets are compile-time multiples of 32 rows, the swizzle term depends on (row / WIN) only
+  int a_off[WM], b_off[WN], a_sw[WM], b_sw[WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int row = wm * (32 * WM) + i * 32 + r;
+    a_off[i] = row * ROWB;
+    a_sw[i] = (row / WIN) & (CPR - 1);
+  }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int row = wn * (32 * WN) + j * 32 + r;
+    b_off[j] = row * ROWB;
+    b_sw[j] = (row / WIN) & (CPR - 1);
+  }
+
+  const int nk = K / BK;
+  issue(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    const unsigned char* base = smem + buf * BUF;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int chunk = 2 * ks + h;
+      bf16x8 a[P][WM], b[P][WN];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[p][i] = *reinterpret_cast<const bf16x8*>(base + p * A_PL + a_off[i] + ((chunk ^ a_sw[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          b[p][j] = *reinterpret_cast<const bf16x8*>(base + P * A_PL + p * B_PL + b_off[j] + ((chunk ^ b_sw[j]) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int s = P - 1; s >= 0; --s)        // plane-index sum s = pa + pw: small terms first
+#pragma unroll
+            for (int pa = 0; pa <= s; ++pa)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[s - pa][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // every wave has read this slab; the barrier's vmcnt(0) retires the DMA of the next one
+  }
+
+  // ---- epilogue through LDS, one wave-row (32 WM tile rows) at a time; a thread owns 8 consecutive columns
+  float* Cs = reinterpret_cast<float*>(smem);
+  constexpr int TPR = BN / 8, RPP = 256 / TPR;
+  const int c8 = (tid % TPR) * 8;
+  const int n = n0 + c8;
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = g.bias ? g.bias[n + e] : 0.f;
+#pragma unroll
+  for (int wmi = 0; wmi < 2; ++wmi) {
+    if (wm == wmi) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            Cs[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDCS + wn * (32 * WN) + j * 32 + r] = acc[i][j][e];
+    }
+    __syncthreads();
+    for (int rr = tid / TPR; rr < CH; rr += RPP) {
+      const int m = m0 + wmi * CH + rr;
+      if (m < g.M) {
+        const size_t off = (size_t)m * g.N + n;
+        float v[8];
+        *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(Cs + rr * LDCS + c8);
+        *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(Cs + rr * LDCS + c8 + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+        if (g.pre_out) {
+          *reinterpret_cast<float4*>(g.pre_out + off) = *reinterpret_cast<const float4*>(v);
+          *reinterpret_cast<float4*>(g.pre_out + off + 4) = *reinterpret_cast<const float4*>(v + 4);
+        }
+        if (g.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        }
+        if (g.residual) {
+          float rs[8];
+          *reinterpret_cast<float4*>(rs) = *reinterpret_cast<const float4*>(g.residual + off);
+          *reinterpret_cast<float4*>(rs + 4) = *reinterpret_cast<const float4*>(g.residual + off + 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rs[e];
+        }
+        if (g.C) {
+          *reinterpret_cast<float4*>(g.C + off) = *reinterpret_cast<const float4*>(v);
+          *reinterpret_cast<float4*>(g.C + off + 4) = *reinterpret_cast<const float4*>(v + 4);
+        }
+        if (g.po > 0) {
+          bf16x8 q0, q1, q2;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            __bf16 p0, p1, p2;
+            split3(v[e], p0, p1, p2);
+            q0[e] = p0; q1[e] = p1; q2[e] = p2;
+          }
+          *reinterpret_cast<bf16x8*>(g.Cp + off) = q0;
+          if (g.po > 1) *reinterpret_cast<bf16x8*>(g.Cp + g.c_stride + off) = q1;
+          if (g.po > 2) *reinterpret_cast<bf16x8*>(g.Cp + 2 * g.c_stride + off) = q2;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int P, int BK, int WM, int WN>
+static int launch_planes(const PlaneArgs& g, hipStream_t s) {
+  const int tiles = ((g.M + 64 * WM - 1) / (64 * WM)) * (g.N / (64 * WN));
+  hipLaunchKernelGGL((gemm_planes_kernel<P, BK, WM, WN>), dim3(tiles), dim3(256), 0, s, g);
+  TT_CHECK_LAUNCH("gemm_planes");
+  return TT_OK;
+}
+
+// ---- f32 -> bf16 planes (weights once per change, activations whose producer is an fp32 kernel)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long stride, int planes,
+                                                           long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    float v[8];
+    *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(src + 8 * i);
+    *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(src + 8 * i + 4);
+    bf16x8 q0, q1, q2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      __bf16 p0, p1, p2;
+      split3(v[e], p0, p1, p2);
+      q0[e] = p0; q1[e] = p1; q2[e] = p2;
+    }
+    *reinterpret_cast<bf16x8*>(dst + 8 * i) = q0;
+    if (planes > 1) *reinterpret_cast<bf16x8*>(dst + stride + 8 * i) = q1;
+    if (planes > 2) *reinterpret_cast<bf16x8*>(dst + 2 * stride + 8 * i) = q2;
+  }
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" int tt_split_planes(const float* src, void* dst_planes, long long plane_stride, int planes, long long n, tt_stream_t stream) {
+  TT_REQUIRE(src && dst_planes && n > 0 && planes >= 1 && planes <= 3, "split_planes: bad arguments");
+  TT_REQUIRE(n % 8 == 0 && plane_stride % 8 == 0 && aligned16(src) && aligned16(dst_planes), "split_planes: n and the plane stride must be "
+             "multiples of 8 elements and the buffers 16-byte aligned");
+  long long blocks = (n / 8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, static_cast<__bf16*>(dst_planes),
+                     plane_stride, planes, n / 8);
+  TT_CHECK_LAUNCH("split_planes");
+  return TT_OK;
+}
+
+extern "C" int tt_linear_fwd_planes(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes,
+                                    const float* bias, const float* residual, float* y, float* pre_out, void* y_planes,
+                                    long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, tt_stream_t stream) {
+  TT_REQUIRE(x_planes && w_planes && (y || y_planes), "linear_fwd_planes: null operand / no output");
+  TT_REQUIRE(planes >= 1 && planes <= 3 && y_nplanes >= 0 && y_nplanes <= 3 && (y_nplanes == 0) == (y_planes == nullptr),
+             "linear_fwd_planes: planes must be 1..3 and y_nplanes 0..3 (0 iff y_planes is null)");
+  TT_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "linear_fwd_planes: need N %% 64 == 0 and K %% 64 == 0 (got N=%d K=%d)", N, K);
+  auto ok16 = [](const void* p) { return p == nullptr || aligned16(p); };
+  TT_REQUIRE(aligned16(x_planes) && aligned16(w_planes) && ok16(y) && ok16(pre_out) && ok16(y_planes) && ok16(residual) && ok16(bias),
+             "linear_fwd_planes: buffers must be 16-byte aligned");
+  TT_REQUIRE(x_plane_stride % 8 == 0 && w_plane_stride % 8 == 0 && y_plane_stride % 8 == 0, "linear_fwd_planes: plane strides must be multiples of 8");
+  PlaneArgs g{static_cast<const __bf16*>(x_planes), static_cast<const __bf16*>(w_planes), x_plane_stride, w_plane_stride, M, N, K, bias, residual, y,
+              pre_out, static_cast<__bf16*>(y_planes), y_plane_stride, y_nplanes, act};
+  hipStream_t s = as_stream(stream);
+  // tile: 128 x 128 when the grid still fills the chip more than twice over, else 64-row / 64-column tiles (ViT-S/16's N = 384
+  // products: 1182 instead of 591 workgroups)
+  const long long t128 = (long long)((M + 127) / 128) * (N / 128);
+  const bool big = (N % 128 == 0) && t128 >= 3 * 256;
+  const bool wide = (N % 128 == 0);
+  switch (planes) {
+    case 1:
+      if (big) return launch_planes<1, 64, 2, 2>(g, s);
+      if (wide) return launch_planes<1, 64, 1, 2>(g, s);
+      return launch_planes<1, 64, 1, 1>(g, s);
+    case 2:
+      if (big) return launch_planes<2, 32, 2, 2>(g, s);
+      if (wide) return launch_planes<2, 32, 1, 2>(g, s);
+      return launch_planes<2, 32, 1, 1>(g, s);
+    default:
+      if (big) return launch_planes<3, 16, 2, 2>(g, s);
+      if (wide) return launch_planes<3, 16, 1, 2>(g, s);
+      return launch_planes<3, 16, 1, 1>(g, s);
+  }
+}

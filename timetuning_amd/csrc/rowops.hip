@@ -50,6 +50,56 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
+// The same with the result written as 1..3 bf16 planes (y = p0 + p1 + p2): the operand layout of gemm_planes.hip, so the
+// consuming nn.Linear finds its A operand pre-split and nothing is converted on its path.
+__global__ __launch_bounds__(256) void layernorm_fwd_planes_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, __bf16* __restrict__ y, long long stride,
+                                                                   int planes, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                   int rows, int D, float eps, int skip_group) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long long in_row = skip_group ? (long long)(row / (skip_group - 1)) * skip_group + 1 + row % (skip_group - 1) : row;
+  const float* xr = x + in_row * D;
+  float v[kMaxPerLane];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = (c < D) ? xr[c] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    const float d = (c < D) ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  __bf16* yr = y + (long long)row * D;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) {
+      const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      const __bf16 p0 = (__bf16)o;
+      yr[c] = p0;
+      if (planes > 1) {
+        const float r1 = o - (float)p0;
+        const __bf16 p1 = (__bf16)r1;
+        yr[stride + c] = p1;
+        if (planes > 2) yr[2 * stride + c] = (__bf16)(r1 - (float)p1);
+      }
+    }
+  }
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+}
+
 // Backward.  Each workgroup owns a contiguous run of rows; its 4 waves walk them, keep per-column partial
 // sums of dgamma/dbeta in registers and combine them through LDS into partial[wg][2][D]; a column-sum
 // pass over the partials finishes (deterministic: no atomics).
@@ -294,6 +344,18 @@ extern "C" int tt_layernorm_fwd(const float* x, const float* gamma, const float*
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta, y, mean, rstd,
                      rows, D, eps, skip_group);
   TT_CHECK_LAUNCH("layernorm_fwd");
+  return TT_OK;
+}
+
+extern "C" int tt_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, void* y_planes, long long plane_stride,
+                                       int planes, float* mean, float* rstd, int rows, int D, float eps, int skip_group,
+                                       tt_stream_t stream) {
+  TT_REQUIRE(skip_group == 0 || (skip_group >= 2 && rows % (skip_group - 1) == 0), "layernorm_fwd_planes: rows must be a multiple of skip_group - 1");
+  TT_REQUIRE(x && gamma && beta && y_planes && planes >= 1 && planes <= 3, "layernorm_fwd_planes: null pointer / planes not in 1..3");
+  TT_REQUIRE(rows > 0 && D > 0 && D <= 64 * kMaxPerLane, "layernorm_fwd_planes: need 0 < D <= %d (got %d)", 64 * kMaxPerLane, D);
+  hipLaunchKernelGGL(layernorm_fwd_planes_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta,
+                     static_cast<__bf16*>(y_planes), plane_stride, planes, mean, rstd, rows, D, eps, skip_group);
+  TT_CHECK_LAUNCH("layernorm_fwd_planes");
   return TT_OK;
 }
 

@@ -30,12 +30,58 @@ f32 = torch.float32
 # ViT blocks
 # ------------------------------------------------------------------------------------------------
 
+_WEIGHT_PLANES: Dict[int, tuple] = {}
+
+
+def weight_planes(w: torch.nn.Parameter, planes: int) -> torch.Tensor:
+    """[planes, N, K] bf16 planes of a Linear weight.  Tensors marked static (``_tt_static``: the student's frozen parameters,
+    FeatureExtractor.freeze_backbone) are split once and cached against (storage, version, planes); anything that training or the
+    EMA rewrites through raw pointers is split again on every call (a few MB per step)."""
+    if not getattr(w, "_tt_static", False):
+        return ops.split_planes(w.detach(), planes)
+    key = id(w)
+    hit = _WEIGHT_PLANES.get(key)
+    tag = (w.data_ptr(), w._version, planes)
+    if hit is None or hit[0] != tag:
+        hit = (tag, ops.split_planes(w.detach(), planes))
+        _WEIGHT_PLANES[key] = hit
+    return hit[1]
+
+
+def block_forward_planes(x: torch.Tensor, blk, num_heads: int, planes: int, aux: Optional[dict] = None) -> torch.Tensor:
+    """A block that keeps nothing, on bf16-plane operands (hip_ops.set_gemm_precision "bf16" / "bf16x6"): every Linear reads
+    planes its producer wrote (LayerNorm, the fc1 / attention epilogues) - no conversion on the GEMMs' path.  The residual
+    stream x [F,N,D] stays fp32 and is updated in place.  planes = 1: bf16 qkv and the bf16 attention kernel; planes = 3: fp32
+    qkv, the fp32 attention kernel, its output split for proj."""
+    Fr, N, D = x.shape
+    M = Fr * N
+    x2d = x.view(M, D)
+    at = blk.attn
+    h1 = ops.layernorm_fwd_planes(x, blk.norm1.weight, blk.norm1.bias, planes)
+    if planes == 1 and aux is None and N <= 256 and D // num_heads == 64:
+        qkv = ops.linear_fwd_planes(h1, weight_planes(at.qkv.weight, 1), at.qkv.bias, out_f32=False, out_planes=1)["planes"]
+        att = ops.attention_fwd_bf16(qkv.view(Fr, N, 3 * D), num_heads).view(1, M, D)
+    else:
+        qkv = ops.linear_fwd_planes(h1, weight_planes(at.qkv.weight, planes), at.qkv.bias)["y"]
+        if aux is not None:
+            aux["qkv"] = qkv.view(Fr, N, 3 * D)
+        att32, _, _ = ops.attention_fwd(qkv.view(Fr, N, 3 * D), num_heads)
+        att = ops.split_planes(att32.view(M, D), planes)
+    ops.linear_fwd_planes(att, weight_planes(at.proj.weight, planes), at.proj.bias, residual=x2d, out=x2d)
+    h2 = ops.layernorm_fwd_planes(x, blk.norm2.weight, blk.norm2.bias, planes)
+    a = ops.linear_fwd_planes(h2, weight_planes(blk.mlp.fc1.weight, planes), blk.mlp.fc1.bias, act=1, out_f32=False, out_planes=planes)["planes"]
+    ops.linear_fwd_planes(a, weight_planes(blk.mlp.fc2.weight, planes), blk.mlp.fc2.bias, residual=x2d, out=x2d)
+    return x
+
+
 def block_forward(x: torch.Tensor, blk, num_heads: int, save: Optional[dict] = None, aux: Optional[dict] = None) -> torch.Tensor:
     """One transformer block (dino_vision_transformer.py:147-153) on x [F,N,D].  With ``save`` the
     activations backward needs are kept there; otherwise the residual stream is updated in place.
     ``aux`` (a dict) receives the block's qkv activations [F,N,3D] - what the attention foreground mask reads."""
     Fr, N, D = x.shape
     M = Fr * N
+    if save is None and ops.plane_count() and D % 64 == 0:
+        return block_forward_planes(x, blk, num_heads, ops.plane_count(), aux)
     x2d = x.view(M, D)
     if save is not None:
         h1, save["mean1"], save["rstd1"] = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, save_stats=True)
@@ -90,27 +136,48 @@ def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int,
 
 
 def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None, save_blocks: Optional[Dict[int, dict]] = None,
-               last_block_probs: bool = False, last_block_aux: Optional[dict] = None, tap: Optional[dict] = None):
-    """prepare_tokens + all blocks (dino_vision_transformer.py:236-252).  Returns (tokens [F,N,D] before the final
-    norm, attention probabilities of the last block or None).  ``last_block_aux`` receives the last block's qkv.
+               last_block_probs: bool = False, last_block_aux: Optional[dict] = None, tap: Optional[dict] = None,
+               save_from_frame: int = 0):
+    """prepare_tokens + all blocks (dino_vision_transformer.py:236-252).  Returns (tokens before the final norm, attention
+    probabilities of the last block or None).  ``last_block_aux`` receives the last block's qkv.
     ``tap = {"block": i, "rows": r}`` receives under ``"x"`` a private copy of the first ``r`` frames' residual stream as it
-    ENTERS block ``i`` (``i == depth``: as it leaves the last block) - what an EMA teacher sharing blocks [0, i) continues from."""
+    ENTERS block ``i`` (``i == depth``: as it leaves the last block) - what an EMA teacher sharing blocks [0, i) continues from.
+
+    ``save_blocks`` = {block id: dict} keeps the activations of those blocks for a later ``block_backward`` - of the frames
+    [save_from_frame, F) only: a gradient reaches only the target frames (time_tuning.py:296-302), so from the first kept block
+    on the pass runs as TWO streams, frames [0, save_from_frame) that keep nothing (in place; the bf16-plane kernels when a
+    precision mode selects them) and the kept frames.  The tokens then come back as the pair (lo, hi); with
+    ``save_from_frame == 0`` (or nothing kept) as one tensor."""
     pe = vit.patch_embed.proj
     D = pe.weight.shape[0]
     x = ops.patch_embed_fwd(img, pe.weight.view(D, -1), pe.bias, vit.cls_token.view(D), vit.pos_table(img.shape[-2], img.shape[-1]),
                             vit.patch_embed.patch_size, frame_map)
     probs = None
     depth = len(vit.blocks)
+    first_saved = min(save_blocks) if save_blocks else depth
+    split = save_blocks and save_from_frame > 0
+    lo = hi = None
     for i, blk in enumerate(vit.blocks):
         if tap is not None and tap["block"] == i:
-            tap["x"] = x[: tap["rows"]].clone()
+            tap["x"] = (x if lo is None else lo)[: tap["rows"]].clone()
         sv = save_blocks.get(i) if save_blocks is not None else None
+        aux = last_block_aux if i == depth - 1 else None
+        if split and i >= first_saved:
+            if lo is None:
+                lo, hi = x[:save_from_frame], x[save_from_frame:]
+            aux_lo = {} if aux is not None else None
+            aux_hi = {} if aux is not None else None
+            lo = block_forward(lo, blk, vit.num_heads, None, aux_lo)
+            hi = block_forward(hi, blk, vit.num_heads, sv, aux_hi)
+            if aux is not None:
+                aux["qkv_lo"], aux["qkv_hi"] = aux_lo["qkv"], aux_hi["qkv"]
+            continue
         if last_block_probs and i == depth - 1:
             probs = last_block_attention(x, blk, vit.num_heads)
-        x = block_forward(x, blk, vit.num_heads, sv, last_block_aux if i == depth - 1 else None)
+        x = block_forward(x, blk, vit.num_heads, sv, aux)
     if tap is not None and tap["block"] == depth:
-        tap["x"] = x[: tap["rows"]].clone()
-    return x, probs
+        tap["x"] = (x if lo is None else lo)[: tap["rows"]].clone()
+    return (x if lo is None else (lo, hi)), probs
 
 
 def vit_blocks(vit, x: torch.Tensor, first: int, last_block_aux: Optional[dict] = None) -> torch.Tensor:

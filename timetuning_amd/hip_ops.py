@@ -38,20 +38,34 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
-_PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
+# name -> (mode of the C-side switch for tt_linear_fwd, bf16 planes used by the launch sequences for blocks that keep nothing)
+_PRECISIONS = {"f32": (0, 0), "bf16x3": (1, 0), "bf16": (2, 1), "bf16x6": (0, 3)}
+_precision = "f32"
 
 
 def set_gemm_precision(mode: str) -> None:
-    """Arithmetic of the forward nn.Linear products: "f32" (default, exact), "bf16x3" (split-bf16, ~2^-16 per product) or
-    "bf16" (BASELINE C4's MFMA bf16 path).  Process-wide; see tt_set_gemm_precision in include/timetuning_hip.h."""
+    """Arithmetic of the forward nn.Linear products.  Process-wide.
+    "f32"     (default) exact fp32 MFMA - every headline / parity number.
+    "bf16x6"  fp32-ACCURATE split mode: operands pre-split by their producers into three bf16 planes (24 significant bits), six
+              bf16 MFMAs per product term (gemm_planes.hip).  Applies to the blocks that keep no activations (frozen blocks,
+              teacher, the non-target frames of the trainable blocks); everything with a backward stays exact fp32.
+    "bf16"    BASELINE C4's MFMA bf16 path: the same blocks run on bf16 activations and weights in HBM (one plane, bf16
+              attention); the blocks that keep activations convert fp32 operands while staging (gemm_nt_bf16.hip).
+    "bf16x3"  two-plane split (~2^-16 per product) converted while staging; fp32 in HBM."""
+    global _precision
     if mode not in _PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
-    _lib.check(_lib.load().tt_set_gemm_precision(_PRECISIONS[mode]), "tt_set_gemm_precision")
+    _lib.check(_lib.load().tt_set_gemm_precision(_PRECISIONS[mode][0]), "tt_set_gemm_precision")
+    _precision = mode
 
 
 def get_gemm_precision() -> str:
-    v = _lib.load().tt_get_gemm_precision()
-    return {n: k for k, n in _PRECISIONS.items()}[v]
+    return _precision
+
+
+def plane_count() -> int:
+    """bf16 planes the launch sequences use for blocks that keep no activations (0 = fp32 operands)."""
+    return _PRECISIONS[_precision][1]
 
 
 # bench.py sets PROFILE to a list to get (layout, tile_choice, flops, start_event, end_event) per GEMM launch,
@@ -68,11 +82,21 @@ def _prof_begin():
 
 
 def _prof_end(e0, name: str, M: int, N: int, K: int, batch: int = 1):
+    """name "NT" = a forward Linear: booked as "NT" only when the lean whole-tile kernel really ran it (tt_linear_fwd_route),
+    as "NTgen" when the general kernel did, as "NTbf16" in the on-the-fly bf16 modes."""
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.append((name, _lib.load().tt_gemm_tile_choice(M, N, batch), 2.0 * M * N * K * batch, e0, e1))
+    lib = _lib.load()
+    tile = lib.tt_gemm_tile_choice(M, N, batch)
+    if name == "NT":
+        if _PRECISIONS[_precision][0] != 0:
+            name = "NTbf16"
+        else:
+            route = lib.tt_linear_fwd_route(M, N, K)
+            tile, name = route & 3, ("NT" if route & 256 else "NTgen")
+    PROFILE.append((name, tile, 2.0 * M * N * K * batch, e0, e1))
 
 
 # ---- Linear ------------------------------------------------------------------------------------
@@ -623,3 +647,70 @@ def count_mismatch(a, b) -> int:
     out = torch.empty((1,), dtype=torch.int64, device=a.device)
     _lib.check(lib.tt_count_mismatch(_p(a), _p(b), a.numel(), _p(out), _stream()), "tt_count_mismatch")
     return int(out.item())
+
+
+# ---- bf16-plane operands (include/timetuning_hip.h: "bf16-plane operands") ------------------------------------------------
+bf16 = torch.bfloat16
+
+
+def split_planes(x, planes: int, out=None):
+    """fp32 tensor -> [planes, *x.shape] bf16 with x = sum of the planes (exactly, for planes = 3)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    n = x.numel()
+    if n % 8:
+        raise ValueError("split_planes: the element count must be a multiple of 8")
+    y = out if out is not None else torch.empty((planes, *x.shape), dtype=bf16, device=x.device)
+    _lib.check(lib.tt_split_planes(_p(x), _p(y), n, int(planes), n, _stream()), "tt_split_planes")
+    return y
+
+
+def layernorm_fwd_planes(x, gamma, beta, planes: int, eps=1e-6, save_stats=False, drop_first_token=False):
+    """LayerNorm whose result is written as bf16 planes [planes, rows, D] (see ``layernorm_fwd`` for the arguments)."""
+    lib = _lib.load()
+    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    skip = 0
+    if drop_first_token:
+        skip = x.shape[-2]
+        rows = rows // skip * (skip - 1)
+    y = torch.empty((planes, rows, D), dtype=bf16, device=x.device)
+    mean = torch.empty((rows,), dtype=f32, device=x.device) if save_stats else None
+    rstd = torch.empty((rows,), dtype=f32, device=x.device) if save_stats else None
+    _lib.check(lib.tt_layernorm_fwd_planes(_p(x), _p(gamma), _p(beta), _p(y), rows * D, int(planes), _p(mean), _p(rstd), rows, D, float(eps),
+                                           skip, _stream()), "tt_layernorm_fwd_planes")
+    return (y, mean, rstd) if save_stats else y
+
+
+def linear_fwd_planes(xp, wp, bias=None, residual=None, act: int = 0, out_f32: bool = True, out_planes: int = 0, save_pre: bool = False,
+                      out=None):
+    """y = act(x @ w.T + bias) (+ residual) on bf16-plane operands xp [P, M, K], wp [P, N, K].  Returns a dict with the
+    requested outputs: ``y`` (fp32 [M,N]), ``planes`` (bf16 [out_planes, M, N]), ``pre`` (fp32 pre-activation)."""
+    lib = _lib.load()
+    _chk(xp, "xp", bf16); _chk(wp, "wp", bf16)
+    P, M, K = xp.shape
+    N = wp.shape[1]
+    assert wp.shape[0] == P and wp.shape[2] == K, (xp.shape, wp.shape)
+    if bias is not None: _chk(bias, "bias")
+    if residual is not None: _chk(residual, "residual")
+    y = (out if out is not None else torch.empty((M, N), dtype=f32, device=xp.device)) if out_f32 else None
+    yp = torch.empty((out_planes, M, N), dtype=bf16, device=xp.device) if out_planes else None
+    pre = torch.empty((M, N), dtype=f32, device=xp.device) if save_pre else None
+    e0 = _prof_begin()
+    _lib.check(lib.tt_linear_fwd_planes(_p(xp), M * K, _p(wp), N * K, P, _p(bias), _p(residual), _p(y), _p(pre), _p(yp), M * N, int(out_planes),
+                                        M, N, K, int(act), _stream()), "tt_linear_fwd_planes")
+    _prof_end(e0, f"PLANES{P}", M, N, K)
+    return dict(y=y, planes=yp, pre=pre)
+
+
+def attention_fwd_bf16(qkv, num_heads: int):
+    """qkv [F,N,3*D] bf16 -> out [F,N,D] bf16 (N <= 256, head_dim 64)."""
+    lib = _lib.load()
+    _chk(qkv, "qkv", bf16)
+    F, N, D3 = qkv.shape
+    D = D3 // 3
+    hd = D // num_heads
+    out = torch.empty((F, N, D), dtype=bf16, device=qkv.device)
+    _lib.check(lib.tt_attention_fwd_bf16(_p(qkv), _p(out), F, N, num_heads, hd, float(hd ** -0.5), _stream()), "tt_attention_fwd_bf16")
+    return out

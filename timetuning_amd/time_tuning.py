@@ -304,16 +304,28 @@ class TimeT(nn.Module):
         use_mask = hp.get("mask_features", False)
         g = fe.spatial_resolution
         s_aux: Optional[dict] = {} if use_mask else None
-        tok, _ = engine.vit_tokens(vit, xf, self._frame_map(bs, fs, dev), save, last_block_aux=s_aux, tap=tap)
-        N, D = tok.shape[1], tok.shape[2]
+        # Only the target frames (time-major: the last bs) carry a gradient (time_tuning.py:296-302): the trainable blocks keep
+        # their activations for those frames only and run the other frames as a second stream that keeps nothing.
+        f0 = (fs - 1) * bs
+        tok, _ = engine.vit_tokens(vit, xf, self._frame_map(bs, fs, dev), save, last_block_aux=s_aux, tap=tap, save_from_frame=f0)
+        tok_lo, tok_hi = tok if isinstance(tok, tuple) else (tok[:f0], tok[f0:])
+        N, D = tok_hi.shape[1], tok_hi.shape[2]
         n = N - 1
         # --use_mask (time_tuning.py:244-246 -> models.py:93-144): foreground masks from the last block's cls attention.
         # Only the frames whose head features are consumed need one: the target frames and, without a teacher, frame 0.
-        mask_tgt = ops.foreground_mask(s_aux["qkv"][(fs - 1) * bs:], vit.num_heads, g).view(-1) if use_mask else None
-        if need_grad:
-            feats, mean_f, rstd_f = ops.layernorm_fwd(tok, vit.norm.weight, vit.norm.bias, save_stats=True, drop_first_token=True)
+        if use_mask:
+            qkv_tgt = s_aux["qkv_hi"] if "qkv_hi" in s_aux else s_aux["qkv"][f0:]
+            qkv_src = (s_aux["qkv_lo"] if "qkv_lo" in s_aux else s_aux["qkv"])[:bs]
+            mask_tgt = ops.foreground_mask(qkv_tgt, vit.num_heads, g).view(-1)
         else:
-            feats = ops.layernorm_fwd(tok, vit.norm.weight, vit.norm.bias, drop_first_token=True)
+            mask_tgt = qkv_src = None
+        feats = torch.empty((Fr * n, D), dtype=torch.float32, device=dev)
+        ops.layernorm_fwd(tok_lo, vit.norm.weight, vit.norm.bias, drop_first_token=True, out=feats[: f0 * n])
+        if need_grad:   # statistics of the target frames' rows, for the backward of the final norm
+            _, mean_f, rstd_f = ops.layernorm_fwd(tok_hi, vit.norm.weight, vit.norm.bias, save_stats=True, drop_first_token=True,
+                                                  out=feats[f0 * n:])
+        else:
+            ops.layernorm_fwd(tok_hi, vit.norm.weight, vit.norm.bias, drop_first_token=True, out=feats[f0 * n:])
         xn_bb = ops.l2norm_fwd(feats).view(fs, bs, n, D)           # label-propagation features (pre-head tokens)
         src_rows, tgt_rows = feats[: bs * n], feats[(fs - 1) * bs * n:]
 
@@ -324,7 +336,7 @@ class TimeT(nn.Module):
             if tap is not None:   # frame 0 = the first bs frames of the time-major pass
                 t_tok = engine.vit_blocks(tvit, tap["x"], t_first, last_block_aux=t_aux)
                 if use_mask and t_first == depth:
-                    t_aux["qkv"] = s_aux["qkv"][:bs]
+                    t_aux["qkv"] = qkv_src
             else:
                 t_tok, _ = engine.vit_tokens(tvit, xf, self._frame_map(bs, fs, dev, only_t=0), last_block_aux=t_aux)
             t_feats = ops.layernorm_fwd(t_tok, tvit.norm.weight, tvit.norm.bias, drop_first_token=True)
@@ -334,7 +346,7 @@ class TimeT(nn.Module):
         else:
             z_q = engine.head_forward(src_rows, fe.head) if fe.head is not None else src_rows
             protos_q = self.prototypes.data
-            mask_q = ops.foreground_mask(s_aux["qkv"][:bs], vit.num_heads, g).view(-1) if use_mask else None
+            mask_q = ops.foreground_mask(qkv_src, vit.num_heads, g).view(-1) if use_mask else None
             if use_mask and fe.head is None:
                 z_q = z_q.clone()  # src_rows is a view of the propagation features, which stay unmasked (time_tuning.py:285)
         if use_mask:
@@ -382,15 +394,13 @@ class TimeT(nn.Module):
         d_feats = engine.head_backward(dz, fe.head, sv_head, grads) if fe.head is not None else dz
         exchange.push(grads)  # prototypes + head
         if train_ids:
-            f0 = (fs - 1) * bs
             wg = vit.norm.weight.requires_grad
-            dx, dg, db = ops.layernorm_bwd(d_feats, tok[f0:], vit.norm.weight, mean_f[f0 * n:], rstd_f[f0 * n:], need_wgrad=wg,
-                                           drop_first_token=True)
+            dx, dg, db = ops.layernorm_bwd(d_feats, tok_hi, vit.norm.weight, mean_f, rstd_f, need_wgrad=wg, drop_first_token=True)
             if wg:
                 grads[vit.norm.weight], grads[vit.norm.bias] = dg, db
             dx = dx.view(bs * N, D)
-            for i in range(len(vit.blocks) - 1, first - 1, -1):
-                dx = engine.block_backward(dx, vit.blocks[i], vit.num_heads, save[i], f0, Fr, grads, need_dx=i > first)
+            for i in range(len(vit.blocks) - 1, first - 1, -1):   # the kept activations ARE the target frames: rows [0, bs)
+                dx = engine.block_backward(dx, vit.blocks[i], vit.num_heads, save[i], 0, bs, grads, need_dx=i > first)
                 if i > first:
                     exchange.push(grads)  # this block's gradients travel while the next block's backward runs
         grads = {p: g for p, g in grads.items() if p.requires_grad}
