@@ -13,8 +13,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int Q2_HD = 64, Q2_KCH = 32, Q2_KSTR = 66, Q2_VSTR = 68;
 
+// 3 resident workgroups per CU (168 VGPRs, 10 of them spilled) beat 2 (190 VGPRs, no spill) by 3 %: tools/ab_attn.py,
+// 107.4 vs 111.0 us per ViT-S/16 layer of 128 frames - the load / softmax / store phases of a third workgroup fill MFMA gaps.
+#ifndef TT_Q2_WAVES_PER_SIMD
+#define TT_Q2_WAVES_PER_SIMD 3
+#endif
+
 template <int NT>
-__global__ __launch_bounds__(256, 2) void attention_fwd_q2_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ __launch_bounds__(256, TT_Q2_WAVES_PER_SIMD) void attention_fwd_q2_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                   float* __restrict__ lse, int N, int H, int FH, float scale) {
   constexpr int NC = (NT + 1) / 2;
   __shared__ __attribute__((aligned(16))) float smem[2 * Q2_KCH * Q2_KSTR + 2 * Q2_KCH * Q2_VSTR];

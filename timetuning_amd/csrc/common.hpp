@@ -64,6 +64,18 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// GELU for the bf16-plane epilogues (gemm_planes.hip), where the matrix work per output element is 6-16x cheaper than on the
+// f32-MFMA path and ocml's erff (~40 instructions) would dominate the epilogue: erf by Abramowitz-Stegun 7.1.26 (one v_rcp,
+// one v_exp, five FMAs; |error| <= 1.5e-7 absolute on erf, i.e. <= 1e-7 |x| on GELU - inside the 2e-5 bound the fp32-accurate
+// plane mode is tested at).
+__device__ __forceinline__ float gelu_fast_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
 // XCD-aware bijective remap of a linear workgroup id (guide T1): the dispatcher deals consecutive
 // ids round-robin over the 8 XCDs; this hands each XCD a contiguous run of logical tiles so that
 // neighbouring tiles (which share an operand panel) hit the same 4 MiB L2.

@@ -453,9 +453,9 @@ extern "C" int tt_gemm_tile_choice(int M, int N, int batch) { return tt::gemm_ti
 extern "C" int tt_linear_fwd_route(int M, int N, int K) {
   const int tile = tt::gemm_tile_choice(M, N, 1);
   if (K % 16 != 0 || K < 16) return tile;
-  const int bm = (tile == 0 || tile == 2) ? 128 : 64, bn = (tile == 0 || tile == 1) ? 128 : 64;
-  if (M % bm == 0 && N % bn == 0) return tile | 256;
-  if (M % 64 == 0 && N % 64 == 0) return 3 | 256;
+  const int bn = (tile == 0 || tile == 1) ? 128 : 64;
+  if (N % bn == 0) return tile | 256;
+  if (N % 64 == 0) return 3 | 256;
   return tile;
 }
 

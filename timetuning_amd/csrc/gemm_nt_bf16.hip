@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(Bf16Args g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-  const int ntn = g.N / BN, ntm = g.M / BM;
+  const int ntn = g.N / BN, ntm = (g.M + BM - 1) / BM;   // partial last row tile: loads clamp, stores mask
   const int tile = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
   const int K = g.K;
@@ -70,16 +70,23 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(Bf16Args g) {
   // staging: 8 float4 per 32-k row; thread owns row (tid >> 3) + 32 i, k-chunk (tid & 7) * 4
   constexpr int NA = BM / 32, NB = BN / 32;
   const int srow = tid >> 3, skc = (tid & 7) * 4;
-  const float* pa = g.A + (size_t)(m0 + srow) * K + skc;
+  const float* pa[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = m0 + srow + 32 * i;
+    pa[i] = g.A + (size_t)(row < g.M ? row : g.M - 1) * K + skc;
+  }
   const float* pb = g.B + (size_t)(n0 + srow) * K + skc;
   const size_t step32 = (size_t)32 * K;
   float4 ra[NA], rb[NB];
   auto gload = [&]() {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(pa + i * step32);
+    for (int i = 0; i < NA; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(pa[i]);
+      pa[i] += BK;
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const float4*>(pb + i * step32);
-    pa += BK;
     pb += BK;
   };
   auto sstore = [&]() {
@@ -164,6 +171,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(Bf16Args g) {
     }
     __syncthreads();
     for (int rr = tid / TPR; rr < CH; rr += RPP) {
+      if (m0 + wmi * CH + rr >= g.M) break;
       const size_t off = (size_t)(m0 + wmi * CH + rr) * g.N + n;
       float4 v = *reinterpret_cast<const float4*>(Cs + rr * LDCS + c4);
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(Bf16Args g) {
 
 template <int WM, int WN>
 static int launch_bf16(const Bf16Args& g, int npass, hipStream_t s) {
-  const int tiles = (g.M / (64 * WM)) * (g.N / (64 * WN));
+  const int tiles = ((g.M + 64 * WM - 1) / (64 * WM)) * (g.N / (64 * WN));
   if (npass == 3) hipLaunchKernelGGL((gemm_nt_bf16_kernel<WM, WN, 3>), dim3(tiles), dim3(256), 0, s, g);
   else hipLaunchKernelGGL((gemm_nt_bf16_kernel<WM, WN, 1>), dim3(tiles), dim3(256), 0, s, g);
   TT_CHECK_LAUNCH("gemm_nt_bf16");
@@ -199,9 +207,9 @@ int try_launch_gemm_nt_bf16(const float* A, const float* B, float* C, int M, int
   if (K % 32 != 0 || K < 32 || !aligned16(A) || !aligned16(B) || !aligned16(C) || !ok16(bias) || !ok16(residual) || !ok16(pre_out)) return 1;
   Bf16Args g{A, B, C, M, N, K, bias, residual, pre_out, act};
   const int tile = gemm_tile_choice(M, N, 1);
-  const int bm = (tile == 0 || tile == 2) ? 128 : 64, bn = (tile == 0 || tile == 1) ? 128 : 64;
-  if (M % bm != 0 || N % bn != 0) {
-    if (M % 64 == 0 && N % 64 == 0) return launch_bf16<1, 1>(g, npass, s);
+  const int bn = (tile == 0 || tile == 1) ? 128 : 64;
+  if (N % bn != 0) {   // (any M)
+    if (N % 64 == 0) return launch_bf16<1, 1>(g, npass, s);
     return 1;
   }
   switch (tile) {

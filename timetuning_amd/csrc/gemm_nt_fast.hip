@@ -1,6 +1,6 @@
 // Lean instance of the f32-MFMA GEMM for the shapes that carry >90 % of a training step: every forward nn.Linear
-// (y = act(x @ w^T + b) (+ residual)) whose extents fill whole tiles (M % BM == 0, N % BN == 0, K % 16 == 0, 16-byte
-// aligned operands).  Same algorithm and LDS image as gemm_f32.hip (k-major double buffer, ds_read_b32 fragments,
+// (y = act(x @ w^T + b) (+ residual)) with whole column tiles (N % BN == 0, K % 16 == 0, 16-byte aligned operands; any M -
+// the last row tile clamps its loads and masks its stores).  Same algorithm and LDS image as gemm_f32.hip (k-major double buffer, ds_read_b32 fragments,
 // v_mfma_f32_32x32x2_f32) but with everything the general kernel pays for stripped: no bounds checks, no layout
 // switches, row pointers advanced instead of recomputed, and - the part that matters - the tile leaves through the
 // idle LDS as 16-byte, fully coalesced row-major stores.  tools/mfma_peak.hip measures the inner loop at
@@ -59,23 +59,30 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-  const int ntn = g.N / BN, ntm = g.M / BM;
+  const int ntn = g.N / BN, ntm = (g.M + BM - 1) / BM;   // the last row tile may be partial: loads clamp, stores mask
   const int tile = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
   const int K = g.K;
 
   // staging: thread owns row (tid >> 2) + 64 i of each operand tile and the 4 k's at (tid & 3) * 4
   const int srow = tid >> 2, skc = (tid & 3) * 4;
-  const float* pa = g.A + (size_t)(m0 + srow) * K + skc;
+  const float* pa[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int row = m0 + srow + 64 * i;
+    pa[i] = g.A + (size_t)(row < g.M ? row : g.M - 1) * K + skc;
+  }
   const float* pb = g.B + (size_t)(n0 + srow) * K + skc;
   const size_t step64 = (size_t)64 * K;
   float4 ra[WM], rb[WN];
   auto gload = [&]() {
 #pragma unroll
-    for (int i = 0; i < WM; ++i) ra[i] = *reinterpret_cast<const float4*>(pa + i * step64);
+    for (int i = 0; i < WM; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(pa[i]);
+      pa[i] += BK;
+    }
 #pragma unroll
     for (int i = 0; i < WN; ++i) rb[i] = *reinterpret_cast<const float4*>(pb + i * step64);
-    pa += BK;
     pb += BK;
   };
   auto sstore = [&](int buf) {
@@ -165,6 +172,7 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
     }
     __syncthreads();
     for (int rr = tid / TPR; rr < CH; rr += RPP) {
+      if (m0 + wmi * CH + rr >= g.M) break;
       const size_t off = (size_t)(m0 + wmi * CH + rr) * g.N + n;
       float4 v = *reinterpret_cast<const float4*>(lds + rr * LDCS + c4);
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
 
 template <int WM, int WN>
 static int launch_fast(const FastArgs& g, hipStream_t s) {
-  const int tiles = (g.M / (64 * WM)) * (g.N / (64 * WN));
+  const int tiles = ((g.M + 64 * WM - 1) / (64 * WM)) * (g.N / (64 * WN));
   // tuning aid: TT_GEMM_DYNLDS=<bytes> adds unused dynamic LDS to every launch, which caps the workgroups per CU
   static const int dyn_lds = [] { const char* e = getenv("TT_GEMM_DYNLDS"); return e ? atoi(e) : 0; }();
   hipLaunchKernelGGL((gemm_nt_fast_kernel<WM, WN>), dim3(tiles), dim3(256), dyn_lds, s, g);
@@ -204,9 +212,9 @@ int try_launch_gemm_nt_fast(const float* A, const float* B, float* C, int M, int
   if (K % 16 != 0 || K < 16 || !aligned16(A) || !aligned16(B) || !aligned16(C) || !ok16(bias) || !ok16(residual) || !ok16(pre_out)) return 1;
   FastArgs g{A, B, C, M, N, K, bias, residual, pre_out, act};
   const int tile = gemm_tile_choice(M, N, 1);
-  const int bm = (tile == 0 || tile == 2) ? 128 : 64, bn = (tile == 0 || tile == 1) ? 128 : 64;
-  if (M % bm != 0 || N % bn != 0) {
-    if (M % 64 == 0 && N % 64 == 0) return launch_fast<1, 1>(g, s);
+  const int bn = (tile == 0 || tile == 1) ? 128 : 64;
+  if (N % bn != 0) {   // (any M: a partial last row tile is clamped / masked)
+    if (N % 64 == 0) return launch_fast<1, 1>(g, s);
     return 1;
   }
   switch (tile) {

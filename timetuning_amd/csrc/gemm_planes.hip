@@ -18,9 +18,10 @@
 //
 // Tile (64 WM) x (64 WN), 4 waves as 2 x 2, double-buffered LDS, ONE barrier per slab: the DMA of slab t+1 is issued before
 // the MFMAs of slab t and retired by the barrier's vmcnt(0).  Rows beyond M are clamped on load and masked on store.
-// Epilogue through LDS (8 columns per thread): bias, exact GELU, residual, and any of: fp32 y, fp32 pre-activation, bf16 planes
+// Epilogue through LDS (8 columns per thread): bias, GELU (erf to 1.5e-7, common.hpp gelu_fast_f), residual, and any of: fp32 y, fp32 pre-activation, bf16 planes
 // of y (so the consumer finds its operand pre-split).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace tt {
 
@@ -53,7 +54,14 @@ __device__ __forceinline__ void split3(float v, __bf16& p0, __bf16& p1, __bf16& 
   p2 = (__bf16)r2;
 }
 
-template <int P, int BK, int WM, int WN>
+// s_waitcnt vmcnt(N) with a compile-time N (the LDS-DMA pieces this wave may leave in flight)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int P, int BK, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int ROWB = BK * 2;              // bytes per LDS row
@@ -64,9 +72,13 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
   constexpr int BUF = P * (A_PL + B_PL);
   constexpr int CH = 32 * WM, LDCS = BN + 4;
   constexpr int EPI = CH * LDCS * 4;
-  constexpr int LDS_BYTES = 2 * BUF > EPI ? 2 * BUF : EPI;
-  static_assert(LDS_BYTES <= 65536, "LDS budget");
+  constexpr int LDS_BYTES = NBUF * BUF > EPI ? NBUF * BUF : EPI;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   static_assert(BM % RPI == 0 && BN % RPI == 0, "whole DMA pieces");
+  // DMA pieces (wave-instructions) every wave issues per slab; the counted waits below need the same number in all waves
+  constexpr int G = P * (BM / RPI / 4 + BN / RPI / 4);
+  static_assert(NBUF == 2 || ((BM / RPI) % 4 == 0 && (BN / RPI) % 4 == 0), "ring depths > 2 need equal piece counts per wave");
+  static_assert((NBUF - 2) * G < 64, "vmcnt range");
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -129,11 +141,7 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
   }
 
   const int nk = K / BK;
-  issue(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+  auto compute = [&](int buf) {
     const unsigned char* base = smem + buf * BUF;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
@@ -157,7 +165,39 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
             for (int pa = 0; pa <= s; ++pa)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[s - pa][j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();  // every wave has read this slab; the barrier's vmcnt(0) retires the DMA of the next one
+  };
+  if constexpr (NBUF == 2) {
+    // double buffer, one barrier per slab: the DMA of slab t+1 flies under the MFMAs of slab t and is retired by the barrier's
+    // vmcnt(0)
+    issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+      compute(buf);
+      __syncthreads();
+    }
+  } else {
+    // ring of NBUF slabs, NBUF - 1 of them in flight: per slab ONE raw s_barrier behind a COUNTED vmcnt that leaves the younger
+    // slabs' DMA pieces outstanding (a __syncthreads() would drain them: its fence waits vmcnt(0)).  Passing the barrier of
+    // iteration kt means (a) every wave's pieces of slab kt have landed and (b) every wave is done reading slab kt - 1, whose
+    // buffer the DMA issued right behind the barrier overwrites.
+#pragma unroll
+    for (int t = 0; t < NBUF - 1; ++t)
+      if (t < nk) issue(t, t);
+    int buf = 0, nxt = NBUF - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int younger = nk - 1 - kt;   // slabs issued after kt that may stay in flight
+      if (younger >= NBUF - 2) wait_vmcnt<(NBUF - 2) * G>();
+      else if (NBUF > 3 && younger == 1) wait_vmcnt<G>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + NBUF - 1 < nk) issue(kt + NBUF - 1, nxt);
+      compute(buf);
+      buf = buf + 1 == NBUF ? 0 : buf + 1;
+      nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+    }
+    __builtin_amdgcn_s_barrier();   // all reads of the last slab done before the epilogue reuses the LDS
   }
 
   // ---- epilogue through LDS, one wave-row (32 WM tile rows) at a time; a thread owns 8 consecutive columns
@@ -195,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
         }
         if (g.act == 1) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+          for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
         }
         if (g.residual) {
           float rs[8];
@@ -226,10 +266,10 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
   }
 }
 
-template <int P, int BK, int WM, int WN>
+template <int P, int BK, int WM, int WN, int NBUF = 2>
 static int launch_planes(const PlaneArgs& g, hipStream_t s) {
   const int tiles = ((g.M + 64 * WM - 1) / (64 * WM)) * (g.N / (64 * WN));
-  hipLaunchKernelGGL((gemm_planes_kernel<P, BK, WM, WN>), dim3(tiles), dim3(256), 0, s, g);
+  hipLaunchKernelGGL((gemm_planes_kernel<P, BK, WM, WN, NBUF>), dim3(tiles), dim3(256), 0, s, g);
   TT_CHECK_LAUNCH("gemm_planes");
   return TT_OK;
 }
@@ -289,9 +329,15 @@ extern "C" int tt_linear_fwd_planes(const void* x_planes, long long x_plane_stri
   const long long t128 = (long long)((M + 127) / 128) * (N / 128);
   const bool big = (N % 128 == 0) && t128 >= 3 * 256;
   const bool wide = (N % 128 == 0);
+  static const int variant = [] { const char* e = getenv("TT_PLANES_VARIANT"); return e ? atoi(e) : 0; }();  // tuning aid
   switch (planes) {
     case 1:
-      if (big) return launch_planes<1, 64, 2, 2>(g, s);
+      if (big) {
+        if (variant == 1) return launch_planes<1, 64, 2, 2, 2>(g, s);
+        if (variant == 2) return launch_planes<1, 32, 2, 2, 3>(g, s);
+        if (variant == 3) return launch_planes<1, 64, 2, 2, 3>(g, s);
+        return launch_planes<1, 32, 2, 2, 4>(g, s);
+      }
       if (wide) return launch_planes<1, 64, 1, 2>(g, s);
       return launch_planes<1, 64, 1, 1>(g, s);
     case 2:
@@ -299,8 +345,16 @@ extern "C" int tt_linear_fwd_planes(const void* x_planes, long long x_plane_stri
       if (wide) return launch_planes<2, 32, 1, 2>(g, s);
       return launch_planes<2, 32, 1, 1>(g, s);
     default:
-      if (big) return launch_planes<3, 16, 2, 2>(g, s);
-      if (wide) return launch_planes<3, 16, 1, 2>(g, s);
+      if (big) {
+        if (variant == 1) return launch_planes<3, 16, 2, 2, 2>(g, s);
+        if (variant == 2) return launch_planes<3, 16, 2, 2, 4>(g, s);
+        if (variant == 3) return launch_planes<3, 32, 2, 2, 2>(g, s);
+        return launch_planes<3, 16, 2, 2, 3>(g, s);
+      }
+      if (wide) {
+        if (variant == 1) return launch_planes<3, 16, 1, 2, 2>(g, s);
+        return launch_planes<3, 32, 1, 2, 2>(g, s);
+      }
       return launch_planes<3, 16, 1, 1>(g, s);
   }
 }

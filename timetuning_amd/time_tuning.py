@@ -307,7 +307,10 @@ class TimeT(nn.Module):
         # Only the target frames (time-major: the last bs) carry a gradient (time_tuning.py:296-302): the trainable blocks keep
         # their activations for those frames only and run the other frames as a second stream that keeps nothing.
         f0 = (fs - 1) * bs
-        tok, _ = engine.vit_tokens(vit, xf, self._frame_map(bs, fs, dev), save, last_block_aux=s_aux, tap=tap, save_from_frame=f0)
+        # (in the default f32 mode the two streams would run the same kernels on smaller launches: split only when a bf16-plane
+        # mode gives the stream that keeps nothing a faster path)
+        tok, _ = engine.vit_tokens(vit, xf, self._frame_map(bs, fs, dev), save, last_block_aux=s_aux, tap=tap,
+                                   save_from_frame=f0 if ops.plane_count() else 0)
         tok_lo, tok_hi = tok if isinstance(tok, tuple) else (tok[:f0], tok[f0:])
         N, D = tok_hi.shape[1], tok_hi.shape[2]
         n = N - 1
@@ -399,8 +402,11 @@ class TimeT(nn.Module):
             if wg:
                 grads[vit.norm.weight], grads[vit.norm.bias] = dg, db
             dx = dx.view(bs * N, D)
-            for i in range(len(vit.blocks) - 1, first - 1, -1):   # the kept activations ARE the target frames: rows [0, bs)
-                dx = engine.block_backward(dx, vit.blocks[i], vit.num_heads, save[i], 0, bs, grads, need_dx=i > first)
+            # kept activations: the target frames only (two-stream pass: rows [0, bs)) or all frames (rows [f0, Fr))
+            kept = save[first]["x_in"].shape[0]
+            b0, b1 = (0, bs) if kept == bs else (f0, Fr)
+            for i in range(len(vit.blocks) - 1, first - 1, -1):
+                dx = engine.block_backward(dx, vit.blocks[i], vit.num_heads, save[i], b0, b1, grads, need_dx=i > first)
                 if i > first:
                     exchange.push(grads)  # this block's gradients travel while the next block's backward runs
         grads = {p: g for p, g in grads.items() if p.requires_grad}
