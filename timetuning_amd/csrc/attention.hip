@@ -12,6 +12,7 @@
 // (double-buffered, next chunk's global loads in flight during the current chunk's MFMAs).  q/k/v are read
 // straight out of the qkv Linear's [F, N, 3*H*64] output (256-byte contiguous head rows): no permute kernel.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace tt {
 

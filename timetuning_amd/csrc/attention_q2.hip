@@ -4,7 +4,14 @@
 // from registers) but each wave owns 32 queries = two 16-query tiles that SHARE every K / V fragment read from LDS:
 // one ds_read_b32 feeds two MFMAs, a workgroup (4 waves) covers 128 queries, and the work between two barriers
 // doubles (64 MFMAs per wave per 32-key chunk), which is what the one-tile version was short of (44 % MFMA busy).
-// Costs ~190 VGPRs (2 waves per SIMD).  The one-tile kernel stays for the probability output.
+// The one-tile kernel stays for the probability output.
+//
+// Measured alternative, not shipped (round 2): a register-streaming form with NO LDS and NO barriers - every wave an independent
+// stream that loads K / Q fragments straight from global memory as 16-byte loads (the contraction order over d permuted to
+// d = 16 g + s so that a lane's sixteen values are consecutive) and the V^T operand as sixteen dwords per key tile, next tile in
+// flight under the MFMAs (223 VGPRs, counted vmcnt throughout, bit-compatible results): 129 us per ViT-S/16 layer of 128 frames
+// against 112 us for this kernel on the same box.  Sharing K / V through LDS (one fetch per workgroup instead of four) is
+// worth more than the sixteen barriers cost.
 #include "common.hpp"
 
 namespace tt {

@@ -13,7 +13,13 @@
 //   * operands swapped (D^T = W X^T) so that a lane owns 4 consecutive output columns and stores 16 bytes straight from
 //     the accumulators, no LDS pass: bit-identical, 1-2 % slower (32 rows x 32 B per store instruction);
 //   * [row][k] LDS image with ds_write_b128 / ds_read_b128 (k-permuted fragments): bit-identical, -9 ... +2 % by shape;
-//   * capping the workgroups per CU: flat from 6 down to 3, -10 % at 2, -26 % at 1 - the loop is not latency-bound.
+//   * capping the workgroups per CU: flat from 6 down to 3, -10 % at 2, -26 % at 1 - the loop is not latency-bound;
+//   * (round 2) LDS-DMA staging: global_load_lds_dwordx4 into a [row][16 k] image XOR-swizzled through the source address,
+//     ds_read_b128 fragments with the k order permuted (k = 4 (2 j + h) + e), no staging VGPRs, no ds_write, ring of 2 / 3 / 4
+//     slabs behind counted vmcnt + raw s_barrier (the structure of gemm_planes.hip): 886 / 895 / 948 us per ViT-S/16 block of
+//     128 frames (qkv + proj + fc1 + fc2) against 834 us for this kernel on the same box (tools/bench_linear.py), same 5e-7
+//     error.  Three very different loop structures (this one, the DMA ring, hipBLASLt's stream-K) land within +-8 % of
+//     110 TFLOP/s at K = 384: the ceiling is not in the staging path.
 #include "common.hpp"
 #include <cstdlib>
 
