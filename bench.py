@@ -257,6 +257,7 @@ def main():
     ap.add_argument("--architecture", default="dino-s16")
     ap.add_argument("--use_teacher", action="store_true")
     ap.add_argument("--use_queue", action="store_true")
+    ap.add_argument("--queue_size", type=int, default=16384, help="global queue rows (the reference's default); each rank holds queue_size // world")
     ap.add_argument("--use_mask", action="store_true", help="time the --use_mask variant (attention foreground masks) instead")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
@@ -309,7 +310,7 @@ def main():
         model.init_momentum_teacher()
         model.set_momentum_teacher_schedular_params(0.995, 1.0, 1, total_steps)
     if a.use_queue:
-        model.init_queue(16384 // world)
+        model.init_queue(a.queue_size // world)
         model.queue.copy_(torch.nn.functional.normalize(torch.randn_like(model.queue), dim=1))
         model._queue_rows_pushed = model.queue.shape[0]
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1 + rank)).to(device)  # resident in HBM before timing
@@ -388,7 +389,7 @@ def main():
             "config": {"workload": ("C2: " if (a.architecture, bs, fs, K) == ("dino-s16", 32, 4, 200) else
                                     "C4 (per-GPU share): " if (a.architecture, bs, fs, K) == ("dino-b16", 16, 8, 400) else "") +
                                    f"{a.architecture} full TimeT training step (fwd+bwd+AdamW), {fs}-frame 224x224 clips, {bs} clips/GPU, "
-                                   f"{K} prototypes" + (", EMA teacher" if a.use_teacher else "") + (", queue" if a.use_queue else "") +
+                                   f"{K} prototypes" + (", EMA teacher" if a.use_teacher else "") + (f", queue {a.queue_size // world} rows/rank" if a.use_queue else "") +
                                    (", use_mask" if a.use_mask else ""),
                        "clips_per_gpu": bs, "num_frames": fs, "num_clusters": K,
                        "global_batch": bs * world, "parallelism": f"dp{world}"},
