@@ -329,7 +329,9 @@ int gemm_tile_choice(int M, int N, int batch) {
   static const int forced = [] { const char* e = getenv("TT_FORCE_TILE"); return e ? atoi(e) : -1; }();  // tuning aid
   if (forced >= 0 && forced <= 3) return forced;
   struct Cfg { int wm, wn; double pen; };
-  const Cfg cfgs[4] = {{2, 2, 1.00}, {1, 2, 1.04}, {2, 1, 1.04}, {1, 1, 1.10}};
+  // (128 x 64 beats 64 x 128 at equal tile counts on every ViT-S/16 block shape - 813.6 vs 836.3 us per block of 128 frames,
+  // tools/bench_linear.py with TT_FORCE_TILE: the streamed activation rows are the taller operand, the L2-resident weights the narrower)
+  const Cfg cfgs[4] = {{2, 2, 1.00}, {1, 2, 1.04}, {2, 1, 1.03}, {1, 1, 1.10}};
   int best = 0;
   double best_cost = 1e300;
   for (int c = 0; c < 4; ++c) {

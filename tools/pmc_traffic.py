@@ -24,9 +24,12 @@ print(f"{'kernel':90s} {'launches':>8s} {'read MB':>9s} {'write MB':>9s}")
 for tot, k, n, fb, wb in rows[:14]:
     print(f"{k[:90]:90s} {n:8d} {fb/1e6:9.1f} {wb/1e6:9.1f}")
 if len(sys.argv) > 3:
-    dom = [r for r in rows if "gemm_nt_fast_kernel<1, 2>" in r[1]] or rows[:1]
+    # the dominant kernel of the step: the gemm_nt_fast instantiation with the most launches (bench.py's roofline kernel)
+    dom = sorted([r for r in rows if "gemm_nt_fast_kernel" in r[1]], key=lambda r: -r[2]) or rows[:1]
     tot, k, n, fb, wb = dom[0]
     head = sys.argv[4] if len(sys.argv) > 4 else "unknown"
-    json.dump({"kernel": k, "kernel_label": "gemm_nt_fast_kernel<64x128>", "git_head": head, "launches_profiled": n, "hbm_read_bytes_per_launch": round(fb), "hbm_write_bytes_per_launch": round(wb),
+    names = {"<2, 2>": "128x128", "<1, 2>": "64x128", "<2, 1>": "128x64", "<1, 1>": "64x64"}
+    label = next((f"gemm_nt_fast_kernel<{v}>" for t, v in names.items() if t in k), k)
+    json.dump({"kernel": k, "kernel_label": label, "git_head": head, "launches_profiled": n, "hbm_read_bytes_per_launch": round(fb), "hbm_write_bytes_per_launch": round(wb),
                "hbm_bytes_per_launch": round(fb + wb), "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 per the gfx950 correction; average over the launches of one bench.py run (mixed shapes of this instantiation)"},
               open(sys.argv[3], "w"), indent=1)
