@@ -230,6 +230,11 @@ typedef struct {
 int tt_adamw_step(const tt_adamw_tensor* tensors, int count, int step, float beta1, float beta2, float eps,
                   tt_stream_t stream);
 
+/* g[i] *= *scale_device for the `g` buffers (n floats each) of up to TT_MAX_TENSORS table entries (p, m, v, lr, weight_decay are
+ * ignored), one launch: the chain rule of `loss.backward()` applied to the gradients the fused step produced
+ * (time_tuning.py:420-423 calls backward on the scalar loss; its incoming gradient is a device scalar). */
+int tt_scale_tensors(const tt_adamw_tensor* tensors, int count, const float* scale_device, tt_stream_t stream);
+
 /* ---- k19: EMA teacher update (time_tuning.py:109-118): t = t*(1-m) + s*m over n floats. */
 int tt_ema_update(float* teacher, const float* student, long long n, double momentum, tt_stream_t stream);
 

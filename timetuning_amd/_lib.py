@@ -67,6 +67,7 @@ SIGNATURES = {
     "tt_ce_workspace_bytes": (c_sz, [c_i]),
     "tt_queue_push": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp]),
     "tt_adamw_step": (c_i, [C.POINTER(AdamwTensor), c_i, c_i, c_f, c_f, c_f, c_vp]),
+    "tt_scale_tensors": (c_i, [C.POINTER(AdamwTensor), c_i, c_vp, c_vp]),
     "tt_ema_update": (c_i, [c_vp, c_vp, c_ll, c_d, c_vp]),
     "tt_add_inplace": (c_i, [c_vp, c_vp, c_ll, c_vp]),
     "tt_count_mismatch": (c_i, [c_vp, c_vp, c_ll, c_vp, c_vp]),

@@ -304,6 +304,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamTable tab, float beta1, 
   }
 }
 
+// g[i] *= *scale for every tensor of the table (the incoming gradient of the loss, a device scalar, applied to the gradients
+// the fused step already holds: what autograd's chain rule asks of _FusedLoss.backward)
+__global__ __launch_bounds__(256) void scale_tensors_kernel(AdamTable tab, const float* __restrict__ scale) {
+  const tt_adamw_tensor t = tab.t[blockIdx.y];
+  const float sc = *scale;
+  float* gp = const_cast<float*>(t.g);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < t.n; i += (long long)gridDim.x * 256) gp[i] *= sc;
+}
+
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const float* __restrict__ s, long long n, float m,
                                                   float one_minus_m) {
   long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -488,6 +497,22 @@ extern "C" int tt_adamw_step(const tt_adamw_tensor* tensors, int count, int step
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)bx, count), dim3(256), 0, as_stream(stream), tab, beta1, beta2, eps, (float)bc1,
                      (float)sqrt(bc2));
   TT_CHECK_LAUNCH("adamw");
+  return TT_OK;
+}
+
+extern "C" int tt_scale_tensors(const tt_adamw_tensor* tensors, int count, const float* scale_device, tt_stream_t stream) {
+  TT_REQUIRE(tensors && scale_device && count > 0 && count <= TT_MAX_TENSORS, "scale_tensors: need 1..%d tensors", TT_MAX_TENSORS);
+  AdamTable tab{};
+  long long maxn = 0;
+  for (int i = 0; i < count; ++i) {
+    TT_REQUIRE(tensors[i].g && tensors[i].n > 0, "scale_tensors: tensor %d has a null gradient pointer", i);
+    tab.t[i] = tensors[i];
+    if (tensors[i].n > maxn) maxn = tensors[i].n;
+  }
+  long long bx = (maxn + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(scale_tensors_kernel, dim3((unsigned)bx, count), dim3(256), 0, as_stream(stream), tab, scale_device);
+  TT_CHECK_LAUNCH("scale_tensors");
   return TT_OK;
 }
 

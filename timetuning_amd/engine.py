@@ -330,10 +330,13 @@ class GradExchange:
         if self.dist is None:
             return grads
         self.push(grads)
-        inv = 1.0 / self.dist.get_world_size()
+        inv = torch.full((1,), 1.0 / self.dist.get_world_size(), dtype=f32, device=self.buckets[0][1].device) if self.buckets else None
         for keys, flat, work in self.buckets:
             work.wait()
-            flat *= inv
+            if flat.is_cuda:
+                ops.scale_tensors_([flat], inv)      # SUM -> mean
+            else:
+                flat *= inv                          # (CPU tensors: only the gloo tests of the collective logic)
             off = 0
             for k in keys:
                 grads[k] = flat[off:off + k.numel()].view(k.shape)

@@ -623,6 +623,20 @@ def adamw_step_(entries: Sequence[tuple], step: int, beta1=0.9, beta2=0.999, eps
         _lib.check(lib.tt_adamw_step(arr, len(chunk), int(step), float(beta1), float(beta2), float(eps), _stream()), "tt_adamw_step")
 
 
+def scale_tensors_(tensors: Sequence[torch.Tensor], scale: torch.Tensor):
+    """t *= scale for every tensor (scale: a one-element fp32 GPU tensor), one launch per 40 tensors."""
+    lib = _lib.load()
+    _chk(scale, "scale")
+    cap = 40
+    for i in range(0, len(tensors), cap):
+        chunk = tensors[i:i + cap]
+        arr = (_lib.AdamwTensor * len(chunk))()
+        for j, t in enumerate(chunk):
+            _chk(t, "tensor")
+            arr[j] = _lib.AdamwTensor(None, t.data_ptr(), None, None, t.numel(), 0.0, 0.0)
+        _lib.check(lib.tt_scale_tensors(arr, len(chunk), _p(scale), _stream()), "tt_scale_tensors")
+
+
 def ema_update_(teacher, student, momentum: float):
     """teacher <- teacher * (1 - m) + student * m  (time_tuning.py:113-115)."""
     lib = _lib.load()

@@ -106,7 +106,7 @@ class _FusedLoss(torch.autograd.Function):
             raise RuntimeError("the fused TimeT step was run without gradients")
         out, ctx.grads = ctx.grads, None  # hand the buffers over: with no other owner AccumulateGrad adopts them instead of cloning
         live = [g for g in out if g is not None]
-        torch._foreach_mul_(live, gout)
+        ops.scale_tensors_(live, gout.reshape(1).to(torch.float32).contiguous())   # chain rule: d loss_out / d loss (1 for loss.backward())
         return (None, None, None, None, *out)
 
 
