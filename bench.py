@@ -123,8 +123,10 @@ def cpu_baseline(fs, K, budget_s=30.0, arch="dino-s16", precision="f32"):
     from oracle import timet_oracle as O
     from timetuning_amd import synth
 
-    # torch-CPU stops scaling (and then collapses) well below the socket's core count on these op sizes: use at most 32
-    cores = min(os.cpu_count() or 1, 32)
+    # torch-CPU stops scaling at 16 threads on these op sizes and then collapses (tools/cpu_threads_sweep.py on the 256-core
+    # box, profiles/r02_cpu_threads_sweep.txt: 14.3 / 17.4 / 10.7 / 4.3 / 1.7 / 0.04 clip-frames/s at 8 / 16 / 32 / 64 / 128 / 256
+    # threads): the baseline runs at its best setting
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     bs = 2
     om = O.build_oracle(arch, K, (1024, 1024, 512, 256), mode="dino")

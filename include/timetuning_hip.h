@@ -171,6 +171,20 @@ int tt_linear_fwd_planes(const void* x_planes, long long x_plane_stride, const v
                          const float* bias, const float* residual, float* y, float* pre_out, void* y_planes,
                          long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, tt_stream_t stream);
 int tt_attention_fwd_bf16(const void* qkv, void* out, int F, int N, int H, int head_dim, float scale, tt_stream_t stream);
+/*   The backward products of the same nn.Linear sites on bf16-plane operands (autograd of dino_vision_transformer.py:94-103,
+ *   115-130; the bf16 path only - the fp32 modes keep the f32-MFMA backward kernels):
+ *   tt_transpose_planes               fp32 [R][C] -> bf16 [C][Rpad], transposed, columns R..Rpad-1 zero (reduction index contiguous)
+ *   tt_linear_bwd_data_planes         dx[M,K] = dy[M,N] @ w[N,K] (* gelu'(gelu_pre[M,K]) when given): dy in planes [M][N], the weight
+ *                                     transposed in planes wT [K][N]; N % 64 == 0, K % 64 == 0
+ *   tt_linear_bwd_weight_planes       dw[N,K] = dy[M,N]^T @ x[M,K]: dyT [N][Mpad] and xT [K][Mpad] from tt_transpose_planes with the
+ *                                     same Mpad (a multiple of 64); split-K over Mpad with a fixed-order fold; N, K % 64 == 0 */
+int tt_transpose_planes(const float* src, void* dst, int R, int C, int Rpad, tt_stream_t stream);
+int tt_linear_bwd_data_planes(const void* dy_planes, long long dy_plane_stride, const void* wT_planes, long long wT_plane_stride,
+                              int planes, const float* gelu_pre, float* dx, int M, int N, int K, tt_stream_t stream);
+int tt_linear_bwd_weight_planes(const void* dyT_planes, long long dyT_plane_stride, const void* xT_planes, long long xT_plane_stride,
+                                int planes, float* dw, int N, int K, int Mpad, void* workspace, size_t workspace_bytes,
+                                tt_stream_t stream);
+size_t tt_linear_bwd_weight_planes_workspace_bytes(int N, int K, int Mpad);
 
 /* ---- k14: temporal label propagation (time_tuning.py:143-154 -> mask_propagation.py:396-496)
  *   xn   [fs, bs, n, D]  L2-normalised backbone tokens, time-major (frame t of clip b at [t][b])

@@ -31,7 +31,8 @@ def rnd(name, *shape, std=1.0):
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (591, 1152, 384), (130, 72, 20), (64, 64, 64), (257, 200, 256), (25216, 384, 1536),
-                                   (392, 50, 256), (77, 21, 30), (5, 3, 2), (6304, 1536, 384), (3, 128, 64), (18912, 384, 384)])
+                                   (392, 50, 256), (77, 21, 30), (5, 3, 2), (6304, 1536, 384), (3, 128, 64), (18912, 384, 384),
+                                   (788, 1536, 384), (788, 384, 1536), (788, 1152, 384), (394, 1024, 1024)])   # small grids: BK = 64 slabs
 def test_linear_fwd(ops, M, N, K):
     x, w, b, r = rnd("lx", M, K), rnd("lw", N, K, std=0.05), rnd("lb", N), rnd("lr", M, N)
     ref = F.linear(x.double(), w.double(), b.double())

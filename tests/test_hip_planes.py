@@ -106,3 +106,30 @@ def test_attention_bf16(Fr, N, H):
     # P and the output are rounded to bf16 (8 significant bits each)
     assert rel_err(out.double(), ref) < 1.5e-2
     assert (out.double() - ref).abs().mean().item() < 2e-3 * ref.abs().mean().item() + 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(3152, 768, 3072), (6304, 1536, 384), (591, 256, 512), (6304, 384, 1152)])
+def test_backward_products_on_bf16_planes(M, N, K):
+    """dx = dy @ w (* gelu'(pre)) and dw = dy^T @ x on bf16 operands (the "bf16" mode's backward, BASELINE C4): against fp64
+    products of the SAME bf16-rounded operands at the f32 bound (only the fp32 accumulation differs; split-K fold included),
+    and loosely against the fp32 operands."""
+    from timetuning_amd import hip_ops as ops
+
+    dy, w, x = rnd(f"bwd.dy{M}.{N}", M, N, scale=0.1), rnd(f"bwd.w{N}.{K}", N, K, scale=0.05), rnd(f"bwd.x{M}.{K}", M, K)
+    pre = rnd(f"bwd.pre{M}.{K}", M, K)
+    dyb, wb, xb = dy.to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), x.to(torch.bfloat16).double()
+    assert ops.bwd_planes_ok(M, N, K)
+    dx = ops.linear_bwd_data_planes(dy.cuda(), w.cuda())
+    assert rel_err(dx.cpu(), dyb @ wb) < TOL_F32
+    assert rel_err(dx.cpu(), dy.double() @ w.double()) < 2e-2
+    pd = pre.double().requires_grad_(True)
+    F.gelu(pd).sum().backward()
+    dxg = ops.linear_bwd_data_planes(dy.cuda(), w.cuda(), pre.cuda())
+    assert rel_err(dxg.cpu(), (dyb @ wb) * pd.grad) < TOL_F32
+    dw, db = ops.linear_bwd_weight_planes(dy.cuda(), x.cuda())
+    assert rel_err(dw.cpu(), dyb.t() @ xb) < TOL_F32
+    assert rel_err(dw.cpu(), dy.double().t() @ x.double()) < 2e-2
+    assert rel_err(db.cpu(), dy.double().sum(0)) < 1e-5
+    t = ops.transpose_planes(x.cuda())
+    assert t.shape == (1, K, (M + 63) // 64 * 64) and torch.equal(t[0, :, :M].cpu(), x.to(torch.bfloat16).t())
+    assert (t[0, :, M:] == 0).all()

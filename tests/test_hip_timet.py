@@ -649,6 +649,35 @@ def test_c4_shape_in_bf16_mode():
         hip_ops.set_gemm_precision("f32")
 
 
+def test_bf16_mode_gradients_track_f32(golden):
+    """BASELINE C4's bf16 path end to end WITH its bf16 backward products (dgrad / wgrad on bf16 operands): loss and gradients
+    of one training step on the tiny ViT against the f32 run of the same step, at bf16-sized bounds (not the fp32 contract)."""
+    from timetuning_amd import hip_ops
+
+    g = golden("timet_tiny")
+    bs, fs = int(g["cfg"][0]), int(g["cfg"][1])
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1)).cuda()
+    names = ("feature_extractor.head.0.weight", "feature_extractor.head.6.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight",
+             "feature_extractor.backbone.blocks.11.mlp.fc2.weight", "feature_extractor.backbone.blocks.10.norm1.weight", "prototypes")
+    out = {}
+    try:
+        for mode in ("f32", "bf16"):
+            hip_ops.set_gemm_precision(mode)
+            model, _ = _build(g)
+            labels = None if mode == "f32" else out["f32"][2]
+            loss = model.get_loss(x, target_labels=labels)
+            loss.backward()
+            params = dict(model.named_parameters())
+            out[mode] = (loss.item(), {n: params[n].grad.double().cpu() for n in names}, model.last_aux["labels"].cpu())
+    finally:
+        hip_ops.set_gemm_precision("f32")
+    assert abs(out["bf16"][0] - out["f32"][0]) < 0.05 * abs(out["f32"][0])
+    for n in names:
+        a, b = out["bf16"][1][n].flatten(), out["f32"][1][n].flatten()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        assert cos > 0.98 and abs(float(a.norm() / b.norm()) - 1) < 0.1, (n, cos)
+
+
 @pytest.mark.parametrize("mode,feat_tol", [("bf16x3", 1e-3), ("bf16", 6e-2)])
 def test_precision_modes_end_to_end(golden, mode, feat_tol):
     """The opt-in bf16 MFMA modes of the forward Linears against the reference's numbers (tiny ViT golden fixture):

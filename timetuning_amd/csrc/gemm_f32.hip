@@ -325,6 +325,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+int launch_splitk_reduce(const float* partial, float* out, long long n, int splits, long long stride, hipStream_t s) {
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, partial, out, n, splits, stride);
+  TT_CHECK_LAUNCH("splitk_reduce");
+  return TT_OK;
+}
+
 int gemm_tile_choice(int M, int N, int batch) {
   static const int forced = [] { const char* e = getenv("TT_FORCE_TILE"); return e ? atoi(e) : -1; }();  // tuning aid
   if (forced >= 0 && forced <= 3) return forced;

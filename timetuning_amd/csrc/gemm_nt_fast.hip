@@ -48,9 +48,12 @@ extern "C" int tt_debug_read_clock_stamps(unsigned long long* host, int count) {
 }
 #endif
 
-template <int WM, int WN>
+// BK = 16 is the throughput instance (5-6 workgroups per CU hide every latency).  BK = 64 is for grids of at most about one
+// workgroup per CU (BASELINE C1: 2 x 2 frames = 788 rows, 13 row tiles): there nothing hides the global-load latency of the
+// one slab in flight, a launch is (K / BK) dependent round trips long, and four times deeper slabs cut the trips four-fold.
+template <int WM, int WN, int BK = 16>
 __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
-  constexpr int BM = 64 * WM, BN = 64 * WN, BK = 16;
+  constexpr int BM = 64 * WM, BN = 64 * WN, KQ = BK / 16;
   // k-row stride = tile extent + 2: the transposing staging writes (lane -> k-rows 4 (tid & 3) + e, column tid >> 2) then
   // spread over all 32 banks of a ds_write_b32 lane group (4 * stride = 8 mod 32); with + 4 (= 16 mod 32) they collide
   // two-way on every write (SQ_LDS_BANK_CONFLICT was 24 % of the LDS-active cycles).  Fragment reads walk consecutive
@@ -80,33 +83,39 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
   }
   const float* pb = g.B + (size_t)(n0 + srow) * K + skc;
   const size_t step64 = (size_t)64 * K;
-  float4 ra[WM], rb[WN];
+  // a thread stages, per 16 k, the 4 k's at skc of its row(s); a BK = 64 slab is four such quarters (q)
+  float4 ra[KQ][WM], rb[KQ][WN];
   auto gload = [&]() {
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      ra[i] = *reinterpret_cast<const float4*>(pa[i]);
-      pa[i] += BK;
+    for (int q = 0; q < KQ; ++q) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) ra[q][i] = *reinterpret_cast<const float4*>(pa[i] + 16 * q);
+#pragma unroll
+      for (int i = 0; i < WN; ++i) rb[q][i] = *reinterpret_cast<const float4*>(pb + i * step64 + 16 * q);
     }
 #pragma unroll
-    for (int i = 0; i < WN; ++i) rb[i] = *reinterpret_cast<const float4*>(pb + i * step64);
+    for (int i = 0; i < WM; ++i) pa[i] += BK;
     pb += BK;
   };
   auto sstore = [&](int buf) {
-    float* da = lds + buf * ASZ + skc * LDA + srow;
-    float* db = lds + 2 * ASZ + buf * BSZ + skc * LDB + srow;
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      da[0 * LDA + 64 * i] = ra[i].x;
-      da[1 * LDA + 64 * i] = ra[i].y;
-      da[2 * LDA + 64 * i] = ra[i].z;
-      da[3 * LDA + 64 * i] = ra[i].w;
-    }
+    for (int q = 0; q < KQ; ++q) {
+      float* da = lds + buf * ASZ + (16 * q + skc) * LDA + srow;
+      float* db = lds + 2 * ASZ + buf * BSZ + (16 * q + skc) * LDB + srow;
 #pragma unroll
-    for (int i = 0; i < WN; ++i) {
-      db[0 * LDB + 64 * i] = rb[i].x;
-      db[1 * LDB + 64 * i] = rb[i].y;
-      db[2 * LDB + 64 * i] = rb[i].z;
-      db[3 * LDB + 64 * i] = rb[i].w;
+      for (int i = 0; i < WM; ++i) {
+        da[0 * LDA + 64 * i] = ra[q][i].x;
+        da[1 * LDA + 64 * i] = ra[q][i].y;
+        da[2 * LDA + 64 * i] = ra[q][i].z;
+        da[3 * LDA + 64 * i] = ra[q][i].w;
+      }
+#pragma unroll
+      for (int i = 0; i < WN; ++i) {
+        db[0 * LDB + 64 * i] = rb[q][i].x;
+        db[1 * LDB + 64 * i] = rb[q][i].y;
+        db[2 * LDB + 64 * i] = rb[q][i].z;
+        db[3 * LDB + 64 * i] = rb[q][i].w;
+      }
     }
   };
 
@@ -204,6 +213,12 @@ static int launch_fast(const FastArgs& g, hipStream_t s) {
   const int tiles = ((g.M + 64 * WM - 1) / (64 * WM)) * (g.N / (64 * WN));
   // tuning aid: TT_GEMM_DYNLDS=<bytes> adds unused dynamic LDS to every launch, which caps the workgroups per CU
   static const int dyn_lds = [] { const char* e = getenv("TT_GEMM_DYNLDS"); return e ? atoi(e) : 0; }();
+  static const int small_grid = [] { const char* e = getenv("TT_GEMM_SMALL_GRID"); return e ? atoi(e) : 320; }();  // tuning aid
+  if (tiles <= small_grid && g.K % 64 == 0) {   // latency-bound grid: deep slabs
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<WM, WN, 64>), dim3(tiles), dim3(256), dyn_lds, s, g);
+    TT_CHECK_LAUNCH("gemm_nt_fast");
+    return TT_OK;
+  }
   hipLaunchKernelGGL((gemm_nt_fast_kernel<WM, WN>), dim3(tiles), dim3(256), dyn_lds, s, g);
   TT_CHECK_LAUNCH("gemm_nt_fast");
   return TT_OK;

@@ -43,6 +43,9 @@ struct PlaneArgs {
   long long c_stride;
   int po;                 // number of output planes (0..3)
   int act;                // 1 = GELU
+  const float* gelu_pre;  // backward-data use: y *= gelu'(gelu_pre[m][n]) (dino_vision_transformer.py:100 through autograd) or null
+  int splits;             // split-K: grid.y slices of the reduction, slice z writes plain fp32 partials to C + z * split_stride
+  long long split_stride;
 };
 
 // x -> up to three bf16 planes with x = p0 + p1 + p2 (exact when 3 planes are taken and no exponent underflow)
@@ -87,6 +90,11 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
   const int tile = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
   const int K = g.K;
+  // split-K (weight gradients: few output tiles, long reduction): this workgroup owns slabs [kt_lo, kt_lo + nk)
+  const int nk_all = K / BK;
+  const int per = (nk_all + g.splits - 1) / g.splits;
+  const int kt_lo = blockIdx.y * per;
+  const int nk = kt_lo + per <= nk_all ? per : (nk_all > kt_lo ? nk_all - kt_lo : 0);
 
   // ---- LDS-DMA: piece i (RPI rows) of an operand plane; lane -> (row, slot), source chunk = slot ^ f(row)
   const int l_row = lane / CPR, l_slot = lane % CPR;
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
         const int chunk = l_slot ^ ((row / WIN) & (CPR - 1));
         int grow = m0 + row;
         grow = grow < g.M ? grow : g.M - 1;
-        const __bf16* src = g.A + p * g.a_stride + (size_t)grow * K + kt * BK + chunk * 8;
+        const __bf16* src = g.A + p * g.a_stride + (size_t)grow * K + (kt_lo + kt) * BK + chunk * 8;
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                          (void __attribute__((address_space(3)))*)(base + p * A_PL + piece * 1024), 16, 0, 0);
       }
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
         const int piece = wave + 4 * i, row = piece * RPI + l_row;
         if ((BN / RPI) % 4 != 0 && piece >= BN / RPI) break;   // wave-uniform
         const int chunk = l_slot ^ ((row / WIN) & (CPR - 1));
-        const __bf16* src = g.B + p * g.b_stride + (size_t)(n0 + row) * K + kt * BK + chunk * 8;
+        const __bf16* src = g.B + p * g.b_stride + (size_t)(n0 + row) * K + (kt_lo + kt) * BK + chunk * 8;
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                          (void __attribute__((address_space(3)))*)(base + P * A_PL + p * B_PL + piece * 1024), 16, 0, 0);
       }
@@ -140,7 +148,6 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
     b_sw[j] = (row / WIN) & (CPR - 1);
   }
 
-  const int nk = K / BK;
   auto compute = [&](int buf) {
     const unsigned char* base = smem + buf * BUF;
 #pragma unroll
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
   if constexpr (NBUF == 2) {
     // double buffer, one barrier per slab: the DMA of slab t+1 flies under the MFMAs of slab t and is retired by the barrier's
     // vmcnt(0)
-    issue(0, 0);
+    if (nk > 0) issue(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
@@ -237,6 +244,13 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
         }
+        if (g.gelu_pre) {
+          float pr[8];
+          *reinterpret_cast<float4*>(pr) = *reinterpret_cast<const float4*>(g.gelu_pre + off);
+          *reinterpret_cast<float4*>(pr + 4) = *reinterpret_cast<const float4*>(g.gelu_pre + off + 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(pr[e]);
+        }
         if (g.residual) {
           float rs[8];
           *reinterpret_cast<float4*>(rs) = *reinterpret_cast<const float4*>(g.residual + off);
@@ -245,8 +259,9 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
           for (int e = 0; e < 8; ++e) v[e] += rs[e];
         }
         if (g.C) {
-          *reinterpret_cast<float4*>(g.C + off) = *reinterpret_cast<const float4*>(v);
-          *reinterpret_cast<float4*>(g.C + off + 4) = *reinterpret_cast<const float4*>(v + 4);
+          float* c = g.C + (size_t)blockIdx.y * g.split_stride + off;
+          *reinterpret_cast<float4*>(c) = *reinterpret_cast<const float4*>(v);
+          *reinterpret_cast<float4*>(c + 4) = *reinterpret_cast<const float4*>(v + 4);
         }
         if (g.po > 0) {
           bf16x8 q0, q1, q2;
@@ -269,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
 template <int P, int BK, int WM, int WN, int NBUF = 2>
 static int launch_planes(const PlaneArgs& g, hipStream_t s) {
   const int tiles = ((g.M + 64 * WM - 1) / (64 * WM)) * (g.N / (64 * WN));
-  hipLaunchKernelGGL((gemm_planes_kernel<P, BK, WM, WN, NBUF>), dim3(tiles), dim3(256), 0, s, g);
+  hipLaunchKernelGGL((gemm_planes_kernel<P, BK, WM, WN, NBUF>), dim3(tiles, g.splits), dim3(256), 0, s, g);
   TT_CHECK_LAUNCH("gemm_planes");
   return TT_OK;
 }
@@ -294,9 +309,36 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   }
 }
 
+// ---- fp32 [R][C] -> bf16 [C][Rpad] (transpose; columns R..Rpad-1 zero): the operands of the backward products in the layout
+// gemm_planes_kernel reads (reduction index contiguous).  64 x 64 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int R, int C, int Rpad) {
+  __shared__ float t[64][65];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    t[i][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < Rpad) dst[(size_t)c * Rpad + r] = (__bf16)t[tx][i];
+  }
+}
+
+int launch_splitk_reduce(const float* partial, float* out, long long n, int splits, long long stride, hipStream_t s);  // gemm_f32.hip
+
 }  // namespace tt
 
 using namespace tt;
+
+extern "C" int tt_transpose_planes(const float* src, void* dst, int R, int C, int Rpad, tt_stream_t stream) {
+  TT_REQUIRE(src && dst && R > 0 && C > 0 && Rpad >= R, "transpose_planes: bad arguments");
+  hipLaunchKernelGGL(transpose_planes_kernel, dim3((Rpad + 63) / 64, (C + 63) / 64), dim3(256), 0, as_stream(stream), src,
+                     static_cast<__bf16*>(dst), R, C, Rpad);
+  TT_CHECK_LAUNCH("transpose_planes");
+  return TT_OK;
+}
 
 extern "C" int tt_split_planes(const float* src, void* dst_planes, long long plane_stride, int planes, long long n, tt_stream_t stream) {
   TT_REQUIRE(src && dst_planes && n > 0 && planes >= 1 && planes <= 3, "split_planes: bad arguments");
@@ -310,9 +352,60 @@ extern "C" int tt_split_planes(const float* src, void* dst_planes, long long pla
   return TT_OK;
 }
 
+static int linear_planes_impl(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes,
+                              const float* bias, const float* residual, float* y, float* pre_out, void* y_planes,
+                              long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, const float* gelu_pre, int splits,
+                              long long split_stride, tt_stream_t stream);
+
 extern "C" int tt_linear_fwd_planes(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes,
                                     const float* bias, const float* residual, float* y, float* pre_out, void* y_planes,
                                     long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, tt_stream_t stream) {
+  return linear_planes_impl(x_planes, x_plane_stride, w_planes, w_plane_stride, planes, bias, residual, y, pre_out, y_planes, y_plane_stride,
+                            y_nplanes, M, N, K, act, nullptr, 1, 0, stream);
+}
+
+// dx[M,K] = dy[M,N] @ w[N,K] (* gelu'(gelu_pre)): dy in planes [M][N], the weight TRANSPOSED in planes wT [K][N] (tt_transpose_planes)
+extern "C" int tt_linear_bwd_data_planes(const void* dy_planes, long long dy_plane_stride, const void* wT_planes, long long wT_plane_stride,
+                                         int planes, const float* gelu_pre, float* dx, int M, int N, int K, tt_stream_t stream) {
+  TT_REQUIRE(dx, "linear_bwd_data_planes: null output");
+  return linear_planes_impl(dy_planes, dy_plane_stride, wT_planes, wT_plane_stride, planes, nullptr, nullptr, dx, nullptr, nullptr, 0, 0, M, K, N, 0,
+                            gelu_pre, 1, 0, stream);
+}
+
+// dw[N,K] = dy[M,N]^T @ x[M,K]: both operands TRANSPOSED and zero-padded along the reduction, dyT [N][Mpad], xT [K][Mpad].
+// Split-K over Mpad (few output tiles, long reduction): partials in the workspace, folded in fixed order.
+static int wgrad_splits(int N, int K, int Mpad) {
+  const long long tiles = (long long)((N + 63) / 64) * (K / 64);
+  int s = (int)((768 + tiles - 1) / tiles);
+  const int smax = Mpad / 256;   // >= 4 slabs of 64 per slice
+  if (s > smax) s = smax;
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : s;
+}
+extern "C" size_t tt_linear_bwd_weight_planes_workspace_bytes(int N, int K, int Mpad) {
+  const int s = wgrad_splits(N, K, Mpad);
+  return s > 1 ? (size_t)s * N * K * sizeof(float) : 16;
+}
+extern "C" int tt_linear_bwd_weight_planes(const void* dyT_planes, long long dyT_plane_stride, const void* xT_planes, long long xT_plane_stride,
+                                           int planes, float* dw, int N, int K, int Mpad, void* workspace, size_t workspace_bytes,
+                                           tt_stream_t stream) {
+  TT_REQUIRE(dw && workspace, "linear_bwd_weight_planes: null pointer");
+  TT_REQUIRE(workspace_bytes >= tt_linear_bwd_weight_planes_workspace_bytes(N, K, Mpad), "linear_bwd_weight_planes: workspace too small");
+  const int s = wgrad_splits(N, K, Mpad);
+  if (s == 1)
+    return linear_planes_impl(dyT_planes, dyT_plane_stride, xT_planes, xT_plane_stride, planes, nullptr, nullptr, dw, nullptr, nullptr, 0, 0, N, K,
+                              Mpad, 0, nullptr, 1, 0, stream);
+  float* part = static_cast<float*>(workspace);
+  const int rc = linear_planes_impl(dyT_planes, dyT_plane_stride, xT_planes, xT_plane_stride, planes, nullptr, nullptr, part, nullptr, nullptr, 0, 0,
+                                    N, K, Mpad, 0, nullptr, s, (long long)N * K, stream);
+  if (rc != TT_OK) return rc;
+  return launch_splitk_reduce(part, dw, (long long)N * K, s, (long long)N * K, as_stream(stream));
+}
+
+static int linear_planes_impl(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes,
+                              const float* bias, const float* residual, float* y, float* pre_out, void* y_planes,
+                              long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, const float* gelu_pre, int splits,
+                              long long split_stride, tt_stream_t stream) {
   TT_REQUIRE(x_planes && w_planes && (y || y_planes), "linear_fwd_planes: null operand / no output");
   TT_REQUIRE(planes >= 1 && planes <= 3 && y_nplanes >= 0 && y_nplanes <= 3 && (y_nplanes == 0) == (y_planes == nullptr),
              "linear_fwd_planes: planes must be 1..3 and y_nplanes 0..3 (0 iff y_planes is null)");
@@ -321,14 +414,17 @@ extern "C" int tt_linear_fwd_planes(const void* x_planes, long long x_plane_stri
   TT_REQUIRE(aligned16(x_planes) && aligned16(w_planes) && ok16(y) && ok16(pre_out) && ok16(y_planes) && ok16(residual) && ok16(bias),
              "linear_fwd_planes: buffers must be 16-byte aligned");
   TT_REQUIRE(x_plane_stride % 8 == 0 && w_plane_stride % 8 == 0 && y_plane_stride % 8 == 0, "linear_fwd_planes: plane strides must be multiples of 8");
+  TT_REQUIRE(splits >= 1 && (splits == 1 || (y && !bias && !residual && !pre_out && !y_planes && !act && !gelu_pre)),
+             "linear_planes: a split-K launch writes plain fp32 partials only");
+  TT_REQUIRE(gelu_pre == nullptr || aligned16(gelu_pre), "linear_planes: gelu_pre must be 16-byte aligned");
   PlaneArgs g{static_cast<const __bf16*>(x_planes), static_cast<const __bf16*>(w_planes), x_plane_stride, w_plane_stride, M, N, K, bias, residual, y,
-              pre_out, static_cast<__bf16*>(y_planes), y_plane_stride, y_nplanes, act};
+              pre_out, static_cast<__bf16*>(y_planes), y_plane_stride, y_nplanes, act, gelu_pre, splits, split_stride};
   hipStream_t s = as_stream(stream);
   // tile: 128 x 128 when the grid still fills the chip more than twice over, else 64-row / 64-column tiles (ViT-S/16's N = 384
   // products: 1182 instead of 591 workgroups)
   const long long t128 = (long long)((M + 127) / 128) * (N / 128);
-  const bool big = (N % 128 == 0) && t128 >= 3 * 256;
-  const bool wide = (N % 128 == 0);
+  const bool big = (N % 128 == 0) && t128 * splits >= 3 * 256;
+  const bool wide = (N % 128 == 0) && (long long)((M + 63) / 64) * (N / 128) * splits >= 2 * 256;
   static const int variant = [] { const char* e = getenv("TT_PLANES_VARIANT"); return e ? atoi(e) : 0; }();  // tuning aid
   switch (planes) {
     case 1:

@@ -728,3 +728,55 @@ def attention_fwd_bf16(qkv, num_heads: int):
     out = torch.empty((F, N, D), dtype=bf16, device=qkv.device)
     _lib.check(lib.tt_attention_fwd_bf16(_p(qkv), _p(out), F, N, num_heads, hd, float(hd ** -0.5), _stream()), "tt_attention_fwd_bf16")
     return out
+
+
+def transpose_planes(x, rpad: Optional[int] = None):
+    """fp32 [R, C] -> bf16 [1, C, Rpad] (transposed, zero-padded along R to a multiple of 64 by default)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    R, Cc = x.shape
+    rpad = (R + 63) // 64 * 64 if rpad is None else rpad
+    y = torch.empty((1, Cc, rpad), dtype=bf16, device=x.device)
+    _lib.check(lib.tt_transpose_planes(_p(x), _p(y), R, Cc, rpad, _stream()), "tt_transpose_planes")
+    return y
+
+
+def bwd_planes_ok(M: int, N: int, K: int) -> bool:
+    """Shapes the bf16 backward products take (dy [M,N], w [N,K]): whole 64-wide tiles along N and K."""
+    return N % 64 == 0 and K % 64 == 0
+
+
+def linear_bwd_data_planes(dy, w, gelu_pre=None):
+    """dx = dy @ w (* gelu'(gelu_pre)) on bf16 operands: dy [M,N] and w [N,K] fp32 are converted here (dy rounded, w
+    transposed), fp32 accumulate and output."""
+    lib = _lib.load()
+    _chk(dy, "dy"); _chk(w, "w")
+    M, N = dy.shape
+    K = w.shape[1]
+    dyp = split_planes(dy, 1)
+    wT = transpose_planes(w, N)                      # [1, K, N]
+    dx = torch.empty((M, K), dtype=f32, device=dy.device)
+    if gelu_pre is not None: _chk(gelu_pre, "gelu_pre")
+    e0 = _prof_begin()
+    _lib.check(lib.tt_linear_bwd_data_planes(_p(dyp), M * N, _p(wT), K * N, 1, _p(gelu_pre), _p(dx), M, N, K, _stream()),
+               "tt_linear_bwd_data_planes")
+    _prof_end(e0, "PLANES1", M, K, N)
+    return dx
+
+
+def linear_bwd_weight_planes(dy, x, need_bias=True):
+    """dw = dy.T @ x on bf16 operands (both transposed + rounded here), db = dy.sum(0) in fp32."""
+    lib = _lib.load()
+    _chk(dy, "dy"); _chk(x, "x")
+    M, N = dy.shape
+    K = x.shape[1]
+    dyT, xT = transpose_planes(dy), transpose_planes(x)      # [1, N, Mpad], [1, K, Mpad]
+    Mpad = dyT.shape[2]
+    dw = torch.empty((N, K), dtype=f32, device=dy.device)
+    nb = lib.tt_linear_bwd_weight_planes_workspace_bytes(N, K, Mpad)
+    ws = _ws(nb, dy.device)
+    e0 = _prof_begin()
+    _lib.check(lib.tt_linear_bwd_weight_planes(_p(dyT), N * Mpad, _p(xT), K * Mpad, 1, _p(dw), N, K, Mpad, _p(ws), nb, _stream()),
+               "tt_linear_bwd_weight_planes")
+    _prof_end(e0, "PLANES1", N, K, Mpad)
+    return dw, (colsum(dy) if need_bias else None)
