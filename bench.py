@@ -49,7 +49,8 @@ def kernel_label(name, tile):
         return f"gemm_nt_bf16_kernel<{TILE_NAMES[tile]}> (forward nn.Linear, fp32 operands converted while staged)"
     if name.startswith("PLANES"):
         return f"gemm_planes_kernel<P={name[6:]}> (forward nn.Linear on bf16-plane operands)"
-    return f"gemm_f32_kernel<{TILE_NAMES[tile]},{name}>"
+    fam = {"NN": "dgrad (dy @ w)", "TN": "wgrad (dy^T @ x, split-K)", "patch": "patch embed", "NTgen": "forward nn.Linear, general kernel"}.get(name, name)
+    return f"gemm f32 {TILE_NAMES[tile]}: {fam}"
 
 
 def build_model(arch, K, device, teacher=False, queue=0, world=1):
@@ -404,7 +405,12 @@ def main():
                          "frac": round(flops / sec / 1e12 / peak, 4), "traffic": traffic,
                          "avg_launch_us": round(sec / cnt * 1e6, 2),
                          "all_gemm_tflops": round(all_flops / all_sec / 1e12, 2),
-                         "gemm_share_of_step": round(all_sec / (elapsed / a.steps), 3)},
+                         "gemm_share_of_step": round(all_sec / (elapsed / a.steps), 3),
+                         # every GEMM family of the step (forward Linears, dgrad "NN", wgrad "TN", patch embed, plane kernels): launches,
+                         # achieved TFLOP/s on algorithmic flops, share of the step - the dominant one is the roofline kernel above
+                         "by_kernel": {kernel_label(nm, tl): {"launches": c_, "tflops": round(f_ / s_ / 1e12, 1),
+                                                              "share_of_step": round(s_ / (elapsed / a.steps), 3)}
+                                       for (nm, tl), (c_, f_, s_) in sorted(prof.items(), key=lambda kv: -kv[1][2])}},
             "alt_precision": alt or None,
             "sinkhorn": None if sk_rate is None else {"iters_per_sec": round(sk_rate, 1), "algorithmic_GBps": round(sk_gbs, 1),
                                                       "shape": "K=200 x B=6272, 10 iterations"},

@@ -245,3 +245,21 @@ def test_ddp_wrapper_checkpoint_keys_match_the_reference(tmp_path):
     ddp.load_state_dict(torch.load(path)["model"])                      # strict
     assert torch.equal(inner.prototypes.detach(), ref_style["model.module.prototypes"])
     assert ddp.get_non_ddp_model() is inner and ddp.prototypes is inner.prototypes
+
+
+def test_kmeans_empty_cluster_split_terminates():
+    """faiss' donor loop has no accepting donor when n == k or every cluster holds one point; it must not spin."""
+    import numpy as np
+    import torch
+
+    from timetuning_amd.clustering import Kmeans
+
+    km = Kmeans.__new__(Kmeans)
+    cent = torch.arange(12.0).view(4, 3).clone()
+    before = cent.clone()
+    counts = np.array([1, 0, 1, 1])
+    assert km._split_empty(cent, counts, 4) == 0 and torch.equal(cent, before)          # n == k: nothing to split
+    counts = np.array([1, 0, 1, 1])
+    assert km._split_empty(cent, counts, 9) == 0                                        # all singletons
+    counts = np.array([5, 0, 1, 1])
+    assert km._split_empty(cent, counts, 7) == 1 and counts.tolist() == [3, 2, 1, 1]    # the populated donor is split

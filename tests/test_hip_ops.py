@@ -437,3 +437,19 @@ def test_linear_precision_modes(ops, M, N, K):
     assert errs["f32"] < TOL
     assert errs["bf16x3"] < 1e-4, errs     # ~2^-16 per product, averaged over K
     assert errs["f32"] < errs["bf16x3"] < errs["bf16"] < 2e-2, errs
+
+
+def test_label_propagation_with_exact_ties(ops):
+    """identical tokens (flat frames) tie EXACTLY, so "top-k plus ties" keeps every windowed source; the propagated
+    map must still be normalised (columns of aff sum to 1 -> each query's map sums to the seed's row sum) and equal the oracle."""
+    from oracle import timet_oracle as O
+
+    fs, bs, g, D, K = 3, 1, 14, 32, 6
+    n = g * g
+    tok = torch.ones(fs, bs, n, D) / D ** 0.5                                   # every token identical, unit norm
+    seed = torch.softmax(torch.from_numpy(synth.normal("ties.seed", (bs, n, K))) * 2, dim=-1)
+    labels, pmap = ops.label_propagate(dev(tok), dev(seed.float()), 7, 6, 5, 0.1, return_pmap=True)
+    assert torch.allclose(pmap.sum(-1).cpu(), torch.ones(bs, n, dtype=torch.float64), atol=1e-5)
+    omaps = O.propagate_labels(7, 6, 5, g, tok[:, 0].clone(), seed[0].view(g, g, K).permute(2, 0, 1).unsqueeze(0))
+    want = omaps[-1].reshape(K, n).t()
+    assert rel_err(pmap[0].cpu(), want) < 1e-5

@@ -33,8 +33,9 @@ from . import hip_ops as ops
 # ------------------------------------------------------------------------------------------------
 
 def fit_scaler_pca(feats: torch.Tensor, pca_dim: int):
-    """feats [n, dim] on the GPU -> (scale_mul [dim], scale_shift [dim], basis [pca_dim, dim]) such that
-    ``((feats * scale_mul + scale_shift) @ basis.T)`` is ``normalize_and_transform(feats, pca_dim)``."""
+    """feats [n, dim] on the GPU -> (scale_mul [dim], scale_shift [dim], z_mean [dim], basis [pca_dim, dim], z [n, dim]) with
+    ``z = feats * scale_mul + scale_shift`` (the standardised features) such that ``(z - z_mean) @ basis.T`` is
+    ``normalize_and_transform(feats, pca_dim)``."""
     n, dim = feats.shape
     mean, var = ops.col_moments(feats)
     scale = var.sqrt()
@@ -91,12 +92,18 @@ class Kmeans:
         for ci in range(k):
             if counts[ci] != 0:
                 continue
-            cj = 0
+            if n <= k or counts.max() <= 1:
+                break   # nothing left to split (n == k, or every cluster holds at most one point): faiss' loop would never accept
+            cj, tries = 0, 0
             while True:  # (counts[cj] - 1) / (n - k) acceptance, as faiss
                 p = (counts[cj] - 1.0) / float(n - k)
                 if rng.random_sample() < p:
                     break
                 cj = (cj + 1) % k
+                tries += 1
+                if tries > 64 * k:   # vanishing acceptance (duplicates everywhere): take the largest cluster instead of spinning
+                    cj = int(np.argmax(counts))
+                    break
             cent[ci] = cent[cj] * sign
             cent[cj] = cent[cj] * (2.0 - sign)
             counts[ci] = counts[cj] // 2

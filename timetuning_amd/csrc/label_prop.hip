@@ -21,7 +21,9 @@ constexpr int LP_MAXC = 8;      // context frames (frame 0 + n_last_frames <= 7)
 // candidates per thread (template parameter of the kernel): 8 covers the training protocol (13x13 window x 8 context
 // frames = 1352 <= 2048); 16 covers the DAVIS evaluation protocol on the 28x28 grid (25x25 window x 5 frames = 3125)
 constexpr int LP_CAND_MAX = 16;
-constexpr int LP_MAXKEEP = 64;  // kept sources per query (top-k plus ties)
+// kept sources per query = top-k plus ties: normally topk (5), but EVERY candidate on degenerate inputs (identical tokens on flat
+// frames tie exactly) - the keep list holds all LP_CAND * 256 candidates a block examines, so nothing is ever dropped and
+// aff / aff.sum(0) stays normalised (the former 64-entry list silently truncated such rows)
 
 struct LpArgs {
   const float* sims;        // [bs][c][n][n]  (target, source)
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(256) void label_prop_kernel(LpArgs a) {
   __shared__ int s_idx[4];
   __shared__ int s_cnt[4];
   __shared__ float s_sum[4];
+  constexpr int LP_MAXKEEP = LP_CAND * 256;
   __shared__ int keep_src[LP_MAXKEEP];   // ctx * n + source patch
   __shared__ float keep_w[LP_MAXKEEP];
   __shared__ double s_best[4];
