@@ -13,7 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "tt_cpu.c")
 OUT = os.path.join(HERE, "_build", "libtt_cpu.so")
 TWINS = ["sinkhorn", "ce_loss_fwd_bwd", "img_resample_h", "img_resample_v", "img_color", "img_box_blur", "confusion_counts",
-         "upsample_argmax", "kmeans_assign", "col_moments"]
+         "upsample_argmax", "kmeans_assign", "col_moments",
+         # round 2: the hot path's row ops and (naive) matrix products
+         "linear_fwd", "linear_bwd_data", "linear_bwd_weight", "layernorm_fwd", "l2norm_fwd", "normalize_rows_inplace", "attention_fwd",
+         "adamw_step", "ema_update", "queue_push", "scale_rows_inplace", "sinkhorn_from_q", "split_planes", "count_mismatch"]
 _lib = None
 
 

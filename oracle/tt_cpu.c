@@ -4,7 +4,8 @@
  * workspace arguments are accepted and ignored), so that one ctypes prototype drives either side.  They cover the ops whose
  * arithmetic is integer / byte exact (the Pillow-defined image transforms, the confusion matrix) or a short, order-defined
  * float recurrence (Sinkhorn-Knopp, cross-entropy, arg-max of a bilinear upsampling, nearest-centroid assignment, column
- * moments).  The GEMM / attention / propagation ops have their restatement in oracle/timet_oracle.py (torch-CPU).
+ * moments) and - second half of the file, round 2 - the hot path's row ops and naive matrix products.  Label propagation, the
+ * backward of attention / LayerNorm and the foreground mask have their restatement in oracle/timet_oracle.py (torch-CPU) only.
  *
  * Built by __graft_entry__.build() (gcc -O2 -shared) into oracle/_build/libtt_cpu.so; only tests/ load it.  Every function
  * cites the reference lines (paths relative to /root/reference) or the third-party algorithm it restates. */
@@ -276,5 +277,232 @@ int tt_cpu_col_moments(const float* x, double* mean, double* var, long long rows
     const double v = s2 / (double)rows - mean[c] * mean[c];
     var[c] = v > 0 ? v : 0;
   }
+  return 0;
+}
+
+/* =====================================================================================================================
+ * Round 2: twins of the hot path's row ops and (naive, small sizes) of its matrix products.  double accumulation where the
+ * device kernels use fp32 chains: the tests compare at the f32-MFMA bound (2e-5 relative), not bit for bit.
+ * ===================================================================================================================== */
+
+static float tt_cpu_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+static float tt_cpu_gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+/* ---- nn.Linear forward (dino_vision_transformer.py:94-103,115-130; models.py:915-926): y = act(x w^T + b) (+ residual) */
+int tt_cpu_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, float* pre_act, int M, int N,
+                      int K, int act, tt_stream_t stream) {
+  (void)stream;
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < N; ++n) {
+      double s = bias ? (double)bias[n] : 0.0;
+      for (int k = 0; k < K; ++k) s += (double)x[(size_t)m * K + k] * (double)w[(size_t)n * K + k];
+      float v = (float)s;
+      if (pre_act) pre_act[(size_t)m * N + n] = v;
+      if (act == 1) v = tt_cpu_gelu(v);
+      if (residual) v += residual[(size_t)m * N + n];
+      y[(size_t)m * N + n] = v;
+    }
+  return 0;
+}
+
+/* ---- autograd of the above: dx = dy w (* gelu'(pre)); dw = dy^T x, db = colsum(dy) */
+int tt_cpu_linear_bwd_data(const float* dy, const float* w, const float* gelu_pre, float* dx, int M, int N, int K, tt_stream_t stream) {
+  (void)stream;
+  for (int m = 0; m < M; ++m)
+    for (int k = 0; k < K; ++k) {
+      double s = 0.0;
+      for (int n = 0; n < N; ++n) s += (double)dy[(size_t)m * N + n] * (double)w[(size_t)n * K + k];
+      float v = (float)s;
+      if (gelu_pre) v *= tt_cpu_gelu_grad(gelu_pre[(size_t)m * K + k]);
+      dx[(size_t)m * K + k] = v;
+    }
+  return 0;
+}
+int tt_cpu_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, void* workspace,
+                             size_t workspace_bytes, tt_stream_t stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  for (int n = 0; n < N; ++n) {
+    for (int k = 0; k < K; ++k) {
+      double s = 0.0;
+      for (int m = 0; m < M; ++m) s += (double)dy[(size_t)m * N + n] * (double)x[(size_t)m * K + k];
+      dw[(size_t)n * K + k] = (float)s;
+    }
+    if (db) {
+      double s = 0.0;
+      for (int m = 0; m < M; ++m) s += (double)dy[(size_t)m * N + n];
+      db[n] = (float)s;
+    }
+  }
+  return 0;
+}
+
+/* ---- nn.LayerNorm(eps) (dino_vision_transformer.py:139,143,196); skip_group = N drops token 0 of every group of N rows
+ *      (the cls token, models.py:967) */
+int tt_cpu_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int rows, int D,
+                         float eps, int skip_group, tt_stream_t stream) {
+  (void)stream;
+  for (int r = 0; r < rows; ++r) {
+    const long long in_row = skip_group ? (long long)(r / (skip_group - 1)) * skip_group + 1 + r % (skip_group - 1) : r;
+    const float* xr = x + in_row * D;
+    double mu = 0.0, var = 0.0;
+    for (int c = 0; c < D; ++c) mu += xr[c];
+    mu /= D;
+    for (int c = 0; c < D; ++c) var += (xr[c] - mu) * (xr[c] - mu);
+    const double rs = 1.0 / sqrt(var / D + (double)eps);
+    for (int c = 0; c < D; ++c) y[(size_t)r * D + c] = (float)((xr[c] - mu) * rs * gamma[c] + beta[c]);
+    if (mean) mean[r] = (float)mu;
+    if (rstd) rstd[r] = (float)rs;
+  }
+  return 0;
+}
+
+/* ---- F.normalize(x, dim=-1) (time_tuning.py:136) and the in-place prototype renormalisation (:124-128); eps 1e-12 */
+int tt_cpu_l2norm_fwd(const float* x, int ldx, float* xn, float* inv_norm, int rows, int D, tt_stream_t stream) {
+  (void)stream;
+  for (int r = 0; r < rows; ++r) {
+    double s = 0.0;
+    for (int c = 0; c < D; ++c) s += (double)x[(size_t)r * ldx + c] * (double)x[(size_t)r * ldx + c];
+    const double nrm = sqrt(s);
+    const float inv = (float)(1.0 / (nrm > 1e-12 ? nrm : 1e-12));
+    for (int c = 0; c < D; ++c) xn[(size_t)r * D + c] = x[(size_t)r * ldx + c] * inv;
+    if (inv_norm) inv_norm[r] = inv;
+  }
+  return 0;
+}
+int tt_cpu_normalize_rows_inplace(float* w, int rows, int D, tt_stream_t stream) { return tt_cpu_l2norm_fwd(w, D, w, NULL, rows, D, stream); }
+
+/* ---- Attention.forward between the qkv and proj Linears (dino_vision_transformer.py:122-129): softmax(q k^T scale) v per
+ *      (frame, head); qkv [F, N, 3 H hd] as the Linear wrote it; optional lse [F,H,N] and probs [F,H,N,N] */
+int tt_cpu_attention_fwd(const float* qkv, float* out, float* lse, float* probs, int F, int N, int H, int hd, float scale,
+                         tt_stream_t stream) {
+  (void)stream;
+  const int D = H * hd, D3 = 3 * D;
+  double* p = (double*)malloc((size_t)N * sizeof(double));
+  if (!p) return -3;
+  for (int f = 0; f < F; ++f)
+    for (int h = 0; h < H; ++h)
+      for (int i = 0; i < N; ++i) {
+        const float* q = qkv + ((size_t)f * N + i) * D3 + h * hd;
+        double mx = -INFINITY;
+        for (int j = 0; j < N; ++j) {
+          const float* k = qkv + ((size_t)f * N + j) * D3 + D + h * hd;
+          double s = 0.0;
+          for (int d = 0; d < hd; ++d) s += (double)q[d] * (double)k[d];
+          p[j] = s * scale;
+          if (p[j] > mx) mx = p[j];
+        }
+        double sum = 0.0;
+        for (int j = 0; j < N; ++j) { p[j] = exp(p[j] - mx); sum += p[j]; }
+        if (lse) lse[((size_t)f * H + h) * N + i] = (float)(mx + log(sum));
+        for (int j = 0; j < N; ++j) {
+          p[j] /= sum;
+          if (probs) probs[(((size_t)f * H + h) * N + i) * N + j] = (float)p[j];
+        }
+        for (int d = 0; d < hd; ++d) {
+          double o = 0.0;
+          for (int j = 0; j < N; ++j) o += p[j] * (double)qkv[((size_t)f * N + j) * D3 + 2 * D + h * hd + d];
+          out[((size_t)f * N + i) * D + h * hd + d] = (float)o;
+        }
+      }
+  free(p);
+  return 0;
+}
+
+/* ---- torch.optim.AdamW step as SwavOptimizer drives it (time_tuning.py:413-429): decoupled decay, bias-corrected moments */
+typedef struct { float* p; const float* g; float* m; float* v; long long n; float lr; float weight_decay; } tt_cpu_adamw_tensor;
+int tt_cpu_adamw_step(const tt_cpu_adamw_tensor* tensors, int count, int step, float beta1, float beta2, float eps, tt_stream_t stream) {
+  (void)stream;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  for (int t = 0; t < count; ++t) {
+    const tt_cpu_adamw_tensor a = tensors[t];
+    for (long long i = 0; i < a.n; ++i) {
+      const float g = a.g[i];
+      float p = a.p[i] * (1.0f - a.lr * a.weight_decay);
+      const float m = a.m[i] + (g - a.m[i]) * (1.0f - beta1);
+      const float v = a.v[i] * beta2 + (1.0f - beta2) * g * g;
+      const float denom = sqrtf(v) / (float)sqrt(bc2) + eps;
+      p -= (a.lr / (float)bc1) * (m / denom);
+      a.p[i] = p; a.m[i] = m; a.v[i] = v;
+    }
+  }
+  return 0;
+}
+
+/* ---- time_tuning.py:113-115: teacher = teacher * (1 - m) + student * m */
+int tt_cpu_ema_update(float* teacher, const float* student, long long n, double momentum, tt_stream_t stream) {
+  (void)stream;
+  const float m = (float)momentum, om = (float)(1.0 - momentum);
+  for (long long i = 0; i < n; ++i) teacher[i] = teacher[i] * om + student[i] * m;
+  return 0;
+}
+
+/* ---- time_tuning.py:250-261: queue[m:] = queue[:-m]; queue[:m] = feats[idx] */
+int tt_cpu_queue_push(float* queue, float* scratch, const float* feats, const int64_t* idx, int Q, int D, int m, tt_stream_t stream) {
+  (void)stream;
+  for (int r = 0; r < Q; ++r)
+    for (int c = 0; c < D; ++c)
+      scratch[(size_t)r * D + c] = (r < m) ? feats[(size_t)idx[r] * D + c] : queue[(size_t)(r - m) * D + c];
+  memcpy(queue, scratch, (size_t)Q * D * sizeof(float));
+  return 0;
+}
+
+/* ---- features * mask (models.py:142) */
+int tt_cpu_scale_rows_inplace(float* x, const float* row_scale, int rows, int cols, tt_stream_t stream) {
+  (void)stream;
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) x[(size_t)r * cols + c] *= row_scale[r];
+  return 0;
+}
+
+/* ---- my_utils.sinkhorn(Q, nmb_iters) on the positive matrix itself (my_utils.py:246-274): Q [K][B] (transposed = 0) or [B][K] */
+int tt_cpu_sinkhorn_from_q(const float* Qin, int transposed, float* q_out, int B_total, int K, int row0, int rows_out, int iters,
+                           void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  const size_t n = (size_t)B_total * K;
+  float* s = (float*)malloc(n * sizeof(float));   /* log of the matrix in [B][K] layout: reuse the scores twin with eps = 1 */
+  if (!s) return -3;
+  for (int b = 0; b < B_total; ++b)
+    for (int k = 0; k < K; ++k) s[(size_t)b * K + k] = logf(transposed ? Qin[(size_t)b * K + k] : Qin[(size_t)k * B_total + b]);
+  const int rc = tt_cpu_sinkhorn(s, q_out, B_total, K, row0, rows_out, 1.0f, iters, workspace, workspace_bytes, stream);
+  free(s);
+  return rc;
+}
+
+/* ---- fp32 -> bf16 planes (round to nearest even), x = p0 + p1 + p2 */
+static uint16_t tt_cpu_bf16(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   /* NaN stays NaN */
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float tt_cpu_bf16_to_f32(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float v;
+  memcpy(&v, &u, 4);
+  return v;
+}
+int tt_cpu_split_planes(const float* src, void* dst_planes, long long plane_stride, int planes, long long n, tt_stream_t stream) {
+  (void)stream;
+  uint16_t* d = (uint16_t*)dst_planes;
+  for (long long i = 0; i < n; ++i) {
+    float r = src[i];
+    for (int p = 0; p < planes; ++p) {
+      const uint16_t h = tt_cpu_bf16(r);
+      d[p * plane_stride + i] = h;
+      r -= tt_cpu_bf16_to_f32(h);
+    }
+  }
+  return 0;
+}
+
+/* ---- positions where two fp32 buffers differ bitwise */
+int tt_cpu_count_mismatch(const float* a, const float* b, long long n, long long* count_out, tt_stream_t stream) {
+  (void)stream;
+  long long c = 0;
+  for (long long i = 0; i < n; ++i) c += memcmp(a + i, b + i, 4) != 0;
+  *count_out = c;
   return 0;
 }

@@ -148,3 +148,191 @@ def test_hip_library_equals_its_cpu_twin(twin):
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
     assert hip.tt_sinkhorn(d_sc.data_ptr(), d_q.data_ptr(), 392, 50, 0, 392, 0.05, 10, ws.data_ptr(), nb, st) == 0
     assert np.abs(d_q.cpu().numpy() - q_cpu).max() < 5e-5 * q_cpu.max()
+
+
+# ---- round 2: the hot path's row ops and (naive) matrix products ------------------------------------------------------------
+
+class _Side:
+    """One call site for both libraries: ``run(name, *args)`` calls ``<prefix><name>`` with numpy arrays passed as host pointers
+    (twin) or as device copies (HIP); arrays listed in ``outs`` are copied back after the call."""
+
+    def __init__(self, lib, prefix, device=None):
+        self.lib, self.prefix, self.device = lib, prefix, device
+
+    def run(self, name, *args, outs=()):
+        fn = getattr(self.lib, self.prefix + name)
+        if self.device is None:
+            rc = fn(*[ptr(a) if isinstance(a, np.ndarray) else a for a in args])
+            assert rc == 0, (name, rc)
+            return
+        dev = {}
+        conv = []
+        for a in args:
+            if isinstance(a, np.ndarray):
+                t = torch.from_numpy(a).to(self.device)
+                dev[id(a)] = (a, t)
+                conv.append(t.data_ptr())
+            elif a == "STREAM":
+                conv.append(torch.cuda.current_stream().cuda_stream)
+            else:
+                conv.append(a)
+        rc = fn(*conv)
+        assert rc == 0, (name, rc, self.lib.tt_last_error() if hasattr(self.lib, "tt_last_error") else "")
+        torch.cuda.synchronize()
+        for o in outs:
+            o[...] = dev[id(o)][1].cpu().numpy()
+
+
+def _round2_cases(side, tol):
+    """Runs every round-2 twin op on ``side`` and returns the results; the caller compares them with a reference."""
+    st = "STREAM" if side.device else None
+    rng = np.random.default_rng(7)
+    f32 = lambda *s, scale=1.0: (rng.standard_normal(s) * scale).astype(np.float32)
+    R = {}
+    # Linear forward / backward
+    M, N, K = 70, 64, 48
+    x, w, b, res = f32(M, K), f32(N, K, scale=0.1), f32(N), f32(M, N)
+    y, pre = np.empty((M, N), np.float32), np.empty((M, N), np.float32)
+    side.run("linear_fwd", x, w, b, res, y, pre, M, N, K, 1, st, outs=(y, pre))
+    R["linear_fwd"] = (x, w, b, res, y.copy(), pre.copy())
+    dy, gp = f32(M, N), f32(M, K)
+    dx = np.empty((M, K), np.float32)
+    side.run("linear_bwd_data", dy, w, gp, dx, M, N, K, st, outs=(dx,))
+    dw, db = np.empty((N, K), np.float32), np.empty(N, np.float32)
+    nb = 1 << 22
+    ws = np.empty(nb, np.uint8)
+    side.run("linear_bwd_weight", dy, x, dw, db, M, N, K, ws, nb, st, outs=(dw, db))
+    R["linear_bwd"] = (dy, gp, dx.copy(), dw.copy(), db.copy())
+    # LayerNorm (with and without the cls-dropping row map), l2norm, prototype renormalisation
+    Fr, Nt, D = 3, 5, 40
+    xl, g, be = f32(Fr, Nt, D), 1 + 0.1 * f32(D), 0.1 * f32(D)
+    yl, mu, rs = np.empty((Fr * Nt, D), np.float32), np.empty(Fr * Nt, np.float32), np.empty(Fr * Nt, np.float32)
+    side.run("layernorm_fwd", xl, g, be, yl, mu, rs, Fr * Nt, D, 1e-6, 0, st, outs=(yl, mu, rs))
+    yd = np.empty((Fr * (Nt - 1), D), np.float32)
+    side.run("layernorm_fwd", xl, g, be, yd, None, None, Fr * (Nt - 1), D, 1e-6, Nt, st, outs=(yd,))
+    R["layernorm"] = (xl, g, be, yl.copy(), mu.copy(), rs.copy(), yd.copy())
+    xn, inv = np.empty((M, K), np.float32), np.empty(M, np.float32)
+    side.run("l2norm_fwd", x, K, xn, inv, M, K, st, outs=(xn, inv))
+    wn = w.copy()
+    side.run("normalize_rows_inplace", wn, N, K, st, outs=(wn,))
+    R["l2norm"] = (xn.copy(), inv.copy(), wn.copy())
+    # attention forward: out, lse and probabilities
+    Fa, Na, H = 2, 37, 2
+    qkv = f32(Fa, Na, 3 * H * 64, scale=0.5)
+    out, lse, probs = np.empty((Fa, Na, H * 64), np.float32), np.empty((Fa, H, Na), np.float32), np.empty((Fa, H, Na, Na), np.float32)
+    side.run("attention_fwd", qkv, out, lse, probs, Fa, Na, H, 64, 0.125, st, outs=(out, lse, probs))
+    R["attention"] = (qkv, out.copy(), lse.copy(), probs.copy())
+    # EMA, queue push, row scaling, sinkhorn on the positive matrix, bf16 planes, mismatch count
+    t, s = f32(1000), f32(1000)
+    t2 = t.copy()
+    side.run("ema_update", t2, s, 1000, 0.37, st, outs=(t2,))
+    queue, feats, idx = f32(20, 8), f32(30, 8), rng.permutation(30)[:6].astype(np.int64)
+    q2, scratch = queue.copy(), np.empty_like(queue)
+    side.run("queue_push", q2, scratch, feats, idx, 20, 8, 6, st, outs=(q2,))
+    xs, sc = x.copy(), (rng.random(M) < 0.5).astype(np.float32)
+    side.run("scale_rows_inplace", xs, sc, M, K, st, outs=(xs,))
+    R["misc"] = (t, s, t2.copy(), queue, feats, idx, q2.copy(), sc, xs.copy())
+    scores = f32(96, 24, scale=0.2)
+    Qkb = np.ascontiguousarray(np.exp(scores / 0.05).T)
+    q_a, q_b = np.empty((96, 24), np.float32), np.empty((40, 24), np.float32)
+    nbs = 1 << 20
+    wss = np.empty(nbs, np.uint8)
+    side.run("sinkhorn_from_q", Qkb, 0, q_a, 96, 24, 0, 96, 5, wss, nbs, st, outs=(q_a,))
+    side.run("sinkhorn_from_q", np.ascontiguousarray(Qkb.T), 1, q_b, 96, 24, 16, 40, 5, wss, nbs, st, outs=(q_b,))
+    R["sinkhorn_from_q"] = (scores, q_a.copy(), q_b.copy())
+    v = f32(64, 40, scale=3.0)
+    planes = np.empty((3, 64, 40), np.uint16)
+    side.run("split_planes", v, planes, 64 * 40, 3, 64 * 40, st, outs=(planes,))
+    a1, a2 = f32(777), None
+    a2 = a1.copy()
+    a2[[5, 99, 700]] += 1.0
+    cnt = np.zeros(1, np.int64)
+    side.run("count_mismatch", a1, a2, 777, cnt, st, outs=(cnt,))
+    R["planes"] = (v, planes.copy(), int(cnt[0]))
+    # AdamW (table of two tensors, step 3)
+    import ctypes as C2
+    from timetuning_amd._lib import AdamwTensor
+    p0, g0, m0, v0 = f32(500), f32(500), f32(500, scale=0.1), np.abs(f32(500, scale=0.1))
+    p1, g1, m1, v1 = f32(33), f32(33), f32(33, scale=0.1), np.abs(f32(33, scale=0.1))
+    arrs = [a.copy() for a in (p0, g0, m0, v0, p1, g1, m1, v1)]
+    if side.device is None:
+        tab = (AdamwTensor * 2)(AdamwTensor(arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data, 500, 1e-3, 0.1),
+                                AdamwTensor(arrs[4].ctypes.data, arrs[5].ctypes.data, arrs[6].ctypes.data, arrs[7].ctypes.data, 33, 1e-2, 0.0))
+        assert side.lib.tt_cpu_adamw_step(tab, 2, 3, 0.9, 0.999, 1e-8, None) == 0
+        res_ad = [a.copy() for a in arrs]
+    else:
+        dts = [torch.from_numpy(a).cuda() for a in arrs]
+        tab = (AdamwTensor * 2)(AdamwTensor(dts[0].data_ptr(), dts[1].data_ptr(), dts[2].data_ptr(), dts[3].data_ptr(), 500, 1e-3, 0.1),
+                                AdamwTensor(dts[4].data_ptr(), dts[5].data_ptr(), dts[6].data_ptr(), dts[7].data_ptr(), 33, 1e-2, 0.0))
+        assert side.lib.tt_adamw_step(tab, 2, 3, 0.9, 0.999, 1e-8, torch.cuda.current_stream().cuda_stream) == 0
+        res_ad = [d.cpu().numpy() for d in dts]
+    R["adamw"] = ((p0, g0, m0, v0, p1, g1, m1, v1), res_ad)
+    return R
+
+
+def _re(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(np.asarray(b, np.float64)).max(), 1e-30))
+
+
+def test_round2_twins_against_torch(twin):
+    """The new C twins against torch fp64 / NumPy restatements of the reference ops they cite."""
+    R = _round2_cases(_Side(twin, "tt_cpu_"), 1e-6)
+    x, w, b, res, y, pre = R["linear_fwd"]
+    ref_pre = x.astype(np.float64) @ w.astype(np.float64).T + b
+    assert _re(pre, ref_pre) < 1e-6 and _re(y, F.gelu(torch.from_numpy(ref_pre)).numpy() + res) < 1e-6
+    dy, gp, dx, dw, db = R["linear_bwd"]
+    gpt = torch.from_numpy(gp).double().requires_grad_(True)
+    F.gelu(gpt).sum().backward()
+    assert _re(dx, (dy.astype(np.float64) @ w.astype(np.float64)) * gpt.grad.numpy()) < 1e-6
+    assert _re(dw, dy.astype(np.float64).T @ x.astype(np.float64)) < 1e-6 and _re(db, dy.astype(np.float64).sum(0)) < 1e-6
+    xl, g, be, yl, mu, rs, yd = R["layernorm"]
+    ref = F.layer_norm(torch.from_numpy(xl).double(), (xl.shape[-1],), torch.from_numpy(g).double(), torch.from_numpy(be).double(), 1e-6).numpy()
+    assert _re(yl, ref.reshape(yl.shape)) < 1e-6 and _re(yd, ref[:, 1:].reshape(yd.shape)) < 1e-6
+    assert _re(mu, xl.astype(np.float64).mean(-1).reshape(-1)) < 1e-6
+    xn, inv, wn = R["l2norm"]
+    assert _re(xn, F.normalize(torch.from_numpy(x).double(), dim=1).numpy()) < 1e-6
+    assert _re(wn, F.normalize(torch.from_numpy(w).double(), dim=1).numpy()) < 1e-6
+    qkv, out, lse, probs = R["attention"]
+    Fa, Na, D3 = qkv.shape
+    q, k, v = torch.from_numpy(qkv).double().view(Fa, Na, 3, 2, 64).permute(2, 0, 3, 1, 4)
+    s_ = q @ k.transpose(-1, -2) * 0.125
+    p = torch.softmax(s_, -1)
+    assert _re(probs, p.numpy()) < 1e-6 and _re(lse, torch.logsumexp(s_, -1).numpy()) < 1e-6
+    assert _re(out, (p @ v).permute(0, 2, 1, 3).reshape(Fa, Na, 128).numpy()) < 1e-6
+    t, s, t2, queue, feats, idx, q2, sc, xs = R["misc"]
+    assert _re(t2, t * np.float32(1 - 0.37) + s * np.float32(0.37)) < 1e-6
+    assert (q2[:6] == feats[idx]).all() and (q2[6:] == queue[:-6]).all() and (xs == x * sc[:, None]).all()
+    scores, q_a, q_b = R["sinkhorn_from_q"]
+    want = O.sinkhorn(torch.exp(torch.from_numpy(scores) / 0.05).t(), 5).numpy()
+    assert _re(q_a, want) < 1e-4 and _re(q_b, want[16:56]) < 1e-4
+    v_, planes, cnt = R["planes"]
+    bf = torch.from_numpy(planes.astype(np.int16)).view(torch.bfloat16).double().numpy()
+    assert (bf.sum(0) == v_.astype(np.float64)).all() and cnt == 3
+    assert torch.equal(torch.from_numpy(planes[0].astype(np.int16)).view(torch.bfloat16), torch.from_numpy(v_).to(torch.bfloat16))
+    (p0, g0, m0, v0, p1, g1, m1, v1), got = R["adamw"]
+    for (p, g, m, v__, lr, wd), (gp_, gm_, gv_) in (((p0, g0, m0, v0, 1e-3, 0.1), (got[0], got[2], got[3])), ((p1, g1, m1, v1, 1e-2, 0.0), (got[4], got[6], got[7]))):
+        tp = torch.nn.Parameter(torch.from_numpy(p.copy()).double())
+        opt = torch.optim.AdamW([tp], lr=lr, weight_decay=wd)
+        tp.grad = torch.from_numpy(g).double()
+        opt.state[tp] = dict(step=torch.tensor(2.0), exp_avg=torch.from_numpy(m.copy()).double(), exp_avg_sq=torch.from_numpy(v__.copy()).double())
+        opt.step()
+        assert _re(gp_, tp.detach().numpy()) < 1e-6 and _re(gm_, opt.state[tp]["exp_avg"].numpy()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_library_equals_its_cpu_twin_round2(twin):
+    """The HIP entry points of the hot path's row ops and matrix products against their plain-C twins, one call site."""
+    from timetuning_amd import _lib
+
+    A = _round2_cases(_Side(_lib.load(), "tt_", device="cuda"), 2e-5)
+    B = _round2_cases(_Side(twin, "tt_cpu_"), 2e-5)
+    for key in ("linear_fwd", "linear_bwd", "layernorm", "l2norm", "attention", "sinkhorn_from_q"):
+        for i, (a, b) in enumerate(zip(A[key], B[key])):
+            if isinstance(a, np.ndarray) and a.dtype == np.float32:
+                assert _re(a, b) < 2e-5, (key, i, _re(a, b))
+    for i, (a, b) in enumerate(zip(A["misc"], B["misc"])):
+        if isinstance(a, np.ndarray):
+            assert _re(a, b) < 1e-6, ("misc", i)
+    assert (A["planes"][1] == B["planes"][1]).all() and A["planes"][2] == B["planes"][2] == 3     # bf16 planes bit for bit
+    for a, b in zip(A["adamw"][1], B["adamw"][1]):
+        assert _re(a, b) < 1e-6

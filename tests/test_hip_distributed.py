@@ -199,3 +199,25 @@ def test_bench_gpus_2_through_its_own_launcher():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert out["rccl"] == {"world_size": 2, "backend": "gloo"}
     assert out["value"] > 0 and out["scaling"] == "weak" and np.isfinite(out["loss"])
+
+
+@pytest.mark.timeout(900)
+def test_training_cli_spawns_two_ranks(tmp_path):
+    """`python -m timetuning_amd.time_tuning -g 2` (mp.spawn, time_tuning.py:714-717) end to end on synthetic clips: two ranks
+    (both on cuda:0 over gloo here), teacher + queue, the rank-0 evaluation at epoch 0 with the barrier behind it
+    (:634-648), per-rank queues of queue_size // world_size rows, a checkpoint with the reference's DDP key layout."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, TT_SHARE_DEVICE="1", TT_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "timetuning_amd.time_tuning", "-g", "2", "--dataset", "synthetic", "--model_path", "",
+                        "--batch_size", "2", "--num_frames", "2", "--num_clusters", "20", "--num_epochs", "1", "--steps_per_epoch", "2",
+                        "--use_queue", "1", "--queue_size", "256", "--eval_clips", "4", "--logging_directory", str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=800, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Scores/localization" in r.stdout and r.stdout.count("Iteration:") == 2           # rank 0 only prints
+    ck = torch.load(str(tmp_path / "checkpoint.pth"), map_location="cpu", weights_only=False)
+    assert all(k.startswith("model.module.") for k in ck["model"]) and "model.module.teacher_prototypes" in ck["model"]

@@ -666,12 +666,16 @@ def time_tuning(gpu=0, args=None):
 
     global world_size
     seed_everything(1)
-    device = torch.device("cuda", gpu)
-    torch.cuda.set_device(device)
     world_size = args.gpus * args.nodes
     rank = args.nr * args.gpus + gpu
+    # test aids (not reference flags): TT_SHARE_DEVICE=1 puts every rank on cuda:0 of a 1-GPU box, TT_DIST_BACKEND=gloo carries
+    # the exchange there (RCCL refuses two ranks on one device); the default is one GPU per rank over RCCL ("nccl")
+    if os.environ.get("TT_SHARE_DEVICE"):
+        gpu = 0
+    device = torch.device("cuda", gpu)
+    torch.cuda.set_device(device)
     if world_size > 1 and not dist.is_initialized():
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world_size, rank=rank)
+        dist.init_process_group(backend=os.environ.get("TT_DIST_BACKEND", "nccl"), init_method="env://", world_size=world_size, rank=rank)
     if args.use_projection_head:
         fe = FeatureExtractor(args.architecture, args.model_path, [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"],
                               return_attention=False)
