@@ -16,7 +16,13 @@
 // base + 16 * lane), so the swizzle is applied to the per-lane SOURCE address: LDS slot s of row r receives chunk s ^ f(r).
 // v_mfma_f32_32x32x16_bf16: lane l (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j], j = 0..7 = chunk 2 ks + h of its row.
 //
-// Tile (64 WM) x (64 WN), 4 waves as 2 x 2, double-buffered LDS, ONE barrier per slab: the DMA of slab t+1 is issued before
+// Where the time goes (round-2 ablations on ViT-B/16's qkv product, 25216 x 2304 x 768, tools/ab_planes.py + build_variant.sh):
+// full kernel 163 us; epilogue removed 116; MFMAs and fragment reads removed (DMA + barriers + epilogue only) 115 - i.e. the
+// 1.4 GB of L2 -> LDS operand traffic of a 128 x 128 tiling costs as much as the matrix work, and the two hardly overlap.
+// Ring depth (2 / 3 / 4 slabs), slab width (32 / 64 k), 2 or 3 workgroups per CU and loader / compute wave specialisation
+// (LD = 1) all land within +-5 %; halving the traffic with 256-wide tiles (8 waves) is worth 6-16 % where the grid allows.
+//
+// Tile (32 WM GM) x (32 WN GN), GM x GN waves (4 as 2 x 2 by default), LDS ring of NBUF slabs, ONE barrier per slab: the DMA of slab t+1 is issued before
 // the MFMAs of slab t and retired by the barrier's vmcnt(0).  Rows beyond M are clamped on load and masked on store.
 // Epilogue through LDS (8 columns per thread): bias, GELU (erf to 1.5e-7, common.hpp gelu_fast_f), residual, and any of: fp32 y, fp32 pre-activation, bf16 planes
 // of y (so the consumer finds its operand pre-split).
@@ -64,9 +70,20 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int P, int BK, int WM, int WN, int NBUF>
-__global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
+// GM x GN waves (default 2 x 2), each owning a (32 WM) x (32 WN) sub-tile: block tile (32 WM GM) x (32 WN GN).  The 8-wave
+// 256 x 256 / 256 x 128 instances exist because the 4-wave 128 x 128 tile is bound by the L2 -> LDS operand traffic, not by the
+// matrix pipe (ablation, tools/ab_planes.py: with the MFMAs and fragment reads REMOVED the ViT-B/16 qkv launch still takes 115 of
+// its 163 us - 1.4 GB of DMA at 12 TB/s); traffic per flop falls as 1/BM + 1/BN.
+// LD = 1 (wave specialisation): GM x GN MORE waves join the workgroup as LOADERS - they issue every LDS-DMA piece and wait for
+// it, the compute waves issue only ds_read_b128 + MFMA.  A DMA piece costs its issuing wave 100+ cycles (address VALU, M0, the
+// request itself) - as long as the MFMAs of the k-step it feeds when every wave does both; on its own wave it overlaps the
+// other wave's matrix work instead of delaying it (one loader and one compute wave per SIMD at GM x GN = 2 x 2).
+template <int P, int BK, int WM, int WN, int NBUF, int GM = 2, int GN = 2, int LD = 0>
+__global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(PlaneArgs g) {
+  constexpr int NC = GM * GN;                 // compute waves
+  constexpr int NW = LD ? NC : NC;            // waves that share the DMA pieces (the loaders when LD, else everybody)
+  constexpr int NT = 64 * NC * (1 + LD);      // threads
+  constexpr int BM = 32 * WM * GM, BN = 32 * WN * GN;
   constexpr int ROWB = BK * 2;              // bytes per LDS row
   constexpr int CPR = ROWB / 16;            // 16-byte chunks per row
   constexpr int WIN = 256 / ROWB;           // rows per 256-byte bank window
@@ -79,13 +96,15 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   static_assert(BM % RPI == 0 && BN % RPI == 0, "whole DMA pieces");
   // DMA pieces (wave-instructions) every wave issues per slab; the counted waits below need the same number in all waves
-  constexpr int G = P * (BM / RPI / 4 + BN / RPI / 4);
-  static_assert(NBUF == 2 || ((BM / RPI) % 4 == 0 && (BN / RPI) % 4 == 0), "ring depths > 2 need equal piece counts per wave");
+  constexpr int G = P * (BM / RPI / NW + BN / RPI / NW);
+  static_assert(NBUF == 2 || ((BM / RPI) % NW == 0 && (BN / RPI) % NW == 0), "ring depths > 2 need equal piece counts per wave");
   static_assert((NBUF - 2) * G < 64, "vmcnt range");
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave_id = tid >> 6;
+  const bool loader = LD ? wave_id >= NC : true, computes = LD ? wave_id < NC : true;
+  const int wave = LD && wave_id >= NC ? wave_id - NC : wave_id;   // index among the loaders / among the compute waves
+  const int wm = wave / GN, wn = wave % GN, r = lane & 31, h = lane >> 5;
   const int ntn = g.N / BN, ntm = (g.M + BM - 1) / BM;
   const int tile = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
@@ -103,9 +122,9 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
 #pragma unroll
-      for (int i = 0; i < (BM / RPI + 3) / 4; ++i) {
-        const int piece = wave + 4 * i, row = piece * RPI + l_row;
-        if ((BM / RPI) % 4 != 0 && piece >= BM / RPI) break;   // wave-uniform
+      for (int i = 0; i < (BM / RPI + NW - 1) / NW; ++i) {
+        const int piece = wave + NW * i, row = piece * RPI + l_row;
+        if ((BM / RPI) % NW != 0 && piece >= BM / RPI) break;   // wave-uniform
         const int chunk = l_slot ^ ((row / WIN) & (CPR - 1));
         int grow = m0 + row;
         grow = grow < g.M ? grow : g.M - 1;
@@ -114,9 +133,9 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
                                          (void __attribute__((address_space(3)))*)(base + p * A_PL + piece * 1024), 16, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < (BN / RPI + 3) / 4; ++i) {
-        const int piece = wave + 4 * i, row = piece * RPI + l_row;
-        if ((BN / RPI) % 4 != 0 && piece >= BN / RPI) break;   // wave-uniform
+      for (int i = 0; i < (BN / RPI + NW - 1) / NW; ++i) {
+        const int piece = wave + NW * i, row = piece * RPI + l_row;
+        if ((BN / RPI) % NW != 0 && piece >= BN / RPI) break;   // wave-uniform
         const int chunk = l_slot ^ ((row / WIN) & (CPR - 1));
         const __bf16* src = g.B + p * g.b_stride + (size_t)(n0 + row) * K + (kt_lo + kt) * BK + chunk * 8;
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
@@ -149,6 +168,9 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
   }
 
   auto compute = [&](int buf) {
+#ifdef TT_PLANES_NO_MAINLOOP   // timing study only: DMA and barriers stay, no fragment reads / MFMAs
+    return;
+#endif
     const unsigned char* base = smem + buf * BUF;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
@@ -176,12 +198,12 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
   if constexpr (NBUF == 2) {
     // double buffer, one barrier per slab: the DMA of slab t+1 flies under the MFMAs of slab t and is retired by the barrier's
     // vmcnt(0)
-    if (nk > 0) issue(0, 0);
+    if (nk > 0 && loader) issue(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
-      if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
-      compute(buf);
+      if (kt + 1 < nk && loader) issue(kt + 1, buf ^ 1);
+      if (computes) compute(buf);
       __syncthreads();
     }
   } else {
@@ -191,33 +213,48 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
     // buffer the DMA issued right behind the barrier overwrites.
 #pragma unroll
     for (int t = 0; t < NBUF - 1; ++t)
-      if (t < nk) issue(t, t);
+      if (t < nk && loader) issue(t, t);
     int buf = 0, nxt = NBUF - 1;
     for (int kt = 0; kt < nk; ++kt) {
       const int younger = nk - 1 - kt;   // slabs issued after kt that may stay in flight
-      if (younger >= NBUF - 2) wait_vmcnt<(NBUF - 2) * G>();
-      else if (NBUF > 3 && younger == 1) wait_vmcnt<G>();
-      else wait_vmcnt<0>();
+      if (loader) {
+        if (younger >= NBUF - 2) wait_vmcnt<(NBUF - 2) * G>();
+        else if (NBUF > 3 && younger == 1) wait_vmcnt<G>();
+        else wait_vmcnt<0>();
+      }
       __builtin_amdgcn_s_barrier();
-      if (kt + NBUF - 1 < nk) issue(kt + NBUF - 1, nxt);
-      compute(buf);
+      if (kt + NBUF - 1 < nk && loader) issue(kt + NBUF - 1, nxt);
+      if (computes) compute(buf);
       buf = buf + 1 == NBUF ? 0 : buf + 1;
       nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
     }
     __builtin_amdgcn_s_barrier();   // all reads of the last slab done before the epilogue reuses the LDS
   }
 
+#ifdef TT_PLANES_NO_EPILOGUE   // timing study only (tools/build_variant.sh): keep the accumulators alive with one store per lane
+  {
+    float sres = 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sres += acc[i][j][e];
+    if (g.C && sres == 12345.678f) g.C[tid] = sres;
+    return;
+  }
+#endif
   // ---- epilogue through LDS, one wave-row (32 WM tile rows) at a time; a thread owns 8 consecutive columns
   float* Cs = reinterpret_cast<float*>(smem);
-  constexpr int TPR = BN / 8, RPP = 256 / TPR;
+  constexpr int TPR = BN / 8, RPP = NT / TPR;
   const int c8 = (tid % TPR) * 8;
   const int n = n0 + c8;
   float bias8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = g.bias ? g.bias[n + e] : 0.f;
 #pragma unroll
-  for (int wmi = 0; wmi < 2; ++wmi) {
-    if (wm == wmi) {
+  for (int wmi = 0; wmi < GM; ++wmi) {
+    if (computes && wm == wmi) {
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -281,10 +318,11 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(PlaneArgs g) {
   }
 }
 
-template <int P, int BK, int WM, int WN, int NBUF = 2>
+template <int P, int BK, int WM, int WN, int NBUF = 2, int GM = 2, int GN = 2, int LD = 0>
 static int launch_planes(const PlaneArgs& g, hipStream_t s) {
-  const int tiles = ((g.M + 64 * WM - 1) / (64 * WM)) * (g.N / (64 * WN));
-  hipLaunchKernelGGL((gemm_planes_kernel<P, BK, WM, WN, NBUF>), dim3(tiles, g.splits), dim3(256), 0, s, g);
+  constexpr int BM = 32 * WM * GM, BN = 32 * WN * GN;
+  const int tiles = ((g.M + BM - 1) / BM) * (g.N / BN);
+  hipLaunchKernelGGL((gemm_planes_kernel<P, BK, WM, WN, NBUF, GM, GN, LD>), dim3(tiles, g.splits), dim3(64 * GM * GN * (1 + LD)), 0, s, g);
   TT_CHECK_LAUNCH("gemm_planes");
   return TT_OK;
 }
@@ -432,6 +470,15 @@ static int linear_planes_impl(const void* x_planes, long long x_plane_stride, co
         if (variant == 1) return launch_planes<1, 64, 2, 2, 2>(g, s);
         if (variant == 2) return launch_planes<1, 32, 2, 2, 3>(g, s);
         if (variant == 3) return launch_planes<1, 64, 2, 2, 3>(g, s);
+        if (variant == 4 && N % 256 == 0) return launch_planes<1, 32, 4, 2, 3, 2, 4>(g, s);   // 256 x 256, 8 waves of 128 x 64
+        if (variant == 5 && N % 256 == 0) return launch_planes<1, 64, 4, 2, 2, 2, 4>(g, s);   // same, 128-byte rows, 2 slabs
+        if (variant == 6) return launch_planes<1, 32, 2, 2, 4, 4, 2>(g, s);                    // 256 x 128, 8 waves of 64 x 64
+        if (variant == 7) return launch_planes<1, 64, 2, 2, 3, 4, 2>(g, s);
+        if (variant == 8) return launch_planes<1, 32, 2, 2, 4, 2, 2, 1>(g, s);                 // 128 x 128, 4 compute + 4 loader waves
+        if (variant == 9) return launch_planes<1, 64, 2, 2, 2, 2, 2, 1>(g, s);
+        // default: 256 x 256 (8 waves) when that still makes >= 3 tiles per CU (ViT-B/16 qkv / fc1: 131 / 208 us against 150 / 213
+        // for 128 x 128, profiles/r02_gemm_planes_variants.txt), else 128 x 128 with a 4-slab ring
+        if (variant == 0 && N % 256 == 0 && (long long)((M + 255) / 256) * (N / 256) >= 3 * 256) return launch_planes<1, 64, 4, 2, 2, 2, 4>(g, s);
         return launch_planes<1, 32, 2, 2, 4>(g, s);
       }
       if (wide) return launch_planes<1, 64, 1, 2>(g, s);
@@ -445,6 +492,13 @@ static int linear_planes_impl(const void* x_planes, long long x_plane_stride, co
         if (variant == 1) return launch_planes<3, 16, 2, 2, 2>(g, s);
         if (variant == 2) return launch_planes<3, 16, 2, 2, 4>(g, s);
         if (variant == 3) return launch_planes<3, 32, 2, 2, 2>(g, s);
+        if (variant == 6) return launch_planes<3, 32, 2, 2, 2, 4, 2>(g, s);                    // 256 x 128, 8 waves, 64-byte rows
+        if (variant == 7) return launch_planes<3, 16, 2, 2, 2, 4, 2>(g, s);
+        if (variant == 8) return launch_planes<3, 16, 2, 2, 3, 2, 2, 1>(g, s);
+        if (variant == 9) return launch_planes<3, 32, 2, 2, 2, 2, 2, 1>(g, s);
+        // default: 256 x 128 (8 waves, 64-byte rows) when that still makes >= 3 tiles per CU (ViT-S/16 qkv / fc1: 160 / 230 us against
+        // 185 / 247), else 128 x 128
+        if (variant == 0 && (long long)((M + 255) / 256) * (N / 128) >= 3 * 256) return launch_planes<3, 32, 2, 2, 2, 4, 2>(g, s);
         return launch_planes<3, 16, 2, 2, 3>(g, s);
       }
       if (wide) {

@@ -93,6 +93,9 @@ class FeatureExtractor(nn.Module):
         """models.py:929-935: substring match on backbone parameter names."""
         for name, param in self.backbone.named_parameters():
             param.requires_grad = any(u in name for u in unfreeze_layers)
+            # frozen tensors never change (no optimizer step, no EMA - they are the EMA's source): derived copies of them, such as the
+            # bf16 planes of the plane-GEMM modes, may be cached (engine.weight_planes checks storage and version as well)
+            param._tt_static = not param.requires_grad
 
     def trainable_block_ids(self) -> List[int]:
         ids = []

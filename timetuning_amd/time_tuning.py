@@ -137,6 +137,8 @@ class TimeT(nn.Module):
         if teacher is None:
             self.teacher = copy.deepcopy(self.feature_extractor)
             self.teacher.requires_grad_(False)
+            for p in self.teacher.parameters():     # the EMA rewrites teacher tensors through raw pointers: never cache copies
+                p._tt_static = False
             self.teacher_prototypes = nn.Parameter(self.prototypes.detach().clone())
             self.teacher_prototypes.requires_grad_(False)
         else:
