@@ -48,9 +48,8 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
-      const int q = qtile * 64 + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q < N) v = *reinterpret_cast<const float4*>(base + (long long)q * D3 + c4);
+      const int q = min(qtile * 64 + row, N - 1);   // clamped, not branched around: rows >= N are never stored
+      const float4 v = *reinterpret_cast<const float4*>(base + (long long)q * D3 + c4);
       float2* d = reinterpret_cast<float2*>(Qs + row * KSTR + c4);
       d[0] = make_float2(v.x, v.y);
       d[1] = make_float2(v.z, v.w);
@@ -67,10 +66,8 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
-      const int key = chunk * KCH + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (key < N) v = *reinterpret_cast<const float4*>(base + (long long)key * D3 + which * H * HD + c4);
-      st[i] = v;
+      const int key = min(chunk * KCH + row, N - 1);   // keys >= N: clamped here, masked to -inf before the softmax
+      st[i] = *reinterpret_cast<const float4*>(base + (long long)key * D3 + which * H * HD + c4);
     }
   };
   auto swrite_k = [&](int buf) {
@@ -219,9 +216,8 @@ __global__ __launch_bounds__(256) void attention_fwd_flash_kernel(const float* _
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
-      const int q = qtile * 64 + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q < N) v = *reinterpret_cast<const float4*>(base + (long long)q * D3 + c4);
+      const int q = min(qtile * 64 + row, N - 1);   // clamped, not branched around: rows >= N are never stored
+      const float4 v = *reinterpret_cast<const float4*>(base + (long long)q * D3 + c4);
       float2* d = reinterpret_cast<float2*>(Qs + row * KSTR + c4);
       d[0] = make_float2(v.x, v.y);
       d[1] = make_float2(v.z, v.w);
@@ -238,12 +234,9 @@ __global__ __launch_bounds__(256) void attention_fwd_flash_kernel(const float* _
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
-      const int key = chunk * KCH + row;
-      stk[i] = stv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (key < N) {
-        stk[i] = *reinterpret_cast<const float4*>(base + (long long)key * D3 + H * HD + c4);
-        stv[i] = *reinterpret_cast<const float4*>(base + (long long)key * D3 + 2 * H * HD + c4);
-      }
+      const int key = min(chunk * KCH + row, N - 1);   // keys >= N: clamped here, masked to -inf before the softmax
+      stk[i] = *reinterpret_cast<const float4*>(base + (long long)key * D3 + H * HD + c4);
+      stv[i] = *reinterpret_cast<const float4*>(base + (long long)key * D3 + 2 * H * HD + c4);
     }
   };
   auto swrite = [&](int buf) {

@@ -48,9 +48,10 @@ __global__ __launch_bounds__(256, TT_Q2_WAVES_PER_SIMD) void attention_fwd_q2_ke
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
-      const int q = qblk * 128 + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q < N) v = *reinterpret_cast<const float4*>(base + (long long)q * D3 + c4);
+      // rows beyond N are CLAMPED, not branched around (queries >= N are never stored, keys >= N are masked to -inf below and
+      // their V rows meet P = 0): no exec-mask juggling around the loads
+      const int q = min(qblk * 128 + row, N - 1);
+      const float4 v = *reinterpret_cast<const float4*>(base + (long long)q * D3 + c4);
       float2* d = reinterpret_cast<float2*>(smem + row * Q2_KSTR + c4);
       d[0] = make_float2(v.x, v.y);
       d[1] = make_float2(v.z, v.w);
@@ -69,10 +70,8 @@ __global__ __launch_bounds__(256, TT_Q2_WAVES_PER_SIMD) void attention_fwd_q2_ke
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
-      const int key = chunk * Q2_KCH + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (key < N) v = *reinterpret_cast<const float4*>(base + (long long)key * D3 + which * H * Q2_HD + c4);
-      st[i] = v;
+      const int key = min(chunk * Q2_KCH + row, N - 1);
+      st[i] = *reinterpret_cast<const float4*>(base + (long long)key * D3 + which * H * Q2_HD + c4);
     }
   };
   auto swrite_k = [&](int buf) {
