@@ -33,7 +33,9 @@ __global__ __launch_bounds__(256, TT_Q2_WAVES_PER_SIMD) void attention_fwd_q2_ke
   __shared__ __attribute__((aligned(16))) float smem[2 * Q2_KCH * Q2_KSTR + 2 * Q2_KCH * Q2_VSTR];
   float* Ks = smem;
   float* Vs = smem + 2 * Q2_KCH * Q2_KSTR;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the wave index through readfirstlane: the compiler then KNOWS that q0 / wave_active are wave-uniform and branches on SCC
+  // instead of saving and restoring EXEC around every guarded MFMA block)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = lane & 15, g = lane >> 4;
   int fh, qblk;
   if (!xcd_group_decode(blockIdx.x, (N + 127) / 128, FH, fh, qblk)) return;
