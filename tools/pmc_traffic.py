@@ -28,8 +28,8 @@ if len(sys.argv) > 3:
     dom = sorted([r for r in rows if "gemm_nt_fast_kernel" in r[1]], key=lambda r: -r[2]) or rows[:1]
     tot, k, n, fb, wb = dom[0]
     head = sys.argv[4] if len(sys.argv) > 4 else "unknown"
-    names = {"<2, 2>": "128x128", "<1, 2>": "64x128", "<2, 1>": "128x64", "<1, 1>": "64x64"}
-    label = next((f"gemm_nt_fast_kernel<{v}>" for t, v in names.items() if t in k), k)
+    names = {"<2, 2": "128x128", "<1, 2": "64x128", "<2, 1": "128x64", "<1, 1": "64x64"}   # <WM, WN[, BK]>
+    label = next((f"gemm_nt_fast_kernel<{v}>" for t, v in names.items() if ("gemm_nt_fast_kernel" + t) in k), k)
     json.dump({"kernel": k, "kernel_label": label, "git_head": head, "launches_profiled": n, "hbm_read_bytes_per_launch": round(fb), "hbm_write_bytes_per_launch": round(wb),
                "hbm_bytes_per_launch": round(fb + wb), "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 per the gfx950 correction; average over the launches of one bench.py run (mixed shapes of this instantiation)"},
               open(sys.argv[3], "w"), indent=1)
