@@ -64,16 +64,26 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
-// GELU for the bf16-plane epilogues (gemm_planes.hip), where the matrix work per output element is 6-16x cheaper than on the
-// f32-MFMA path and ocml's erff (~40 instructions) would dominate the epilogue: erf by Abramowitz-Stegun 7.1.26 (one v_rcp,
-// one v_exp, five FMAs; |error| <= 1.5e-7 absolute on erf, i.e. <= 1e-7 |x| on GELU - inside the 2e-5 bound the fp32-accurate
-// plane mode is tested at).
-__device__ __forceinline__ float gelu_fast_f(float x) {
+// GELU of every forward epilogue (nn.GELU's exact-erf form, dino_vision_transformer.py:100): erf by Abramowitz-Stegun 7.1.26
+// (one v_rcp, one v_exp, five FMAs; |error| <= 1.5e-7 absolute on erf, i.e. <= 1e-7 |x| on GELU - the size of an fp32 rounding,
+// far inside every tolerance the kernels are tested at; the measured error of the fc1 product against fp64 is 6.8e-7 with
+// either form).  ocml's erff is ~40 instructions: 32 calls per thread made the fc1 epilogue of the f32 kernel 9 % of its
+// launch (290 -> 263 us on the ViT-S/16 shape, tools/ab_linear.py), and would dominate a bf16 epilogue.  The backward's
+// gelu' uses the same erf (gelu_grad_fast_f); gelu_f / gelu_grad_f (ocml erff) are kept as the references the tools compare with.
+__device__ __forceinline__ float erf_fast_f(float x, float* exp_neg_half_x2_out = nullptr) {   // erf(x / sqrt 2), |error| <= 1.5e-7
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
   const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-  const float erf_abs = 1.0f - poly * __expf(-z * z);
-  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+  const float e = __expf(-z * z);   // = exp(-x^2 / 2): also the Gaussian of gelu'
+  if (exp_neg_half_x2_out) *exp_neg_half_x2_out = e;
+  return copysignf(1.0f - poly * e, x);
+}
+__device__ __forceinline__ float gelu_fast_f(float x) { return 0.5f * x * (1.0f + erf_fast_f(x)); }
+// gelu'(x) = Phi(x) + x phi(x) with the same erf and its exp(-x^2 / 2) reused for phi
+__device__ __forceinline__ float gelu_grad_fast_f(float x) {
+  float g;
+  const float cdf = 0.5f * (1.0f + erf_fast_f(x, &g));
+  return cdf + x * 0.39894228040143267794f * g;
 }
 
 // XCD-aware bijective remap of a linear workgroup id (guide T1): the dispatcher deals consecutive

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(Pl
           *reinterpret_cast<float4*>(pr) = *reinterpret_cast<const float4*>(g.gelu_pre + off);
           *reinterpret_cast<float4*>(pr + 4) = *reinterpret_cast<const float4*>(g.gelu_pre + off + 4);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f(pr[e]);
+          for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_fast_f(pr[e]);
         }
         if (g.residual) {
           float rs[8];
