@@ -30,21 +30,19 @@ f32 = torch.float32
 # ViT blocks
 # ------------------------------------------------------------------------------------------------
 
-_WEIGHT_PLANES: Dict[int, tuple] = {}
-
-
 def weight_planes(w: torch.nn.Parameter, planes: int) -> torch.Tensor:
     """[planes, N, K] bf16 planes of a Linear weight.  Tensors marked static (``_tt_static``: the student's frozen parameters,
     FeatureExtractor.freeze_backbone) are split once and cached against (storage, version, planes); anything that training or the
     EMA rewrites through raw pointers is split again on every call (a few MB per step)."""
     if not getattr(w, "_tt_static", False):
         return ops.split_planes(w.detach(), planes)
-    key = id(w)
-    hit = _WEIGHT_PLANES.get(key)
+    # the cache lives ON the parameter object (not in a table keyed by id(): a recycled id + recycled storage of a dead model's
+    # parameter would otherwise hit), so it dies with it
+    hit = getattr(w, "_tt_planes", None)
     tag = (w.data_ptr(), w._version, planes)
     if hit is None or hit[0] != tag:
         hit = (tag, ops.split_planes(w.detach(), planes))
-        _WEIGHT_PLANES[key] = hit
+        w._tt_planes = hit
     return hit[1]
 
 
