@@ -64,12 +64,9 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
-// GELU of every forward epilogue (nn.GELU's exact-erf form, dino_vision_transformer.py:100): erf by Abramowitz-Stegun 7.1.26
-// (one v_rcp, one v_exp, five FMAs; |error| <= 1.5e-7 absolute on erf, i.e. <= 1e-7 |x| on GELU - the size of an fp32 rounding,
-// far inside every tolerance the kernels are tested at; the measured error of the fc1 product against fp64 is 6.8e-7 with
-// either form).  ocml's erff is ~40 instructions: 32 calls per thread made the fc1 epilogue of the f32 kernel 9 % of its
-// launch (290 -> 263 us on the ViT-S/16 shape, tools/ab_linear.py), and would dominate a bf16 epilogue.  The backward's
-// gelu' uses the same erf (gelu_grad_fast_f); gelu_f / gelu_grad_f (ocml erff) are kept as the references the tools compare with.
+// GELU / GELU' of the bf16-plane epilogues (gemm_planes.hip): erf by Abramowitz-Stegun 7.1.26 (one v_rcp, one v_exp, five
+// FMAs; |error| <= 1.5e-7 absolute on erf, i.e. <= 1e-7 |x| on GELU - inside the 2e-5 bound the fp32-accurate plane mode is
+// tested at).  The f32-MFMA kernels keep ocml's erff (gelu_f / gelu_grad_f): measured, the cheaper erf buys them nothing.
 __device__ __forceinline__ float erf_fast_f(float x, float* exp_neg_half_x2_out = nullptr) {   // erf(x / sqrt 2), |error| <= 1.5e-7
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));

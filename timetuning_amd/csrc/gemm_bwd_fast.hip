@@ -151,7 +151,7 @@ __device__ __forceinline__ void bwd_epilogue(float* lds, const f32x16 (&acc)[WM]
       float4 v = *reinterpret_cast<const float4*>(lds + rr * LDCS + c4);
       if (gelu_pre) {
         const float4 gp = *reinterpret_cast<const float4*>(gelu_pre + off);
-        v.x *= gelu_grad_fast_f(gp.x); v.y *= gelu_grad_fast_f(gp.y); v.z *= gelu_grad_fast_f(gp.z); v.w *= gelu_grad_fast_f(gp.w);
+        v.x *= gelu_grad_f(gp.x); v.y *= gelu_grad_f(gp.y); v.z *= gelu_grad_f(gp.z); v.w *= gelu_grad_f(gp.w);
       }
       *reinterpret_cast<float4*>(C + off) = v;
     }

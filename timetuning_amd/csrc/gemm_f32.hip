@@ -300,9 +300,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
           off = (long long)m * g.ldc + n;
         }
         if (g.pre_out) g.pre_out[off] = v;
-        if (g.act == 1) v = gelu_fast_f(v);
+        if (g.act == 1) v = gelu_f(v);
         if (g.row_scale) v *= g.row_scale[m];
-        if (g.gelu_pre) v *= gelu_grad_fast_f(g.gelu_pre[off]);
+        if (g.gelu_pre) v *= gelu_grad_f(g.gelu_pre[off]);
         if (g.residual) v += g.residual[off];
         C[off] = v;
       }

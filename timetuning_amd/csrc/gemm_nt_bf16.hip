@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(Bf16Args g) {
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
       if (g.pre_out) *reinterpret_cast<float4*>(g.pre_out + off) = v;
       if (g.act == 1) {
-        v.x = gelu_fast_f(v.x); v.y = gelu_fast_f(v.y); v.z = gelu_fast_f(v.z); v.w = gelu_fast_f(v.w);
+        v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
       }
       if (g.residual) {
         const float4 rs = *reinterpret_cast<const float4*>(g.residual + off);

@@ -19,7 +19,8 @@
 //     slabs behind counted vmcnt + raw s_barrier (the structure of gemm_planes.hip): 886 / 895 / 948 us per ViT-S/16 block of
 //     128 frames (qkv + proj + fc1 + fc2) against 834 us for this kernel on the same box (tools/bench_linear.py), same 5e-7
 //     error.  Three very different loop structures (this one, the DMA ring, hipBLASLt's stream-K) land within +-8 % of
-//     110 TFLOP/s at K = 384: the ceiling is not in the staging path.
+//     110 TFLOP/s at K = 384: the ceiling is not in the staging path;
+//   * (round 2) s_setprio 1 / 2 for the main loop (epilogue at 0): no difference (interleaved A/B, all four block shapes).
 #include "common.hpp"
 #include <cstdlib>
 
@@ -193,7 +194,9 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
       if (g.pre_out) *reinterpret_cast<float4*>(g.pre_out + off) = v;
       if (g.act == 1) {
-        v.x = gelu_fast_f(v.x); v.y = gelu_fast_f(v.y); v.z = gelu_fast_f(v.z); v.w = gelu_fast_f(v.w);
+        // (exact-erf GELU as nn.GELU; an Abramowitz-Stegun erf is NOT faster here: 265.4 vs 266.8 us on the fc1 shape in an
+        // interleaved A/B, tools/ab_linear.py - the epilogue's VALU work hides under the other workgroups' MFMAs)
+        v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
       }
       if (g.residual) {
         const float4 rs = *reinterpret_cast<const float4*>(g.residual + off);

@@ -16,9 +16,10 @@
 // base + 16 * lane), so the swizzle is applied to the per-lane SOURCE address: LDS slot s of row r receives chunk s ^ f(r).
 // v_mfma_f32_32x32x16_bf16: lane l (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j], j = 0..7 = chunk 2 ks + h of its row.
 //
-// Where the time goes (round-2 ablations on ViT-B/16's qkv product, 25216 x 2304 x 768, tools/ab_planes.py + build_variant.sh):
-// full kernel 163 us; epilogue removed 116; MFMAs and fragment reads removed (DMA + barriers + epilogue only) 115 - i.e. the
-// 1.4 GB of L2 -> LDS operand traffic of a 128 x 128 tiling costs as much as the matrix work, and the two hardly overlap.
+// Where the time goes (round-2 ablations on ViT-B/16's qkv product, 25216 x 2304 x 768, 128 x 128 tiles, interleaved A/B of
+// tools/ab_planes.py + build_variant.sh): full kernel 122 us; epilogue removed 91; MFMAs and fragment reads removed (DMA +
+// barriers + epilogue only) 99 - i.e. the 1.4 GB of L2 -> LDS operand traffic of a 128 x 128 tiling costs as much as the matrix
+// work and the two overlap poorly; the epilogue is a quarter of the launch (a third at N = 3072 with GELU + bf16 stores).
 // Ring depth (2 / 3 / 4 slabs), slab width (32 / 64 k), 2 or 3 workgroups per CU and loader / compute wave specialisation
 // (LD = 1) all land within +-5 %; halving the traffic with 256-wide tiles (8 waves) is worth 6-16 % where the grid allows.
 //
@@ -72,8 +73,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // GM x GN waves (default 2 x 2), each owning a (32 WM) x (32 WN) sub-tile: block tile (32 WM GM) x (32 WN GN).  The 8-wave
 // 256 x 256 / 256 x 128 instances exist because the 4-wave 128 x 128 tile is bound by the L2 -> LDS operand traffic, not by the
-// matrix pipe (ablation, tools/ab_planes.py: with the MFMAs and fragment reads REMOVED the ViT-B/16 qkv launch still takes 115 of
-// its 163 us - 1.4 GB of DMA at 12 TB/s); traffic per flop falls as 1/BM + 1/BN.
+// matrix pipe (ablation, tools/ab_planes.py: with the MFMAs and fragment reads REMOVED the ViT-B/16 qkv launch still takes 99 of
+// its 122 us); traffic per flop falls as 1/BM + 1/BN.
 // LD = 1 (wave specialisation): GM x GN MORE waves join the workgroup as LOADERS - they issue every LDS-DMA piece and wait for
 // it, the compute waves issue only ds_read_b128 + MFMA.  A DMA piece costs its issuing wave 100+ cycles (address VALU, M0, the
 // request itself) - as long as the MFMAs of the k-step it feeds when every wave does both; on its own wave it overlaps the

@@ -13,15 +13,14 @@ for N, K, name, act, res in ((1152, 384, "qkv", 0, 0), (384, 384, "proj", 0, 1),
     ref = torch.nn.functional.linear(x[:256].double(), w.double(), b.double())
     if act: ref = torch.nn.functional.gelu(ref)
     if res: ref = ref + r[:256].double()
-    out = []
-    for p_, lib in libs:
-        ts = []
-        for rd in range(8):
+    ts = {p_: [] for p_, _ in libs}
+    errs = {}
+    for rd in range(12):                      # rounds INTERLEAVED across the builds: no build owns the cold / ramping clock
+        for p_, lib in libs:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10): assert lib.tt_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, y.data_ptr(), None, M, N, K, act, st) == 0
             e1.record(); torch.cuda.synchronize()
-            if rd >= 2: ts.append(e0.elapsed_time(e1) * 1e2)
-        err = ((y[:256].double() - ref).abs().max() / ref.abs().max()).item()
-        out.append(f"{os.path.basename(p_)[3:-3]} {statistics.median(ts):7.1f} us (err {err:.1e})")
-    print(f"{name:5s} N={N:5d} K={K:5d}: " + " | ".join(out), flush=True)
+            if rd >= 3: ts[p_].append(e0.elapsed_time(e1) * 1e2)
+            errs[p_] = ((y[:256].double() - ref).abs().max() / ref.abs().max()).item()
+    print(f"{name:5s} N={N:5d} K={K:5d}: " + " | ".join(f"{os.path.basename(p_)[3:-3]} {statistics.median(ts[p_]):7.1f} us (err {errs[p_]:.1e})" for p_, _ in libs), flush=True)

@@ -17,16 +17,14 @@ for P, shapes in ((1, [(2304, 768, "qkv", 0, 1, 0), (768, 768, "proj", 0, 0, 1),
         y = torch.empty(M, N, device="cuda") if not po or res else None
         yp = torch.empty(po, M, N, device="cuda", dtype=torch.bfloat16) if po else None
         if res: y = r
-        out = []
-        for p_, lib in libs:
-            ts = []
-            for rd in range(6):
+        ts = {p_: [] for p_, _ in libs}
+        for rd in range(10):                      # rounds INTERLEAVED across the builds (the first ~100 ms of a burst run ~9 % slow)
+            for p_, lib in libs:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(10):
                     assert lib.tt_linear_fwd_planes(x.data_ptr(), M * K, w.data_ptr(), N * K, P, b.data_ptr(), r.data_ptr() if res else None,
                                                     y.data_ptr() if y is not None else None, None, yp.data_ptr() if po else None, M * N, po, M, N, K, act, st) == 0
                 e1.record(); torch.cuda.synchronize()
-                if rd >= 1: ts.append(e0.elapsed_time(e1) * 1e2)
-            out.append(f"{os.path.basename(p_)[3:-3]} {statistics.median(ts):7.1f} us")
-        print(f"P={P} {name:5s} N={N:5d} K={K:5d}: " + " | ".join(out), flush=True)
+                if rd >= 3: ts[p_].append(e0.elapsed_time(e1) * 1e2)
+        print(f"P={P} {name:5s} N={N:5d} K={K:5d}: " + " | ".join(f"{os.path.basename(p_)[3:-3]} {statistics.median(ts[p_]):7.1f} us" for p_, _ in libs), flush=True)
