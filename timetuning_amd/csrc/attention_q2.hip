@@ -11,7 +11,9 @@
 // d = 16 g + s so that a lane's sixteen values are consecutive) and the V^T operand as sixteen dwords per key tile, next tile in
 // flight under the MFMAs (223 VGPRs, counted vmcnt throughout, bit-compatible results): 129 us per ViT-S/16 layer of 128 frames
 // against 112 us for this kernel on the same box.  Sharing K / V through LDS (one fetch per workgroup instead of four) is
-// worth more than the sixteen barriers cost.
+// worth more than the sixteen barriers cost.  A hybrid - this kernel with the d-permuted Q loads (no Q staging, no barriers
+// for it) and a 256-byte-row K image XOR-swizzled for conflict-free ds_read_b128 fragments (4 reads per key tile instead of
+// 16 ds_read_b32) - was correct to 1.4e-6 and 10 % SLOWER (118 vs 108 us, 128 bytes of scratch per lane): also not shipped.
 #include "common.hpp"
 
 namespace tt {

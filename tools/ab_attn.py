@@ -16,4 +16,9 @@ for rd in range(12):
         for _ in range(5): assert lib.tt_attention_fwd(qkv.data_ptr(), out.data_ptr(), None, None, F, N, H, 64, 0.125, st) == 0
         e1.record(); torch.cuda.synchronize()
         if rd >= 2: res[p].append(e0.elapsed_time(e1)*1e3/5)
+outs = {}
+for p, lib in libs:
+    lib.tt_attention_fwd(qkv.data_ptr(), out.data_ptr(), None, None, F, N, H, 64, 0.125, st); torch.cuda.synchronize(); outs[p] = out.clone()
+p0 = libs[0][0]
+for p, _ in libs[1:]: print(f"max |out[{os.path.basename(p)}] - out[{os.path.basename(p0)}]| = {(outs[p] - outs[p0]).abs().max().item():.3e}  (max |out| {outs[p0].abs().max().item():.3f})")
 for p, v in res.items(): print(f"{os.path.basename(p):28s} median {statistics.median(v):7.1f} us  min {min(v):7.1f} us")
