@@ -13,7 +13,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
            "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp -d $OUT/g$i -o p -- python3 /root/repo/tools/gemm_shapes.py $SHAPE > $OUT/g$i.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -o p -- python3 /root/repo/tools/gemm_shapes.py $SHAPE > $OUT/g$i.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections
