@@ -506,3 +506,208 @@ int tt_cpu_count_mismatch(const float* a, const float* b, long long n, long long
   *count_out = c;
   return 0;
 }
+
+/* ---- second batch of round 2: backward of the row ops, the attention backward, the patch embedding, the plane ops ---------- */
+
+/* bias gradient: column sums of a [M][N] matrix */
+int tt_cpu_colsum(const float* a, float* out, int M, int N, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  for (int n = 0; n < N; ++n) {
+    double s = 0.0;
+    for (int m = 0; m < M; ++m) s += a[(size_t)m * N + n];
+    out[n] = (float)s;
+  }
+  return 0;
+}
+
+int tt_cpu_add_inplace(float* dst, const float* src, long long n, tt_stream_t stream) {
+  (void)stream;
+  for (long long i = 0; i < n; ++i) dst[i] += src[i];
+  return 0;
+}
+
+/* ---- autograd of nn.LayerNorm: dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma; dgamma = sum dy xhat; dbeta = sum dy.
+ *      skip_group = N: dy has no rows for token 0 of each group; those rows of dx are left untouched.  add_to_dx accumulates. */
+int tt_cpu_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                         float* dgamma, float* dbeta, int rows, int D, int add_to_dx, int skip_group, void* workspace,
+                         size_t workspace_bytes, tt_stream_t stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  double* dg = (double*)calloc((size_t)2 * D, sizeof(double));
+  if (!dg) return -3;
+  double* db = dg + D;
+  for (int r = 0; r < rows; ++r) {
+    const long long xr = skip_group ? (long long)(r / (skip_group - 1)) * skip_group + 1 + r % (skip_group - 1) : r;
+    const float* xv = x + xr * D;
+    const float* dv = dy + (size_t)r * D;
+    double m1 = 0.0, m2 = 0.0;
+    for (int c = 0; c < D; ++c) {
+      const double xh = ((double)xv[c] - mean[r]) * rstd[r], gg = (double)dv[c] * gamma[c];
+      m1 += gg; m2 += gg * xh;
+      dg[c] += (double)dv[c] * xh; db[c] += dv[c];
+    }
+    m1 /= D; m2 /= D;
+    for (int c = 0; c < D; ++c) {
+      const double xh = ((double)xv[c] - mean[r]) * rstd[r], gg = (double)dv[c] * gamma[c];
+      const float v = (float)(rstd[r] * (gg - m1 - xh * m2));
+      if (add_to_dx) dx[xr * D + c] += v; else dx[xr * D + c] = v;
+    }
+  }
+  if (dgamma) for (int c = 0; c < D; ++c) { dgamma[c] = (float)dg[c]; dbeta[c] = (float)db[c]; }
+  free(dg);
+  return 0;
+}
+
+/* ---- autograd of F.normalize: dx = (dxn - xn <xn, dxn>) inv_norm */
+int tt_cpu_l2norm_bwd(const float* dxn, const float* xn, const float* inv_norm, float* dx, int rows, int D, tt_stream_t stream) {
+  (void)stream;
+  for (int r = 0; r < rows; ++r) {
+    double dot = 0.0;
+    for (int c = 0; c < D; ++c) dot += (double)xn[(size_t)r * D + c] * dxn[(size_t)r * D + c];
+    for (int c = 0; c < D; ++c) dx[(size_t)r * D + c] = (float)(((double)dxn[(size_t)r * D + c] - xn[(size_t)r * D + c] * dot) * inv_norm[r]);
+  }
+  return 0;
+}
+
+/* ---- autograd of Attention.forward's softmax(q k^T scale) v (dino_vision_transformer.py:122-129) from the saved lse:
+ *      P = exp(s - lse); dV = P^T dO; dP = dO V^T; dS = P (dP - rowsum(dO O)); dQ = dS K scale; dK = dS^T Q scale */
+int tt_cpu_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N, int H, int hd,
+                         float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  const int D = H * hd, D3 = 3 * D;
+  memset(dqkv, 0, (size_t)F * N * D3 * sizeof(float));
+  double* acc = (double*)calloc((size_t)N * D3, sizeof(double));   /* one frame's dqkv in double */
+  if (!acc) return -3;
+  for (int f = 0; f < F; ++f) {
+    memset(acc, 0, (size_t)N * D3 * sizeof(double));
+    for (int h = 0; h < H; ++h)
+      for (int i = 0; i < N; ++i) {
+        const float* q = qkv + ((size_t)f * N + i) * D3 + h * hd;
+        const float* dO = dout + ((size_t)f * N + i) * D + h * hd;
+        const float* O = out + ((size_t)f * N + i) * D + h * hd;
+        double delta = 0.0;
+        for (int d = 0; d < hd; ++d) delta += (double)dO[d] * O[d];
+        for (int j = 0; j < N; ++j) {
+          const float* k = qkv + ((size_t)f * N + j) * D3 + D + h * hd;
+          const float* v = qkv + ((size_t)f * N + j) * D3 + 2 * D + h * hd;
+          double s = 0.0, dp = 0.0;
+          for (int d = 0; d < hd; ++d) { s += (double)q[d] * k[d]; dp += (double)dO[d] * v[d]; }
+          const double p = exp(s * scale - lse[((size_t)f * H + h) * N + i]);
+          const double ds = p * (dp - delta) * scale;
+          for (int d = 0; d < hd; ++d) {
+            acc[(size_t)i * D3 + h * hd + d] += ds * k[d];
+            acc[(size_t)j * D3 + D + h * hd + d] += ds * q[d];
+            acc[(size_t)j * D3 + 2 * D + h * hd + d] += p * dO[d];
+          }
+        }
+      }
+    for (size_t t = 0; t < (size_t)N * D3; ++t) dqkv[(size_t)f * N * D3 + t] = (float)acc[t];
+  }
+  free(acc);
+  return 0;
+}
+
+/* ---- PatchEmbed + prepare_tokens (dino_vision_transformer.py:156-171,236-247): conv2d(k = s = P) as a per-patch dot product,
+ *      cls token prepended, position embedding added; frame_map selects / reorders source frames (NULL: identity) */
+int tt_cpu_patch_embed_fwd(const float* img, const int32_t* frame_map, const float* w, const float* bias, const float* cls, const float* pos,
+                           float* tokens, int F, int C, int H, int W, int P, int D, tt_stream_t stream) {
+  (void)stream;
+  const int gh = H / P, gw = W / P, n = gh * gw;
+  for (int f = 0; f < F; ++f) {
+    const float* src = img + (size_t)(frame_map ? frame_map[f] : f) * C * H * W;
+    float* tok = tokens + (size_t)f * (n + 1) * D;
+    for (int d = 0; d < D; ++d) tok[d] = cls[d] + pos[d];
+    for (int py = 0; py < gh; ++py)
+      for (int px = 0; px < gw; ++px)
+        for (int d = 0; d < D; ++d) {
+          double s = bias[d];
+          for (int c = 0; c < C; ++c)
+            for (int y = 0; y < P; ++y)
+              for (int x = 0; x < P; ++x)
+                s += (double)src[((size_t)c * H + py * P + y) * W + px * P + x] * w[(((size_t)d * C + c) * P + y) * P + x];
+          tok[(size_t)(1 + py * gw + px) * D + d] = (float)s + pos[(size_t)(1 + py * gw + px) * D + d];
+        }
+  }
+  return 0;
+}
+
+/* ---- StandardScaler.transform: x[r][c] = x[r][c] * scale[c] + shift[c] */
+int tt_cpu_affine_cols_inplace(float* x, const float* scale, const float* shift, long long rows, int cols, tt_stream_t stream) {
+  (void)stream;
+  for (long long r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) x[r * cols + c] = x[r * cols + c] * scale[c] + shift[c];
+  return 0;
+}
+
+/* ---- the plane ops: transposing conversion, LayerNorm into planes, the plane GEMM (sum over plane pairs i + j <= planes + 1),
+ *      and the bf16 attention (fp32 arithmetic on bf16 inputs, P and the output rounded to bf16 as the kernel does) */
+int tt_cpu_transpose_planes(const float* src, void* dst, int R, int C, int Rpad, tt_stream_t stream) {
+  (void)stream;
+  uint16_t* d = (uint16_t*)dst;
+  for (int c = 0; c < C; ++c)
+    for (int r = 0; r < Rpad; ++r) d[(size_t)c * Rpad + r] = r < R ? tt_cpu_bf16(src[(size_t)r * C + c]) : 0;
+  return 0;
+}
+int tt_cpu_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, void* y_planes, long long plane_stride, int planes,
+                                float* mean, float* rstd, int rows, int D, float eps, int skip_group, tt_stream_t stream) {
+  float* y = (float*)malloc((size_t)rows * D * sizeof(float));
+  if (!y) return -3;
+  tt_cpu_layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, eps, skip_group, stream);
+  const int rc = tt_cpu_split_planes(y, y_planes, plane_stride, planes, (long long)rows * D, stream);
+  free(y);
+  return rc;
+}
+int tt_cpu_linear_fwd_planes(const void* x_planes, long long xs, const void* w_planes, long long wsd, int planes, const float* bias,
+                             const float* residual, float* y, float* pre_out, void* y_planes, long long ys, int y_nplanes, int M, int N,
+                             int K, int act, tt_stream_t stream) {
+  const uint16_t* xp = (const uint16_t*)x_planes;
+  const uint16_t* wp = (const uint16_t*)w_planes;
+  float* tmp = (float*)malloc((size_t)M * N * sizeof(float));
+  if (!tmp) return -3;
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < N; ++n) {
+      double s = bias ? (double)bias[n] : 0.0;
+      for (int pa = 0; pa < planes; ++pa)
+        for (int pw = 0; pa + pw < planes; ++pw)
+          for (int k = 0; k < K; ++k)
+            s += (double)tt_cpu_bf16_to_f32(xp[pa * xs + (size_t)m * K + k]) * (double)tt_cpu_bf16_to_f32(wp[pw * wsd + (size_t)n * K + k]);
+      float v = (float)s;
+      if (pre_out) pre_out[(size_t)m * N + n] = v;
+      if (act == 1) v = tt_cpu_gelu(v);
+      if (residual) v += residual[(size_t)m * N + n];
+      tmp[(size_t)m * N + n] = v;
+    }
+  if (y_planes) tt_cpu_split_planes(tmp, y_planes, ys, y_nplanes, (long long)M * N, stream);
+  if (y) memcpy(y, tmp, (size_t)M * N * sizeof(float));
+  free(tmp);
+  return 0;
+}
+int tt_cpu_attention_fwd_bf16(const void* qkv, void* out, int F, int N, int H, int head_dim, float scale, tt_stream_t stream) {
+  (void)stream;
+  const uint16_t* in = (const uint16_t*)qkv;
+  uint16_t* o = (uint16_t*)out;
+  const int D = H * head_dim, D3 = 3 * D;
+  double* p = (double*)malloc((size_t)N * sizeof(double));
+  if (!p) return -3;
+  for (int f = 0; f < F; ++f)
+    for (int h = 0; h < H; ++h)
+      for (int i = 0; i < N; ++i) {
+        const uint16_t* q = in + ((size_t)f * N + i) * D3 + h * head_dim;
+        double mx = -INFINITY;
+        for (int j = 0; j < N; ++j) {
+          const uint16_t* k = in + ((size_t)f * N + j) * D3 + D + h * head_dim;
+          double s = 0.0;
+          for (int d = 0; d < head_dim; ++d) s += (double)tt_cpu_bf16_to_f32(q[d]) * tt_cpu_bf16_to_f32(k[d]);
+          p[j] = s * scale;
+          if (p[j] > mx) mx = p[j];
+        }
+        double sum = 0.0;
+        for (int j = 0; j < N; ++j) { p[j] = exp(p[j] - mx); sum += p[j]; p[j] = tt_cpu_bf16_to_f32(tt_cpu_bf16((float)p[j])); }
+        for (int d = 0; d < head_dim; ++d) {
+          double acc = 0.0;
+          for (int j = 0; j < N; ++j) acc += p[j] * tt_cpu_bf16_to_f32(in[((size_t)f * N + j) * D3 + 2 * D + h * head_dim + d]);
+          o[((size_t)f * N + i) * D + h * head_dim + d] = tt_cpu_bf16((float)(acc / sum));
+        }
+      }
+  free(p);
+  return 0;
+}

@@ -336,3 +336,156 @@ def test_hip_library_equals_its_cpu_twin_round2(twin):
     assert (A["planes"][1] == B["planes"][1]).all() and A["planes"][2] == B["planes"][2] == 3     # bf16 planes bit for bit
     for a, b in zip(A["adamw"][1], B["adamw"][1]):
         assert _re(a, b) < 1e-6
+
+
+# ---- second batch: backward of the row ops, attention backward, patch embedding, plane ops --------------------------------------
+
+def _round2b_cases(side):
+    st = "STREAM" if side.device else None
+    rng = np.random.default_rng(11)
+    f32 = lambda *s, scale=1.0: (rng.standard_normal(s) * scale).astype(np.float32)
+    R = {}
+    # colsum / add
+    a = f32(50, 24)
+    cs = np.empty(24, np.float32)
+    ws = np.empty(1 << 20, np.uint8)
+    side.run("colsum", a, cs, 50, 24, ws, 1 << 20, st, outs=(cs,))
+    b_ = f32(50 * 24)
+    a2 = a.reshape(-1).copy()
+    side.run("add_inplace", a2, b_, 50 * 24, st, outs=(a2,))
+    R["colsum_add"] = (a, cs.copy(), b_, a2.copy())
+    # LayerNorm backward (plain, accumulating, and with the dropped cls rows) + l2norm backward
+    Fr, Nt, D = 2, 5, 40
+    x, g = f32(Fr, Nt, D), 1 + 0.1 * f32(D)
+    mu = x.astype(np.float64).mean(-1).reshape(-1).astype(np.float32)
+    rs = (1.0 / np.sqrt(x.astype(np.float64).var(-1) + 1e-6)).reshape(-1).astype(np.float32)
+    dy = f32(Fr * Nt, D)
+    dx, dg, db = np.empty((Fr * Nt, D), np.float32), np.empty(D, np.float32), np.empty(D, np.float32)
+    side.run("layernorm_bwd", dy, x, g, mu, rs, dx, dg, db, Fr * Nt, D, 0, 0, ws, 1 << 20, st, outs=(dx, dg, db))
+    # dropped-cls form: statistics / dy only for the patch rows, dx has x's layout and its cls rows are not written
+    keep = np.array([r for r in range(Fr * Nt) if r % Nt != 0])
+    dyd = np.ascontiguousarray(dy[keep])
+    dxd = np.zeros((Fr * Nt, D), np.float32)
+    side.run("layernorm_bwd", dyd, x, g, np.ascontiguousarray(mu[keep]), np.ascontiguousarray(rs[keep]), dxd, None, None, Fr * (Nt - 1), D, 1, Nt, ws, 1 << 20,
+             st, outs=(dxd,))
+    R["ln_bwd"] = (x, g, dy, dx.copy(), dg.copy(), db.copy(), keep, dxd.copy())
+    xn = x.reshape(-1, D) / np.linalg.norm(x.reshape(-1, D), axis=1, keepdims=True)
+    inv = (1.0 / np.linalg.norm(x.reshape(-1, D), axis=1)).astype(np.float32)
+    dxn, dxl = f32(Fr * Nt, D), np.empty((Fr * Nt, D), np.float32)
+    side.run("l2norm_bwd", dxn, xn.astype(np.float32), inv, dxl, Fr * Nt, D, st, outs=(dxl,))
+    R["l2_bwd"] = (x.reshape(-1, D), dxn, dxl.copy())
+    # attention backward from the forward's saved out / lse
+    Fa, Na, H = 2, 21, 2
+    qkv = f32(Fa, Na, 3 * H * 64, scale=0.5)
+    out, lse = np.empty((Fa, Na, H * 64), np.float32), np.empty((Fa, H, Na), np.float32)
+    side.run("attention_fwd", qkv, out, lse, None, Fa, Na, H, 64, 0.125, st, outs=(out, lse))
+    dout, dqkv = f32(Fa, Na, H * 64), np.empty_like(qkv)
+    nbw = 1 << 24
+    wsa = np.empty(nbw, np.uint8)
+    side.run("attention_bwd", qkv, out, dout, lse, dqkv, Fa, Na, H, 64, 0.125, wsa, nbw, st, outs=(dqkv,))
+    R["att_bwd"] = (qkv, dout, dqkv.copy())
+    # patch embedding with a frame map
+    Fp, C, Hh, Ww, P, Dm = 3, 3, 32, 48, 16, 24
+    img, w, b, cls, pos = f32(4, C, Hh, Ww), f32(Dm, C * P * P, scale=0.05), f32(Dm), f32(Dm), f32(1 + 6, Dm)
+    fmap = np.array([2, 0, 3], np.int32)
+    tok = np.empty((Fp, 7, Dm), np.float32)
+    side.run("patch_embed_fwd", img, fmap, w, b, cls, pos, tok, Fp, C, Hh, Ww, P, Dm, st, outs=(tok,))
+    R["patch"] = (img, fmap, w, b, cls, pos, tok.copy())
+    xa, sc, sh = f32(30, 7), f32(7), f32(7)
+    xa2 = xa.copy()
+    side.run("affine_cols_inplace", xa2, sc, sh, 30, 7, st, outs=(xa2,))
+    R["affine"] = (xa, sc, sh, xa2.copy())
+    # plane ops
+    xt = f32(70, 24)
+    tp = np.empty((24, 128), np.uint16)
+    side.run("transpose_planes", xt, tp, 70, 24, 128, st, outs=(tp,))
+    xl, gl, bl = f32(3, 5, 64), 1 + 0.1 * f32(64), 0.1 * f32(64)
+    lp = np.empty((3, 15, 64), np.uint16)
+    side.run("layernorm_fwd_planes", xl, gl, bl, lp, 15 * 64, 3, None, None, 15, 64, 1e-6, 0, st, outs=(lp,))
+    R["planes_misc"] = (xt, tp.copy(), xl, gl, bl, lp.copy())
+    M, N, K = 70, 64, 128
+    xs_, w_, bb, rr = f32(M, K), f32(N, K, scale=0.1), f32(N), f32(M, N)
+    res = {}
+    for P_ in (1, 3):
+        xp, wp = np.empty((P_, M, K), np.uint16), np.empty((P_, N, K), np.uint16)
+        side.run("split_planes", xs_, xp, M * K, P_, M * K, st, outs=(xp,))
+        side.run("split_planes", w_, wp, N * K, P_, N * K, st, outs=(wp,))
+        y, pre, yp = np.empty((M, N), np.float32), np.empty((M, N), np.float32), np.empty((P_, M, N), np.uint16)
+        side.run("linear_fwd_planes", xp, M * K, wp, N * K, P_, bb, rr, y, pre, yp, M * N, P_, M, N, K, 1, st, outs=(y, pre, yp))
+        res[P_] = (xp.copy(), wp.copy(), y.copy(), pre.copy(), yp.copy())
+    R["plane_gemm"] = (xs_, w_, bb, rr, res)
+    qb = np.empty((2, 21, 3 * 128), np.uint16)
+    side.run("split_planes", f32(2, 21, 3 * 128, scale=0.6), qb, 2 * 21 * 384, 1, 2 * 21 * 384, st, outs=(qb,))
+    ob = np.empty((2, 21, 128), np.uint16)
+    side.run("attention_fwd_bf16", qb, ob, 2, 21, 2, 64, 0.125, st, outs=(ob,))
+    R["att_bf16"] = (qb, ob.copy())
+    return R
+
+
+def _bf(a):
+    return torch.from_numpy(a.astype(np.int16)).view(torch.bfloat16).double().numpy()
+
+
+def test_round2b_twins_against_torch(twin):
+    R = _round2b_cases(_Side(twin, "tt_cpu_"))
+    a, cs, b_, a2 = R["colsum_add"]
+    assert _re(cs, a.astype(np.float64).sum(0)) < 1e-6 and np.array_equal(a2, a.reshape(-1) + b_)
+    x, g, dy, dx, dg, db, keep, dxd = R["ln_bwd"]
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    gt = torch.from_numpy(g).double().requires_grad_(True)
+    bt = torch.zeros(x.shape[-1], dtype=torch.float64, requires_grad=True)
+    (F.layer_norm(xt, (x.shape[-1],), gt, bt, 1e-6).reshape(-1, x.shape[-1]) * torch.from_numpy(dy).double()).sum().backward()
+    assert _re(dx, xt.grad.reshape(dx.shape).numpy()) < 1e-5 and _re(dg, gt.grad.numpy()) < 1e-5 and _re(db, bt.grad.numpy()) < 1e-6
+    xt.grad = None
+    y2 = F.layer_norm(xt, (x.shape[-1],), gt.detach(), bt.detach(), 1e-6).reshape(-1, x.shape[-1])[torch.from_numpy(keep)]
+    (y2 * torch.from_numpy(dy[keep]).double()).sum().backward()
+    assert _re(dxd, xt.grad.reshape(dxd.shape).numpy()) < 1e-5 and (dxd[::5] == 0).all()
+    xx, dxn, dxl = R["l2_bwd"]
+    xt = torch.from_numpy(xx).double().requires_grad_(True)
+    (F.normalize(xt, dim=1) * torch.from_numpy(dxn).double()).sum().backward()
+    assert _re(dxl, xt.grad.numpy()) < 1e-5
+    qkv, dout, dqkv = R["att_bwd"]
+    qt = torch.from_numpy(qkv).double().requires_grad_(True)
+    q, k, v = qt.view(2, 21, 3, 2, 64).permute(2, 0, 3, 1, 4)
+    o = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(2, 21, 128)
+    (o * torch.from_numpy(dout).double()).sum().backward()
+    assert _re(dqkv, qt.grad.numpy()) < 1e-5
+    img, fmap, w, b, cls, pos, tok = R["patch"]
+    conv = F.conv2d(torch.from_numpy(img[fmap]).double(), torch.from_numpy(w).double().view(24, 3, 16, 16), torch.from_numpy(b).double(), stride=16)
+    ref = torch.cat([torch.from_numpy(cls).double().expand(3, 1, 24), conv.flatten(2).transpose(1, 2)], 1) + torch.from_numpy(pos).double()
+    assert _re(tok, ref.numpy()) < 1e-6
+    xa, sc, sh, xa2 = R["affine"]
+    assert np.array_equal(xa2, xa * sc + sh)
+    xt_, tp, xl, gl, bl, lp = R["planes_misc"]
+    assert np.array_equal(_bf(tp)[:, :70], torch.from_numpy(xt_).to(torch.bfloat16).double().numpy().T) and (tp[:, 70:] == 0).all()
+    lnref = F.layer_norm(torch.from_numpy(xl).double(), (64,), torch.from_numpy(gl).double(), torch.from_numpy(bl).double(), 1e-6).numpy()
+    assert _re(_bf(lp).sum(0), lnref.reshape(15, 64)) < 1e-6
+    xs_, w_, bb, rr, res = R["plane_gemm"]
+    for P_, (xp, wp, y, pre, yp) in res.items():
+        ref_pre = sum(_bf(xp[i]) @ _bf(wp[j]).T for i in range(P_) for j in range(P_ - i)) + bb
+        assert _re(pre, ref_pre) < 1e-6 and _re(y, F.gelu(torch.from_numpy(ref_pre)).numpy() + rr) < 1e-6
+        assert _re(_bf(yp).sum(0), y) < (1e-7 if P_ == 3 else 2.0 ** -8)
+    assert _re(res[3][3], xs_.astype(np.float64) @ w_.astype(np.float64).T + bb) < 2e-6          # three planes: fp32-accurate
+    qb, ob = R["att_bf16"]
+    qf = torch.from_numpy(_bf(qb))
+    q, k, v = qf.view(2, 21, 3, 2, 64).permute(2, 0, 3, 1, 4)
+    o = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(2, 21, 128)
+    assert _re(_bf(ob), o.numpy()) < 1.5e-2
+
+
+@pytest.mark.gpu
+def test_hip_library_equals_its_cpu_twin_round2b(twin):
+    from timetuning_amd import _lib
+
+    A = _round2b_cases(_Side(_lib.load(), "tt_", device="cuda"))
+    B = _round2b_cases(_Side(twin, "tt_cpu_"))
+    for key in ("colsum_add", "ln_bwd", "l2_bwd", "att_bwd", "patch", "affine"):
+        for i, (a, b) in enumerate(zip(A[key], B[key])):
+            if isinstance(a, np.ndarray) and a.dtype == np.float32:
+                assert _re(a, b) < 2e-5, (key, i, _re(a, b))
+    assert np.array_equal(A["planes_misc"][1], B["planes_misc"][1])                         # transposed bf16 image: bit for bit
+    assert _re(_bf(A["planes_misc"][5]).sum(0), _bf(B["planes_misc"][5]).sum(0)) < 2e-6       # LayerNorm planes: same value to fp32 rounding
+    for P_ in (1, 3):
+        for i in (2, 3):
+            assert _re(A["plane_gemm"][4][P_][i], B["plane_gemm"][4][P_][i]) < 2e-5, (P_, i)
+    assert _re(_bf(A["att_bf16"][1]), _bf(B["att_bf16"][1])) < 1.5e-2

@@ -20,7 +20,10 @@
 //     128 frames (qkv + proj + fc1 + fc2) against 834 us for this kernel on the same box (tools/bench_linear.py), same 5e-7
 //     error.  Three very different loop structures (this one, the DMA ring, hipBLASLt's stream-K) land within +-8 % of
 //     110 TFLOP/s at K = 384: the ceiling is not in the staging path;
-//   * (round 2) s_setprio 1 / 2 for the main loop (epilogue at 0): no difference (interleaved A/B, all four block shapes).
+//   * (round 2) s_setprio 1 / 2 for the main loop (epilogue at 0): no difference (interleaved A/B, all four block shapes);
+//   * (round 2) BK = 32 slabs on the large grids (half the barriers, twice the staging registers and LDS): 899 us per block
+//     against 810 us at BK = 16 - the extra LDS drops a workgroup per CU.  BK = 64 is kept only for grids <= 320 tiles, where
+//     a CU holds one workgroup anyway.
 #include "common.hpp"
 #include <cstdlib>
 
