@@ -71,10 +71,8 @@ USE_MASK = False  # --use_mask: the attention-masked variant of the objective (n
 
 def train_step(model, opt, x, use_teacher):
     loss = model(x, None, True, USE_MASK)
-    opt.step(loss)
-    model.normalize_prototypes()
-    if use_teacher:
-        model.update_momentum_teacher(min(opt.global_step, len(model.momentum_schedule) - 1))
+    # optimizer.step(loss) + normalize_prototypes() + update_momentum_teacher(step) (time_tuning.py:659-663), one C call
+    model.train_update(opt, loss, min(opt.global_step + 1, len(model.momentum_schedule) - 1) if use_teacher else 0)
     return loss
 
 

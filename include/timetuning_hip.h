@@ -321,6 +321,64 @@ int tt_img_color(unsigned char* img, int F, int H, int W, int mode, float factor
 int tt_img_box_blur(const unsigned char* in, unsigned char* out, int F, int H, int W, int direction, int radius, unsigned ww, unsigned fw,
                     tt_stream_t stream);
 
+/* ---- Coarse entry points: whole reference functions as ONE call each.  They sequence the op-level entry
+ *      points above on `stream` (same kernels, same results bit for bit as calling those one by one; they honour
+ *      tt_set_gemm_precision the way tt_linear_fwd does) and add nothing but the scratch layout.  Parameter tables are HOST
+ *      arrays of DEVICE pointers, read during the call only.
+ *
+ *   tt_vit_forward       VisionTransformer.prepare_tokens + blocks + norm (dino_vision_transformer.py:236-252,265-273; Block
+ *                        :135-153, Attention :108-132, Mlp :89-105), i.e. FeatureExtractor.get_features' backbone pass
+ *                        (models.py:965-969).  img [F_src, C, H, W] and frame_map (int32 [F], optional) as tt_patch_embed_fwd;
+ *                        img == NULL: `tokens` already holds a residual stream [F, N, D] (an EMA teacher continuing from the
+ *                        student's frozen blocks) and p->patch_* / cls / pos are not read.  Blocks p->blocks[0 .. n_blocks) run
+ *                        in place on tokens [F, N, D], N = 1 + (H / patch)(W / patch).  normed (optional): the final LayerNorm of
+ *                        the tokens, [F, N, D] or, with drop_cls != 0, [F, N - 1, D] (get_features drops the cls token).
+ *                        last_qkv (optional, [F, N, 3 D]): the last block's qkv activations (what tt_foreground_mask reads);
+ *                        last_probs (optional, [F, heads, N, N]): its attention probabilities (get_last_selfattention, :256-263).
+ *   tt_mlp_head_forward  the projection head (models.py:915-926,1075-1077): Linear (GELU Linear)*, x [M, layers[0].in_features]
+ *                        -> out [M, layers[n - 1].out_features].
+ *   tt_scores_sinkhorn   TimeT.get_scores (time_tuning.py:195-217) for one rank: scores = normalize(z) @ prototypes^T for the
+ *                        batch rows z [B, dim] and, when queue != NULL, the queue rows [queue_rows, dim] (:207-211), then the
+ *                        Sinkhorn assignment over all B + queue_rows columns; q_out [rows_out, K] = the first rows_out rows.
+ *                        scores [B + queue_rows, K] is an output too (batch_scores = its first B rows).  For world_size > 1 the
+ *                        caller all-gathers `scores` and calls tt_sinkhorn on the gathered rows (the "gathered pointer" form).
+ *   tt_adamw_ema_step    optimizer.step() + normalize_prototypes() + update_momentum_teacher() (time_tuning.py:659-663 ->
+ *                        :413-429, :124-128, :109-122): AdamW over `tensors` (any count), prototypes [K, dim] renormalised in
+ *                        place (skipped when NULL), then - when teacher_flat != NULL - teacher <- teacher (1 - m) + student m
+ *                        over the flat parameter buffers and the teacher prototypes, which are renormalised too. */
+typedef struct {
+  const float *norm1_w, *norm1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+  const void *qkv_wp, *proj_wp, *fc1_wp, *fc2_wp;   /* planes > 0: the four weights as bf16 planes [planes][out][in] (tt_split_planes) */
+} tt_vit_block_params;
+typedef struct {
+  const float *patch_w, *patch_b, *cls, *pos;   /* [D, C P P], [D], [D], [N, D] (position table at the input's grid) */
+  const tt_vit_block_params* blocks;            /* host array, n_blocks entries */
+  int n_blocks;
+  const float *norm_w, *norm_b;                 /* final LayerNorm (may be NULL when normed == NULL) */
+  int dim, heads, hidden, patch;                /* D, attention heads (head_dim = D / heads), MLP width, patch size */
+  int planes;                                   /* 0: fp32 operands (tt_linear_fwd); 1 / 3: the bf16-plane path of the blocks
+                                                   (tt_linear_fwd_planes; 1 = BASELINE C4's bf16 path, 3 = fp32-accurate), D % 64 == 0 */
+} tt_vit_params;
+typedef struct {
+  const float* w;   /* [out_features, in_features] */
+  const float* b;   /* [out_features] or NULL */
+  int out_features, in_features;
+} tt_linear_params;
+size_t tt_vit_forward_workspace_bytes(int F, int N, int D, int hidden, int planes);
+int tt_vit_forward(const tt_vit_params* p, const float* img, const int32_t* frame_map, int F, int C, int H, int W, float* tokens,
+                   float* normed, int drop_cls, float* last_qkv, float* last_probs, void* workspace, size_t workspace_bytes,
+                   tt_stream_t stream);
+size_t tt_mlp_head_forward_workspace_bytes(int M, const tt_linear_params* layers, int n_layers);
+int tt_mlp_head_forward(const float* x, int M, const tt_linear_params* layers, int n_layers, float* out, void* workspace,
+                        size_t workspace_bytes, tt_stream_t stream);
+size_t tt_scores_sinkhorn_workspace_bytes(int B, int queue_rows, int K, int dim);
+int tt_scores_sinkhorn(const float* z, int B, const float* queue, int queue_rows, const float* prototypes, int K, int dim,
+                       float* scores, float* q_out, int rows_out, float eps, int iters, void* workspace, size_t workspace_bytes,
+                       tt_stream_t stream);
+int tt_adamw_ema_step(const tt_adamw_tensor* tensors, int count, int step, float beta1, float beta2, float eps, float* prototypes,
+                      int K, int dim, float* teacher_flat, const float* student_flat, long long n_flat, float* teacher_prototypes,
+                      double momentum, tt_stream_t stream);
+
 /* features * mask[..., None] (models.py:142) and its backward: x[r][:] *= row_scale[r], cols % 4 == 0. */
 int tt_scale_rows_inplace(float* x, const float* row_scale, int rows, int cols, tt_stream_t stream);
 

@@ -711,3 +711,130 @@ int tt_cpu_attention_fwd_bf16(const void* qkv, void* out, int F, int N, int H, i
   free(p);
   return 0;
 }
+
+/* ---- the coarse entry points (include/timetuning_hip.h, "Coarse entry points"): the same sequences over the twins above.
+ *      Scratch is malloc'ed here (the workspace arguments are ignored, the *_workspace_bytes twins return 0). */
+typedef struct {
+  const float *norm1_w, *norm1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+  const void *qkv_wp, *proj_wp, *fc1_wp, *fc2_wp;
+} tt_cpu_vit_block_params;
+typedef struct {
+  const float *patch_w, *patch_b, *cls, *pos;
+  const tt_cpu_vit_block_params* blocks;
+  int n_blocks;
+  const float *norm_w, *norm_b;
+  int dim, heads, hidden, patch;
+  int planes;
+} tt_cpu_vit_params;
+typedef struct { const float* w; const float* b; int out_features, in_features; } tt_cpu_linear_params;
+
+size_t tt_cpu_vit_forward_workspace_bytes(int F, int N, int D, int hidden, int planes) { return 0; }
+size_t tt_cpu_mlp_head_forward_workspace_bytes(int M, const tt_cpu_linear_params* layers, int n_layers) { return 0; }
+size_t tt_cpu_scores_sinkhorn_workspace_bytes(int B, int queue_rows, int K, int dim) { return 0; }
+
+/* dino_vision_transformer.py:236-252 (prepare_tokens, blocks), :135-153 (Block), :265-273 (final norm) */
+int tt_cpu_vit_forward(const tt_cpu_vit_params* p, const float* img, const int32_t* frame_map, int F, int C, int H, int W, float* tokens,
+                       float* normed, int drop_cls, float* last_qkv, float* last_probs, void* workspace, size_t workspace_bytes,
+                       tt_stream_t stream) {
+  const int D = p->dim, hd = D / p->heads, P = p->planes, Hd = p->hidden;
+  const int N = 1 + (H / p->patch) * (W / p->patch);
+  const size_t M = (size_t)F * N;
+  const float scale = 1.0f / sqrtf((float)hd);
+  if (img) tt_cpu_patch_embed_fwd(img, frame_map, p->patch_w, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, stream);
+  float* h = (float*)malloc(M * D * 4), *qkv_own = (float*)malloc(M * 3 * D * 4), *att = (float*)malloc(M * D * 4);
+  float* act = (float*)malloc(M * Hd * 4);
+  const int PP = P > 0 ? P : 1;
+  uint16_t* hp = (uint16_t*)malloc(PP * M * D * 2), *qkvb = (uint16_t*)malloc(M * 3 * D * 2), *attp = (uint16_t*)malloc(PP * M * D * 2);
+  uint16_t* actp = (uint16_t*)malloc(PP * M * Hd * 2);
+  if (!h || !qkv_own || !att || !act || !hp || !qkvb || !attp || !actp) return -3;
+  for (int i = 0; i < p->n_blocks; ++i) {
+    const tt_cpu_vit_block_params* b = &p->blocks[i];
+    const int last = i == p->n_blocks - 1;
+    float* probs = last ? last_probs : NULL;
+    float* qkv = (last && last_qkv) ? last_qkv : qkv_own;
+    if (P == 0) {
+      tt_cpu_layernorm_fwd(tokens, b->norm1_w, b->norm1_b, h, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
+      tt_cpu_linear_fwd(h, b->qkv_w, b->qkv_b, NULL, qkv, NULL, (int)M, 3 * D, D, 0, stream);
+      tt_cpu_attention_fwd(qkv, att, NULL, probs, F, N, p->heads, hd, scale, stream);
+      tt_cpu_linear_fwd(att, b->proj_w, b->proj_b, tokens, tokens, NULL, (int)M, D, D, 0, stream);
+      tt_cpu_layernorm_fwd(tokens, b->norm2_w, b->norm2_b, h, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
+      tt_cpu_linear_fwd(h, b->fc1_w, b->fc1_b, NULL, act, NULL, (int)M, Hd, D, 1, stream);
+      tt_cpu_linear_fwd(act, b->fc2_w, b->fc2_b, tokens, tokens, NULL, (int)M, D, Hd, 0, stream);
+      continue;
+    }
+    const long long MD = (long long)M * D;
+    tt_cpu_layernorm_fwd_planes(tokens, b->norm1_w, b->norm1_b, hp, MD, P, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
+    const void* proj_in;
+    if (P == 1 && !(last && last_qkv) && !probs && N <= 256 && hd == 64) {
+      tt_cpu_linear_fwd_planes(hp, MD, b->qkv_wp, 3ll * D * D, 1, b->qkv_b, NULL, NULL, NULL, qkvb, (long long)M * 3 * D, 1, (int)M, 3 * D, D, 0,
+                               stream);
+      tt_cpu_attention_fwd_bf16(qkvb, attp, F, N, p->heads, hd, scale, stream);
+    } else {
+      tt_cpu_linear_fwd_planes(hp, MD, b->qkv_wp, 3ll * D * D, P, b->qkv_b, NULL, qkv, NULL, NULL, 0, 0, (int)M, 3 * D, D, 0, stream);
+      tt_cpu_attention_fwd(qkv, att, NULL, probs, F, N, p->heads, hd, scale, stream);
+      tt_cpu_split_planes(att, attp, MD, P, MD, stream);
+    }
+    proj_in = attp;
+    tt_cpu_linear_fwd_planes(proj_in, MD, b->proj_wp, (long long)D * D, P, b->proj_b, tokens, tokens, NULL, NULL, 0, 0, (int)M, D, D, 0, stream);
+    tt_cpu_layernorm_fwd_planes(tokens, b->norm2_w, b->norm2_b, hp, MD, P, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
+    tt_cpu_linear_fwd_planes(hp, MD, b->fc1_wp, (long long)Hd * D, P, b->fc1_b, NULL, NULL, NULL, actp, (long long)M * Hd, P, (int)M, Hd, D, 1,
+                             stream);
+    tt_cpu_linear_fwd_planes(actp, (long long)M * Hd, b->fc2_wp, (long long)Hd * D, P, b->fc2_b, tokens, tokens, NULL, NULL, 0, 0, (int)M, D, Hd,
+                             0, stream);
+  }
+  free(h); free(qkv_own); free(att); free(act); free(hp); free(qkvb); free(attp); free(actp);
+  if (normed) {
+    if (drop_cls) tt_cpu_layernorm_fwd(tokens, p->norm_w, p->norm_b, normed, NULL, NULL, F * (N - 1), D, 1e-6f, N, stream);
+    else tt_cpu_layernorm_fwd(tokens, p->norm_w, p->norm_b, normed, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
+  }
+  return 0;
+}
+
+/* models.py:915-926,1075-1077: Linear (GELU Linear)* */
+int tt_cpu_mlp_head_forward(const float* x, int M, const tt_cpu_linear_params* layers, int n_layers, float* out, void* workspace,
+                            size_t workspace_bytes, tt_stream_t stream) {
+  int width = 1;
+  for (int i = 0; i < n_layers; ++i) width = layers[i].out_features > width ? layers[i].out_features : width;
+  float* buf[2] = {(float*)malloc((size_t)M * width * 4), (float*)malloc((size_t)M * width * 4)};
+  if (!buf[0] || !buf[1]) return -3;
+  const float* cur = x;
+  for (int i = 0; i < n_layers; ++i) {
+    const int last = i == n_layers - 1;
+    float* dst = last ? out : buf[i & 1];
+    tt_cpu_linear_fwd(cur, layers[i].w, layers[i].b, NULL, dst, NULL, M, layers[i].out_features, layers[i].in_features, last ? 0 : 1, stream);
+    cur = dst;
+  }
+  free(buf[0]); free(buf[1]);
+  return 0;
+}
+
+/* time_tuning.py:195-217 (get_scores) on one rank: normalised batch and queue rows against the prototypes, one assignment */
+int tt_cpu_scores_sinkhorn(const float* z, int B, const float* queue, int queue_rows, const float* prototypes, int K, int dim, float* scores,
+                           float* q_out, int rows_out, float eps, int iters, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  if (!queue) queue_rows = 0;
+  const int total = B + queue_rows;
+  float* zn = (float*)malloc((size_t)total * dim * 4);
+  if (!zn) return -3;
+  tt_cpu_l2norm_fwd(z, dim, zn, NULL, B, dim, stream);
+  tt_cpu_linear_fwd(zn, prototypes, NULL, NULL, scores, NULL, B, K, dim, 0, stream);
+  if (queue_rows) {
+    tt_cpu_l2norm_fwd(queue, dim, zn + (size_t)B * dim, NULL, queue_rows, dim, stream);
+    tt_cpu_linear_fwd(zn + (size_t)B * dim, prototypes, NULL, NULL, scores + (size_t)B * K, NULL, queue_rows, K, dim, 0, stream);
+  }
+  free(zn);
+  return tt_cpu_sinkhorn(scores, q_out, total, K, 0, rows_out, eps, iters, NULL, 0, stream);
+}
+
+/* time_tuning.py:659-663: optimizer.step(), normalize_prototypes() (:124-128), update_momentum_teacher() (:109-122) */
+int tt_cpu_adamw_ema_step(const tt_cpu_adamw_tensor* tensors, int count, int step, float beta1, float beta2, float eps, float* prototypes, int K,
+                          int dim, float* teacher_flat, const float* student_flat, long long n_flat, float* teacher_prototypes, double momentum,
+                          tt_stream_t stream) {
+  tt_cpu_adamw_step(tensors, count, step, beta1, beta2, eps, stream);
+  if (prototypes) tt_cpu_normalize_rows_inplace(prototypes, K, dim, stream);
+  if (n_flat > 0) tt_cpu_ema_update(teacher_flat, student_flat, n_flat, momentum, stream);
+  if (teacher_prototypes) {
+    tt_cpu_ema_update(teacher_prototypes, prototypes, (long long)K * dim, momentum, stream);
+    tt_cpu_normalize_rows_inplace(teacher_prototypes, K, dim, stream);
+  }
+  return 0;
+}

@@ -28,6 +28,21 @@ class AdamwTensor(C.Structure):
                 ("lr", C.c_float), ("weight_decay", C.c_float)]
 
 
+class VitBlockParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b",
+                                          "fc2_w", "fc2_b", "qkv_wp", "proj_wp", "fc1_wp", "fc2_wp")]
+
+
+class VitParams(C.Structure):
+    _fields_ = [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
+                ("blocks", C.POINTER(VitBlockParams)), ("n_blocks", C.c_int), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
+                ("dim", C.c_int), ("heads", C.c_int), ("hidden", C.c_int), ("patch", C.c_int), ("planes", C.c_int)]
+
+
+class LinearParams(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("out_features", C.c_int), ("in_features", C.c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol include/timetuning_hip.h declares
 SIGNATURES = {
     "tt_last_error": (C.c_char_p, []),
@@ -73,6 +88,13 @@ SIGNATURES = {
     "tt_adamw_step": (c_i, [C.POINTER(AdamwTensor), c_i, c_i, c_f, c_f, c_f, c_vp]),
     "tt_scale_tensors": (c_i, [C.POINTER(AdamwTensor), c_i, c_vp, c_vp]),
     "tt_ema_update": (c_i, [c_vp, c_vp, c_ll, c_d, c_vp]),
+    "tt_vit_forward_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "tt_vit_forward": (c_i, [C.POINTER(VitParams), c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tt_mlp_head_forward_workspace_bytes": (c_sz, [c_i, C.POINTER(LinearParams), c_i]),
+    "tt_mlp_head_forward": (c_i, [c_vp, c_i, C.POINTER(LinearParams), c_i, c_vp, c_vp, c_sz, c_vp]),
+    "tt_scores_sinkhorn_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "tt_scores_sinkhorn": (c_i, [c_vp, c_i, c_vp, c_i, c_vp, c_i, c_i, c_vp, c_vp, c_i, c_f, c_i, c_vp, c_sz, c_vp]),
+    "tt_adamw_ema_step": (c_i, [C.POINTER(AdamwTensor), c_i, c_i, c_f, c_f, c_f, c_vp, c_i, c_i, c_vp, c_vp, c_ll, c_vp, c_d, c_vp]),
     "tt_add_inplace": (c_i, [c_vp, c_vp, c_ll, c_vp]),
     "tt_count_mismatch": (c_i, [c_vp, c_vp, c_ll, c_vp, c_vp]),
     "tt_foreground_mask": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_vp]),

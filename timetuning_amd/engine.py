@@ -146,6 +146,42 @@ def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int,
     return dx_in if need_dx else None
 
 
+def vit_params(vit, first: int, last: int, pos: Optional[torch.Tensor] = None):
+    """The parameter table ``ops.vit_forward`` (tt_vit_forward) reads, for blocks [first, last) of ``vit`` in the arithmetic the
+    precision mode selects for blocks that keep nothing (fp32 operands, or the bf16 planes of ``weight_planes``).  Returns
+    (struct, keep-alive list); rebuilt per call - parameters are re-homed by ``.to()`` / the EMA flattening, and the teacher's
+    planes are re-split every step."""
+    from . import _lib
+
+    D = vit.patch_embed.proj.weight.shape[0]
+    planes = ops.plane_count() if D % 64 == 0 else 0
+    n = last - first
+    arr = (_lib.VitBlockParams * max(n, 1))()
+    keep = [arr]
+    for j in range(n):
+        blk = vit.blocks[first + j]
+        at, mlp = blk.attn, blk.mlp
+        b = arr[j]
+        for name, t in (("norm1_w", blk.norm1.weight), ("norm1_b", blk.norm1.bias), ("qkv_w", at.qkv.weight), ("qkv_b", at.qkv.bias),
+                        ("proj_w", at.proj.weight), ("proj_b", at.proj.bias), ("norm2_w", blk.norm2.weight), ("norm2_b", blk.norm2.bias),
+                        ("fc1_w", mlp.fc1.weight), ("fc1_b", mlp.fc1.bias), ("fc2_w", mlp.fc2.weight), ("fc2_b", mlp.fc2.bias)):
+            setattr(b, name, t.data_ptr() if t is not None else None)
+        if planes:
+            for name, w in (("qkv_wp", at.qkv.weight), ("proj_wp", at.proj.weight), ("fc1_wp", mlp.fc1.weight), ("fc2_wp", mlp.fc2.weight)):
+                wp = weight_planes(w, planes)
+                keep.append(wp)
+                setattr(b, name, wp.data_ptr())
+    pe = vit.patch_embed.proj
+    vp = _lib.VitParams()
+    vp.patch_w, vp.patch_b, vp.cls = pe.weight.data_ptr(), pe.bias.data_ptr(), vit.cls_token.data_ptr()
+    vp.pos = pos.data_ptr() if pos is not None else None
+    vp.blocks, vp.n_blocks = arr, n
+    vp.norm_w, vp.norm_b = vit.norm.weight.data_ptr(), vit.norm.bias.data_ptr()
+    vp.dim, vp.heads, vp.hidden, vp.patch, vp.planes = D, vit.num_heads, vit.blocks[0].mlp.fc1.weight.shape[0], vit.patch_embed.patch_size, planes
+    keep.append(pos)
+    return vp, keep
+
+
 def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None, save_blocks: Optional[Dict[int, dict]] = None,
                last_block_probs: bool = False, last_block_aux: Optional[dict] = None, tap: Optional[dict] = None,
                save_from_frame: int = 0):
@@ -161,14 +197,28 @@ def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None,
     ``save_from_frame == 0`` (or nothing kept) as one tensor."""
     pe = vit.patch_embed.proj
     D = pe.weight.shape[0]
-    x = ops.patch_embed_fwd(img, pe.weight.view(D, -1), pe.bias, vit.cls_token.view(D), vit.pos_table(img.shape[-2], img.shape[-1]),
-                            vit.patch_embed.patch_size, frame_map)
     probs = None
     depth = len(vit.blocks)
     first_saved = min(save_blocks) if save_blocks else depth
     split = save_blocks and save_from_frame > 0
     lo = hi = None
+    pos = vit.pos_table(img.shape[-2], img.shape[-1])
+    done = 0
+    if ops.fine_grained():
+        x = ops.patch_embed_fwd(img, pe.weight.view(D, -1), pe.bias, vit.cls_token.view(D), pos, vit.patch_embed.patch_size, frame_map)
+    else:
+        # ONE call (tt_vit_forward) for prepare_tokens and every leading block that keeps nothing and is not tapped
+        done = min(first_saved, tap["block"] if tap is not None else depth, depth - 1 if last_block_probs else depth)
+        Fr = img.shape[0] if frame_map is None else frame_map.numel()
+        P_ = vit.patch_embed.patch_size
+        x = torch.empty((Fr, 1 + (img.shape[-2] // P_) * (img.shape[-1] // P_), D), dtype=f32, device=img.device)
+        want_qkv = last_block_aux is not None and done == depth
+        _, qkv_last, _ = ops.vit_forward(vit_params(vit, 0, done, pos), done, x, img=img, frame_map=frame_map, last_qkv=want_qkv)
+        if want_qkv:
+            last_block_aux["qkv"] = qkv_last
     for i, blk in enumerate(vit.blocks):
+        if i < done:
+            continue
         if tap is not None and tap["block"] == i:
             tap["x"] = (x if lo is None else lo)[: tap["rows"]].clone()
         sv = save_blocks.get(i) if save_blocks is not None else None
@@ -194,6 +244,11 @@ def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None,
 def vit_blocks(vit, x: torch.Tensor, first: int, last_block_aux: Optional[dict] = None) -> torch.Tensor:
     """Blocks [first, depth) of ``vit`` on a residual stream x [F,N,D] that is the caller's to overwrite."""
     depth = len(vit.blocks)
+    if not ops.fine_grained() and first < depth:
+        _, qkv_last, _ = ops.vit_forward(vit_params(vit, first, depth), depth - first, x, last_qkv=last_block_aux is not None)
+        if last_block_aux is not None:
+            last_block_aux["qkv"] = qkv_last
+        return x
     for i in range(first, depth):
         x = block_forward(x, vit.blocks[i], vit.num_heads, None, last_block_aux if i == depth - 1 else None)
     return x
@@ -218,6 +273,8 @@ def head_linears(head) -> List[torch.nn.Linear]:
 
 def head_forward(x: torch.Tensor, head, save: Optional[dict] = None) -> torch.Tensor:
     lins = head_linears(head)
+    if save is None and not ops.fine_grained():
+        return ops.mlp_head_forward(x, [(lin.weight, lin.bias) for lin in lins])   # tt_mlp_head_forward: one call
     acts = [x]
     pres = []
     for i, lin in enumerate(lins):

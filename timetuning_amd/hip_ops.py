@@ -780,3 +780,105 @@ def linear_bwd_weight_planes(dy, x, need_bias=True):
                "tt_linear_bwd_weight_planes")
     _prof_end(e0, "PLANES1", N, K, Mpad)
     return dw, (colsum(dy) if need_bias else None)
+
+
+# ---- coarse entry points: one C call per reference function ------------------------------------------------
+
+def fine_grained() -> bool:
+    """True while a per-launch GEMM profile is being collected (bench.py's roofline leg): the launch sequences then go through
+    the op-level entry points one ctypes call at a time - the same kernels in the same order as the coarse entry points
+    enqueue - so that every GEMM launch can be bracketed by events."""
+    return PROFILE is not None
+
+
+def vit_forward(params, n_blocks: int, tokens, img=None, frame_map=None, normed_out=None, drop_cls: bool = False, last_qkv: bool = False,
+                last_probs: bool = False):
+    """``tt_vit_forward``: [prepare_tokens of ``img``] + ``n_blocks`` blocks in place on ``tokens`` [F,N,D] [+ final norm].
+    ``params`` = (VitParams struct, keep-alive list) as ``engine.vit_params`` builds it.  Returns (normed or None, qkv of the
+    last block or None, its attention probabilities or None)."""
+    lib = _lib.load()
+    vp, _keep = params
+    _chk(tokens, "tokens")
+    F, N, D = tokens.shape
+    vp.n_blocks = int(n_blocks)
+    dev = tokens.device
+    if img is not None:
+        _chk(img, "img")
+        C_, H, W = img.shape[1], img.shape[2], img.shape[3]
+    else:
+        # the token grid only matters through N: hand the entry point an H x W that yields it
+        C_, H, W = 3, vp.patch, (N - 1) * vp.patch
+    normed = None
+    if normed_out is not None:
+        normed = normed_out if isinstance(normed_out, torch.Tensor) else torch.empty((F * (N - 1), D) if drop_cls else (F, N, D), dtype=f32, device=dev)
+        _chk(normed, "normed_out")
+    qkv = torch.empty((F, N, 3 * D), dtype=f32, device=dev) if last_qkv else None
+    probs = torch.empty((F, vp.heads, N, N), dtype=f32, device=dev) if last_probs else None
+    nb = lib.tt_vit_forward_workspace_bytes(F, N, D, vp.hidden, vp.planes) if n_blocks else 0
+    ws = _ws(nb, dev)
+    _lib.check(lib.tt_vit_forward(vp, _p(img), _p(frame_map), F, C_, H, W, _p(tokens), _p(normed), int(bool(drop_cls)), _p(qkv), _p(probs),
+                                  _p(ws), nb, _stream()), "tt_vit_forward")
+    return normed, qkv, probs
+
+
+def mlp_head_forward(x, layers: Sequence[tuple]):
+    """``tt_mlp_head_forward``: layers = [(weight [out,in], bias or None), ...], GELU between them."""
+    lib = _lib.load()
+    _chk(x, "x")
+    M = x.shape[0]
+    arr = (_lib.LinearParams * len(layers))()
+    for i, (w, b) in enumerate(layers):
+        _chk(w, "weight")
+        if b is not None: _chk(b, "bias")
+        arr[i] = _lib.LinearParams(w.data_ptr(), b.data_ptr() if b is not None else None, w.shape[0], w.shape[1])
+    out = torch.empty((M, layers[-1][0].shape[0]), dtype=f32, device=x.device)
+    nb = lib.tt_mlp_head_forward_workspace_bytes(M, arr, len(layers))
+    ws = _ws(nb, x.device)
+    _lib.check(lib.tt_mlp_head_forward(_p(x), M, arr, len(layers), _p(out), _p(ws), nb, _stream()), "tt_mlp_head_forward")
+    return out
+
+
+def scores_sinkhorn(z, prototypes, queue=None, iters: int = 10, eps: float = 0.05, rows_out: Optional[int] = None):
+    """``tt_scores_sinkhorn``: (q [rows_out, K], scores [B + queue rows, K]) of TimeT.get_scores on one rank."""
+    lib = _lib.load()
+    _chk(z, "z"); _chk(prototypes, "prototypes")
+    B, dim = z.shape
+    K = prototypes.shape[0]
+    Qr = 0
+    if queue is not None:
+        _chk(queue, "queue")
+        Qr = queue.shape[0]
+    rows_out = B if rows_out is None else rows_out
+    scores = torch.empty((B + Qr, K), dtype=f32, device=z.device)
+    q = torch.empty((rows_out, K), dtype=f32, device=z.device)
+    nb = lib.tt_scores_sinkhorn_workspace_bytes(B, Qr, K, dim)
+    ws = _ws(nb, z.device)
+    _lib.check(lib.tt_scores_sinkhorn(_p(z), B, _p(queue), Qr, _p(prototypes), K, dim, _p(scores), _p(q), rows_out, float(eps), int(iters),
+                                      _p(ws), nb, _stream()), "tt_scores_sinkhorn")
+    return q, scores
+
+
+def adamw_ema_step_(entries: Sequence[tuple], step: int, beta1=0.9, beta2=0.999, eps=1e-8, prototypes=None, teacher_flat=None,
+                    student_flat=None, teacher_prototypes=None, momentum: float = 0.0):
+    """``tt_adamw_ema_step``: AdamW over ``entries`` (as ``adamw_step_``), prototypes renormalised, then the EMA teacher update of
+    the flat parameter buffers and the teacher prototypes (each part skipped when its tensors are None)."""
+    lib = _lib.load()
+    arr = (_lib.AdamwTensor * max(len(entries), 1))()
+    for j, (p, g, m, v, lr, wd) in enumerate(entries):
+        for t, nm in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
+            _chk(t, nm)
+        arr[j] = _lib.AdamwTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(wd))
+    K = dim = 0
+    if prototypes is not None:
+        _chk(prototypes, "prototypes")
+        K, dim = prototypes.shape
+    n_flat = 0
+    if teacher_flat is not None:
+        _chk(teacher_flat, "teacher_flat"); _chk(student_flat, "student_flat")
+        assert teacher_flat.numel() == student_flat.numel()
+        n_flat = teacher_flat.numel()
+    if teacher_prototypes is not None:
+        _chk(teacher_prototypes, "teacher_prototypes")
+    _lib.check(lib.tt_adamw_ema_step(arr, len(entries), int(step), float(beta1), float(beta2), float(eps), _p(prototypes), K, dim,
+                                     _p(teacher_flat) if n_flat else None, _p(student_flat) if n_flat else None, n_flat, _p(teacher_prototypes),
+                                     float(momentum), _stream()), "tt_adamw_ema_step")

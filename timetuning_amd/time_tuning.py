@@ -59,6 +59,12 @@ class PatchPrototypeSimilarity(nn.Module):
         bs, n, dim = features.shape
         eps = self.epsilon if epsilon is None else epsilon
         iters = self.sinkhorn_iterations if sinkhorn_iterations is None else sinkhorn_iterations
+        if engine.exchange_group() is None and features.is_cuda and not ops.fine_grained():
+            # one rank: scores of the batch (and of a full queue) + the assignment as ONE call (tt_scores_sinkhorn)
+            protos = (o.teacher_prototypes if use_teacher else o.prototypes).detach()
+            queue = o.queue if o.queue is not None and o.queue_is_full() else None
+            q, scores = ops.scores_sinkhorn(features.detach().reshape(bs * n, dim).contiguous().float(), protos, queue, int(iters), eps, bs * n)
+            return q.view(bs, n, -1), scores[: bs * n].view(bs, n, -1)
         batch_scores = self.similarity(features.reshape(bs * n, dim), use_teacher)
         scores = batch_scores
         if o.queue is not None and o.queue_is_full():
@@ -225,6 +231,21 @@ class TimeT(nn.Module):
     def normalize_prototypes(self):
         with torch.no_grad():
             ops.normalize_rows_(self.prototypes.data)
+
+    def train_update(self, optimizer: "SwavOptimizer", loss, step: int, writer=None) -> None:
+        """The tail of a training iteration (time_tuning.py:659-663) - ``optimizer.step(loss)``, ``normalize_prototypes()`` and,
+        with a teacher, ``update_momentum_teacher(step)`` - with the device work of all three enqueued by ONE call
+        (tt_adamw_ema_step).  Same results as calling the three reference-named methods one after the other."""
+        tail = dict(prototypes=self.prototypes.data)
+        if self.teacher is not None:
+            momentum = float(self.momentum_schedule[step])
+            if writer is not None:
+                writer.add_scalar("momentum", momentum, step)
+            c = self._flatten_for_ema()
+            n = c["n_train"] if c["shared"] else c["s"].numel()
+            tail.update(teacher_flat=c["t"][:n] if n else None, student_flat=c["s"][:n] if n else None,
+                        teacher_prototypes=self.teacher_prototypes.data, momentum=momentum)
+        optimizer.step(loss, tail=tail)
 
     # -- reference method names, delegating to the HIP path ------------------------------------------
     def get_feature_prototype_similarity(self, x, use_teacher=False):
@@ -428,7 +449,9 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, tail: Optional[dict] = None):
+        """``tail`` (TimeT.train_update): what follows the parameter update in a training iteration - prototype
+        renormalisation and the EMA teacher - enqueued by the same C call as the update (tt_adamw_ema_step)."""
         by_step: Dict[int, list] = {}
         for group in self.param_groups:
             b1, b2 = group["betas"]
@@ -444,8 +467,14 @@ class FusedAdamW(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 key = (int(st["step"].item()), b1, b2, group["eps"])
                 by_step.setdefault(key, []).append((p.data, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], group["weight_decay"]))
-        for (step, b1, b2, eps), entries in by_step.items():
-            ops.adamw_step_(entries, step, b1, b2, eps)
+        groups = list(by_step.items())
+        for i, ((step, b1, b2, eps), entries) in enumerate(groups):
+            if tail is not None and i == len(groups) - 1:
+                ops.adamw_ema_step_(entries, step, b1, b2, eps, **tail)
+            else:
+                ops.adamw_step_(entries, step, b1, b2, eps)
+        if tail is not None and not groups:
+            ops.adamw_ema_step_([], 1, **tail)
         return None
 
 
@@ -490,10 +519,10 @@ class SwavOptimizer:
     def state_dict(self):
         return self.optimizer.state_dict(), self.global_step
 
-    def step(self, loss):
+    def step(self, loss, tail: Optional[dict] = None):
         self.optimizer.zero_grad()
         loss.backward()
-        self.optimizer.step()
+        self.optimizer.step(tail=tail) if tail is not None else self.optimizer.step()
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
         self.global_step += 1
@@ -734,10 +763,8 @@ def time_tuning(gpu=0, args=None):
         for i, (data, annotations, label) in enumerate(loader):
             data = data.squeeze(1)
             loss = model(data, annotations, True, args.use_mask)
-            opt.step(loss)
-            model.normalize_prototypes()
-            if args.use_teacher:
-                model.update_momentum_teacher(min(opt.global_step, last))
+            # optimizer.step(loss); model.normalize_prototypes(); model.update_momentum_teacher(global_step) (:659-663) as one call
+            model.train_update(opt, loss, min(opt.global_step + 1, last))
             if rank == 0:
                 print("Iteration: {}/{} loss {:.4f}".format(i, num_itr, loss.item()))
     model.eval_scores = scores
