@@ -14,6 +14,8 @@
 // worth more than the sixteen barriers cost.  A hybrid - this kernel with the d-permuted Q loads (no Q staging, no barriers
 // for it) and a 256-byte-row K image XOR-swizzled for conflict-free ds_read_b128 fragments (4 reads per key tile instead of
 // 16 ds_read_b32) - was correct to 1.4e-6 and 10 % SLOWER (118 vs 108 us, 128 bytes of scratch per lane): also not shipped.
+// Rotating which 32-query slice a wave owns with the (frame, head) index, so that the slices beyond N (wave 3 of every second
+// workgroup at N = 197: no MFMA work) do not always fall on the same SIMD: 108.1 vs 108.3 us - the SIMDs are not the imbalance.
 #include "common.hpp"
 
 namespace tt {
