@@ -623,6 +623,35 @@ def gen_mask(ref):
     print("attention_mask.npz written")
 
 
+def gen_scaler(ref):
+    """my_utils.normalize_and_transform (my_utils.py:19-37) with the REAL scikit-learn StandardScaler (installed here) and
+    faiss.PCAMatrix (not installed) replaced by a recorder: what it is trained on IS the reference's standardised features."""
+    import torch
+
+    from timetuning_amd import synth
+
+    mu = ref["my_utils"]
+    seen = {}
+
+    class _RecordingPCA:
+        def __init__(self, d, k):
+            self.k, self.is_trained = k, True
+
+        def train(self, feats):
+            seen["z"] = np.array(feats, copy=True)
+
+        def apply_py(self, feats):
+            return feats[:, : self.k]
+
+    mu.faiss.PCAMatrix = _RecordingPCA
+    mu.normalize_and_transform(torch.from_numpy(synth.make_scaler_features()), 3)
+    z = seen["z"]
+    rows = np.r_[0:32, 99984:100016, 199984:200016, z.shape[0] - 32:z.shape[0]]
+    np.savez_compressed(os.path.join(OUT, "scaler.npz"), rows=rows, z_rows=z[rows], z_colsum=z.astype(np.float64).sum(0),
+                        z_colsumsq=(z.astype(np.float64) ** 2).sum(0), shape=np.array(z.shape))
+    print("scaler.npz", z.shape, z.dtype, z[rows].std(0))
+
+
 def gen_sched(ref):
     cs = ref["my_utils"].cosine_scheduler
     np.savez_compressed(os.path.join(OUT, "schedules.npz"), wd_1_4=cs(0.04, 0.4, 1, 4), ema_2_5=cs(0.995, 1.0, 2, 5),
@@ -642,6 +671,7 @@ def main():
     tiny = synth.ARCHS["tiny-s16"]
     jobs = {
         "sched": lambda: gen_sched(ref),
+        "scaler": lambda: gen_scaler(ref),
         "sinkhorn": lambda: gen_sinkhorn(ref),
         "sinkhorn_w2": lambda: gen_sinkhorn_dist(ref),
         "label_prop": lambda: gen_label_prop(ref),

@@ -376,14 +376,21 @@ def proto_clustering(x, prototypes, input_size=14, output_size=224):
     return scores.permute(0, 2, 3, 1).argmax(dim=-1)
 
 
+def standard_scale(x: np.ndarray) -> np.ndarray:
+    """sklearn.preprocessing.StandardScaler as my_utils.py:23-30 drives it (partial_fit over row batches, then transform):
+    per-column mean and POPULATION variance, scale = sqrt(var) with (near-)zero scales replaced by 1, in float64.  Pinned
+    against the reference run with the real scikit-learn (tests/golden/scaler.npz)."""
+    x = x.astype(np.float64)
+    mean, std = x.mean(0), x.std(0)
+    std[std < 10 * np.finfo(np.float64).eps] = 1.0
+    return (x - mean) / std
+
+
 def standard_scale_pca(x: np.ndarray, pca_dim: int):
     """StandardScaler (population variance, zero scales -> 1) followed by PCA onto the top ``pca_dim`` eigenvectors of the
     covariance of the standardised data (faiss.PCAMatrix with eigen_power 0); rows oriented so that their largest-magnitude
     entry is positive.  Returns (transformed [n, pca_dim], basis [pca_dim, dim])."""
-    x = x.astype(np.float64)
-    mean, std = x.mean(0), x.std(0)
-    std[std < 10 * np.finfo(np.float64).eps] = 1.0
-    z = (x - mean) / std
+    z = standard_scale(x)
     zc = z - z.mean(0)
     evals, evecs = np.linalg.eigh(zc.T @ zc / len(z))
     basis = evecs[:, np.argsort(evals)[::-1][:pca_dim]].T

@@ -64,6 +64,20 @@ def test_kmeans_kernels(ops):
     assert torch.equal(s2, sums) and torch.equal(c2, counts)               # deterministic
 
 
+def test_standard_scaler_golden(golden):
+    """The scaler stage of normalize_and_transform (tt_col_moments + tt_affine_cols_inplace) against the reference's own run with the
+    real scikit-learn StandardScaler (tests/golden/scaler.npz; three partial_fit batches, one zero-variance column)."""
+    from timetuning_amd import clustering, synth
+
+    g = golden("scaler")
+    x = torch.from_numpy(synth.make_scaler_features()).cuda()
+    *_, z = clustering.fit_scaler_pca(x, 3)
+    z = z.cpu().numpy().astype(np.float64)
+    assert np.abs(z[g["rows"]] - g["z_rows"]).max() < 2e-5
+    assert np.abs(z.sum(0) - g["z_colsum"]).max() < 0.5 and np.abs((z ** 2).sum(0) - g["z_colsumsq"]).max() < 2.0
+    assert (z[:, 4] == 0).all()
+
+
 def test_normalize_and_transform_vs_oracle():
     from timetuning_amd.clustering import normalize_and_transform
 

@@ -315,3 +315,38 @@ def test_full_size_c1_single_pass(golden):
             mine = params[key.split(":", 1)[1]].grad.numpy()
             mine = mine if mine.size < 70000 else mine.reshape(-1)[::97]
             assert rel_err(mine, g[key]) < 5e-4, key
+
+
+def test_standard_scaler_against_the_reference_run_with_scikit_learn(golden):
+    """my_utils.normalize_and_transform's scaler stage (my_utils.py:23-30) as the reference ran it here with the REAL scikit-learn
+    StandardScaler (three partial_fit batches, a constant column): the oracle's restatement on the same regenerated input."""
+    from timetuning_amd import synth
+
+    g = golden("scaler")
+    z = O.standard_scale(synth.make_scaler_features())
+    assert z.shape == tuple(g["shape"])
+    assert np.abs(z[g["rows"]] - g["z_rows"]).max() < 2e-5          # the reference transforms in place in fp32
+    assert np.abs(z.sum(0) - g["z_colsum"]).max() < 0.5 and np.abs((z ** 2).sum(0) - g["z_colsumsq"]).max() < 2.0   # of 230 000 rows
+    assert (z[:, 4] == 0).all()                                      # zero-variance column: scale 1, not a division by zero
+
+
+def test_pca_and_lloyd_restatements_against_scikit_learn():
+    """The evaluator's two unpinned third-party pieces (faiss.PCAMatrix, faiss.Kmeans: not installed, parity unpinned) cross-checked
+    against an INDEPENDENT implementation of the same published algorithms that is installed: scikit-learn's PCA (up to the sign
+    of each component) and its Lloyd k-means from the same initial centroids."""
+    skd = pytest.importorskip("sklearn.decomposition")
+    skc = pytest.importorskip("sklearn.cluster")
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((4000, 12)) @ rng.standard_normal((12, 12)) + rng.standard_normal(12) * 3).astype(np.float32)
+    t, basis = O.standard_scale_pca(x, 5)
+    z = O.standard_scale(x)
+    pca = skd.PCA(n_components=5, svd_solver="full").fit(z)
+    sign = np.sign((pca.components_ * basis).sum(1))
+    assert np.abs(pca.components_ * sign[:, None] - basis).max() < 1e-8
+    assert np.abs(pca.transform(z) * sign - t).max() < 1e-8
+    # Lloyd from the same start: same centroids, labels and objective
+    pts = np.concatenate([rng.standard_normal((300, 4)) + c for c in rng.standard_normal((6, 4)) * 6]).astype(np.float32)
+    init = rng.choice(len(pts), 6, replace=False)
+    cent, lab, obj = O.kmeans_lloyd(pts, init, 25)
+    km = skc.KMeans(n_clusters=6, init=pts[init].astype(np.float64), n_init=1, max_iter=25, tol=0.0, algorithm="lloyd").fit(pts.astype(np.float64))
+    assert np.abs(km.cluster_centers_ - cent).max() < 1e-6 and (km.labels_ == lab).all() and abs(km.inertia_ - obj) < 1e-6 * obj

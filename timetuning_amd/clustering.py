@@ -5,6 +5,7 @@ layouts.  The reference leans on two third-party CPU libraries here: scikit-lear
 (``PCAMatrix``, ``Kmeans``).  Their published algorithms are restated on the GPU:
 
 * StandardScaler        per-column mean / population variance (``tt_col_moments``), scale = sqrt(var) with zeros -> 1
+                        (pinned: tests/golden/scaler.npz is the reference's run with the real scikit-learn)
 * faiss.PCAMatrix(d, p) eigenvectors of the covariance of the (standardised) data, largest eigenvalues first; the p x d basis
                         comes from a d x d eigen-problem solved on the host in fp64, the Gram matrix and the projection are
                         device GEMMs.  Component SIGNS are LAPACK's choice in faiss; here each row is oriented so that its

@@ -51,6 +51,16 @@ def normal(name: str, shape, std: float = 1.0, mean: float = 0.0, seed: int = 1)
     return a
 
 
+def make_scaler_features() -> np.ndarray:
+    """Input of the ``scaler.npz`` fixture (tests/golden; regenerated, not stored): 230 000 x 6 fp32 - three batches of the
+    reference's 100 000-row ``partial_fit`` loop (my_utils.py:23-30) - with unequal column scales / offsets and one constant
+    column (zero variance: scikit-learn's scale 1)."""
+    x = normal("scaler.x", (230000, 6))
+    x *= np.array([1.0, 0.02, 35.0, 1.0, 0.0, 3.0], np.float32)
+    x += np.array([0.0, 5.0, -120.0, 1e3, 2.5, 0.0], np.float32)
+    return x
+
+
 def vit_param_shapes(embed_dim: int, depth: int, num_heads: int, patch_size: int,
                      img_size: int = 224, in_chans: int = 3, mlp_ratio: int = 4) -> "OrderedDict[str, tuple]":
     """state_dict layout of the DINO ViT (``dino_vision_transformer.py:174-199``)."""
