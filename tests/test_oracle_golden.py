@@ -350,3 +350,13 @@ def test_pca_and_lloyd_restatements_against_scikit_learn():
     cent, lab, obj = O.kmeans_lloyd(pts, init, 25)
     km = skc.KMeans(n_clusters=6, init=pts[init].astype(np.float64), n_init=1, max_iter=25, tol=0.0, algorithm="lloyd").fit(pts.astype(np.float64))
     assert np.abs(km.cluster_centers_ - cent).max() < 1e-6 and (km.labels_ == lab).all() and abs(km.inertia_ - obj) < 1e-6 * obj
+
+
+def test_gaussian_blur_against_scipy():
+    """The restated torchvision GaussianBlur(7, 0.6) (parity unpinned: torchvision is not installed) against an independent
+    implementation of the same filter: scipy's gaussian_filter with mirror (= torch 'reflect') borders and the radius-3 kernel."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    x = torch.from_numpy(np.random.default_rng(2).random((3, 1, 14, 14)).astype(np.float32))
+    ref = np.stack([ndi.gaussian_filter(x[i, 0].numpy().astype(np.float64), sigma=float(np.float32(0.6)), mode="mirror", truncate=5.0)
+                    for i in range(3)])
+    assert np.abs(O.gaussian_blur(x)[:, 0].numpy() - ref).max() < 1e-6
