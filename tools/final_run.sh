@@ -8,11 +8,13 @@ python bench.py --steps 10 --warmup 3 --architecture dino-b16 --num_frames 8 --n
 python bench.py --steps 10 --warmup 3 --architecture dino-s8 --batch_size 16 --no_alt_precision --no_cpu_baseline > gpurun_out/r2_final_c5.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -o c2 -- python3 $R/bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_alt_precision > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final_c4 -o c4 -- python3 $R/bench.py --steps 10 --warmup 3 --architecture dino-b16 --num_frames 8 --num_clusters 400 --batch_size 16 --precision bf16 --no_alt_precision --no_cpu_baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final_c1 -o c1 -- python3 $R/bench.py --steps 50 --warmup 10 --batch_size 2 --num_frames 2 --num_clusters 50 --no_alt_precision --no_cpu_baseline > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_alt_precision > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_alt_precision > /dev/null 2>&1
 cd $R
 find gpurun_out/prof_final gpurun_out/pmc_fetch gpurun_out/pmc_write -type f | head -30
-find gpurun_out/prof_final -name "*kernel_trace.csv" -delete
+find gpurun_out/prof_final gpurun_out/prof_final_c4 gpurun_out/prof_final_c1 -name "*kernel_trace.csv" -delete
 find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*kernel_trace.csv" -delete
 du -sh gpurun_out/prof_final gpurun_out/pmc_fetch gpurun_out/pmc_write
 cat gpurun_out/r2_final_tests.log
