@@ -96,6 +96,19 @@ def instrumented_step(model, opt, x, use_teacher):
     return by
 
 
+def by_label(prof, step_seconds):
+    """{kernel label: launches, TFLOP/s, share of the step}, largest share first; instantiations that share a label (the plane
+    kernels' tile variants) are summed."""
+    acc = {}
+    for (nm, tl), (c_, f_, s_) in prof.items():
+        d = acc.setdefault(kernel_label(nm, tl), [0, 0.0, 0.0])
+        d[0] += c_
+        d[1] += f_
+        d[2] += s_
+    return {k: {"launches": c_, "tflops": round(f_ / s_ / 1e12, 1), "share_of_step": round(s_ / step_seconds, 3)}
+            for k, (c_, f_, s_) in sorted(acc.items(), key=lambda kv: -kv[1][2])}
+
+
 def sinkhorn_rate(device, B=6272, K=200, iters=10, reps=30):
     from timetuning_amd import hip_ops, synth
 
@@ -406,9 +419,7 @@ def main():
                          "gemm_share_of_step": round(all_sec / (elapsed / a.steps), 3),
                          # every GEMM family of the step (forward Linears, dgrad "NN", wgrad "TN", patch embed, plane kernels): launches,
                          # achieved TFLOP/s on algorithmic flops, share of the step - the dominant one is the roofline kernel above
-                         "by_kernel": {kernel_label(nm, tl): {"launches": c_, "tflops": round(f_ / s_ / 1e12, 1),
-                                                              "share_of_step": round(s_ / (elapsed / a.steps), 3)}
-                                       for (nm, tl), (c_, f_, s_) in sorted(prof.items(), key=lambda kv: -kv[1][2])}},
+                         "by_kernel": by_label(prof, elapsed / a.steps)},
             "alt_precision": alt or None,
             "sinkhorn": None if sk_rate is None else {"iters_per_sec": round(sk_rate, 1), "algorithmic_GBps": round(sk_gbs, 1),
                                                       "shape": "K=200 x B=6272, 10 iterations"},

@@ -453,3 +453,32 @@ def test_label_propagation_with_exact_ties(ops):
     omaps = O.propagate_labels(7, 6, 5, g, tok[:, 0].clone(), seed[0].view(g, g, K).permute(2, 0, 1).unsqueeze(0))
     want = omaps[-1].reshape(K, n).t()
     assert rel_err(pmap[0].cpu(), want) < 1e-5
+
+
+def test_label_propagation_chunked_similarities(ops, monkeypatch):
+    """The target x context similarities are computed up front for as many target frames as fit a workspace cap: a 10-frame clip
+    with 3 context frames (both slot regimes: queue filling, queue full) run whole and in chunks of 1 / 2 / 4 target frames must
+    give the same maps bit for bit, and those must equal the oracle's."""
+    bs, fs, g, D, K, nlast = 2, 10, 7, 32, 5, 3
+    n = g * g
+    feats = rnd("lpc", fs, bs, n, D)
+    for t in range(1, fs):
+        feats[t] = 0.8 * feats[t - 1] + 0.2 * feats[t]
+    q0 = F.softmax(rnd("lpcq", bs, n, K) * 3, -1)
+    xn = ops.l2norm_fwd(dev(feats.reshape(-1, D))).reshape(fs, bs, n, D)
+    whole = ops.label_propagate_maps(xn, dev(q0), nlast, 2, 3, 0.1)
+    assert whole.shape == (fs - 1, bs, n, K)
+    for b in range(bs):
+        seed = q0[b].view(g, g, K).permute(2, 0, 1).unsqueeze(0)
+        ref = torch.stack(O.propagate_labels(nlast, 2, 3, g, feats[:, b], seed)).reshape(fs - 1, K, n).transpose(1, 2).numpy()
+        bad = np.abs(whole[:, b].cpu().numpy() - ref).max(-1) > 1e-5 * np.abs(ref).max()
+        assert bad.mean() <= 0.01
+    # chunked: the cap is in MB, so widen the batch with copies until a frame's similarities exceed one
+    reps = 24                                                   # per-frame similarities: 24 x 2 x 4 x 49^2 x 4 B = 1.84 MB
+    xn_w, q0_w = xn.repeat(1, reps, 1, 1).contiguous(), dev(q0).repeat(reps, 1, 1).contiguous()
+    base = ops.label_propagate_maps(xn_w, q0_w, nlast, 2, 3, 0.1)
+    assert torch.equal(base[:, :bs], whole)
+    for cap_mb in (1, 4, 8):                                    # 1 (floor), 2 and 4 target frames per chunk
+        monkeypatch.setenv("TT_LP_SIMS_CAP_MB", str(cap_mb))
+        assert torch.equal(ops.label_propagate_maps(xn_w, q0_w, nlast, 2, 3, 0.1), base), cap_mb
+    monkeypatch.delenv("TT_LP_SIMS_CAP_MB")

@@ -44,6 +44,8 @@ struct GemmArgs {
   const float* row_scale;  // [M]
   int act;                 // 1 = GELU
   long long strideA, strideB, strideC;  // batch strides (grid.y)
+  int batch_inner;                      // two-level batch: grid.y = inner + batch_inner * outer (0: one level)
+  long long strideA2, strideB2, strideC2;  // strides of the outer level
   int splits, kchunk;                   // split-K over grid.z: slice z covers k in [z*kchunk, (z+1)*kchunk)
   long long strideS;                    // element stride between split-K partial outputs
   int vecA, vecB;                       // 16-byte loads legal for A / B (alignment, leading dimension and extents % 4)
@@ -80,9 +82,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int ntm = (g.M + BM - 1) / BM;
   const int tile = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-  const float* __restrict__ A = g.A + (long long)blockIdx.y * g.strideA;
-  const float* __restrict__ B = g.B + (long long)blockIdx.y * g.strideB;
-  float* __restrict__ C = g.C + (long long)blockIdx.y * g.strideC + (long long)blockIdx.z * g.strideS;
+  const int by_outer = g.batch_inner ? (int)blockIdx.y / g.batch_inner : 0;
+  const int by = g.batch_inner ? (int)blockIdx.y - by_outer * g.batch_inner : (int)blockIdx.y;
+  const float* __restrict__ A = g.A + (long long)by * g.strideA + (long long)by_outer * g.strideA2;
+  const float* __restrict__ B = g.B + (long long)by * g.strideB + (long long)by_outer * g.strideB2;
+  float* __restrict__ C = g.C + (long long)by * g.strideC + (long long)by_outer * g.strideC2 + (long long)blockIdx.z * g.strideS;
   const int kbeg = blockIdx.z * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
 
@@ -408,7 +412,7 @@ int launch_gemm(const GemmArgs& g_in, int amode, int bmode, int batch, hipStream
   }
   // 16-byte loads need an aligned base, a leading dimension that keeps rows aligned, and whole float4s inside the
   // extent along the contiguous axis; otherwise (e.g. 50 prototypes) the kernel falls back to element loads
-  const bool batch_ok = batch == 1 || ((g.strideA % 4 == 0) && (g.strideB % 4 == 0));
+  const bool batch_ok = batch == 1 || ((g.strideA % 4 == 0) && (g.strideB % 4 == 0) && (g.strideA2 % 4 == 0) && (g.strideB2 % 4 == 0));
   const int kq = (g.K % 4 == 0) && (g.kchunk % 4 == 0);
   g.vecA = aligned16(g.A) && batch_ok && g.lda % 4 == 0 && (amode == 1 ? g.M % 4 == 0 : kq);
   g.vecB = aligned16(g.B) && batch_ok && g.ldb % 4 == 0 && (bmode == 1 ? g.N % 4 == 0 : kq);
@@ -431,12 +435,14 @@ static GemmArgs base_args(const float* A, const float* B, float* C, int M, int N
   return g;
 }
 
-// plain (optionally batched) NT product used by other translation units (label propagation)
-int launch_gemm_plain(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int batch,
-                      long long sA, long long sB, long long sC, hipStream_t s) {
+// plain NT product with a two-level batch, used by other translation units (label propagation): problem (i, o), i < batch_inner, o < batch_outer, at i * s?1 + o * s?2
+int launch_gemm_plain2(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int batch_inner,
+                       int batch_outer, long long sA, long long sB, long long sC, long long sA2, long long sB2, long long sC2, hipStream_t s) {
   GemmArgs g = base_args(A, B, C, M, N, K, lda, ldb, ldc);
   g.strideA = sA; g.strideB = sB; g.strideC = sC;
-  return launch_gemm(g, 0, 0, batch, s);
+  g.batch_inner = batch_inner;
+  g.strideA2 = sA2; g.strideB2 = sB2; g.strideC2 = sC2;
+  return launch_gemm(g, 0, 0, batch_inner * batch_outer, s);
 }
 
 }  // namespace tt

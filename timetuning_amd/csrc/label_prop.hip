@@ -3,7 +3,11 @@
 // The reference loops in Python over samples and frames, builds a dense [c*n, n] affinity per target frame,
 // masks it to a (2r+1)^2 window, keeps the per-query top-k sources, column-normalises and multiplies the fp64
 // label maps by it - on the host, one sample at a time.  Here, per target frame t:
-//   1. cosine similarities target x context: batched fp32 MFMA GEMM over (clip, context frame)   [gemm_f32.hip]
+//   1. cosine similarities target x context: batched fp32 MFMA GEMM over (clip, context frame)   [gemm_f32.hip].  They depend
+//      on the features only, not on the propagated maps, so they are computed UP FRONT for a whole chunk of target frames
+//      (as many as fit LP_SIMS_CAP bytes of workspace): one launch for the pairs (t, frame 0) of all t, and one or two per
+//      lag d for the pairs (t, t - d) - 3 launches instead of 6 at fs = 4, 7 instead of 28 at fs = 8, each with a batch large
+//      enough to fill the chip (a 196 x 196 x D product per clip is 16 tiles).
 //   2. one workgroup per (clip, query patch): window gather -> exp(sim / 0.1) -> exact k-th largest with
 //      multiplicity (k rounds of block arg-max) -> keep >= threshold (ties kept, as `aff[aff < min] = 0`) ->
 //      fp32 normalise -> fp64 weighted sum of the kept sources' label rows.
@@ -11,11 +15,12 @@
 // maps become context for frame t+1, so the frames are sequential; everything inside a frame is parallel.
 // The last frame also emits argmax_K (the hard labels the loss consumes, time_tuning.py:296).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace tt {
 
-int launch_gemm_plain(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int batch,
-                      long long sA, long long sB, long long sC, hipStream_t s);
+int launch_gemm_plain2(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int batch_inner,
+                       int batch_outer, long long sA, long long sB, long long sC, long long sA2, long long sB2, long long sC2, hipStream_t s);
 
 constexpr int LP_MAXC = 8;      // context frames (frame 0 + n_last_frames <= 7)
 // candidates per thread (template parameter of the kernel): 8 covers the training protocol (13x13 window x 8 context
@@ -26,13 +31,13 @@ constexpr int LP_CAND_MAX = 16;
 // aff / aff.sum(0) stays normalised (the former 64-entry list silently truncated such rows)
 
 struct LpArgs {
-  const float* sims;        // [bs][c][n][n]  (target, source)
+  const float* sims;        // [bs][cs][n][n]  (target, source); slots j < c used
   const float* seg0;        // [bs][n][K] fp32 (frame 0 labels)
   const double* seg_prev;   // base of fp64 maps: frame f (>=1) at seg_prev + (f-1) * bs*n*K
   double* seg_out;          // [bs][n][K] this frame's map
   int64_t* labels;          // [bs][n] or null
   int ctx_frame[LP_MAXC];
-  int c, bs, g, K, radius, topk;
+  int c, cs, bs, g, K, radius, topk;
   float temp;
 };
 
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256) void label_prop_kernel(LpArgs a) {
       const int j = cand / per_ctx, w = cand - j * per_ctx;
       const int sy = y0 + w / ww, sx = x0 + w % ww;
       const int sp = sy * a.g + sx;
-      const float sim = a.sims[(((long long)b * a.c + j) * n + qi) * n + sp];
+      const float sim = a.sims[(((long long)b * a.cs + j) * n + qi) * n + sp];
       val[i] = expf(sim / a.temp);
       src[i] = j * n + sp;
     }
@@ -217,6 +222,17 @@ static int lp_cmax(int fs, int n_last) {
   return c < 1 ? 1 : c;
 }
 
+// target frames whose similarities are held at once (all of them unless that needs more than LP_SIMS_CAP bytes)
+constexpr size_t LP_SIMS_CAP = 512ull << 20;
+static int lp_chunk(int bs, int fs, int n, int n_last) {
+  const size_t per_t = (size_t)bs * lp_cmax(fs, n_last) * n * n * sizeof(float);
+  const char* e = getenv("TT_LP_SIMS_CAP_MB");   // test aid: a small cap exercises the chunked path on small inputs
+  size_t T = (e ? (size_t)atoll(e) << 20 : LP_SIMS_CAP) / per_t;
+  if (T < 1) T = 1;
+  if (T > (size_t)(fs - 1)) T = fs > 1 ? fs - 1 : 1;
+  return (int)T;
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -224,7 +240,7 @@ using namespace tt;
 extern "C" size_t tt_label_propagate_workspace_bytes(int bs, int fs, int g, int D, int K, int n_last_frames) {
   (void)D;
   const size_t n = (size_t)g * g;
-  const size_t sims = (size_t)bs * lp_cmax(fs, n_last_frames) * n * n * sizeof(float);
+  const size_t sims = (size_t)lp_chunk(bs, fs, (int)n, n_last_frames) * bs * lp_cmax(fs, n_last_frames) * n * n * sizeof(float);
   const size_t segs = (size_t)(fs > 1 ? fs - 1 : 1) * bs * n * K * sizeof(double);
   return ((sims + 255) / 256) * 256 + segs;
 }
@@ -245,34 +261,57 @@ static int lp_run(const char* who, const float* xn, const float* seg0, int64_t* 
   TT_REQUIRE(workspace_bytes >= tt_label_propagate_workspace_bytes(bs, fs, g, D, K, n_last_frames), "%s: workspace too small", who);
   hipStream_t s = as_stream(stream);
   const int n = g * g;
-  const size_t sims_bytes = (((size_t)bs * lp_cmax(fs, n_last_frames) * n * n * sizeof(float)) + 255) / 256 * 256;
+  const int cmax = lp_cmax(fs, n_last_frames), T = lp_chunk(bs, fs, n, n_last_frames);
+  const size_t sims_bytes = (((size_t)T * bs * cmax * n * n * sizeof(float)) + 255) / 256 * 256;
   float* sims = static_cast<float*>(workspace);
   // the fp64 maps of frames 1..fs-1: the caller's buffer when all of them are wanted, the workspace otherwise
   double* segs = pmap_all ? pmap_all : reinterpret_cast<double*>(static_cast<char*>(workspace) + sims_bytes);
   const long long fstride = (long long)bs * n * K;
-  for (int t = 1; t < fs; ++t) {
-    LpArgs a{};
-    int c = 0;
-    a.ctx_frame[c++] = 0;  // the first frame is always context (mask_propagation.py:482-483)
-    const int lo = (t - n_last_frames > 1) ? t - n_last_frames : 1;
-    for (int fr = lo; fr < t; ++fr) a.ctx_frame[c++] = fr;
-    // cosine similarities: sims[b][j] = xn[t][b] @ xn[ctx_j][b]^T
-    for (int j = 0; j < c; ++j) {
-      int rc = launch_gemm_plain(xn + (long long)t * bs * n * D, xn + (long long)a.ctx_frame[j] * bs * n * D, sims + (long long)j * n * n,
-                                 n, n, D, D, D, n, bs, (long long)n * D, (long long)n * D, (long long)c * n * n, s);
-      if (rc != TT_OK) return rc;
+  const long long nn = (long long)n * n, frame = (long long)bs * n * D, per_t = (long long)bs * cmax * nn;
+  for (int t0 = 1; t0 < fs; t0 += T) {
+    const int t1 = t0 + T < fs ? t0 + T : fs;
+    // ---- cosine similarities of the chunk, sims[t - t0][b][j] = xn[t][b] @ xn[ctx_j(t)][b]^T with ctx(t) = {0} + [lo_t, t),
+    //      lo_t = max(1, t - n_last)  (mask_propagation.py:480-487: the first frame and the queue of the last n_last frames)
+    // slot 0, the pairs (t, 0) of every t in the chunk: inner batch = clip, outer = t
+    int rc = launch_gemm_plain2(xn + t0 * frame, xn, sims, n, n, D, D, D, n, bs, t1 - t0, (long long)n * D, (long long)n * D,
+                                (long long)cmax * nn, frame, 0, per_t, s);
+    if (rc != TT_OK) return rc;
+    for (int d = 1; d <= n_last_frames; ++d) {
+      // pairs (t, t - d), t - d >= 1.  While the queue is still filling (t <= n_last + 1: lo_t = 1) the slot is j = t - d and
+      // moves with t; afterwards (lo_t = t - n_last) it is j = 1 + n_last - d
+      const int a0 = t0 > d + 1 ? t0 : d + 1;
+      const int a1 = t1 < n_last_frames + 2 ? t1 : n_last_frames + 2;
+      if (a1 > a0) {
+        rc = launch_gemm_plain2(xn + a0 * frame, xn + (a0 - d) * frame, sims + (a0 - t0) * per_t + (a0 - d) * nn, n, n, D, D, D, n, bs,
+                                a1 - a0, (long long)n * D, (long long)n * D, (long long)cmax * nn, frame, frame, per_t + nn, s);
+        if (rc != TT_OK) return rc;
+      }
+      const int b0 = a0 > n_last_frames + 2 ? a0 : n_last_frames + 2;
+      if (t1 > b0) {
+        rc = launch_gemm_plain2(xn + b0 * frame, xn + (b0 - d) * frame, sims + (b0 - t0) * per_t + (1 + n_last_frames - d) * nn, n, n, D, D,
+                                D, n, bs, t1 - b0, (long long)n * D, (long long)n * D, (long long)cmax * nn, frame, frame, per_t, s);
+        if (rc != TT_OK) return rc;
+      }
     }
-    a.sims = sims;
-    a.seg0 = seg0;
-    a.seg_prev = segs;
-    a.seg_out = segs + (long long)(t - 1) * fstride;
-    a.labels = (t == fs - 1) ? labels : nullptr;
-    a.c = c; a.bs = bs; a.g = g; a.K = K; a.radius = radius; a.topk = topk; a.temp = temperature;
-    if (cand_max <= 256LL * 8)
-      hipLaunchKernelGGL((label_prop_kernel<8>), dim3(n, bs), dim3(256), 0, s, a);
-    else
-      hipLaunchKernelGGL((label_prop_kernel<LP_CAND_MAX>), dim3(n, bs), dim3(256), 0, s, a);
-    TT_CHECK_LAUNCH(who);
+    // ---- the maps, frame by frame: frame t's map is context for frame t + 1
+    for (int t = t0; t < t1; ++t) {
+      LpArgs a{};
+      int c = 0;
+      a.ctx_frame[c++] = 0;  // the first frame is always context (mask_propagation.py:482-483)
+      const int lo = (t - n_last_frames > 1) ? t - n_last_frames : 1;
+      for (int fr = lo; fr < t; ++fr) a.ctx_frame[c++] = fr;
+      a.sims = sims + (t - t0) * per_t;
+      a.seg0 = seg0;
+      a.seg_prev = segs;
+      a.seg_out = segs + (long long)(t - 1) * fstride;
+      a.labels = (t == fs - 1) ? labels : nullptr;
+      a.c = c; a.cs = cmax; a.bs = bs; a.g = g; a.K = K; a.radius = radius; a.topk = topk; a.temp = temperature;
+      if (cand_max <= 256LL * 8)
+        hipLaunchKernelGGL((label_prop_kernel<8>), dim3(n, bs), dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL((label_prop_kernel<LP_CAND_MAX>), dim3(n, bs), dim3(256), 0, s, a);
+      TT_CHECK_LAUNCH(who);
+    }
   }
   if (pmap_last) {
     const long long cnt = fstride;
