@@ -21,7 +21,11 @@ TWINS = ["sinkhorn", "ce_loss_fwd_bwd", "img_resample_h", "img_resample_v", "img
          "transpose_planes", "layernorm_fwd_planes", "linear_fwd_planes", "attention_fwd_bf16",
          # the coarse entry points: the same sequences over the twins
          "vit_forward", "vit_forward_workspace_bytes", "mlp_head_forward", "mlp_head_forward_workspace_bytes", "scores_sinkhorn",
-         "scores_sinkhorn_workspace_bytes", "adamw_ema_step"]
+         "scores_sinkhorn_workspace_bytes", "adamw_ema_step",
+         # third batch: what had a torch restatement only
+         "scale_tensors", "gemm_f32", "pos_embed_interpolate", "upsample_bilinear_tokens", "upsample_argmax_f32", "kmeans_accumulate",
+         "kmeans_accumulate_workspace_bytes", "linear_bwd_data_planes", "linear_bwd_weight_planes", "linear_bwd_weight_planes_workspace_bytes",
+         "foreground_mask", "foreground_mask_from_probs", "label_propagate", "label_propagate_maps", "label_propagate_workspace_bytes"]
 _lib = None
 
 

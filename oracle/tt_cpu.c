@@ -4,8 +4,9 @@
  * workspace arguments are accepted and ignored), so that one ctypes prototype drives either side.  They cover the ops whose
  * arithmetic is integer / byte exact (the Pillow-defined image transforms, the confusion matrix) or a short, order-defined
  * float recurrence (Sinkhorn-Knopp, cross-entropy, arg-max of a bilinear upsampling, nearest-centroid assignment, column
- * moments) and - second half of the file, round 2 - the hot path's row ops and naive matrix products.  Label propagation, the
- * backward of attention / LayerNorm and the foreground mask have their restatement in oracle/timet_oracle.py (torch-CPU) only.
+ * moments) and - the rest of the file, round 2 - the hot path's row ops, naive matrix products, backward ops, the plane ops, the
+ * coarse entry points, label propagation, the foreground mask and the evaluator's resampling: every compute entry point of the
+ * header has a twin here (the *_workspace_bytes twins return 0: scratch is malloc'ed).
  *
  * Built by __graft_entry__.build() (gcc -O2 -shared) into oracle/_build/libtt_cpu.so; only tests/ load it.  Every function
  * cites the reference lines (paths relative to /root/reference) or the third-party algorithm it restates. */
@@ -837,4 +838,341 @@ int tt_cpu_adamw_ema_step(const tt_cpu_adamw_tensor* tensors, int count, int ste
     tt_cpu_normalize_rows_inplace(teacher_prototypes, K, dim, stream);
   }
   return 0;
+}
+
+/* ====================================================================================================================
+ * Third batch (round 2): the ops that had their restatement in oracle/timet_oracle.py only.  With these every compute entry
+ * point of include/timetuning_hip.h has a plain-C twin.
+ * ==================================================================================================================== */
+
+/* g[i] *= *scale for every table entry: loss.backward()'s chain rule on the fused step's gradients (time_tuning.py:420-423) */
+int tt_cpu_scale_tensors(const tt_cpu_adamw_tensor* tensors, int count, const float* scale, tt_stream_t stream) {
+  for (int t = 0; t < count; ++t) {
+    float* g = (float*)tensors[t].g;
+    for (long long i = 0; i < tensors[t].n; ++i) g[i] *= *scale;
+  }
+  return 0;
+}
+
+/* C = alpha op(A) op(B), optionally batched; the generic product behind the op sites (double accumulation) */
+int tt_cpu_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_mmajor, int b_nmajor,
+                    float alpha, int batch, long long strideA, long long strideB, long long strideC, tt_stream_t stream) {
+  for (int z = 0; z < batch; ++z) {
+    const float *a = A + z * strideA, *b = B + z * strideB;
+    float* c = C + z * strideC;
+    for (int m = 0; m < M; ++m)
+      for (int n = 0; n < N; ++n) {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k)
+          s += (double)(a_mmajor ? a[(size_t)k * lda + m] : a[(size_t)m * lda + k]) * (double)(b_nmajor ? b[(size_t)k * ldb + n] : b[(size_t)n * ldb + k]);
+        c[(size_t)m * ldc + n] = (float)(alpha * s);
+      }
+  }
+  return 0;
+}
+
+/* ---- dino_vision_transformer.py:219-231: nn.functional.interpolate(patch_pos_embed, scale_factor=(sh, sw), mode="bicubic"):
+ *      align_corners False, source coordinate = (dst + 0.5) / scale_factor - 0.5, cubic convolution with A = -0.75 (ATen's
+ *      upsample_bicubic2d), taps clamped to the border; the class row is copied (:232-233). */
+static void cubic_taps(double t, double w[4]) {
+  const double A = -0.75, x0 = t + 1.0, x3 = 2.0 - t, u = 1.0 - t;
+  w[0] = ((A * x0 - 5.0 * A) * x0 + 8.0 * A) * x0 - 4.0 * A;
+  w[1] = ((A + 2.0) * t - (A + 3.0)) * t * t + 1.0;
+  w[2] = ((A + 2.0) * u - (A + 3.0)) * u * u + 1.0;
+  w[3] = ((A * x3 - 5.0 * A) * x3 + 8.0 * A) * x3 - 4.0 * A;
+}
+int tt_cpu_pos_embed_interpolate(const float* pos, float* out, int g, int gh, int gw, int D, float scale_h, float scale_w, tt_stream_t stream) {
+  memcpy(out, pos, (size_t)D * sizeof(float));
+  const float rh = 1.0f / scale_h, rw = 1.0f / scale_w;   /* ATen keeps the coordinate scale in the tensor's dtype */
+  for (int oy = 0; oy < gh; ++oy)
+    for (int ox = 0; ox < gw; ++ox) {
+      const float ry = rh * (oy + 0.5f) - 0.5f, rx = rw * (ox + 0.5f) - 0.5f;
+      const int fy = (int)floorf(ry), fx = (int)floorf(rx);
+      double wy[4], wx[4];
+      cubic_taps((double)(ry - (float)fy), wy);
+      cubic_taps((double)(rx - (float)fx), wx);
+      for (int d = 0; d < D; ++d) {
+        double acc = 0.0;
+        for (int i = 0; i < 4; ++i) {
+          int yy = fy - 1 + i; yy = yy < 0 ? 0 : (yy > g - 1 ? g - 1 : yy);
+          double row = 0.0;
+          for (int j = 0; j < 4; ++j) {
+            int xx = fx - 1 + j; xx = xx < 0 ? 0 : (xx > g - 1 ? g - 1 : xx);
+            row += wx[j] * (double)pos[(size_t)(1 + yy * g + xx) * D + d];
+          }
+          acc += wy[i] * row;
+        }
+        out[(size_t)(1 + oy * gw + ox) * D + d] = (float)acc;
+      }
+    }
+  return 0;
+}
+
+/* ---- clustering.py:34-36: nn.functional.interpolate(x.double(), (R, R), mode="bilinear").float() on token maps [M, g*g, C] */
+int tt_cpu_upsample_bilinear_tokens(const float* x, float* out, int M, int g, int C, int R, tt_stream_t stream) {
+  const double scale = (double)g / (double)R;
+  for (int m = 0; m < M; ++m)
+    for (int oy = 0; oy < R; ++oy)
+      for (int ox = 0; ox < R; ++ox) {
+        double sy = scale * (oy + 0.5) - 0.5, sx = scale * (ox + 0.5) - 0.5;
+        sy = sy < 0 ? 0 : sy; sx = sx < 0 ? 0 : sx;
+        const int y0 = (int)sy, x0 = (int)sx, y1 = y0 + (y0 < g - 1), x1 = x0 + (x0 < g - 1);
+        const double ly = sy - y0, lx = sx - x0, hy = 1.0 - ly, hx = 1.0 - lx;
+        const float* b = x + (size_t)m * g * g * C;
+        for (int c = 0; c < C; ++c)
+          out[(((size_t)m * R + oy) * R + ox) * C + c] =
+              (float)(hy * (hx * b[(size_t)(y0 * g + x0) * C + c] + lx * b[(size_t)(y0 * g + x1) * C + c]) +
+                      ly * (hx * b[(size_t)(y1 * g + x0) * C + c] + lx * b[(size_t)(y1 * g + x1) * C + c]));
+      }
+  return 0;
+}
+
+/* ---- clustering.py:101-104: the same interpolation of fp32 prototype scores [M, g*g, K] (in fp32, as the reference), arg-max over K */
+int tt_cpu_upsample_argmax_f32(const float* maps, int64_t* labels_out, int M, int g, int K, int R, tt_stream_t stream) {
+  const float scale = (float)g / (float)R;
+  for (int m = 0; m < M; ++m)
+    for (int oy = 0; oy < R; ++oy)
+      for (int ox = 0; ox < R; ++ox) {
+        float sy = scale * (oy + 0.5f) - 0.5f, sx = scale * (ox + 0.5f) - 0.5f;
+        sy = sy < 0 ? 0 : sy; sx = sx < 0 ? 0 : sx;
+        const int y0 = (int)sy, x0 = (int)sx, y1 = y0 + (y0 < g - 1), x1 = x0 + (x0 < g - 1);
+        const float ly = sy - y0, lx = sx - x0, hy = 1.0f - ly, hx = 1.0f - lx;
+        const float* b = maps + (size_t)m * g * g * K;
+        float best = -INFINITY;
+        int besti = 0;
+        for (int k = 0; k < K; ++k) {
+          const float v = hy * (hx * b[(size_t)(y0 * g + x0) * K + k] + lx * b[(size_t)(y0 * g + x1) * K + k]) +
+                          ly * (hx * b[(size_t)(y1 * g + x0) * K + k] + lx * b[(size_t)(y1 * g + x1) * K + k]);
+          if (v > best) { best = v; besti = k; }
+        }
+        labels_out[((size_t)m * R + oy) * R + ox] = besti;
+      }
+  return 0;
+}
+
+/* ---- the mean step of Lloyd's iteration (faiss Clustering::train as clustering.py:39-41 configures it): per-label sums and counts */
+size_t tt_cpu_kmeans_accumulate_workspace_bytes(long long P, int d, int k) { return 0; }
+int tt_cpu_kmeans_accumulate(const float* x, const int32_t* labels, double* sums, long long* counts, long long P, int d, int k, void* workspace,
+                             size_t workspace_bytes, tt_stream_t stream) {
+  memset(sums, 0, (size_t)k * d * sizeof(double));
+  memset(counts, 0, (size_t)k * sizeof(long long));
+  for (long long p = 0; p < P; ++p) {
+    const int j = labels[p];
+    if (j < 0 || j >= k) continue;
+    counts[j] += 1;
+    for (int t = 0; t < d; ++t) sums[(size_t)j * d + t] += (double)x[p * d + t];
+  }
+  return 0;
+}
+
+/* ---- backward products of the nn.Linear sites on bf16-plane operands (autograd of dino_vision_transformer.py:94-103,115-130) */
+int tt_cpu_linear_bwd_data_planes(const void* dy_planes, long long dys, const void* wT_planes, long long wts, int planes, const float* gelu_pre,
+                                  float* dx, int M, int N, int K, tt_stream_t stream) {
+  const uint16_t *dy = (const uint16_t*)dy_planes, *wT = (const uint16_t*)wT_planes;   /* dy [P][M][N], wT [P][K][N] */
+  for (int m = 0; m < M; ++m)
+    for (int k = 0; k < K; ++k) {
+      double s = 0.0;
+      for (int pa = 0; pa < planes; ++pa)
+        for (int pw = 0; pa + pw < planes; ++pw)
+          for (int n = 0; n < N; ++n)
+            s += (double)tt_cpu_bf16_to_f32(dy[pa * dys + (size_t)m * N + n]) * (double)tt_cpu_bf16_to_f32(wT[pw * wts + (size_t)k * N + n]);
+      float v = (float)s;
+      if (gelu_pre) v *= tt_cpu_gelu_grad(gelu_pre[(size_t)m * K + k]);
+      dx[(size_t)m * K + k] = v;
+    }
+  return 0;
+}
+size_t tt_cpu_linear_bwd_weight_planes_workspace_bytes(int N, int K, int Mpad) { return 0; }
+int tt_cpu_linear_bwd_weight_planes(const void* dyT_planes, long long dys, const void* xT_planes, long long xs, int planes, float* dw, int N,
+                                    int K, int Mpad, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  const uint16_t *dyT = (const uint16_t*)dyT_planes, *xT = (const uint16_t*)xT_planes;   /* dyT [P][N][Mpad], xT [P][K][Mpad] */
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) {
+      double s = 0.0;
+      for (int pa = 0; pa < planes; ++pa)
+        for (int pw = 0; pa + pw < planes; ++pw)
+          for (int m = 0; m < Mpad; ++m)
+            s += (double)tt_cpu_bf16_to_f32(dyT[pa * dys + (size_t)n * Mpad + m]) * (double)tt_cpu_bf16_to_f32(xT[pw * xs + (size_t)k * Mpad + m]);
+      dw[(size_t)n * K + k] = (float)s;
+    }
+  return 0;
+}
+
+/* ---- models.py:93-131 process_attentions: cls-query attention of the last block, mean over heads (:107-112), GaussianBlur(ksize,
+ *      sigma) with reflect padding (torchvision: pdf on linspace(-half, half, ksize), normalised, outer product), ascending sort,
+ *      unit mass, cumulative sum, keep where the cumulative mass exceeds 1 - threshold (:117-123), drop 8-connected components of
+ *      <= 2 pixels (:124-130; by flood fill here).  float32 as the reference. */
+static int fm_from_cls(const float* cls, float* mask_out, float* blurred_out, float* margin_out, int N, int H, int g, float threshold,
+                       float sigma, int ksize) {
+  const int n = N - 1, half = ksize / 2;
+  float *att = (float*)calloc(n, 4), *blur = (float*)malloc(n * 4), *k1 = (float*)malloc(ksize * 4), *sorted = (float*)malloc(n * 4);
+  int *rank = (int*)malloc(n * sizeof(int)), *stack = (int*)malloc(n * sizeof(int)), *comp = (int*)malloc(n * sizeof(int));
+  unsigned char *th = (unsigned char*)malloc(n), *seen = (unsigned char*)calloc(n, 1);
+  if (!att || !blur || !k1 || !sorted || !rank || !stack || !comp || !th || !seen) return -3;
+  for (int h = 0; h < H; ++h)
+    for (int i = 0; i < n; ++i) att[i] += cls[(size_t)h * N + i + 1] * 1.0f / (float)H;
+  float ksum = 0.f;
+  for (int i = 0; i < ksize; ++i) { const float x = (float)(i - half) / sigma; k1[i] = expf(-0.5f * (x * x)); ksum += k1[i]; }
+  for (int i = 0; i < ksize; ++i) k1[i] /= ksum;
+  for (int i = 0; i < n; ++i) {
+    const int y = i / g, x = i % g;
+    float s = 0.f;
+    for (int dy = 0; dy < ksize; ++dy) {
+      int yy = y + dy - half; yy = yy < 0 ? -yy : (yy >= g ? 2 * (g - 1) - yy : yy);
+      for (int dx = 0; dx < ksize; ++dx) {
+        int xx = x + dx - half; xx = xx < 0 ? -xx : (xx >= g ? 2 * (g - 1) - xx : xx);
+        s += (k1[dy] * k1[dx]) * att[yy * g + xx];
+      }
+    }
+    blur[i] = s;
+    if (blurred_out) blurred_out[i] = s;
+  }
+  float total = 0.f;
+  for (int i = 0; i < n; ++i) {   /* stable ascending rank */
+    int r = 0;
+    for (int j = 0; j < n; ++j) r += (blur[j] < blur[i] || (blur[j] == blur[i] && j < i)) ? 1 : 0;
+    rank[i] = r;
+    sorted[r] = blur[i];
+  }
+  for (int i = 0; i < n; ++i) total += sorted[i];
+  float c = 0.f;
+  for (int i = 0; i < n; ++i) { c += sorted[i] / total; sorted[i] = c; }   /* sorted[] now holds the cumulative mass */
+  const float cut = (float)(1.0 - (double)threshold);
+  for (int i = 0; i < n; ++i) {
+    th[i] = sorted[rank[i]] > cut;
+    if (margin_out) margin_out[i] = fabsf(sorted[rank[i]] - cut);
+  }
+  for (int i = 0; i < n; ++i) {   /* components by flood fill; sizes <= 2 cleared */
+    if (!th[i] || seen[i]) continue;
+    int top = 0, size = 0;
+    stack[top++] = i; seen[i] = 1;
+    while (top) {
+      const int p = stack[--top];
+      comp[size++] = p;
+      const int y = p / g, x = p % g;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = y + dy, xx = x + dx;
+          if ((dy | dx) != 0 && yy >= 0 && yy < g && xx >= 0 && xx < g && th[yy * g + xx] && !seen[yy * g + xx]) {
+            seen[yy * g + xx] = 1;
+            stack[top++] = yy * g + xx;
+          }
+        }
+    }
+    if (size <= 2) for (int q = 0; q < size; ++q) th[comp[q]] = 0;
+  }
+  for (int i = 0; i < n; ++i) mask_out[i] = (float)th[i];
+  free(att); free(blur); free(k1); free(sorted); free(rank); free(stack); free(comp); free(th); free(seen);
+  return 0;
+}
+int tt_cpu_foreground_mask_from_probs(const float* cls_probs, float* mask_out, float* blurred_out, float* margin_out, int F, int N, int H, int g,
+                                      float threshold, float sigma, int ksize, tt_stream_t stream) {
+  const int n = N - 1;
+  for (int f = 0; f < F; ++f) {
+    const int rc = fm_from_cls(cls_probs + (size_t)f * H * N, mask_out + (size_t)f * n, blurred_out ? blurred_out + (size_t)f * n : NULL,
+                               margin_out ? margin_out + (size_t)f * n : NULL, N, H, g, threshold, sigma, ksize);
+    if (rc) return rc;
+  }
+  return 0;
+}
+/* the same from the last block's qkv activations: row 0 of softmax(q k^T scale) per head (dino_vision_transformer.py:122-125) */
+int tt_cpu_foreground_mask(const float* qkv, float* mask_out, float* blurred_out, float* margin_out, int F, int N, int H, int hd, int g,
+                           float scale, float threshold, float sigma, int ksize, tt_stream_t stream) {
+  const int D = H * hd, n = N - 1;
+  float* cls = (float*)malloc((size_t)H * N * 4);
+  if (!cls) return -3;
+  for (int f = 0; f < F; ++f) {
+    const float* base = qkv + (size_t)f * N * 3 * D;
+    for (int h = 0; h < H; ++h) {
+      float mx = -INFINITY, sum = 0.f;
+      for (int j = 0; j < N; ++j) {
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s += base[h * hd + d] * base[(size_t)j * 3 * D + D + h * hd + d];
+        cls[(size_t)h * N + j] = s * scale;
+        mx = s * scale > mx ? s * scale : mx;
+      }
+      for (int j = 0; j < N; ++j) { cls[(size_t)h * N + j] = expf(cls[(size_t)h * N + j] - mx); sum += cls[(size_t)h * N + j]; }
+      for (int j = 0; j < N; ++j) cls[(size_t)h * N + j] /= sum;
+    }
+    const int rc = fm_from_cls(cls, mask_out + (size_t)f * n, blurred_out ? blurred_out + (size_t)f * n : NULL,
+                               margin_out ? margin_out + (size_t)f * n : NULL, N, H, g, threshold, sigma, ksize);
+    if (rc) { free(cls); return rc; }
+  }
+  free(cls);
+  return 0;
+}
+
+/* ---- mask_propagation.py:396-496 (label_propagation / propagate_labels with features_exist) as time_tuning.py:143-154 calls it,
+ *      batched over clips: for each target frame t the context is frame 0 plus the last n_last frames (:480-487); affinity =
+ *      exp(<f_t(q), f_ctx(p)> / temperature) in fp32 (:418-422) inside the |dy|, |dx| <= radius window (:424-429), per query keep
+ *      the top-k sources over all contexts - everything >= the k-th largest, ties kept (:432-434) -, column-normalise in fp32
+ *      (:436), and the target map is the fp64 product of the context maps with it (:442-444). */
+static int lp_cpu(const float* xn, const float* seg0, int64_t* labels, double* pmap_last, double* pmap_all, int bs, int fs, int g, int D, int K,
+                  int n_last, int radius, int topk, float temperature) {
+  const int n = g * g;
+  const size_t fstride = (size_t)bs * n * K;
+  double* segs = pmap_all ? pmap_all : (double*)malloc((size_t)(fs - 1) * fstride * sizeof(double));
+  const int cmax = 1 + n_last, win = (2 * radius + 1) * (2 * radius + 1);
+  float* aff = (float*)malloc((size_t)cmax * win * sizeof(float));
+  int* src = (int*)malloc((size_t)cmax * win * sizeof(int));
+  float* topv = (float*)malloc((size_t)topk * sizeof(float));
+  if (!segs || !aff || !src || !topv) return -3;
+  for (int t = 1; t < fs; ++t) {
+    int ctx[64], c = 0;
+    ctx[c++] = 0;
+    for (int fr = (t - n_last > 1 ? t - n_last : 1); fr < t; ++fr) ctx[c++] = fr;
+    for (int b = 0; b < bs; ++b)
+      for (int q = 0; q < n; ++q) {
+        const int qy = q / g, qx = q % g;
+        const float* ft = xn + (((size_t)t * bs + b) * n + q) * D;
+        int cnt = 0;
+        for (int j = 0; j < c; ++j)
+          for (int sy = (qy - radius < 0 ? 0 : qy - radius); sy <= (qy + radius > g - 1 ? g - 1 : qy + radius); ++sy)
+            for (int sx = (qx - radius < 0 ? 0 : qx - radius); sx <= (qx + radius > g - 1 ? g - 1 : qx + radius); ++sx) {
+              const float* fsrc = xn + (((size_t)ctx[j] * bs + b) * n + sy * g + sx) * D;
+              float dot = 0.f;
+              for (int d = 0; d < D; ++d) dot += ft[d] * fsrc[d];
+              aff[cnt] = expf(dot / temperature);
+              src[cnt++] = j * n + sy * g + sx;
+            }
+        /* k-th largest with multiplicity (sources outside the window have affinity 0 < every exp) */
+        int nt = 0;
+        for (int i = 0; i < cnt; ++i) {
+          int pos = nt < topk ? nt++ : -1;
+          if (pos < 0) { if (aff[i] <= topv[topk - 1]) continue; pos = topk - 1; }
+          while (pos > 0 && topv[pos - 1] < aff[i]) { topv[pos] = topv[pos - 1]; --pos; }
+          topv[pos] = aff[i];
+        }
+        const float thr = nt == topk ? topv[topk - 1] : 0.f;
+        float sum = 0.f;
+        for (int i = 0; i < cnt; ++i) if (aff[i] >= thr) sum += aff[i];
+        double* out = segs + (size_t)(t - 1) * fstride + ((size_t)b * n + q) * K;
+        for (int k = 0; k < K; ++k) out[k] = 0.0;
+        for (int i = 0; i < cnt; ++i) {
+          if (aff[i] < thr) continue;
+          const double w = (double)(aff[i] / sum);
+          const int j = src[i] / n, p = src[i] % n, fr = ctx[j];
+          for (int k = 0; k < K; ++k)
+            out[k] += w * (fr == 0 ? (double)seg0[((size_t)b * n + p) * K + k] : segs[(size_t)(fr - 1) * fstride + ((size_t)b * n + p) * K + k]);
+        }
+        if (labels && t == fs - 1) {
+          int best = 0;
+          for (int k = 1; k < K; ++k) if (out[k] > out[best]) best = k;
+          labels[(size_t)b * n + q] = best;
+        }
+      }
+  }
+  if (pmap_last) memcpy(pmap_last, segs + (size_t)(fs - 2) * fstride, fstride * sizeof(double));
+  if (!pmap_all) free(segs);
+  free(aff); free(src); free(topv);
+  return 0;
+}
+size_t tt_cpu_label_propagate_workspace_bytes(int bs, int fs, int g, int D, int K, int n_last_frames) { return 0; }
+int tt_cpu_label_propagate(const float* xn, const float* seg0, int64_t* labels, double* pmap_last, int bs, int fs, int g, int D, int K,
+                           int n_last_frames, int radius, int topk, float temperature, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  return lp_cpu(xn, seg0, labels, pmap_last, NULL, bs, fs, g, D, K, n_last_frames, radius, topk, temperature);
+}
+int tt_cpu_label_propagate_maps(const float* xn, const float* seg0, double* pmap_all, int bs, int fs, int g, int D, int K, int n_last_frames,
+                                int radius, int topk, float temperature, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  return lp_cpu(xn, seg0, NULL, NULL, pmap_all, bs, fs, g, D, K, n_last_frames, radius, topk, temperature);
 }

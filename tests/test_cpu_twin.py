@@ -489,3 +489,149 @@ def test_hip_library_equals_its_cpu_twin_round2b(twin):
         for i in (2, 3):
             assert _re(A["plane_gemm"][4][P_][i], B["plane_gemm"][4][P_][i]) < 2e-5, (P_, i)
     assert _re(_bf(A["att_bf16"][1]), _bf(B["att_bf16"][1])) < 1.5e-2
+
+
+# ---- third batch: generic GEMM, position-table resampling, evaluator resampling, k-means sums, plane backward products, the
+# ---- foreground mask and label propagation ----------------------------------------------------------------------------------
+
+def _round2c_cases(side):
+    st = "STREAM" if side.device else None
+    rng = np.random.default_rng(23)
+    f32 = lambda *s, scale=1.0: (rng.standard_normal(s) * scale).astype(np.float32)
+    R = {}
+    # generic GEMM: k-major A, n-major B, alpha, batch of 2
+    M, N, K = 37, 29, 24
+    A, B = f32(2, K, 40), f32(2, K, 32)
+    Cm = np.zeros((2, M, 36), np.float32)
+    side.run("gemm_f32", A, B, Cm, M, N, K, 40, 32, 36, 1, 1, 0.5, 2, K * 40, K * 32, M * 36, st, outs=(Cm,))
+    R["gemm"] = (A, B, Cm.copy(), (M, N, K))
+    # position table 5x5 -> 3x7 tokens (dino_vision_transformer.py:219-231)
+    g, gh, gw, D = 5, 3, 7, 8
+    pos, out = f32(1 + g * g, D), np.empty((1 + gh * gw, D), np.float32)
+    sh, sw = (gh + 0.1) / g, (gw + 0.1) / g
+    side.run("pos_embed_interpolate", pos, out, g, gh, gw, D, sh, sw, st, outs=(out,))
+    R["pos"] = (pos, out.copy(), (g, gh, gw, D, sh, sw))
+    # evaluator resampling
+    Mm, gg, C, Rr, Kk = 2, 6, 5, 20, 7
+    x, up = f32(Mm, gg * gg, C), np.empty((Mm, Rr * Rr, C), np.float32)
+    side.run("upsample_bilinear_tokens", x, up, Mm, gg, C, Rr, st, outs=(up,))
+    maps, lab = f32(Mm, gg * gg, Kk), np.empty((Mm, Rr, Rr), np.int64)
+    side.run("upsample_argmax_f32", maps, lab, Mm, gg, Kk, Rr, st, outs=(lab,))
+    R["upsample"] = (x, up.copy(), maps, lab.copy(), (Mm, gg, C, Rr, Kk))
+    # k-means sums
+    P, d, k = 5000, 6, 9
+    pts, lbl = f32(P, d), rng.integers(0, k, P).astype(np.int32)
+    sums, counts = np.empty((k, d), np.float64), np.empty(k, np.int64)
+    nb = 1 << 24
+    ws = np.empty(nb, np.uint8)
+    side.run("kmeans_accumulate", pts, lbl, sums, counts, P, d, k, ws, nb, st, outs=(sums, counts))
+    R["kmeans"] = (pts, lbl, sums.copy(), counts.copy())
+    # plane backward products (one plane: the bf16 path)
+    M2, N2, K2, Mpad = 100, 64, 128, 128
+    dy, w, xx, pre = f32(M2, N2), f32(N2, K2, scale=0.1), f32(M2, K2), f32(M2, K2)
+    dyp, wT = np.empty((1, M2, N2), np.uint16), np.empty((K2, N2), np.uint16)
+    side.run("split_planes", dy, dyp, M2 * N2, 1, M2 * N2, st, outs=(dyp,))
+    side.run("transpose_planes", w, wT, N2, K2, N2, st, outs=(wT,))
+    dx = np.empty((M2, K2), np.float32)
+    side.run("linear_bwd_data_planes", dyp, M2 * N2, wT, K2 * N2, 1, pre, dx, M2, N2, K2, st, outs=(dx,))
+    dyT, xT = np.empty((N2, Mpad), np.uint16), np.empty((K2, Mpad), np.uint16)
+    side.run("transpose_planes", dy, dyT, M2, N2, Mpad, st, outs=(dyT,))
+    side.run("transpose_planes", xx, xT, M2, K2, Mpad, st, outs=(xT,))
+    dw = np.empty((N2, K2), np.float32)
+    side.run("linear_bwd_weight_planes", dyT, N2 * Mpad, xT, K2 * Mpad, 1, dw, N2, K2, Mpad, ws, nb, st, outs=(dw,))
+    R["plane_bwd"] = (dy, w, xx, pre, dx.copy(), dw.copy())
+    # foreground mask: from qkv and from the probabilities
+    Fm, gm, H, hd = 3, 14, 2, 64
+    Nm = gm * gm + 1
+    qkv = f32(Fm, Nm, 3 * H * hd, scale=0.6)
+    mask, blur, margin = (np.empty((Fm, gm * gm), np.float32) for _ in range(3))
+    side.run("foreground_mask", qkv, mask, blur, margin, Fm, Nm, H, hd, gm, 0.125, 0.65, 0.6, 7, st, outs=(mask, blur, margin))
+    q, kx = qkv.reshape(Fm, Nm, 3, H, hd)[:, 0, 0], qkv.reshape(Fm, Nm, 3, H, hd)[:, :, 1]
+    logits = np.einsum("fhd,fjhd->fhj", q.astype(np.float64), kx.astype(np.float64)) * 0.125
+    probs = np.exp(logits - logits.max(-1, keepdims=True))
+    probs = np.ascontiguousarray((probs / probs.sum(-1, keepdims=True)).astype(np.float32))   # (einsum's output order is not C)
+    mask2, blur2, margin2 = (np.empty((Fm, gm * gm), np.float32) for _ in range(3))
+    side.run("foreground_mask_from_probs", probs, mask2, blur2, margin2, Fm, Nm, H, gm, 0.65, 0.6, 7, st, outs=(mask2, blur2, margin2))
+    R["mask"] = (probs, mask.copy(), blur.copy(), margin.copy(), mask2.copy(), blur2.copy(), margin2.copy(), (Fm, gm, H))
+    # label propagation: 5 frames, 2 context frames (queue filling, then full), hard labels + last map + all maps
+    bs, fs, gl, Dl, Kl, nlast = 2, 5, 6, 16, 4, 2
+    nl = gl * gl
+    feats = f32(fs, bs, nl, Dl)
+    for t in range(1, fs):
+        feats[t] = 0.8 * feats[t - 1] + 0.2 * feats[t]
+    xn = (feats / np.linalg.norm(feats, axis=-1, keepdims=True)).astype(np.float32)
+    seg0 = np.exp(f32(bs, nl, Kl) * 2)
+    seg0 = (seg0 / seg0.sum(-1, keepdims=True)).astype(np.float32)
+    labels, last, allm = np.empty((bs, nl), np.int64), np.empty((bs, nl, Kl), np.float64), np.empty((fs - 1, bs, nl, Kl), np.float64)
+    side.run("label_propagate", xn, seg0, labels, last, bs, fs, gl, Dl, Kl, nlast, 2, 3, 0.1, ws, nb, st, outs=(labels, last))
+    side.run("label_propagate_maps", xn, seg0, allm, bs, fs, gl, Dl, Kl, nlast, 2, 3, 0.1, ws, nb, st, outs=(allm,))
+    R["lp"] = (xn, seg0, labels.copy(), last.copy(), allm.copy(), (bs, fs, gl, Dl, Kl, nlast))
+    return R
+
+
+def test_round2c_twins_against_references(twin):
+    R = _round2c_cases(_Side(twin, "tt_cpu_"))
+    A, B, Cm, (M, N, K) = R["gemm"]
+    for z in range(2):
+        ref = 0.5 * A[z, :, :M].T.astype(np.float64) @ B[z, :, :N].astype(np.float64)
+        assert _re(Cm[z, :, :N], ref) < 1e-6 and (Cm[z, :, N:] == 0).all()
+    pos, out, (g, gh, gw, D, sh, sw) = R["pos"]
+    grid = torch.from_numpy(pos[1:]).view(1, g, g, D).permute(0, 3, 1, 2)
+    ref = F.interpolate(grid, scale_factor=(sh, sw), mode="bicubic").permute(0, 2, 3, 1).reshape(-1, D)   # dino_vision_transformer.py:224-228
+    assert ref.shape[0] == gh * gw and np.array_equal(out[0], pos[0]) and _re(out[1:], ref.numpy()) < 1e-5
+    x, up, maps, lab, (Mm, gg, C, Rr, Kk) = R["upsample"]
+    ref = F.interpolate(torch.from_numpy(x).double().view(Mm, gg, gg, C).permute(0, 3, 1, 2), (Rr, Rr), mode="bilinear").float()
+    assert _re(up, ref.permute(0, 2, 3, 1).reshape(Mm, Rr * Rr, C).numpy()) < 1e-7
+    ref = F.interpolate(torch.from_numpy(maps).view(Mm, gg, gg, Kk).permute(0, 3, 1, 2), (Rr, Rr), mode="bilinear").argmax(1)
+    assert (lab != ref.numpy()).mean() < 2e-3
+    pts, lbl, sums, counts = R["kmeans"]
+    for j in range(len(counts)):
+        assert counts[j] == (lbl == j).sum() and _re(sums[j], pts[lbl == j].astype(np.float64).sum(0)) < 1e-12
+    dy, w, xx, pre, dx, dw = R["plane_bwd"]
+    b = lambda a: torch.from_numpy(a).to(torch.bfloat16).double().numpy()
+    pd = torch.from_numpy(pre).double()
+    gelu_grad = (0.5 * (1 + torch.erf(pd / 2 ** 0.5)) + pd * torch.exp(-0.5 * pd * pd) / (2 * np.pi) ** 0.5).numpy()
+    assert _re(dx, (b(dy) @ b(w)) * gelu_grad) < 1e-5 and _re(dw, b(dy).T @ b(xx)) < 1e-6
+    probs, mask, blur, margin, mask2, blur2, margin2, (Fm, gm, H) = R["mask"]
+    full = torch.zeros(Fm, H, gm * gm + 1, gm * gm + 1)
+    full[:, :, 0, :] = torch.from_numpy(probs)
+    omask, oblur, omargin = O.process_attentions(full, gm, 0.65, 0.6, return_blurred=True)
+    for mk, bl in ((mask, blur), (mask2, blur2)):
+        assert _re(bl, oblur.numpy()) < 1e-5
+        diff = mk != omask.reshape(Fm, -1).numpy()
+        assert not (diff & (omargin.numpy() > 2e-6)).any() and diff.mean() < 0.01
+    assert 0.2 < mask.mean() < 0.9
+    xn, seg0, labels, last, allm, (bs, fs, gl, Dl, Kl, nlast) = R["lp"]
+    assert np.array_equal(last, allm[-1])
+    for bi in range(bs):
+        seed = torch.from_numpy(seg0[bi]).view(gl, gl, Kl).permute(2, 0, 1).unsqueeze(0)
+        ref = torch.stack(O.propagate_labels(nlast, 2, 3, gl, torch.from_numpy(xn[:, bi]), seed)).reshape(fs - 1, Kl, gl * gl).transpose(1, 2).numpy()
+        bad = np.abs(allm[:, bi] - ref).max(-1) > 1e-5 * np.abs(ref).max()
+        assert bad.mean() <= 0.01
+        assert (labels[bi] != ref[-1].argmax(1)).mean() <= 0.03
+    # the table-driven scale: g *= scale for every entry
+    from timetuning_amd._lib import AdamwTensor
+    gs = [np.arange(5, dtype=np.float32), np.ones(3, np.float32)]
+    tab = (AdamwTensor * 2)(*[AdamwTensor(None, ptr(a), None, None, a.size, 0.0, 0.0) for a in gs])
+    sc = np.array([0.25], np.float32)
+    assert twin.tt_cpu_scale_tensors(tab, 2, ptr(sc), None) == 0
+    assert np.array_equal(gs[0], np.arange(5) * 0.25) and np.array_equal(gs[1], np.full(3, 0.25, np.float32))
+
+
+@pytest.mark.gpu
+def test_hip_library_equals_its_cpu_twin_round2c(twin):
+    from timetuning_amd import _lib
+
+    A = _round2c_cases(_Side(_lib.load(), "tt_", device="cuda"))
+    B = _round2c_cases(_Side(twin, "tt_cpu_"))
+    assert _re(A["gemm"][2], B["gemm"][2]) < 2e-5 and _re(A["pos"][1], B["pos"][1]) < 1e-5
+    assert _re(A["upsample"][1], B["upsample"][1]) < 1e-6 and (A["upsample"][3] != B["upsample"][3]).mean() < 2e-3
+    # (the kernel sums a block's points in fp32 in LDS - as faiss accumulates its centroids in float - and folds the blocks in fp64)
+    assert np.array_equal(A["kmeans"][3], B["kmeans"][3]) and _re(A["kmeans"][2], B["kmeans"][2]) < 1e-6
+    assert _re(A["plane_bwd"][4], B["plane_bwd"][4]) < 2e-5 and _re(A["plane_bwd"][5], B["plane_bwd"][5]) < 2e-5
+    for i in (1, 4):                                         # masks: equal except within the cut's rounding margin
+        diff = A["mask"][i] != B["mask"][i]
+        assert not (diff & (B["mask"][i + 2] > 2e-6)).any() and diff.mean() < 0.01
+        assert _re(A["mask"][i + 1], B["mask"][i + 1]) < 1e-5
+    bad = np.abs(A["lp"][4] - B["lp"][4]).max(-1) > 1e-5 * np.abs(B["lp"][4]).max()
+    assert bad.mean() <= 0.01 and (A["lp"][2] != B["lp"][2]).mean() <= 0.03 and np.array_equal(A["lp"][3], A["lp"][4][-1])
