@@ -153,6 +153,72 @@ __global__ __launch_bounds__(256) void layernorm_fwd_planes_kernel(const float* 
   }
 }
 
+// The plane-writing LayerNorm for D = 128 NV: 8-byte loads, 4-byte (two bf16) stores per plane, two rows per wave in flight.
+template <int NV, int R>
+__global__ __launch_bounds__(256) void layernorm_fwd_planes_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, __bf16* __restrict__ y, long long stride,
+                                                                       int planes, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                       int rows, float eps, int skip_group) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  constexpr int D = 128 * NV;
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
+  float2 v[R][NV];
+  float s[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    s[r] = 0.f;
+    const int row = row0 + r < rows ? row0 + r : row0;
+    const long long in_row = skip_group ? (long long)(row / (skip_group - 1)) * skip_group + 1 + row % (skip_group - 1) : row;
+    const float2* xr = reinterpret_cast<const float2*>(x + in_row * D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[r][i] = xr[lane + 64 * i];
+      s[r] += v[r][i].x + v[r][i].y;
+    }
+  }
+  float2 gm[NV], bt[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    gm[i] = reinterpret_cast<const float2*>(gamma)[lane + 64 * i];
+    bt[i] = reinterpret_cast<const float2*>(beta)[lane + 64 * i];
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (row0 + r >= rows) break;
+    const float mean = wave_sum(s[r]) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float dx = v[r][i].x - mean, dy = v[r][i].y - mean;
+      q += dx * dx + dy * dy;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    bf16x2* yr = reinterpret_cast<bf16x2*>(y + (long long)(row0 + r) * D);
+    const long long st2 = stride / 2;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float o0 = (v[r][i].x - mean) * rstd * gm[i].x + bt[i].x, o1 = (v[r][i].y - mean) * rstd * gm[i].y + bt[i].y;
+      bf16x2 p0 = {(__bf16)o0, (__bf16)o1};
+      yr[lane + 64 * i] = p0;
+      if (planes > 1) {
+        const float r0 = o0 - (float)p0[0], r1 = o1 - (float)p0[1];
+        bf16x2 p1 = {(__bf16)r0, (__bf16)r1};
+        yr[st2 + lane + 64 * i] = p1;
+        if (planes > 2) {
+          bf16x2 p2 = {(__bf16)(r0 - (float)p1[0]), (__bf16)(r1 - (float)p1[1])};
+          yr[2 * st2 + lane + 64 * i] = p2;
+        }
+      }
+    }
+    if (lane == 0) {
+      if (mean_out) mean_out[row0 + r] = mean;
+      if (rstd_out) rstd_out[row0 + r] = rstd;
+    }
+  }
+}
+
 // Backward.  Each workgroup owns a contiguous run of rows; its 4 waves walk them, keep per-column partial
 // sums of dgamma/dbeta in registers and combine them through LDS into partial[wg][2][D]; a column-sum
 // pass over the partials finishes (deterministic: no atomics).
@@ -434,6 +500,24 @@ extern "C" int tt_layernorm_fwd_planes(const float* x, const float* gamma, const
   TT_REQUIRE(skip_group == 0 || (skip_group >= 2 && rows % (skip_group - 1) == 0), "layernorm_fwd_planes: rows must be a multiple of skip_group - 1");
   TT_REQUIRE(x && gamma && beta && y_planes && planes >= 1 && planes <= 3, "layernorm_fwd_planes: null pointer / planes not in 1..3");
   TT_REQUIRE(rows > 0 && D > 0 && D <= 64 * kMaxPerLane, "layernorm_fwd_planes: need 0 < D <= %d (got %d)", 64 * kMaxPerLane, D);
+  const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 7u) == 0 &&
+                  (reinterpret_cast<uintptr_t>(y_planes) & 3u) == 0 && plane_stride % 2 == 0;
+  if (al && (D == 384 || D == 768 || D == 128 || D == 256 || D == 512 || D == 1024)) {
+    constexpr int R = 2;
+    const dim3 grid((rows + 4 * R - 1) / (4 * R)), block(256);
+    hipStream_t s = as_stream(stream);
+    __bf16* yp = static_cast<__bf16*>(y_planes);
+    switch (D / 128) {
+      case 1: hipLaunchKernelGGL((layernorm_fwd_planes_vec_kernel<1, R>), grid, block, 0, s, x, gamma, beta, yp, plane_stride, planes, mean, rstd, rows, eps, skip_group); break;
+      case 2: hipLaunchKernelGGL((layernorm_fwd_planes_vec_kernel<2, R>), grid, block, 0, s, x, gamma, beta, yp, plane_stride, planes, mean, rstd, rows, eps, skip_group); break;
+      case 3: hipLaunchKernelGGL((layernorm_fwd_planes_vec_kernel<3, R>), grid, block, 0, s, x, gamma, beta, yp, plane_stride, planes, mean, rstd, rows, eps, skip_group); break;
+      case 4: hipLaunchKernelGGL((layernorm_fwd_planes_vec_kernel<4, R>), grid, block, 0, s, x, gamma, beta, yp, plane_stride, planes, mean, rstd, rows, eps, skip_group); break;
+      case 6: hipLaunchKernelGGL((layernorm_fwd_planes_vec_kernel<6, R>), grid, block, 0, s, x, gamma, beta, yp, plane_stride, planes, mean, rstd, rows, eps, skip_group); break;
+      default: hipLaunchKernelGGL((layernorm_fwd_planes_vec_kernel<8, R>), grid, block, 0, s, x, gamma, beta, yp, plane_stride, planes, mean, rstd, rows, eps, skip_group); break;
+    }
+    TT_CHECK_LAUNCH("layernorm_fwd_planes");
+    return TT_OK;
+  }
   hipLaunchKernelGGL(layernorm_fwd_planes_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta,
                      static_cast<__bf16*>(y_planes), plane_stride, planes, mean, rstd, rows, D, eps, skip_group);
   TT_CHECK_LAUNCH("layernorm_fwd_planes");
