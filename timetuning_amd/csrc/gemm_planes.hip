@@ -363,6 +363,19 @@ __global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __re
     t[i][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
   }
   __syncthreads();
+  // out row c = 64 consecutive r: 16 lanes x 4 bf16 (8-byte stores; Rpad % 64 == 0 keeps them aligned), 16 rows per pass
+  if (Rpad % 4 == 0) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const int q = threadIdx.x & 15, cr = threadIdx.x >> 4;
+    for (int i = cr; i < 64; i += 16) {
+      const int c = c0 + i, r = r0 + 4 * q;
+      if (c < C && r < Rpad) {   // (Rpad % 4 == 0: the four r of a quad are inside or outside together)
+        bf16x4 v = {(__bf16)t[4 * q][i], (__bf16)t[4 * q + 1][i], (__bf16)t[4 * q + 2][i], (__bf16)t[4 * q + 3][i]};
+        *reinterpret_cast<bf16x4*>(dst + (size_t)c * Rpad + r) = v;
+      }
+    }
+    return;
+  }
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
     if (c < C && r < Rpad) dst[(size_t)c * Rpad + r] = (__bf16)t[tx][i];
