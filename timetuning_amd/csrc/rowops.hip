@@ -288,6 +288,88 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
+// The same for D = 128 NV with 8-byte accesses, a compile-time trip count and two rows per wave in flight.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, float* __restrict__ dx,
+                                                                float* __restrict__ partial, int rows, int rows_per_wg, int add_to_dx,
+                                                                int skip_group) {
+  constexpr int D = 128 * NV;
+  __shared__ float2 red[4][2][64 * NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * rows_per_wg;
+  const int r1 = min(rows, r0 + rows_per_wg);
+  float2 dg[NV], db[NV], gm[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    dg[i] = make_float2(0.f, 0.f);
+    db[i] = make_float2(0.f, 0.f);
+    gm[i] = reinterpret_cast<const float2*>(gamma)[lane + 64 * i];
+  }
+  for (int rowa = r0 + wave; rowa < r1; rowa += 8) {
+    float2 xh[2][NV], gy[2][NV];
+    float s1[2], s2[2], rs[2];
+    long long in_row[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = rowa + 4 * r < r1 ? rowa + 4 * r : rowa;
+      const float mu = mean[row];
+      rs[r] = rstd[row];
+      in_row[r] = skip_group ? (long long)(row / (skip_group - 1)) * skip_group + 1 + row % (skip_group - 1) : row;
+      const float2* xr = reinterpret_cast<const float2*>(x + in_row[r] * D);
+      const float2* dyr = reinterpret_cast<const float2*>(dy + (long long)row * D);
+      s1[r] = 0.f;
+      s2[r] = 0.f;
+      const bool live = r == 0 || rowa + 4 < r1;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const float2 xv = xr[lane + 64 * i], dv = dyr[lane + 64 * i];
+        xh[r][i] = make_float2((xv.x - mu) * rs[r], (xv.y - mu) * rs[r]);
+        gy[r][i] = make_float2(dv.x * gm[i].x, dv.y * gm[i].y);
+        if (live) {
+          dg[i].x += dv.x * xh[r][i].x; dg[i].y += dv.y * xh[r][i].y;
+          db[i].x += dv.x; db[i].y += dv.y;
+        }
+        s1[r] += gy[r][i].x * xh[r][i].x + gy[r][i].y * xh[r][i].y;
+        s2[r] += gy[r][i].x + gy[r][i].y;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (r == 1 && rowa + 4 >= r1) break;
+      const float c1 = wave_sum(s1[r]) / (float)D, c2 = wave_sum(s2[r]) / (float)D;
+      float2* dxr = reinterpret_cast<float2*>(dx + in_row[r] * D);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        float2 o = make_float2(rs[r] * (gy[r][i].x - c2 - xh[r][i].x * c1), rs[r] * (gy[r][i].y - c2 - xh[r][i].y * c1));
+        if (add_to_dx) {
+          const float2 old = dxr[lane + 64 * i];
+          o.x += old.x; o.y += old.y;
+        }
+        dxr[lane + 64 * i] = o;
+      }
+    }
+  }
+  if (!partial) return;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    red[wave][0][lane + 64 * i] = dg[i];
+    red[wave][1][lane + 64 * i] = db[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D / 2; c += 256) {
+    float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      a.x += red[w][0][c].x; a.y += red[w][0][c].y;
+      b.x += red[w][1][c].x; b.y += red[w][1][c].y;
+    }
+    reinterpret_cast<float2*>(partial + ((long long)blockIdx.x * 2 + 0) * D)[c] = a;
+    reinterpret_cast<float2*>(partial + ((long long)blockIdx.x * 2 + 1) * D)[c] = b;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Column sums: out[n] = sum_m a[m][n] (row stride lda).  Stage 1 writes partial[chunk][n]; stage 2 folds.
 // ------------------------------------------------------------------------------------------------
@@ -525,8 +607,10 @@ extern "C" int tt_layernorm_fwd_planes(const float* x, const float* gamma, const
 }
 
 static int ln_bwd_wgs(int rows) {
-  int w = (rows + 31) / 32;
-  return w > 512 ? 512 : (w < 1 ? 1 : w);
+  // 8 rows per workgroup (two per wave, both in flight) until the fold of the per-workgroup dgamma / dbeta partials would outgrow
+  // the pass itself: 6304 rows -> 788 workgroups (26 -> 11 us at D = 384 against 197 workgroups of 32 rows)
+  int w = (rows + 7) / 8;
+  return w > 1024 ? 1024 : (w < 1 ? 1 : w);
 }
 extern "C" size_t tt_layernorm_bwd_workspace_bytes(int rows, int D) { return (size_t)ln_bwd_wgs(rows) * 2 * D * sizeof(float); }
 
@@ -542,8 +626,15 @@ extern "C" int tt_layernorm_bwd(const float* dy, const float* x, const float* ga
   const int rpw = (rows + wgs - 1) / wgs;
   if (want) TT_REQUIRE(workspace && workspace_bytes >= tt_layernorm_bwd_workspace_bytes(rows, D), "layernorm_bwd: workspace too small");
   float* partial = want ? static_cast<float*>(workspace) : nullptr;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(wgs), dim3(256), 0, as_stream(stream), dy, x, gamma, mean, rstd, dx, partial, rows,
-                     D, rpw, add_to_dx, skip_group);
+  const bool al8 = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) |
+                     reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(partial)) & 7u) == 0;
+  hipStream_t s = as_stream(stream);
+  const dim3 grid(wgs), block(256);
+  if (al8 && D == 384) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<3>), grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, rpw, add_to_dx, skip_group);
+  else if (al8 && D == 768) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<6>), grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, rpw, add_to_dx, skip_group);
+  else if (al8 && D == 128) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<1>), grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, rpw, add_to_dx, skip_group);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel, grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, D, rpw, add_to_dx, skip_group);
   TT_CHECK_LAUNCH("layernorm_bwd");
   if (want) {
     hipLaunchKernelGGL(colsum_stage2, dim3((D + 63) / 64), dim3(256), 0, as_stream(stream), partial, dgamma, wgs, D, 2 * D, 0);
