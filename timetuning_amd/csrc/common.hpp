@@ -105,4 +105,22 @@ __device__ __forceinline__ bool xcd_group_decode(int b, int inner, int n_outer, 
 }
 inline int xcd_group_grid(int n_outer, int inner) { return ((n_outer + 7) / 8) * 8 * inner; }
 
+
+// out[n] = sum over chunks of partial[chunk][poff + n] for the 64 columns of block `blk`: the 4 waves split the chunks (fixed
+// assignment and order: deterministic).  Shared by colsum_stage2 (rowops.hip) and the weight-gradient fold (gemm_f32.hip) so
+// that a bias gradient has the same bits whichever launch folds it.  red: 4 x 64 floats of LDS.
+__device__ __forceinline__ void colsum_fold_block(const float* __restrict__ partial, float* __restrict__ out, int chunks, int N, int pstride,
+                                                  int poff, int blk, float (*red)[64]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = blk * 64 + lane;
+  float s = 0.f;
+  if (n < N) {
+#pragma unroll 8
+    for (int c = w; c < chunks; c += 4) s += partial[(long long)c * pstride + poff + n];
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && n < N) out[n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
 }  // namespace tt

@@ -329,6 +329,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// The same launch also folds the bias gradient's column partials [colparts][N] (written by the weight-gradient kernel) into db:
+// workgroups >= blocks_main take 64 columns each, in colsum_stage2's order (common.hpp: colsum_fold_block).
+__global__ __launch_bounds__(256) void splitk_reduce_colfold_kernel(const float* __restrict__ partial, float* __restrict__ out, long long n,
+                                                                    int splits, long long stride, int blocks_main,
+                                                                    const float* __restrict__ colpart, float* __restrict__ db, int colparts,
+                                                                    int N) {
+  __shared__ float red[4][64];
+  if ((int)blockIdx.x >= blocks_main) {
+    colsum_fold_block(colpart, db, colparts, N, N, 0, (int)blockIdx.x - blocks_main, red);
+    return;
+  }
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long long step = (long long)blocks_main * 256 * 4;
+  for (; i < n; i += step) {
+    float4 s = *reinterpret_cast<const float4*>(partial + i);
+    for (int z = 1; z < splits; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + z * stride + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = s;
+  }
+}
+
 int launch_splitk_reduce(const float* partial, float* out, long long n, int splits, long long stride, hipStream_t s) {
   long long blocks = (n / 4 + 255) / 256;
   if (blocks > 1024) blocks = 1024;
@@ -558,6 +581,12 @@ extern "C" int tt_linear_bwd_weight(const float* dy, const float* x, float* dw, 
     TT_REQUIRE(n % 4 == 0, "linear_bwd_weight: N*K must be a multiple of 4");
     long long blocks = (n / 4 + 255) / 256;
     if (blocks > 1024) blocks = 1024;
+    if (bias_fused && db) {   // one launch folds the split-K partials of dw AND the column partials of db
+      hipLaunchKernelGGL(tt::splitk_reduce_colfold_kernel, dim3((unsigned)blocks + (N + 63) / 64), dim3(256), 0, tt::as_stream(stream),
+                         static_cast<const float*>(workspace), dw, n, s, (long long)N * K, (int)blocks, colpart, db, colparts, N);
+      TT_CHECK_LAUNCH("splitk_reduce_colfold");
+      return TT_OK;
+    }
     hipLaunchKernelGGL(tt::splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, tt::as_stream(stream),
                        static_cast<const float*>(workspace), dw, n, s, (long long)N * K);
     TT_CHECK_LAUNCH("splitk_reduce");

@@ -388,18 +388,16 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ a
 }
 __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ partial, float* __restrict__ out, int chunks,
                                                      int N, int pstride, int poff) {
-  // 64 columns per workgroup; the 4 waves split the chunks (fixed assignment and order: deterministic)
+  // 64 columns per workgroup (common.hpp: colsum_fold_block)
   __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (n < N) {
-#pragma unroll 8
-    for (int c = w; c < chunks; c += 4) s += partial[(long long)c * pstride + poff + n];
-  }
-  red[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && n < N) out[n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  colsum_fold_block(partial, out, chunks, N, pstride, poff, blockIdx.x, red);
+}
+
+// dgamma and dbeta of the LayerNorm backward in ONE launch: partial[wg][2][D] -> dgamma[D] (y = 0), dbeta[D] (y = 1)
+__global__ __launch_bounds__(256) void colsum_stage2_pair(const float* __restrict__ partial, float* __restrict__ out0, float* __restrict__ out1,
+                                                          int chunks, int N) {
+  __shared__ float red[4][64];
+  colsum_fold_block(partial, blockIdx.y ? out1 : out0, chunks, N, 2 * N, blockIdx.y ? N : 0, blockIdx.x, red);
 }
 
 // fold of partial[chunks][N] into out[N] for other translation units (the weight-gradient GEMM's fused bias gradient)
@@ -637,8 +635,7 @@ extern "C" int tt_layernorm_bwd(const float* dy, const float* x, const float* ga
     hipLaunchKernelGGL(layernorm_bwd_kernel, grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, D, rpw, add_to_dx, skip_group);
   TT_CHECK_LAUNCH("layernorm_bwd");
   if (want) {
-    hipLaunchKernelGGL(colsum_stage2, dim3((D + 63) / 64), dim3(256), 0, as_stream(stream), partial, dgamma, wgs, D, 2 * D, 0);
-    hipLaunchKernelGGL(colsum_stage2, dim3((D + 63) / 64), dim3(256), 0, as_stream(stream), partial, dbeta, wgs, D, 2 * D, D);
+    hipLaunchKernelGGL(colsum_stage2_pair, dim3((D + 63) / 64, 2), dim3(256), 0, as_stream(stream), partial, dgamma, dbeta, wgs, D);
     TT_CHECK_LAUNCH("layernorm_bwd.reduce");
   }
   return TT_OK;
