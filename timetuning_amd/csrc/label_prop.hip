@@ -211,6 +211,126 @@ __global__ __launch_bounds__(256) void label_prop_kernel(LpArgs a) {
   }
 }
 
+// The same per-query work with ONE WAVE per (clip, query) and no LDS or barriers, for windows of at most 16 x 16 patches and at
+// most CTX context frames (the training protocol: radius 6 -> 13 x 13).  A lane owns window column lane & 15 and rows
+// (lane >> 4) + 4 r of every context (4 CTX candidate slots, no integer division); the k rounds of arg-max are wave shuffles, the
+// kept sources are broadcast lane by lane in (slot, lane) order, a lane owns the label channels k = lane + 64 t.  Same arithmetic
+// as label_prop_kernel (fp32 affinities, fp32 column sum, fp64 maps); the column sum and the fp64 accumulation visit the kept
+// sources in a different fixed order.  Measured on C2's launch (32 clips x 196 queries, 3 contexts, K = 200): 48.6 us for the
+// workgroup-per-query kernel, 24.5 us for this one - which is bound by its instruction count (every wave of the launch is
+// resident at once; compacting the kept list through LDS to batch the label-row loads made it slower, 32.7 us).
+template <int CTX, int KT>
+__global__ __launch_bounds__(256) void label_prop_wave_kernel(LpArgs a) {
+  constexpr int CPL = 4 * CTX;
+  const int lane = threadIdx.x & 63;
+  const int n = a.g * a.g;
+  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (long long)a.bs * n) return;
+  const int b = (int)(item / n), qi = (int)(item - (long long)b * n);
+  const int qy = qi / a.g, qx = qi - qy * a.g;
+  const int y0 = max(0, qy - a.radius), y1 = min(a.g - 1, qy + a.radius);
+  const int x0 = max(0, qx - a.radius), x1 = min(a.g - 1, qx + a.radius);
+  const int ww = x1 - x0 + 1, wh = y1 - y0 + 1;
+  const int total = ww * wh * a.c;
+  const int lx = lane & 15, ly = lane >> 4;
+
+  float val[CPL];
+  int src[CPL];   // context << 12 | source patch, -1 = no candidate
+#pragma unroll
+  for (int j = 0; j < CTX; ++j) {
+    const float* row = a.sims + (((long long)b * a.cs + j) * n + qi) * n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = j * 4 + r, y = ly + 4 * r;
+      val[i] = -1.f;
+      src[i] = -1;
+      if (j < a.c && lx < ww && y < wh) {
+        const int sp = (y0 + y) * a.g + x0 + lx;
+        val[i] = expf(row[sp] / a.temp);
+        src[i] = (j << 12) | sp;
+      }
+    }
+  }
+  // k-th largest with multiplicity
+  float thr = 0.f;
+  unsigned taken = 0u;
+  const int rounds = min(a.topk, total);
+  for (int rd = 0; rd < rounds; ++rd) {
+    float bv = -2.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+      if (!((taken >> i) & 1u) && src[i] >= 0 && val[i] > bv) {   // (slots ascend: the first of equal values has the lowest id)
+        bv = val[i];
+        bi = lane + 64 * i;
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    thr = bv;
+    if ((bi & 63) == lane) taken |= 1u << (bi >> 6);
+  }
+  if (total < a.topk) thr = 0.f;
+  float mysum = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i)
+    if (src[i] >= 0 && val[i] >= thr) mysum += val[i];
+  const float colsum = wave_sum(mysum);
+
+  // seg_tar[:, q] = sum_s segs[:, s] * aff[s, q] in fp64 (mask_propagation.py:442-444)
+  double acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) acc[t] = 0.0;
+  const long long fstride = (long long)a.bs * n * a.K;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    unsigned long long mask = __ballot(src[i] >= 0 && val[i] >= thr);
+    while (mask) {
+      const int l = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int s_ = __shfl(src[i], l, 64);
+      const double w = (double)(__shfl(val[i], l, 64) / colsum);   // aff / aff.sum(0) in fp32 (mask_propagation.py:436)
+      const int fr = a.ctx_frame[s_ >> 12];
+      const long long off = ((long long)b * n + (s_ & 4095)) * a.K;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        const int k = lane + 64 * t;
+        if (k < a.K) acc[t] += ((fr == 0) ? (double)a.seg0[off + k] : a.seg_prev[(long long)(fr - 1) * fstride + off + k]) * w;
+      }
+    }
+  }
+  double best = -1.0;
+  int besti = 0x7fffffff;
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    const int k = lane + 64 * t;
+    if (k < a.K) {
+      a.seg_out[((long long)b * n + qi) * a.K + k] = acc[t];
+      if (acc[t] > best) {
+        best = acc[t];
+        besti = k;
+      }
+    }
+  }
+  if (!a.labels) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) {
+      best = ov;
+      besti = oi;
+    }
+  }
+  if (lane == 0) a.labels[(long long)b * n + qi] = besti;   // torch.argmax: first index of the maximum
+}
+
 __global__ void f64_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long st = (long long)gridDim.x * blockDim.x;
@@ -306,7 +426,18 @@ static int lp_run(const char* who, const float* xn, const float* seg0, int64_t* 
       a.seg_out = segs + (long long)(t - 1) * fstride;
       a.labels = (t == fs - 1) ? labels : nullptr;
       a.c = c; a.cs = cmax; a.bs = bs; a.g = g; a.K = K; a.radius = radius; a.topk = topk; a.temp = temperature;
-      if (cand_max <= 256LL * 8)
+      const unsigned wgrid = (unsigned)(((long long)bs * n + 3) / 4);
+      static const bool wave_env = [] { const char* e = getenv("TT_LP_WAVE"); return !e || atoi(e) != 0; }();   // tuning aid
+      const bool wave_kernel = wave_env && win <= 16 && n <= 4096 && K <= 512;   // (source patch packed into 12 bits)
+      if (wave_kernel && c <= 3 && K <= 256)
+        hipLaunchKernelGGL((label_prop_wave_kernel<3, 4>), dim3(wgrid), dim3(256), 0, s, a);
+      else if (wave_kernel && c <= 3)
+        hipLaunchKernelGGL((label_prop_wave_kernel<3, 8>), dim3(wgrid), dim3(256), 0, s, a);
+      else if (wave_kernel && K <= 256)
+        hipLaunchKernelGGL((label_prop_wave_kernel<8, 4>), dim3(wgrid), dim3(256), 0, s, a);
+      else if (wave_kernel)
+        hipLaunchKernelGGL((label_prop_wave_kernel<8, 8>), dim3(wgrid), dim3(256), 0, s, a);
+      else if (cand_max <= 256LL * 8)
         hipLaunchKernelGGL((label_prop_kernel<8>), dim3(n, bs), dim3(256), 0, s, a);
       else
         hipLaunchKernelGGL((label_prop_kernel<LP_CAND_MAX>), dim3(n, bs), dim3(256), 0, s, a);
