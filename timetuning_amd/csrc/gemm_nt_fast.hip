@@ -43,6 +43,12 @@ struct FastArgs {
   const float* residual;  // [M][N] or null (may alias C)
   float* pre_out;         // [M][N] or null
   int act;                // 1 = GELU
+  // GATHER instance (patch embedding, dino_vision_transformer.py:156-171 + 236-247): A row m = patch (m % n_patch) of frame
+  // frame_map[m / n_patch] of the image batch A = img [F_src][Cin][H][W], k = (channel, row in patch, pixel in row); P = 16, so a
+  // 16-k slab is one contiguous pixel row.  The epilogue adds the position rows and writes token row f (n_patch + 1) + 1 + patch.
+  const int* frame_map;   // [M / n_patch] or null (identity)
+  const float* pos;       // [n_patch + 1][N]
+  int Cin, H, W, gw, n_patch;
 };
 
 #ifdef TT_CLOCK_STAMP
@@ -58,8 +64,9 @@ extern "C" int tt_debug_read_clock_stamps(unsigned long long* host, int count) {
 // BK = 16 is the throughput instance (5-6 workgroups per CU hide every latency).  BK = 64 is for grids of at most about one
 // workgroup per CU (BASELINE C1: 2 x 2 frames = 788 rows, 13 row tiles): there nothing hides the global-load latency of the
 // one slab in flight, a launch is (K / BK) dependent round trips long, and four times deeper slabs cut the trips four-fold.
-template <int WM, int WN, int BK = 16>
+template <int WM, int WN, int BK = 16, int GATHER = 0>
 __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
+  static_assert(!GATHER || BK == 16, "the patch gather stages one pixel row (16 k) per slab");
   constexpr int BM = 64 * WM, BN = 64 * WN, KQ = BK / 16;
   // k-row stride = tile extent + 2: the transposing staging writes (lane -> k-rows 4 (tid & 3) + e, column tid >> 2) then
   // spread over all 32 banks of a ds_write_b32 lane group (4 * stride = 8 mod 32); with + 4 (= 16 mod 32) they collide
@@ -85,9 +92,18 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
   const float* pa[WM];
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
-    const int row = m0 + srow + 64 * i;
-    pa[i] = g.A + (size_t)(row < g.M ? row : g.M - 1) * K + skc;
+    int row = m0 + srow + 64 * i;
+    row = row < g.M ? row : g.M - 1;
+    if constexpr (GATHER) {
+      const int f = row / g.n_patch, pi = row - f * g.n_patch;
+      const int fs = g.frame_map ? g.frame_map[f] : f;
+      const int pr = pi / g.gw, pc = pi - pr * g.gw;
+      pa[i] = g.A + ((size_t)fs * g.Cin * g.H + (size_t)pr * 16) * g.W + pc * 16 + skc;
+    } else {
+      pa[i] = g.A + (size_t)row * K + skc;
+    }
   }
+  [[maybe_unused]] int gather_py = 0;   // pixel row inside the patch of the NEXT slab to load
   const float* pb = g.B + (size_t)(n0 + srow) * K + skc;
   const size_t step64 = (size_t)64 * K;
   // a thread stages, per 16 k, the 4 k's at skc of its row(s); a BK = 64 slab is four such quarters (q)
@@ -100,8 +116,15 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
 #pragma unroll
       for (int i = 0; i < WN; ++i) rb[q][i] = *reinterpret_cast<const float4*>(pb + i * step64 + 16 * q);
     }
+    if constexpr (GATHER) {   // next pixel row of the patch; after the 16th, the first row of the next channel
+      const size_t adv = (++gather_py == 16) ? (size_t)g.H * g.W - (size_t)15 * g.W : (size_t)g.W;
+      if (gather_py == 16) gather_py = 0;
 #pragma unroll
-    for (int i = 0; i < WM; ++i) pa[i] += BK;
+      for (int i = 0; i < WM; ++i) pa[i] += adv;
+    } else {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) pa[i] += BK;
+    }
     pb += BK;
   };
   auto sstore = [&](int buf) {
@@ -195,9 +218,15 @@ __global__ __launch_bounds__(256) void gemm_nt_fast_kernel(FastArgs g) {
     __syncthreads();
     for (int rr = tid / TPR; rr < CH; rr += RPP) {
       if (m0 + wmi * CH + rr >= g.M) break;
-      const size_t off = (size_t)(m0 + wmi * CH + rr) * g.N + n;
+      size_t off = (size_t)(m0 + wmi * CH + rr) * g.N + n;
       float4 v = *reinterpret_cast<const float4*>(lds + rr * LDCS + c4);
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      if constexpr (GATHER) {
+        const int m = m0 + wmi * CH + rr, f = m / g.n_patch, pi = m - f * g.n_patch;
+        off = ((size_t)f * (g.n_patch + 1) + 1 + pi) * g.N + n;
+        const float4 ps = *reinterpret_cast<const float4*>(g.pos + (size_t)(1 + pi) * g.N + n);
+        v.x += ps.x; v.y += ps.y; v.z += ps.z; v.w += ps.w;
+      }
       if (g.pre_out) *reinterpret_cast<float4*>(g.pre_out + off) = v;
       if (g.act == 1) {
         // (exact-erf GELU as nn.GELU; an Abramowitz-Stegun erf is NOT faster here: 265.4 vs 266.8 us on the fc1 shape in an
@@ -235,12 +264,28 @@ static int launch_fast(const FastArgs& g, hipStream_t s) {
 
 int gemm_tile_choice(int M, int N, int batch);
 
+// Patch embedding on the lean kernel (P = 16, D % 64 == 0, 16-byte aligned rows): TT_OK if launched, 1 if not eligible.
+int try_launch_patch_embed_fast(const float* img, const int* frame_map, const float* w, const float* bias, const float* pos, float* tokens,
+                                int F, int C, int H, int W, int P, int D, hipStream_t s) {
+  if (P != 16 || D % 64 != 0 || W % 4 != 0 || !aligned16(img) || !aligned16(w) || !aligned16(bias) || !aligned16(pos) || !aligned16(tokens))
+    return 1;
+  const int gw = W / P, n = gw * (H / P);
+  FastArgs g{img, w, tokens, F * n, D, C * P * P, bias, nullptr, nullptr, 0, frame_map, pos, C, H, W, gw, n};
+  const int tile = gemm_tile_choice(g.M, D, 1);
+  const bool bm128 = tile == 0 || tile == 2;
+  const int tiles = ((g.M + (bm128 ? 127 : 63)) / (bm128 ? 128 : 64)) * (D / 64);
+  if (bm128) hipLaunchKernelGGL((gemm_nt_fast_kernel<2, 1, 16, 1>), dim3(tiles), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_nt_fast_kernel<1, 1, 16, 1>), dim3(tiles), dim3(256), 0, s, g);
+  TT_CHECK_LAUNCH("patch_embed_fast");
+  return TT_OK;
+}
+
 // Returns TT_OK if launched, 1 if the shape is not eligible (caller falls back to the general kernel).
 int try_launch_gemm_nt_fast(const float* A, const float* B, float* C, int M, int N, int K, const float* bias,
                             const float* residual, float* pre_out, int act, hipStream_t s) {
   auto ok16 = [](const void* p) { return p == nullptr || aligned16(p); };
   if (K % 16 != 0 || K < 16 || !aligned16(A) || !aligned16(B) || !aligned16(C) || !ok16(bias) || !ok16(residual) || !ok16(pre_out)) return 1;
-  FastArgs g{A, B, C, M, N, K, bias, residual, pre_out, act};
+  FastArgs g{A, B, C, M, N, K, bias, residual, pre_out, act, nullptr, nullptr, 0, 0, 0, 0, 0};
   const int tile = gemm_tile_choice(M, N, 1);
   const int bn = (tile == 0 || tile == 1) ? 128 : 64;
   if (N % bn != 0) {   // (any M: a partial last row tile is clamped / masked)
