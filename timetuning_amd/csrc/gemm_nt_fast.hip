@@ -5,6 +5,7 @@
 // switches, row pointers advanced instead of recomputed, and - the part that matters - the tile leaves through the
 // idle LDS as 16-byte, fully coalesced row-major stores.  tools/mfma_peak.hip measures the inner loop at
 // 133 TFLOP/s, 105 with the natural 64-scalar-stores-per-lane epilogue (store-issue bound) and 121-125 with this one.
+// GATHER = 1 is the patch-embedding instance (the conv as a GEMM whose A rows are gathered from the image batch).
 //
 // Measured dead ends, kept out of the source (DESIGN.md section 5 has the numbers, git history the code):
 //   * fragment reads hand-pipelined with inline-asm ds_read_b32 into a register double buffer and counted lgkmcnt waits
