@@ -27,7 +27,9 @@
 //     a CU holds one workgroup anyway;
 //   * (round 2) non-temporal epilogue (nt stores of C, nt loads of the residual) to keep the streamed output out of L2, where
 //     the weights and the A row blocks live: qkv / fc1 -0.7 %, fc2 +1.0 %, proj +5.6 % (interleaved A/B) - nothing, and in the
-//     step the next kernel WANTS the output in the caches.
+//     step the next kernel WANTS the output in the caches;
+//   * (round 2) the compiler's other scheduling strategies (-mllvm -amdgpu-sched-strategy=max-ilp / max-memory-clause /
+//     iterative-ilp, -amdgpu-schedule-metric-bias=100): all four block shapes within 1 % of the default.
 #include "common.hpp"
 #include <cstdlib>
 
