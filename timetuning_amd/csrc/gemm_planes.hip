@@ -25,7 +25,10 @@
 // Four waves with 128 x 128 (P = 1) / 128 x 64 (P = 3) wave tiles - half the LDS fragment traffic per MFMA, 256 accumulator
 // registers, one wave per SIMD - are 10-25 % SLOWER at P = 1 and equal at P = 3 (tools/bench_planes.py): with one wave per SIMD
 // nothing hides the fragment reads.  Register staging (16-byte global loads before the MFMAs of a slab, ds_write_b128 after them, same
-// LDS image) instead of LDS-DMA: equal to 10 % slower on every shape and tiling.  For scale: a bare v_mfma_f32_32x32x16_bf16 loop on random operands sustains 1.81 PFLOP/s on
+// LDS image) instead of LDS-DMA: equal to 10 % slower on every shape and tiling; fragment reads of k-step ks + 1 issued before the
+// MFMAs of k-step ks (two register sets, scheduler fenced): +-2 %; 3- and 4-slab rings on the 256 x 256 tile, 128 x 256 / 256 x 128
+// tiles with two 4-wave workgroups per CU, a 32 KB-per-workgroup 128 x 128 tile at 4 workgroups per CU: all within +-5 % or slower
+// (PMC reading of the 256 x 256 instance: profiles/r02_gemm_planes_pmc.json).  For scale: a bare v_mfma_f32_32x32x16_bf16 loop on random operands sustains 1.81 PFLOP/s on
 // this part (2.39 on zeros; tools/mfma_bf16_shapes.hip, profiles/r02_mfma_bf16_shapes.txt) - this kernel reaches 0.33-0.48 of that.
 //
 // Tile (32 WM GM) x (32 WN GN), GM x GN waves (4 as 2 x 2 by default), LDS ring of NBUF slabs, ONE barrier per slab: the DMA of slab t+1 is issued before
