@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Randomised shape fuzz of the HIP ops against torch fp64 / the oracle (development aid; run on the GPU box).
+usage: fuzz_ops.py [rounds=40] [seed=0]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, torch.nn.functional as F
+from timetuning_amd import hip_ops as ops
+from oracle import timet_oracle as O
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = lambda a: torch.as_tensor(a).cuda()
+rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).abs().max() / (b.double().abs().max() + 1e-30))
+worst = {}
+def note(name, err, tol, info):
+    worst[name] = max(worst.get(name, 0.0), err)
+    assert err < tol, (name, err, info)
+
+for it in range(rounds):
+    # Linear forward: ragged M, N multiple of 64 or not, K multiple of 16 or not, epilogues
+    M, N, K = int(rng.integers(1, 700)), int(rng.choice([64, 128, 192, 200, 384, 50])), int(rng.choice([16, 48, 64, 100, 384]))
+    x, w, b = torch.randn(M, K), torch.randn(N, K) * 0.1, torch.randn(N)
+    res = torch.randn(M, N) if rng.random() < 0.5 else None
+    act = int(rng.random() < 0.5)
+    ref = F.linear(x.double(), w.double(), b.double())
+    if act: ref = F.gelu(ref)
+    if res is not None: ref = ref + res.double()
+    y = ops.linear_fwd(dev(x), dev(w), dev(b), residual=dev(res) if res is not None else None, act=act)
+    note("linear_fwd", rel(y, ref), 3e-5, (M, N, K, act))
+    dy = torch.randn(M, N)
+    dx = ops.linear_bwd_data(dev(dy), dev(w))
+    note("linear_bwd_data", rel(dx, dy.double() @ w.double()), 3e-5, (M, N, K))
+    dw, db = ops.linear_bwd_weight(dev(dy), dev(x))
+    note("linear_bwd_weight", max(rel(dw, dy.double().t() @ x.double()), rel(db, dy.double().sum(0))), 3e-5, (M, N, K))
+    # LayerNorm forward / backward, plain and with the dropped first token
+    D = int(rng.choice([64, 128, 256, 384, 512, 768, 1000, 1024]))
+    Fr, Nt = int(rng.integers(1, 9)), int(rng.integers(2, 40))
+    xx, g, bb = torch.randn(Fr, Nt, D) * 2 + 0.3, 1 + 0.1 * torch.randn(D), 0.1 * torch.randn(D)
+    for drop in (False, True):
+        xd = xx.double().requires_grad_(True)
+        r = F.layer_norm(xd, (D,), g.double(), bb.double(), 1e-6)
+        r = r[:, 1:] if drop else r
+        dyl = torch.randn_like(r)
+        r.backward(dyl)
+        y, mean, rstd = ops.layernorm_fwd(dev(xx), dev(g), dev(bb), save_stats=True, drop_first_token=drop)
+        note("layernorm_fwd", rel(y.reshape(r.shape), r.detach()), 3e-5, (Fr, Nt, D, drop))
+        dxl, dg, dbt = ops.layernorm_bwd(dev(dyl.reshape(-1, D).float()), dev(xx), dev(g), mean, rstd, drop_first_token=drop)
+        note("layernorm_bwd", rel(dxl.reshape(xx.shape), xd.grad), 1e-4, (Fr, Nt, D, drop))
+        rows = r.reshape(-1, D).shape[0]
+        gref = (dyl.reshape(-1, D) * ((xx[:, 1:] if drop else xx).reshape(-1, D).double() - torch.as_tensor(mean.cpu().double())[:, None]) * rstd.cpu().double()[:, None]).sum(0)
+        note("layernorm_bwd.dgamma", rel(dg, gref), 1e-4, (Fr, Nt, D, drop, rows))
+    # attention
+    Fa, Na, H = int(rng.integers(1, 4)), int(rng.choice([5, 17, 50, 197, 256, 257, 300])), int(rng.integers(1, 4))
+    qkv = torch.randn(Fa, Na, 3 * H * 64)
+    q, k, v = qkv.double().view(Fa, Na, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(Fa, Na, H * 64)
+    out, _, _ = ops.attention_fwd(dev(qkv), H)
+    note("attention_fwd", rel(out, ref), 3e-5, (Fa, Na, H))
+    # label propagation: random grid, window, contexts, prototypes
+    gl, Dl, Kl = int(rng.choice([5, 7, 14])), int(rng.choice([16, 32])), int(rng.choice([3, 20, 200, 300]))
+    fs, bs, nlast, rad, topk = int(rng.integers(2, 7)), int(rng.integers(1, 4)), int(rng.integers(1, 5)), int(rng.integers(1, 8)), int(rng.integers(1, 7))   # (n_last_frames = 0 crashes the reference itself, mask_propagation.py:489)
+    nl = gl * gl
+    feats = torch.randn(fs, bs, nl, Dl)
+    for t in range(1, fs): feats[t] = 0.7 * feats[t - 1] + 0.3 * feats[t]
+    xn = F.normalize(feats, dim=-1)
+    seg0 = torch.softmax(torch.randn(bs, nl, Kl) * 2, -1)
+    maps = ops.label_propagate_maps(dev(xn), dev(seg0), nlast, rad, topk, 0.1).cpu().numpy()
+    bad = tot = 0
+    for b_ in range(bs):
+        seed = seg0[b_].view(gl, gl, Kl).permute(2, 0, 1).unsqueeze(0)
+        refm = torch.stack(O.propagate_labels(nlast, rad, topk, gl, xn[:, b_], seed)).reshape(fs - 1, Kl, nl).transpose(1, 2).numpy()
+        d = np.abs(maps[:, b_] - refm).max(-1) > 1e-5 * np.abs(refm).max()
+        bad += d.sum(); tot += d.size
+    note("label_propagate_maps (fraction of queries off)", bad / tot, 0.03, (gl, Dl, Kl, fs, bs, nlast, rad, topk))
+    # patch embedding (lean gather instance for 16-pixel patches)
+    Dp, Hh, Ww = int(rng.choice([64, 128, 384])), 16 * int(rng.integers(1, 5)), 16 * int(rng.integers(1, 5))
+    nsrc = int(rng.integers(1, 5)); fmap = rng.integers(0, nsrc, int(rng.integers(1, 6))).astype(np.int32)
+    img, wp, bp, cls = torch.randn(nsrc, 3, Hh, Ww), torch.randn(Dp, 768) * 0.05, torch.randn(Dp), torch.randn(Dp)
+    npat = (Hh // 16) * (Ww // 16)
+    pos = torch.randn(1 + npat, Dp)
+    conv = F.conv2d(img[torch.as_tensor(fmap).long()].double(), wp.double().view(Dp, 3, 16, 16), bp.double(), stride=16)
+    ref = torch.cat([cls.double().expand(len(fmap), 1, Dp), conv.flatten(2).transpose(1, 2)], 1) + pos.double()
+    tok = ops.patch_embed_fwd(dev(img), dev(wp), dev(bp), dev(cls), dev(pos), 16, dev(fmap))
+    note("patch_embed_fwd", rel(tok, ref), 3e-5, (Dp, Hh, Ww, nsrc, len(fmap)))
+print("fuzz ok:", {k: f"{v:.2e}" for k, v in worst.items()})
