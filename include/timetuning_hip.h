@@ -34,7 +34,7 @@ extern "C" {
 typedef void* tt_stream_t;
 
 const char* tt_last_error(void);
-int tt_abi_version(void);
+int tt_abi_version(void);   /* 3 = this header (2: before the coarse entry points) */
 /* Fills name (<= cap bytes) with the gcnArchName of the current device; returns CU count or <0. */
 int tt_device_info(char* name, int cap);
 

@@ -24,7 +24,6 @@ from typing import Optional
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import hip_ops as ops
 

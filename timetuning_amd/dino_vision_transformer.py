@@ -8,7 +8,7 @@ launches HIP kernels through ``engine`` / ``hip_ops`` and raises if the library 
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List
 
 import torch
 import torch.nn as nn

@@ -9,7 +9,7 @@ pass (``tt_confusion_counts``) builds that matrix and the rest is exact integer 
 from __future__ import annotations
 
 from collections import defaultdict
-from typing import Dict, List, Tuple
+from typing import Dict, List
 
 import numpy as np
 import torch

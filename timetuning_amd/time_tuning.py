@@ -11,9 +11,8 @@ from __future__ import annotations
 
 import argparse
 import copy
-import math
 import os
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import numpy as np
 import torch
