@@ -82,4 +82,16 @@ for it in range(rounds):
     ref = torch.cat([cls.double().expand(len(fmap), 1, Dp), conv.flatten(2).transpose(1, 2)], 1) + pos.double()
     tok = ops.patch_embed_fwd(dev(img), dev(wp), dev(bp), dev(cls), dev(pos), 16, dev(fmap))
     note("patch_embed_fwd", rel(tok, ref), 3e-5, (Dp, Hh, Ww, nsrc, len(fmap)))
+    # bf16-plane Linear (P = 1, 3): ragged M, N and K multiples of 64, epilogue variants
+    P_ = int(rng.choice([1, 3])); Mp, Np, Kp = int(rng.integers(1, 600)), 64 * int(rng.integers(1, 6)), 64 * int(rng.integers(1, 5))
+    xs, wsn, bs_ = torch.randn(Mp, Kp), torch.randn(Np, Kp) * 0.1, torch.randn(Np)
+    xp, wpl = ops.split_planes(dev(xs), P_), ops.split_planes(dev(wsn), P_)
+    actp = int(rng.random() < 0.5)
+    resp = torch.randn(Mp, Np) if rng.random() < 0.5 else None
+    out = ops.linear_fwd_planes(xp, wpl, dev(bs_), residual=dev(resp) if resp is not None else None, act=actp)["y"]
+    xd_, wd_ = xp.double().sum(0).cpu() if P_ == 3 else xp[0].double().cpu(), wpl.double().sum(0).cpu() if P_ == 3 else wpl[0].double().cpu()
+    refp = F.linear(xd_, wd_, bs_.double())
+    if actp: refp = F.gelu(refp)
+    if resp is not None: refp = refp + resp.double()
+    note(f"linear_fwd_planes P={P_}", rel(out, refp), 3e-5, (P_, Mp, Np, Kp, actp))
 print("fuzz ok:", {k: f"{v:.2e}" for k, v in worst.items()})
