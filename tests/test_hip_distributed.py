@@ -163,7 +163,7 @@ def test_rccl_calls_execute_on_one_gpu():
     p.join(500)
     assert p.exitcode == 0, p.exitcode
     out = ret["out"]
-    assert out["calls"]["all_gather"] == 2 and out["calls"]["all_reduce"] == 6, out["calls"]   # per step: 1 gather + 3 buckets
+    assert out["calls"]["all_gather"] == 2 and out["calls"]["all_reduce"] == 8, out["calls"]   # per step: 1 gather + 4 buckets
 
     model = _model()
     opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, 1, 4), 4, 1)

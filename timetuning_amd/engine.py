@@ -117,9 +117,10 @@ def _bwd_data(dy: torch.Tensor, w: torch.Tensor, gelu_pre: Optional[torch.Tensor
 
 
 def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int, f1: int, grads: Dict[torch.nn.Parameter, torch.Tensor],
-                   need_dx: bool = True) -> Optional[torch.Tensor]:
+                   need_dx: bool = True, after_mlp=None) -> Optional[torch.Tensor]:
     """Backward of one block restricted to frames [f0, f1) of the saved activations.  dx_out [(f1-f0)*N, D]
-    is consumed (overwritten).  Writes parameter gradients into ``grads``."""
+    is consumed (overwritten).  Writes parameter gradients into ``grads``.  ``after_mlp()`` is called once the MLP's
+    gradients (two thirds of a block's parameters) exist - the data-parallel exchange sends them while the attention half runs."""
     Fr, N, D = sv["x_in"].shape
     r0, r1 = f0 * N, f1 * N
     a, pre, h2 = sv["a"][r0:r1], sv["pre"][r0:r1], sv["h2"][r0:r1]
@@ -130,6 +131,8 @@ def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int,
     d_h2 = _bwd_data(d_pre, blk.mlp.fc1.weight)
     dx_mid, grads[blk.norm2.weight], grads[blk.norm2.bias] = ops.layernorm_bwd(
         d_h2, sv["x_mid"][r0:r1], blk.norm2.weight, sv["mean2"][r0:r1], sv["rstd2"][r0:r1], dx_accum=dx_out)
+    if after_mlp is not None:
+        after_mlp()
     # x_mid = x_in + proj(attention(qkv(ln1(x_in))))
     att = sv["att"].view(Fr * N, D)[r0:r1]
     grads[blk.attn.proj.weight], grads[blk.attn.proj.bias] = _bwd_weight(dx_mid, att)
@@ -375,8 +378,9 @@ class GradExchange:
     and not yet sent into one buffer and starts an asynchronous all-reduce (SUM) on it - RCCL runs it on its own stream
     while the backward of the earlier blocks continues on the compute stream; ``finish(grads)`` sends the rest, waits for
     every bucket and returns the averaged gradients as views into the flat buffers.  Without an initialised process group
-    (or with one rank) both are no-ops.  At C2 sizes the three buckets are prototypes + head (2.2 M floats), final norm +
-    blocks.11 (1.8 M) and blocks.10 (1.8 M): only the last one is exposed."""
+    (or with one rank) both are no-ops.  At C2 sizes the four buckets are prototypes + head (2.2 M floats), final norm +
+    blocks.11 (1.8 M), the MLP half of blocks.10 (1.2 M, sent from inside that block's backward) and its attention half (0.6 M):
+    only the last one is exposed."""
 
     def __init__(self):
         self.dist = exchange_group()

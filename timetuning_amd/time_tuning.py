@@ -428,7 +428,10 @@ class TimeT(nn.Module):
             kept = save[first]["x_in"].shape[0]
             b0, b1 = (0, bs) if kept == bs else (f0, Fr)
             for i in range(len(vit.blocks) - 1, first - 1, -1):
-                dx = engine.block_backward(dx, vit.blocks[i], vit.num_heads, save[i], b0, b1, grads, need_dx=i > first)
+                # the LAST block of the backward has nothing after it to hide its bucket behind: its MLP gradients (two thirds of
+                # the block) leave as soon as they exist, so only the attention third is exposed
+                dx = engine.block_backward(dx, vit.blocks[i], vit.num_heads, save[i], b0, b1, grads, need_dx=i > first,
+                                           after_mlp=(lambda: exchange.push(grads)) if i == first else None)
                 if i > first:
                     exchange.push(grads)  # this block's gradients travel while the next block's backward runs
         grads = {p: g for p, g in grads.items() if p.requires_grad}
