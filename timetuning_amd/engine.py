@@ -398,14 +398,26 @@ class GradExchange:
         self.sent.update(keys)
         self.buckets.append((keys, flat, work))
 
-    def finish(self, grads: Dict[torch.nn.Parameter, torch.Tensor]) -> Dict[torch.nn.Parameter, torch.Tensor]:
+    def prescale_(self, root_grad: torch.Tensor) -> bool:
+        """Applies the 1 / world_size of the mean at the ROOT of the backward (the loss gradient, one small tensor) instead of to
+        every bucket after its all-reduce: every gradient is linear in it, so the summed buckets then ARE the means (bit for bit
+        when the world size is a power of two).  Returns True when applied; ``finish`` must then be told ``scale=False``."""
+        if self.dist is None or not root_grad.is_cuda:
+            return False
+        inv = torch.full((1,), 1.0 / self.dist.get_world_size(), dtype=f32, device=root_grad.device)
+        ops.scale_tensors_([root_grad], inv)
+        return True
+
+    def finish(self, grads: Dict[torch.nn.Parameter, torch.Tensor], scale: bool = True) -> Dict[torch.nn.Parameter, torch.Tensor]:
         if self.dist is None:
             return grads
         self.push(grads)
-        inv = torch.full((1,), 1.0 / self.dist.get_world_size(), dtype=f32, device=self.buckets[0][1].device) if self.buckets else None
+        inv = torch.full((1,), 1.0 / self.dist.get_world_size(), dtype=f32, device=self.buckets[0][1].device) if self.buckets and scale else None
         for keys, flat, work in self.buckets:
             work.wait()
-            if flat.is_cuda:
+            if not scale:
+                pass                                 # (already the mean: prescale_)
+            elif flat.is_cuda:
                 ops.scale_tensors_([flat], inv)      # SUM -> mean
             else:
                 flat *= inv                          # (CPU tensors: only the gloo tests of the collective logic)

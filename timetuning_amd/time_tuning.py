@@ -412,6 +412,7 @@ class TimeT(nn.Module):
         # ---- backward on the target frames only
         grads: Dict[nn.Parameter, torch.Tensor] = {}
         exchange = engine.GradExchange()  # the data-parallel exchange: bucketed all-reduce (mean) over RCCL, overlapped with backward
+        prescaled = exchange.prescale_(dscores)   # 1 / W once, on the 5 MB loss gradient, instead of on every bucket
         grads[self.prototypes], _ = ops.linear_bwd_weight(dscores, sv_sc["zn"], need_bias=False)
         dz = ops.l2norm_bwd(ops.linear_bwd_data(dscores, self.prototypes.data), sv_sc["zn"], sv_sc["inv"])
         if use_mask:
@@ -435,7 +436,7 @@ class TimeT(nn.Module):
                 if i > first:
                     exchange.push(grads)  # this block's gradients travel while the next block's backward runs
         grads = {p: g for p, g in grads.items() if p.requires_grad}
-        return loss, exchange.finish(grads)
+        return loss, exchange.finish(grads, scale=not prescaled)
 
 
 # ------------------------------------------------------------------------------------------------
