@@ -29,7 +29,15 @@
 //     the weights and the A row blocks live: qkv / fc1 -0.7 %, fc2 +1.0 %, proj +5.6 % (interleaved A/B) - nothing, and in the
 //     step the next kernel WANTS the output in the caches;
 //   * (round 2) the compiler's other scheduling strategies (-mllvm -amdgpu-sched-strategy=max-ilp / max-memory-clause /
-//     iterative-ilp, -amdgpu-schedule-metric-bias=100): all four block shapes within 1 % of the default.
+//     iterative-ilp, -amdgpu-schedule-metric-bias=100): all four block shapes within 1 % of the default;
+//   * (round 2) a PERSISTENT form: 256 x occupancy workgroups that walk tiles handed out dynamically (per-XCD atomic counters, so
+//     that the tile quantisation of a static round-robin does not eat the gain and the tiles sharing an A row block stay on one
+//     L2) and load the first slab of their next tile into registers during the last slab of the current one, so that the epilogue
+//     overlaps that latency (the structure tools/mfma_peak.hip measures at 123-125 against 116-119 TFLOP/s for one workgroup per
+//     tile): correct on the full matrices, and 7 % SLOWER on the shapes it applies to (qkv 199 -> 214 us, fc1 279 -> 298 us; with the
+//     atomic's round trip hidden under the first slabs as well).  68 VGPRs + the accumulators allow 4 resident workgroups per CU
+//     against 6, and with 5-6 short-lived workgroups per CU the hardware's own dispatch already overlaps one workgroup's prologue
+//     and epilogue with the others' main loops.
 #include "common.hpp"
 #include <cstdlib>
 
