@@ -20,7 +20,8 @@ def _build(g, teacher=False, queue=0):
     D, depth, heads, patch = [int(v) for v in g["vit_cfg"]]
     cfg = dict(embed_dim=D, depth=depth, num_heads=heads, patch_size=patch)
     bs, fs, K, _, _, steps, E, I = [int(v) for v in g["cfg"]]
-    fe = FeatureExtractor("dino-s16", "", [int(v) for v in g["head_list"]], unfreeze_layers=["blocks.11", "blocks.10"],
+    arch = str(g["arch"]) if "arch" in g.files else "dino-s16"
+    fe = FeatureExtractor(arch, "", [int(v) for v in g["head_list"]], unfreeze_layers=["blocks.11", "blocks.10"],
                           vit_cfg=cfg, init=str(g["mode"]))
     model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, fe.feature_dim))).cuda()
     opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, E, I), I, E)
@@ -146,6 +147,25 @@ def _run_steps(g, teacher, queue):
 
 def test_training_steps_tiny(golden, accurate_precision):
     _run_steps(golden("timet_tiny"), False, 0)
+
+
+def test_training_steps_tiny_six_frames(golden):
+    """Six-frame clips against the reference's own run: up to five context frames per target in the label propagation (the
+    similarities of all 15 (target, context) pairs in 6 batched launches, the 8-context instance of the wave-per-query kernel)."""
+    _run_steps(golden("timet_tiny_f6"), False, 0)
+
+
+def test_training_steps_tiny_patch8(golden):
+    """Patch size 8 (BASELINE C5's shape: 785 tokens - the KV-tiled attention, the general patch-embedding kernel, the 28 x 28
+    propagation grid) against the REFERENCE's own run on a narrow ViT (head dim 64): extractor outputs, then loss, gradients
+    and parameters over two optimizer steps."""
+    g = golden("timet_tiny_s8")
+    model, _ = _build(g)
+    bs, fs = int(g["cfg"][0]), int(g["cfg"][1])
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1)).view(bs * fs, 3, 224, 224).cuda()
+    f, attn = model.feature_extractor(x)
+    assert f.shape[1] == 784 and rel_err(f.cpu(), g["features"]) < 1e-4 and rel_err(attn[:, :, 0, :].cpu(), g["attn_cls_row"]) < 1e-4
+    _run_steps(g, False, 0)
 
 
 def test_training_steps_tiny_teacher_queue(golden, accurate_precision):

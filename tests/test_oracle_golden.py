@@ -68,7 +68,8 @@ def _build_from_fixture(g, teacher=False, queue=0):
     D, depth, heads, patch = [int(v) for v in g["vit_cfg"]]
     cfg = dict(embed_dim=D, depth=depth, num_heads=heads, patch_size=patch)
     K = int(g["cfg"][2])
-    m = O.build_oracle("dino-s16", K, tuple(int(v) for v in g["head_list"]), mode=str(g["mode"]), vit_cfg=cfg)
+    arch = str(g["arch"]) if "arch" in g.files else "dino-s16"
+    m = O.build_oracle(arch, K, tuple(int(v) for v in g["head_list"]), mode=str(g["mode"]), vit_cfg=cfg)
     if teacher:
         m.init_momentum_teacher()
     if queue:
@@ -174,6 +175,26 @@ def _run_steps(g, teacher, queue):
 
 def test_training_steps_tiny(golden):
     _run_steps(golden("timet_tiny"), False, 0)
+
+
+def test_training_steps_tiny_six_frames(golden):
+    """Six-frame clips: the label propagation runs with up to five context frames per target (frame 0 + the queue of previous
+    frames, mask_propagation.py:480-487); the reference's own run."""
+    _run_steps(golden("timet_tiny_f6"), False, 0)
+
+
+def test_training_steps_tiny_patch8(golden):
+    """Patch size 8 (BASELINE C5's shape: 28 x 28 token grid, 785 tokens) against the reference's own run on a narrow ViT:
+    extractor outputs, loss, gradients and parameters of two optimizer steps."""
+    g = golden("timet_tiny_s8")
+    m = _build_from_fixture(g)
+    assert m.feature_extractor.spatial_resolution == 28
+    bs, fs = int(g["cfg"][0]), int(g["cfg"][1])
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1)).view(bs * fs, 3, 224, 224)
+    with torch.no_grad():
+        f, attn = m.feature_extractor(x)
+    assert f.shape[1] == 784 and rel_err(f.numpy(), g["features"]) < 1e-5 and rel_err(attn[:, :, 0, :].numpy(), g["attn_cls_row"]) < 1e-5
+    _run_steps(g, False, 0)
 
 
 def test_training_steps_tiny_teacher_queue(golden):
