@@ -678,6 +678,8 @@ def main():
         "aux_tiny": lambda: gen_aux(ref, "tiny", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "stress"),
         "timet_tiny": lambda: gen_timet(ref, "tiny", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "stress", False, 0, 3, True),
         "timet_tiny_tq": lambda: gen_timet(ref, "tiny_tq", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 2, "stress", True, 40, 3, True),
+        # 300 prototypes (BASELINE config C4 has 400): the K > 256 instances of the propagation / Sinkhorn / cross-entropy kernels
+        "timet_tiny_k300": lambda: gen_timet(ref, "tiny_k300", "dino-s16", tiny, 300, (128, 128, 64, 32), 2, 3, "stress", False, 0, 2, True),
         # six-frame clips (BASELINE config C4 has eight): up to five context frames per target in the label propagation
         "timet_tiny_f6": lambda: gen_timet(ref, "tiny_f6", "dino-s16", tiny, 20, (128, 128, 64, 32), 1, 6, "stress", False, 0, 2, True),
         # patch size 8 (BASELINE config C5's shape: 28 x 28 token grid, 785 tokens, the KV-tiled attention and the general patch-embed

@@ -149,6 +149,12 @@ def test_training_steps_tiny(golden, accurate_precision):
     _run_steps(golden("timet_tiny"), False, 0)
 
 
+def test_training_steps_tiny_300_prototypes(golden):
+    """K = 300 prototypes against the reference's own run: the K > 256 instances of the label-propagation, Sinkhorn and
+    cross-entropy kernels (BASELINE C4 has 400) and a score GEMM whose width is not a multiple of 64."""
+    _run_steps(golden("timet_tiny_k300"), False, 0)
+
+
 def test_training_steps_tiny_six_frames(golden):
     """Six-frame clips against the reference's own run: up to five context frames per target in the label propagation (the
     similarities of all 15 (target, context) pairs in 6 batched launches, the 8-context instance of the wave-per-query kernel)."""

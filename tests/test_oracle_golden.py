@@ -177,6 +177,11 @@ def test_training_steps_tiny(golden):
     _run_steps(golden("timet_tiny"), False, 0)
 
 
+def test_training_steps_tiny_300_prototypes(golden):
+    """K = 300 prototypes (more than 256: BASELINE C4 has 400); the reference's own run."""
+    _run_steps(golden("timet_tiny_k300"), False, 0)
+
+
 def test_training_steps_tiny_six_frames(golden):
     """Six-frame clips: the label propagation runs with up to five context frames per target (frame 0 + the queue of previous
     frames, mask_propagation.py:480-487); the reference's own run."""
