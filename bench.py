@@ -80,13 +80,18 @@ def instrumented_step(model, opt, x, use_teacher):
     """One more identical step with every GEMM launch bracketed by HIP events on the launch stream."""
     from timetuning_amd import hip_ops
 
+    from timetuning_amd import engine
+
     rec = []
     hip_ops.PROFILE = rec
+    engine.RCCL_PROFILE = []
     try:
         train_step(model, opt, x, use_teacher)
         torch.cuda.synchronize()
     finally:
         hip_ops.PROFILE = None
+        waits, engine.RCCL_PROFILE = engine.RCCL_PROFILE, None
+    instrumented_step.rccl = [{"collective": k, "bytes": n, "exposed_wait_ms": round(e0.elapsed_time(e1), 4)} for k, n, e0, e1 in waits]
     by = {}
     for name, tile, flops, e0, e1 in rec:
         d = by.setdefault((name, tile), [0, 0.0, 0.0])
@@ -109,6 +114,45 @@ def by_label(prof, step_seconds):
             for k, (c_, f_, s_) in sorted(acc.items(), key=lambda kv: -kv[1][2])}
 
 
+def rccl_report(dist, waits):
+    """What carried the exchange and what it cost the compute stream in the instrumented step: per collective its payload and the
+    time the compute stream sat in ``work.wait()`` (HIP events around the wait: 0 when RCCL had finished under the backward)."""
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "collectives_per_step": len(waits),
+            "bytes": sum(w["bytes"] for w in waits), "exposed_wait_ms": round(sum(w["exposed_wait_ms"] for w in waits), 4), "waits": waits}
+
+
+def single_rank_exchange_probe(model, opt, x, use_teacher, device):
+    """Untimed, after the measurement, 1-GPU runs only: joins a ONE-rank ``nccl`` process group and runs the step with
+    TT_EXCHANGE_SINGLE_RANK=1, i.e. with the very RCCL calls of an N-GPU run (1 asynchronous all-gather of the score rows + the
+    gradient buckets' asynchronous all-reduces, engine.exchange_group) on a one-rank communicator - RCCL refuses two ranks on one
+    device, so this is how a 1-GPU box exercises the exchange and the ``rccl`` fields an 8-GPU line will carry."""
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ["TT_EXCHANGE_SINGLE_RANK"] = "1"
+    try:
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=1, rank=0, device_id=device)
+        for _ in range(2):
+            train_step(model, opt, x, use_teacher)
+        torch.cuda.synchronize()
+        instrumented_step(model, opt, x, use_teacher)
+        out = rccl_report(dist, instrumented_step.rccl)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            train_step(model, opt, x, use_teacher)
+        torch.cuda.synchronize()
+        out["ms_per_step_with_exchange"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+        out["note"] = "one-rank communicator on one GPU (TT_EXCHANGE_SINGLE_RANK=1): same calls, no peer; not part of `value`"
+        return out
+    except Exception as e:  # a box whose RCCL cannot initialise must not cost the bench line
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        os.environ.pop("TT_EXCHANGE_SINGLE_RANK", None)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
 def sinkhorn_rate(device, B=6272, K=200, iters=10, reps=30):
     from timetuning_amd import hip_ops, synth
 
@@ -124,8 +168,9 @@ def sinkhorn_rate(device, B=6272, K=200, iters=10, reps=30):
     e1.record()
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3 / reps
-    algo_bytes = 4.0 * K * B * (2 * iters + 2)
-    return iters / sec, algo_bytes / sec / 1e9
+    algo_bytes = 4.0 * K * B * (2 * iters + 2)  # two sweeps of Q per iteration
+    swept_bytes = 4.0 * K * B * (iters + 3)     # what tt_sinkhorn moves: scaling-vector form, ONE sweep per iteration (13 for 10 iterations)
+    return iters / sec, algo_bytes / sec / 1e9, swept_bytes / sec / 1e9
 
 
 def cpu_baseline(fs, K, budget_s=30.0, arch="dino-s16", precision="f32"):
@@ -138,9 +183,10 @@ def cpu_baseline(fs, K, budget_s=30.0, arch="dino-s16", precision="f32"):
     # torch-CPU stops scaling at 16 threads on these op sizes and then collapses (tools/cpu_threads_sweep.py on the 256-core
     # box, profiles/r02_cpu_threads_sweep.txt: 14.3 / 17.4 / 10.7 / 4.3 / 1.7 / 0.04 clip-frames/s at 8 / 16 / 32 / 64 / 128 / 256
     # threads): the baseline runs at its best setting
-    cores = min(os.cpu_count() or 1, 16)
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 16)
     torch.set_num_threads(cores)
-    bs = 2
+    bs = 8   # clips per CPU step (round 2 ran 2: too little parallel work per op for a fair host number)
     om = O.build_oracle(arch, K, (1024, 1024, 512, 256), mode="dino")
     opt = O.SwavOptimizerOracle(om, 1e-5, 1e-4, O.cosine_scheduler(0.04, 0.4, 1, 128), 128, 1)
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1))
@@ -171,7 +217,7 @@ def cpu_baseline(fs, K, budget_s=30.0, arch="dino-s16", precision="f32"):
             O.sinkhorn(sk_in.clone(), 10)
         sk_cpu = 30.0 / (time.perf_counter() - t0)
     n, t_total = 0, 0.0
-    while n == 0 or (t_total < 0.5 * budget_s and n < 64):  # >= ~15 s of CPU work, at least one step
+    while n == 0 or (t_total < 0.5 * budget_s and n < 64):  # ~15-25 s of CPU work, at least one step
         t0 = time.perf_counter()
         loss = om.get_loss(x, faithful=True, mask_features=USE_MASK)
         opt.zero_grad()
@@ -180,7 +226,9 @@ def cpu_baseline(fs, K, budget_s=30.0, arch="dino-s16", precision="f32"):
         om.normalize_prototypes()
         t_total += time.perf_counter() - t0
         n += 1
-    return {"value": round(bs * fs * n / t_total, 4), "unit": "clip-frames/sec", "cores": cores, "kind": "port",
+    return {"value": round(bs * fs * n / t_total, 4), "unit": "clip-frames/sec", "cores": cores, "threads": cores, "host_cores": host_cores, "kind": "port",
+            "threads_note": "torch-CPU peaks at 16 threads on these op sizes and collapses beyond (profiles/r02_cpu_threads_sweep.txt); "
+                            "a weak baseline by construction - it is reported, never the target",
             "sample": f"{n} training step(s) of {bs} clips x {fs} frames of {arch} (per-clip work identical to the timed batch), torch-CPU fp32, "
                       "reference-faithful structure (4 ViT passes per frame, per-sample host label propagation)",
             "seconds_per_step": round(t_total / n, 3), "sinkhorn_iters_per_sec": round(sk_cpu, 1), "parity_vs_gpu": parity}
@@ -278,6 +326,7 @@ def main():
                     help="arithmetic of the forward Linears for the TIMED region (default f32 = the headline / parity mode; "
                          "hip_ops.set_gemm_precision documents the others)")
     ap.add_argument("--no_alt_precision", action="store_true", help="skip the secondary bf16x3 / bf16 measurements")
+    ap.add_argument("--no_exchange_probe", action="store_true", help="skip the one-rank RCCL probe of the exchange path (1-GPU runs)")
     a = ap.parse_args()
     global USE_MASK
     USE_MASK = a.use_mask
@@ -318,7 +367,7 @@ def main():
 
     bs, fs, K = a.batch_size, a.num_frames, a.num_clusters
     model = build_model(a.architecture, K, device, world=world)
-    total_steps = a.steps + a.warmup + 20
+    total_steps = a.steps + a.warmup + 40
     opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, 1, total_steps), total_steps, 1)
     if a.use_teacher:
         model.init_momentum_teacher()
@@ -326,7 +375,6 @@ def main():
     if a.use_queue:
         model.init_queue(a.queue_size // world)
         model.queue.copy_(torch.nn.functional.normalize(torch.randn_like(model.queue), dim=1))
-        model._queue_rows_pushed = model.queue.shape[0]
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1 + rank)).to(device)  # resident in HBM before timing
 
     from timetuning_amd import hip_ops
@@ -389,31 +437,38 @@ def main():
                 "NTbf16": BF16_MATRIX_PEAK_TFLOPS / (3 if a.precision == "bf16x3" else 1)}.get(dom_name, F32_MATRIX_PEAK_TFLOPS)
         # HBM bytes per launch of the dominant kernel from the committed PMC pass (tools/pmc_traffic.py) - only when that pass
         # measured THIS kernel
-        traffic = None
+        traffic = traffic_git_head = None
         tpath = os.path.join(REPO, "profiles", "dominant_kernel_traffic.json")
         if os.path.isfile(tpath):
             tj = json.load(open(tpath))
             if tj.get("kernel_label", "gemm_nt_fast_kernel<64x128>") in kernel_label(dom_name, dom_tile):
                 traffic = tj.get("hbm_bytes_per_launch")
-        sk_rate, sk_gbs = sinkhorn_rate(device) if world == 1 else (None, None)
+                traffic_git_head = tj.get("git_head")
+        sk_rate, sk_gbs, sk_swept = sinkhorn_rate(device) if world == 1 else (None, None, None)
+        workload = ("C2: " if (a.architecture, bs, fs, K, a.use_teacher, a.use_queue) == ("dino-s16", 32, 4, 200, False, False) else
+                    "C3 (per-GPU share): " if (a.architecture, bs, fs, K, a.use_teacher, a.use_queue) == ("dino-s16", 32, 4, 200, True, True) else
+                    "C4 (per-GPU share): " if (a.architecture, bs, fs, K) == ("dino-b16", 16, 8, 400) else
+                    "C5 (per-GPU share): " if (a.architecture, bs, fs, K) == ("dino-s8", 16, 4, 200) else "")
         out = {
             "metric": "clip-frames/sec", "value": round(world * bs * fs * a.steps / elapsed, 2), "unit": "clip-frames/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": ("C2: " if (a.architecture, bs, fs, K) == ("dino-s16", 32, 4, 200) else
-                                    "C4 (per-GPU share): " if (a.architecture, bs, fs, K) == ("dino-b16", 16, 8, 400) else "") +
-                                   f"{a.architecture} full TimeT training step (fwd+bwd+AdamW), {fs}-frame 224x224 clips, {bs} clips/GPU, "
+            "config": {"workload": workload + f"{a.architecture} full TimeT training step (fwd+bwd+AdamW), {fs}-frame 224x224 clips, {bs} clips/GPU, "
                                    f"{K} prototypes" + (", EMA teacher" if a.use_teacher else "") + (f", queue {a.queue_size // world} rows/rank" if a.use_queue else "") +
                                    (", use_mask" if a.use_mask else ""),
                        "clips_per_gpu": bs, "num_frames": fs, "num_clusters": K,
                        "global_batch": bs * world, "parallelism": f"dp{world}"},
             "loss": round(final_loss, 5),
             # proof of what carried the exchange: RCCL ("nccl") saw this many ranks (None for the single-process run)
-            "rccl": {"world_size": dist.get_world_size(), "backend": dist.get_backend()} if world > 1 else None,
+            # with the compute stream's exposed wait per collective in the instrumented step
+            "rccl": rccl_report(dist, instrumented_step.rccl) if world > 1 else None,
             "roofline": {"bound": "mfma", "precision": a.precision,
                          "kernel": kernel_label(dom_name, dom_tile), "launches_per_step": cnt,
                          "achieved": round(flops / sec / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(flops / sec / 1e12 / peak, 4), "traffic": traffic,
+                         # NOT a counter of this run: HBM bytes per launch of this kernel from the committed PMC passes
+                         "traffic_source": None if traffic is None else "profiles/dominant_kernel_traffic.json (rocprofv3 --pmc, separate passes)",
+                         "traffic_git_head": traffic_git_head,
                          "avg_launch_us": round(sec / cnt * 1e6, 2),
                          "all_gemm_tflops": round(all_flops / all_sec / 1e12, 2),
                          "gemm_share_of_step": round(all_sec / (elapsed / a.steps), 3),
@@ -422,12 +477,19 @@ def main():
                          "by_kernel": by_label(prof, elapsed / a.steps)},
             "alt_precision": alt or None,
             "sinkhorn": None if sk_rate is None else {"iters_per_sec": round(sk_rate, 1), "algorithmic_GBps": round(sk_gbs, 1),
+                                                      "swept_GBps": round(sk_swept, 1),
+                                                      "note": "algorithmic = SURVEY 8(d)'s 4 K B (2 iters + 2) bytes; swept = the 13 sweeps the "
+                                                              "scaling-vector kernel really makes (iters + 3); the 5 MB matrix is cache-resident",
                                                       "shape": "K=200 x B=6272, 10 iterations"},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fs, K, arch=a.architecture, precision=a.precision)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not a.no_exchange_probe:
+            hip_ops.set_gemm_precision(a.precision)
+            out["rccl_single_rank_probe"] = single_rank_exchange_probe(model, opt, x, a.use_teacher, device)
+            hip_ops.set_gemm_precision("f32")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -212,6 +212,30 @@ def gen_sinkhorn_dist(ref):
     print("sinkhorn_w2.npz", q.shape)
 
 
+def gen_sinkhorn_w8(ref):
+    """8 gloo ranks of the reference's distributed Sinkhorn (my_utils.py:250-272) at C3's shape; every 52nd row of each rank's q is
+    kept (160 rows x 8 ranks), the scores are regenerated by ``synth.make_sinkhorn_w8_scores``."""
+    import torch.multiprocessing as mp
+
+    K, Bl, iters, W, stride = 200, 8320, 10, 8, 52
+    from timetuning_amd import synth
+
+    scores = synth.make_sinkhorn_w8_scores()
+    assert scores.shape == (W * Bl, K) and np.all(scores * 1024 == np.rint(scores * 1024))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    procs = [mp.get_context("spawn").Process(target=_sk_worker, args=(r, W, 29617, scores, iters, ret)) for r in range(W)]
+    [p_.start() for p_ in procs]
+    [p_.join() for p_ in procs]
+    q = np.stack([ret[r][::stride] for r in range(W)])        # [W, 160, K]
+    rowsum = np.stack([ret[r].sum(1) for r in range(W)])      # [W, Bl]: every row of q sums to 1
+    colsum = np.sum([ret[r].astype(np.float64).sum(0) for r in range(W)], axis=0)   # [K]: prototype usage over the global batch
+    np.savez_compressed(os.path.join(OUT, "sinkhorn_w8.npz"), q=q, stride=np.int64(stride), iters=np.int64(iters), world_size=np.int64(W),
+                        rows_per_rank=np.int64(Bl), rowsum_min=np.float64(rowsum.min()), rowsum_max=np.float64(rowsum.max()), colsum=colsum,
+                        scores_checksum=np.float64(scores.astype(np.float64).sum()))
+    print("sinkhorn_w8.npz", q.shape)
+
+
 def gen_label_prop(ref):
     import torch
 
@@ -674,6 +698,7 @@ def main():
         "scaler": lambda: gen_scaler(ref),
         "sinkhorn": lambda: gen_sinkhorn(ref),
         "sinkhorn_w2": lambda: gen_sinkhorn_dist(ref),
+        "sinkhorn_w8": lambda: gen_sinkhorn_w8(ref),
         "label_prop": lambda: gen_label_prop(ref),
         "aux_tiny": lambda: gen_aux(ref, "tiny", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "stress"),
         "timet_tiny": lambda: gen_timet(ref, "tiny", "dino-s16", tiny, 20, (128, 128, 64, 32), 2, 3, "stress", False, 0, 3, True),

@@ -118,6 +118,8 @@ def test_full_size_parameter_counts():
 
 
 def test_queue_fullness_is_tracked_on_the_host():
+    """Own pushes are counted on the host; a write from outside (copy_, set_queue) is detected by the storage / version signature and
+    answered by the reference's own check of the last row (time_tuning.py:207)."""
     from timetuning_amd.models import FeatureExtractor
     from timetuning_amd.time_tuning import TimeT
 
@@ -126,10 +128,40 @@ def test_queue_fullness_is_tracked_on_the_host():
     assert not m.queue_is_full()
     m.init_queue(40)
     assert m.queue.shape == (40, 32) and not m.queue_is_full()
-    m._queue_rows_pushed = 20
+    m._queue_pushed(20)
     assert not m.queue_is_full()
-    m._queue_rows_pushed = 40
+    m._queue_pushed(20)
     assert m.queue_is_full()
+    # a drop-in caller fills the tensor itself, as the reference's callers may
+    m.init_queue(40)
+    m.queue[:10].fill_(1.0)
+    assert not m.queue_is_full()          # last row still zero
+    m.queue.copy_(torch.ones(40, 32))
+    assert m.queue_is_full()
+    m.queue.zero_()
+    assert not m.queue_is_full()
+    m.set_queue(torch.ones(40, 32))
+    assert m.queue_is_full()
+    m.set_queue(torch.ones(24, 32))       # a different size re-allocates
+    assert m.queue.shape == (24, 32) and m.queue_is_full()
+    m.queue = torch.zeros(24, 32)         # a replaced tensor
+    assert not m.queue_is_full()
+
+
+def test_partial_unfreeze_follows_the_reference_substring_match():
+    """models.py:929-935 accepts any substring; parts of a block train with the whole block on the backward path, tensors below the
+    first block raise at construction."""
+    from timetuning_amd.models import FeatureExtractor
+
+    cfg = synth.ARCHS["tiny-s16"]
+    fe = FeatureExtractor("dino-s16", "", [128, 128, 64, 32], unfreeze_layers=["blocks.11.attn", "blocks.9.mlp.fc2.weight"], vit_cfg=cfg)
+    names = {n for n, p in fe.backbone.named_parameters() if p.requires_grad}
+    assert names == {"blocks.11.attn.qkv.weight", "blocks.11.attn.qkv.bias", "blocks.11.attn.proj.weight", "blocks.11.attn.proj.bias",
+                     "blocks.9.mlp.fc2.weight"}
+    assert fe.trainable_block_ids() == [9, 11]
+    for bad in (["patch_embed"], ["pos_embed"], ["cls_token"], ["blocks.11", "embed"]):
+        with pytest.raises(NotImplementedError):
+            FeatureExtractor("dino-s16", "", [128, 128, 64, 32], unfreeze_layers=bad, vit_cfg=cfg)
 
 
 def test_unknown_architecture_raises_clearly():

@@ -181,6 +181,24 @@ def test_sinkhorn_golden(ops, golden):
     assert rel_err(q.cpu(), g2["q"][196:]) < 5e-5
 
 
+@pytest.mark.parametrize("rank", [0, 3, 7])
+def test_sinkhorn_c3_global_problem_vs_reference(ops, golden, rank):
+    """BASELINE C3's gathered problem on one GPU: K = 200 x 8 ranks x 8320 rows (6272 patches + 2048 queue rows each), solved once over
+    the gathered scores; rank r keeps its own first 6272 rows (time_tuning.py:213-215).  Fixture: the reference's my_utils.sinkhorn under
+    8 gloo ranks (my_utils.py:250-272), every 52nd row of each rank's q."""
+    from timetuning_amd import synth
+
+    g = golden("sinkhorn_w8")
+    W, Bl, stride = int(g["world_size"]), int(g["rows_per_rank"]), int(g["stride"])
+    gathered = dev(synth.make_sinkhorn_w8_scores())
+    assert gathered.shape == (W * Bl, 200)
+    q = ops.sinkhorn(gathered, int(g["iters"]), row0=rank * Bl, rows_out=6272).cpu()
+    assert q.shape == (6272, 200)
+    keep = torch.arange(0, 6272, stride)
+    assert rel_err(q[keep], g["q"][rank][: len(keep)]) < 5e-5
+    assert rel_err(q.sum(1), torch.ones(6272)) < 1e-5
+
+
 def test_sinkhorn_c2_size_vs_oracle(ops):
     """BASELINE C2: K=200, B=6272 (+ queue rows variant), checked against the oracle and by invariants."""
     for B in (6272, 6272 + 2048):

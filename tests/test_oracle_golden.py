@@ -45,6 +45,21 @@ def test_sinkhorn_world2_equals_concat(golden):
     assert rel_err(q.numpy(), g["q"]) < 2e-6
 
 
+def test_sinkhorn_world8_c3_shape(golden):
+    """SURVEY 8(c)'s third Sinkhorn case (K, B_loc, iters, W) = (200, 8320, 10, 8) - BASELINE C3's global problem - from an 8-rank
+    gloo run of the reference's my_utils.sinkhorn (my_utils.py:250-272): the single solve over the concatenated columns equals it."""
+    from timetuning_amd import synth
+
+    g = golden("sinkhorn_w8")
+    scores = synth.make_sinkhorn_w8_scores()
+    assert float(scores.astype(np.float64).sum()) == float(g["scores_checksum"])          # the regenerated input is the generator's, bit for bit
+    W, Bl, stride = int(g["world_size"]), int(g["rows_per_rank"]), int(g["stride"])
+    q = O.sinkhorn(torch.exp(torch.from_numpy(scores) / 0.05).t(), int(g["iters"])).view(W, Bl, -1)
+    assert rel_err(q[:, ::stride].numpy(), g["q"]) < 5e-6
+    np.testing.assert_allclose(q.double().sum((0, 1)).numpy(), g["colsum"], rtol=1e-5)
+    assert abs(float(g["rowsum_min"]) - 1) < 1e-5 and abs(float(g["rowsum_max"]) - 1) < 1e-5
+
+
 def test_window_mask_counts(golden):
     g = golden("label_prop")
     assert int(O.restrict_neighborhood(14, 14, 6).sum()) == int(g["mask_nnz_g14_r6"]) == 19600

@@ -125,9 +125,11 @@ class HipLibraryError(RuntimeError):
     pass
 
 
-def build(verbose: bool = False) -> str:
-    """Compile csrc/*.hip for gfx950 into timetuning_amd/libtimetuning_hip.so (hipcc cross-compiles without a GPU)."""
-    proc = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+def build(verbose: bool = False, force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into timetuning_amd/libtimetuning_hip.so (hipcc cross-compiles without a GPU).
+    ``force`` recompiles every source (``make -B``): what ``__graft_entry__.build()`` uses, so that object files left in the
+    working tree cannot stand in for a source that no longer compiles."""
+    proc = subprocess.run(["make", "-C", CSRC, "-j8"] + (["-B"] if force else []), capture_output=True, text=True)
     if verbose or proc.returncode != 0:
         print(proc.stdout[-4000:])
         print(proc.stderr[-4000:])

@@ -83,6 +83,15 @@ __device__ __forceinline__ float gelu_grad_fast_f(float x) {
   return cdf + x * 0.39894228040143267794f * g;
 }
 
+// GELU of the bf16-only path (gemm_planes8.hip, P = 1: the result is rounded to bf16, 2^-9 relative): x * sigmoid(2 u) with
+// u = sqrt(2/pi) (x + 0.044715 x^3) - the tanh form of GELU, |error| <= 5e-4 absolute, one v_exp and one v_rcp instead of the
+// erf ladder (a 128 x 64 wave tile pays 128 of these per lane in the epilogue: 36 instead of 90 issue cycles each).
+__device__ __forceinline__ float gelu_bf16_f(float x) {
+  const float x2 = x * x;
+  const float u2 = x * fmaf(x2, -0.1029432f, -2.3022082f);           // -2 u log2(e)
+  return x * __frcp_rn(1.0f + __builtin_amdgcn_exp2f(u2));
+}
+
 // XCD-aware bijective remap of a linear workgroup id (guide T1): the dispatcher deals consecutive
 // ids round-robin over the 8 XCDs; this hands each XCD a contiguous run of logical tiles so that
 // neighbouring tiles (which share an operand panel) hit the same 4 MiB L2.

@@ -387,6 +387,9 @@ __global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __re
 }
 
 int launch_splitk_reduce(const float* partial, float* out, long long n, int splits, long long stride, hipStream_t s);  // gemm_f32.hip
+int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes, const float* bias,
+                const float* residual, float* y, void* y_planes, long long y_plane_stride, int y_nplanes, int M, int N, int K, int act,
+                hipStream_t s);                                                                                       // gemm_planes8.hip
 
 }  // namespace tt
 
@@ -480,12 +483,18 @@ static int linear_planes_impl(const void* x_planes, long long x_plane_stride, co
   PlaneArgs g{static_cast<const __bf16*>(x_planes), static_cast<const __bf16*>(w_planes), x_plane_stride, w_plane_stride, M, N, K, bias, residual, y,
               pre_out, static_cast<__bf16*>(y_planes), y_plane_stride, y_nplanes, act, gelu_pre, splits, split_stride};
   hipStream_t s = as_stream(stream);
+  const int variant = [] { const char* e = getenv("TT_PLANES_VARIANT"); return e ? atoi(e) : 0; }();  // tuning aid (read per call: A/B in one process)
+  // whole-tile forward products on a grid that fills the chip: the persistent 8-phase kernel (gemm_planes8.hip)
+  if (variant == 0 && !pre_out && !gelu_pre && splits == 1) {
+    const int rc = planes8_try(x_planes, x_plane_stride, w_planes, w_plane_stride, planes, bias, residual, y, y_planes, y_plane_stride, y_nplanes, M, N,
+                               K, act, s);
+    if (rc <= 0) return rc;
+  }
   // tile: 128 x 128 when the grid still fills the chip more than twice over, else 64-row / 64-column tiles (ViT-S/16's N = 384
   // products: 1182 instead of 591 workgroups)
   const long long t128 = (long long)((M + 127) / 128) * (N / 128);
   const bool big = (N % 128 == 0) && t128 * splits >= 3 * 256;
   const bool wide = (N % 128 == 0) && (long long)((M + 63) / 64) * (N / 128) * splits >= 2 * 256;
-  static const int variant = [] { const char* e = getenv("TT_PLANES_VARIANT"); return e ? atoi(e) : 0; }();  // tuning aid
   switch (planes) {
     case 1:
       if (big) {

@@ -34,7 +34,9 @@ def weight_planes(w: torch.nn.Parameter, planes: int) -> torch.Tensor:
     """[planes, N, K] bf16 planes of a Linear weight.  Tensors marked static (``_tt_static``: the student's frozen parameters,
     FeatureExtractor.freeze_backbone) are split once and cached against (storage, version, planes); anything that training or the
     EMA rewrites through raw pointers is split again on every call (a few MB per step)."""
-    if not getattr(w, "_tt_static", False):
+    # staticness is re-derived at use time: a tensor unfrozen after freeze_backbone (a fine-tuning schedule) is updated by the
+    # optimizer through raw pointers, whatever its stale flag says
+    if w.requires_grad or not getattr(w, "_tt_static", False):
         return ops.split_planes(w.detach(), planes)
     # the cache lives ON the parameter object (not in a table keyed by id(): a recycled id + recycled storage of a dead model's
     # parameter would otherwise hit), so it dies with it
@@ -333,6 +335,23 @@ def exchange_group():
     return None
 
 
+# Instrumented runs only (bench.py): a list that receives (kind, payload bytes, event before, event after) for every wait of the
+# compute stream on a collective - the time between the two events is what the exchange EXPOSES (the stream had nothing else to do).
+RCCL_PROFILE = None
+
+
+def wait_collective(work, kind: str, nbytes: int, device) -> None:
+    """``work.wait()`` (the compute stream waits for the collective's stream), bracketed by HIP events when ``RCCL_PROFILE`` is set."""
+    if RCCL_PROFILE is None or not (isinstance(device, torch.device) and device.type == "cuda"):
+        work.wait()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    work.wait()
+    e1.record()
+    RCCL_PROFILE.append((kind, int(nbytes), e0, e1))
+
+
 def global_sinkhorn_begin(scores_local: torch.Tensor):
     """Starts the all-gather of the local score rows (asynchronous: RCCL moves them on its own stream while the caller
     keeps launching work that does not need the assignment) and returns the context ``global_sinkhorn_end`` consumes."""
@@ -356,7 +375,7 @@ def global_sinkhorn_end(ctx, rows_out: int, eps: float, iters: int, solver=None)
     local, gathered, work = ctx
     if gathered is None:
         return solver(local, iters, eps, row0=0, rows_out=rows_out)
-    work.wait()
+    wait_collective(work, "all_gather(scores)", gathered.numel() * 4, gathered.device)
     return solver(gathered, iters, eps, row0=dist.get_rank() * local.shape[0], rows_out=rows_out)
 
 
@@ -413,8 +432,8 @@ class GradExchange:
             return grads
         self.push(grads)
         inv = torch.full((1,), 1.0 / self.dist.get_world_size(), dtype=f32, device=self.buckets[0][1].device) if self.buckets and scale else None
-        for keys, flat, work in self.buckets:
-            work.wait()
+        for b_i, (keys, flat, work) in enumerate(self.buckets):
+            wait_collective(work, f"all_reduce(grad bucket {b_i})", flat.numel() * 4, flat.device)
             if not scale:
                 pass                                 # (already the mean: prescale_)
             elif flat.is_cuda:

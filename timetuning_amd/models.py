@@ -90,22 +90,25 @@ class FeatureExtractor(nn.Module):
             self.feature_dim = head_layer_list[-1]
 
     def freeze_backbone(self, unfreeze_layers=()):
-        """models.py:929-935: substring match on backbone parameter names."""
+        """models.py:929-935: a backbone parameter trains iff one of ``unfreeze_layers`` is a SUBSTRING of its name - whole blocks
+        (``"blocks.11"``), parts of one (``"blocks.11.attn"``, ``"blocks.10.mlp.fc2.weight"``) or the final ``"norm"``.
+        The backward of this build runs from the loss down to the FIRST block that holds a trainable tensor and stops there, so
+        the tensors below every block - ``patch_embed.*``, ``pos_embed``, ``cls_token`` - cannot be trained: asking for them raises
+        here, at construction, instead of silently leaving them without gradients."""
         for name, param in self.backbone.named_parameters():
             param.requires_grad = any(u in name for u in unfreeze_layers)
+            if param.requires_grad and not (name.startswith("blocks.") or name.startswith("norm.")):
+                raise NotImplementedError(f"unfreeze_layers={list(unfreeze_layers)} selects '{name}': gradients of the patch embedding, the "
+                                          "position embedding and the cls token are not built (the backward stops at the first trainable block)")
             # frozen tensors never change (no optimizer step, no EMA - they are the EMA's source): derived copies of them, such as the
-            # bf16 planes of the plane-GEMM modes, may be cached (engine.weight_planes checks storage and version as well)
+            # bf16 planes of the plane-GEMM modes, may be cached (engine.weight_planes re-checks requires_grad, storage and version)
             param._tt_static = not param.requires_grad
 
     def trainable_block_ids(self) -> List[int]:
-        ids = []
-        for i, blk in enumerate(self.backbone.blocks):
-            flags = [p.requires_grad for p in blk.parameters()]
-            if any(flags):
-                if not all(flags):
-                    raise NotImplementedError("partially unfrozen blocks are not built (the reference unfreezes whole blocks)")
-                ids.append(i)
-        return ids
+        """Blocks that hold at least one trainable tensor.  A partly unfrozen block (``"blocks.11.attn"``, as the reference's
+        substring match allows) is on the backward path as a whole: all of its gradients are computed, those of its frozen tensors
+        are dropped before they reach autograd / the optimizer / the gradient exchange."""
+        return [i for i, blk in enumerate(self.backbone.blocks) if any(p.requires_grad for p in blk.parameters())]
 
     # -- forward surface ---------------------------------------------------------------------------
     @torch.no_grad()

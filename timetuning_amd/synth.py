@@ -51,6 +51,16 @@ def normal(name: str, shape, std: float = 1.0, mean: float = 0.0, seed: int = 1)
     return a
 
 
+def make_sinkhorn_w8_scores() -> np.ndarray:
+    """Scores of the ``sinkhorn_w8.npz`` fixture (tests/golden; REGENERATED, 53 MB, not stored): [8 * 8320, 200] fp32 - SURVEY 8(c)'s
+    third Sinkhorn case (K, B_loc, iters, W) = (200, 8320, 10, 8), BASELINE config C3's global problem (6272 patches + 2048 queue
+    rows per rank).  Integer factors with |entry| <= 8 over 32 terms: every dot product is an integer below 2^12, so the fp32
+    matmul and the division by 1024 are exact on any BLAS and a test's scores equal the generator's bit for bit."""
+    xi = np.clip(np.rint(4.0 * normal("skw8.x", (8 * 8320, 32))), -8, 8).astype(np.float32)
+    pi = np.clip(np.rint(4.0 * normal("skw8.p", (200, 32))), -8, 8).astype(np.float32)
+    return (xi @ pi.T) / np.float32(1024.0)
+
+
 def make_scaler_features() -> np.ndarray:
     """Input of the ``scaler.npz`` fixture (tests/golden; regenerated, not stored): 230 000 x 6 fp32 - three batches of the
     reference's 100 000-row ``partial_fit`` loop (my_utils.py:23-30) - with unequal column scales / offsets and one constant

@@ -129,6 +129,7 @@ class TimeT(nn.Module):
         self.momentum_schedule = None
         self.data_parallel = False
         self._queue_rows_pushed = 0
+        self._queue_seen = None
         self._ema_flat = None
         self._frame_maps: Dict[tuple, torch.Tensor] = {}
         if prototype_init is None:
@@ -136,29 +137,66 @@ class TimeT(nn.Module):
         self.prototypes = nn.Parameter(prototype_init)
         self.similarity = PatchPrototypeSimilarity(self)
         self.last_aux: Dict[str, torch.Tensor] = {}
+        self.register_load_state_dict_post_hook(TimeT._after_load)
 
     # -- teacher / queue state (time_tuning.py:96-128) ---------------------------------------------
     def init_momentum_teacher(self, teacher=None, prototypes=None):
         if teacher is None:
             self.teacher = copy.deepcopy(self.feature_extractor)
             self.teacher.requires_grad_(False)
-            for p in self.teacher.parameters():     # the EMA rewrites teacher tensors through raw pointers: never cache copies
-                p._tt_static = False
             self.teacher_prototypes = nn.Parameter(self.prototypes.detach().clone())
             self.teacher_prototypes.requires_grad_(False)
         else:
             self.teacher = teacher
             self.teacher_prototypes = prototypes
+        # The EMA rewrites EVERY teacher tensor through raw pointers (no version bump) unless the teacher still shares the student's
+        # frozen tensors - a teacher passed in from outside normally does not: derived copies of teacher tensors (the bf16 planes of
+        # the plane-GEMM modes, engine.weight_planes) must never be cached, whichever branch built the teacher.
+        for p in self.teacher.parameters():
+            p._tt_static = False
+            if hasattr(p, "_tt_planes"):
+                del p._tt_planes
         self._ema_flat = None
 
     def init_queue(self, queue_size):
         self.queue = torch.zeros((queue_size, self.feature_extractor.feature_dim), device=self.prototypes.device)
         self._queue_rows_pushed = 0
+        self._queue_seen = self._queue_signature()
+
+    def set_queue(self, rows: torch.Tensor) -> None:
+        """Replace the queue's contents (a restored checkpoint, a pre-filled benchmark queue): ``rows`` [queue_size, feature_dim].
+        Equivalent to ``model.queue.copy_(rows)``, which is detected too (``queue_is_full``); allocates the queue if there is none
+        or its size differs."""
+        rows = rows.detach()
+        if self.queue is None or self.queue.shape != rows.shape:
+            self.queue = torch.zeros(tuple(rows.shape), dtype=torch.float32, device=self.prototypes.device)
+        self.queue.copy_(rows)
+        self._queue_seen = None   # fullness is read from the device at the next use
+
+    def _queue_signature(self):
+        return None if self.queue is None else (self.queue.data_ptr(), self.queue._version, tuple(self.queue.shape))
+
+    def _queue_pushed(self, m: int) -> None:
+        """Bookkeeping after this module's own ``tt_queue_push`` (a raw-pointer write: no version bump)."""
+        if self._queue_rows_pushed is not None:
+            self._queue_rows_pushed += m
+        self._queue_seen = self._queue_signature() if self._queue_rows_pushed is not None else None
 
     def queue_is_full(self) -> bool:
-        """``self.queue[-1].count_nonzero() != 0`` (time_tuning.py:207) tracked on the host: the FIFO's last row
-        becomes non-zero exactly when ``queue_size`` rows have been pushed, so no device sync is needed."""
-        return self.queue is not None and self._queue_rows_pushed >= self.queue.shape[0]
+        """``self.queue[-1].count_nonzero() != 0`` (time_tuning.py:207).  While only this module writes the queue the answer is
+        tracked on the host - the FIFO's last row becomes non-zero exactly when ``queue_size`` rows have been pushed - so the
+        training loop pays no device sync.  When somebody else has written the tensor (``model.queue.copy_(...)``, ``set_queue``,
+        a loaded checkpoint, a replaced tensor: the storage pointer / version / shape no longer match what this module left
+        behind) the reference's own device check runs, once if it says full (a full FIFO stays full), else at every call until
+        it does."""
+        if self.queue is None:
+            return False
+        if self._queue_seen is None or self._queue_seen != self._queue_signature():
+            full = bool(self.queue[-1].count_nonzero().item() != 0)
+            self._queue_rows_pushed = self.queue.shape[0] if full else None   # None: contents unknown, keep asking the device
+            self._queue_seen = self._queue_signature() if full else None
+            return full
+        return self._queue_rows_pushed >= self.queue.shape[0]
 
     def set_momentum_teacher_schedular_params(self, momentum_teacher, momentum_teacher_end, max_epochs, train_iter_per_epoch):
         self.momentum_schedule = cosine_scheduler(momentum_teacher, momentum_teacher_end, max_epochs, train_iter_per_epoch)
@@ -201,14 +239,17 @@ class TimeT(nn.Module):
         return self._ema_flat
 
     def invalidate_teacher_cache(self):
-        """Call after changing teacher or student FROZEN tensors by hand (``load_state_dict`` does it by itself): the next
+        """Call after changing teacher or student FROZEN tensors by hand (``load_state_dict`` does it by itself, also through a
+        wrapping module): the next
         step re-checks whether the teacher may share the student's frozen-block activations."""
         self._ema_flat = None
 
-    def load_state_dict(self, *args, **kwargs):
-        out = super().load_state_dict(*args, **kwargs)
-        self._ema_flat = None
-        return out
+    @staticmethod
+    def _after_load(module, incompatible_keys) -> None:
+        """load_state_dict post-hook: runs for a direct ``model.load_state_dict`` AND when the state arrives through a parent
+        module (``DistributedDataParallelModel.load_state_dict`` recurses with ``_load_from_state_dict`` and never calls a child's
+        ``load_state_dict``): the loaded teacher may differ from the student's frozen tensors, so the sharing decision is retaken."""
+        module._ema_flat = None
 
     def teacher_shares_frozen_blocks(self) -> bool:
         return self.teacher is not None and self.prototypes.is_cuda and self._flatten_for_ema()["shared"]
@@ -257,17 +298,17 @@ class TimeT(nn.Module):
     def get_scores(self, features, epsilon, sinkhorn_iterations, use_teacher=False):
         return self.similarity(features, use_teacher, epsilon, sinkhorn_iterations)
 
-    def make_seg_maps(self, first_frame_segmentation, orig_x, n_last_frames, size_mask_neighborhood, topk, features_exist=True):
-        """first_frame_segmentation [n,K], orig_x [fs,n,D] backbone tokens -> the LAST frame's map [K,g,g] fp64 stacked
-        as the reference's list tail (time_tuning.py:143-154 returns all fs-1 maps; only [-1] is ever read, :294)."""
-        if not features_exist:
-            raise NotImplementedError("make_seg_maps is only used with precomputed features on the training path")
-        fs, n, D = orig_x.shape
+    def make_seg_maps(self, first_frame_segmentation, orig_x, n_last_frames, size_mask_neighborhood, topk, features_exist=False):
+        """``time_tuning.py:143-154``: first_frame_segmentation [n, K] (a Sinkhorn assignment used as soft labels), orig_x the
+        clip's backbone tokens [fs, n, D] (``features_exist=True``, the training path :294) or its frames [fs, 3, H, W] (the
+        reference's default: each frame goes through the extractor without head, mask_propagation.py:462-466).  Returns the STACK
+        of all fs - 1 propagated maps [fs-1, K, g, g] fp64 as the reference does (only [-1] is read on the training path)."""
+        from .mask_propagation import propagate_labels
+
         g = self.feature_extractor.spatial_resolution
-        xn = ops.l2norm_fwd(orig_x.reshape(fs * n, D).contiguous()).view(fs, 1, n, D)
-        _, pmap = ops.label_propagate(xn, first_frame_segmentation.reshape(1, n, -1).contiguous().float(), n_last_frames,
-                                      size_mask_neighborhood, topk, 0.1, return_pmap=True)
-        return pmap[0].t().reshape(1, -1, g, g)
+        scores = first_frame_segmentation.view(g, g, -1).permute(2, 0, 1)
+        maps = propagate_labels(n_last_frames, size_mask_neighborhood, topk, self.feature_extractor, orig_x, scores.unsqueeze(0), features_exist)
+        return torch.stack(maps)
 
     def reshape_to_spatial_resolution(self, x, spatial_resolution):
         return x.view(spatial_resolution, spatial_resolution, -1).permute(2, 0, 1)
@@ -381,8 +422,11 @@ class TimeT(nn.Module):
             m = min(bs * 10, self.queue.shape[0])
             perm = hp["queue_perm"]
             perm = torch.randperm(bs * n) if perm is None else torch.as_tensor(perm)
+            foreign = self._queue_seen is None or self._queue_seen != self._queue_signature()
+            if foreign:
+                self.queue_is_full()   # somebody else wrote the queue: read its state from the device before this push hides it
             ops.queue_push_(self.queue, z_q, perm[:m].to(device=dev, dtype=torch.int64))
-            self._queue_rows_pushed += m
+            self._queue_pushed(m)
 
         scores_q = engine.prototype_scores(z_q, protos_q)
         if self.queue_is_full():
@@ -553,6 +597,9 @@ def load_checkpoint(model, swav_optimizer: SwavOptimizer, filename: str) -> int:
     # (the optimizer / scheduler state holds plain Python and NumPy scalars: the reference's torch.load predates weights_only)
     state = torch.load(filename, map_location="cpu", weights_only=False)
     model.load_state_dict(state["model"])
+    inner = model.get_non_ddp_model() if hasattr(model, "get_non_ddp_model") else model
+    if hasattr(inner, "invalidate_teacher_cache"):
+        inner.invalidate_teacher_cache()   # (the post-hook has done it already; kept explicit for wrappers that bypass hooks)
     swav_optimizer.optimizer.load_state_dict(state["optimizer"])
     swav_optimizer.global_step = state["global_step"]
     if swav_optimizer.lr_scheduler is not None and state.get("scheduler") is not None:

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""gemm_planes8 (persistent 8-phase plane GEMM) against fp64 and against gemm_planes_kernel, through tt_linear_fwd_planes.
+  p8_check.py check   correctness on shapes that exercise the M tail, several tiles per workgroup, every epilogue; repeated runs compared bit for bit
+  p8_check.py time    interleaved A/B timing (TT_PLANES_VARIANT=0: new where eligible, 10: old) on the ViT-B/16 (P=1) and ViT-S/16 (P=3) block shapes"""
+import os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from timetuning_amd import hip_ops as ops
+
+def run(xp, wp, b, res, act, po, variant):
+    os.environ["TT_PLANES_VARIANT"] = str(variant)
+    r = res.clone() if res is not None else None
+    o = ops.linear_fwd_planes(xp, wp, b, residual=r, act=act, out_f32=(po == 0 or res is not None), out_planes=po, out=r)
+    return o
+
+def check():
+    torch.manual_seed(0)
+    bad = 0
+    cases = []
+    for P in (1, 3):
+        BN = 256 if P == 1 else 128
+        for (M, N, K) in [(25216, 3 * BN, 256), (50000, BN, 128), (197 * 130 + 7, 2 * BN, 384), (25216, 9 * BN if P == 1 else 9 * BN, 768 if P == 1 else 384)]:
+            for (act, po, res) in [(0, 0, 0), (1, P, 0), (0, 0, 1), (0, P, 1)]:
+                cases.append((P, M, N, K, act, po, res))
+    for (P, M, N, K, act, po, res) in cases:
+        x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda") * 0.1
+        r = torch.randn(M, N, device="cuda") if res else None
+        xp, wp = ops.split_planes(x, P), ops.split_planes(w, P)
+        new = run(xp, wp, b, r, act, po, 0)
+        old = run(xp, wp, b, r, act, po, 10)
+        # fp64 reference on a row sample (first / last rows + random rows)
+        idx = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M), torch.randint(0, M, (400,))]).cuda()
+        ref = xp.double().sum(0)[idx] @ wp.double().sum(0).t() + b.double()
+        if act: ref = torch.nn.functional.gelu(ref)
+        if res: ref = ref + r.double()[idx]
+        def err(t): return ((t.double()[idx] - ref).norm() / ref.norm()).item()
+        msgs = []
+        for name, o in (("new", new), ("old", old)):
+            if o["y"] is not None: msgs.append(f"{name}.y {err(o['y']):.2e}")
+            if o["planes"] is not None: msgs.append(f"{name}.planes {err(o['planes'].double().sum(0)):.2e}")
+        # new vs old over the WHOLE output (catches a wrong tile anywhere)
+        full = []
+        if new["y"] is not None: full.append(((new["y"] - old["y"]).abs().max() / old["y"].abs().max()).item())
+        if new["planes"] is not None:
+            a, c = new["planes"].float().sum(0), old["planes"].float().sum(0)
+            full.append(((a - c).abs().max() / c.abs().max()).item())
+        # race screen: 5 more runs, bitwise equal to the first
+        same = True
+        for _ in range(5):
+            again = run(xp, wp, b, r, act, po, 0)
+            for k in ("y", "planes"):
+                if new[k] is not None and not torch.equal(new[k], again[k]): same = False
+        tol_full = 2e-2 if (P == 1 and act) else (1e-2 if P == 1 and po else 1e-4)   # P=1 GELU: tanh form vs erf, then bf16 rounding
+        ok = same and all(f < tol_full for f in full)
+        bad += (not ok)
+        print(f"P={P} M={M} N={N} K={K} act={act} po={po} res={res}: " + " ".join(msgs) + f" | new-old max {max(full):.2e} | repeat-bitwise {same} {'OK' if ok else 'FAIL'}", flush=True)
+    print("FAILED" if bad else "ALL OK", bad)
+    return bad
+
+def timeit():
+    M = 25216
+    for P, shapes in ((1, [(2304, 768, "qkv", 0, 1, 0), (768, 768, "proj", 0, 0, 1), (3072, 768, "fc1", 1, 1, 0), (768, 3072, "fc2", 0, 0, 1)]),
+                      (3, [(1152, 384, "qkv", 0, 0, 0), (384, 384, "proj", 0, 0, 1), (1536, 384, "fc1", 1, 3, 0), (384, 1536, "fc2", 0, 0, 1)])):
+        for N, K, name, act, po, res in shapes:
+            x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda")
+            r = torch.randn(M, N, device="cuda") if res else None
+            xp, wp = ops.split_planes(x, P), ops.split_planes(w, P)
+            ts = {0: [], 10: []}
+            for rd in range(10):
+                for v in (0, 10):
+                    os.environ["TT_PLANES_VARIANT"] = str(v)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10): ops.linear_fwd_planes(xp, wp, b, residual=r, act=act, out_f32=(po == 0 or res), out_planes=po, out=r)
+                    e1.record(); torch.cuda.synchronize()
+                    if rd >= 3: ts[v].append(e0.elapsed_time(e1) * 1e2)
+            n, o = statistics.median(ts[0]), statistics.median(ts[10])
+            nprod = P * (P + 1) // 2
+            print(f"P={P} {name:5s} N={N:5d} K={K:5d}: new {n:7.1f} us ({2.0 * M * N * K * nprod / n / 1e6:7.0f} TF/s raw bf16) | old {o:7.1f} us ({2.0 * M * N * K * nprod / o / 1e6:7.0f})", flush=True)
+
+if __name__ == "__main__":
+    mode = sys.argv[1] if len(sys.argv) > 1 else "check"
+    rc = 0
+    if mode in ("check", "both"): rc = check()
+    if mode in ("time", "both"): timeit()
+    sys.exit(1 if rc else 0)
