@@ -679,33 +679,44 @@ def test_c4_shape_in_bf16_mode():
         hip_ops.set_gemm_precision("f32")
 
 
-def test_bf16_mode_gradients_track_f32(golden):
-    """BASELINE C4's bf16 path end to end WITH its bf16 backward products (dgrad / wgrad on bf16 operands): loss and gradients
-    of one training step on the tiny ViT against the f32 run of the same step, at bf16-sized bounds (not the fp32 contract)."""
+@pytest.mark.timeout(900)
+def test_c4_bf16_step_gradients_vs_fp32_oracle():
+    """BASELINE C4's "MFMA bf16 path" with its bf16 backward products, at C4's shape (ViT-B/16, one clip of 8 frames, 400
+    prototypes), against the fp32 ORACLE - not against another run of the HIP path: loss, and the gradients of the prototypes, a
+    head weight, a blocks.10 attention weight and a blocks.11 MLP weight.  bf16 carries 8 significant bits, so the bounds are
+    bf16-sized and stated here: loss within 1 %, every gradient within 2 % of the oracle (relative L2 error) and at cosine > 0.9995 with it
+    (measured on MI355X, round 3: loss 5.97655 vs 5.97659, gradient errors 0.3-0.7 %, cosines >= 0.99997; the test prints them).  The hard labels are the oracle's, so the loss and its
+    gradients are continuous functions of the features."""
+    from oracle import timet_oracle as O
     from timetuning_amd import hip_ops
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
 
-    g = golden("timet_tiny")
-    bs, fs = int(g["cfg"][0]), int(g["cfg"][1])
-    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1)).cuda()
-    names = ("feature_extractor.head.0.weight", "feature_extractor.head.6.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight",
-             "feature_extractor.backbone.blocks.11.mlp.fc2.weight", "feature_extractor.backbone.blocks.10.norm1.weight", "prototypes")
-    out = {}
+    K, bs, fs = 400, 1, 8
+    fe = FeatureExtractor("dino-b16", "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="dino", return_attention=False)
+    model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, 256))).cuda()
+    om = O.build_oracle("dino-b16", K, (1024, 1024, 512, 256), mode="dino")
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=5))
+    oloss, aux = om.get_loss(x, faithful=False, return_aux=True)
+    oloss.backward()
+    og = dict(om.named_parameters())
+    names = ("prototypes", "feature_extractor.head.0.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight",
+             "feature_extractor.backbone.blocks.11.mlp.fc2.weight")
     try:
-        for mode in ("f32", "bf16"):
-            hip_ops.set_gemm_precision(mode)
-            model, _ = _build(g)
-            labels = None if mode == "f32" else out["f32"][2]
-            loss = model.get_loss(x, target_labels=labels)
-            loss.backward()
-            params = dict(model.named_parameters())
-            out[mode] = (loss.item(), {n: params[n].grad.double().cpu() for n in names}, model.last_aux["labels"].cpu())
+        hip_ops.set_gemm_precision("bf16")
+        loss = model.get_loss(x.cuda(), target_labels=aux["labels"].reshape(bs, -1))
+        loss.backward()
     finally:
         hip_ops.set_gemm_precision("f32")
-    assert abs(out["bf16"][0] - out["f32"][0]) < 0.05 * abs(out["f32"][0])
+    mg = dict(model.named_parameters())
+    print(f"\nC4 bf16 vs fp32 oracle: loss {loss.item():.5f} / {oloss.item():.5f}")
+    assert abs(loss.item() - oloss.item()) < 0.01 * abs(oloss.item()), (loss.item(), oloss.item())
     for n in names:
-        a, b = out["bf16"][1][n].flatten(), out["f32"][1][n].flatten()
-        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
-        assert cos > 0.98 and abs(float(a.norm() / b.norm()) - 1) < 0.1, (n, cos)
+        a_, b_ = mg[n].grad.double().cpu().flatten(), og[n].grad.double().flatten()
+        cos = float(torch.dot(a_, b_) / (a_.norm() * b_.norm()))
+        ratio = float(a_.norm() / b_.norm())
+        print(f"  {n}: cosine {cos:.5f}  norm ratio {ratio:.4f}  rel err {float((a_ - b_).norm() / b_.norm()):.4f}")
+        assert cos > 0.9995 and float((a_ - b_).norm() / b_.norm()) < 0.02, (n, cos, ratio)
 
 
 @pytest.mark.parametrize("mode,feat_tol", [("bf16x3", 1e-3), ("bf16", 6e-2)])

@@ -69,7 +69,7 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // tested at).  The f32-MFMA kernels keep ocml's erff (gelu_f / gelu_grad_f): measured, the cheaper erf buys them nothing.
 __device__ __forceinline__ float erf_fast_f(float x, float* exp_neg_half_x2_out = nullptr) {   // erf(x / sqrt 2), |error| <= 1.5e-7
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // v_rcp_f32, 1 ulp (__frcp_rn is an 11-instruction IEEE division)
   const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
   const float e = __expf(-z * z);   // = exp(-x^2 / 2): also the Gaussian of gelu'
   if (exp_neg_half_x2_out) *exp_neg_half_x2_out = e;
@@ -89,7 +89,7 @@ __device__ __forceinline__ float gelu_grad_fast_f(float x) {
 __device__ __forceinline__ float gelu_bf16_f(float x) {
   const float x2 = x * x;
   const float u2 = x * fmaf(x2, -0.1029432f, -2.3022082f);           // -2 u log2(e)
-  return x * __frcp_rn(1.0f + __builtin_amdgcn_exp2f(u2));
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u2));
 }
 
 // XCD-aware bijective remap of a linear workgroup id (guide T1): the dispatcher deals consecutive

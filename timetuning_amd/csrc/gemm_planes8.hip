@@ -17,43 +17,69 @@
 //     issued D phases before the phase that needs it, the wait of phase f retires everything but the youngest L chunks, and
 //     a chunk is read one phase after the wait that retired it.  The schedule tables below are checked at compile time
 //     against the two hazards (RAW: DMA -> ds_read, WAR: ds_read -> DMA of the K-tile two later into the same slot).
-//   * PERSISTENT: a workgroup walks a contiguous run of tiles; the DMA cursor runs D chunks ahead of the compute cursor ACROSS
-//     tile boundaries, so a tile's first K-tiles land while the previous tile finishes - no per-tile prologue bubble.
+//   * PERSISTENT: a workgroup walks a run of work items; the DMA cursor runs D chunks ahead of the compute cursor ACROSS item
+//     boundaries, so an item's first K-tiles land while the previous one finishes - no per-tile prologue bubble.  The tiles that
+//     do not make a whole round over the CUs are cut into HALF tiles (128 rows: the X1 chunk and the two phases that use it are
+//     skipped) when that fills the chip better; workgroups with a half tile take it first or last by parity, which puts the two
+//     populations half a tile apart in time so that their epilogues (the only HBM-heavy part) do not all hit memory at once.
+//     (Starting the workgroups that have no half tile - and therefore half a tile of slack - a quarter of that slack apart was
+//     measured too: no gain, 153 -> 159 us on ViT-B/16's fc2; not kept.)
 //   * swapped operands: D = W_tile . X_tile^T puts an output ROW on a lane and 4 consecutive columns in 4 registers; the epilogue
 //     stages one 32 x 32 MFMA tile at a time through the wave's private scratch (no workgroup barrier: both groups run their
-//     epilogues concurrently) and leaves as full 128-byte row segments with bias / GELU / residual applied on the way.
+//     epilogues concurrently) and leaves as whole row segments.  It is specialised at compile time (EPI), branch-free (buffer
+//     loads / stores: rows beyond M are out of range and dropped by the hardware), residual rows are prefetched two MFMA tiles
+//     ahead, and the stores are NOT waited for: they drain under the next tile's main loop, whose counted waits allow for them.
 //
 // LDS images and the fragment / DMA lane maps are those of gemm_planes.hip (rows of BK bf16, 16-byte chunks XOR-swizzled through
 // the per-lane SOURCE address; conflict-free ds_read_b128 for v_mfma_f32_32x32x16_bf16).
+//
+// Round-3 measurements that shaped it (tools/p8_ablate.py, profiles/r03_p8_ablation.txt): first version 841 / 744 TFLOP/s on
+// ViT-B/16's qkv / fc2 (gemm_planes_kernel: 627 / 701); its epilogue - a chain of runtime branches with every residual load
+// consumed at once, an IEEE division inside the GELU (__frcp_rn) and a vmcnt(0) behind the stores, all CUs in lockstep - was
+// 17-43 % of the launches.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace tt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// epilogue kinds (compile time)
+enum { P8_BF16 = 0, P8_BF16_GELU = 1, P8_F32 = 2, P8_F32_RES = 3, P8_PL3_GELU = 4 };
 
 struct P8Args {
   const __bf16* X;   // [P][M][K]
   const __bf16* W;   // [P][N][K]
   long long x_stride, w_stride;   // plane strides in elements
   int M, N, K;
-  const float* bias;      // [N] or null
-  const float* residual;  // [M][N] or null (may alias C)
-  float* C;               // [M][N] fp32 or null
-  __bf16* Cp;             // [po][M][N] bf16 planes or null
+  const float* bias;      // [N]
+  const float* residual;  // [M][N] (P8_F32_RES; may alias C)
+  float* C;               // [M][N] fp32 (P8_F32*)
+  __bf16* Cp;             // [po][M][N] bf16 planes (P8_BF16*, P8_PL3_GELU)
   long long c_stride;
-  int po;                 // output planes 0..3
-  int act;                // 1 = GELU
-  int ntn, ntiles, ncu;   // column tiles, tiles, workgroups launched
+  int ntn, ntiles, ncu;   // column tiles, whole tiles, workgroups launched
+  int n_full;             // whole tiles per workgroup in the first part (tiles [0, n_full * ncu)); with n_half = 0 and n_full = 0:
+                          // balanced contiguous runs of all tiles
+  int n_half;             // half tiles that follow (tiles [n_full * ncu, ntiles) cut in two): workgroup h < n_half takes half h
 };
 
-
+// Device helpers at namespace scope: the buffer builtins inside a generic lambda of the kernel template make clang's HOST pass
+// drop the kernel's stub (ROCm 7.2: undefined __device_stub__ at load time, no diagnostic).
 __device__ __forceinline__ void p8_dma16(const void* base, unsigned char* lds_dst, int voffset, int soffset) {
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_dst, 16, voffset, soffset, 0, 0);
+}
+__device__ __forceinline__ f32x4 p8_ld128(const void* base, unsigned nbytes, unsigned voff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, nbytes, 0x00020000);
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ void p8_st128(void* base, unsigned nbytes, unsigned voff, u32x4 v) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, nbytes, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
 }
 
 template <int N>
@@ -62,12 +88,12 @@ __device__ __forceinline__ void p8_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// ---- the schedule, per P.  A K-tile is NCH = 4 chunk slots issued one per phase; chunk i of K-tile t has stream index 4 t + i.
+// ---- the schedule, per P.  A K-tile is 4 chunk slots issued one per phase; chunk i of K-tile t has stream index 4 t + i.
 template <int P>
 struct P8Cfg;
 template <>
 struct P8Cfg<1> {
-  static constexpr int BK = 64, NHW = 2, D = 6, L = 4;
+  static constexpr int BK = 64, NHW = 2, D = 6, L = 4, X1 = 3;
   // chunks in need order: W0, X0, W1, X1
   static constexpr bool exists(int i) { return true; }
   static constexpr bool is_x(int i) { return i & 1; }
@@ -77,7 +103,7 @@ struct P8Cfg<1> {
 };
 template <>
 struct P8Cfg<3> {
-  static constexpr int BK = 32, NHW = 1, D = 5, L = 3;
+  static constexpr int BK = 32, NHW = 1, D = 5, L = 3, X1 = 2;
   // chunks: W, X0, X1, (none)
   static constexpr bool exists(int i) { return i < 3; }
   static constexpr bool is_x(int i) { return i >= 1; }
@@ -100,20 +126,26 @@ constexpr bool p8_schedule_ok() {
   return C::D - C::L >= 1 && C::D <= 8;
 }
 // wave-instructions of the youngest L chunks after the issue of compute phase ph (chunks ph + D - L + 1 .. ph + D of the stream);
-// gch = wave-instructions per wave and chunk
+// gch = wave-instructions per wave and chunk.  half: the X1 chunk is not issued (half tiles) - also the safe (smaller) count
+// while the window may still hold a slot of a half tile.
 template <int P>
-constexpr int p8_window(int ph, int gch) {
+constexpr int p8_window(int ph, int gch, bool half) {
   using C = P8Cfg<P>;
   int n = 0;
-  for (int k = 0; k < C::L; ++k) n += C::exists((ph + C::D - k) & 3) ? gch : 0;
+  for (int k = 0; k < C::L; ++k) {
+    const int idx = (ph + C::D - k) & 3;
+    n += (C::exists(idx) && !(half && idx == C::X1)) ? gch : 0;
+  }
   return n;
 }
 static_assert(p8_schedule_ok<1>() && p8_schedule_ok<3>(), "LDS-DMA schedule violates a RAW / WAR rule");
 
-template <int P>
+// DBG (timing studies only, tools/p8_ablate.py; the shipped instantiations are DBG = 0), a bit mask: 1 no MFMAs, 2 no LDS-DMA, 4 no fragment
+// reads, 8 no epilogue (accumulators consumed by a dummy store), 16 epilogue without global loads / stores
+template <int P, int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   using CF = P8Cfg<P>;
-  constexpr int BK = CF::BK, NHW = CF::NHW, D = CF::D;
+  constexpr int BK = CF::BK, NHW = CF::NHW, D = CF::D, L = CF::L;
   constexpr int ROWB = BK * 2;              // bytes per LDS row
   constexpr int CPR = ROWB / 16;            // 16-byte chunks per row
   constexpr int WIN = 256 / ROWB;           // rows per 256-byte bank window
@@ -128,8 +160,17 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   constexpr int RING_B = 2 * BUF_B;
   constexpr int SCR_B = (160 * 1024 - RING_B) / 8;   // per-wave epilogue scratch
   constexpr int CW = SCR_B / 128;                    // columns of a 32-row MFMA tile staged per pass (32 or 16)
+  constexpr int NPASS = 32 / CW;
   constexpr int BN = 128 * NHW;
   constexpr int NF = P == 1 ? NKS : P;               // fragments per register set
+  constexpr bool F32OUT = EPI == P8_F32 || EPI == P8_F32_RES, RES = EPI == P8_F32_RES, ACT = EPI == P8_BF16_GELU || EPI == P8_PL3_GELU;
+  constexpr int PO = F32OUT ? 0 : (EPI == P8_PL3_GELU ? 3 : 1);
+  // stores a wave issues per whole tile (the epilogue's loads come on top): what the counted waits of the following phases may
+  // leave outstanding besides their DMA window.  A LOWER bound is what keeps those waits safe (see `epilogue`).
+  constexpr int ST_TILE = F32OUT ? 4 : 2 * PO;                  // per 32 x 32 MFMA tile (fp32: 4 KB in 1 KB pieces; bf16: 2 KB per plane)
+  constexpr int ST_FULL = 4 * NHW * ST_TILE, ST_HALF = ST_FULL / 2;
+  constexpr int WMAX = GCH * L;
+  constexpr int S_FULL = ST_FULL < 63 - WMAX ? ST_FULL : 63 - WMAX, S_HALF = ST_HALF < 63 - WMAX ? ST_HALF : 63 - WMAX;
   static_assert(RING_B + 8 * SCR_B <= 160 * 1024 && (CW == 32 || CW == 16), "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem[160 * 1024];
 
@@ -140,12 +181,38 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   const int r = lane & 31, h = lane >> 5;
   const int K2 = g.K * 2, nk = g.K / BK;
 
-  // ---- this workgroup's tiles: workgroups that share an XCD (equal id mod 8) get adjacent runs of the row-major tile order,
-  // so an activation row block is fetched into one L2 while the weight strips stay hot in all of them
+  // ---- this workgroup's work items.  Workgroups that share an XCD (equal id mod 8) get adjacent runs of the row-major tile
+  // order, so an activation row block is fetched into one L2 while the weight strips stay hot in all of them.
   int cu = blockIdx.x;
   if ((g.ncu & 7) == 0) cu = (blockIdx.x & 7) * (g.ncu >> 3) + (blockIdx.x >> 3);
-  const int t_begin = (int)(((long long)cu * g.ntiles) / g.ncu), t_end = (int)(((long long)(cu + 1) * g.ntiles) / g.ncu);
-  if (t_begin >= t_end) return;   // whole workgroup
+  int t_begin, n_whole;
+  bool has_half = false;
+  if (g.n_full > 0 || g.n_half > 0) {
+    t_begin = cu * g.n_full;
+    n_whole = g.n_full;
+    has_half = cu < g.n_half;
+  } else {
+    t_begin = (int)(((long long)cu * g.ntiles) / g.ncu);
+    n_whole = (int)(((long long)(cu + 1) * g.ntiles) / g.ncu) - t_begin;
+  }
+  const int n_items = n_whole + (has_half ? 1 : 0);
+  if (n_items == 0) return;   // whole workgroup
+  const bool half_first = has_half && (cu & 1) && n_whole > 0;
+  // item -> first row, first column, half?
+  auto item = [&](int it, int& row0, int& n0, bool& half) {
+    int tile;
+    half = has_half && (half_first ? it == 0 : it == n_whole);
+    int hsel = 0;
+    if (half) {
+      tile = g.n_full * g.ncu + (cu >> 1);
+      hsel = cu & 1;
+    } else {
+      tile = t_begin + (half_first ? it - 1 : it);
+    }
+    const int mb = tile / g.ntn, ns = tile - mb * g.ntn;
+    row0 = mb * 256 + hsel * 128;
+    n0 = ns * BN;
+  };
 
   // ---- LDS-DMA lane map (see gemm_planes.hip): lane -> (row, slot) of the 1 KiB piece, source chunk = slot ^ f(row)
   const int l_row = lane / CPR, l_slot = lane % CPR;
@@ -154,44 +221,47 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   const int w_voff = d_row0 * K2 + d_chunk * 16;
   const int xps = (int)(g.x_stride * 2), wps = (int)(g.w_stride * 2);     // plane strides in bytes
 
-  // DMA cursor (scalar state + the X voffsets of its tile; rows beyond M are clamped to M - 1 and masked at the store)
-  int d_tile = t_begin, d_kt = 0, d_mb = t_begin / g.ntn, d_ns = t_begin % g.ntn;
-  bool d_done = false;
+  // DMA cursor (scalar state + the X voffsets of its item; rows beyond M are clamped to M - 1 and dropped at the store)
+  int d_item = 0, d_kt = 0;
+  bool d_done = false, d_half = false;
+  int half_guard = 0;   // > 0: the DMA window may hold a slot of a half tile (no X1 chunk): the counted waits take the smaller count
   int d_kofs = 0;       // d_kt * ROWB
-  int d_wbase = 0;      // first W row of the tile * K2
+  int d_wbase = 0;      // first W row of the item * K2
   int x_voff[2][JPW];
-  auto cursor_tile = [&]() {
-    d_wbase = d_ns * BN * K2;
+  auto cursor_item = [&]() {
+    int row0, n0;
+    item(d_item, row0, n0, d_half);
+    d_wbase = n0 * K2;
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
       for (int i = 0; i < JPW; ++i) {
-        int row = d_mb * 256 + ha * 128 + 8 * i * RPI + d_row0;
+        int row = row0 + ha * 128 + 8 * i * RPI + d_row0;
         row = row < g.M ? row : g.M - 1;
         x_voff[ha][i] = row * K2 + d_chunk * 16;
       }
   };
-  cursor_tile();
+  cursor_item();
   auto cursor_next_ktile = [&]() {
     ++d_kt;
     d_kofs += ROWB;
     if (d_kt == nk) {
       d_kt = 0;
       d_kofs = 0;
-      ++d_tile;
-      if (d_tile >= t_end) {
+      ++d_item;
+      if (d_item >= n_items) {
         d_done = true;
       } else {
-        if (++d_ns == g.ntn) { d_ns = 0; ++d_mb; }
-        cursor_tile();
+        cursor_item();
       }
     }
   };
   // issue chunk IDX of the cursor's K-tile into ring buffer B
   auto issue = [&](auto idx_c, auto buf_c) {
     constexpr int IDX = decltype(idx_c)::value, B = decltype(buf_c)::value;
-    if constexpr (CF::exists(IDX)) {
+    if constexpr (CF::exists(IDX) && !(DBG & 2)) {
       if (d_done) return;
+      if (IDX == CF::X1 && d_half) return;
       constexpr int HA = CF::half(IDX);
       const int lds_base = B * BUF_B + IDX * HALF_B + wave * 1024;
 #pragma unroll
@@ -225,149 +295,254 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
         for (int e = 0; e < 16; ++e) acc[a][b][m][e] = 0.f;
   bf16x8 Wf[2][NF], Xf[2][NF];
 
-  auto ld = [&](int off) { return *reinterpret_cast<const bf16x8*>(smem + off); };
+  auto ld = [&](int off) {
+    if constexpr (DBG & 4) {
+      bf16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (__bf16)(float)(off & 7);
+      return z;
+    } else {
+      return *reinterpret_cast<const bf16x8*>(smem + off);
+    }
+  };
+
+  int post_epi = 0;          // phases left in which the stores of the last epilogue may still be outstanding
+  bool post_half = false;    // ... and whether that epilogue was a half tile's
+  bool c_half = false;       // the item being computed is a half tile
 
   // ---- one phase: [fragment reads | DMA issue | counted wait] barrier [MFMAs] barrier
   auto phase = [&](auto buf_c, auto ph_c) {
     constexpr int B = decltype(buf_c)::value, PH = decltype(ph_c)::value;
     constexpr int base = B * BUF_B;
-    if constexpr (P == 1) {
-      // chunks W0 X0 W1 X1 in slots 0..3; quadrants (hA, hW): (0,0) (0,1) (1,1) (1,0)
-      if constexpr (PH == 0) {
+    const bool work = !(PH >= 2 && c_half);   // phases 2 and 3 of either schedule use the X1 chunk only
+    if (work) {
+      if constexpr (P == 1) {
+        // chunks W0 X0 W1 X1 in slots 0..3; quadrants (hA, hW): (0,0) (0,1) (1,1) (1,0)
+        if constexpr (PH == 0) {
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) Wf[0][ks] = ld(base + 0 * HALF_B + w_slice + lo[ks]);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int ks = 0; ks < NKS; ++ks) Wf[0][ks] = ld(base + 0 * HALF_B + w_slice + lo[ks]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) Xf[mt][ks] = ld(base + 1 * HALF_B + x_slice + mt * 32 * ROWB + lo[ks]);
+        } else if constexpr (PH == 1) {
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) Wf[1][ks] = ld(base + 2 * HALF_B + w_slice + lo[ks]);
+        } else if constexpr (PH == 2) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) Xf[mt][ks] = ld(base + 3 * HALF_B + x_slice + mt * 32 * ROWB + lo[ks]);
+        }
+      } else {
+        // chunks W X0 X1 in slots 0..2 (planes inside a chunk); phases (hA, ks): (0,0) (0,1) (1,1) (1,0)
+        constexpr int HA = PH >> 1, KS = (PH == 1 || PH == 2) ? 1 : 0;
+        if constexpr (PH < 2) {
+#pragma unroll
+          for (int p = 0; p < P; ++p) Wf[KS][p] = ld(base + 0 * HALF_B + p * PLANE_B + w_slice + lo[KS]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int ks = 0; ks < NKS; ++ks) Xf[mt][ks] = ld(base + 1 * HALF_B + x_slice + mt * 32 * ROWB + lo[ks]);
-      } else if constexpr (PH == 1) {
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) Wf[1][ks] = ld(base + 2 * HALF_B + w_slice + lo[ks]);
-      } else if constexpr (PH == 2) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int ks = 0; ks < NKS; ++ks) Xf[mt][ks] = ld(base + 3 * HALF_B + x_slice + mt * 32 * ROWB + lo[ks]);
+          for (int p = 0; p < P; ++p) Xf[mt][p] = ld(base + (1 + HA) * HALF_B + p * PLANE_B + x_slice + mt * 32 * ROWB + lo[KS]);
       }
-    } else {
-      // chunks W X0 X1 in slots 0..2 (planes inside a chunk); phases (hA, ks): (0,0) (0,1) (1,1) (1,0)
-      constexpr int HA = PH >> 1, KS = (PH == 1 || PH == 2) ? 1 : 0;
-      if constexpr (PH < 2) {
-#pragma unroll
-        for (int p = 0; p < P; ++p) Wf[KS][p] = ld(base + 0 * HALF_B + p * PLANE_B + w_slice + lo[KS]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int p = 0; p < P; ++p) Xf[mt][p] = ld(base + (1 + HA) * HALF_B + p * PLANE_B + x_slice + mt * 32 * ROWB + lo[KS]);
     }
     // DMA: chunk (PH + D) of the stream = chunk (PH + D) & 3 of the K-tile (PH + D) / 4 further on
     constexpr int CI = (PH + D) & 3, BT = (B + (PH + D) / 4) & 1;
     if constexpr (CI == 0) cursor_next_ktile();
     issue(std::integral_constant<int, CI>{}, std::integral_constant<int, BT>{});
-    if (d_done) p8_wait_vmcnt<0>();
-    else p8_wait_vmcnt<p8_window<P>(PH, GCH)>();
+    // counted wait: everything but the youngest L chunks (and, for L phases behind an epilogue, its stores) has landed
+    half_guard = (d_half && !d_done) ? L + 1 : (half_guard > 0 ? half_guard - 1 : 0);
+    constexpr int WF = p8_window<P>(PH, GCH, false), WH = p8_window<P>(PH, GCH, true);
+    if (d_done || (DBG & 2)) {
+      p8_wait_vmcnt<0>();
+    } else if (post_epi > 0) {
+      --post_epi;
+      if (half_guard > 0 || post_half) p8_wait_vmcnt<WH + S_HALF>();
+      else p8_wait_vmcnt<WF + S_FULL>();
+    } else if (half_guard > 0) {
+      p8_wait_vmcnt<WH>();
+    } else {
+      p8_wait_vmcnt<WF>();
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    if constexpr (P == 1) {
-      constexpr int HA = PH >> 1, HW = (PH == 1 || PH == 2) ? 1 : 0;
+    if (work) {
+      __builtin_amdgcn_s_setprio(1);
+      if constexpr (DBG & 1) {
+        // keep the fragment reads alive without matrix work
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)
+        for (int i = 0; i < NF; ++i) {
+          asm volatile("" ::"v"(Wf[0][i]), "v"(Wf[1][i]));
+          asm volatile("" ::"v"(Xf[0][i]), "v"(Xf[1][i]));
+        }
+      } else if constexpr (P == 1) {
+        constexpr int HA = PH >> 1, HW = (PH == 1 || PH == 2) ? 1 : 0;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            acc[HA][HW][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[HW][ks], Xf[mt][ks], acc[HA][HW][mt], 0, 0, 0);
+      } else {
+        constexpr int HA = PH >> 1, KS = (PH == 1 || PH == 2) ? 1 : 0;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-          acc[HA][HW][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[HW][ks], Xf[mt][ks], acc[HA][HW][mt], 0, 0, 0);
-    } else {
-      constexpr int HA = PH >> 1, KS = (PH == 1 || PH == 2) ? 1 : 0;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+          for (int s = P - 1; s >= 0; --s)          // plane-index sum: small terms first (as gemm_planes_kernel)
 #pragma unroll
-        for (int s = P - 1; s >= 0; --s)          // plane-index sum: small terms first (as gemm_planes_kernel)
-#pragma unroll
-          for (int pa = 0; pa <= s; ++pa)
-            acc[HA][0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[KS][s - pa], Xf[mt][pa], acc[HA][0][mt], 0, 0, 0);
+            for (int pa = 0; pa <= s; ++pa)
+              acc[HA][0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[KS][s - pa], Xf[mt][pa], acc[HA][0][mt], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
     }
-    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   };
 
-  // ---- epilogue of one tile: per wave, through its private scratch, no workgroup barrier
+  // ---- epilogue of one item: per wave, through its private scratch, no workgroup barrier.
+  // Lane (m = r) holds columns 8 g + 4 h + {0..3} of a 32 x 32 MFMA tile in registers 4 g .. 4 g + 3.  A pass stages CW columns
+  // ([32][CW] fp32, 16-byte chunks XOR-swizzled by the row) and reads them back row-major: fp32 outputs 4 columns per lane
+  // (rows of CW * 4 bytes leave whole), bf16 outputs 8 columns per lane (16-byte stores).
+  // Every global access is a buffer access on [M][N]: rows >= M are beyond the range and dropped, so the instruction count per
+  // wave is FIXED - ST_FULL (ST_HALF) stores plus the bias / residual loads - which is what lets the next phases' waits count.
   unsigned char* scr = smem + RING_B + wave * SCR_B;
-  constexpr int CPRW = CW / 4;      // 16-byte chunks per staged row
-  constexpr int RPW = 64 / CPRW;    // rows per read-back instruction
-  const int rr = lane / CPRW, cc = lane % CPRW;
-  auto epilogue = [&](int row0, int n0) {
+  constexpr int CPRW = CW / 4;                    // 16-byte chunks per staged row
+  constexpr int LPR = F32OUT ? CPRW : CPRW / 2;   // lanes per staged row on the way back
+  constexpr int RPW = 64 / LPR;                   // rows per read-back instruction
+  constexpr int NRB = 32 / RPW;                   // read-back instructions per pass
+  constexpr int NLD = NPASS * NRB;                // ... per MFMA tile (fp32: 4)
+  const int rr = lane / LPR, cc = lane % LPR;
+  const unsigned out_bytes = (unsigned)g.M * (unsigned)g.N * (F32OUT ? 4u : 2u);
+  auto epilogue = [&](int row0, int n0, bool half) {
+    if constexpr (DBG & 8) {
+      float sres = 0.f;
 #pragma unroll
-    for (int hw = 0; hw < NHW; ++hw) {
-      const int nbase = n0 + hw * 128 + wc * 32;
-      f32x4 bias4[32 / CW];
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int q = 0; q < 32 / CW; ++q) {
-        if (g.bias) bias4[q] = *reinterpret_cast<const f32x4*>(g.bias + nbase + q * CW + 4 * cc);
-        else bias4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NHW; ++b)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sres += acc[a][b][m][e]; acc[a][b][m][e] = 0.f; }
+      if (g.C && sres == 12345.678f) g.C[threadIdx.x] = sres;
+      return;
+    }
+    // MFMA tiles in the order (ha, hw, mt): a half item ends after the first 2 NHW
+    constexpr int NT = 4 * NHW;
+    const int nt = half ? NT / 2 : NT;
+    auto tile_rc = [&](int j, int& mbase, int& nbase, int& hw, int& ha, int& mt) {
+      ha = j / (2 * NHW); hw = (j / 2) % NHW; mt = j & 1;
+      mbase = row0 + ha * 128 + wr * 64 + mt * 32;
+      nbase = n0 + hw * 128 + wc * 32;
+    };
+    // bias of this lane's columns, per (hw, pass)
+    f32x4 bias_lo[NHW][NPASS], bias_hi[NHW][NPASS];
+#pragma unroll
+    for (int hw = 0; hw < NHW; ++hw)
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q) {
+        const int n = n0 + hw * 128 + wc * 32 + q * CW + (F32OUT ? 4 : 8) * cc;
+        bias_lo[hw][q] = *reinterpret_cast<const f32x4*>(g.bias + n);
+        if constexpr (!F32OUT) bias_hi[hw][q] = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
       }
+    // residual rows, two MFMA tiles ahead of their use
+    f32x4 rres[3][RES ? NLD : 1];
+    auto prefetch = [&](int j, int slot) {
+      if constexpr (RES && !(DBG & 16)) {
+        int mbase, nbase, hw, ha, mt;
+        tile_rc(j, mbase, nbase, hw, ha, mt);
 #pragma unroll
-      for (int ha = 0; ha < 2; ++ha)
+        for (int q = 0; q < NPASS; ++q)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          const int mbase = row0 + ha * 128 + wr * 64 + mt * 32;
+          for (int i = 0; i < NRB; ++i) {
+            const unsigned off = ((unsigned)(mbase + i * RPW + rr) * (unsigned)g.N + (unsigned)(nbase + q * CW + 4 * cc)) * 4u;
+            rres[slot][q * NRB + i] = p8_ld128(g.residual, out_bytes, off);
+          }
+      }
+    };
+    if constexpr (RES) {
+      prefetch(0, 0);
+      prefetch(1, 1);
+    }
 #pragma unroll
-          for (int q = 0; q < 32 / CW; ++q) {
-            // lane (m = r) holds columns 8 g + 4 h + {0..3} in registers 4 g .. 4 g + 3
+    for (int j = 0; j < NT; ++j) {
+      if (j < nt) {
+        int mbase, nbase, hw, ha, mt;
+        tile_rc(j, mbase, nbase, hw, ha, mt);
+        if constexpr (RES) {
+          if (j + 2 < nt) prefetch(j + 2, (j + 2) % 3);
+        }
 #pragma unroll
-            for (int gg = 0; gg < CW / 8; ++gg) {
-              const int gi = q * (CW / 8) + gg;
-              const int phys = (2 * gg + h) ^ (r & (CPRW - 1));
-              f32x4 v = {acc[ha][hw][mt][4 * gi], acc[ha][hw][mt][4 * gi + 1], acc[ha][hw][mt][4 * gi + 2], acc[ha][hw][mt][4 * gi + 3]};
-              *reinterpret_cast<f32x4*>(scr + r * (CW * 4) + phys * 16) = v;
-            }
+        for (int q = 0; q < NPASS; ++q) {
 #pragma unroll
-            for (int i = 0; i < 32 / RPW; ++i) {
-              const int row = i * RPW + rr;
-              const int phys = cc ^ (row & (CPRW - 1));
-              f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + phys * 16);
-              const int m = mbase + row;
-              v += bias4[q];
-              if (g.act == 1) {
-                if constexpr (P == 1) {
+          for (int gg = 0; gg < CW / 8; ++gg) {
+            const int gi = q * (CW / 8) + gg;
+            const int phys = (2 * gg + h) ^ (r & (CPRW - 1));
+            f32x4 v = {acc[ha][hw][mt][4 * gi], acc[ha][hw][mt][4 * gi + 1], acc[ha][hw][mt][4 * gi + 2], acc[ha][hw][mt][4 * gi + 3]};
+            *reinterpret_cast<f32x4*>(scr + r * (CW * 4) + phys * 16) = v;
+          }
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] = gelu_bf16_f(v[e]);
-                } else {
+          for (int i = 0; i < NRB; ++i) {
+            const int row = i * RPW + rr;
+            const int m = mbase + row;
+            if constexpr (F32OUT) {
+              f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + ((cc ^ (row & (CPRW - 1))) << 4));
+              v += bias_lo[hw][q];
+              if constexpr (RES && !(DBG & 16)) v += rres[j % 3][q * NRB + i];
+              const unsigned off = ((unsigned)m * (unsigned)g.N + (unsigned)(nbase + q * CW + 4 * cc)) * 4u;
+              if constexpr (DBG & 16) {
+                if (v[0] == 12345.678f) p8_st128(g.C, out_bytes, off, __builtin_bit_cast(u32x4, v));
+              } else {
+                p8_st128(g.C, out_bytes, off, __builtin_bit_cast(u32x4, v));
+              }
+            } else {
+              f32x4 v0 = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + (((2 * cc) ^ (row & (CPRW - 1))) << 4));
+              f32x4 v1 = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + (((2 * cc + 1) ^ (row & (CPRW - 1))) << 4));
+              v0 += bias_lo[hw][q];
+              v1 += bias_hi[hw][q];
+              float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+              if constexpr (ACT) {
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] = gelu_fast_f(v[e]);
+                for (int e = 0; e < 8; ++e) v[e] = P == 1 ? gelu_bf16_f(v[e]) : gelu_fast_f(v[e]);
+              }
+              const unsigned off = ((unsigned)m * (unsigned)g.N + (unsigned)(nbase + q * CW + 8 * cc)) * 2u;
+              bf16x8 q0, q1, q2;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const __bf16 p0 = (__bf16)v[e];
+                q0[e] = p0;
+                if constexpr (PO > 1) {
+                  const float r1 = v[e] - (float)p0;
+                  const __bf16 p1 = (__bf16)r1;
+                  q1[e] = p1;
+                  q2[e] = (__bf16)(r1 - (float)p1);
                 }
               }
-              if (m < g.M) {
-                const size_t off = (size_t)m * g.N + nbase + q * CW + 4 * cc;
-                if (g.residual) v += *reinterpret_cast<const f32x4*>(g.residual + off);
-                if (g.C) *reinterpret_cast<f32x4*>(g.C + off) = v;
-                if (g.po > 0) {
-                  bf16x4 q0, q1, q2;
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) {
-                    const __bf16 p0 = (__bf16)v[e];
-                    const float r1 = v[e] - (float)p0;
-                    const __bf16 p1 = (__bf16)r1;
-                    q0[e] = p0; q1[e] = p1; q2[e] = (__bf16)(r1 - (float)p1);
-                  }
-                  *reinterpret_cast<bf16x4*>(g.Cp + off) = q0;
-                  if (g.po > 1) *reinterpret_cast<bf16x4*>(g.Cp + g.c_stride + off) = q1;
-                  if (g.po > 2) *reinterpret_cast<bf16x4*>(g.Cp + 2 * g.c_stride + off) = q2;
+              const bool go = (DBG & 16) ? v[0] == 12345.678f : true;
+              if (go) {
+                p8_st128(g.Cp, out_bytes, off, __builtin_bit_cast(u32x4, q0));
+                if constexpr (PO > 1) {
+                  p8_st128(g.Cp + g.c_stride, out_bytes, off, __builtin_bit_cast(u32x4, q1));
+                  p8_st128(g.Cp + 2 * g.c_stride, out_bytes, off, __builtin_bit_cast(u32x4, q2));
                 }
               }
             }
           }
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[ha][hw][mt][e] = 0.f;
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ha][hw][mt][e] = 0.f;
+      }
     }
-    // the stores share the vmcnt queue with the LDS-DMA in flight: retire them here so that the counted waits of the next tile's
-    // phases see DMA pieces only (their count is what makes those waits correct)
-    p8_wait_vmcnt<0>();
+    // The stores are NOT waited for.  They share the vmcnt queue with the LDS-DMA, in issue order: a wait of the next item's
+    // phases that must retire chunk c allows (its window of younger chunks) + (the stores issued between them) outstanding -
+    // for the L phases whose window still reaches back across this epilogue.  The count used, S_FULL / S_HALF, is at most the
+    // number of stores really issued (and there are loads on top): allowing FEWER than really sit behind c only waits for a few
+    // of the oldest epilogue operations as well, which finished long ago.
+    post_epi = L;
+    post_half = half;
   };
 
   // ---- prologue: chunks 0 .. D - 1 of the stream
@@ -381,28 +556,32 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     pro(std::integral_constant<int, 3>{}); pro(std::integral_constant<int, 4>{});
     if constexpr (D > 5) pro(std::integral_constant<int, 5>{});
     static_assert(D == 5 || D == 6, "prologue issues chunks 0 .. D - 1");
-    p8_wait_vmcnt<p8_window<P>(3, GCH)>();   // "phase -1": chunks D - L .. D - 1 may stay in flight
+    half_guard = d_half ? L + 1 : 0;
+    // "phase -1": chunks D - L .. D - 1 may stay in flight
+    if (DBG & 2) p8_wait_vmcnt<0>();
+    else if (d_half) p8_wait_vmcnt<p8_window<P>(3, GCH, true)>();
+    else p8_wait_vmcnt<p8_window<P>(3, GCH, false)>();
     __builtin_amdgcn_s_barrier();
   }
 
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-  int mb = t_begin / g.ntn, ns = t_begin % g.ntn;
-  for (int t = t_begin; t < t_end; ++t) {
+  for (int it = 0; it < n_items; ++it) {
+    int row0, n0;
+    item(it, row0, n0, c_half);
     if (grp1) __builtin_amdgcn_s_barrier();   // the second group runs one barrier interval behind
     for (int kk = 0; kk < nk; kk += 2) {
       phase(I0{}, I0{}); phase(I0{}, I1{}); phase(I0{}, I2{}); phase(I0{}, I3{});
       phase(I1{}, I0{}); phase(I1{}, I1{}); phase(I1{}, I2{}); phase(I1{}, I3{});
     }
     if (!grp1) __builtin_amdgcn_s_barrier();  // realign: both groups run their epilogues at the same time
-    epilogue(mb * 256, ns * BN);
-    if (++ns == g.ntn) { ns = 0; ++mb; }
+    epilogue(row0, n0, c_half);
   }
 }
 
-template <int P>
+template <int P, int EPI, int DBG = 0>
 static int launch_planes8(const P8Args& g, hipStream_t s) {
-  hipLaunchKernelGGL((gemm_planes8_kernel<P>), dim3(g.ncu), dim3(512), 0, s, g);
+  hipLaunchKernelGGL((gemm_planes8_kernel<P, EPI, DBG>), dim3(g.ncu), dim3(512), 0, s, g);
   TT_CHECK_LAUNCH("gemm_planes8");
   return TT_OK;
 }
@@ -414,10 +593,17 @@ int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_pl
                 hipStream_t s) {
   if (planes != 1 && planes != 3) return 1;
   const int BN = planes == 1 ? 256 : 128, BK = planes == 1 ? 64 : 32;
-  if (N % BN != 0 || K % (2 * BK) != 0 || M < 256) return 1;
-  if ((long long)M * K * 2 >= 0x7fffffffLL || (long long)N * K * 2 >= 0x7fffffffLL) return 1;                      // 32-bit buffer offsets
+  if (N % BN != 0 || K % (2 * BK) != 0 || M < 256 || !bias) return 1;
+  // epilogue kind
+  int epi = -1;
+  if (y && !y_planes && !act) epi = residual ? P8_F32_RES : P8_F32;
+  else if (!y && y_planes && !residual && planes == 1 && y_nplanes == 1) epi = act ? P8_BF16_GELU : P8_BF16;
+  else if (!y && y_planes && !residual && planes == 3 && y_nplanes == 3 && act) epi = P8_PL3_GELU;
+  if (epi < 0) return 1;
+  // 32-bit buffer offsets
   if ((long long)(planes - 1) * x_plane_stride * 2 + (long long)M * K * 2 >= 0x7fffffffLL) return 1;
   if ((long long)(planes - 1) * w_plane_stride * 2 + (long long)N * K * 2 >= 0x7fffffffLL) return 1;
+  if ((long long)M * N * 4 >= 0x7fffffffLL) return 1;
   const int ntm = (M + 255) / 256, ntn = N / BN;
   const long long ntiles = (long long)ntm * ntn;
   static const int ncu_dev = [] {
@@ -426,10 +612,56 @@ int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_pl
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
     return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
   }();
-  if (ntiles < (3 * ncu_dev) / 4) return 1;   // a persistent grid that cannot fill the chip: the small-tile kernel does better
+  if (ntiles < ncu_dev / 2) return 1;   // a persistent grid that cannot fill the chip: the small-tile kernel does better
+  // decomposition: R whole rounds of tiles over the CUs; the r tiles left over are cut into 2 r half tiles (one per workgroup)
+  // when that is a shorter tail than another whole round (2 r <= CUs), else the tiles are dealt as balanced contiguous runs
+  int ncu = (int)(ntiles < ncu_dev ? ntiles : ncu_dev), n_full = 0, n_half = 0;
+  const long long R = ntiles / ncu_dev, rem = ntiles - R * ncu_dev;
+  const bool no_half = getenv("TT_P8_NO_HALF") != nullptr;   // tuning aid (read per call: A/B in one process)
+  if (!no_half && rem > 0 && 2 * rem <= ncu_dev) {
+    ncu = ncu_dev;
+    n_full = (int)R;
+    n_half = (int)(2 * rem);
+  }
   P8Args g{static_cast<const __bf16*>(x_planes), static_cast<const __bf16*>(w_planes), x_plane_stride, w_plane_stride, M, N, K, bias, residual, y,
-           static_cast<__bf16*>(y_planes), y_plane_stride, y_nplanes, act, ntn, (int)ntiles, (int)(ntiles < ncu_dev ? ntiles : ncu_dev)};
-  return planes == 1 ? launch_planes8<1>(g, s) : launch_planes8<3>(g, s);
+           static_cast<__bf16*>(y_planes), y_plane_stride, ntn, (int)ntiles, ncu, n_full, n_half};
+#ifdef TT_P8_ABLATE   // timing-study build only (tools/build_variant.sh -DTT_P8_ABLATE): TT_P8_DBG selects a crippled instantiation
+  {
+    const char* e = getenv("TT_P8_DBG");
+    const int dbg = e ? atoi(e) : 0;
+#define P8_DBG_CASE(PV, EV)                                       \
+  if (planes == PV && epi == EV) {                                \
+    if (dbg == 1) return launch_planes8<PV, EV, 1>(g, s);         \
+    if (dbg == 2) return launch_planes8<PV, EV, 2>(g, s);         \
+    if (dbg == 4) return launch_planes8<PV, EV, 4>(g, s);         \
+    if (dbg == 8) return launch_planes8<PV, EV, 8>(g, s);         \
+    if (dbg == 16) return launch_planes8<PV, EV, 16>(g, s);       \
+    if (dbg == 11) return launch_planes8<PV, EV, 11>(g, s);       \
+    if (dbg == 13) return launch_planes8<PV, EV, 13>(g, s);       \
+    if (dbg == 14) return launch_planes8<PV, EV, 14>(g, s);       \
+    if (dbg == 15) return launch_planes8<PV, EV, 15>(g, s);       \
+    if (dbg == 9) return launch_planes8<PV, EV, 9>(g, s);         \
+  }
+    P8_DBG_CASE(1, P8_BF16) P8_DBG_CASE(1, P8_BF16_GELU) P8_DBG_CASE(1, P8_F32_RES)
+    P8_DBG_CASE(3, P8_F32) P8_DBG_CASE(3, P8_F32_RES) P8_DBG_CASE(3, P8_PL3_GELU)
+#undef P8_DBG_CASE
+  }
+#endif
+  if (planes == 1) {
+    switch (epi) {
+      case P8_BF16: return launch_planes8<1, P8_BF16>(g, s);
+      case P8_BF16_GELU: return launch_planes8<1, P8_BF16_GELU>(g, s);
+      case P8_F32: return launch_planes8<1, P8_F32>(g, s);
+      case P8_F32_RES: return launch_planes8<1, P8_F32_RES>(g, s);
+      default: return 1;
+    }
+  }
+  switch (epi) {
+    case P8_F32: return launch_planes8<3, P8_F32>(g, s);
+    case P8_F32_RES: return launch_planes8<3, P8_F32_RES>(g, s);
+    case P8_PL3_GELU: return launch_planes8<3, P8_PL3_GELU>(g, s);
+    default: return 1;
+  }
 }
 
 }  // namespace tt

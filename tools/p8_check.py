@@ -19,8 +19,11 @@ def check():
     cases = []
     for P in (1, 3):
         BN = 256 if P == 1 else 128
-        for (M, N, K) in [(25216, 3 * BN, 256), (50000, BN, 128), (197 * 130 + 7, 2 * BN, 384), (25216, 9 * BN if P == 1 else 9 * BN, 768 if P == 1 else 384)]:
-            for (act, po, res) in [(0, 0, 0), (1, P, 0), (0, 0, 1), (0, P, 1)]:
+        # tile counts: 297 (1 round + 82 half tiles), 196 (balanced runs, grid not a multiple of 8), 202 (balanced), 891 (3 rounds + 246
+        # half tiles), 128 (half tiles only), 512 (two whole rounds)
+        for (M, N, K) in [(25216, 3 * BN, 256), (50000, BN, 128), (197 * 130 + 7, 2 * BN, 384), (25216, 9 * BN, 768 if P == 1 else 384),
+                          (32768, BN, 256), (16384, 8 * BN, 128)]:
+            for (act, po, res) in ([(0, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1)] if P == 1 else [(0, 0, 0), (1, 3, 0), (0, 0, 1), (0, 3, 1)]):
                 cases.append((P, M, N, K, act, po, res))
     for (P, M, N, K, act, po, res) in cases:
         x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda") * 0.1
@@ -65,18 +68,20 @@ def timeit():
             x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda")
             r = torch.randn(M, N, device="cuda") if res else None
             xp, wp = ops.split_planes(x, P), ops.split_planes(w, P)
-            ts = {0: [], 10: []}
+            variants = {"new": dict(TT_PLANES_VARIANT="0"), "new,no half tiles": dict(TT_PLANES_VARIANT="0", TT_P8_NO_HALF="1"), "old": dict(TT_PLANES_VARIANT="10")}
+            ts = {k: [] for k in variants}
             for rd in range(10):
-                for v in (0, 10):
-                    os.environ["TT_PLANES_VARIANT"] = str(v)
+                for k, env in variants.items():
+                    os.environ.pop("TT_P8_NO_HALF", None)
+                    os.environ.update(env)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(10): ops.linear_fwd_planes(xp, wp, b, residual=r, act=act, out_f32=(po == 0 or res), out_planes=po, out=r)
                     e1.record(); torch.cuda.synchronize()
-                    if rd >= 3: ts[v].append(e0.elapsed_time(e1) * 1e2)
-            n, o = statistics.median(ts[0]), statistics.median(ts[10])
+                    if rd >= 3: ts[k].append(e0.elapsed_time(e1) * 1e2)
+            os.environ.pop("TT_P8_NO_HALF", None)
             nprod = P * (P + 1) // 2
-            print(f"P={P} {name:5s} N={N:5d} K={K:5d}: new {n:7.1f} us ({2.0 * M * N * K * nprod / n / 1e6:7.0f} TF/s raw bf16) | old {o:7.1f} us ({2.0 * M * N * K * nprod / o / 1e6:7.0f})", flush=True)
+            print(f"P={P} {name:5s} N={N:5d} K={K:5d}: " + " | ".join(f"{k} {statistics.median(v):7.1f} us ({2.0 * M * N * K * nprod / statistics.median(v) / 1e6:5.0f})" for k, v in ts.items()) + "   (TF/s raw bf16)", flush=True)
 
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "check"

@@ -3,7 +3,9 @@
 # usage (on the GPU box, from the repo root): bash tools/pmc_gemm.sh "25216,1536,384,1"
 cd /tmp && export TMPDIR=/tmp
 SHAPE=${1:-25216,1536,384,1}
-OUT=/root/repo/gpurun_out/pmc_gemm
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export R
+OUT=$R/gpurun_out/pmc_gemm
 mkdir -p $OUT
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM" \
@@ -13,11 +15,11 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
            "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -o p -- python3 /root/repo/tools/gemm_shapes.py $SHAPE > $OUT/g$i.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -o p -- python3 $R/tools/gemm_shapes.py $SHAPE > $OUT/g$i.log 2>&1
 done
 python3 - <<'PY'
-import csv, glob, collections
-for d in sorted(glob.glob('/root/repo/gpurun_out/pmc_gemm/g*/')):
+import csv, glob, collections, os
+for d in sorted(glob.glob(os.environ['R'] + '/gpurun_out/pmc_gemm/g*/')):
     for f in glob.glob(d + '**/*counter_collection.csv', recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
         for r in csv.DictReader(open(f)):
