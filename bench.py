@@ -47,6 +47,8 @@ def kernel_label(name, tile):
         return f"gemm_nt_fast_kernel<{TILE_NAMES[tile]}> (forward nn.Linear, whole tiles)"
     if name == "NTbf16":
         return f"gemm_nt_bf16_kernel<{TILE_NAMES[tile]}> (forward nn.Linear, fp32 operands converted while staged)"
+    if name.startswith("PLANES8_"):
+        return f"gemm_planes8_kernel<P={name[8:]}> (forward nn.Linear on bf16-plane operands, persistent 8-phase kernel)"
     if name.startswith("PLANES"):
         return f"gemm_planes_kernel<P={name[6:]}> (forward nn.Linear on bf16-plane operands)"
     fam = {"NN": "dgrad (dy @ w)", "TN": "wgrad (dy^T @ x, split-K)", "patch": "patch embed", "NTgen": "forward nn.Linear, general kernel"}.get(name, name)
@@ -121,36 +123,102 @@ def rccl_report(dist, waits):
             "bytes": sum(w["bytes"] for w in waits), "exposed_wait_ms": round(sum(w["exposed_wait_ms"] for w in waits), 4), "waits": waits}
 
 
-def single_rank_exchange_probe(model, opt, x, use_teacher, device):
-    """Untimed, after the measurement, 1-GPU runs only: joins a ONE-rank ``nccl`` process group and runs the step with
-    TT_EXCHANGE_SINGLE_RANK=1, i.e. with the very RCCL calls of an N-GPU run (1 asynchronous all-gather of the score rows + the
+def single_rank_exchange_probe_child(a):
+    """Child process of the 1-GPU bench (``--exchange_probe_child``): joins a ONE-rank ``nccl`` process group and runs the configured step
+    with TT_EXCHANGE_SINGLE_RANK=1, i.e. with the very RCCL calls of an N-GPU run (1 asynchronous all-gather of the score rows + the
     gradient buckets' asynchronous all-reduces, engine.exchange_group) on a one-rank communicator - RCCL refuses two ranks on one
-    device, so this is how a 1-GPU box exercises the exchange and the ``rccl`` fields an 8-GPU line will carry."""
+    device, so this is how a 1-GPU box exercises the exchange and the ``rccl`` fields an 8-GPU line will carry.  Prints one JSON object."""
     import torch.distributed as dist
+
+    from timetuning_amd import hip_ops, synth
+    from timetuning_amd.my_utils import cosine_scheduler
+    from timetuning_amd.time_tuning import SwavOptimizer
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ["MASTER_PORT"] = str(_free_port())
     os.environ["TT_EXCHANGE_SINGLE_RANK"] = "1"
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    dist.init_process_group(backend="nccl", init_method="env://", world_size=1, rank=0, device_id=device)
+    bs, fs, K = a.batch_size, a.num_frames, a.num_clusters
+    model = build_model(a.architecture, K, device)
+    opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, 1, 64), 64, 1)
+    if a.use_teacher:
+        model.init_momentum_teacher()
+        model.set_momentum_teacher_schedular_params(0.995, 1.0, 1, 64)
+    if a.use_queue:
+        model.init_queue(a.queue_size)
+        model.set_queue(torch.nn.functional.normalize(torch.randn_like(model.queue), dim=1))
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1)).to(device)
+    hip_ops.set_gemm_precision(a.precision)
+    for _ in range(3):
+        train_step(model, opt, x, a.use_teacher)
+    torch.cuda.synchronize()
+    instrumented_step(model, opt, x, a.use_teacher)
+    out = rccl_report(dist, instrumented_step.rccl)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        train_step(model, opt, x, a.use_teacher)
+    torch.cuda.synchronize()
+    out["ms_per_step_with_exchange"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+    out["note"] = "one-rank communicator on one GPU (TT_EXCHANGE_SINGLE_RANK=1): same calls, no peer; separate process, not part of `value`"
+    print(json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
+def single_rank_exchange_probe(argv, timeout_s=240):
+    """Runs ``single_rank_exchange_probe_child`` in a fresh child process (a fresh interpreter started with subprocess - never a re-exec of this
+    process, which has initialised the GPU) and returns its JSON object; a child that crashes, hangs or cannot initialise RCCL costs an
+    ``error`` entry, never the bench line."""
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=1, rank=0, device_id=device)
-        for _ in range(2):
-            train_step(model, opt, x, use_teacher)
-        torch.cuda.synchronize()
-        instrumented_step(model, opt, x, use_teacher)
-        out = rccl_report(dist, instrumented_step.rccl)
-        t0 = time.perf_counter()
-        for _ in range(5):
-            train_step(model, opt, x, use_teacher)
-        torch.cuda.synchronize()
-        out["ms_per_step_with_exchange"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
-        out["note"] = "one-rank communicator on one GPU (TT_EXCHANGE_SINGLE_RANK=1): same calls, no peer; not part of `value`"
-        return out
-    except Exception as e:  # a box whose RCCL cannot initialise must not cost the bench line
-        return {"error": f"{type(e).__name__}: {e}"}
-    finally:
-        os.environ.pop("TT_EXCHANGE_SINGLE_RANK", None)
-        if dist.is_initialized():
-            dist.destroy_process_group()
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), *argv, "--exchange_probe_child"], env=env, capture_output=True, text=True,
+                           timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"probe child exceeded {timeout_s} s"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"probe child exited with {r.returncode}: {r.stderr.strip().splitlines()[-1][:300] if r.stderr.strip() else 'no output'}"}
+    return json.loads(lines[-1])
+
+
+def roofline_block(prof, step_seconds, precision):
+    """The `roofline` object of a line: the GEMM instantiation with the largest time share of the instrumented step, its algorithmic
+    flops / its HIP-event durations, against the peak of the arithmetic it runs in."""
+    (dom_name, dom_tile), (cnt, flops, sec) = max(prof.items(), key=lambda kv: kv[1][2])
+    all_flops = sum(v[1] for v in prof.values())
+    all_sec = sum(v[2] for v in prof.values())
+    # peak the dominant kernel is priced against: dense f32 MFMA, or dense bf16 MFMA / the MFMAs it issues per product term
+    peak = {"PLANES1": BF16_MATRIX_PEAK_TFLOPS, "PLANES2": BF16_MATRIX_PEAK_TFLOPS / 3, "PLANES3": BF16_MATRIX_PEAK_TFLOPS / 6,
+            "PLANES8_1": BF16_MATRIX_PEAK_TFLOPS, "PLANES8_3": BF16_MATRIX_PEAK_TFLOPS / 6,
+            "NTbf16": BF16_MATRIX_PEAK_TFLOPS / (3 if precision == "bf16x3" else 1)}.get(dom_name, F32_MATRIX_PEAK_TFLOPS)
+    # HBM bytes per launch of the dominant kernel from the committed PMC pass (tools/pmc_traffic.py) - only when that pass
+    # measured THIS kernel
+    traffic = traffic_git_head = None
+    tpath = os.path.join(REPO, "profiles", "dominant_kernel_traffic.json")
+    if os.path.isfile(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("kernel_label", "gemm_nt_fast_kernel<64x128>") in kernel_label(dom_name, dom_tile):
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_git_head = tj.get("git_head")
+    return {"bound": "mfma", "precision": precision,
+            "kernel": kernel_label(dom_name, dom_tile), "launches_per_step": cnt,
+            "achieved": round(flops / sec / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(flops / sec / 1e12 / peak, 4), "traffic": traffic,
+            # NOT a counter of this run: HBM bytes per launch of this kernel from the committed PMC passes
+            "traffic_source": None if traffic is None else "profiles/dominant_kernel_traffic.json (rocprofv3 --pmc, separate passes)",
+            "traffic_git_head": traffic_git_head,
+            "avg_launch_us": round(sec / cnt * 1e6, 2),
+            "all_gemm_tflops": round(all_flops / all_sec / 1e12, 2),
+            "gemm_share_of_step": round(all_sec / step_seconds, 3),
+            # every GEMM family of the step (forward Linears, dgrad "NN", wgrad "TN", patch embed, plane kernels): launches,
+            # achieved TFLOP/s on algorithmic flops, share of the step - the dominant one is the roofline kernel above
+            "by_kernel": by_label(prof, step_seconds)}
 
 
 def sinkhorn_rate(device, B=6272, K=200, iters=10, reps=30):
@@ -327,9 +395,13 @@ def main():
                          "hip_ops.set_gemm_precision documents the others)")
     ap.add_argument("--no_alt_precision", action="store_true", help="skip the secondary bf16x3 / bf16 measurements")
     ap.add_argument("--no_exchange_probe", action="store_true", help="skip the one-rank RCCL probe of the exchange path (1-GPU runs)")
+    ap.add_argument("--exchange_probe_child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     global USE_MASK
     USE_MASK = a.use_mask
+
+    if a.exchange_probe_child:
+        return single_rank_exchange_probe_child(a)
 
     # ---- N > 1 without an external launcher: this process only starts the N rank processes (before any GPU call)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -374,7 +446,7 @@ def main():
         model.set_momentum_teacher_schedular_params(0.995, 1.0, 1, total_steps)
     if a.use_queue:
         model.init_queue(a.queue_size // world)
-        model.queue.copy_(torch.nn.functional.normalize(torch.randn_like(model.queue), dim=1))
+        model.set_queue(torch.nn.functional.normalize(torch.randn_like(model.queue), dim=1))
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1 + rank)).to(device)  # resident in HBM before timing
 
     from timetuning_amd import hip_ops
@@ -427,23 +499,13 @@ def main():
                 dt = float(tt_.item())
             alt[mode] = {"clip_frames_per_sec": round(world * bs * fs * 5 / dt, 1), "ms_per_step": round(dt / 5 * 1e3, 3), "loss": round(float(la.item()), 5),
                          "note": ALT_NOTES[mode]}
+            if mode == "bf16x6":   # the fp32-accurate mode carries its own roofline block (its dominant kernel is the plane GEMM)
+                aprof = instrumented_step(model, opt, x, a.use_teacher)
+                if rank == 0:
+                    alt[mode]["roofline"] = roofline_block(aprof, dt / 5, mode)
         hip_ops.set_gemm_precision("f32")
     if rank == 0:
-        (dom_name, dom_tile), (cnt, flops, sec) = max(prof.items(), key=lambda kv: kv[1][2])
-        all_flops = sum(v[1] for v in prof.values())
-        all_sec = sum(v[2] for v in prof.values())
-        # peak the dominant kernel is priced against: dense f32 MFMA, or dense bf16 MFMA / the MFMAs it issues per product term
-        peak = {"PLANES1": BF16_MATRIX_PEAK_TFLOPS, "PLANES2": BF16_MATRIX_PEAK_TFLOPS / 3, "PLANES3": BF16_MATRIX_PEAK_TFLOPS / 6,
-                "NTbf16": BF16_MATRIX_PEAK_TFLOPS / (3 if a.precision == "bf16x3" else 1)}.get(dom_name, F32_MATRIX_PEAK_TFLOPS)
-        # HBM bytes per launch of the dominant kernel from the committed PMC pass (tools/pmc_traffic.py) - only when that pass
-        # measured THIS kernel
-        traffic = traffic_git_head = None
-        tpath = os.path.join(REPO, "profiles", "dominant_kernel_traffic.json")
-        if os.path.isfile(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("kernel_label", "gemm_nt_fast_kernel<64x128>") in kernel_label(dom_name, dom_tile):
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_git_head = tj.get("git_head")
+        roof = roofline_block(prof, elapsed / a.steps, a.precision)
         sk_rate, sk_gbs, sk_swept = sinkhorn_rate(device) if world == 1 else (None, None, None)
         workload = ("C2: " if (a.architecture, bs, fs, K, a.use_teacher, a.use_queue) == ("dino-s16", 32, 4, 200, False, False) else
                     "C3 (per-GPU share): " if (a.architecture, bs, fs, K, a.use_teacher, a.use_queue) == ("dino-s16", 32, 4, 200, True, True) else
@@ -462,19 +524,7 @@ def main():
             # proof of what carried the exchange: RCCL ("nccl") saw this many ranks (None for the single-process run)
             # with the compute stream's exposed wait per collective in the instrumented step
             "rccl": rccl_report(dist, instrumented_step.rccl) if world > 1 else None,
-            "roofline": {"bound": "mfma", "precision": a.precision,
-                         "kernel": kernel_label(dom_name, dom_tile), "launches_per_step": cnt,
-                         "achieved": round(flops / sec / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(flops / sec / 1e12 / peak, 4), "traffic": traffic,
-                         # NOT a counter of this run: HBM bytes per launch of this kernel from the committed PMC passes
-                         "traffic_source": None if traffic is None else "profiles/dominant_kernel_traffic.json (rocprofv3 --pmc, separate passes)",
-                         "traffic_git_head": traffic_git_head,
-                         "avg_launch_us": round(sec / cnt * 1e6, 2),
-                         "all_gemm_tflops": round(all_flops / all_sec / 1e12, 2),
-                         "gemm_share_of_step": round(all_sec / (elapsed / a.steps), 3),
-                         # every GEMM family of the step (forward Linears, dgrad "NN", wgrad "TN", patch embed, plane kernels): launches,
-                         # achieved TFLOP/s on algorithmic flops, share of the step - the dominant one is the roofline kernel above
-                         "by_kernel": by_label(prof, elapsed / a.steps)},
+            "roofline": roof,
             "alt_precision": alt or None,
             "sinkhorn": None if sk_rate is None else {"iters_per_sec": round(sk_rate, 1), "algorithmic_GBps": round(sk_gbs, 1),
                                                       "swept_GBps": round(sk_swept, 1),
@@ -487,9 +537,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         if world == 1 and not a.no_exchange_probe:
-            hip_ops.set_gemm_precision(a.precision)
-            out["rccl_single_rank_probe"] = single_rank_exchange_probe(model, opt, x, a.use_teacher, device)
-            hip_ops.set_gemm_precision("f32")
+            out["rccl_single_rank_probe"] = single_rank_exchange_probe([v for v in sys.argv[1:] if v != "--exchange_probe_child"])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

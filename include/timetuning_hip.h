@@ -75,6 +75,10 @@ int tt_gemm_tile_choice(int M, int N, int batch);
 /* Which kernel an fp32 tt_linear_fwd of this shape runs: bits 0-1 tile (0 128x128, 1 64x128, 2 128x64, 3 64x64), bit 8 set = the
  * lean whole-tile instance (gemm_nt_fast_kernel), clear = the general kernel.  For profilers' labels only. */
 int tt_linear_fwd_route(int M, int N, int K);
+/* Which kernel a tt_linear_fwd_planes call with these arguments runs: 8 = the persistent 8-phase kernel (gemm_planes8_kernel: whole
+ * 256-wide column tiles, a grid that fills the chip, one of its compiled epilogues), 0 = gemm_planes_kernel.  For profilers' labels only. */
+int tt_linear_fwd_planes_route(int planes, int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int y_nplanes,
+                               int has_pre_out);
 
 /* ---- k1b: interpolate_pos_encoding for inputs whose token grid differs from the stored one
  *      (dino_vision_transformer.py:214-234): bicubic resampling of the patch position table, as

@@ -56,11 +56,17 @@ def _worker(rank, W, port, ret, backend="gloo"):
     dist.init_process_group(backend, rank=rank, world_size=W)
     model = DistributedDataParallelModel(_model(), dev)
     x = torch.from_numpy(synth.make_clips(BS, FS, 224, seed=11 + rank)).cuda()
+    from timetuning_amd import engine
+
+    engine.RCCL_PROFILE = []   # every wait of the compute stream on a collective: (kind, payload bytes, events)
     loss = model(x, None, True, False)
     loss.backward()
+    torch.cuda.synchronize()
+    waits, engine.RCCL_PROFILE = engine.RCCL_PROFILE, None
     params = dict(model.get_non_ddp_model().named_parameters())
     ret[rank] = dict(loss=float(loss.item()), grads={n: params[n].grad.cpu().numpy() for n in WATCH},
-                     q=model.last_aux["q"].cpu().numpy())
+                     q=model.last_aux["q"].cpu().numpy(), waits=[(k, n, e0.elapsed_time(e1)) for k, n, e0, e1 in waits],
+                     trainable=sum(p.numel() for p in model.get_non_ddp_model().parameters() if p.requires_grad))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -83,6 +89,14 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(backend):
     [p.start() for p in procs]
     [p.join(500) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    # the exchange each rank issued: ONE all-gather of the score rows of all ranks, FOUR gradient buckets that carry every trainable
+    # float exactly once, and a (non-negative) exposed wait of the compute stream measured for each
+    for r in range(W):
+        waits = ret[r]["waits"]
+        assert [k for k, _, _ in waits] == ["all_gather(scores)"] + [f"all_reduce(grad bucket {i})" for i in range(4)], waits
+        assert waits[0][1] == W * BS * 196 * K * 4
+        assert sum(n for _, n, _ in waits[1:]) == 4 * ret[r]["trainable"]
+        assert all(ms >= 0 for _, _, ms in waits)
 
     model = _model()
     x_all = torch.from_numpy(np.concatenate([synth.make_clips(BS, FS, 224, seed=11 + r) for r in range(W)], axis=0)).cuda()
@@ -197,7 +211,16 @@ def test_bench_gpus_2_through_its_own_launcher():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
-    assert out["rccl"] == {"world_size": 2, "backend": "gloo"}
+    rc = out["rccl"]
+    assert rc["world_size"] == 2 and rc["backend"] == "gloo"
+    # the exchange of the instrumented step: ONE all-gather of the score rows (2 ranks x 2 clips x 196 patches x 50 prototypes, fp32)
+    # and the gradient buckets' all-reduces (every trainable float exactly once), each with the compute stream's exposed wait
+    kinds = [w["collective"] for w in rc["waits"]]
+    assert kinds[0] == "all_gather(scores)" and rc["waits"][0]["bytes"] == 2 * 2 * 196 * 50 * 4
+    buckets = [w for w in rc["waits"] if w["collective"].startswith("all_reduce(grad bucket")]
+    assert len(buckets) == 4 and rc["collectives_per_step"] == 5
+    assert sum(w["bytes"] for w in buckets) == 4 * (5_700_096 - 200 * 256 + 50 * 256)          # 5.70 M trainable floats at K = 200
+    assert all(w["exposed_wait_ms"] >= 0 for w in rc["waits"]) and rc["exposed_wait_ms"] >= 0 and rc["bytes"] > 0
     assert out["value"] > 0 and out["scaling"] == "weak" and np.isfinite(out["loss"])
 
 

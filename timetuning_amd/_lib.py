@@ -57,6 +57,7 @@ SIGNATURES = {
     "tt_gemm_f32": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_ll, c_ll, c_ll, c_vp]),
     "tt_gemm_tile_choice": (c_i, [c_i, c_i, c_i]),
     "tt_linear_fwd_route": (c_i, [c_i, c_i, c_i]),
+    "tt_linear_fwd_planes_route": (c_i, [c_i] * 10),
     "tt_set_gemm_precision": (c_i, [c_i]),
     "tt_get_gemm_precision": (c_i, []),
     "tt_patch_embed_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),

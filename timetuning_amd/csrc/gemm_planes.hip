@@ -390,6 +390,7 @@ int launch_splitk_reduce(const float* partial, float* out, long long n, int spli
 int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes, const float* bias,
                 const float* residual, float* y, void* y_planes, long long y_plane_stride, int y_nplanes, int M, int N, int K, int act,
                 hipStream_t s);                                                                                       // gemm_planes8.hip
+int planes8_would_run(int planes, int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int y_nplanes);
 
 }  // namespace tt
 
@@ -419,6 +420,13 @@ static int linear_planes_impl(const void* x_planes, long long x_plane_stride, co
                               const float* bias, const float* residual, float* y, float* pre_out, void* y_planes,
                               long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, const float* gelu_pre, int splits,
                               long long split_stride, tt_stream_t stream);
+
+extern "C" int tt_linear_fwd_planes_route(int planes, int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int y_nplanes,
+                                          int has_pre_out) {
+  const char* e = getenv("TT_PLANES_VARIANT");
+  if ((e && atoi(e) != 0) || has_pre_out) return 0;
+  return planes8_would_run(planes, M, N, K, act, has_bias, has_residual, has_y, y_nplanes) ? 8 : 0;
+}
 
 extern "C" int tt_linear_fwd_planes(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes,
                                     const float* bias, const float* residual, float* y, float* pre_out, void* y_planes,

@@ -63,8 +63,9 @@ struct P8Args {
   long long c_stride;
   int ntn, ntiles, ncu;   // column tiles, whole tiles, workgroups launched
   int n_full;             // whole tiles per workgroup in the first part (tiles [0, n_full * ncu)); with n_half = 0 and n_full = 0:
-                          // balanced contiguous runs of all tiles
+                          // all tiles dealt round-robin
   int n_half;             // half tiles that follow (tiles [n_full * ncu, ntiles) cut in two): workgroup h < n_half takes half h
+  int clock_print;        // TT_P8_CLOCK diagnostic builds only
 };
 
 // Device helpers at namespace scope: the buffer builtins inside a generic lambda of the kernel template make clang's HOST pass
@@ -89,21 +90,27 @@ __device__ __forceinline__ void p8_wait_vmcnt() {
 }
 
 // ---- the schedule, per P.  A K-tile is 4 chunk slots issued one per phase; chunk i of K-tile t has stream index 4 t + i.
-template <int P>
+template <int P, bool DEEP>
 struct P8Cfg;
-template <>
-struct P8Cfg<1> {
-  static constexpr int BK = 64, NHW = 2, D = 6, L = 4, X1 = 3;
+template <bool DEEP>
+struct P8Cfg<1, DEEP> {
+  // DEEP: one more chunk in flight (5 x 16 KB per CU instead of 4): the L2 -> LDS stream is latency-bound on what may be outstanding
+  // (tools/p8_ablate.py: 64 KB in flight = 73 GB/s per CU).  The W0 chunk of K-tile t + 2 is then issued only ONE phase after the last
+  // read of W0 of K-tile t, which is legal because phase 0 retires its W0 reads (issued first) with lgkmcnt(8) BEFORE its barrier.
+  static constexpr int BK = 64, NHW = 2, D = DEEP ? 7 : 6, L = DEEP ? 5 : 4, X1 = 3;
+  static constexpr bool early_w0 = DEEP;
   // chunks in need order: W0, X0, W1, X1
   static constexpr bool exists(int i) { return true; }
   static constexpr bool is_x(int i) { return i & 1; }
   static constexpr int half(int i) { return i >> 1; }
   static constexpr int need(int i) { return i == 0 ? 0 : i - 1; }        // first phase (0..3) that reads the chunk
-  static constexpr int last_read(int i) { return i == 0 ? 0 : i - 1; }   // W0 / W1 fragments stay in registers for the K-tile
+  static constexpr int last_read(int i) { return i == 0 ? (DEEP ? -1 : 0) : i - 1; }   // W0 / W1 fragments stay in registers for the K-tile;
+                                                                                       // (-1: retired before phase 0's own barrier)
 };
-template <>
-struct P8Cfg<3> {
+template <bool DEEP>
+struct P8Cfg<3, DEEP> {
   static constexpr int BK = 32, NHW = 1, D = 5, L = 3, X1 = 2;
+  static constexpr bool early_w0 = false;
   // chunks: W, X0, X1, (none)
   static constexpr bool exists(int i) { return i < 3; }
   static constexpr bool is_x(int i) { return i >= 1; }
@@ -115,9 +122,9 @@ struct P8Cfg<3> {
 // Compile-time check of the two hazards for "phase f issues chunk f + D and then waits for all but the youngest L chunks":
 //   RAW  chunk h (needed at phase N(h)) must have been retired by the wait of phase N(h) - 1:  h <= N(h) - 1 + D - L
 //   WAR  chunk h of K-tile t + 2 is issued at phase h - D, which must be >= 2 phases after the last read of the same slot in K-tile t
-template <int P>
+template <int P, bool DEEP>
 constexpr bool p8_schedule_ok() {
-  using C = P8Cfg<P>;
+  using C = P8Cfg<P, DEEP>;
   for (int i = 0; i < 4; ++i) {
     if (!C::exists(i)) continue;
     if (!(i <= C::need(i) - 1 + C::D - C::L)) return false;
@@ -128,9 +135,9 @@ constexpr bool p8_schedule_ok() {
 // wave-instructions of the youngest L chunks after the issue of compute phase ph (chunks ph + D - L + 1 .. ph + D of the stream);
 // gch = wave-instructions per wave and chunk.  half: the X1 chunk is not issued (half tiles) - also the safe (smaller) count
 // while the window may still hold a slot of a half tile.
-template <int P>
+template <int P, bool DEEP>
 constexpr int p8_window(int ph, int gch, bool half) {
-  using C = P8Cfg<P>;
+  using C = P8Cfg<P, DEEP>;
   int n = 0;
   for (int k = 0; k < C::L; ++k) {
     const int idx = (ph + C::D - k) & 3;
@@ -138,13 +145,13 @@ constexpr int p8_window(int ph, int gch, bool half) {
   }
   return n;
 }
-static_assert(p8_schedule_ok<1>() && p8_schedule_ok<3>(), "LDS-DMA schedule violates a RAW / WAR rule");
+static_assert(p8_schedule_ok<1, false>() && p8_schedule_ok<1, true>() && p8_schedule_ok<3, false>(), "LDS-DMA schedule violates a RAW / WAR rule");
 
 // DBG (timing studies only, tools/p8_ablate.py; the shipped instantiations are DBG = 0), a bit mask: 1 no MFMAs, 2 no LDS-DMA, 4 no fragment
 // reads, 8 no epilogue (accumulators consumed by a dummy store), 16 epilogue without global loads / stores
-template <int P, int EPI, int DBG = 0>
+template <int P, int EPI, int DBG = 0, bool DEEP = false>
 __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
-  using CF = P8Cfg<P>;
+  using CF = P8Cfg<P, DEEP>;
   constexpr int BK = CF::BK, NHW = CF::NHW, D = CF::D, L = CF::L;
   constexpr int ROWB = BK * 2;              // bytes per LDS row
   constexpr int CPR = ROWB / 16;            // 16-byte chunks per row
@@ -174,6 +181,9 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   static_assert(RING_B + 8 * SCR_B <= 160 * 1024 && (CW == 32 || CW == 16), "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem[160 * 1024];
 
+#ifdef TT_P8_CLOCK   // diagnostic build only: the clock the chip holds under this kernel (s_memtime ticks per 100 MHz s_memrealtime tick)
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool grp1 = wave >= 4;
@@ -185,15 +195,17 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   // order, so an activation row block is fetched into one L2 while the weight strips stay hot in all of them.
   int cu = blockIdx.x;
   if ((g.ncu & 7) == 0) cu = (blockIdx.x & 7) * (g.ncu >> 3) + (blockIdx.x >> 3);
-  int t_begin, n_whole;
+  // Whole tiles are dealt INTERLEAVED: workgroup cu takes tiles cu, cu + ncu, cu + 2 ncu, ... of the row-major order (columns fastest),
+  // so at any time the 32 workgroups of an XCD work on 32 CONSECUTIVE tiles - every activation row block is being read by all the
+  // workgroups of its column strips at once and is fetched into that L2 once (contiguous runs per workgroup put them on different
+  // row blocks: round-3 PMC, L2 hit rate 63 %).
+  int n_whole;
   bool has_half = false;
   if (g.n_full > 0 || g.n_half > 0) {
-    t_begin = cu * g.n_full;
     n_whole = g.n_full;
     has_half = cu < g.n_half;
   } else {
-    t_begin = (int)(((long long)cu * g.ntiles) / g.ncu);
-    n_whole = (int)(((long long)(cu + 1) * g.ntiles) / g.ncu) - t_begin;
+    n_whole = cu < g.ntiles ? (g.ntiles - cu + g.ncu - 1) / g.ncu : 0;
   }
   const int n_items = n_whole + (has_half ? 1 : 0);
   if (n_items == 0) return;   // whole workgroup
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
       tile = g.n_full * g.ncu + (cu >> 1);
       hsel = cu & 1;
     } else {
-      tile = t_begin + (half_first ? it - 1 : it);
+      tile = (half_first ? it - 1 : it) * g.ncu + cu;
     }
     const int mb = tile / g.ntn, ns = tile - mb * g.ntn;
     row0 = mb * 256 + hsel * 128;
@@ -256,12 +268,15 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
       }
     }
   };
+  bool steady = false;   // see `phase`
   // issue chunk IDX of the cursor's K-tile into ring buffer B
   auto issue = [&](auto idx_c, auto buf_c) {
     constexpr int IDX = decltype(idx_c)::value, B = decltype(buf_c)::value;
     if constexpr (CF::exists(IDX) && !(DBG & 2)) {
-      if (d_done) return;
-      if (IDX == CF::X1 && d_half) return;
+      if (!steady) {   // steady state: the cursor is neither done nor in a half tile
+        if (d_done) return;
+        if (IDX == CF::X1 && d_half) return;
+      }
       constexpr int HA = CF::half(IDX);
       const int lds_base = B * BUF_B + IDX * HALF_B + wave * 1024;
 #pragma unroll
@@ -311,6 +326,10 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   bool c_half = false;       // the item being computed is a half tile
 
   // ---- one phase: [fragment reads | DMA issue | counted wait] barrier [MFMAs] barrier
+  // `steady` (set per pair of K-tiles by the main loop): nothing rare can happen in these phases - whole tile being computed, DMA cursor
+  // in a whole tile and not at the end of the stream, no stores of an epilogue left in the window - so ONE scalar branch skips all the
+  // bookkeeping: the load part is then fragment reads, the cursor's scalar adds, the DMA instructions and one counted wait.  (The general
+  // path carries ~10 scalar branches per phase; round-3 PMC showed the waves parked or issue-stalled for 72 % of their cycles.)
   auto phase = [&](auto buf_c, auto ph_c) {
     constexpr int B = decltype(buf_c)::value, PH = decltype(ph_c)::value;
     constexpr int base = B * BUF_B;
@@ -326,6 +345,10 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) Xf[mt][ks] = ld(base + 1 * HALF_B + x_slice + mt * 32 * ROWB + lo[ks]);
+          if constexpr (CF::early_w0) {   // the 4 W0 reads (issued first, LDS returns in order) have landed: their slot may be refilled next phase
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+          }
         } else if constexpr (PH == 1) {
 #pragma unroll
           for (int ks = 0; ks < NKS; ++ks) Wf[1][ks] = ld(base + 2 * HALF_B + w_slice + lo[ks]);
@@ -354,8 +377,11 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     if constexpr (CI == 0) cursor_next_ktile();
     issue(std::integral_constant<int, CI>{}, std::integral_constant<int, BT>{});
     // counted wait: everything but the youngest L chunks (and, for L phases behind an epilogue, its stores) has landed
+    constexpr int WF = p8_window<P, DEEP>(PH, GCH, false), WH = p8_window<P, DEEP>(PH, GCH, true);
+    if (steady && !(DBG & 2)) {
+      p8_wait_vmcnt<WF>();
+    } else {
     half_guard = (d_half && !d_done) ? L + 1 : (half_guard > 0 ? half_guard - 1 : 0);
-    constexpr int WF = p8_window<P>(PH, GCH, false), WH = p8_window<P>(PH, GCH, true);
     if (d_done || (DBG & 2)) {
       p8_wait_vmcnt<0>();
     } else if (post_epi > 0) {
@@ -367,11 +393,11 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     } else {
       p8_wait_vmcnt<WF>();
     }
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (work) {
-      __builtin_amdgcn_s_setprio(1);
       if constexpr (DBG & 1) {
         // keep the fragment reads alive without matrix work
 #pragma unroll
@@ -396,7 +422,6 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
             for (int pa = 0; pa <= s; ++pa)
               acc[HA][0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[KS][s - pa], Xf[mt][pa], acc[HA][0][mt], 0, 0, 0);
       }
-      __builtin_amdgcn_s_setprio(0);
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -555,12 +580,13 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     pro(std::integral_constant<int, 0>{}); pro(std::integral_constant<int, 1>{}); pro(std::integral_constant<int, 2>{});
     pro(std::integral_constant<int, 3>{}); pro(std::integral_constant<int, 4>{});
     if constexpr (D > 5) pro(std::integral_constant<int, 5>{});
-    static_assert(D == 5 || D == 6, "prologue issues chunks 0 .. D - 1");
+    if constexpr (D > 6) pro(std::integral_constant<int, 6>{});
+    static_assert(D >= 5 && D <= 7, "prologue issues chunks 0 .. D - 1");
     half_guard = d_half ? L + 1 : 0;
     // "phase -1": chunks D - L .. D - 1 may stay in flight
     if (DBG & 2) p8_wait_vmcnt<0>();
-    else if (d_half) p8_wait_vmcnt<p8_window<P>(3, GCH, true)>();
-    else p8_wait_vmcnt<p8_window<P>(3, GCH, false)>();
+    else if (d_half) p8_wait_vmcnt<p8_window<P, DEEP>(3, GCH, true)>();
+    else p8_wait_vmcnt<p8_window<P, DEEP>(3, GCH, false)>();
     __builtin_amdgcn_s_barrier();
   }
 
@@ -571,39 +597,50 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     item(it, row0, n0, c_half);
     if (grp1) __builtin_amdgcn_s_barrier();   // the second group runs one barrier interval behind
     for (int kk = 0; kk < nk; kk += 2) {
+      // steady for these 8 phases?  The cursor advances two K-tiles in them: it must stay in whole tiles and short of the end.
+      steady = post_epi == 0 && half_guard == 0 && !c_half && !d_half && !d_done;
+      if (steady && d_kt + 2 >= nk) {   // it crosses into the next item
+        bool nhalf = false;
+        if (d_item + 1 < n_items) { int r0_, n0_; item(d_item + 1, r0_, n0_, nhalf); }
+        steady = d_item + 1 < n_items && !nhalf;
+      }
       phase(I0{}, I0{}); phase(I0{}, I1{}); phase(I0{}, I2{}); phase(I0{}, I3{});
       phase(I1{}, I0{}); phase(I1{}, I1{}); phase(I1{}, I2{}); phase(I1{}, I3{});
     }
+    steady = false;
     if (!grp1) __builtin_amdgcn_s_barrier();  // realign: both groups run their epilogues at the same time
     epilogue(row0, n0, c_half);
   }
+#ifdef TT_P8_CLOCK
+  if (g.clock_print && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 101)) {
+    const unsigned long long dt = __builtin_amdgcn_s_memtime() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    printf("p8 clock: block %d  %llu cycles in %llu x 10 ns = %.3f GHz\n", (int)blockIdx.x, dt, dr, (double)dt / (double)dr * 0.1);
+  }
+#endif
 }
 
-template <int P, int EPI, int DBG = 0>
+template <int P, int EPI, int DBG = 0, bool DEEP = false>
 static int launch_planes8(const P8Args& g, hipStream_t s) {
-  hipLaunchKernelGGL((gemm_planes8_kernel<P, EPI, DBG>), dim3(g.ncu), dim3(512), 0, s, g);
+  hipLaunchKernelGGL((gemm_planes8_kernel<P, EPI, DBG, DEEP>), dim3(g.ncu), dim3(512), 0, s, g);
   TT_CHECK_LAUNCH("gemm_planes8");
   return TT_OK;
 }
 
-// Called by linear_planes_impl (gemm_planes.hip).  Returns TT_OK after a launch, 1 when the shape / epilogue is not this kernel's
-// (the caller then takes gemm_planes_kernel), < 0 on a launch error.
-int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes, const float* bias,
-                const float* residual, float* y, void* y_planes, long long y_plane_stride, int y_nplanes, int M, int N, int K, int act,
-                hipStream_t s) {
-  if (planes != 1 && planes != 3) return 1;
+// Shape / epilogue eligibility and the work decomposition.  Returns the epilogue kind or -1.
+static int planes8_plan(long long x_plane_stride, long long w_plane_stride, int planes, bool has_bias, bool has_residual, bool has_y, int y_nplanes,
+                        int M, int N, int K, int act, int* ntn_out, long long* ntiles_out, int* ncu_out, int* n_full_out, int* n_half_out) {
+  if (planes != 1 && planes != 3) return -1;
   const int BN = planes == 1 ? 256 : 128, BK = planes == 1 ? 64 : 32;
-  if (N % BN != 0 || K % (2 * BK) != 0 || M < 256 || !bias) return 1;
-  // epilogue kind
+  if (N % BN != 0 || K % (2 * BK) != 0 || M < 256 || !has_bias) return -1;
   int epi = -1;
-  if (y && !y_planes && !act) epi = residual ? P8_F32_RES : P8_F32;
-  else if (!y && y_planes && !residual && planes == 1 && y_nplanes == 1) epi = act ? P8_BF16_GELU : P8_BF16;
-  else if (!y && y_planes && !residual && planes == 3 && y_nplanes == 3 && act) epi = P8_PL3_GELU;
-  if (epi < 0) return 1;
+  if (has_y && !y_nplanes && !act) epi = has_residual ? P8_F32_RES : P8_F32;
+  else if (!has_y && !has_residual && planes == 1 && y_nplanes == 1) epi = act ? P8_BF16_GELU : P8_BF16;
+  else if (!has_y && !has_residual && planes == 3 && y_nplanes == 3 && act) epi = P8_PL3_GELU;
+  if (epi < 0) return -1;
   // 32-bit buffer offsets
-  if ((long long)(planes - 1) * x_plane_stride * 2 + (long long)M * K * 2 >= 0x7fffffffLL) return 1;
-  if ((long long)(planes - 1) * w_plane_stride * 2 + (long long)N * K * 2 >= 0x7fffffffLL) return 1;
-  if ((long long)M * N * 4 >= 0x7fffffffLL) return 1;
+  if ((long long)(planes - 1) * x_plane_stride * 2 + (long long)M * K * 2 >= 0x7fffffffLL) return -1;
+  if ((long long)(planes - 1) * w_plane_stride * 2 + (long long)N * K * 2 >= 0x7fffffffLL) return -1;
+  if ((long long)M * N * 4 >= 0x7fffffffLL) return -1;
   const int ntm = (M + 255) / 256, ntn = N / BN;
   const long long ntiles = (long long)ntm * ntn;
   static const int ncu_dev = [] {
@@ -612,9 +649,9 @@ int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_pl
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
     return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
   }();
-  if (ntiles < ncu_dev / 2) return 1;   // a persistent grid that cannot fill the chip: the small-tile kernel does better
+  if (ntiles < ncu_dev / 2) return -1;   // a persistent grid that cannot fill the chip: the small-tile kernel does better
   // decomposition: R whole rounds of tiles over the CUs; the r tiles left over are cut into 2 r half tiles (one per workgroup)
-  // when that is a shorter tail than another whole round (2 r <= CUs), else the tiles are dealt as balanced contiguous runs
+  // when that is a shorter tail than another whole round (2 r <= CUs), else all tiles are dealt round-robin
   int ncu = (int)(ntiles < ncu_dev ? ntiles : ncu_dev), n_full = 0, n_half = 0;
   const long long R = ntiles / ncu_dev, rem = ntiles - R * ncu_dev;
   const bool no_half = getenv("TT_P8_NO_HALF") != nullptr;   // tuning aid (read per call: A/B in one process)
@@ -623,8 +660,32 @@ int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_pl
     n_full = (int)R;
     n_half = (int)(2 * rem);
   }
+  *ntn_out = ntn; *ntiles_out = ntiles; *ncu_out = ncu; *n_full_out = n_full; *n_half_out = n_half;
+  return epi;
+}
+
+// Would tt_linear_fwd_planes with these arguments run gemm_planes8_kernel?  (profilers' labels: tt_linear_fwd_planes_route)
+int planes8_would_run(int planes, int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int y_nplanes) {
+  int ntn, ncu, n_full, n_half;
+  long long ntiles;
+  const long long xs = (long long)M * K, ws = (long long)N * K;
+  return planes8_plan(xs, ws, planes, has_bias != 0, has_residual != 0, has_y != 0, y_nplanes, M, N, K, act, &ntn, &ntiles, &ncu, &n_full, &n_half) >= 0;
+}
+
+// Called by linear_planes_impl (gemm_planes.hip).  Returns TT_OK after a launch, 1 when the shape / epilogue is not this kernel's
+// (the caller then takes gemm_planes_kernel), < 0 on a launch error.
+int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes, const float* bias,
+                const float* residual, float* y, void* y_planes, long long y_plane_stride, int y_nplanes, int M, int N, int K, int act,
+                hipStream_t s) {
+  int ntn, ncu, n_full, n_half;
+  long long ntiles;
+  if ((y != nullptr) == (y_planes != nullptr) && y) {}   // (y together with planes is not an epilogue of this kernel: the plan rejects it below)
+  const int epi = (y && y_planes) ? -1
+                                  : planes8_plan(x_plane_stride, w_plane_stride, planes, bias != nullptr, residual != nullptr, y != nullptr,
+                                                 y_planes ? y_nplanes : 0, M, N, K, act, &ntn, &ntiles, &ncu, &n_full, &n_half);
+  if (epi < 0) return 1;
   P8Args g{static_cast<const __bf16*>(x_planes), static_cast<const __bf16*>(w_planes), x_plane_stride, w_plane_stride, M, N, K, bias, residual, y,
-           static_cast<__bf16*>(y_planes), y_plane_stride, ntn, (int)ntiles, ncu, n_full, n_half};
+           static_cast<__bf16*>(y_planes), y_plane_stride, ntn, (int)ntiles, ncu, n_full, n_half, getenv("TT_P8_CLOCK_PRINT") != nullptr};
 #ifdef TT_P8_ABLATE   // timing-study build only (tools/build_variant.sh -DTT_P8_ABLATE): TT_P8_DBG selects a crippled instantiation
   {
     const char* e = getenv("TT_P8_DBG");
@@ -641,6 +702,8 @@ int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_pl
     if (dbg == 14) return launch_planes8<PV, EV, 14>(g, s);       \
     if (dbg == 15) return launch_planes8<PV, EV, 15>(g, s);       \
     if (dbg == 9) return launch_planes8<PV, EV, 9>(g, s);         \
+    if (dbg == 10) return launch_planes8<PV, EV, 10>(g, s);       \
+    if (dbg == 12) return launch_planes8<PV, EV, 12>(g, s);       \
   }
     P8_DBG_CASE(1, P8_BF16) P8_DBG_CASE(1, P8_BF16_GELU) P8_DBG_CASE(1, P8_F32_RES)
     P8_DBG_CASE(3, P8_F32) P8_DBG_CASE(3, P8_F32_RES) P8_DBG_CASE(3, P8_PL3_GELU)

@@ -711,10 +711,13 @@ def linear_fwd_planes(xp, wp, bias=None, residual=None, act: int = 0, out_f32: b
     y = (out if out is not None else torch.empty((M, N), dtype=f32, device=xp.device)) if out_f32 else None
     yp = torch.empty((out_planes, M, N), dtype=bf16, device=xp.device) if out_planes else None
     pre = torch.empty((M, N), dtype=f32, device=xp.device) if save_pre else None
+    # (profiled runs book the launch under the kernel that really runs it)
+    p8 = PROFILE is not None and lib.tt_linear_fwd_planes_route(P, M, N, K, int(act), int(bias is not None), int(residual is not None),
+                                                                int(y is not None), int(out_planes), int(pre is not None)) == 8
     e0 = _prof_begin()
     _lib.check(lib.tt_linear_fwd_planes(_p(xp), M * K, _p(wp), N * K, P, _p(bias), _p(residual), _p(y), _p(pre), _p(yp), M * N, int(out_planes),
                                         M, N, K, int(act), _stream()), "tt_linear_fwd_planes")
-    _prof_end(e0, f"PLANES{P}", M, N, K)
+    _prof_end(e0, f"PLANES8_{P}" if p8 else f"PLANES{P}", M, N, K)
     return dict(y=y, planes=yp, pre=pre)
 
 

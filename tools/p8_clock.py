@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""In-kernel clock of gemm_planes8 and of its crippled variants (tools/build_variant.sh p8clock gemm_planes8.hip -DTT_P8_ABLATE -DTT_P8_CLOCK):
+~1 s of back-to-back launches per variant, the last launch prints s_memtime / s_memrealtime."""
+import ctypes as C, os, sys, time, torch
+vp, ll, i32 = C.c_void_p, C.c_longlong, C.c_int
+lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libp8clock.so"))
+lib.tt_linear_fwd_planes.restype = C.c_int
+lib.tt_linear_fwd_planes.argtypes = [vp, ll, vp, ll, i32, vp, vp, vp, vp, vp, ll, i32, i32, i32, i32, i32, vp]
+lib.tt_split_planes.restype = C.c_int
+lib.tt_split_planes.argtypes = [vp, vp, ll, i32, ll, vp]
+st = torch.cuda.current_stream().cuda_stream
+def split(x, P):
+    out = torch.empty((P,) + tuple(x.shape), device="cuda", dtype=torch.bfloat16)
+    assert lib.tt_split_planes(x.data_ptr(), out.data_ptr(), x.numel(), P, x.numel(), st) == 0
+    return out
+for P, M, N, K, po in ((1, 25216, 2304, 768, 1), (3, 25216, 1152, 384, 0)):
+    x = split(torch.randn(M, K, device="cuda"), P); w = split(torch.randn(N, K, device="cuda") * 0.05, P); b = torch.randn(N, device="cuda")
+    y = torch.empty(M, N, device="cuda") if not po else None
+    yp = torch.empty(po, M, N, device="cuda", dtype=torch.bfloat16) if po else None
+    for dbg, name in ((0, "full"), (14, "MFMA only"), (9, "skeleton (no MFMA, no epilogue)"), (8, "no epilogue"), (10, "no epilogue, no DMA"), (12, "no epilogue, no LDS reads")):
+        os.environ["TT_P8_DBG"] = str(dbg)
+        print(f"== P={P} {name}", flush=True)
+        def go():
+            lib.tt_linear_fwd_planes(x.data_ptr(), M * K, w.data_ptr(), N * K, P, b.data_ptr(), None, y.data_ptr() if y is not None else None, None,
+                                     yp.data_ptr() if po else None, M * N, po, M, N, K, 0, st)
+        os.environ.pop("TT_P8_CLOCK_PRINT", None)
+        for _ in range(6000): go()      # ~0.6 s of back-to-back launches: the clock has settled
+        os.environ["TT_P8_CLOCK_PRINT"] = "1"
+        go()
+        torch.cuda.synchronize()
+        sys.stdout.flush()
