@@ -33,6 +33,15 @@
 // LDS images and the fragment / DMA lane maps are those of gemm_planes.hip (rows of BK bf16, 16-byte chunks XOR-swizzled through
 // the per-lane SOURCE address; conflict-free ds_read_b128 for v_mfma_f32_32x32x16_bf16).
 //
+// Measured and dropped (profiles/r03_p8_variants.txt): s_setprio around the MFMA clusters (+8 % time here - the clusters are pinned by
+// sched_barrier anyway), a fifth chunk in flight (D = 7, L = 5 with phase 0 retiring its W0 reads before its barrier: +-1 %), the nt
+// cache policy on either LDS-DMA stream (3-60 % slower), a start delay for the workgroups with slack (no gain), and the cursor / DMA issue /
+// counted wait moved into the MFMA part of the phase so that the load part is fragment reads only (D = 7 / 6 at the same L: 13-16 %
+// SLOWER - a DMA instruction that waits for the texture path blocks the in-order wave's next MFMAs).
+// Where the time goes now (profiles/r03_p8_clock.txt, r03_p8_ablation.txt): in CYCLES the main loop is at 72 % (P = 1) / 86 % (P = 3) of
+// the MFMA-only cycle count; the fragment reads cost no cycles beside the MFMAs but pull the clock from 2.4 to ~1.85 GHz (MFMA + LDS reads
+// alone: same cycles, 1.85 GHz), so the wall-clock gap to the nominal peak is mostly the power the chip has for LDS reads + MFMAs.
+//
 // Round-3 measurements that shaped it (tools/p8_ablate.py, profiles/r03_p8_ablation.txt): first version 841 / 744 TFLOP/s on
 // ViT-B/16's qkv / fc2 (gemm_planes_kernel: 627 / 701); its epilogue - a chain of runtime branches with every residual load
 // consumed at once, an IEEE division inside the GELU (__frcp_rn) and a vmcnt(0) behind the stores, all CUs in lockstep - was
@@ -90,27 +99,21 @@ __device__ __forceinline__ void p8_wait_vmcnt() {
 }
 
 // ---- the schedule, per P.  A K-tile is 4 chunk slots issued one per phase; chunk i of K-tile t has stream index 4 t + i.
-template <int P, bool DEEP>
+template <int P>
 struct P8Cfg;
-template <bool DEEP>
-struct P8Cfg<1, DEEP> {
-  // DEEP: one more chunk in flight (5 x 16 KB per CU instead of 4): the L2 -> LDS stream is latency-bound on what may be outstanding
-  // (tools/p8_ablate.py: 64 KB in flight = 73 GB/s per CU).  The W0 chunk of K-tile t + 2 is then issued only ONE phase after the last
-  // read of W0 of K-tile t, which is legal because phase 0 retires its W0 reads (issued first) with lgkmcnt(8) BEFORE its barrier.
-  static constexpr int BK = 64, NHW = 2, D = DEEP ? 7 : 6, L = DEEP ? 5 : 4, X1 = 3;
-  static constexpr bool early_w0 = DEEP;
+template <>
+struct P8Cfg<1> {
+  static constexpr int BK = 64, NHW = 2, D = 6, L = 4, X1 = 3;
   // chunks in need order: W0, X0, W1, X1
   static constexpr bool exists(int i) { return true; }
   static constexpr bool is_x(int i) { return i & 1; }
   static constexpr int half(int i) { return i >> 1; }
   static constexpr int need(int i) { return i == 0 ? 0 : i - 1; }        // first phase (0..3) that reads the chunk
-  static constexpr int last_read(int i) { return i == 0 ? (DEEP ? -1 : 0) : i - 1; }   // W0 / W1 fragments stay in registers for the K-tile;
-                                                                                       // (-1: retired before phase 0's own barrier)
+  static constexpr int last_read(int i) { return i == 0 ? 0 : i - 1; }   // W0 / W1 fragments stay in registers for the K-tile
 };
-template <bool DEEP>
-struct P8Cfg<3, DEEP> {
+template <>
+struct P8Cfg<3> {
   static constexpr int BK = 32, NHW = 1, D = 5, L = 3, X1 = 2;
-  static constexpr bool early_w0 = false;
   // chunks: W, X0, X1, (none)
   static constexpr bool exists(int i) { return i < 3; }
   static constexpr bool is_x(int i) { return i >= 1; }
@@ -122,9 +125,9 @@ struct P8Cfg<3, DEEP> {
 // Compile-time check of the two hazards for "phase f issues chunk f + D and then waits for all but the youngest L chunks":
 //   RAW  chunk h (needed at phase N(h)) must have been retired by the wait of phase N(h) - 1:  h <= N(h) - 1 + D - L
 //   WAR  chunk h of K-tile t + 2 is issued at phase h - D, which must be >= 2 phases after the last read of the same slot in K-tile t
-template <int P, bool DEEP>
+template <int P>
 constexpr bool p8_schedule_ok() {
-  using C = P8Cfg<P, DEEP>;
+  using C = P8Cfg<P>;
   for (int i = 0; i < 4; ++i) {
     if (!C::exists(i)) continue;
     if (!(i <= C::need(i) - 1 + C::D - C::L)) return false;
@@ -135,9 +138,9 @@ constexpr bool p8_schedule_ok() {
 // wave-instructions of the youngest L chunks after the issue of compute phase ph (chunks ph + D - L + 1 .. ph + D of the stream);
 // gch = wave-instructions per wave and chunk.  half: the X1 chunk is not issued (half tiles) - also the safe (smaller) count
 // while the window may still hold a slot of a half tile.
-template <int P, bool DEEP>
+template <int P>
 constexpr int p8_window(int ph, int gch, bool half) {
-  using C = P8Cfg<P, DEEP>;
+  using C = P8Cfg<P>;
   int n = 0;
   for (int k = 0; k < C::L; ++k) {
     const int idx = (ph + C::D - k) & 3;
@@ -145,13 +148,13 @@ constexpr int p8_window(int ph, int gch, bool half) {
   }
   return n;
 }
-static_assert(p8_schedule_ok<1, false>() && p8_schedule_ok<1, true>() && p8_schedule_ok<3, false>(), "LDS-DMA schedule violates a RAW / WAR rule");
+static_assert(p8_schedule_ok<1>() && p8_schedule_ok<3>(), "LDS-DMA schedule violates a RAW / WAR rule");
 
 // DBG (timing studies only, tools/p8_ablate.py; the shipped instantiations are DBG = 0), a bit mask: 1 no MFMAs, 2 no LDS-DMA, 4 no fragment
 // reads, 8 no epilogue (accumulators consumed by a dummy store), 16 epilogue without global loads / stores
-template <int P, int EPI, int DBG = 0, bool DEEP = false>
+template <int P, int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
-  using CF = P8Cfg<P, DEEP>;
+  using CF = P8Cfg<P>;
   constexpr int BK = CF::BK, NHW = CF::NHW, D = CF::D, L = CF::L;
   constexpr int ROWB = BK * 2;              // bytes per LDS row
   constexpr int CPR = ROWB / 16;            // 16-byte chunks per row
@@ -345,10 +348,6 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) Xf[mt][ks] = ld(base + 1 * HALF_B + x_slice + mt * 32 * ROWB + lo[ks]);
-          if constexpr (CF::early_w0) {   // the 4 W0 reads (issued first, LDS returns in order) have landed: their slot may be refilled next phase
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-          }
         } else if constexpr (PH == 1) {
 #pragma unroll
           for (int ks = 0; ks < NKS; ++ks) Wf[1][ks] = ld(base + 2 * HALF_B + w_slice + lo[ks]);
@@ -374,36 +373,46 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     }
     // DMA: chunk (PH + D) of the stream = chunk (PH + D) & 3 of the K-tile (PH + D) / 4 further on
     constexpr int CI = (PH + D) & 3, BT = (B + (PH + D) / 4) & 1;
-    if constexpr (CI == 0) cursor_next_ktile();
-    issue(std::integral_constant<int, CI>{}, std::integral_constant<int, BT>{});
+    auto dma_issue = [&]() {
+      if constexpr (CI == 0) cursor_next_ktile();
+      issue(std::integral_constant<int, CI>{}, std::integral_constant<int, BT>{});
+    };
     // counted wait: everything but the youngest L chunks (and, for L phases behind an epilogue, its stores) has landed
-    constexpr int WF = p8_window<P, DEEP>(PH, GCH, false), WH = p8_window<P, DEEP>(PH, GCH, true);
-    if (steady && !(DBG & 2)) {
-      p8_wait_vmcnt<WF>();
-    } else {
-    half_guard = (d_half && !d_done) ? L + 1 : (half_guard > 0 ? half_guard - 1 : 0);
-    if (d_done || (DBG & 2)) {
-      p8_wait_vmcnt<0>();
-    } else if (post_epi > 0) {
-      --post_epi;
-      if (half_guard > 0 || post_half) p8_wait_vmcnt<WH + S_HALF>();
-      else p8_wait_vmcnt<WF + S_FULL>();
-    } else if (half_guard > 0) {
-      p8_wait_vmcnt<WH>();
-    } else {
-      p8_wait_vmcnt<WF>();
-    }
-    }
+    auto dma_wait = [&]() {
+      constexpr int WF = p8_window<P>(PH, GCH, false), WH = p8_window<P>(PH, GCH, true);
+      if (steady && !(DBG & 2)) {
+        p8_wait_vmcnt<WF>();
+      } else {
+        half_guard = (d_half && !d_done) ? L + 1 : (half_guard > 0 ? half_guard - 1 : 0);
+        if (d_done || (DBG & 2)) {
+          p8_wait_vmcnt<0>();
+        } else if (post_epi > 0) {
+          --post_epi;
+          if (half_guard > 0 || post_half) p8_wait_vmcnt<WH + S_HALF>();
+          else p8_wait_vmcnt<WF + S_FULL>();
+        } else if (half_guard > 0) {
+          p8_wait_vmcnt<WH>();
+        } else {
+          p8_wait_vmcnt<WF>();
+        }
+      }
+    };
+    dma_issue();
+    dma_wait();
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (work) {
+    // MFMAs [lo, hi) of this phase's sequence (8 at P = 1, 12 at P = 3)
+    auto mfmas = [&](auto lo_c, auto hi_c) {
+      constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
       if constexpr (DBG & 1) {
         // keep the fragment reads alive without matrix work
+        if constexpr (LO == 0) {
 #pragma unroll
-        for (int i = 0; i < NF; ++i) {
-          asm volatile("" ::"v"(Wf[0][i]), "v"(Wf[1][i]));
-          asm volatile("" ::"v"(Xf[0][i]), "v"(Xf[1][i]));
+          for (int i = 0; i < NF; ++i) {
+            asm volatile("" ::"v"(Wf[0][i]), "v"(Wf[1][i]));
+            asm volatile("" ::"v"(Xf[0][i]), "v"(Xf[1][i]));
+          }
         }
       } else if constexpr (P == 1) {
         constexpr int HA = PH >> 1, HW = (PH == 1 || PH == 2) ? 1 : 0;
@@ -411,18 +420,23 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
-            acc[HA][HW][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[HW][ks], Xf[mt][ks], acc[HA][HW][mt], 0, 0, 0);
+            if (ks * 2 + mt >= LO && ks * 2 + mt < HI)
+              acc[HA][HW][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[HW][ks], Xf[mt][ks], acc[HA][HW][mt], 0, 0, 0);
       } else {
         constexpr int HA = PH >> 1, KS = (PH == 1 || PH == 2) ? 1 : 0;
+        int idx = 0;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int s = P - 1; s >= 0; --s)          // plane-index sum: small terms first (as gemm_planes_kernel)
 #pragma unroll
-            for (int pa = 0; pa <= s; ++pa)
-              acc[HA][0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[KS][s - pa], Xf[mt][pa], acc[HA][0][mt], 0, 0, 0);
+            for (int pa = 0; pa <= s; ++pa, ++idx)
+              if (idx >= LO && idx < HI)
+                acc[HA][0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[KS][s - pa], Xf[mt][pa], acc[HA][0][mt], 0, 0, 0);
       }
-    }
+    };
+    constexpr int NM = P == 1 ? 2 * NKS : 12;
+    if (work) mfmas(std::integral_constant<int, 0>{}, std::integral_constant<int, NM>{});
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   };
@@ -580,13 +594,12 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     pro(std::integral_constant<int, 0>{}); pro(std::integral_constant<int, 1>{}); pro(std::integral_constant<int, 2>{});
     pro(std::integral_constant<int, 3>{}); pro(std::integral_constant<int, 4>{});
     if constexpr (D > 5) pro(std::integral_constant<int, 5>{});
-    if constexpr (D > 6) pro(std::integral_constant<int, 6>{});
-    static_assert(D >= 5 && D <= 7, "prologue issues chunks 0 .. D - 1");
+    static_assert(D == 5 || D == 6, "prologue issues chunks 0 .. D - 1");
     half_guard = d_half ? L + 1 : 0;
     // "phase -1": chunks D - L .. D - 1 may stay in flight
     if (DBG & 2) p8_wait_vmcnt<0>();
-    else if (d_half) p8_wait_vmcnt<p8_window<P, DEEP>(3, GCH, true)>();
-    else p8_wait_vmcnt<p8_window<P, DEEP>(3, GCH, false)>();
+    else if (d_half) p8_wait_vmcnt<p8_window<P>(3, GCH, true)>();
+    else p8_wait_vmcnt<p8_window<P>(3, GCH, false)>();
     __builtin_amdgcn_s_barrier();
   }
 
@@ -619,9 +632,9 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
 #endif
 }
 
-template <int P, int EPI, int DBG = 0, bool DEEP = false>
+template <int P, int EPI, int DBG = 0>
 static int launch_planes8(const P8Args& g, hipStream_t s) {
-  hipLaunchKernelGGL((gemm_planes8_kernel<P, EPI, DBG, DEEP>), dim3(g.ncu), dim3(512), 0, s, g);
+  hipLaunchKernelGGL((gemm_planes8_kernel<P, EPI, DBG>), dim3(g.ncu), dim3(512), 0, s, g);
   TT_CHECK_LAUNCH("gemm_planes8");
   return TT_OK;
 }
