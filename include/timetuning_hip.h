@@ -56,6 +56,12 @@ int tt_linear_bwd_data(const float* dy, const float* w, const float* gelu_pre, f
 int tt_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
                          void* workspace, size_t workspace_bytes, tt_stream_t stream);
 size_t tt_linear_bwd_weight_workspace_bytes(int M, int N, int K); /* split-K partials and/or the column-sum scratch */
+/* Both products of one nn.Linear in one call (they share dy and do not depend on each other): dx as tt_linear_bwd_data, dw / db as
+ * tt_linear_bwd_weight, bit for bit.  Where both lean kernels apply and the weight gradient is split along its reduction, ONE launch carries
+ * the dgrad tiles and the weight-gradient slices (neither fills the chip on the target frames alone), else the two are launched one after
+ * the other.  x is the layer's input [M, Kx] with Kx = K; workspace: tt_linear_bwd_weight_workspace_bytes(M, N, K). */
+int tt_linear_bwd(const float* dy, const float* w, const float* x, const float* gelu_pre, float* dx, float* dw, float* db, int M, int N, int K,
+                  void* workspace, size_t workspace_bytes, tt_stream_t stream);
 size_t tt_colsum_workspace_bytes(int M, int N);
 /* out[N] = sum over rows of a[M,N] (deterministic two-stage reduction). */
 int tt_colsum(const float* a, float* out, int M, int N, void* workspace, size_t workspace_bytes, tt_stream_t stream);

@@ -340,6 +340,13 @@ int tt_cpu_linear_bwd_weight(const float* dy, const float* x, float* dw, float* 
   return 0;
 }
 
+int tt_cpu_linear_bwd(const float* dy, const float* w, const float* x, const float* gelu_pre, float* dx, float* dw, float* db, int M, int N,
+                      int K, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  const int rc = tt_cpu_linear_bwd_weight(dy, x, dw, db, M, N, K, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  return tt_cpu_linear_bwd_data(dy, w, gelu_pre, dx, M, N, K, stream);
+}
+
 /* ---- nn.LayerNorm(eps) (dino_vision_transformer.py:139,143,196); skip_group = N drops token 0 of every group of N rows
  *      (the cls token, models.py:967) */
 int tt_cpu_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int rows, int D,

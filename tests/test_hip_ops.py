@@ -149,6 +149,27 @@ def test_l2norm(ops):
     assert rel_err(w.cpu(), ref_w) < TOL
 
 
+@pytest.mark.parametrize("M,N,K,gelu", [(6304, 384, 1536, True), (6304, 1536, 384, False), (6304, 1152, 384, False), (6304, 384, 384, False),
+                                         (788, 256, 512, True), (400, 48, 64, False)])
+def test_linear_bwd_fused_equals_the_two_products(ops, M, N, K, gelu):
+    """tt_linear_bwd: both backward products of an nn.Linear in one call - one LAUNCH for the two GEMMs on the block / head shapes of the
+    32 target frames (dgrad tiles + split-K weight-gradient slices in one grid) - must equal tt_linear_bwd_data + tt_linear_bwd_weight bit
+    for bit and the fp64 products within the f32 bound."""
+    dy, w, x = rnd(f"lbf.dy{M}.{N}", M, N), rnd(f"lbf.w{N}.{K}", N, K, std=0.05), rnd(f"lbf.x{M}.{K}", M, K)
+    pre = rnd(f"lbf.pre{M}.{K}", M, K) if gelu else None
+    dx, dw, db = ops.linear_bwd(dev(dy), dev(w), dev(x), gelu_pre=dev(pre) if gelu else None)
+    dx2 = ops.linear_bwd_data(dev(dy), dev(w), gelu_pre=dev(pre) if gelu else None)
+    dw2, db2 = ops.linear_bwd_weight(dev(dy), dev(x))
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    ref_dx = dy.double() @ w.double()
+    if gelu:
+        p64 = pre.double()
+        ref_dx = ref_dx * (0.5 * (1 + torch.erf(p64 / 2 ** 0.5)) + p64 * torch.exp(-0.5 * p64 * p64) / (2 * np.pi) ** 0.5)
+    assert rel_err(dx.cpu(), ref_dx) < 2e-5
+    assert rel_err(dw.cpu(), dy.double().t() @ x.double()) < 2e-5
+    assert rel_err(db.cpu(), dy.double().sum(0)) < 2e-5
+
+
 def test_my_utils_sinkhorn_signature(golden):
     """``my_utils.sinkhorn(Q, nmb_iters, world_size)`` as the reference calls it (Q = exp(scores / eps).T, my_utils.py:246-274)."""
     from timetuning_amd.my_utils import sinkhorn

@@ -52,6 +52,7 @@ SIGNATURES = {
     "tt_linear_bwd_data": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp]),
     "tt_linear_bwd_weight": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_linear_bwd_weight_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "tt_linear_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_colsum_workspace_bytes": (c_sz, [c_i, c_i]),
     "tt_colsum": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_gemm_f32": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_ll, c_ll, c_ll, c_vp]),

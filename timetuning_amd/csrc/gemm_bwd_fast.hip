@@ -159,12 +159,13 @@ __device__ __forceinline__ void bwd_epilogue(float* lds, const f32x16 (&acc)[WM]
   }
 }
 
+// The two tile bodies, shared by the stand-alone kernels and by the fused launch below.  `id` = linear workgroup index among the
+// tiles of its kind, z = split-K slice (wgrad).
 template <int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_dgrad_fast_kernel(BwdArgs g) {
-  constexpr int BM = 64 * WM, BN = 64 * WN, BK = 16;
-  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (BM + 4 + BN + 4)];
+__device__ __forceinline__ void dgrad_tile(const BwdArgs& g, float* lds, int id) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
   const int ntn = g.N / BN, ntm = (g.M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tile = xcd_remap(id, ntm * ntn);
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
   f32x16 acc[WM][WN];
   bwd_mainloop<WM, WN, false, true>(g, lds, m0, n0, 0, g.K, acc);
@@ -172,13 +173,12 @@ __global__ __launch_bounds__(256) void gemm_dgrad_fast_kernel(BwdArgs g) {
 }
 
 template <int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_wgrad_fast_kernel(BwdArgs g) {
-  constexpr int BM = 64 * WM, BN = 64 * WN, BK = 16;
-  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (BM + 4 + BN + 4)];
+__device__ __forceinline__ void wgrad_tile(const BwdArgs& g, float* lds, int id, int z) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
   const int ntn = g.N / BN, ntm = g.M / BM;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tile = xcd_remap(id, ntm * ntn);
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-  const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int kbeg = z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
   f32x16 acc[WM][WN];
   // the ntn workgroups of a row block each sum the slabs s with s % ntn == their column-tile index: the bias gradient's
   // extra adds are spread evenly instead of making one workgroup per row block the straggler
@@ -196,11 +196,42 @@ __global__ __launch_bounds__(256) void gemm_wgrad_fast_kernel(BwdArgs g) {
       float sum = 0.f;
 #pragma unroll
       for (int rr = 0; rr < R; ++rr) sum += red[rr * BM + tid];
-      g.colpart[((size_t)blockIdx.z * ntn + n0 / BN) * g.M + m0 + tid] = sum;
+      g.colpart[((size_t)z * ntn + n0 / BN) * g.M + m0 + tid] = sum;
     }
     __syncthreads();
   }
-  bwd_epilogue<WM, WN, false>(lds, acc, g.C + (long long)blockIdx.z * g.strideS, g.N, m0, n0, g.M, nullptr);
+  bwd_epilogue<WM, WN, false>(lds, acc, g.C + (long long)z * g.strideS, g.N, m0, n0, g.M, nullptr);
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_dgrad_fast_kernel(BwdArgs g) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, BK = 16;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (BM + 4 + BN + 4)];
+  dgrad_tile<WM, WN>(g, lds, blockIdx.x);
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_wgrad_fast_kernel(BwdArgs g) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, BK = 16;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (BM + 4 + BN + 4)];
+  wgrad_tile<WM, WN>(g, lds, blockIdx.x, blockIdx.z);
+}
+
+// BOTH backward products of an nn.Linear in one launch - they read the same dy and do not depend on each other: workgroups
+// [0, nd) are the dgrad tiles (WM x WN), the rest the 64 x 64 split-K tiles of the weight gradient (slice-major).  Neither product
+// fills the chip on the 32 target frames (594 dgrad tiles of width 384 = 2.3 per CU; ~1000 weight-gradient slices): as two kernels
+// each ends in a tail of idle CUs (and two kernels on two streams did not fill each other's tails, round 2), one grid does.
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_bwd_fused_kernel(BwdArgs gd, BwdArgs gw, int nd, int wtiles) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, BK = 16;   // (>= the 64 x 64 tile of the weight-gradient part)
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (BM + 4 + BN + 4)];
+  const int b = blockIdx.x;
+  if (b < nd) {
+    dgrad_tile<WM, WN>(gd, lds, b);
+  } else {
+    const int w = b - nd;
+    wgrad_tile<1, 1>(gw, lds, w % wtiles, w / wtiles);
+  }
 }
 
 int gemm_tile_choice(int M, int N, int batch);
@@ -241,6 +272,32 @@ int try_launch_wgrad_fast(const float* dy, const float* x, float* out, int M, in
   else if (bn128) hipLaunchKernelGGL((gemm_wgrad_fast_kernel<1, 2>), grid, dim3(256), 0, s, g);
   else hipLaunchKernelGGL((gemm_wgrad_fast_kernel<1, 1>), grid, dim3(256), 0, s, g);
   TT_CHECK_LAUNCH("gemm_wgrad_fast");
+  return TT_OK;
+}
+
+// dx = dy @ w (* gelu'(pre)) and the split-K partials of dw = dy^T @ x (+ the column partials of db) in ONE launch.  Returns 1 when
+// either product is not eligible for its lean kernel (the caller then launches them separately).
+int try_launch_bwd_fused(const float* dy, const float* w, const float* x, const float* gelu_pre, float* dx, float* wpart, int M, int N, int K,
+                         int splits, int kchunk, float* colpart, int* colparts, hipStream_t s) {
+  auto ok16 = [](const void* p) { return p == nullptr || aligned16(p); };
+  // dgrad: dx[M,K] = dy[M,N] @ w[N,K]
+  if (N % 16 != 0 || N < 16 || K % 64 != 0 || !aligned16(dy) || !aligned16(w) || !aligned16(dx) || !ok16(gelu_pre)) return 1;
+  // wgrad: partial[z][N][K] = dy[zslice,N]^T @ x[zslice,K], 64 x 64 tiles
+  if (splits < 2 || M % 16 != 0 || kchunk % 16 != 0 || N % 64 != 0 || !aligned16(x) || !aligned16(wpart)) return 1;
+  BwdArgs gd{dy, w, dx, M, K, N, N, K, gelu_pre, N, 0, nullptr};
+  BwdArgs gw{dy, x, wpart, N, K, M, N, K, nullptr, kchunk, (long long)N * K, colpart};
+  const int tile = gemm_tile_choice(M, K, 1);
+  const bool bn128 = (tile == 0 || tile == 1) && K % 128 == 0;
+  const bool bm128 = (tile == 0 || tile == 2);
+  const int bm = bm128 ? 128 : 64, bn = bn128 ? 128 : 64;
+  const int nd = ((M + bm - 1) / bm) * (K / bn), wtiles = (N / 64) * (K / 64);
+  if (colparts) *colparts = splits * (K / 64);
+  dim3 grid(nd + wtiles * splits);
+  if (bm128 && bn128) hipLaunchKernelGGL((gemm_bwd_fused_kernel<2, 2>), grid, dim3(256), 0, s, gd, gw, nd, wtiles);
+  else if (bm128) hipLaunchKernelGGL((gemm_bwd_fused_kernel<2, 1>), grid, dim3(256), 0, s, gd, gw, nd, wtiles);
+  else if (bn128) hipLaunchKernelGGL((gemm_bwd_fused_kernel<1, 2>), grid, dim3(256), 0, s, gd, gw, nd, wtiles);
+  else hipLaunchKernelGGL((gemm_bwd_fused_kernel<1, 1>), grid, dim3(256), 0, s, gd, gw, nd, wtiles);
+  TT_CHECK_LAUNCH("gemm_bwd_fused");
   return TT_OK;
 }
 

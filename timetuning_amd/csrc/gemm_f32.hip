@@ -483,6 +483,8 @@ int try_launch_dgrad_fast(const float* dy, const float* w, const float* gelu_pre
 int try_launch_wgrad_fast(const float* dy, const float* x, float* out, int M, int N, int K, int splits, int kchunk, float* colpart,
                           int* colparts, hipStream_t s);
 int launch_colsum_fold(const float* partial, float* out, int chunks, int N, hipStream_t s);  // rowops.hip
+int try_launch_bwd_fused(const float* dy, const float* w, const float* x, const float* gelu_pre, float* dx, float* wpart, int M, int N, int K,
+                         int splits, int kchunk, float* colpart, int* colparts, hipStream_t s);    // gemm_bwd_fast.hip
 }
 
 extern "C" int tt_gemm_tile_choice(int M, int N, int batch) { return tt::gemm_tile_choice(M, N, batch); }
@@ -599,6 +601,40 @@ extern "C" int tt_linear_bwd_weight(const float* dy, const float* x, float* dw, 
   if (!db) return TT_OK;
   if (bias_fused) return tt::launch_colsum_fold(colpart, db, colparts, N, tt::as_stream(stream));
   return tt_colsum(dy, db, M, N, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tt_linear_bwd(const float* dy, const float* w, const float* x, const float* gelu_pre, float* dx, float* dw, float* db, int M,
+                             int N, int K, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(dy && w && x && dx && dw && M > 0 && N > 0 && K > 0, "linear_bwd: null operand / bad shape");
+  // ONE launch when the weight gradient is split along M (its plan: gemm_splitk_choice) and both lean kernels take the shapes
+  const int s = (((long long)N * K) % 4 == 0) ? tt::gemm_splitk_choice(N, K, M, nullptr) : 1;
+  static const bool no_fuse = getenv("TT_BWD_NO_FUSE") != nullptr;   // tuning aid
+  if (s > 1 && !no_fuse && workspace && workspace_bytes >= tt_linear_bwd_weight_workspace_bytes(M, N, K)) {
+    const int kchunk = ((M + s - 1) / s + tt::kBK - 1) / tt::kBK * tt::kBK;
+    float* part = static_cast<float*>(workspace);
+    float* colpart = db ? part + (size_t)s * N * K : nullptr;
+    int colparts = 0;
+    const int rc = tt::try_launch_bwd_fused(dy, w, x, gelu_pre, dx, part, M, N, K, s, kchunk, colpart, &colparts, tt::as_stream(stream));
+    if (rc < 0) return rc;
+    if (rc == TT_OK) {
+      const long long n = (long long)N * K;
+      long long blocks = (n / 4 + 255) / 256;
+      if (blocks > 1024) blocks = 1024;
+      if (db) {
+        hipLaunchKernelGGL(tt::splitk_reduce_colfold_kernel, dim3((unsigned)blocks + (N + 63) / 64), dim3(256), 0, tt::as_stream(stream),
+                           static_cast<const float*>(workspace), dw, n, s, (long long)N * K, (int)blocks, colpart, db, colparts, N);
+        TT_CHECK_LAUNCH("splitk_reduce_colfold");
+      } else {
+        hipLaunchKernelGGL(tt::splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, tt::as_stream(stream),
+                           static_cast<const float*>(workspace), dw, n, s, (long long)N * K);
+        TT_CHECK_LAUNCH("splitk_reduce");
+      }
+      return TT_OK;
+    }
+  }
+  const int rc = tt_linear_bwd_weight(dy, x, dw, db, M, N, K, workspace, workspace_bytes, stream);
+  if (rc != TT_OK) return rc;
+  return tt_linear_bwd_data(dy, w, gelu_pre, dx, M, N, K, stream);
 }
 
 namespace tt {

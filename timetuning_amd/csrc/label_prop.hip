@@ -342,8 +342,11 @@ static int lp_cmax(int fs, int n_last) {
   return c < 1 ? 1 : c;
 }
 
-// target frames whose similarities are held at once (all of them unless that needs more than LP_SIMS_CAP bytes)
-constexpr size_t LP_SIMS_CAP = 512ull << 20;
+// target frames whose similarities are held at once (all of them unless that needs more than LP_SIMS_CAP bytes).  256 MB holds every
+// target frame of C2 (44 MB) and all but one of C4's (138 MB at 16 clips x 8 frames); the evaluation protocol's long clips on the
+// 28 x 28 grid are chunked (there a few more similarity launches do not matter - the per-query kernel dominates).  The cost is
+// workspace the caller allocates: see INTEGRATION.md "Workspaces".
+constexpr size_t LP_SIMS_CAP = 256ull << 20;
 static int lp_chunk(int bs, int fs, int n, int n_last) {
   const size_t per_t = (size_t)bs * lp_cmax(fs, n_last) * n * n * sizeof(float);
   const char* e = getenv("TT_LP_SIMS_CAP_MB");   // test aid: a small cap exercises the chunked path on small inputs
@@ -351,6 +354,11 @@ static int lp_chunk(int bs, int fs, int n, int n_last) {
   if (T < 1) T = 1;
   if (T > (size_t)(fs - 1)) T = fs > 1 ? fs - 1 : 1;
   return (int)T;
+}
+static size_t lp_workspace(int T, int bs, int fs, size_t n, int K, int n_last) {
+  const size_t sims = (size_t)T * bs * lp_cmax(fs, n_last) * n * n * sizeof(float);
+  const size_t segs = (size_t)(fs > 1 ? fs - 1 : 1) * bs * n * K * sizeof(double);
+  return ((sims + 255) / 256) * 256 + segs;
 }
 
 }  // namespace tt
@@ -360,9 +368,7 @@ using namespace tt;
 extern "C" size_t tt_label_propagate_workspace_bytes(int bs, int fs, int g, int D, int K, int n_last_frames) {
   (void)D;
   const size_t n = (size_t)g * g;
-  const size_t sims = (size_t)lp_chunk(bs, fs, (int)n, n_last_frames) * bs * lp_cmax(fs, n_last_frames) * n * n * sizeof(float);
-  const size_t segs = (size_t)(fs > 1 ? fs - 1 : 1) * bs * n * K * sizeof(double);
-  return ((sims + 255) / 256) * 256 + segs;
+  return lp_workspace(lp_chunk(bs, fs, (int)n, n_last_frames), bs, fs, n, K, n_last_frames);
 }
 
 static int lp_run(const char* who, const float* xn, const float* seg0, int64_t* labels, double* pmap_last, double* pmap_all, int bs,
@@ -378,10 +384,14 @@ static int lp_run(const char* who, const float* xn, const float* seg0, int64_t* 
   TT_REQUIRE(cand_max <= 256LL * LP_CAND_MAX, "%s: window %dx%d with %d context frames exceeds %d candidates per query", who, win, win,
              lp_cmax(fs, n_last_frames), 256 * LP_CAND_MAX);
   TT_REQUIRE(D % 4 == 0, "%s: feature dim must be a multiple of 4", who);
-  TT_REQUIRE(workspace_bytes >= tt_label_propagate_workspace_bytes(bs, fs, g, D, K, n_last_frames), "%s: workspace too small", who);
   hipStream_t s = as_stream(stream);
   const int n = g * g;
-  const int cmax = lp_cmax(fs, n_last_frames), T = lp_chunk(bs, fs, n, n_last_frames);
+  // The chunk length follows the workspace that was actually handed over, not a second reading of the cap (the environment may have
+  // changed between the caller's size query and this call): the largest chunk, up to the cap's, that fits.
+  int T = lp_chunk(bs, fs, n, n_last_frames);
+  while (T > 1 && lp_workspace(T, bs, fs, (size_t)n, K, n_last_frames) > workspace_bytes) --T;
+  TT_REQUIRE(workspace_bytes >= lp_workspace(T, bs, fs, (size_t)n, K, n_last_frames), "%s: workspace too small", who);
+  const int cmax = lp_cmax(fs, n_last_frames);
   const size_t sims_bytes = (((size_t)T * bs * cmax * n * n * sizeof(float)) + 255) / 256 * 256;
   float* sims = static_cast<float*>(workspace);
   // the fp64 maps of frames 1..fs-1: the caller's buffer when all of them are wanted, the workspace otherwise

@@ -118,6 +118,14 @@ def _bwd_data(dy: torch.Tensor, w: torch.Tensor, gelu_pre: Optional[torch.Tensor
     return ops.linear_bwd_data(dy, w, gelu_pre=gelu_pre)
 
 
+def _bwd_both(dy: torch.Tensor, w: torch.Tensor, x: torch.Tensor, gelu_pre: Optional[torch.Tensor] = None):
+    """(dx, dw, db) of an nn.Linear whose input gradient is needed too: one launch for both products in the f32 mode."""
+    if ops.plane_count() == 1:
+        dw, db = _bwd_weight(dy, x)
+        return _bwd_data(dy, w, gelu_pre), dw, db
+    return ops.linear_bwd(dy, w, x, gelu_pre=gelu_pre)
+
+
 def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int, f1: int, grads: Dict[torch.nn.Parameter, torch.Tensor],
                    need_dx: bool = True, after_mlp=None) -> Optional[torch.Tensor]:
     """Backward of one block restricted to frames [f0, f1) of the saved activations.  dx_out [(f1-f0)*N, D]
@@ -127,24 +135,20 @@ def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int,
     r0, r1 = f0 * N, f1 * N
     a, pre, h2 = sv["a"][r0:r1], sv["pre"][r0:r1], sv["h2"][r0:r1]
     # x_out = x_mid + fc2(gelu(fc1(ln2(x_mid))))
-    grads[blk.mlp.fc2.weight], grads[blk.mlp.fc2.bias] = _bwd_weight(dx_out, a)
-    d_pre = _bwd_data(dx_out, blk.mlp.fc2.weight, pre)
-    grads[blk.mlp.fc1.weight], grads[blk.mlp.fc1.bias] = _bwd_weight(d_pre, h2)
-    d_h2 = _bwd_data(d_pre, blk.mlp.fc1.weight)
+    d_pre, grads[blk.mlp.fc2.weight], grads[blk.mlp.fc2.bias] = _bwd_both(dx_out, blk.mlp.fc2.weight, a, pre)
+    d_h2, grads[blk.mlp.fc1.weight], grads[blk.mlp.fc1.bias] = _bwd_both(d_pre, blk.mlp.fc1.weight, h2)
     dx_mid, grads[blk.norm2.weight], grads[blk.norm2.bias] = ops.layernorm_bwd(
         d_h2, sv["x_mid"][r0:r1], blk.norm2.weight, sv["mean2"][r0:r1], sv["rstd2"][r0:r1], dx_accum=dx_out)
     if after_mlp is not None:
         after_mlp()
     # x_mid = x_in + proj(attention(qkv(ln1(x_in))))
     att = sv["att"].view(Fr * N, D)[r0:r1]
-    grads[blk.attn.proj.weight], grads[blk.attn.proj.bias] = _bwd_weight(dx_mid, att)
-    d_att = _bwd_data(dx_mid, blk.attn.proj.weight)
+    d_att, grads[blk.attn.proj.weight], grads[blk.attn.proj.bias] = _bwd_both(dx_mid, blk.attn.proj.weight, att)
     qkv = sv["qkv"].view(Fr, N, 3 * D)[f0:f1]
     dqkv = ops.attention_bwd(qkv, sv["att"][f0:f1], d_att.view(f1 - f0, N, D), sv["lse"][f0:f1], num_heads)
     dqkv2 = dqkv.view((f1 - f0) * N, 3 * D)
     h1 = sv["h1"].view(Fr * N, D)[r0:r1]
-    grads[blk.attn.qkv.weight], grads[blk.attn.qkv.bias] = _bwd_weight(dqkv2, h1)
-    d_h1 = _bwd_data(dqkv2, blk.attn.qkv.weight)
+    d_h1, grads[blk.attn.qkv.weight], grads[blk.attn.qkv.bias] = _bwd_both(dqkv2, blk.attn.qkv.weight, h1)
     x_in = sv["x_in"].view(Fr * N, D)[r0:r1]
     dx_in, grads[blk.norm1.weight], grads[blk.norm1.bias] = ops.layernorm_bwd(
         d_h1, x_in, blk.norm1.weight, sv["mean1"][r0:r1], sv["rstd1"][r0:r1], dx_accum=dx_mid)
@@ -300,8 +304,7 @@ def head_backward(dz: torch.Tensor, head, sv: dict, grads) -> torch.Tensor:
     d = dz
     for i in range(len(lins) - 1, -1, -1):
         lin = lins[i]
-        grads[lin.weight], grads[lin.bias] = _bwd_weight(d, sv["acts"][i])
-        d = _bwd_data(d, lin.weight, sv["pres"][i - 1] if i > 0 else None)
+        d, grads[lin.weight], grads[lin.bias] = _bwd_both(d, lin.weight, sv["acts"][i], sv["pres"][i - 1] if i > 0 else None)
     return d
 
 

@@ -152,6 +152,27 @@ def linear_bwd_weight(dy, x, need_bias=True, dw_out=None, db_out=None):
     return dw, db
 
 
+def linear_bwd(dy, w, x, gelu_pre=None, need_bias=True):
+    """Both backward products of an nn.Linear: dx = dy @ w (* gelu'(gelu_pre)), dw = dy.T @ x, db = dy.sum(0) - ONE launch for the
+    two GEMMs where the lean kernels apply (tt_linear_bwd), bit-identical to linear_bwd_data + linear_bwd_weight."""
+    lib = _lib.load()
+    _chk(dy, "dy"); _chk(w, "w"); _chk(x, "x")
+    M, N = dy.shape
+    K = w.shape[1]
+    assert w.shape[0] == N and tuple(x.shape) == (M, K), (dy.shape, w.shape, x.shape)
+    if PROFILE is not None:   # per-GEMM event profile: one call per product (the same kernels)
+        dw, db = linear_bwd_weight(dy, x, need_bias=need_bias)
+        return linear_bwd_data(dy, w, gelu_pre=gelu_pre), dw, db
+    if gelu_pre is not None: _chk(gelu_pre, "gelu_pre")
+    dx = torch.empty((M, K), dtype=f32, device=dy.device)
+    dw = torch.empty((N, K), dtype=f32, device=dy.device)
+    db = torch.empty((N,), dtype=f32, device=dy.device) if need_bias else None
+    nb = lib.tt_linear_bwd_weight_workspace_bytes(M, N, K)
+    ws = _ws(nb, dy.device)
+    _lib.check(lib.tt_linear_bwd(_p(dy), _p(w), _p(x), _p(gelu_pre), _p(dx), _p(dw), _p(db), M, N, K, _p(ws), nb, _stream()), "tt_linear_bwd")
+    return dx, dw, db
+
+
 def colsum(a):
     lib = _lib.load()
     _chk(a, "a")
