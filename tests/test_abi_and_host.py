@@ -117,6 +117,19 @@ def test_full_size_parameter_counts():
     assert np.array_equal(fe.backbone.blocks[3].attn.qkv.weight.detach().numpy(), w["blocks.3.attn.qkv.weight"])
 
 
+def test_planes_route_decisions_without_a_gpu():
+    """tt_linear_fwd_planes_route is host logic (shape / epilogue eligibility and the tile decomposition of the persistent plane GEMM); with
+    no device it assumes 256 CUs."""
+    lib = _lib.load()
+    route = lambda P, M, N, K, act=0, bias=1, res=0, y=1, po=0, pre=0: lib.tt_linear_fwd_planes_route(P, M, N, K, act, bias, res, y, po, pre)
+    assert route(1, 25216, 2304, 768, y=0, po=1) == 8            # ViT-B/16 qkv, bf16 out
+    assert route(1, 25216, 768, 3072, res=1) == 8                # fc2, fp32 + residual
+    assert route(3, 25216, 1536, 384, act=1, y=0, po=3) == 8     # ViT-S/16 fc1 in the fp32-accurate mode
+    assert route(1, 25216, 2304, 768, act=1) == 0                # GELU with an fp32 output is not a compiled epilogue
+    assert route(1, 6304, 768, 768, res=1) == 0                  # 75 tiles: the small-tile kernel
+    assert route(3, 25216, 1152, 200) == 0                       # K not a multiple of two K-tiles
+
+
 def test_queue_fullness_is_tracked_on_the_host():
     """Own pushes are counted on the host; a write from outside (copy_, set_queue) is detected by the storage / version signature and
     answered by the reference's own check of the last row (time_tuning.py:207)."""

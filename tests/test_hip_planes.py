@@ -133,3 +133,87 @@ def test_backward_products_on_bf16_planes(M, N, K):
     t = ops.transpose_planes(x.cuda())
     assert t.shape == (1, K, (M + 63) // 64 * 64) and torch.equal(t[0, :, :M].cpu(), x.to(torch.bfloat16).t())
     assert (t[0, :, M:] == 0).all()
+
+
+# ---- gemm_planes8_kernel (round 3): the persistent 8-phase kernel behind tt_linear_fwd_planes ------------------------------------------
+
+P8_SHAPES = {   # tile counts (256-row x 256 / 128-column tiles): what the work decomposition does with them on 256 CUs
+    "one round + 82 half tiles": (25216, 3, 256),
+    "ragged M, round-robin deal of 202 tiles": (197 * 130 + 7, 2, 384),
+    "half tiles only (128 tiles)": (32768, 1, 256),
+    "two whole rounds": (16384, 8, 128),
+    "three rounds + 246 half tiles": (25216, 9, 256),
+}
+
+
+@pytest.mark.parametrize("planes", [1, 3])
+@pytest.mark.parametrize("case", list(P8_SHAPES))
+def test_linear_planes8_every_epilogue(planes, case, monkeypatch):
+    """The persistent kernel on every tile-count regime of its work decomposition x every compiled epilogue (fp32, fp32 + residual in
+    place, bf16 / 3-plane output with and without GELU): (1) the route query says it runs, (2) fp64 products of the same plane operands
+    on a row sample that includes the first rows, the LAST rows (ragged tail, half tiles) and random ones, (3) the WHOLE output against
+    gemm_planes_kernel (TT_PLANES_VARIANT=10) - identical bits at one plane without GELU, (4) a second run equals the first bit for bit
+    (the counted-vmcnt schedule has no run-to-run freedom)."""
+    from timetuning_amd import _lib, hip_ops as ops
+
+    M, strips, K = P8_SHAPES[case]
+    N = strips * (256 if planes == 1 else 128)
+    g = torch.Generator().manual_seed(100 * planes + list(P8_SHAPES).index(case))
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    xp, wp = ops.split_planes(x, planes), ops.split_planes(w, planes)
+    idx = torch.cat([torch.arange(0, 200), torch.arange(M - 200, M), torch.randint(0, M, (200,), generator=g)]).cuda()
+    ref = planes_to_f64(xp[:, idx]) @ planes_to_f64(wp).t() + b.double()
+    lib = _lib.load()
+    epilogues = [dict(act=0, po=0, res=False), dict(act=0, po=0, res=True)]
+    epilogues += [dict(act=0, po=1, res=False), dict(act=1, po=1, res=False)] if planes == 1 else [dict(act=1, po=3, res=False)]
+    for e in epilogues:
+        r = torch.randn(M, N, generator=g).cuda() if e["res"] else None
+
+        def run():
+            rr = r.clone() if r is not None else None
+            o = ops.linear_fwd_planes(xp, wp, b, residual=rr, act=e["act"], out_f32=e["po"] == 0, out_planes=e["po"], out=rr)
+            return o["y"] if e["po"] == 0 else o["planes"]
+
+        monkeypatch.delenv("TT_PLANES_VARIANT", raising=False)
+        assert lib.tt_linear_fwd_planes_route(planes, M, N, K, e["act"], 1, int(e["res"]), int(e["po"] == 0), e["po"], 0) == 8, (case, e)
+        new = run()
+        again = run()
+        assert torch.equal(new, again), (case, e)
+        monkeypatch.setenv("TT_PLANES_VARIANT", "10")
+        assert lib.tt_linear_fwd_planes_route(planes, M, N, K, e["act"], 1, int(e["res"]), int(e["po"] == 0), e["po"], 0) == 0
+        old = run()
+        monkeypatch.delenv("TT_PLANES_VARIANT")
+        want = torch.nn.functional.gelu(ref) if e["act"] else ref
+        if e["res"]:
+            want = want + r.double()[idx]
+        got = new.double()[idx] if e["po"] == 0 else new.double().sum(0)[idx]
+        tol = TOL_F32 if (planes == 3 or e["po"] == 0) else 5e-3          # bf16 output: 2^-9 rounding (and the tanh-form GELU, 5e-4 absolute)
+        assert rel_err(got.cpu(), want.cpu()) < tol, (case, e)
+        a, c = (new, old) if e["po"] == 0 else (new.float().sum(0), old.float().sum(0))
+        if planes == 1 and not e["act"]:
+            assert torch.equal(a, c), (case, e)                            # same products in the same order: identical bits
+        else:
+            lim = 1e-2 if planes == 1 else 2e-6                            # P = 1 GELU: tanh form vs erf, then bf16 rounding
+            assert ((a - c).abs().max() / c.abs().max()).item() < lim, (case, e)
+
+
+def test_linear_planes_route_and_fallbacks():
+    """What does NOT go to the persistent kernel keeps working on gemm_planes_kernel: a pre-activation output, fp32 y together with plane
+    outputs, too few tiles, a column count that is not a whole tile, no bias."""
+    from timetuning_amd import _lib, hip_ops as ops
+
+    lib = _lib.load()
+    route = lambda P, M, N, K, act=0, bias=1, res=0, y=1, po=0, pre=0: lib.tt_linear_fwd_planes_route(P, M, N, K, act, bias, res, y, po, pre)
+    assert route(1, 25216, 2304, 768, y=0, po=1) == 8 and route(3, 25216, 1152, 384) == 8
+    assert route(1, 25216, 2304, 768, y=0, po=1, pre=1) == 0          # pre-activation wanted
+    assert route(1, 25216, 2304, 768, y=1, po=1) == 0                 # y and planes together
+    assert route(1, 25216, 2304, 768, bias=0) == 0
+    assert route(1, 2048, 768, 3072) == 0                             # 24 tiles
+    assert route(1, 25216, 1152, 768) == 0 and route(3, 25216, 1152 + 64, 384) == 0   # not whole column tiles
+    assert route(2, 25216, 2304, 768) == 0                            # two-plane mode
+    x, w, b = rnd("rt.x", 2048, 128), rnd("rt.w", 768, 128, scale=0.05), rnd("rt.b", 768, scale=0.1)
+    o = ops.linear_fwd_planes(ops.split_planes(x.cuda(), 3), ops.split_planes(w.cuda(), 3), b.cuda(), act=1, save_pre=True, out_planes=3)
+    ref = x.double() @ w.double().t() + b.double()
+    assert rel_err(o["pre"].cpu(), ref) < TOL_F32 and rel_err(planes_to_f64(o["planes"].cpu()), F.gelu(ref)) < TOL_F32
