@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   bool post_half = false;    // ... and whether that epilogue was a half tile's
   bool c_half = false;       // the item being computed is a half tile
 
-  // ---- one phase: [fragment reads | DMA issue | counted wait] barrier [MFMAs] barrier
+  // ---- one phase: [DMA issue | fragment reads | counted wait] barrier [MFMAs] barrier
   // `steady` (set per pair of K-tiles by the main loop): nothing rare can happen in these phases - whole tile being computed, DMA cursor
   // in a whole tile and not at the end of the stream, no stores of an epilogue left in the window - so ONE scalar branch skips all the
   // bookkeeping: the load part is then fragment reads, the cursor's scalar adds, the DMA instructions and one counted wait.  (The general
@@ -337,6 +337,7 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     constexpr int B = decltype(buf_c)::value, PH = decltype(ph_c)::value;
     constexpr int base = B * BUF_B;
     const bool work = !(PH >= 2 && c_half);   // phases 2 and 3 of either schedule use the X1 chunk only
+    auto frag_reads = [&]() {
     if (work) {
       if constexpr (P == 1) {
         // chunks W0 X0 W1 X1 in slots 0..3; quadrants (hA, hW): (0,0) (0,1) (1,1) (1,0)
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
           for (int p = 0; p < P; ++p) Xf[mt][p] = ld(base + (1 + HA) * HALF_B + p * PLANE_B + x_slice + mt * 32 * ROWB + lo[KS]);
       }
     }
+    };
     // DMA: chunk (PH + D) of the stream = chunk (PH + D) & 3 of the K-tile (PH + D) / 4 further on
     constexpr int CI = (PH + D) & 3, BT = (B + (PH + D) / 4) & 1;
     auto dma_issue = [&]() {
@@ -397,7 +399,14 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
         }
       }
     };
-    dma_issue();
+    if constexpr (DBG & 64) {   // timing study: the fragment reads ahead of the DMA instructions (3-4 % slower, profiles/r03_p8_variants.txt)
+      frag_reads();
+      dma_issue();
+    } else {   // the DMA instructions first: the texture path works on them while the wave issues its ds_reads
+      dma_issue();
+      __builtin_amdgcn_sched_barrier(0);
+      frag_reads();
+    }
     dma_wait();
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -406,13 +415,12 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     auto mfmas = [&](auto lo_c, auto hi_c) {
       constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
       if constexpr (DBG & 1) {
-        // keep the fragment reads alive without matrix work
+        // keep the fragment reads alive without matrix work (one conversion + add per fragment)
         if constexpr (LO == 0) {
+          float keep = 0.f;
 #pragma unroll
-          for (int i = 0; i < NF; ++i) {
-            asm volatile("" ::"v"(Wf[0][i]), "v"(Wf[1][i]));
-            asm volatile("" ::"v"(Xf[0][i]), "v"(Xf[1][i]));
-          }
+          for (int i = 0; i < NF; ++i) keep += (float)Wf[0][i][0] + (float)Wf[1][i][0] + (float)Xf[0][i][0] + (float)Xf[1][i][0];
+          acc[0][0][0][0] += keep;
         }
       } else if constexpr (P == 1) {
         constexpr int HA = PH >> 1, HW = (PH == 1 || PH == 2) ? 1 : 0;
@@ -715,6 +723,8 @@ int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_pl
     if (dbg == 14) return launch_planes8<PV, EV, 14>(g, s);       \
     if (dbg == 15) return launch_planes8<PV, EV, 15>(g, s);       \
     if (dbg == 9) return launch_planes8<PV, EV, 9>(g, s);         \
+    if (dbg == 64) return launch_planes8<PV, EV, 64>(g, s);       \
+    if (dbg == 72) return launch_planes8<PV, EV, 72>(g, s);       \
     if (dbg == 10) return launch_planes8<PV, EV, 10>(g, s);       \
     if (dbg == 12) return launch_planes8<PV, EV, 12>(g, s);       \
   }
