@@ -51,6 +51,8 @@ def kernel_label(name, tile):
         return f"gemm_planes8_kernel<P={name[8:]}> (forward nn.Linear on bf16-plane operands, persistent 8-phase kernel)"
     if name.startswith("PLANES"):
         return f"gemm_planes_kernel<P={name[6:]}> (forward nn.Linear on bf16-plane operands)"
+    if name == "BWD":
+        return "gemm_bwd_fused_kernel: dgrad + wgrad of one nn.Linear in one launch (+ split-K fold)"
     fam = {"NN": "dgrad (dy @ w)", "TN": "wgrad (dy^T @ x, split-K)", "patch": "patch embed", "NTgen": "forward nn.Linear, general kernel"}.get(name, name)
     return f"gemm f32 {TILE_NAMES[tile]}: {fam}"
 

@@ -72,6 +72,9 @@ extern "C" int tt_debug_read_clock_stamps(unsigned long long* host, int count) {
 }
 #endif
 
+// (Round 3, measured and not kept: the 64 x 64 small-grid instance with FOUR 64-deep slabs in flight in registers - 236 VGPRs, every
+// slab of a K = 384 product requested up front - made BASELINE C1's step SLOWER, 3.17 against 2.91 ms in two interleaved pairs of runs:
+// these launches are not bound by the slab round trips alone.)
 // BK = 16 is the throughput instance (5-6 workgroups per CU hide every latency).  BK = 64 is for grids of at most about one
 // workgroup per CU (BASELINE C1: 2 x 2 frames = 788 rows, 13 row tiles): there nothing hides the global-load latency of the
 // one slab in flight, a launch is (K / BK) dependent round trips long, and four times deeper slabs cut the trips four-fold.

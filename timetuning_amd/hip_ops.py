@@ -160,16 +160,18 @@ def linear_bwd(dy, w, x, gelu_pre=None, need_bias=True):
     M, N = dy.shape
     K = w.shape[1]
     assert w.shape[0] == N and tuple(x.shape) == (M, K), (dy.shape, w.shape, x.shape)
-    if PROFILE is not None:   # per-GEMM event profile: one call per product (the same kernels)
-        dw, db = linear_bwd_weight(dy, x, need_bias=need_bias)
-        return linear_bwd_data(dy, w, gelu_pre=gelu_pre), dw, db
     if gelu_pre is not None: _chk(gelu_pre, "gelu_pre")
     dx = torch.empty((M, K), dtype=f32, device=dy.device)
     dw = torch.empty((N, K), dtype=f32, device=dy.device)
     db = torch.empty((N,), dtype=f32, device=dy.device) if need_bias else None
     nb = lib.tt_linear_bwd_weight_workspace_bytes(M, N, K)
     ws = _ws(nb, dy.device)
+    e0 = _prof_begin()   # booked as ONE entry: both products (4 M N K flops) and the split-K fold they end in
     _lib.check(lib.tt_linear_bwd(_p(dy), _p(w), _p(x), _p(gelu_pre), _p(dx), _p(dw), _p(db), M, N, K, _p(ws), nb, _stream()), "tt_linear_bwd")
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append(("BWD", 3, 4.0 * M * N * K, e0, e1))
     return dx, dw, db
 
 
