@@ -73,29 +73,38 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_bf16_kernel(const __bf16
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
       }
     }
-    // softmax over the keys of this lane column: registers, then the other half (lane ^ 32)
+    // softmax over the keys of this lane column: registers, then the other half (lane ^ 32).  The softmax phase is VALU time the
+    // matrix pipe idles through (112 elements per lane and query tile), so it is kept to a max, one fma and one v_exp per element:
+    // the logit scale is folded into the exponent's constant, p = 2^(s c - m c) with c = scale log2(e), and only the key tiles that
+    // reach past N pay for the mask.
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+      if (kt * 32 + 31 >= N) {   // (uniform) a key tile that reaches past N: masked to -inf before the max
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= N) sacc[kt][e] = -INFINITY;
+        }
+      }
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float v = key < N ? sacc[kt][e] * scale : -INFINITY;
-        sacc[kt][e] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float c = scale * 1.44269504088896340736f;   // (scale > 0: the max of the raw scores is the max of the scaled ones)
+    const float mc = mx * c;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float p = fast_exp(sacc[kt][e] - mx);
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], c, -mc));
         sacc[kt][e] = p;
         sum += p;
       }
     sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);
 
     // O^T [64 d x 32 queries] = V^T P^T
     f32x16 oacc[2];
@@ -155,7 +164,7 @@ using namespace tt;
 
 extern "C" int tt_attention_fwd_bf16(const void* qkv, void* out, int F, int N, int H, int head_dim, float scale, tt_stream_t stream) {
   TT_REQUIRE(qkv && out, "attention_fwd_bf16: null pointer");
-  TT_REQUIRE(F > 0 && N > 0 && H > 0, "attention_fwd_bf16: bad shape");
+  TT_REQUIRE(F > 0 && N > 0 && H > 0 && scale > 0.f, "attention_fwd_bf16: bad shape / non-positive scale");
   TT_REQUIRE(head_dim == 64, "attention_fwd_bf16: head_dim must be 64 (got %d)", head_dim);
   TT_REQUIRE(N <= 256, "attention_fwd_bf16: N <= 256 tokens (got %d); longer sequences use the fp32 kernel", N);
   TT_REQUIRE(aligned16(qkv) && aligned16(out), "attention_fwd_bf16: buffers must be 16-byte aligned");

@@ -64,11 +64,13 @@ __global__ __launch_bounds__(256, TT_Q2_WAVES_PER_SIMD) void attention_fwd_q2_ke
     }
   }
   __syncthreads();
+  // scores in LOG2 units (q pre-multiplied by scale log2(e)): the softmax is then a subtract and a bare v_exp_f32 per element
+  const float scale2 = scale * 1.44269504088896340736f;
   float qreg[2][16];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) qreg[t][s] = smem[(wave * 32 + t * 16 + qi) * Q2_KSTR + 4 * s + g] * scale;
+    for (int s = 0; s < 16; ++s) qreg[t][s] = smem[(wave * 32 + t * 16 + qi) * Q2_KSTR + 4 * s + g] * scale2;
   __syncthreads();
 
   float4 st[2];
@@ -134,12 +136,15 @@ __global__ __launch_bounds__(256, TT_Q2_WAVES_PER_SIMD) void attention_fwd_q2_ke
   for (int t = 0; t < 2; ++t) {
     float mx = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < NT; ++k)
+    for (int k = 0; k < NT; ++k) {
+      if (16 * k + 15 >= N) {   // (wave-uniform) only the last key tiles can hold keys >= N
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (16 * k + 4 * g + e >= N) sacc[t][k][e] = -INFINITY;
-        mx = fmaxf(mx, sacc[t][k][e]);
+        for (int e = 0; e < 4; ++e)
+          if (16 * k + 4 * g + e >= N) sacc[t][k][e] = -INFINITY;
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, sacc[t][k][e]);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256, TT_Q2_WAVES_PER_SIMD) void attention_fwd_q2_ke
     for (int k = 0; k < NT; ++k)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float p = fast_exp(sacc[t][k][e] - mx);
+        const float p = __builtin_amdgcn_exp2f(sacc[t][k][e] - mx);
         sacc[t][k][e] = p;
         sum += p;
       }
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256, TT_Q2_WAVES_PER_SIMD) void attention_fwd_q2_ke
     sum += __shfl_xor(sum, 32, 64);
     inv[t] = 1.0f / sum;
     const int q = q0 + 16 * t + qi;
-    if (lse && g == 0 && q < N) lse[((long long)f * H + h) * N + q] = mx + logf(sum);
+    if (lse && g == 0 && q < N) lse[((long long)f * H + h) * N + q] = (mx + log2f(sum)) * 0.69314718055994530942f;   // natural-log units
   }
 
   f32x4 oacc[2][4];

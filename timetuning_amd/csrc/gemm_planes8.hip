@@ -313,12 +313,25 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
         for (int e = 0; e < 16; ++e) acc[a][b][m][e] = 0.f;
   bf16x8 Wf[2][NF], Xf[2][NF];
 
+  // ablation operands (DBG & 4): per-lane pseudo-random bf16 in [-2, 2), made once, the mantissas re-mixed per fragment address with five
+  // VALU instructions - NOT constants, because the clock the chip holds under MFMA load depends on the operand data
+  // (MI355X_MICROARCH.md "DVFS give-back")
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 rnd4 = {0u, 0u, 0u, 0u};
+  if constexpr (DBG & 4) {
+    unsigned st = (unsigned)threadIdx.x * 2654435761u + (unsigned)blockIdx.x * 40503u + 12345u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      st = st * 1664525u + 1013904223u;
+      rnd4[e] = (st & 0x80ff80ffu) | 0x3f003f00u | ((st >> 5) & 0x00800080u);
+    }
+  }
   auto ld = [&](int off) {
     if constexpr (DBG & 4) {
-      bf16x8 z;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = (__bf16)(float)(off & 7);
-      return z;
+      const unsigned m = ((unsigned)off * 0x9E3779B1u >> 9) & 0x007f007fu;
+      u32x4 z = rnd4;
+      z[0] ^= m; z[1] ^= m << 1 & 0x007f007fu; z[2] ^= m >> 1; z[3] ^= ~m & 0x007f007fu;
+      return __builtin_bit_cast(bf16x8, z);
     } else {
       return *reinterpret_cast<const bf16x8*>(smem + off);
     }

@@ -17,7 +17,7 @@ for P, M, N, K, po in ((1, 25216, 2304, 768, 1), (3, 25216, 1152, 384, 0)):
     x = split(torch.randn(M, K, device="cuda"), P); w = split(torch.randn(N, K, device="cuda") * 0.05, P); b = torch.randn(N, device="cuda")
     y = torch.empty(M, N, device="cuda") if not po else None
     yp = torch.empty(po, M, N, device="cuda", dtype=torch.bfloat16) if po else None
-    for dbg, name in ((0, "full"), (14, "MFMA only"), (9, "skeleton (no MFMA, no epilogue)"), (8, "no epilogue"), (10, "no epilogue, no DMA"), (12, "no epilogue, no LDS reads")):
+    for dbg, name in ((0, "full"), (14, "MFMA only (pseudo-random register operands)"), (9, "skeleton (no MFMA, no epilogue)"), (8, "no epilogue"), (10, "no epilogue, no DMA (MFMA + LDS reads of the random data the full variant left in LDS)"), (12, "no epilogue, no LDS reads (MFMA on pseudo-random registers + DMA)")):
         os.environ["TT_P8_DBG"] = str(dbg)
         print(f"== P={P} {name}", flush=True)
         def go():
@@ -29,3 +29,4 @@ for P, M, N, K, po in ((1, 25216, 2304, 768, 1), (3, 25216, 1152, 384, 0)):
         go()
         torch.cuda.synchronize()
         sys.stdout.flush()
+        print(f"   ^ {name}", flush=True)
