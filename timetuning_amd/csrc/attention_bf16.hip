@@ -20,13 +20,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int NKT>
+// DBG (timing-study builds only, -DTT_ABF_ABLATE + TT_ABF_DBG): 1 no MFMAs, 2 no K/V DMA, 4 no Q loads, 8 no exponentials, 16 no stores
+template <int NKT, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void attention_fwd_bf16_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out, int N, int H,
                                                                     float scale) {
   constexpr int KROWS = NKT * 32;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KROWS * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KROWS * 128 + 4 * 4096];
   unsigned char* Ks = smem;
   unsigned char* Vs = smem + KROWS * 128;
+  unsigned char* Os = smem + 2 * KROWS * 128 + (threadIdx.x >> 6) * 4096;   // this wave's output tile: 32 queries x 128 B, chunks swizzled
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int fh = blockIdx.x, f = fh / H, hd = fh - f * H;
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_bf16_kernel(const __bf16
   // ---- K and V: 8 keys x 128 B per DMA piece; lane -> (key, slot), source chunk = slot ^ swizzle(key)
   {
     const int l_row = lane >> 3, l_slot = lane & 7;
-    for (int piece = wave; piece < KROWS / 8; piece += 4) {
+    for (int piece = wave; piece < ((DBG & 2) ? 0 : KROWS / 8); piece += 4) {
       const int key = piece * 8 + l_row;
       const int krow = key < N ? key : N - 1;
       const __bf16* src = base + (long long)krow * D3;
@@ -57,7 +59,14 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_bf16_kernel(const __bf16
     const int qrow = query < N ? query : N - 1;
     bf16x8 qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long long)qrow * D3 + 16 * ks + 8 * h);
+    for (int ks = 0; ks < 4; ++ks) {
+      if constexpr (DBG & 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (__bf16)(0.01f * (float)((lane + j + ks) & 15));
+      } else {
+        qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long long)qrow * D3 + 16 * ks + 8 * h);
+      }
+    }
 
     f32x16 sacc[NKT];
 #pragma unroll
@@ -70,7 +79,8 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_bf16_kernel(const __bf16
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + (((2 * ks + h) ^ sw) << 4));
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
+        if constexpr (DBG & 1) sacc[kt][ks] += (float)kf[0] * (float)qf[ks][1];
+        else sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
       }
     }
     // softmax over the keys of this lane column: registers, then the other half (lane ^ 32).  The softmax phase is VALU time the
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_bf16_kernel(const __bf16
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], c, -mc));
+        const float p = (DBG & 8) ? fmaf(sacc[kt][e], c, -mc) : __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], c, -mc));
         sacc[kt][e] = p;
         sum += p;
       }
@@ -139,12 +149,15 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_bf16_kernel(const __bf16
           union { s16x4 s2[2]; bf16x8 v; } vf;
           vf.s2[0] = lo;
           vf.s2[1] = hi;
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf, oacc[dt], 0, 0, 0);
+          if constexpr (DBG & 1) oacc[dt][s] += (float)vf.v[0] * (float)pf[1];
+          else oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf, oacc[dt], 0, 0, 0);
         }
       }
     }
-    if (query < N) {
-      __bf16* o = out + ((long long)f * N + query) * Dm + hd * 64;
+    // The output tile leaves through the wave's private LDS scratch so that a store instruction writes EIGHT WHOLE 128-byte rows (16 B per
+    // lane): written straight from the accumulator layout a row would go out as sixteen 8-byte pieces in eight instructions - 42 of the
+    // kernel's 56 us (tools/abf_ablate.py, round 3).  16-byte chunk c of row q sits at chunk position c ^ (q & 7).
+    if constexpr (!(DBG & 16)) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -152,8 +165,16 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_bf16_kernel(const __bf16
           bf16x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = (__bf16)(oacc[dt][4 * g4 + e] * inv);
-          *reinterpret_cast<bf16x4*>(o + dt * 32 + 8 * g4 + 4 * h) = v;
+          *reinterpret_cast<bf16x4*>(Os + r * 128 + (((dt * 4 + g4) ^ (r & 7)) << 4) + 8 * h) = v;
         }
+      const int c8 = lane & 7;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (lane >> 3) + 8 * i;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + row * 128 + ((c8 ^ (row & 7)) << 4));
+        const int q = qt * 32 + row;
+        if (q < N) *reinterpret_cast<bf16x8*>(out + ((long long)f * N + q) * Dm + hd * 64 + 8 * c8) = v;
+      }
     }
   }
 }
@@ -171,6 +192,18 @@ extern "C" int tt_attention_fwd_bf16(const void* qkv, void* out, int F, int N, i
   hipStream_t s = as_stream(stream);
   const __bf16* q = static_cast<const __bf16*>(qkv);
   __bf16* o = static_cast<__bf16*>(out);
+#ifdef TT_ABF_ABLATE
+  {
+    const char* e = getenv("TT_ABF_DBG");
+    const int dbg = e ? atoi(e) : 0;
+    TT_REQUIRE(N <= 224, "ablation build: N <= 224");
+#define ABF(D) case D: hipLaunchKernelGGL((attention_fwd_bf16_kernel<7, D>), dim3(F * H), dim3(256), 0, s, q, o, N, H, scale); break;
+    switch (dbg) { ABF(0) ABF(1) ABF(2) ABF(4) ABF(8) ABF(16) ABF(22) ABF(9) ABF(31) ABF(30) default: TT_REQUIRE(false, "TT_ABF_DBG"); }
+#undef ABF
+    TT_CHECK_LAUNCH("attention_fwd_bf16");
+    return TT_OK;
+  }
+#endif
   if (N <= 224) hipLaunchKernelGGL((attention_fwd_bf16_kernel<7>), dim3(F * H), dim3(256), 0, s, q, o, N, H, scale);
   else hipLaunchKernelGGL((attention_fwd_bf16_kernel<8>), dim3(F * H), dim3(256), 0, s, q, o, N, H, scale);
   TT_CHECK_LAUNCH("attention_fwd_bf16");

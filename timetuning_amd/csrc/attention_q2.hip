@@ -198,7 +198,11 @@ __global__ __launch_bounds__(256, TT_Q2_WAVES_PER_SIMD) void attention_fwd_q2_ke
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int q = q0 + 16 * t + qi;
+#ifdef TT_Q2_NOSTORE   // timing-study builds only (tools/build_variant.sh): what the output stores cost
+    if (q < -1) {
+#else
     if (q < N) {
+#endif
       float* o = out + ((long long)f * N + q) * (H * Q2_HD) + h * Q2_HD + 4 * g;
 #pragma unroll
       for (int d = 0; d < 4; ++d)

@@ -246,6 +246,7 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   auto cursor_item = [&]() {
     int row0, n0;
     item(d_item, row0, n0, d_half);
+    if constexpr (DBG & 32) row0 = 0, n0 = 0;   // (ablation) every workgroup streams the SAME operand tile: the DMA stream from a warm L2
     d_wbase = n0 * K2;
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha)
@@ -313,30 +314,36 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
         for (int e = 0; e < 16; ++e) acc[a][b][m][e] = 0.f;
   bf16x8 Wf[2][NF], Xf[2][NF];
 
-  // ablation operands (DBG & 4): per-lane pseudo-random bf16 in [-2, 2), made once, the mantissas re-mixed per fragment address with five
-  // VALU instructions - NOT constants, because the clock the chip holds under MFMA load depends on the operand data
-  // (MI355X_MICROARCH.md "DVFS give-back")
+  // ablation operands (DBG & 4): four per-lane pseudo-random bf16x8 vectors in [-2, 2), made once and handed out by the (compile-time)
+  // fragment tag - NOT constants, because the clock the chip holds under MFMA load depends on the operand data (MI355X_MICROARCH.md
+  // "DVFS give-back"), and no VALU work per fragment
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 rnd4 = {0u, 0u, 0u, 0u};
+  u32x4 rnd4[4];
   if constexpr (DBG & 4) {
     unsigned st = (unsigned)threadIdx.x * 2654435761u + (unsigned)blockIdx.x * 40503u + 12345u;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      st = st * 1664525u + 1013904223u;
-      rnd4[e] = (st & 0x80ff80ffu) | 0x3f003f00u | ((st >> 5) & 0x00800080u);
-    }
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        st = st * 1664525u + 1013904223u;
+        rnd4[v][e] = (st & 0x80ff80ffu) | 0x3f003f00u | ((st >> 5) & 0x00800080u);
+      }
   }
-  auto ld = [&](int off) {
+  auto ld = [&](int off, int tag) {
     if constexpr (DBG & 4) {
-      const unsigned m = ((unsigned)off * 0x9E3779B1u >> 9) & 0x007f007fu;
-      u32x4 z = rnd4;
-      z[0] ^= m; z[1] ^= m << 1 & 0x007f007fu; z[2] ^= m >> 1; z[3] ^= ~m & 0x007f007fu;
-      return __builtin_bit_cast(bf16x8, z);
+      return __builtin_bit_cast(bf16x8, rnd4[tag & 3]);
     } else {
       return *reinterpret_cast<const bf16x8*>(smem + off);
     }
   };
 
+#ifdef TT_P8_STAMP   // diagnostic build only: where a wave's steady-state phase goes (s_memtime stamps, consumed behind the phase's own lgkmcnt(0))
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
+  unsigned st_issue = 0, st_reads = 0, st_wait = 0, st_bar1 = 0, st_mfma = 0, st_bar2 = 0, st_n = 0;
+#define P8_STAMP(t) asm volatile("s_memtime %0" : "=s"(t)::"memory")
+#else
+#define P8_STAMP(t)
+#endif
   int post_epi = 0;          // phases left in which the stores of the last epilogue may still be outstanding
   bool post_half = false;    // ... and whether that epilogue was a half tile's
   bool c_half = false;       // the item being computed is a half tile
@@ -356,33 +363,33 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
         // chunks W0 X0 W1 X1 in slots 0..3; quadrants (hA, hW): (0,0) (0,1) (1,1) (1,0)
         if constexpr (PH == 0) {
 #pragma unroll
-          for (int ks = 0; ks < NKS; ++ks) Wf[0][ks] = ld(base + 0 * HALF_B + w_slice + lo[ks]);
+          for (int ks = 0; ks < NKS; ++ks) Wf[0][ks] = ld(base + 0 * HALF_B + w_slice + lo[ks], ks);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) Xf[mt][ks] = ld(base + 1 * HALF_B + x_slice + mt * 32 * ROWB + lo[ks]);
+            for (int ks = 0; ks < NKS; ++ks) Xf[mt][ks] = ld(base + 1 * HALF_B + x_slice + mt * 32 * ROWB + lo[ks], 1 + mt + ks);
         } else if constexpr (PH == 1) {
 #pragma unroll
-          for (int ks = 0; ks < NKS; ++ks) Wf[1][ks] = ld(base + 2 * HALF_B + w_slice + lo[ks]);
+          for (int ks = 0; ks < NKS; ++ks) Wf[1][ks] = ld(base + 2 * HALF_B + w_slice + lo[ks], 2 + ks);
         } else if constexpr (PH == 2) {
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) Xf[mt][ks] = ld(base + 3 * HALF_B + x_slice + mt * 32 * ROWB + lo[ks]);
+            for (int ks = 0; ks < NKS; ++ks) Xf[mt][ks] = ld(base + 3 * HALF_B + x_slice + mt * 32 * ROWB + lo[ks], 3 + mt + ks);
         }
       } else {
         // chunks W X0 X1 in slots 0..2 (planes inside a chunk); phases (hA, ks): (0,0) (0,1) (1,1) (1,0)
         constexpr int HA = PH >> 1, KS = (PH == 1 || PH == 2) ? 1 : 0;
         if constexpr (PH < 2) {
 #pragma unroll
-          for (int p = 0; p < P; ++p) Wf[KS][p] = ld(base + 0 * HALF_B + p * PLANE_B + w_slice + lo[KS]);
+          for (int p = 0; p < P; ++p) Wf[KS][p] = ld(base + 0 * HALF_B + p * PLANE_B + w_slice + lo[KS], p + KS);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int p = 0; p < P; ++p) Xf[mt][p] = ld(base + (1 + HA) * HALF_B + p * PLANE_B + x_slice + mt * 32 * ROWB + lo[KS]);
+          for (int p = 0; p < P; ++p) Xf[mt][p] = ld(base + (1 + HA) * HALF_B + p * PLANE_B + x_slice + mt * 32 * ROWB + lo[KS], 1 + mt + p + HA);
       }
     }
     };
@@ -416,13 +423,26 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
       frag_reads();
       dma_issue();
     } else {   // the DMA instructions first: the texture path works on them while the wave issues its ds_reads
+      P8_STAMP(ts0);
       dma_issue();
       __builtin_amdgcn_sched_barrier(0);
+      P8_STAMP(ts1);
       frag_reads();
+      P8_STAMP(ts2);
     }
     dma_wait();
+    P8_STAMP(ts3);
     __builtin_amdgcn_s_barrier();
+    P8_STAMP(ts4);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef TT_P8_STAMP
+    if (steady) {   // (ts5 / ts6: the previous phase's MFMA part)
+      st_issue += (unsigned)(ts1 - ts0); st_reads += (unsigned)(ts2 - ts1); st_wait += (unsigned)(ts3 - ts2); st_bar1 += (unsigned)(ts4 - ts3);
+      if (ts6 > ts5 && ts0 > ts6) { st_mfma += (unsigned)(ts6 - ts5); st_bar2 += (unsigned)(ts0 - ts6); }
+      ++st_n;
+    }
+    P8_STAMP(ts5);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // MFMAs [lo, hi) of this phase's sequence (8 at P = 1, 12 at P = 3)
     auto mfmas = [&](auto lo_c, auto hi_c) {
@@ -459,6 +479,7 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     constexpr int NM = P == 1 ? 2 * NKS : 12;
     if (work) mfmas(std::integral_constant<int, 0>{}, std::integral_constant<int, NM>{});
     __builtin_amdgcn_sched_barrier(0);
+    P8_STAMP(ts6);   // (all MFMAs issued)
     __builtin_amdgcn_s_barrier();
   };
 
@@ -645,6 +666,12 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     if (!grp1) __builtin_amdgcn_s_barrier();  // realign: both groups run their epilogues at the same time
     epilogue(row0, n0, c_half);
   }
+#ifdef TT_P8_STAMP
+  if (g.clock_print && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x == 3 && st_n > 0)
+    printf("p8 stamps: wave %d  %u steady phases, cycles per phase: DMA issue %.0f | fragment reads issued %.0f | counted wait %.0f | barrier 1 %.0f | "
+           "lgkmcnt(0) + MFMAs issued %.0f | barrier 2 (to the next phase's start) %.0f\n", wave, st_n, (double)st_issue / st_n, (double)st_reads / st_n,
+           (double)st_wait / st_n, (double)st_bar1 / st_n, (double)st_mfma / st_n, (double)st_bar2 / st_n);
+#endif
 #ifdef TT_P8_CLOCK
   if (g.clock_print && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 101)) {
     const unsigned long long dt = __builtin_amdgcn_s_memtime() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
@@ -740,6 +767,9 @@ int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_pl
     if (dbg == 72) return launch_planes8<PV, EV, 72>(g, s);       \
     if (dbg == 10) return launch_planes8<PV, EV, 10>(g, s);       \
     if (dbg == 12) return launch_planes8<PV, EV, 12>(g, s);       \
+    if (dbg == 32) return launch_planes8<PV, EV, 32>(g, s);       \
+    if (dbg == 40) return launch_planes8<PV, EV, 40>(g, s);       \
+    if (dbg == 41) return launch_planes8<PV, EV, 41>(g, s);       \
   }
     P8_DBG_CASE(1, P8_BF16) P8_DBG_CASE(1, P8_BF16_GELU) P8_DBG_CASE(1, P8_F32_RES)
     P8_DBG_CASE(3, P8_F32) P8_DBG_CASE(3, P8_F32_RES) P8_DBG_CASE(3, P8_PL3_GELU)

@@ -10,7 +10,7 @@ lib.tt_linear_fwd_planes.argtypes = [vp, ll, vp, ll, i32, vp, vp, vp, vp, vp, ll
 lib.tt_split_planes.restype = C.c_int
 lib.tt_split_planes.argtypes = [vp, vp, ll, i32, ll, vp]
 st = torch.cuda.current_stream().cuda_stream
-NAMES = {0: "full", 1: "noMFMA", 2: "noDMA", 4: "noLDSrd", 8: "noEpi", 16: "epiNoGlobal", 9: "noEpi+noMFMA", 11: "noEpi+noMFMA+noDMA", 13: "noEpi+noMFMA+noLDS", 15: "barriers only", 14: "MFMA only(noEpi,noDMA,noLDS)", 64: "reads before DMA", 72: "noEpi+reads before DMA"}
+NAMES = {0: "full", 32: "full, one warm tile", 40: "noEpi, one warm tile", 41: "noEpi+noMFMA, one warm tile", 1: "noMFMA", 2: "noDMA", 4: "noLDSrd", 8: "noEpi", 16: "epiNoGlobal", 9: "noEpi+noMFMA", 11: "noEpi+noMFMA+noDMA", 13: "noEpi+noMFMA+noLDS", 15: "barriers only", 14: "MFMA only(noEpi,noDMA,noLDS)", 64: "reads before DMA", 72: "noEpi+reads before DMA"}
 def split(x, P):
     out = torch.empty((P,) + tuple(x.shape), device="cuda", dtype=torch.bfloat16)
     assert lib.tt_split_planes(x.data_ptr(), out.data_ptr(), x.numel(), P, x.numel(), st) == 0
