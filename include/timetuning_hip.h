@@ -34,7 +34,7 @@ extern "C" {
 typedef void* tt_stream_t;
 
 const char* tt_last_error(void);
-int tt_abi_version(void);   /* 3 = this header (2: before the coarse entry points) */
+int tt_abi_version(void);   /* 4 = this header (3: before tt_vit_params.patch_wp; 2: before the coarse entry points) */
 /* Fills name (<= cap bytes) with the gcnArchName of the current device; returns CU count or <0. */
 int tt_device_info(char* name, int cap);
 
@@ -109,6 +109,15 @@ int tt_get_gemm_precision(void);
 int tt_patch_embed_fwd(const float* img, const int32_t* frame_map, const float* w, const float* bias,
                        const float* cls, const float* pos, float* tokens, int F, int C, int H, int W, int P, int D,
                        tt_stream_t stream);
+/* The same on bf16 operands - BASELINE C4's bf16 path, what torch.autocast makes of the conv (dino_vision_transformer.py:166-171):
+ * w_planes = tt_split_planes(w, 1 plane) [D, C*P*P] bf16, the patches rounded to bf16 on the way into an im2col buffer, fp32
+ * accumulation, fp32 tokens.  One row pass + ONE tt_linear_fwd_planes over all F (n + 1) token rows (the class-token rows are zero
+ * rows that meet cls + pos[0] in the residual).  Needs P % 4 == 0, W % 4 == 0, C P P % 64 == 0, D % 64 == 0; workspace of
+ * tt_patch_embed_planes_workspace_bytes = F (n + 1) C P P bf16. */
+size_t tt_patch_embed_planes_workspace_bytes(int F, int C, int H, int W, int P);
+int tt_patch_embed_fwd_planes(const float* img, const int32_t* frame_map, const void* w_planes, const float* bias, const float* cls,
+                              const float* pos, float* tokens, int F, int C, int H, int W, int P, int D, void* workspace,
+                              size_t workspace_bytes, tt_stream_t stream);
 
 /* ---- k3: LayerNorm over the last dim (dino_vision_transformer.py:139,143,196; eps = 1e-6)
  *   mean/rstd (optional, [rows]) are saved for backward.  `rows` counts OUTPUT rows.
@@ -368,6 +377,8 @@ typedef struct {
   int dim, heads, hidden, patch;                /* D, attention heads (head_dim = D / heads), MLP width, patch size */
   int planes;                                   /* 0: fp32 operands (tt_linear_fwd); 1 / 3: the bf16-plane path of the blocks
                                                    (tt_linear_fwd_planes; 1 = BASELINE C4's bf16 path, 3 = fp32-accurate), D % 64 == 0 */
+  const void* patch_wp;                         /* planes == 1, optional: patch_w as one bf16 plane [D, C P P] - prepare_tokens then runs
+                                                   tt_patch_embed_fwd_planes where its shape rules hold (ABI 4) */
 } tt_vit_params;
 typedef struct {
   const float* w;   /* [out_features, in_features] */

@@ -720,6 +720,48 @@ int tt_cpu_attention_fwd_bf16(const void* qkv, void* out, int F, int N, int H, i
   return 0;
 }
 
+/* ---- PatchEmbed on bf16 operands (tt_patch_embed_fwd_planes): patches and weight rounded to bf16 (the weight arrives as its plane), double
+ *      accumulation, fp32 tokens (dino_vision_transformer.py:166-171,236-247 under autocast) */
+static float bf16_bits_to_float(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static float round_to_bf16(float x) {
+  uint16_t b;
+  tt_cpu_split_planes(&x, &b, 1, 1, 1, NULL);
+  return bf16_bits_to_float(b);
+}
+size_t tt_cpu_patch_embed_planes_workspace_bytes(int F, int C, int H, int W, int P) { return 0; }
+int tt_cpu_patch_embed_fwd_planes(const float* img, const int32_t* frame_map, const void* w_planes, const float* bias, const float* cls,
+                                  const float* pos, float* tokens, int F, int C, int H, int W, int P, int D, void* workspace,
+                                  size_t workspace_bytes, tt_stream_t stream) {
+  (void)stream; (void)workspace; (void)workspace_bytes;
+  const uint16_t* wp = (const uint16_t*)w_planes;
+  const int gh = H / P, gw = W / P, n = gh * gw, K = C * P * P;
+  float* patch = (float*)malloc((size_t)K * 4);
+  if (!patch) return -3;
+  for (int f = 0; f < F; ++f) {
+    const float* src = img + (size_t)(frame_map ? frame_map[f] : f) * C * H * W;
+    float* tok = tokens + (size_t)f * (n + 1) * D;
+    for (int d = 0; d < D; ++d) tok[d] = (cls[d] + pos[d] - bias[d]) + bias[d];   /* the zero row meets the bias in the GEMM's epilogue */
+    for (int py = 0; py < gh; ++py)
+      for (int px = 0; px < gw; ++px) {
+        for (int c = 0; c < C; ++c)
+          for (int y = 0; y < P; ++y)
+            for (int x = 0; x < P; ++x) patch[(c * P + y) * P + x] = round_to_bf16(src[((size_t)c * H + py * P + y) * W + px * P + x]);
+        for (int d = 0; d < D; ++d) {
+          double s = 0.0;
+          for (int k = 0; k < K; ++k) s += (double)patch[k] * bf16_bits_to_float(wp[(size_t)d * K + k]);
+          tok[(size_t)(1 + py * gw + px) * D + d] = ((float)s + bias[d]) + pos[(size_t)(1 + py * gw + px) * D + d];
+        }
+      }
+  }
+  free(patch);
+  return 0;
+}
+
 /* ---- the coarse entry points (include/timetuning_hip.h, "Coarse entry points"): the same sequences over the twins above.
  *      Scratch is malloc'ed here (the workspace arguments are ignored, the *_workspace_bytes twins return 0). */
 typedef struct {
@@ -733,6 +775,7 @@ typedef struct {
   const float *norm_w, *norm_b;
   int dim, heads, hidden, patch;
   int planes;
+  const void* patch_wp;
 } tt_cpu_vit_params;
 typedef struct { const float* w; const float* b; int out_features, in_features; } tt_cpu_linear_params;
 
@@ -748,7 +791,13 @@ int tt_cpu_vit_forward(const tt_cpu_vit_params* p, const float* img, const int32
   const int N = 1 + (H / p->patch) * (W / p->patch);
   const size_t M = (size_t)F * N;
   const float scale = 1.0f / sqrtf((float)hd);
-  if (img) tt_cpu_patch_embed_fwd(img, frame_map, p->patch_w, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, stream);
+  if (img) {
+    /* (C P P <= 9 D: the HIP side keeps the im2col rows in the attention phase of its scratch) */
+    if (P == 1 && p->patch_wp && p->patch % 4 == 0 && W % 4 == 0 && (C * p->patch * p->patch) % 64 == 0 && D % 64 == 0 && C * p->patch * p->patch <= 9 * D)
+      tt_cpu_patch_embed_fwd_planes(img, frame_map, p->patch_wp, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, NULL, 0, stream);
+    else
+      tt_cpu_patch_embed_fwd(img, frame_map, p->patch_w, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, stream);
+  }
   float* h = (float*)malloc(M * D * 4), *qkv_own = (float*)malloc(M * 3 * D * 4), *att = (float*)malloc(M * D * 4);
   float* act = (float*)malloc(M * Hd * 4);
   const int PP = P > 0 ? P : 1;

@@ -419,6 +419,17 @@ def _round2b_cases(side):
     ob = np.empty((2, 21, 128), np.uint16)
     side.run("attention_fwd_bf16", qb, ob, 2, 21, 2, 64, 0.125, st, outs=(ob,))
     R["att_bf16"] = (qb, ob.copy())
+    # patch embedding on bf16 operands (frame map, 2 x 3 grid, D = 64)
+    Fp, C, Hh, Ww, P, Dm = 3, 3, 32, 48, 16, 64
+    img, w, b, cls, pos = f32(4, C, Hh, Ww), f32(Dm, C * P * P, scale=0.05), f32(Dm), f32(Dm), f32(1 + 6, Dm)
+    fmap = np.array([2, 0, 3], np.int32)
+    wpl = np.empty((1, Dm, C * P * P), np.uint16)
+    side.run("split_planes", w, wpl, Dm * C * P * P, 1, Dm * C * P * P, st, outs=(wpl,))
+    tok = np.empty((Fp, 7, Dm), np.float32)
+    nbp = max(int(getattr(side.lib, side.prefix + "patch_embed_planes_workspace_bytes")(Fp, C, Hh, Ww, P)), 16)
+    wsp = np.empty(nbp, np.uint8)
+    side.run("patch_embed_fwd_planes", img, fmap, wpl, b, cls, pos, tok, Fp, C, Hh, Ww, P, Dm, wsp, nbp, st, outs=(tok,))
+    R["patch_bf16"] = (img, fmap, w, wpl.copy(), b, cls, pos, tok.copy())
     return R
 
 
@@ -471,6 +482,14 @@ def test_round2b_twins_against_torch(twin):
     q, k, v = qf.view(2, 21, 3, 2, 64).permute(2, 0, 3, 1, 4)
     o = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(2, 21, 128)
     assert _re(_bf(ob), o.numpy()) < 1.5e-2
+    img, fmap, w, wpl, b, cls, pos, tok = R["patch_bf16"]
+    assert np.array_equal(_bf(wpl)[0], torch.from_numpy(w).to(torch.bfloat16).double().numpy())
+    conv = F.conv2d(torch.from_numpy(img[fmap]).to(torch.bfloat16).double(), torch.from_numpy(_bf(wpl)[0]).view(64, 3, 16, 16),
+                    torch.from_numpy(b).double(), stride=16)     # the conv of the ROUNDED operands, exactly
+    ref = torch.cat([torch.from_numpy(cls).double().expand(3, 1, 64), conv.flatten(2).transpose(1, 2)], 1) + torch.from_numpy(pos).double()
+    assert _re(tok, ref.numpy()) < 1e-6
+    full = F.conv2d(torch.from_numpy(img[fmap]).double(), torch.from_numpy(w).double().view(64, 3, 16, 16), torch.from_numpy(b).double(), stride=16)
+    assert _re(tok[:, 1:], (full.flatten(2).transpose(1, 2) + torch.from_numpy(pos).double()[1:]).numpy()) < 1e-2     # bf16 operands
 
 
 @pytest.mark.gpu
@@ -489,6 +508,7 @@ def test_hip_library_equals_its_cpu_twin_round2b(twin):
         for i in (2, 3):
             assert _re(A["plane_gemm"][4][P_][i], B["plane_gemm"][4][P_][i]) < 2e-5, (P_, i)
     assert _re(_bf(A["att_bf16"][1]), _bf(B["att_bf16"][1])) < 1.5e-2
+    assert np.array_equal(A["patch_bf16"][3], B["patch_bf16"][3]) and _re(A["patch_bf16"][7], B["patch_bf16"][7]) < 2e-5
 
 
 # ---- third batch: generic GEMM, position-table resampling, evaluator resampling, k-means sums, plane backward products, the

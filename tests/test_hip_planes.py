@@ -217,3 +217,29 @@ def test_linear_planes_route_and_fallbacks():
     o = ops.linear_fwd_planes(ops.split_planes(x.cuda(), 3), ops.split_planes(w.cuda(), 3), b.cuda(), act=1, save_pre=True, out_planes=3)
     ref = x.double() @ w.double().t() + b.double()
     assert rel_err(o["pre"].cpu(), ref) < TOL_F32 and rel_err(planes_to_f64(o["planes"].cpu()), F.gelu(ref)) < TOL_F32
+
+
+@pytest.mark.parametrize("Fr,D,route", [(3, 768, 0), (64, 768, 8), (5, 384, 0)])
+def test_patch_embed_on_bf16_operands(Fr, D, route):
+    """tt_patch_embed_fwd_planes (BASELINE C4's bf16 path of dino_vision_transformer.py:166-171,236-247) against the fp64 conv of the
+    SAME bf16-rounded operands (only the fp32 accumulation differs), loosely against the fp32 operands, with a frame map; the large
+    case runs on the persistent 8-phase kernel, the small ones on gemm_planes_kernel."""
+    from timetuning_amd import _lib, hip_ops as ops
+
+    patch, Hh, Ww = 16, 224, 224
+    n = (Hh // patch) * (Ww // patch)
+    img, w, b = rnd("pe.img", Fr + 1, 3, Hh, Ww), rnd("pe.w", D, 3 * patch * patch, scale=0.05), rnd("pe.b", D)
+    cls, pos = rnd("pe.cls", D), rnd("pe.pos", n + 1, D)
+    fmap = torch.arange(Fr, dtype=torch.int32).flip(0) + 1
+    assert _lib.load().tt_linear_fwd_planes_route(1, Fr * (n + 1), D, 768, 0, 1, 1, 1, 0, 0) == route
+    wp = ops.split_planes(w.cuda(), 1)
+    tok = ops.patch_embed_fwd_planes(img.cuda(), wp, b.cuda(), cls.cuda(), pos.cuda(), patch, fmap.cuda()).cpu()
+    src = img[fmap.long()]
+    conv = F.conv2d(src.to(torch.bfloat16).double(), w.to(torch.bfloat16).double().view(D, 3, patch, patch), b.double(), stride=patch)
+    ref = torch.cat([cls.double().expand(Fr, 1, D), conv.flatten(2).transpose(1, 2)], 1) + pos.double()
+    assert rel_err(tok, ref) < TOL_F32
+    assert (tok[:, 0] - (cls + pos[0])).abs().max().item() < 1e-6          # the class row: cls + pos[0] (- bias + bias in fp32)
+    full = F.conv2d(src.double(), w.double().view(D, 3, patch, patch), b.double(), stride=patch).flatten(2).transpose(1, 2) + pos.double()[1:]
+    assert rel_err(tok[:, 1:], full) < 1e-2
+    tok32 = ops.patch_embed_fwd(img.cuda(), w.cuda(), b.cuda(), cls.cuda(), pos.cuda(), patch, fmap.cuda()).cpu()
+    assert rel_err(tok, tok32.double()) < 1e-2

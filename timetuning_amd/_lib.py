@@ -36,7 +36,7 @@ class VitBlockParams(C.Structure):
 class VitParams(C.Structure):
     _fields_ = [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
                 ("blocks", C.POINTER(VitBlockParams)), ("n_blocks", C.c_int), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
-                ("dim", C.c_int), ("heads", C.c_int), ("hidden", C.c_int), ("patch", C.c_int), ("planes", C.c_int)]
+                ("dim", C.c_int), ("heads", C.c_int), ("hidden", C.c_int), ("patch", C.c_int), ("planes", C.c_int), ("patch_wp", C.c_void_p)]
 
 
 class LinearParams(C.Structure):
@@ -62,6 +62,8 @@ SIGNATURES = {
     "tt_set_gemm_precision": (c_i, [c_i]),
     "tt_get_gemm_precision": (c_i, []),
     "tt_patch_embed_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "tt_patch_embed_planes_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "tt_patch_embed_fwd_planes": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_layernorm_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_i, c_vp]),
     "tt_layernorm_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_layernorm_bwd_workspace_bytes": (c_sz, [c_i, c_i]),

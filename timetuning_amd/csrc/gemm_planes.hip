@@ -392,6 +392,43 @@ int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_pl
                 hipStream_t s);                                                                                       // gemm_planes8.hip
 int planes8_would_run(int planes, int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int y_nplanes);
 
+
+// PatchEmbed rows for the bf16-plane path (dino_vision_transformer.py:166-171,236-247): one workgroup per token row m = (frame f, token t).
+//   a [F (n + 1)][C P P] bf16: the im2col row of patch t - 1 (k = (c P + y) P + x, the conv weight's own order), ZERO for the class token
+//   tokens [F][n + 1][D] fp32: what the GEMM's residual epilogue adds to - pos[t], and cls + pos[0] - bias for the class token (its zero
+//   row meets the bias in the epilogue)
+// so that ONE plane GEMM over all F (n + 1) rows (tt_linear_fwd_planes, residual = y = tokens) leaves prepare_tokens' result: no row
+// gather, no separate class-token pass.
+__global__ __launch_bounds__(256) void patch_rows_planes_kernel(const float* __restrict__ img, const int* __restrict__ frame_map,
+                                                                  const float* __restrict__ bias, const float* __restrict__ cls,
+                                                                  const float* __restrict__ pos, __bf16* __restrict__ a,
+                                                                  float* __restrict__ tokens, int C, int H, int W, int P, int D, int gw, int n) {
+  const int m = blockIdx.x, f = m / (n + 1), t = m - f * (n + 1);
+  const int K = C * P * P;
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4* arow = reinterpret_cast<bf16x4*>(a + (long long)m * K);
+  float4* trow = reinterpret_cast<float4*>(tokens + (long long)m * D);
+  const float4* prow = reinterpret_cast<const float4*>(pos + (long long)t * D);
+  if (t == 0) {
+    for (int i = threadIdx.x; i < K / 4; i += 256) arow[i] = (bf16x4){(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    for (int i = threadIdx.x; i < D / 4; i += 256) {
+      const float4 c = reinterpret_cast<const float4*>(cls)[i], b = reinterpret_cast<const float4*>(bias)[i], q = prow[i];
+      trow[i] = make_float4(c.x + q.x - b.x, c.y + q.y - b.y, c.z + q.z - b.z, c.w + q.w - b.w);
+    }
+    return;
+  }
+  const int src = frame_map ? frame_map[f] : f;
+  const int gy = (t - 1) / gw, gx = (t - 1) - gy * gw;
+  const float* base = img + ((long long)src * C * H + gy * P) * W + gx * P;
+  const int P4 = P / 4;
+  for (int i = threadIdx.x; i < K / 4; i += 256) {
+    const int x4 = i % P4, cy = i / P4, y = cy % P, c = cy / P;
+    const float4 v = *reinterpret_cast<const float4*>(base + ((long long)c * H + y) * W + 4 * x4);
+    arow[i] = (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  }
+  for (int i = threadIdx.x; i < D / 4; i += 256) trow[i] = prow[i];
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -546,4 +583,28 @@ static int linear_planes_impl(const void* x_planes, long long x_plane_stride, co
       }
       return launch_planes<3, 16, 1, 1>(g, s);
   }
+}
+
+
+extern "C" size_t tt_patch_embed_planes_workspace_bytes(int F, int C, int H, int W, int P) {
+  if (F <= 0 || C <= 0 || P <= 0 || H < P || W < P) return 0;
+  return (size_t)F * (1 + (size_t)(H / P) * (W / P)) * C * P * P * 2;
+}
+
+extern "C" int tt_patch_embed_fwd_planes(const float* img, const int32_t* frame_map, const void* w_planes, const float* bias, const float* cls,
+                                         const float* pos, float* tokens, int F, int C, int H, int W, int P, int D, void* workspace,
+                                         size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(img && w_planes && bias && cls && pos && tokens && workspace, "patch_embed_planes: null pointer");
+  TT_REQUIRE(F > 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0, "patch_embed_planes: H, W must be multiples of the patch size");
+  const int n = (H / P) * (W / P), K = C * P * P;
+  const long long M = (long long)F * (n + 1);
+  TT_REQUIRE(P % 4 == 0 && W % 4 == 0 && K % 64 == 0 && D % 64 == 0, "patch_embed_planes: need P %% 4 == 0, W %% 4 == 0, C P P %% 64 == 0, D %% 64 == 0");
+  TT_REQUIRE(aligned16(img) && aligned16(bias) && aligned16(cls) && aligned16(pos) && aligned16(tokens) && aligned16(workspace),
+             "patch_embed_planes: buffers must be 16-byte aligned");
+  TT_REQUIRE(M * (long long)(K > D ? K : D) < (1ll << 31), "patch_embed_planes: F (n + 1) max(C P P, D) exceeds the int range");
+  TT_REQUIRE(workspace_bytes >= tt_patch_embed_planes_workspace_bytes(F, C, H, W, P), "patch_embed_planes: workspace too small");
+  hipLaunchKernelGGL(patch_rows_planes_kernel, dim3((unsigned)M), dim3(256), 0, as_stream(stream), img, frame_map, bias, cls, pos,
+                     static_cast<__bf16*>(workspace), tokens, C, H, W, P, D, W / P, n);
+  TT_CHECK_LAUNCH("patch_embed_planes.rows");
+  return tt_linear_fwd_planes(workspace, M * K, w_planes, (long long)D * K, 1, bias, tokens, tokens, nullptr, nullptr, 0, 0, (int)M, D, K, 0, stream);
 }

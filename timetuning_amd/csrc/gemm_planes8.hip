@@ -75,6 +75,7 @@ struct P8Args {
                           // all tiles dealt round-robin
   int n_half;             // half tiles that follow (tiles [n_full * ncu, ntiles) cut in two): workgroup h < n_half takes half h
   int clock_print;        // TT_P8_CLOCK diagnostic builds only
+  int order_mode;         // order of the load part, see `reads_first`
 };
 
 // Device helpers at namespace scope: the buffer builtins inside a generic lambda of the kernel template make clang's HOST pass
@@ -344,6 +345,13 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
 #else
 #define P8_STAMP(t)
 #endif
+  // Order of the load part.  The texture path takes one 1 KiB DMA instruction per ~11-16 cycles; when the four waves of a group all queue
+  // theirs at the start of the load part the last one is accepted ~100 cycles later (phase stamps, tools/p8_stamp.py: DMA issue 120-150
+  // cycles of a ~300-cycle load part against the partner's 250-cycle MFMA part).  order_mode (P8Args, TT_P8_ORDER): 0 every wave DMA
+  // first, 1 every wave reads first, 2 odd waves read first, 3 (the default: 2-4 % faster at P = 1, ~1 % at P = 3, tools/p8_order.py)
+  // waves 2, 3 (6, 7) of a group read first.  Measured and not kept: the next phase's chunk issued behind this phase's MFMAs instead of in
+  // the load part (same vmcnt positions, bit-identical; proj / fc2 3-6 % faster, fc1 and every P = 3 shape 2-6 % slower).
+  const bool reads_first = g.order_mode == 1 || (g.order_mode == 2 && (wave & 1)) || (g.order_mode == 3 && (wave & 2));
   int post_epi = 0;          // phases left in which the stores of the last epilogue may still be outstanding
   bool post_half = false;    // ... and whether that epilogue was a half tile's
   bool c_half = false;       // the item being computed is a half tile
@@ -422,12 +430,16 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     if constexpr (DBG & 64) {   // timing study: the fragment reads ahead of the DMA instructions (3-4 % slower, profiles/r03_p8_variants.txt)
       frag_reads();
       dma_issue();
-    } else {   // the DMA instructions first: the texture path works on them while the wave issues its ds_reads
+    } else {
+      // DMA instructions, then fragment reads: the texture path works on them while the wave issues its ds_reads - except for the waves
+      // that `reads_first` picks, which read first (one copy of the reads, two of the short DMA issue: no extra register pressure)
       P8_STAMP(ts0);
-      dma_issue();
+      if (!reads_first) dma_issue();
       __builtin_amdgcn_sched_barrier(0);
       P8_STAMP(ts1);
       frag_reads();
+      __builtin_amdgcn_sched_barrier(0);
+      if (reads_first) dma_issue();
       P8_STAMP(ts2);
     }
     dma_wait();
@@ -680,6 +692,11 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
 #endif
 }
 
+static int p8_order_mode() {   // read per call: tools A/B the orders in one process
+  const char* e = getenv("TT_P8_ORDER");
+  return e ? atoi(e) : 3;
+}
+
 template <int P, int EPI, int DBG = 0>
 static int launch_planes8(const P8Args& g, hipStream_t s) {
   hipLaunchKernelGGL((gemm_planes8_kernel<P, EPI, DBG>), dim3(g.ncu), dim3(512), 0, s, g);
@@ -746,7 +763,7 @@ int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_pl
                                                  y_planes ? y_nplanes : 0, M, N, K, act, &ntn, &ntiles, &ncu, &n_full, &n_half);
   if (epi < 0) return 1;
   P8Args g{static_cast<const __bf16*>(x_planes), static_cast<const __bf16*>(w_planes), x_plane_stride, w_plane_stride, M, N, K, bias, residual, y,
-           static_cast<__bf16*>(y_planes), y_plane_stride, ntn, (int)ntiles, ncu, n_full, n_half, getenv("TT_P8_CLOCK_PRINT") != nullptr};
+           static_cast<__bf16*>(y_planes), y_plane_stride, ntn, (int)ntiles, ncu, n_full, n_half, getenv("TT_P8_CLOCK_PRINT") != nullptr, p8_order_mode()};
 #ifdef TT_P8_ABLATE   // timing-study build only (tools/build_variant.sh -DTT_P8_ABLATE): TT_P8_DBG selects a crippled instantiation
   {
     const char* e = getenv("TT_P8_DBG");

@@ -75,7 +75,19 @@ extern "C" int tt_vit_forward(const tt_vit_params* p, const float* img, const in
 
   if (img) {
     TT_REQUIRE(p->patch_w && p->patch_b && p->cls && p->pos, "vit_forward: null patch-embedding parameter");
-    TT_FORWARD(tt_patch_embed_fwd(img, frame_map, p->patch_w, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, stream));
+    // the bf16 path (planes == 1) embeds the patches on bf16 operands too where the plane GEMM's shape rules hold and the scratch
+    // (the blocks' qkv / MLP region, idle now) holds the im2col rows; anything else: the fp32 conv
+    const size_t a_bytes = tt_patch_embed_planes_workspace_bytes(F, C, H, W, p->patch);
+    const int Kp = C * p->patch * p->patch;
+    // (C P P <= 9 D: the rows then fit the attention phase of the scratch, 18 M D bytes at planes == 1, whatever the MLP width - a
+    // rule on shapes alone, so that callers sequencing the op-level entry points themselves can make the same decision)
+    if (P == 1 && p->patch_wp && workspace && workspace_bytes >= s.bytes && p->patch % 4 == 0 && W % 4 == 0 && Kp % 64 == 0 && D % 64 == 0 &&
+        Kp <= 9 * D) {
+      TT_FORWARD(tt_patch_embed_fwd_planes(img, frame_map, p->patch_wp, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, s.big,
+                                           a_bytes, stream));
+    } else {
+      TT_FORWARD(tt_patch_embed_fwd(img, frame_map, p->patch_w, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, stream));
+    }
   }
   for (int i = 0; i < p->n_blocks; ++i) {
     const tt_vit_block_params& b = p->blocks[i];

@@ -155,6 +155,21 @@ def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int,
     return dx_in if need_dx else None
 
 
+def patch_weight_planes(pe) -> torch.Tensor:
+    """[1, D, C*P*P] bf16 plane of the patch-embedding weight (cached like the block weights: weight_planes)."""
+    return weight_planes(pe.weight, 1).view(1, pe.weight.shape[0], -1)
+
+
+def patch_planes_ok(vit, img: torch.Tensor) -> bool:
+    """True when prepare_tokens runs on bf16 operands: the "bf16" mode, the plane GEMM's shape rules, and C P P <= 9 D (the im2col
+    rows then fit tt_vit_forward's scratch) - tt_vit_forward's own rule, followed by the op-level path too so that both give the
+    same bits."""
+    pe = vit.patch_embed.proj
+    D = pe.weight.shape[0]
+    K = pe.weight[0].numel()
+    return ops.plane_count() == 1 and K <= 9 * D and ops.patch_embed_planes_ok(vit.patch_embed.patch_size, img.shape[-1], K, D)
+
+
 def vit_params(vit, first: int, last: int, pos: Optional[torch.Tensor] = None):
     """The parameter table ``ops.vit_forward`` (tt_vit_forward) reads, for blocks [first, last) of ``vit`` in the arithmetic the
     precision mode selects for blocks that keep nothing (fp32 operands, or the bf16 planes of ``weight_planes``).  Returns
@@ -187,6 +202,11 @@ def vit_params(vit, first: int, last: int, pos: Optional[torch.Tensor] = None):
     vp.blocks, vp.n_blocks = arr, n
     vp.norm_w, vp.norm_b = vit.norm.weight.data_ptr(), vit.norm.bias.data_ptr()
     vp.dim, vp.heads, vp.hidden, vp.patch, vp.planes = D, vit.num_heads, vit.blocks[0].mlp.fc1.weight.shape[0], vit.patch_embed.patch_size, planes
+    vp.patch_wp = None
+    if planes == 1 and pos is not None:      # (tt_vit_forward applies the shape rules of patch_planes_ok itself)
+        wp = patch_weight_planes(pe)
+        keep.append(wp)
+        vp.patch_wp = wp.data_ptr()
     keep.append(pos)
     return vp, keep
 
@@ -214,7 +234,10 @@ def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None,
     pos = vit.pos_table(img.shape[-2], img.shape[-1])
     done = 0
     if ops.fine_grained():
-        x = ops.patch_embed_fwd(img, pe.weight.view(D, -1), pe.bias, vit.cls_token.view(D), pos, vit.patch_embed.patch_size, frame_map)
+        if patch_planes_ok(vit, img):   # the same decision tt_vit_forward makes from VitParams.patch_wp
+            x = ops.patch_embed_fwd_planes(img, patch_weight_planes(pe), pe.bias, vit.cls_token.view(D), pos, vit.patch_embed.patch_size, frame_map)
+        else:
+            x = ops.patch_embed_fwd(img, pe.weight.view(D, -1), pe.bias, vit.cls_token.view(D), pos, vit.patch_embed.patch_size, frame_map)
     else:
         # ONE call (tt_vit_forward) for prepare_tokens and every leading block that keeps nothing and is not tapped
         done = min(first_saved, tap["block"] if tap is not None else depth, depth - 1 if last_block_probs else depth)

@@ -236,6 +236,36 @@ def patch_embed_fwd(img, w, bias, cls, pos, patch: int, frame_map=None):
     return tokens
 
 
+def patch_embed_planes_ok(patch: int, W: int, K: int, D: int) -> bool:
+    """Shapes ``patch_embed_fwd_planes`` takes (tt_patch_embed_fwd_planes)."""
+    return patch % 4 == 0 and W % 4 == 0 and K % 64 == 0 and D % 64 == 0
+
+
+def patch_embed_fwd_planes(img, w_planes, bias, cls, pos, patch: int, frame_map=None):
+    """``patch_embed_fwd`` on bf16 operands (the "bf16" precision mode, BASELINE C4's path): w_planes [1, D, C*P*P] bf16 =
+    ``split_planes(w, 1)``; the patches are rounded to bf16 on their way into an im2col buffer, fp32 accumulation, fp32 tokens."""
+    lib = _lib.load()
+    _chk(img, "img"); _chk(w_planes, "w_planes", bf16); _chk(bias, "bias"); _chk(cls, "cls"); _chk(pos, "pos")
+    Fs, Cc, H, W = img.shape
+    D = w_planes.shape[1]
+    F = Fs if frame_map is None else frame_map.numel()
+    if frame_map is not None: _chk(frame_map, "frame_map", torch.int32)
+    n = (H // patch) * (W // patch)
+    K = Cc * patch * patch
+    if pos.numel() != (n + 1) * D:
+        raise ValueError("pos_embed does not match the token grid: pass VisionTransformer.pos_table(H, W)")
+    tokens = torch.empty((F, n + 1, D), dtype=f32, device=img.device)
+    nb = lib.tt_patch_embed_planes_workspace_bytes(F, Cc, H, W, patch)
+    ws = _ws(nb, img.device)
+    M = F * (n + 1)
+    p8 = bool(lib.tt_linear_fwd_planes_route(1, M, D, K, 0, 1, 1, 1, 0, 0))
+    e0 = _prof_begin()
+    _lib.check(lib.tt_patch_embed_fwd_planes(_p(img), _p(frame_map), _p(w_planes), _p(bias), _p(cls), _p(pos), _p(tokens), F, Cc, H, W, patch, D,
+                                             _p(ws), nb, _stream()), "tt_patch_embed_fwd_planes")
+    _prof_end(e0, "PLANES8_1" if p8 else "PLANES1", M, D, K)
+    return tokens
+
+
 def pos_embed_interpolate(pos, grid_h: int, grid_w: int):
     """interpolate_pos_encoding's bicubic branch (dino_vision_transformer.py:219-234): pos [1+g*g, D] -> [1+grid_h*grid_w, D]."""
     lib = _lib.load()
