@@ -243,3 +243,20 @@ def test_patch_embed_on_bf16_operands(Fr, D, route):
     assert rel_err(tok[:, 1:], full) < 1e-2
     tok32 = ops.patch_embed_fwd(img.cuda(), w.cuda(), b.cuda(), cls.cuda(), pos.cuda(), patch, fmap.cuda()).cpu()
     assert rel_err(tok, tok32.double()) < 1e-2
+
+
+@pytest.mark.parametrize("planes", [1, 3])
+def test_planes8_load_part_orders_give_the_same_bits(planes, monkeypatch):
+    """TT_P8_ORDER only moves a wave's DMA instructions relative to its fragment reads inside a phase (gemm_planes8.hip `reads_first`):
+    every order must leave the same bits; the default (3) is checked against fp64 by test_linear_planes8_every_epilogue."""
+    from timetuning_amd import hip_ops as ops
+
+    BN = 256 if planes == 1 else 128
+    M, N, K = 25216, 3 * BN, 512
+    xp, wp = ops.split_planes(rnd("ord.x", M, K).cuda(), planes), ops.split_planes(rnd("ord.w", N, K, scale=0.05).cuda(), planes)
+    b = rnd("ord.b", N).cuda()
+    outs = []
+    for order in ("3", "0", "1", "2"):
+        monkeypatch.setenv("TT_P8_ORDER", order)
+        outs.append(ops.linear_fwd_planes(xp, wp, b, act=1, out_f32=False, out_planes=planes)["planes"].clone())
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])

@@ -93,6 +93,11 @@ __device__ __forceinline__ void p8_st128(void* base, unsigned nbytes, unsigned v
   __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
 }
 
+#ifndef TT_P8_SHIFT0
+#define TT_P8_SHIFT0 0
+#endif
+constexpr bool P8_SHIFT0 = TT_P8_SHIFT0 != 0;
+
 template <int N>
 __device__ __forceinline__ void p8_wait_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   // leave outstanding besides their DMA window.  A LOWER bound is what keeps those waits safe (see `epilogue`).
   constexpr int ST_TILE = F32OUT ? 4 : 2 * PO;                  // per 32 x 32 MFMA tile (fp32: 4 KB in 1 KB pieces; bf16: 2 KB per plane)
   constexpr int ST_FULL = 4 * NHW * ST_TILE, ST_HALF = ST_FULL / 2;
-  constexpr int WMAX = GCH * L;
+  constexpr int WMAX = GCH * (L + (P8_SHIFT0 ? 1 : 0));
   constexpr int S_FULL = ST_FULL < 63 - WMAX ? ST_FULL : 63 - WMAX, S_HALF = ST_HALF < 63 - WMAX ? ST_HALF : 63 - WMAX;
   static_assert(RING_B + 8 * SCR_B <= 160 * 1024 && (CW == 32 || CW == 16), "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem[160 * 1024];
@@ -403,13 +408,23 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     };
     // DMA: chunk (PH + D) of the stream = chunk (PH + D) & 3 of the K-tile (PH + D) / 4 further on
     constexpr int CI = (PH + D) & 3, BT = (B + (PH + D) / 4) & 1;
+    // SHIFT0: phase 0 carries half of a K-tile's fragment reads (12 of 24 at P = 1, 9 of 30 at P = 3) and phase 3 the fewest, so phase 3
+    // issues phase 0's chunk as well (one phase early: the same position in the vmcnt queue, the same K-tile of the cursor, still >= 2 phases
+    // behind the last read of its slot - static_assert below) and phase 0 issues none.
+    constexpr int CI0 = D & 3, BT0 = ((B ^ 1) + D / 4) & 1;
+    static_assert(!P8_SHIFT0 || (CI0 != 0 && CF::exists(CI0) && CI0 != CF::X1 && 8 + CI0 - D - 1 >= CF::last_read(CI0) + 2),
+                  "SHIFT0: phase 0's chunk must share the cursor's K-tile with phase 3's, exist in half tiles, and keep the WAR distance");
     auto dma_issue = [&]() {
+      if constexpr (P8_SHIFT0 && PH == 0) return;
       if constexpr (CI == 0) cursor_next_ktile();
       issue(std::integral_constant<int, CI>{}, std::integral_constant<int, BT>{});
+      if constexpr (P8_SHIFT0 && PH == 3) issue(std::integral_constant<int, CI0>{}, std::integral_constant<int, BT0>{});
     };
     // counted wait: everything but the youngest L chunks (and, for L phases behind an epilogue, its stores) has landed
     auto dma_wait = [&]() {
-      constexpr int WF = p8_window<P>(PH, GCH, false), WH = p8_window<P>(PH, GCH, true);
+      // (SHIFT0, phase 3: one chunk more has been issued, the chunk to retire is the same)
+      constexpr int EXTRA = (P8_SHIFT0 && PH == 3) ? GCH : 0;
+      constexpr int WF = p8_window<P>(PH, GCH, false) + EXTRA, WH = p8_window<P>(PH, GCH, true) + EXTRA;
       if (steady && !(DBG & 2)) {
         p8_wait_vmcnt<WF>();
       } else {
@@ -649,11 +664,16 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     pro(std::integral_constant<int, 3>{}); pro(std::integral_constant<int, 4>{});
     if constexpr (D > 5) pro(std::integral_constant<int, 5>{});
     static_assert(D == 5 || D == 6, "prologue issues chunks 0 .. D - 1");
+    constexpr int PRO_EXTRA = P8_SHIFT0 ? GCH : 0;
+    if constexpr (P8_SHIFT0) {   // ... and chunk D, which phase 0 no longer issues
+      if constexpr ((D & 3) == 0) cursor_next_ktile();
+      issue(std::integral_constant<int, (D & 3)>{}, std::integral_constant<int, ((D >> 2) & 1)>{});
+    }
     half_guard = d_half ? L + 1 : 0;
-    // "phase -1": chunks D - L .. D - 1 may stay in flight
+    // "phase -1": chunks D - L .. D - 1 (.. D) may stay in flight
     if (DBG & 2) p8_wait_vmcnt<0>();
-    else if (d_half) p8_wait_vmcnt<p8_window<P>(3, GCH, true)>();
-    else p8_wait_vmcnt<p8_window<P>(3, GCH, false)>();
+    else if (d_half) p8_wait_vmcnt<p8_window<P>(3, GCH, true) + PRO_EXTRA>();
+    else p8_wait_vmcnt<p8_window<P>(3, GCH, false) + PRO_EXTRA>();
     __builtin_amdgcn_s_barrier();
   }
 
