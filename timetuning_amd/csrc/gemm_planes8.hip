@@ -93,10 +93,14 @@ __device__ __forceinline__ void p8_st128(void* base, unsigned nbytes, unsigned v
   __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
 }
 
+// SHIFT0 (see `phase`): phase 3 issues phase 0's DMA chunk as well.  Measured per plane count (tools/ab_planes.py, interleaved, bit-identical):
+// P = 1 1.6-4.4 % faster on the four ViT-B/16 block shapes, P = 3 1.2-3.6 % slower on the ViT-S/16 ones - so it is on for P = 1 only.
+// -DTT_P8_SHIFT0=0/1 forces it for both (timing studies).
 #ifndef TT_P8_SHIFT0
-#define TT_P8_SHIFT0 0
+#define TT_P8_SHIFT0 -1
 #endif
-constexpr bool P8_SHIFT0 = TT_P8_SHIFT0 != 0;
+template <int P>
+constexpr bool p8_shift0() { return TT_P8_SHIFT0 < 0 ? P == 1 : TT_P8_SHIFT0 != 0; }
 
 template <int N>
 __device__ __forceinline__ void p8_wait_vmcnt() {
@@ -162,6 +166,7 @@ template <int P, int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   using CF = P8Cfg<P>;
   constexpr int BK = CF::BK, NHW = CF::NHW, D = CF::D, L = CF::L;
+  constexpr bool P8_SHIFT0 = p8_shift0<P>();
   constexpr int ROWB = BK * 2;              // bytes per LDS row
   constexpr int CPR = ROWB / 16;            // 16-byte chunks per row
   constexpr int WIN = 256 / ROWB;           // rows per 256-byte bank window
