@@ -359,7 +359,9 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   // theirs at the start of the load part the last one is accepted ~100 cycles later (phase stamps, tools/p8_stamp.py: DMA issue 120-150
   // cycles of a ~300-cycle load part against the partner's 250-cycle MFMA part).  order_mode (P8Args, TT_P8_ORDER): 0 every wave DMA
   // first, 1 every wave reads first, 2 odd waves read first, 3 (the default: 2-4 % faster at P = 1, ~1 % at P = 3, tools/p8_order.py)
-  // waves 2, 3 (6, 7) of a group read first.  Measured and not kept: the next phase's chunk issued behind this phase's MFMAs instead of in
+  // waves 2, 3 (6, 7) of a group read first.  Measured and not kept: fragment reads issued in the order the MFMAs consume them with the
+  // compiler's counted lgkmcnt before each MFMA instead of the lgkmcnt(0) behind the barrier (bit-identical, within +-1 % on seven of eight
+  // shapes: the reads have landed by the time the barrier opens); the next phase's chunk issued behind this phase's MFMAs instead of in
   // the load part (same vmcnt positions, bit-identical; proj / fc2 3-6 % faster, fc1 and every P = 3 shape 2-6 % slower).
   const bool reads_first = g.order_mode == 1 || (g.order_mode == 2 && (wave & 1)) || (g.order_mode == 3 && (wave & 2));
   int post_epi = 0;          // phases left in which the stores of the last epilogue may still be outstanding
