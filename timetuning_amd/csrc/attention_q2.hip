@@ -195,21 +195,27 @@ __global__ __launch_bounds__(256, TT_Q2_WAVES_PER_SIMD) void attention_fwd_q2_ke
     if (c + 1 < NC) swrite_v(buf ^ 1);
     __syncthreads();
   }
+  // The 32 x 64 output tile of a wave leaves through LDS (the K / V staging area is idle behind the last barrier; 2144 floats per wave)
+  // so that a store instruction writes FOUR WHOLE 256-byte rows instead of sixteen 64-byte pieces: 16-byte chunk c of row r sits at
+  // chunk position c ^ (r & 15).  (Round 3: the direct stores cost 4.8 of the kernel's 102 us, tools/ab_attn.py.)
+#ifndef TT_Q2_NOSTORE   // (timing-study builds only compile the stores out)
+  if (wave_active) {
+    float* scr = smem + wave * 2144;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int q = q0 + 16 * t + qi;
-#ifdef TT_Q2_NOSTORE   // timing-study builds only (tools/build_variant.sh): what the output stores cost
-    if (q < -1) {
-#else
-    if (q < N) {
-#endif
-      float* o = out + ((long long)f * N + q) * (H * Q2_HD) + h * Q2_HD + 4 * g;
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int d = 0; d < 4; ++d)
-        *reinterpret_cast<float4*>(o + 16 * d) =
+        *reinterpret_cast<float4*>(scr + (16 * t + qi) * 64 + (((4 * d + g) ^ qi) << 2)) =
             make_float4(oacc[t][d][0] * inv[t], oacc[t][d][1] * inv[t], oacc[t][d][2] * inv[t], oacc[t][d][3] * inv[t]);
+    const int c16 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = (lane >> 4) + 4 * i;
+      const float4 v = *reinterpret_cast<const float4*>(scr + row * 64 + ((c16 ^ (row & 15)) << 2));
+      if (q0 + row < N) *reinterpret_cast<float4*>(out + ((long long)f * N + q0 + row) * (H * Q2_HD) + h * Q2_HD + 4 * c16) = v;
     }
   }
+#endif
 }
 
 template <int NT>
