@@ -94,4 +94,28 @@ for it in range(rounds):
     if actp: refp = F.gelu(refp)
     if resp is not None: refp = refp + resp.double()
     note(f"linear_fwd_planes P={P_}", rel(out, refp), 3e-5, (P_, Mp, Np, Kp, actp))
+    # patch embedding on bf16 operands (round 3): against the fp64 conv of the SAME rounded operands
+    Dq = int(rng.choice([64, 128, 256, 384, 768]))
+    wq = torch.randn(Dq, 768) * 0.05; bq, clsq, posq = torch.randn(Dq), torch.randn(Dq), torch.randn(1 + npat, Dq)
+    convq = F.conv2d(img[torch.as_tensor(fmap).long()].to(torch.bfloat16).double(), wq.to(torch.bfloat16).double().view(Dq, 3, 16, 16), bq.double(), stride=16)
+    refq = torch.cat([clsq.double().expand(len(fmap), 1, Dq), convq.flatten(2).transpose(1, 2)], 1) + posq.double()
+    tokq = ops.patch_embed_fwd_planes(dev(img), ops.split_planes(dev(wq), 1), dev(bq), dev(clsq), dev(posq), 16, dev(fmap))
+    note("patch_embed_fwd_planes", rel(tokq, refq), 3e-5, (Dq, Hh, Ww, nsrc, len(fmap)))
+    # bf16 attention forward: any token count up to 256, any head count
+    Fa, Na, Ha = int(rng.integers(1, 4)), int(rng.integers(1, 257)), int(rng.integers(1, 5))
+    qb = (torch.randn(Fa, Na, 3 * Ha * 64) * 0.7).to(torch.bfloat16)
+    q_, k_, v_ = qb.double().view(Fa, Na, 3, Ha, 64).permute(2, 0, 3, 1, 4)
+    refa = (torch.softmax(q_ @ k_.transpose(-1, -2) * 0.125, -1) @ v_).permute(0, 2, 1, 3).reshape(Fa, Na, Ha * 64)
+    note("attention_fwd_bf16", rel(ops.attention_fwd_bf16(dev(qb), Ha).float(), refa), 2e-2, (Fa, Na, Ha))
+    # the persistent 8-phase plane GEMM (large ragged M, whole 256 / 128-wide column tiles, every tile-count regime by chance)
+    if it % 4 == 0:
+        P8 = int(rng.choice([1, 3])); BN = 256 if P8 == 1 else 128; BKq = 128 if P8 == 1 else 64
+        M8, N8, K8 = int(rng.integers(9000, 40000)), BN * int(rng.integers(1, 7)), BKq * int(rng.integers(1, 5))
+        x8, w8, b8 = torch.randn(M8, K8), torch.randn(N8, K8) * 0.1, torch.randn(N8)
+        xp8, wp8 = ops.split_planes(dev(x8), P8), ops.split_planes(dev(w8), P8)
+        res8 = torch.randn(M8, N8) if rng.random() < 0.5 else None
+        out8 = ops.linear_fwd_planes(xp8, wp8, dev(b8), residual=dev(res8) if res8 is not None else None)["y"]
+        ref8 = F.linear(xp8.double().sum(0).cpu(), wp8.double().sum(0).cpu(), b8.double())
+        if res8 is not None: ref8 = ref8 + res8.double()
+        note(f"linear_fwd_planes (large M) P={P8}", rel(out8, ref8), 3e-5, (P8, M8, N8, K8, res8 is not None))
 print("fuzz ok:", {k: f"{v:.2e}" for k, v in worst.items()})
