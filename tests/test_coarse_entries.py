@@ -273,6 +273,14 @@ def test_coarse_entry_argument_checks():
     assert lib.tt_mlp_head_forward(t.data_ptr(), 4, arr, 2, t.data_ptr(), t.data_ptr(), 1 << 20, None) == -1
     assert b"layer 1 takes 9" in lib.tt_last_error()
     assert lib.tt_scores_sinkhorn(t.data_ptr(), 4, None, 0, t.data_ptr(), 4, 8, t.data_ptr(), t.data_ptr(), 9, 0.05, 3, t.data_ptr(), 1 << 20, None) == -1
+    # the bf16 patch embedding: shape rules and the workspace size are checked, nothing is launched on a bad call
+    big = torch.zeros(1 << 20, device="cuda")
+    p_ = big.data_ptr()
+    assert lib.tt_patch_embed_planes_workspace_bytes(2, 3, 32, 48, 16) == 2 * 7 * 768 * 2
+    assert lib.tt_patch_embed_fwd_planes(p_, None, p_, p_, p_, p_, p_, 2, 3, 32, 48, 16, 100, p_, 1 << 22, None) == -1 and b"D % 64" in lib.tt_last_error()
+    assert lib.tt_patch_embed_fwd_planes(p_, None, p_, p_, p_, p_, p_, 2, 3, 32, 48, 16, 128, p_, 100, None) == -1 and b"workspace too small" in lib.tt_last_error()
+    assert lib.tt_patch_embed_fwd_planes(p_, None, p_, p_, p_, p_, p_, 2, 3, 30, 48, 16, 128, p_, 1 << 22, None) == -1
+    assert lib.tt_patch_embed_fwd_planes(p_, None, None, p_, p_, p_, p_, 2, 3, 32, 48, 16, 128, p_, 1 << 22, None) == -1
 
 
 def _tiny_model(teacher=False, queue=0, K=12):
