@@ -143,6 +143,12 @@ int tt_attention_fwd(const float* qkv, float* out, float* lse, float* probs, int
 int tt_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F,
                      int N, int H, int hd, float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream);
 size_t tt_attention_bwd_workspace_bytes(int F, int N, int H, int hd);
+/* The same backward on bf16 MATRIX operands (BASELINE C4's bf16 path; what torch.autocast makes of the backward of q k^T and attn v,
+ * dino_vision_transformer.py:125-129): q, k, v, dout, P and dS are rounded to bf16 where they enter a product, products on
+ * v_mfma_f32_16x16x16_bf16 with fp32 accumulation; the softmax statistics (lse), delta = <dout, out>, P and dS themselves are fp32.
+ * Inputs and outputs stay fp32 in memory; same arguments and workspace as tt_attention_bwd. */
+int tt_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N, int H, int hd,
+                          float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream);
 
 /* ---- k11: F.normalize(x, dim=-1) (time_tuning.py:136; mask_propagation.py:418-419)
  *   xn[rows,D] = x / max(||x||, 1e-12); inv_norm[rows] optional.  x rows may be strided (ldx). */

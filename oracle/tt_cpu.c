@@ -614,6 +614,53 @@ int tt_cpu_attention_bwd(const float* qkv, const float* out, const float* dout, 
   return 0;
 }
 
+/* The same with the matrix operands rounded to bf16 where they enter a product (tt_attention_bwd_bf16): q (scaled), k, v, dout, P, dS. */
+static float bf16_round(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return x;                 /* NaN */
+  u += 0x7fffu + ((u >> 16) & 1u);
+  u &= 0xffff0000u;
+  float r;
+  memcpy(&r, &u, 4);
+  return r;
+}
+int tt_cpu_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N, int H, int hd,
+                              float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  const int D = H * hd, D3 = 3 * D;
+  double* acc = (double*)calloc((size_t)N * D3, sizeof(double));
+  float* qs = (float*)malloc((size_t)hd * 4), *dor = (float*)malloc((size_t)hd * 4);
+  if (!acc || !qs || !dor) return -3;
+  for (int f = 0; f < F; ++f) {
+    memset(acc, 0, (size_t)N * D3 * sizeof(double));
+    for (int h = 0; h < H; ++h)
+      for (int i = 0; i < N; ++i) {
+        const float* q = qkv + ((size_t)f * N + i) * D3 + h * hd;
+        const float* dO = dout + ((size_t)f * N + i) * D + h * hd;
+        const float* O = out + ((size_t)f * N + i) * D + h * hd;
+        double delta = 0.0;
+        for (int d = 0; d < hd; ++d) { delta += (double)dO[d] * O[d]; qs[d] = bf16_round(q[d] * scale); dor[d] = bf16_round(dO[d]); }
+        for (int j = 0; j < N; ++j) {
+          const float* k = qkv + ((size_t)f * N + j) * D3 + D + h * hd;
+          const float* v = qkv + ((size_t)f * N + j) * D3 + 2 * D + h * hd;
+          double s = 0.0, dp = 0.0;
+          for (int d = 0; d < hd; ++d) { s += (double)qs[d] * bf16_round(k[d]); dp += (double)dor[d] * bf16_round(v[d]); }
+          const double p = exp(s - lse[((size_t)f * H + h) * N + i]);
+          const double pr = bf16_round((float)p), dsr = bf16_round((float)(p * (dp - delta)));
+          for (int d = 0; d < hd; ++d) {
+            acc[(size_t)i * D3 + h * hd + d] += dsr * bf16_round(k[d]) * scale;
+            acc[(size_t)j * D3 + D + h * hd + d] += dsr * qs[d];          /* (q already carries the scale) */
+            acc[(size_t)j * D3 + 2 * D + h * hd + d] += pr * dor[d];
+          }
+        }
+      }
+    for (size_t t = 0; t < (size_t)N * D3; ++t) dqkv[(size_t)f * N * D3 + t] = (float)acc[t];
+  }
+  free(acc); free(qs); free(dor);
+  return 0;
+}
+
 /* ---- PatchEmbed + prepare_tokens (dino_vision_transformer.py:156-171,236-247): conv2d(k = s = P) as a per-patch dot product,
  *      cls token prepended, position embedding added; frame_map selects / reorders source frames (NULL: identity) */
 int tt_cpu_patch_embed_fwd(const float* img, const int32_t* frame_map, const float* w, const float* bias, const float* cls, const float* pos,

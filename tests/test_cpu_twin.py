@@ -384,6 +384,9 @@ def _round2b_cases(side):
     wsa = np.empty(nbw, np.uint8)
     side.run("attention_bwd", qkv, out, dout, lse, dqkv, Fa, Na, H, 64, 0.125, wsa, nbw, st, outs=(dqkv,))
     R["att_bwd"] = (qkv, dout, dqkv.copy())
+    dqkv_b = np.empty_like(qkv)
+    side.run("attention_bwd_bf16", qkv, out, dout, lse, dqkv_b, Fa, Na, H, 64, 0.125, wsa, nbw, st, outs=(dqkv_b,))
+    R["att_bwd_bf16"] = (qkv, dout, dqkv_b.copy())
     # patch embedding with a frame map
     Fp, C, Hh, Ww, P, Dm = 3, 3, 32, 48, 16, 24
     img, w, b, cls, pos = f32(4, C, Hh, Ww), f32(Dm, C * P * P, scale=0.05), f32(Dm), f32(Dm), f32(1 + 6, Dm)
@@ -461,6 +464,9 @@ def test_round2b_twins_against_torch(twin):
     o = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(2, 21, 128)
     (o * torch.from_numpy(dout).double()).sum().backward()
     assert _re(dqkv, qt.grad.numpy()) < 1e-5
+    # bf16 products: near the exact gradient (the rounding of q, k, v, dout, P and dS), and NOT equal to it
+    e_bf = _re(R["att_bwd_bf16"][2], qt.grad.numpy())
+    assert 1e-4 < e_bf < 2e-2, e_bf
     img, fmap, w, b, cls, pos, tok = R["patch"]
     conv = F.conv2d(torch.from_numpy(img[fmap]).double(), torch.from_numpy(w).double().view(24, 3, 16, 16), torch.from_numpy(b).double(), stride=16)
     ref = torch.cat([torch.from_numpy(cls).double().expand(3, 1, 24), conv.flatten(2).transpose(1, 2)], 1) + torch.from_numpy(pos).double()
@@ -502,6 +508,7 @@ def test_hip_library_equals_its_cpu_twin_round2b(twin):
         for i, (a, b) in enumerate(zip(A[key], B[key])):
             if isinstance(a, np.ndarray) and a.dtype == np.float32:
                 assert _re(a, b) < 2e-5, (key, i, _re(a, b))
+    assert _re(A["att_bwd_bf16"][2], B["att_bwd_bf16"][2]) < 3e-3          # same rounding points; P / dS may round one bf16 ulp apart
     assert np.array_equal(A["planes_misc"][1], B["planes_misc"][1])                         # transposed bf16 image: bit for bit
     assert _re(_bf(A["planes_misc"][5]).sum(0), _bf(B["planes_misc"][5]).sum(0)) < 2e-6       # LayerNorm planes: same value to fp32 rounding
     for P_ in (1, 3):

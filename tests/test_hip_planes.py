@@ -260,3 +260,25 @@ def test_planes8_load_part_orders_give_the_same_bits(planes, monkeypatch):
         monkeypatch.setenv("TT_P8_ORDER", order)
         outs.append(ops.linear_fwd_planes(xp, wp, b, act=1, out_f32=False, out_planes=planes)["planes"].clone())
     assert all(torch.equal(o, outs[0]) for o in outs[1:])
+
+
+@pytest.mark.parametrize("Fr,N,H", [(2, 197, 12), (3, 50, 2), (1, 256, 3), (2, 17, 1)])
+def test_attention_backward_on_bf16_products(Fr, N, H):
+    """tt_attention_bwd_bf16 (the bf16 path's attention backward: products on v_mfma_f32_16x16x16_bf16, softmax statistics / P / dS in fp32)
+    against fp64 autograd of the fp32 inputs at a bf16 bound, and against the exact-f32 kernel (close, not equal)."""
+    from timetuning_amd import hip_ops as ops
+
+    qkv = rnd("ab.qkv", Fr, N, 3 * H * 64, scale=0.6).cuda()
+    dout = rnd("ab.do", Fr, N, H * 64).cuda()
+    out, lse, _ = ops.attention_fwd(qkv, H, save_lse=True)
+    d32 = ops.attention_bwd(qkv, out, dout, lse, H)
+    d16 = ops.attention_bwd(qkv, out, dout, lse, H, bf16_products=True)
+    qt = qkv.double().cpu().requires_grad_(True)
+    q, k, v = qt.view(Fr, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    o = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(Fr, N, H * 64)
+    (o * dout.double().cpu()).sum().backward()
+    assert rel_err(d32, qt.grad) < TOL_F32
+    e16 = rel_err(d16, qt.grad)
+    assert 1e-5 < e16 < 2e-2, e16
+    cos = torch.nn.functional.cosine_similarity(d16.double().cpu().flatten(), qt.grad.flatten(), dim=0).item()
+    assert cos > 0.9999, cos

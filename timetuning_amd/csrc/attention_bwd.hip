@@ -7,11 +7,26 @@
 // In both, the freshly computed accumulator tile (P / dS) is used as the B operand of the next MFMA directly from
 // registers: the C/D layout (col = lane & 15, row = 4 * (lane >> 4) + e) is the B layout for k = row, so no LDS
 // round trip or shuffle is needed.  No atomics: each output element has exactly one owner (deterministic).
+//
+// BF16 = true (tt_attention_bwd_bf16, BASELINE C4's bf16 path): the same kernels with every group of four k = 4 f32 MFMAs replaced by ONE
+// v_mfma_f32_16x16x16_bf16 on operands rounded to bf16 - what torch.autocast makes of the backward of q k^T and attn v (bf16 products,
+// fp32 accumulation; softmax statistics, delta, P and dS computed in fp32, P and dS rounded where they enter a product).  It is the
+// SAME data movement: element j of a lane's bf16 operand for k-step t is the fp32 kernel's register s = 4 t + j (any assignment of the
+// contraction index to (lane group, element) is valid as long as both operands use it), and a 16 x 16 accumulator tile is the B operand
+// of the wider MFMA as it stands (k = row = 4 g + e, four elements per lane).
 #include "common.hpp"
 
 namespace tt {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ s16x4 pack_bf16(float a, float b, float c, float d) {
+  const bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+  return __builtin_bit_cast(s16x4, v);
+}
+__device__ __forceinline__ f32x4 mma_bf16(s16x4 a, s16x4 b, f32x4 acc) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0); }
 
 constexpr int BHD = 64, BCH = 32, BSTR = 68;  // chunk rows, LDS row stride (16 g + i banks for the transposed reads)
 
@@ -33,6 +48,7 @@ __device__ __forceinline__ void tile_to_regs(const float* __restrict__ src, long
   for (int s = 0; s < 16; ++s) r[s] = stage[(wave * 16 + li) * BSTR + 4 * s + g];
 }
 
+template <bool BF16>
 __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                                const float* __restrict__ dout, const float* __restrict__ lse,
                                                                float* __restrict__ dqkv, float* __restrict__ delta, int N, int H,
@@ -61,6 +77,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
   }
   dl += __shfl_xor(dl, 16, 64);
   dl += __shfl_xor(dl, 32, 64);
+  s16x4 qpk[4], dopk[4];   // (BF16) the query-side operands, rounded once
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    qpk[t] = pack_bf16(qreg[4 * t], qreg[4 * t + 1], qreg[4 * t + 2], qreg[4 * t + 3]);
+    dopk[t] = pack_bf16(doreg[4 * t], doreg[4 * t + 1], doreg[4 * t + 2], doreg[4 * t + 3]);
+  }
   const float lse_q = (q < N) ? lse[((long long)f * H + h) * N + q] : 0.f;
   if (q < N && g == 0) delta[((long long)f * H + h) * N + q] = dl;
 
@@ -102,10 +124,18 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
         const float* kp = Ks + (buf * BCH + 16 * t2 + qi) * BSTR + g;
         const float* vp = Vs + (buf * BCH + 16 * t2 + qi) * BSTR + g;
         f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF16) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[4 * s], qreg[s], sa, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[4 * s], doreg[s], dp, 0, 0, 0);
+          for (int t = 0; t < 4; ++t) {
+            sa = mma_bf16(pack_bf16(kp[16 * t], kp[16 * t + 4], kp[16 * t + 8], kp[16 * t + 12]), qpk[t], sa);
+            dp = mma_bf16(pack_bf16(vp[16 * t], vp[16 * t + 4], vp[16 * t + 8], vp[16 * t + 12]), dopk[t], dp);
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) {
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[4 * s], qreg[s], sa, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[4 * s], doreg[s], dp, 0, 0, 0);
+          }
         }
         float ds[4];
 #pragma unroll
@@ -114,11 +144,19 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
           const float p = (key < N) ? fast_exp(sa[e] - lse_q) : 0.f;
           ds[e] = p * (dp[e] - dl);
         }
+        if constexpr (BF16) {
+          const float* kt = Ks + (buf * BCH + 16 * t2 + 4 * g) * BSTR + qi;
+          const s16x4 dsp = pack_bf16(ds[0], ds[1], ds[2], ds[3]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float* kt = Ks + (buf * BCH + 16 * t2 + 4 * g + e) * BSTR + qi;
+          for (int d = 0; d < 4; ++d)
+            dq[d] = mma_bf16(pack_bf16(kt[16 * d], kt[BSTR + 16 * d], kt[2 * BSTR + 16 * d], kt[3 * BSTR + 16 * d]), dsp, dq[d]);
+        } else {
 #pragma unroll
-          for (int d = 0; d < 4; ++d) dq[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt[16 * d], ds[e], dq[d], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) {
+            const float* kt = Ks + (buf * BCH + 16 * t2 + 4 * g + e) * BSTR + qi;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) dq[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt[16 * d], ds[e], dq[d], 0, 0, 0);
+          }
         }
       }
     }
@@ -133,6 +171,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
   }
 }
 
+template <bool BF16>
 __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 float* __restrict__ dqkv, int N, int H, int FH, float scale) {
@@ -156,6 +195,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
   tile_to_regs(base + 2 * D, D3, k0, N, stage, vreg, tid);
 #pragma unroll
   for (int s = 0; s < 16; ++s) kreg[s] *= scale;
+  s16x4 kpk[4], vpk[4];   // (BF16) the key-side operands, rounded once
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    kpk[t] = pack_bf16(kreg[4 * t], kreg[4 * t + 1], kreg[4 * t + 2], kreg[4 * t + 3]);
+    vpk[t] = pack_bf16(vreg[4 * t], vreg[4 * t + 1], vreg[4 * t + 2], vreg[4 * t + 3]);
+  }
 
   float4 stq[2], sto[2];
   float stl = 0.f, std_ = 0.f;
@@ -208,10 +253,18 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
         const float* qp = Qs + (buf * BCH + 16 * t2 + ki) * BSTR + g;
         const float* op = Os + (buf * BCH + 16 * t2 + ki) * BSTR + g;
         f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF16) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          sa = __builtin_amdgcn_mfma_f32_16x16x4f32(qp[4 * s], kreg[s], sa, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(op[4 * s], vreg[s], dp, 0, 0, 0);
+          for (int t = 0; t < 4; ++t) {
+            sa = mma_bf16(pack_bf16(qp[16 * t], qp[16 * t + 4], qp[16 * t + 8], qp[16 * t + 12]), kpk[t], sa);
+            dp = mma_bf16(pack_bf16(op[16 * t], op[16 * t + 4], op[16 * t + 8], op[16 * t + 12]), vpk[t], dp);
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) {
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(qp[4 * s], kreg[s], sa, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(op[4 * s], vreg[s], dp, 0, 0, 0);
+          }
         }
         float p[4], ds[4];
 #pragma unroll
@@ -221,14 +274,25 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
           p[e] = ok ? fast_exp(sa[e] - Ls[buf * BCH + ql]) : 0.f;
           ds[e] = p[e] * (dp[e] - Dl[buf * BCH + ql]);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float* ot = Os + (buf * BCH + 16 * t2 + 4 * g + e) * BSTR + ki;
-          const float* qt = Qs + (buf * BCH + 16 * t2 + 4 * g + e) * BSTR + ki;
+        if constexpr (BF16) {
+          const float* ot = Os + (buf * BCH + 16 * t2 + 4 * g) * BSTR + ki;
+          const float* qt = Qs + (buf * BCH + 16 * t2 + 4 * g) * BSTR + ki;
+          const s16x4 pp = pack_bf16(p[0], p[1], p[2], p[3]), dsp = pack_bf16(ds[0], ds[1], ds[2], ds[3]);
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
-            dv[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(ot[16 * d], p[e], dv[d], 0, 0, 0);
-            dk[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(qt[16 * d], ds[e], dk[d], 0, 0, 0);
+            dv[d] = mma_bf16(pack_bf16(ot[16 * d], ot[BSTR + 16 * d], ot[2 * BSTR + 16 * d], ot[3 * BSTR + 16 * d]), pp, dv[d]);
+            dk[d] = mma_bf16(pack_bf16(qt[16 * d], qt[BSTR + 16 * d], qt[2 * BSTR + 16 * d], qt[3 * BSTR + 16 * d]), dsp, dk[d]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float* ot = Os + (buf * BCH + 16 * t2 + 4 * g + e) * BSTR + ki;
+            const float* qt = Qs + (buf * BCH + 16 * t2 + 4 * g + e) * BSTR + ki;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              dv[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(ot[16 * d], p[e], dv[d], 0, 0, 0);
+              dk[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(qt[16 * d], ds[e], dk[d], 0, 0, 0);
+            }
           }
         }
       }
@@ -256,8 +320,9 @@ extern "C" size_t tt_attention_bwd_workspace_bytes(int F, int N, int H, int hd) 
   return (size_t)F * H * N * sizeof(float);
 }
 
-extern "C" int tt_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N,
-                                int H, int hd, float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+template <bool BF16>
+static int attention_bwd_impl(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N,
+                              int H, int hd, float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
   TT_REQUIRE(qkv && out && dout && lse && dqkv && workspace, "attention_bwd: null pointer");
   TT_REQUIRE(hd == 64, "attention_bwd: head_dim must be 64 (got %d)", hd);
   TT_REQUIRE(F > 0 && H > 0 && N > 0, "attention_bwd: bad shape");
@@ -266,8 +331,18 @@ extern "C" int tt_attention_bwd(const float* qkv, const float* out, const float*
   hipStream_t s = as_stream(stream);
   float* delta = static_cast<float*>(workspace);
   dim3 grid(xcd_group_grid(F * H, (N + 63) / 64));
-  hipLaunchKernelGGL(attention_bwd_dq_kernel, grid, dim3(256), 0, s, qkv, out, dout, lse, dqkv, delta, N, H, F * H, scale);
-  hipLaunchKernelGGL(attention_bwd_dkv_kernel, grid, dim3(256), 0, s, qkv, dout, lse, delta, dqkv, N, H, F * H, scale);
+  hipLaunchKernelGGL(attention_bwd_dq_kernel<BF16>, grid, dim3(256), 0, s, qkv, out, dout, lse, dqkv, delta, N, H, F * H, scale);
+  hipLaunchKernelGGL(attention_bwd_dkv_kernel<BF16>, grid, dim3(256), 0, s, qkv, dout, lse, delta, dqkv, N, H, F * H, scale);
   TT_CHECK_LAUNCH("attention_bwd");
   return TT_OK;
+}
+
+extern "C" int tt_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N,
+                                int H, int hd, float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  return attention_bwd_impl<false>(qkv, out, dout, lse, dqkv, F, N, H, hd, scale, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tt_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N,
+                                     int H, int hd, float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  return attention_bwd_impl<true>(qkv, out, dout, lse, dqkv, F, N, H, hd, scale, workspace, workspace_bytes, stream);
 }

@@ -145,7 +145,9 @@ def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int,
     att = sv["att"].view(Fr * N, D)[r0:r1]
     d_att, grads[blk.attn.proj.weight], grads[blk.attn.proj.bias] = _bwd_both(dx_mid, blk.attn.proj.weight, att)
     qkv = sv["qkv"].view(Fr, N, 3 * D)[f0:f1]
-    dqkv = ops.attention_bwd(qkv, sv["att"][f0:f1], d_att.view(f1 - f0, N, D), sv["lse"][f0:f1], num_heads)
+    # (the "bf16" mode - BASELINE C4's path - runs the attention backward's products on bf16 MFMA like its dgrad / wgrad products)
+    dqkv = ops.attention_bwd(qkv, sv["att"][f0:f1], d_att.view(f1 - f0, N, D), sv["lse"][f0:f1], num_heads,
+                             bf16_products=ops.plane_count() == 1 and D // num_heads == 64)
     dqkv2 = dqkv.view((f1 - f0) * N, 3 * D)
     h1 = sv["h1"].view(Fr * N, D)[r0:r1]
     d_h1, grads[blk.attn.qkv.weight], grads[blk.attn.qkv.bias] = _bwd_both(dqkv2, blk.attn.qkv.weight, h1)

@@ -336,7 +336,9 @@ def attention_fwd(qkv, num_heads: int, save_lse=False, return_probs=False):
     return out, lse, probs
 
 
-def attention_bwd(qkv, out, dout, lse, num_heads: int):
+def attention_bwd(qkv, out, dout, lse, num_heads: int, bf16_products: bool = False):
+    """dqkv of the fused attention core from the forward's out / lse.  ``bf16_products``: the matrix products on bf16 MFMA
+    (tt_attention_bwd_bf16 - the "bf16" precision mode's backward; statistics, P and dS stay fp32)."""
     lib = _lib.load()
     _chk(qkv, "qkv"); _chk(out, "out"); _chk(dout, "dout"); _chk(lse, "lse")
     F, N, D3 = qkv.shape
@@ -344,8 +346,9 @@ def attention_bwd(qkv, out, dout, lse, num_heads: int):
     dqkv = torch.empty_like(qkv)
     nb = lib.tt_attention_bwd_workspace_bytes(F, N, num_heads, hd)
     ws = _ws(nb, qkv.device)
-    _lib.check(lib.tt_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), F, N, num_heads, hd, float(hd ** -0.5), _p(ws), nb,
-                                    _stream()), "tt_attention_bwd")
+    fn = lib.tt_attention_bwd_bf16 if bf16_products else lib.tt_attention_bwd
+    _lib.check(fn(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), F, N, num_heads, hd, float(hd ** -0.5), _p(ws), nb, _stream()),
+               "tt_attention_bwd_bf16" if bf16_products else "tt_attention_bwd")
     return dqkv
 
 
