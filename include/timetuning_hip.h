@@ -97,8 +97,10 @@ int tt_pos_embed_interpolate(const float* pos, float* out, int g, int gh, int gw
 /* Arithmetic of the forward nn.Linear products (tt_linear_fwd), process-wide:
  *   0 = f32 MFMA (default; exact fmaf chain, the mode every parity claim and the headline benchmark refer to)
  *   1 = "bf16x3": operands split into bf16 hi + lo, three bf16 MFMAs per product term (~2^-16 relative per product)
- *   2 = "bf16":   operands rounded to bf16 (BASELINE config C4's "MFMA bf16 path"; does not meet the 1e-3 fp32 contract)
- * Inputs/outputs stay fp32 in memory in every mode.  Backward products always run in f32. */
+ *   2 = "bf16":   operands rounded to bf16 (BASELINE config C4's "MFMA bf16 path"; does not meet the 1e-3 fp32 contract); in this mode
+ *                 tt_label_propagate[_maps] computes its cosine similarities on bf16 MFMA too (what torch.autocast makes of them)
+ * Inputs/outputs stay fp32 in memory in every mode.  tt_linear_bwd* always run in f32 (the bf16 path's backward products have their own
+ * entry points: tt_linear_bwd_data_planes, tt_linear_bwd_weight_planes, tt_attention_bwd_bf16). */
 int tt_set_gemm_precision(int mode);
 int tt_get_gemm_precision(void);
 

@@ -282,3 +282,39 @@ def test_attention_backward_on_bf16_products(Fr, N, H):
     assert 1e-5 < e16 < 2e-2, e16
     cos = torch.nn.functional.cosine_similarity(d16.double().cpu().flatten(), qt.grad.flatten(), dim=0).item()
     assert cos > 0.9999, cos
+
+
+def test_label_propagation_similarities_on_bf16_products():
+    """In the "bf16" mode (tt_set_gemm_precision 2, BASELINE C4's path) the label propagation's cosine similarities run on bf16 MFMA
+    (gemm_f32_kernel<BF16>): the propagated maps must equal the oracle's on the bf16-ROUNDED features (mask_propagation.py:448-496) as
+    well as the f32 mode's equal the oracle's on the fp32 features, and the mode must actually change the similarities."""
+    import torch.nn.functional as F_
+    from oracle import timet_oracle as O
+    from timetuning_amd import hip_ops as ops
+
+    fs, bs, g, D, K = 4, 2, 14, 768, 21
+    n = g * g
+    feats = rnd("lp.f", fs, bs, n, D)
+    for t in range(1, fs):
+        feats[t] = 0.7 * feats[t - 1] + 0.3 * feats[t]
+    xn = F_.normalize(feats, dim=-1)
+    seg0 = torch.softmax(rnd("lp.s", bs, n, K) * 2, -1)
+
+    def off_fraction(maps, x_ref):
+        bad = tot = 0
+        for b in range(bs):
+            seed = seg0[b].view(g, g, K).permute(2, 0, 1).unsqueeze(0)
+            ref = torch.stack(O.propagate_labels(3, 6, 5, g, x_ref[:, b], seed)).reshape(fs - 1, K, n).transpose(1, 2).numpy()
+            d = np.abs(maps[:, b] - ref).max(-1) > 1e-5 * np.abs(ref).max()
+            bad += int(d.sum()); tot += d.size
+        return bad / tot
+
+    m32 = ops.label_propagate_maps(xn.cuda(), seg0.cuda(), 3, 6, 5, 0.1).cpu().numpy()
+    try:
+        ops.set_gemm_precision("bf16")
+        m16 = ops.label_propagate_maps(xn.cuda(), seg0.cuda(), 3, 6, 5, 0.1).cpu().numpy()
+    finally:
+        ops.set_gemm_precision("f32")
+    assert off_fraction(m32, xn) < 0.01
+    assert off_fraction(m16, xn.to(torch.bfloat16).float()) < 0.01
+    assert not np.array_equal(m16, m32)

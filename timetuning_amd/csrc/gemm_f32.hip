@@ -53,9 +53,22 @@ struct GemmArgs {
   const int* frame_map;
   int Cin, H, W, P, gw, n_patch;
   const float* pos;  // [(n_patch+1)][N]
+  int bf16;          // NT products on bf16 MFMA (operands rounded as they leave LDS); set by launch_gemm_plain2 in the "bf16" mode
 };
 
-template <int WM, int WN, int AMODE, int BMODE, int BK>
+extern int g_gemm_precision;
+
+// BF16 (the "bf16" precision mode's batched products - the label propagation's cosine similarities): every group of four k = 2 f32 MFMAs
+// becomes ONE v_mfma_f32_32x32x8_bf16 on operands rounded to bf16 as they leave LDS (element q of a lane's operand is the fp32 loop's
+// register q: any assignment of the contraction index to (lane half, element) is valid as long as both operands use it).
+typedef __bf16 gemm_bf16x4 __attribute__((ext_vector_type(4)));
+typedef short gemm_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ gemm_s16x4 gemm_pack_bf16(const float (&v)[4]) {
+  const gemm_bf16x4 p = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  return __builtin_bit_cast(gemm_s16x4, p);
+}
+
+template <int WM, int WN, int AMODE, int BMODE, int BK, bool BF16 = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   // TT_KLAYOUT selects the [row][k] image (b128 reads) for k-contiguous sources.  Measured on MI355X (tools/ab_gemm.py):
@@ -268,12 +281,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
           for (int q = 0; q < 4; ++q) b[n][q] = pb[(8 * j + q) * LDB + n * 32];
         }
       }
+      if constexpr (BF16) {
+        gemm_s16x4 ap[WM], bp[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) ap[i] = gemm_pack_bf16(a[i]);
+#pragma unroll
+        for (int n = 0; n < WN; ++n) bp[n] = gemm_pack_bf16(b[n]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ap[i], bp[n], acc[i][n], 0, 0, 0);
+      } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
           for (int n = 0; n < WN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[n][q], acc[i][n], 0, 0, 0);
+      }
     }
     if (kt + 1 < nk) {
       store_a(buf ^ 1);
@@ -389,6 +414,13 @@ static int launch_cfg(const GemmArgs& g, int batch, hipStream_t s) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, batch, g.splits);
+  if constexpr (AMODE == 0 && BMODE == 0) {
+    if (g.bf16) {
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, AMODE, BMODE, kBK, true>), grid, dim3(256), 0, s, g);
+      TT_CHECK_LAUNCH("gemm_f32(bf16 products)");
+      return TT_OK;
+    }
+  }
   hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, AMODE, BMODE, kBK>), grid, dim3(256), 0, s, g);
   TT_CHECK_LAUNCH("gemm_f32");
   return TT_OK;
@@ -465,6 +497,7 @@ int launch_gemm_plain2(const float* A, const float* B, float* C, int M, int N, i
   g.strideA = sA; g.strideB = sB; g.strideC = sC;
   g.batch_inner = batch_inner;
   g.strideA2 = sA2; g.strideB2 = sB2; g.strideC2 = sC2;
+  g.bf16 = g_gemm_precision == 2;   // the "bf16" mode (BASELINE C4's path): these products on bf16 MFMA too, as torch.autocast would run them
   return launch_gemm(g, 0, 0, batch_inner * batch_outer, s);
 }
 
@@ -478,7 +511,7 @@ int try_launch_gemm_nt_fast(const float* A, const float* B, float* C, int M, int
                             const float* residual, float* pre_out, int act, hipStream_t s);
 int try_launch_gemm_nt_bf16(const float* A, const float* B, float* C, int M, int N, int K, const float* bias, const float* residual,
                             float* pre_out, int act, int npass, hipStream_t s);
-int g_gemm_precision = 0;  // 0 = f32 MFMA (default, exact), 1 = bf16x3 split, 2 = bf16; forward nn.Linear only
+int g_gemm_precision = 0;  // 0 = f32 MFMA (default, exact), 1 = bf16x3 split, 2 = bf16; forward nn.Linear (+ label-propagation similarities at 2)
 int try_launch_dgrad_fast(const float* dy, const float* w, const float* gelu_pre, float* dx, int M, int N, int K, hipStream_t s);
 int try_launch_wgrad_fast(const float* dy, const float* x, float* out, int M, int N, int K, int splits, int kchunk, float* colpart,
                           int* colparts, hipStream_t s);
