@@ -99,6 +99,9 @@ __device__ __forceinline__ void p8_st128(void* base, unsigned nbytes, unsigned v
 #ifndef TT_P8_SHIFT0
 #define TT_P8_SHIFT0 -1
 #endif
+#ifndef TT_P8_SHIFT1
+#define TT_P8_SHIFT1 0
+#endif
 template <int P>
 constexpr bool p8_shift0() { return TT_P8_SHIFT0 < 0 ? P == 1 : TT_P8_SHIFT0 != 0; }
 
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   using CF = P8Cfg<P>;
   constexpr int BK = CF::BK, NHW = CF::NHW, D = CF::D, L = CF::L;
   constexpr bool P8_SHIFT0 = p8_shift0<P>();
+  constexpr bool P8_SHIFT1 = TT_P8_SHIFT1 != 0 && P == 3;
   constexpr int ROWB = BK * 2;              // bytes per LDS row
   constexpr int CPR = ROWB / 16;            // 16-byte chunks per row
   constexpr int WIN = 256 / ROWB;           // rows per 256-byte bank window
@@ -421,8 +425,18 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     constexpr int CI0 = D & 3, BT0 = ((B ^ 1) + D / 4) & 1;
     static_assert(!P8_SHIFT0 || (CI0 != 0 && CF::exists(CI0) && CI0 != CF::X1 && 8 + CI0 - D - 1 >= CF::last_read(CI0) + 2),
                   "SHIFT0: phase 0's chunk must share the cursor's K-tile with phase 3's, exist in half tiles, and keep the WAR distance");
+    // SHIFT1 (P = 3 experiment): phase 1 (9 fragment reads + the X1 chunk) hands its chunk to phase 2 (6 reads, no chunk of its own: the
+    // fourth chunk slot does not exist at P = 3) - one phase LATER in time, same place in the vmcnt queue; phase 1's wait then has one
+    // chunk less to allow (X1 is not issued yet), every other wait keeps its number.
+    constexpr int CI1 = (1 + D) & 3, BT1 = (B + (1 + D) / 4) & 1;
+    static_assert(!P8_SHIFT1 || (P == 3 && CI1 == CF::X1 && !CF::exists((2 + D) & 3)), "SHIFT1 is the P = 3 schedule's hole in phase 2");
     auto dma_issue = [&]() {
       if constexpr (P8_SHIFT0 && PH == 0) return;
+      if constexpr (P8_SHIFT1 && PH == 1) return;
+      if constexpr (P8_SHIFT1 && PH == 2) {
+        issue(std::integral_constant<int, CI1>{}, std::integral_constant<int, BT1>{});
+        return;
+      }
       if constexpr (CI == 0) cursor_next_ktile();
       issue(std::integral_constant<int, CI>{}, std::integral_constant<int, BT>{});
       if constexpr (P8_SHIFT0 && PH == 3) issue(std::integral_constant<int, CI0>{}, std::integral_constant<int, BT0>{});
@@ -431,7 +445,8 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     auto dma_wait = [&]() {
       // (SHIFT0, phase 3: one chunk more has been issued, the chunk to retire is the same)
       constexpr int EXTRA = (P8_SHIFT0 && PH == 3) ? GCH : 0;
-      constexpr int WF = p8_window<P>(PH, GCH, false) + EXTRA, WH = p8_window<P>(PH, GCH, true) + EXTRA;
+      constexpr int LESS = (P8_SHIFT1 && PH == 1) ? GCH : 0;   // (SHIFT1: X1 is not in flight yet at phase 1's wait)
+      constexpr int WF = p8_window<P>(PH, GCH, false) + EXTRA - LESS, WH = p8_window<P>(PH, GCH, true) + EXTRA;
       if (steady && !(DBG & 2)) {
         p8_wait_vmcnt<WF>();
       } else {
