@@ -95,12 +95,11 @@ __device__ __forceinline__ void p8_st128(void* base, unsigned nbytes, unsigned v
 
 // SHIFT0 (see `phase`): phase 3 issues phase 0's DMA chunk as well.  Measured per plane count (tools/ab_planes.py, interleaved, bit-identical):
 // P = 1 1.6-4.4 % faster on the four ViT-B/16 block shapes, P = 3 1.2-3.6 % slower on the ViT-S/16 ones - so it is on for P = 1 only.
-// -DTT_P8_SHIFT0=0/1 forces it for both (timing studies).
+// -DTT_P8_SHIFT0=0/1 forces it for both (timing studies).  The P = 3 counterpart - phase 1 (9 reads + the X1 chunk) handing its chunk to
+// phase 2 (6 reads, no chunk: the fourth slot does not exist at P = 3), one phase later, phase 1's wait allowing one chunk less - was
+// built and measured too: bit-identical, within +-1 % on all four ViT-S/16 shapes (profiles/r03_p8_order.txt), not kept.
 #ifndef TT_P8_SHIFT0
 #define TT_P8_SHIFT0 -1
-#endif
-#ifndef TT_P8_SHIFT1
-#define TT_P8_SHIFT1 0
 #endif
 template <int P>
 constexpr bool p8_shift0() { return TT_P8_SHIFT0 < 0 ? P == 1 : TT_P8_SHIFT0 != 0; }
@@ -170,7 +169,6 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   using CF = P8Cfg<P>;
   constexpr int BK = CF::BK, NHW = CF::NHW, D = CF::D, L = CF::L;
   constexpr bool P8_SHIFT0 = p8_shift0<P>();
-  constexpr bool P8_SHIFT1 = TT_P8_SHIFT1 != 0 && P == 3;
   constexpr int ROWB = BK * 2;              // bytes per LDS row
   constexpr int CPR = ROWB / 16;            // 16-byte chunks per row
   constexpr int WIN = 256 / ROWB;           // rows per 256-byte bank window
@@ -425,18 +423,8 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     constexpr int CI0 = D & 3, BT0 = ((B ^ 1) + D / 4) & 1;
     static_assert(!P8_SHIFT0 || (CI0 != 0 && CF::exists(CI0) && CI0 != CF::X1 && 8 + CI0 - D - 1 >= CF::last_read(CI0) + 2),
                   "SHIFT0: phase 0's chunk must share the cursor's K-tile with phase 3's, exist in half tiles, and keep the WAR distance");
-    // SHIFT1 (P = 3 experiment): phase 1 (9 fragment reads + the X1 chunk) hands its chunk to phase 2 (6 reads, no chunk of its own: the
-    // fourth chunk slot does not exist at P = 3) - one phase LATER in time, same place in the vmcnt queue; phase 1's wait then has one
-    // chunk less to allow (X1 is not issued yet), every other wait keeps its number.
-    constexpr int CI1 = (1 + D) & 3, BT1 = (B + (1 + D) / 4) & 1;
-    static_assert(!P8_SHIFT1 || (P == 3 && CI1 == CF::X1 && !CF::exists((2 + D) & 3)), "SHIFT1 is the P = 3 schedule's hole in phase 2");
     auto dma_issue = [&]() {
       if constexpr (P8_SHIFT0 && PH == 0) return;
-      if constexpr (P8_SHIFT1 && PH == 1) return;
-      if constexpr (P8_SHIFT1 && PH == 2) {
-        issue(std::integral_constant<int, CI1>{}, std::integral_constant<int, BT1>{});
-        return;
-      }
       if constexpr (CI == 0) cursor_next_ktile();
       issue(std::integral_constant<int, CI>{}, std::integral_constant<int, BT>{});
       if constexpr (P8_SHIFT0 && PH == 3) issue(std::integral_constant<int, CI0>{}, std::integral_constant<int, BT0>{});
@@ -445,8 +433,7 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     auto dma_wait = [&]() {
       // (SHIFT0, phase 3: one chunk more has been issued, the chunk to retire is the same)
       constexpr int EXTRA = (P8_SHIFT0 && PH == 3) ? GCH : 0;
-      constexpr int LESS = (P8_SHIFT1 && PH == 1) ? GCH : 0;   // (SHIFT1: X1 is not in flight yet at phase 1's wait)
-      constexpr int WF = p8_window<P>(PH, GCH, false) + EXTRA - LESS, WH = p8_window<P>(PH, GCH, true) + EXTRA;
+      constexpr int WF = p8_window<P>(PH, GCH, false) + EXTRA, WH = p8_window<P>(PH, GCH, true) + EXTRA;
       if (steady && !(DBG & 2)) {
         p8_wait_vmcnt<WF>();
       } else {
