@@ -16,6 +16,8 @@
 // 16 ds_read_b32) - was correct to 1.4e-6 and 10 % SLOWER (118 vs 108 us, 128 bytes of scratch per lane): also not shipped.
 // Rotating which 32-query slice a wave owns with the (frame, head) index, so that the slices beyond N (wave 3 of every second
 // workgroup at N = 197: no MFMA work) do not always fall on the same SIMD: 108.1 vs 108.3 us - the SIMDs are not the imbalance.
+// Round 3: the three workgroups a CU receives in the first dispatch wave started 0 / 1 / 2 x {4 k, 10 k, 20 k} cycles apart (so that
+// their load / softmax / store phases do not coincide): 96.8 / 97.7 / 98.9 vs 97.4 us - lockstep is not it either.
 #include "common.hpp"
 
 namespace tt {
