@@ -206,6 +206,11 @@ int tt_attention_fwd_bf16(const void* qkv, void* out, int F, int N, int H, int h
  *   tt_linear_bwd_weight_planes       dw[N,K] = dy[M,N]^T @ x[M,K]: dyT [N][Mpad] and xT [K][Mpad] from tt_transpose_planes with the
  *                                     same Mpad (a multiple of 64); split-K over Mpad with a fixed-order fold; N, K % 64 == 0 */
 int tt_transpose_planes(const float* src, void* dst, int R, int C, int Rpad, tt_stream_t stream);
+/* The same pass that ALSO leaves the fp32 column sums of src in colsum [C] (the bias gradient dy.sum(0) of an nn.Linear whose dy is
+ * being transposed for tt_linear_bwd_weight_planes: one read of dy instead of two); workspace: ceil(Rpad / 64) x C floats. */
+size_t tt_transpose_planes_colsum_workspace_bytes(int R, int C, int Rpad);
+int tt_transpose_planes_colsum(const float* src, void* dst, int R, int C, int Rpad, float* colsum, void* workspace, size_t workspace_bytes,
+                               tt_stream_t stream);
 int tt_linear_bwd_data_planes(const void* dy_planes, long long dy_plane_stride, const void* wT_planes, long long wT_plane_stride,
                               int planes, const float* gelu_pre, float* dx, int M, int N, int K, tt_stream_t stream);
 int tt_linear_bwd_weight_planes(const void* dyT_planes, long long dyT_plane_stride, const void* xT_planes, long long xT_plane_stride,

@@ -702,6 +702,17 @@ int tt_cpu_transpose_planes(const float* src, void* dst, int R, int C, int Rpad,
     for (int r = 0; r < Rpad; ++r) d[(size_t)c * Rpad + r] = r < R ? tt_cpu_bf16(src[(size_t)r * C + c]) : 0;
   return 0;
 }
+size_t tt_cpu_transpose_planes_colsum_workspace_bytes(int R, int C, int Rpad) { return 0; }
+int tt_cpu_transpose_planes_colsum(const float* src, void* dst, int R, int C, int Rpad, float* colsum, void* workspace, size_t workspace_bytes,
+                                   tt_stream_t stream) {
+  (void)workspace; (void)workspace_bytes;
+  for (int c = 0; c < C; ++c) {
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) s += src[(size_t)r * C + c];
+    colsum[c] = (float)s;
+  }
+  return tt_cpu_transpose_planes(src, dst, R, C, Rpad, stream);
+}
 int tt_cpu_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, void* y_planes, long long plane_stride, int planes,
                                 float* mean, float* rstd, int rows, int D, float eps, int skip_group, tt_stream_t stream) {
   float* y = (float*)malloc((size_t)rows * D * sizeof(float));

@@ -405,6 +405,11 @@ def _round2b_cases(side):
     xl, gl, bl = f32(3, 5, 64), 1 + 0.1 * f32(64), 0.1 * f32(64)
     lp = np.empty((3, 15, 64), np.uint16)
     side.run("layernorm_fwd_planes", xl, gl, bl, lp, 15 * 64, 3, None, None, 15, 64, 1e-6, 0, st, outs=(lp,))
+    tp2, cs2 = np.empty((24, 128), np.uint16), np.empty(24, np.float32)
+    nbt = max(int(getattr(side.lib, side.prefix + "transpose_planes_colsum_workspace_bytes")(70, 24, 128)), 16)
+    wst = np.empty(nbt, np.uint8)
+    side.run("transpose_planes_colsum", xt, tp2, 70, 24, 128, cs2, wst, nbt, st, outs=(tp2, cs2))
+    R["transpose_colsum"] = (xt, tp2.copy(), cs2.copy())
     R["planes_misc"] = (xt, tp.copy(), xl, gl, bl, lp.copy())
     M, N, K = 70, 64, 128
     xs_, w_, bb, rr = f32(M, K), f32(N, K, scale=0.1), f32(N), f32(M, N)
@@ -475,6 +480,8 @@ def test_round2b_twins_against_torch(twin):
     assert np.array_equal(xa2, xa * sc + sh)
     xt_, tp, xl, gl, bl, lp = R["planes_misc"]
     assert np.array_equal(_bf(tp)[:, :70], torch.from_numpy(xt_).to(torch.bfloat16).double().numpy().T) and (tp[:, 70:] == 0).all()
+    xt2, tp2, cs2 = R["transpose_colsum"]
+    assert np.array_equal(tp2, tp) and _re(cs2, xt2.astype(np.float64).sum(0)) < 1e-6
     lnref = F.layer_norm(torch.from_numpy(xl).double(), (64,), torch.from_numpy(gl).double(), torch.from_numpy(bl).double(), 1e-6).numpy()
     assert _re(_bf(lp).sum(0), lnref.reshape(15, 64)) < 1e-6
     xs_, w_, bb, rr, res = R["plane_gemm"]
@@ -510,6 +517,7 @@ def test_hip_library_equals_its_cpu_twin_round2b(twin):
                 assert _re(a, b) < 2e-5, (key, i, _re(a, b))
     assert _re(A["att_bwd_bf16"][2], B["att_bwd_bf16"][2]) < 3e-3          # same rounding points; P / dS may round one bf16 ulp apart
     assert np.array_equal(A["planes_misc"][1], B["planes_misc"][1])                         # transposed bf16 image: bit for bit
+    assert np.array_equal(A["transpose_colsum"][1], B["transpose_colsum"][1]) and _re(A["transpose_colsum"][2], B["transpose_colsum"][2]) < 2e-6
     assert _re(_bf(A["planes_misc"][5]).sum(0), _bf(B["planes_misc"][5]).sum(0)) < 2e-6       # LayerNorm planes: same value to fp32 rounding
     for P_ in (1, 3):
         for i in (2, 3):

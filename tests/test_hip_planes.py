@@ -318,3 +318,17 @@ def test_label_propagation_similarities_on_bf16_products():
     assert off_fraction(m32, xn) < 0.01
     assert off_fraction(m16, xn.to(torch.bfloat16).float()) < 0.01
     assert not np.array_equal(m16, m32)
+
+
+@pytest.mark.parametrize("R,C", [(6304, 768), (591, 256), (100, 64), (3152, 2304)])
+def test_transpose_planes_with_column_sums(R, C):
+    """tt_transpose_planes_colsum: the transposed bf16 image is the plain entry point's bit for bit, the fp32 column sums (the bias
+    gradient of the bf16 path's weight-gradient product) match fp64 at fp32 accuracy and are the same on every run."""
+    from timetuning_amd import hip_ops as ops
+
+    x = rnd("tc.x", R, C).cuda()
+    plain = ops.transpose_planes(x)
+    t, s = ops.transpose_planes(x, colsum=True)
+    assert torch.equal(t, plain)
+    assert rel_err(s, x.double().sum(0)) < 2e-6
+    assert torch.equal(ops.transpose_planes(x, colsum=True)[1], s)

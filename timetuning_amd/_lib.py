@@ -73,6 +73,8 @@ SIGNATURES = {
     "tt_linear_fwd_planes": (c_i, [c_vp, c_ll, c_vp, c_ll, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "tt_attention_fwd_bf16": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp]),
     "tt_transpose_planes": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp]),
+    "tt_transpose_planes_colsum_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "tt_transpose_planes_colsum": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp, c_vp, c_sz, c_vp]),
     "tt_linear_bwd_data_planes": (c_i, [c_vp, c_ll, c_vp, c_ll, c_i, c_vp, c_vp, c_i, c_i, c_i, c_vp]),
     "tt_linear_bwd_weight_planes": (c_i, [c_vp, c_ll, c_vp, c_ll, c_i, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_linear_bwd_weight_planes_workspace_bytes": (c_sz, [c_i, c_i, c_i]),

@@ -358,15 +358,27 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 
 // ---- fp32 [R][C] -> bf16 [C][Rpad] (transpose; columns R..Rpad-1 zero): the operands of the backward products in the layout
 // gemm_planes_kernel reads (reduction index contiguous).  64 x 64 tiles through LDS.
-__global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int R, int C, int Rpad) {
+// SUM: the fp32 column sums of the tile's 64 rows go to partial[blockIdx.x][c] as well (a bias gradient = column sums of dy, whose
+// transpose the weight-gradient product needs anyway: one pass over dy instead of two; folded by colsum_fold in a fixed order)
+template <bool SUM>
+__global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int R, int C, int Rpad,
+                                                               float* __restrict__ partial) {
   __shared__ float t[64][65];
+  __shared__ float red[4][64];
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  float csum = 0.f;
   for (int i = ty; i < 64; i += 4) {
     const int r = r0 + i, c = c0 + tx;
-    t[i][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+    const float v = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+    t[i][tx] = v;
+    csum += v;
   }
+  if constexpr (SUM) red[ty][tx] = csum;
   __syncthreads();
+  if constexpr (SUM) {
+    if (ty == 0 && c0 + tx < C) partial[(size_t)blockIdx.x * C + c0 + tx] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  }
   // out row c = 64 consecutive r: 16 lanes x 4 bf16 (8-byte stores; Rpad % 64 == 0 keeps them aligned), 16 rows per pass
   if (Rpad % 4 == 0) {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -435,10 +447,30 @@ using namespace tt;
 
 extern "C" int tt_transpose_planes(const float* src, void* dst, int R, int C, int Rpad, tt_stream_t stream) {
   TT_REQUIRE(src && dst && R > 0 && C > 0 && Rpad >= R, "transpose_planes: bad arguments");
-  hipLaunchKernelGGL(transpose_planes_kernel, dim3((Rpad + 63) / 64, (C + 63) / 64), dim3(256), 0, as_stream(stream), src,
-                     static_cast<__bf16*>(dst), R, C, Rpad);
+  hipLaunchKernelGGL(transpose_planes_kernel<false>, dim3((Rpad + 63) / 64, (C + 63) / 64), dim3(256), 0, as_stream(stream), src,
+                     static_cast<__bf16*>(dst), R, C, Rpad, nullptr);
   TT_CHECK_LAUNCH("transpose_planes");
   return TT_OK;
+}
+
+namespace tt {
+int launch_colsum_fold(const float* partial, float* out, int chunks, int N, hipStream_t s);   // rowops.hip
+}
+
+extern "C" size_t tt_transpose_planes_colsum_workspace_bytes(int R, int C, int Rpad) {
+  if (R <= 0 || C <= 0 || Rpad < R) return 0;
+  return (size_t)((Rpad + 63) / 64) * C * sizeof(float);
+}
+
+extern "C" int tt_transpose_planes_colsum(const float* src, void* dst, int R, int C, int Rpad, float* colsum, void* workspace,
+                                          size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(src && dst && colsum && workspace && R > 0 && C > 0 && Rpad >= R, "transpose_planes_colsum: bad arguments");
+  TT_REQUIRE(workspace_bytes >= tt_transpose_planes_colsum_workspace_bytes(R, C, Rpad), "transpose_planes_colsum: workspace too small");
+  float* partial = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(transpose_planes_kernel<true>, dim3((Rpad + 63) / 64, (C + 63) / 64), dim3(256), 0, as_stream(stream), src,
+                     static_cast<__bf16*>(dst), R, C, Rpad, partial);
+  TT_CHECK_LAUNCH("transpose_planes_colsum");
+  return launch_colsum_fold(partial, colsum, (Rpad + 63) / 64, C, as_stream(stream));
 }
 
 extern "C" int tt_split_planes(const float* src, void* dst_planes, long long plane_stride, int planes, long long n, tt_stream_t stream) {

@@ -789,13 +789,20 @@ def attention_fwd_bf16(qkv, num_heads: int):
     return out
 
 
-def transpose_planes(x, rpad: Optional[int] = None):
-    """fp32 [R, C] -> bf16 [1, C, Rpad] (transposed, zero-padded along R to a multiple of 64 by default)."""
+def transpose_planes(x, rpad: Optional[int] = None, colsum: bool = False):
+    """fp32 [R, C] -> bf16 [1, C, Rpad] (transposed, zero-padded along R to a multiple of 64 by default).  ``colsum``: the same pass also
+    returns x.sum(0) in fp32 (tt_transpose_planes_colsum) -> (planes, sums)."""
     lib = _lib.load()
     _chk(x, "x")
     R, Cc = x.shape
     rpad = (R + 63) // 64 * 64 if rpad is None else rpad
     y = torch.empty((1, Cc, rpad), dtype=bf16, device=x.device)
+    if colsum:
+        sums = torch.empty((Cc,), dtype=f32, device=x.device)
+        nb = lib.tt_transpose_planes_colsum_workspace_bytes(R, Cc, rpad)
+        ws = _ws(nb, x.device)
+        _lib.check(lib.tt_transpose_planes_colsum(_p(x), _p(y), R, Cc, rpad, _p(sums), _p(ws), nb, _stream()), "tt_transpose_planes_colsum")
+        return y, sums
     _lib.check(lib.tt_transpose_planes(_p(x), _p(y), R, Cc, rpad, _stream()), "tt_transpose_planes")
     return y
 
@@ -829,7 +836,9 @@ def linear_bwd_weight_planes(dy, x, need_bias=True):
     _chk(dy, "dy"); _chk(x, "x")
     M, N = dy.shape
     K = x.shape[1]
-    dyT, xT = transpose_planes(dy), transpose_planes(x)      # [1, N, Mpad], [1, K, Mpad]
+    # [1, N, Mpad], [1, K, Mpad]; the bias gradient dy.sum(0) comes out of dy's transposing pass
+    dyT, db = transpose_planes(dy, colsum=True) if need_bias else (transpose_planes(dy), None)
+    xT = transpose_planes(x)
     Mpad = dyT.shape[2]
     dw = torch.empty((N, K), dtype=f32, device=dy.device)
     nb = lib.tt_linear_bwd_weight_planes_workspace_bytes(N, K, Mpad)
@@ -838,7 +847,7 @@ def linear_bwd_weight_planes(dy, x, need_bias=True):
     _lib.check(lib.tt_linear_bwd_weight_planes(_p(dyT), N * Mpad, _p(xT), K * Mpad, 1, _p(dw), N, K, Mpad, _p(ws), nb, _stream()),
                "tt_linear_bwd_weight_planes")
     _prof_end(e0, "PLANES1", N, K, Mpad)
-    return dw, (colsum(dy) if need_bias else None)
+    return dw, db
 
 
 # ---- coarse entry points: one C call per reference function ------------------------------------------------
