@@ -806,3 +806,13 @@ def test_bf16x3_full_size_c1(golden):
     assert rel_err(f[:, ::49, ::16].cpu(), g["features_slice"]) < TOL
     assert rel_err(bf[:, ::49, ::16].cpu(), g["backbone_features_slice"]) < TOL
     assert abs(loss.item() - float(g["loss0"])) < 1e-3 * float(g["loss0"])
+
+
+def test_graft_entry_smoke():
+    """The driver's smoke(): one tiny training iteration on cuda:0 checked against the oracle (__graft_entry__.py)."""
+    import importlib.util, os
+
+    spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.smoke()
