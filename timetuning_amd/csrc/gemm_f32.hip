@@ -416,6 +416,8 @@ static int launch_cfg(const GemmArgs& g, int batch, hipStream_t s) {
   dim3 grid(ntm * ntn, batch, g.splits);
   if constexpr (AMODE == 0 && BMODE == 0) {
     if (g.bf16) {
+      // (a 64-deep-slab instance of this one - a quarter of the barriers - was measured on the C4 label propagation: 795 vs 700 us for the
+      // whole call, tools/lp_time.py; f32: 775 - the extra LDS costs a resident workgroup)
       hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, AMODE, BMODE, kBK, true>), grid, dim3(256), 0, s, g);
       TT_CHECK_LAUNCH("gemm_f32(bf16 products)");
       return TT_OK;
