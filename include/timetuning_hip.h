@@ -198,6 +198,26 @@ int tt_linear_fwd_planes(const void* x_planes, long long x_plane_stride, const v
                          const float* bias, const float* residual, float* y, float* pre_out, void* y_planes,
                          long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, tt_stream_t stream);
 int tt_attention_fwd_bf16(const void* qkv, void* out, int F, int N, int H, int head_dim, float scale, tt_stream_t stream);
+
+/* ---- fp16-PAIR operands: the fp32-accurate split mode "f16x3" (round 4) of the forward nn.Linear sites
+ *   (dino_vision_transformer.py:94-103,115-130; models.py:915-926).  An fp32 value x is held as hi = fp16(x) and lo = fp16((x - hi) * 2^11):
+ *   x = hi + lo * 2^-11 to <= 2^-23 relative.  A tensor "in pairs" has its elements in groups of 32 consecutive ones, each group stored
+ *   as [hi x 32][lo x 32] fp16 - 4 bytes per element, rows as long as in fp32.  A product term costs three fp16 MFMAs (hi hi into one
+ *   fp32 accumulator, hi lo + lo hi into a second one folded in with the exact 2^-11); the dropped lo lo term is <= 2^-22 relative.
+ *   Operands must lie in fp16's range (|x| <= 65504: beyond it the result is inf / NaN, as an fp16 autocast's would be).
+ *   tt_split_pairs          fp32 [n] -> pairs, n % 32 == 0 (weights; activations produced by fp32 kernels).  tt_join_pairs: back.
+ *   tt_layernorm_fwd_pairs  tt_layernorm_fwd with the result in pairs [rows][2 D] (D % 32 == 0; optional mean / rstd as there).
+ *   tt_linear_fwd_pairs     y = act(x @ w^T + bias) (+ residual): x [M,K], w [N,K] in pairs.  Outputs, any of: y fp32 [M,N], pre_out
+ *                           fp32 (pre-activation), y_pairs [M][2 N].  residual fp32 may alias y.  N % 64 == 0, K % 32 == 0; any M.
+ *   tt_linear_fwd_pairs_route  which kernel such a call runs: 8 = the persistent gemm_pairs8_kernel (N % 128 == 0, K % 96 == 0,
+ *                           M >= 256, a bias, a grid that fills the chip, no pre_out), 0 = the general kernel.  Profilers' labels only. */
+int tt_split_pairs(const float* src, void* dst_pairs, long long n, tt_stream_t stream);
+int tt_join_pairs(const void* src_pairs, float* dst, long long n, tt_stream_t stream);
+int tt_layernorm_fwd_pairs(const float* x, const float* gamma, const float* beta, void* y_pairs, float* mean, float* rstd, int rows, int D,
+                           float eps, int skip_group, tt_stream_t stream);
+int tt_linear_fwd_pairs(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out,
+                        void* y_pairs, int M, int N, int K, int act, tt_stream_t stream);
+int tt_linear_fwd_pairs_route(int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int has_y_pairs, int has_pre_out);
 /*   The backward products of the same nn.Linear sites on bf16-plane operands (autograd of dino_vision_transformer.py:94-103,
  *   115-130; the bf16 path only - the fp32 modes keep the f32-MFMA backward kernels):
  *   tt_transpose_planes               fp32 [R][C] -> bf16 [C][Rpad], transposed, columns R..Rpad-1 zero (reduction index contiguous)
@@ -380,7 +400,8 @@ int tt_img_box_blur(const unsigned char* in, unsigned char* out, int F, int H, i
  *                        over the flat parameter buffers and the teacher prototypes, which are renormalised too. */
 typedef struct {
   const float *norm1_w, *norm1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
-  const void *qkv_wp, *proj_wp, *fc1_wp, *fc2_wp;   /* planes > 0: the four weights as bf16 planes [planes][out][in] (tt_split_planes) */
+  const void *qkv_wp, *proj_wp, *fc1_wp, *fc2_wp;   /* planes > 0: the four weights as bf16 planes [planes][out][in] (tt_split_planes),
+                                                       or, planes == 2, as fp16 pairs [out][2 in] (tt_split_pairs) */
 } tt_vit_block_params;
 typedef struct {
   const float *patch_w, *patch_b, *cls, *pos;   /* [D, C P P], [D], [D], [N, D] (position table at the input's grid) */
@@ -389,7 +410,9 @@ typedef struct {
   const float *norm_w, *norm_b;                 /* final LayerNorm (may be NULL when normed == NULL) */
   int dim, heads, hidden, patch;                /* D, attention heads (head_dim = D / heads), MLP width, patch size */
   int planes;                                   /* 0: fp32 operands (tt_linear_fwd); 1 / 3: the bf16-plane path of the blocks
-                                                   (tt_linear_fwd_planes; 1 = BASELINE C4's bf16 path, 3 = fp32-accurate), D % 64 == 0 */
+                                                   (tt_linear_fwd_planes; 1 = BASELINE C4's bf16 path, 3 = fp32-accurate), D % 64 == 0;
+                                                   2: fp16 PAIRS (tt_linear_fwd_pairs, the fp32-accurate "f16x3" mode; *_wp are
+                                                   tt_split_pairs of the weights), D % 64 == 0 and hidden % 64 == 0 */
   const void* patch_wp;                         /* planes == 1, optional: patch_w as one bf16 plane [D, C P P] - prepare_tokens then runs
                                                    tt_patch_embed_fwd_planes where its shape rules hold (ABI 4) */
 } tt_vit_params;

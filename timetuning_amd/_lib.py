@@ -72,6 +72,11 @@ SIGNATURES = {
     "tt_layernorm_fwd_planes": (c_i, [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_vp, c_vp, c_i, c_i, c_f, c_i, c_vp]),
     "tt_linear_fwd_planes": (c_i, [c_vp, c_ll, c_vp, c_ll, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "tt_attention_fwd_bf16": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp]),
+    "tt_split_pairs": (c_i, [c_vp, c_vp, c_ll, c_vp]),
+    "tt_join_pairs": (c_i, [c_vp, c_vp, c_ll, c_vp]),
+    "tt_layernorm_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_i, c_vp]),
+    "tt_linear_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
+    "tt_linear_fwd_pairs_route": (c_i, [c_i] * 9),
     "tt_transpose_planes": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp]),
     "tt_transpose_planes_colsum_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_transpose_planes_colsum": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp, c_vp, c_sz, c_vp]),

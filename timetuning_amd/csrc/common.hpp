@@ -34,6 +34,8 @@ inline hipStream_t as_stream(tt_stream_t s) { return reinterpret_cast<hipStream_
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+int device_cu_count();   // core.cpp: multiprocessors of the CURRENT device (looked up once per device id)
+
 // ---- device helpers -------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -91,6 +93,23 @@ __device__ __forceinline__ float gelu_bf16_f(float x) {
   const float u2 = x * fmaf(x2, -0.1029432f, -2.3022082f);           // -2 u log2(e)
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u2));
 }
+
+// ---- fp16 PAIRS: the operand format of the fp32-accurate split mode "f16x3" (gemm_pairs8.hip has the full description).
+// x -> (hi, lo) with hi = fp16(x), lo = fp16((x - hi) * 2^11): x - hi is exact in fp32 (hi is x rounded to 11 significant bits), the
+// scaling by a power of two is exact, so the only error is lo's own rounding, <= 2^-12 of |x - hi| <= 2^-23 |x|.  Subnormal hi / lo are
+// kept by the conversion and by the MFMA (tools/probes/mfma_f16_probe.hip); |x| > 65504 gives hi = inf (loud, like fp16 autocast).
+// Memory: groups of 32 consecutive elements as [hi x 32][lo x 32].
+constexpr float kPairScale = 2048.0f, kPairInvScale = 0.00048828125f;
+__device__ __forceinline__ void split_pair(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)((v - (float)hi) * kPairScale);
+}
+__device__ __forceinline__ float join_pair(_Float16 hi, _Float16 lo) { return fmaf((float)lo, kPairInvScale, (float)hi); }
+// index of element i of a row-major array whose length is a multiple of 32, in the pair layout: hi at pair_index(i), lo 32 further
+__host__ __device__ __forceinline__ long long pair_index(long long i) { return ((i >> 5) << 6) + (i & 31); }
+
+// epilogue kinds of gemm_pairs8_kernel
+enum { Q8_F32 = 0, Q8_F32_RES = 1, Q8_PAIR = 2, Q8_PAIR_GELU = 3 };
 
 // XCD-aware bijective remap of a linear workgroup id (guide T1): the dispatcher deals consecutive
 // ids round-robin over the 8 XCDs; this hands each XCD a contiguous run of logical tiles so that

@@ -1,5 +1,6 @@
 // Error reporting and device query for libtimetuning_hip.so.
 #include "common.hpp"
+#include <atomic>
 
 namespace tt {
 static thread_local char g_err[512] = "";
@@ -8,6 +9,21 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// CU count of the calling thread's current device, looked up once per device id (a count cached for whichever device was
+// current at the first call is wrong for the others of a multi-GPU process)
+int device_cu_count() {
+  constexpr int kMaxDev = 64;
+  static std::atomic<int> cache[kMaxDev];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  hipDeviceProp_t p;
+  n = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  cache[dev].store(n, std::memory_order_relaxed);
+  return n;
 }
 }  // namespace tt
 

@@ -1,0 +1,534 @@
+// fp16-PAIR GEMM, persistent form - the forward nn.Linear sites (dino_vision_transformer.py:94-103,115-130; models.py:915-926):
+//     y = act(x @ w^T + bias) (+ residual)
+// in the fp32-accurate split mode "f16x3" (round 4): an fp32 operand x is resident in HBM as a PAIR of fp16 numbers
+//     hi = fp16(x),   lo = fp16((x - hi) * 2^11)        x = hi + lo * 2^-11 to <= 2^-23 relative (11 + 1 + 11 significant bits)
+// and a product term x w costs THREE v_mfma_f32_32x32x16_f16 - hi hi into one accumulator, hi lo + lo hi into a SECOND one that is
+// folded in with the exact factor 2^-11 in the epilogue (the dropped lo lo term is <= 2^-22 |x w|, ~4e-8 of it in the mean) - where the
+// three-bf16-plane split (gemm_planes8.hip, P = 3) needs six.  Scaling lo by 2^11 keeps it a NORMAL fp16 number wherever hi is one,
+// so the split needs no per-tensor scale and no subnormal arithmetic; operands must lie in fp16's range (|x| <= 65504; beyond it hi is
+// an infinity and the result says so).  The MFMA keeps fp16 subnormals and has the bf16 instruction's lane maps
+// (tools/probes/mfma_f16_probe.hip, run on the box).
+//
+// Memory format ("pairs"): groups of 32 consecutive elements of a row, [hi x 32][lo x 32] fp16 = 128 bytes per group - a row of C
+// elements is 4 C bytes, as in fp32, and the 32-deep K-tile of a row is ONE 128-byte line.
+//
+// Kernel structure: that of gemm_planes8.hip (one 8-wave workgroup per CU, two wave groups a barrier interval apart alternating a
+// load part and an MFMA part, LDS-DMA in flight across raw barriers behind counted vmcnt, persistent over work items with the DMA
+// cursor running ahead across item boundaries, half tiles for the remainder round, swapped operands, per-wave epilogue through private
+// scratch with stores that are not waited for) on a geometry that fits TWO accumulator sets:
+//   * tile 256 (x rows) x 128 (w rows) x 32: a K-tile is three 16 KB chunks - W, X0, X1 (128 rows of 128 bytes each) - and the LDS
+//     holds a ring of THREE K-tiles (144 KB) + 2 KB of scratch per wave;
+//   * TWO phases per K-tile (x half 0, x half 1) of 12 MFMAs each (2 MFMA tiles x 2 k-steps x 3 products = 384 cycles of matrix pipe
+//     against a load part of 12 / 8 fragment reads and 2 / 4 LDS-DMA instructions per wave): the W fragments of a K-tile are read in
+//     phase 0 and stay in registers for phase 1;
+//   * schedule: phase (t, 0) issues chunk X1 of K-tile t + 1, phase (t, 1) chunks W and X0 of K-tile t + 2; every wait leaves the
+//     youngest three chunks (6 wave-instructions) in flight.  RAW: a chunk is needed three phases after its issue and is retired by the
+//     wait of the phase before.  WAR: slot (t + 2) mod 3 was last read in phase (t - 1, 0), slot part X1 of (t + 1) mod 3 in phase
+//     (t - 2, 1): three phases before the DMA that overwrites them (two are required with the groups staggered).
+//
+// Why not the 256 x 256 tile of the P = 1 kernel: two accumulator sets of it are 256 registers per lane, the whole budget of a wave at
+// two waves per SIMD.
+#include "common.hpp"
+#include <cstdlib>
+
+namespace tt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* q8_lds_ptr_t;
+
+struct Q8Args {
+  const _Float16* X;   // pairs [M][2 K]
+  const _Float16* W;   // pairs [N][2 K]
+  int M, N, K;         // K: reduction length in elements (K % 96 == 0)
+  const float* bias;      // [N]
+  const float* residual;  // [M][N] (Q8_F32_RES; may alias C)
+  float* C;               // [M][N] fp32 (Q8_F32*)
+  _Float16* Cp;           // pairs [M][2 N] (Q8_PAIR*)
+  int ntn, ntiles, ncu;   // column tiles, whole tiles, workgroups launched
+  int n_full, n_half;     // as gemm_planes8.hip: n_full whole tiles per workgroup, then n_half half tiles; both 0: round-robin
+  int order_mode;         // order of the load part (see `reads_first`)
+};
+
+__device__ __forceinline__ void q8_dma16(const void* base, unsigned char* lds_dst, int voffset, int soffset) {
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (q8_lds_ptr_t)lds_dst, 16, voffset, soffset, 0, 0);
+}
+__device__ __forceinline__ f32x4 q8_ld128(const void* base, unsigned nbytes, unsigned voff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, nbytes, 0x00020000);
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ void q8_st128(void* base, unsigned nbytes, unsigned voff, u32x4 v) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, nbytes, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void q8_wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// DBG (timing studies only; the shipped instantiations are DBG = 0), a bit mask: 1 no MFMAs, 2 no LDS-DMA, 8 no epilogue
+template <int EPI, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
+  constexpr int ROWB = 128;                 // bytes per LDS row = one pair group
+  constexpr int CPR = 8;                    // 16-byte chunks per row
+  constexpr int WIN = 2;                    // rows per 256-byte bank window
+  constexpr int RPI = 8;                    // rows one LDS-DMA wave-instruction fills
+  constexpr int JPW = 2;                    // DMA wave-instructions per wave and chunk (128 rows / 8 / 8 waves)
+  constexpr int GCH = JPW;                  // the vmcnt unit: wave-instructions per wave and chunk
+  constexpr int CHUNK_B = 128 * ROWB;       // 16 KB
+  constexpr int SLOT_B = 3 * CHUNK_B;       // W, X0, X1
+  constexpr int RING_B = 3 * SLOT_B;        // three K-tiles
+  constexpr int SCR_B = (160 * 1024 - RING_B) / 8;   // per-wave epilogue scratch (2 KB)
+  constexpr int CW = SCR_B / 128;                    // columns of a 32-row MFMA tile staged per pass (16)
+  constexpr int NPASS = 32 / CW;
+  constexpr int BN = 128;
+  constexpr bool F32OUT = EPI == Q8_F32 || EPI == Q8_F32_RES, RES = EPI == Q8_F32_RES, ACT = EPI == Q8_PAIR_GELU;
+  constexpr int L = 3;                                // chunks a wait leaves in flight
+  constexpr int WFULL = L * GCH;                      // 6
+  constexpr int WGUARD = 2 * GCH;                     // a window that may hold a half tile's K-tile (no X1 chunk): W, X0 only
+  constexpr int ST_TILE = 4;                          // stores a wave issues per 32 x 32 MFMA tile (fp32: 2 passes x 2; pairs: 2 passes x (hi, lo))
+  constexpr int ST_FULL = 4 * ST_TILE, ST_HALF = ST_FULL / 2;
+  constexpr int S_FULL = ST_FULL < 63 - WFULL ? ST_FULL : 63 - WFULL, S_HALF = ST_HALF < 63 - WFULL ? ST_HALF : 63 - WFULL;
+  constexpr int POST = 2;                             // phases whose window still reaches back across an epilogue
+  static_assert(RING_B + 8 * SCR_B <= 160 * 1024 && CW == 16, "LDS budget");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[160 * 1024];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool grp1 = wave >= 4;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r = lane & 31, h = lane >> 5;
+  const int K4 = g.K * 4, nk = g.K / 32;   // bytes per operand row; K-tiles
+
+  // ---- this workgroup's work items (gemm_planes8.hip: whole tiles dealt round-robin so that the 32 workgroups of an XCD work on
+  // 32 consecutive tiles; the tiles beyond the last whole round cut into halves)
+  int cu = blockIdx.x;
+  if ((g.ncu & 7) == 0) cu = (blockIdx.x & 7) * (g.ncu >> 3) + (blockIdx.x >> 3);
+  int n_whole;
+  bool has_half = false;
+  if (g.n_full > 0 || g.n_half > 0) {
+    n_whole = g.n_full;
+    has_half = cu < g.n_half;
+  } else {
+    n_whole = cu < g.ntiles ? (g.ntiles - cu + g.ncu - 1) / g.ncu : 0;
+  }
+  const int n_items = n_whole + (has_half ? 1 : 0);
+  if (n_items == 0) return;   // whole workgroup
+  const bool half_first = has_half && (cu & 1) && n_whole > 0;
+  auto item = [&](int it, int& row0, int& n0, bool& half) {
+    int tile;
+    half = has_half && (half_first ? it == 0 : it == n_whole);
+    int hsel = 0;
+    if (half) {
+      tile = g.n_full * g.ncu + (cu >> 1);
+      hsel = cu & 1;
+    } else {
+      tile = (half_first ? it - 1 : it) * g.ncu + cu;
+    }
+    const int mb = tile / g.ntn, ns = tile - mb * g.ntn;
+    row0 = mb * 256 + hsel * 128;
+    n0 = ns * BN;
+  };
+
+  // ---- LDS-DMA lane map: lane -> (row, slot) of a 1 KiB piece (8 rows), source chunk = slot ^ f(row), f(row) = (row / 2) & 7
+  const int l_row = lane / CPR, l_slot = lane % CPR;
+  const int d_row0 = wave * RPI + l_row;                                  // image row of piece `wave`; piece wave + 8 adds 64 rows (same f)
+  const int d_chunk = l_slot ^ ((d_row0 / WIN) & (CPR - 1));
+  const int w_voff = d_row0 * K4 + d_chunk * 16;
+
+  // DMA cursor: the K-tile whose chunks are issued next (scalar state + the X voffsets of its item; rows beyond M are clamped)
+  int d_item = 0, d_kt = 0;
+  bool d_done = false, d_half = false;
+  int half_guard = 0;   // > 0: the DMA window may hold a K-tile of a half item: the counted waits take the smaller count
+  int d_kofs = 0;       // d_kt * ROWB
+  int d_wbase = 0;      // first W row of the item * K4
+  int x_voff[2][JPW];
+  auto cursor_item = [&]() {
+    int row0, n0;
+    item(d_item, row0, n0, d_half);
+    d_wbase = n0 * K4;
+#pragma unroll
+    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+      for (int i = 0; i < JPW; ++i) {
+        int row = row0 + ha * 128 + 8 * i * RPI + d_row0;
+        row = row < g.M ? row : g.M - 1;
+        x_voff[ha][i] = row * K4 + d_chunk * 16;
+      }
+  };
+  cursor_item();
+  auto cursor_next_ktile = [&]() {
+    ++d_kt;
+    d_kofs += ROWB;
+    if (d_kt == nk) {
+      d_kt = 0;
+      d_kofs = 0;
+      ++d_item;
+      if (d_item >= n_items) {
+        d_done = true;
+      } else {
+        cursor_item();
+      }
+    }
+  };
+  bool steady = false;
+  // issue chunk C (0 W, 1 X0, 2 X1) of the cursor's K-tile into ring slot S
+  auto issue = [&](auto c_c, auto s_c) {
+    constexpr int CI = decltype(c_c)::value, S = decltype(s_c)::value;
+    if constexpr (!(DBG & 2)) {
+      if (!steady) {
+        if (d_done) return;
+        if (CI == 2 && d_half) return;
+      }
+      const int lds_base = S * SLOT_B + CI * CHUNK_B + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < JPW; ++i) {
+        unsigned char* dst = smem + lds_base + i * 8 * 1024;
+        if constexpr (CI == 0)
+          q8_dma16(g.W, dst, w_voff, d_wbase + (8 * i * RPI) * K4 + d_kofs);
+        else
+          q8_dma16(g.X, dst, x_voff[CI - 1][i], d_kofs);
+      }
+    }
+  };
+
+  // ---- fragment addressing: image row = (slice of the chunk) + r; chunk of the row: hi of k-step ks = 2 ks + h, lo = 4 + 2 ks + h;
+  // swizzled by f(r) (slices are multiples of 32 rows)
+  const int f_sw = (r / WIN) & (CPR - 1);
+  int fo[4];   // 0, 1: hi of k-steps 0, 1; 2, 3: lo
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) fo[c4] = r * ROWB + (((2 * c4 + h) ^ f_sw) << 4);
+  const int x_slice = wr * 64 * ROWB, w_slice = wc * 32 * ROWB;
+
+  f32x16 a1[2][2], a2[2][2];   // [x half][MFMA tile]: hi hi | hi lo + lo hi (x 2^11)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { a1[a][m][e] = 0.f; a2[a][m][e] = 0.f; }
+  f16x8 Wf[4], Xf[2][4];
+
+  // order of the load part (gemm_planes8.hip `reads_first`): 0 every wave DMA first, 1 every wave reads first, 2 odd waves read first,
+  // 3 waves 2, 3 (6, 7) of a group read first
+  const bool reads_first = g.order_mode == 1 || (g.order_mode == 2 && (wave & 1)) || (g.order_mode == 3 && (wave & 2));
+  int post_epi = 0;          // phases left in which the stores of the last epilogue may still be outstanding
+  bool post_half = false;
+  bool c_half = false;       // the item being computed is a half tile
+
+  // ---- one phase: [DMA issue | fragment reads | counted wait] barrier [MFMAs] barrier
+  auto phase = [&](auto s_c, auto ha_c) {
+    constexpr int S = decltype(s_c)::value, HA = decltype(ha_c)::value;
+    constexpr int base = S * SLOT_B;
+    const bool work = !(HA == 1 && c_half);   // a half item has no second x half
+    auto frag_reads = [&]() {
+      if (work) {
+        if constexpr (HA == 0) {
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) Wf[c4] = *reinterpret_cast<const f16x8*>(smem + base + w_slice + fo[c4]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4)
+            Xf[mt][c4] = *reinterpret_cast<const f16x8*>(smem + base + (1 + HA) * CHUNK_B + x_slice + mt * 32 * ROWB + fo[c4]);
+      }
+    };
+    auto dma_issue = [&]() {
+      if constexpr (HA == 0) {
+        issue(std::integral_constant<int, 2>{}, std::integral_constant<int, (S + 1) % 3>{});   // X1 of K-tile t + 1 (the cursor's)
+      } else {
+        cursor_next_ktile();                                                                     // -> K-tile t + 2
+        issue(std::integral_constant<int, 0>{}, std::integral_constant<int, (S + 2) % 3>{});
+        issue(std::integral_constant<int, 1>{}, std::integral_constant<int, (S + 2) % 3>{});
+      }
+    };
+    auto dma_wait = [&]() {
+      if (steady && !(DBG & 2)) {
+        q8_wait_vmcnt<WFULL>();
+      } else {
+        half_guard = (d_half && !d_done) ? 4 : (half_guard > 0 ? half_guard - 1 : 0);
+        if (d_done || (DBG & 2)) {
+          q8_wait_vmcnt<0>();
+        } else if (post_epi > 0) {
+          --post_epi;
+          if (half_guard > 0 || post_half) q8_wait_vmcnt<WGUARD + S_HALF>();
+          else q8_wait_vmcnt<WFULL + S_FULL>();
+        } else if (half_guard > 0) {
+          q8_wait_vmcnt<WGUARD>();
+        } else {
+          q8_wait_vmcnt<WFULL>();
+        }
+      }
+    };
+    if (!reads_first) dma_issue();
+    __builtin_amdgcn_sched_barrier(0);
+    frag_reads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (reads_first) dma_issue();
+    dma_wait();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (work && !(DBG & 1)) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          a1[HA][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[ks], Xf[mt][ks], a1[HA][mt], 0, 0, 0);
+          a2[HA][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[ks], Xf[mt][2 + ks], a2[HA][mt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a2[HA][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 + ks], Xf[mt][ks], a2[HA][mt], 0, 0, 0);
+      }
+    }
+    if constexpr (DBG & 1) {
+      if (work) {
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) keep += (float)Wf[i][0] + (float)Xf[0][i][0] + (float)Xf[1][i][0];
+        a1[0][0][0] += keep;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- epilogue of one item: per wave, through its private scratch, no workgroup barrier (gemm_planes8.hip).
+  // Lane (m = r) holds columns 8 g + 4 h + {0..3} of a 32 x 32 MFMA tile in registers 4 g .. 4 g + 3.  A pass stages 16 columns
+  // ([32][16] fp32, 16-byte chunks XOR-swizzled by the row) and reads them back row-major: fp32 outputs 4 columns per lane, pair
+  // outputs 8 columns per lane (16 bytes of hi + 16 bytes of lo: a wave's 32 columns are exactly one pair group of the output row).
+  unsigned char* scr = smem + RING_B + wave * SCR_B;
+  constexpr int CPRW = CW / 4;                    // 16-byte chunks per staged row (4)
+  constexpr int LPR = F32OUT ? CPRW : CPRW / 2;   // lanes per staged row on the way back
+  constexpr int RPW = 64 / LPR;                   // rows per read-back instruction
+  constexpr int NRB = 32 / RPW;                   // read-back instructions per pass
+  constexpr int NLD = NPASS * NRB;                // ... per MFMA tile (fp32: 4)
+  const int rr = lane / LPR, cc = lane % LPR;
+  const unsigned out_bytes = (unsigned)g.M * (unsigned)g.N * 4u;   // fp32 [M][N] and pairs [M][2 N] fp16 alike
+  auto epilogue = [&](int row0, int n0, bool half) {
+    if constexpr (DBG & 8) {
+      float sres = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { sres += a1[a][m][e] + a2[a][m][e]; a1[a][m][e] = 0.f; a2[a][m][e] = 0.f; }
+      if (g.C && sres == 12345.678f) g.C[threadIdx.x] = sres;
+      return;
+    }
+    constexpr int NT = 4;   // MFMA tiles in the order (ha, mt): a half item ends after the first two
+    const int nt = half ? NT / 2 : NT;
+    const int nbase = n0 + wc * 32;
+    f32x4 bias_lo[NPASS], bias_hi[NPASS];
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int n = nbase + q * CW + (F32OUT ? 4 : 8) * cc;
+      bias_lo[q] = *reinterpret_cast<const f32x4*>(g.bias + n);
+      if constexpr (!F32OUT) bias_hi[q] = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
+    }
+    f32x4 rres[3][RES ? NLD : 1];
+    auto prefetch = [&](int j, int slot) {
+      if constexpr (RES) {
+        const int mbase = row0 + (j >> 1) * 128 + wr * 64 + (j & 1) * 32;
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q)
+#pragma unroll
+          for (int i = 0; i < NRB; ++i) {
+            const unsigned off = ((unsigned)(mbase + i * RPW + rr) * (unsigned)g.N + (unsigned)(nbase + q * CW + 4 * cc)) * 4u;
+            rres[slot][q * NRB + i] = q8_ld128(g.residual, out_bytes, off);
+          }
+      }
+    };
+    if constexpr (RES) {
+      prefetch(0, 0);
+      prefetch(1, 1);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (j < nt) {
+        const int ha = j >> 1, mt = j & 1;
+        const int mbase = row0 + ha * 128 + wr * 64 + mt * 32;
+        if constexpr (RES) {
+          if (j + 2 < nt) prefetch(j + 2, (j + 2) % 3);
+        }
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+#pragma unroll
+          for (int gg = 0; gg < CW / 8; ++gg) {
+            const int gi = q * (CW / 8) + gg;
+            const int phys = (2 * gg + h) ^ (r & (CPRW - 1));
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(a2[ha][mt][4 * gi + e], 0.00048828125f, a1[ha][mt][4 * gi + e]);   // exact 2^-11
+            *reinterpret_cast<f32x4*>(scr + r * (CW * 4) + phys * 16) = v;
+          }
+#pragma unroll
+          for (int i = 0; i < NRB; ++i) {
+            const int row = i * RPW + rr;
+            const int m = mbase + row;
+            if constexpr (F32OUT) {
+              f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + ((cc ^ (row & (CPRW - 1))) << 4));
+              v += bias_lo[q];
+              if constexpr (RES) v += rres[j % 3][q * NRB + i];
+              const unsigned off = ((unsigned)m * (unsigned)g.N + (unsigned)(nbase + q * CW + 4 * cc)) * 4u;
+              q8_st128(g.C, out_bytes, off, __builtin_bit_cast(u32x4, v));
+            } else {
+              f32x4 v0 = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + (((2 * cc) ^ (row & (CPRW - 1))) << 4));
+              f32x4 v1 = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + (((2 * cc + 1) ^ (row & (CPRW - 1))) << 4));
+              v0 += bias_lo[q];
+              v1 += bias_hi[q];
+              float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+              if constexpr (ACT) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
+              }
+              f16x8 qh, ql;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                _Float16 hi_, lo_;
+                split_pair(v[e], hi_, lo_);
+                qh[e] = hi_;
+                ql[e] = lo_;
+              }
+              // pair group of this wave's 32 columns: byte offset of (m, nbase) = (m * 2 N + 2 nbase) * 2; hi then lo (64 bytes on)
+              const unsigned off = ((unsigned)m * (unsigned)g.N + (unsigned)nbase) * 4u + (unsigned)(q * CW + 8 * cc) * 2u;
+              q8_st128(g.Cp, out_bytes, off, __builtin_bit_cast(u32x4, qh));
+              q8_st128(g.Cp, out_bytes, off + 64u, __builtin_bit_cast(u32x4, ql));
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { a1[ha][mt][e] = 0.f; a2[ha][mt][e] = 0.f; }
+      }
+    }
+    // The stores are NOT waited for: they share the vmcnt queue with the LDS-DMA in issue order, and the waits of the next POST
+    // phases - whose windows still reach back across this epilogue - allow for S_FULL / S_HALF more outstanding operations, a LOWER
+    // bound of what was really issued (allowing fewer only waits for a few of the oldest epilogue operations as well).
+    post_epi = POST;
+    post_half = half;
+  };
+
+  // ---- prologue: K-tile 0 whole, W and X0 of K-tile 1 (what phases -3 .. -1 of the steady schedule would have issued, in its order)
+  {
+    using I0_ = std::integral_constant<int, 0>; using I1_ = std::integral_constant<int, 1>; using I2_ = std::integral_constant<int, 2>;
+    issue(I0_{}, I0_{}); issue(I1_{}, I0_{}); issue(I2_{}, I0_{});
+    cursor_next_ktile();
+    issue(I0_{}, I1_{}); issue(I1_{}, I1_{});
+    half_guard = d_half ? 4 : 0;
+    if (DBG & 2) q8_wait_vmcnt<0>();
+    else if (d_half || d_done) q8_wait_vmcnt<WGUARD>();   // (d_done: a single K-tile cannot happen, nk >= 3)
+    else q8_wait_vmcnt<WFULL>();
+    __builtin_amdgcn_s_barrier();
+  }
+
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  for (int it = 0; it < n_items; ++it) {
+    int row0, n0;
+    item(it, row0, n0, c_half);
+    if (grp1) __builtin_amdgcn_s_barrier();   // the second group runs one barrier interval behind
+    for (int kk = 0; kk < nk; kk += 3) {
+      // steady for these 6 phases?  The cursor advances three K-tiles in them: it must stay in whole tiles and short of the end.
+      steady = post_epi == 0 && half_guard == 0 && !c_half && !d_half && !d_done;
+      if (steady && d_kt + 3 >= nk) {   // it crosses into the next item
+        bool nhalf = false;
+        if (d_item + 1 < n_items) { int r0_, n0_; item(d_item + 1, r0_, n0_, nhalf); }
+        steady = d_item + 1 < n_items && !nhalf;
+      }
+      phase(I0{}, I0{}); phase(I0{}, I1{});
+      phase(I1{}, I0{}); phase(I1{}, I1{});
+      phase(I2{}, I0{}); phase(I2{}, I1{});
+    }
+    steady = false;
+    if (!grp1) __builtin_amdgcn_s_barrier();  // realign: both groups run their epilogues at the same time
+    epilogue(row0, n0, c_half);
+  }
+}
+
+static int q8_order_mode() {
+  static const int mode = [] { const char* e = getenv("TT_Q8_ORDER"); return e ? atoi(e) : 3; }();
+  return mode;
+}
+
+template <int EPI, int DBG = 0>
+static int launch_pairs8(const Q8Args& g, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_pairs8_kernel<EPI, DBG>), dim3(g.ncu), dim3(512), 0, s, g);
+  TT_CHECK_LAUNCH("gemm_pairs8");
+  return TT_OK;
+}
+
+
+// Shape / epilogue eligibility and the work decomposition.  Returns the epilogue kind or -1.
+static int pairs8_plan(bool has_bias, bool has_residual, bool has_y, bool has_pairs, int M, int N, int K, int act, int* ntn_out,
+                       long long* ntiles_out, int* ncu_out, int* n_full_out, int* n_half_out) {
+  if (N % 128 != 0 || K % 96 != 0 || M < 256 || !has_bias) return -1;
+  int epi = -1;
+  if (has_y && !has_pairs && !act) epi = has_residual ? Q8_F32_RES : Q8_F32;
+  else if (!has_y && has_pairs && !has_residual) epi = act ? Q8_PAIR_GELU : Q8_PAIR;
+  if (epi < 0) return -1;
+  // 32-bit buffer offsets
+  if ((long long)M * K * 4 >= 0x7fffffffLL || (long long)N * K * 4 >= 0x7fffffffLL || (long long)M * N * 4 >= 0x7fffffffLL) return -1;
+  const int ntm = (M + 255) / 256, ntn = N / 128;
+  const long long ntiles = (long long)ntm * ntn;
+  const int ncu_dev = device_cu_count();
+  if (ntiles < ncu_dev / 2) return -1;   // a persistent grid that cannot fill the chip: the small-tile kernel does better
+  int ncu = (int)(ntiles < ncu_dev ? ntiles : ncu_dev), n_full = 0, n_half = 0;
+  const long long R = ntiles / ncu_dev, rem = ntiles - R * ncu_dev;
+  if (rem > 0 && 2 * rem <= ncu_dev) {
+    ncu = ncu_dev;
+    n_full = (int)R;
+    n_half = (int)(2 * rem);
+  }
+  *ntn_out = ntn; *ntiles_out = ntiles; *ncu_out = ncu; *n_full_out = n_full; *n_half_out = n_half;
+  return epi;
+}
+
+int pairs8_would_run(int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int has_pairs) {
+  int ntn, ncu, n_full, n_half;
+  long long ntiles;
+  return pairs8_plan(has_bias != 0, has_residual != 0, has_y != 0, has_pairs != 0, M, N, K, act, &ntn, &ntiles, &ncu, &n_full, &n_half) >= 0;
+}
+
+// Called by tt_linear_fwd_pairs (gemm_planes.hip).  Returns TT_OK after a launch, 1 when the shape / epilogue is not this kernel's (the caller
+// then takes the general kernel), < 0 on a launch error.
+int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, void* y_pairs, int M, int N, int K,
+               int act, hipStream_t s) {
+  int ntn, ncu, n_full, n_half;
+  long long ntiles;
+  const int epi = pairs8_plan(bias != nullptr, residual != nullptr, y != nullptr, y_pairs != nullptr, M, N, K, act, &ntn, &ntiles, &ncu, &n_full,
+                              &n_half);
+  if (epi < 0) return 1;
+  Q8Args g{static_cast<const _Float16*>(x_pairs), static_cast<const _Float16*>(w_pairs), M, N, K, bias, residual, y, static_cast<_Float16*>(y_pairs),
+           ntn, (int)ntiles, ncu, n_full, n_half, q8_order_mode()};
+#ifdef TT_Q8_ABLATE   // timing-study build only: TT_Q8_DBG selects a crippled instantiation
+  {
+    const char* e = getenv("TT_Q8_DBG");
+    const int dbg = e ? atoi(e) : 0;
+#define Q8_DBG_CASE(EV)                                  \
+  if (epi == EV) {                                       \
+    if (dbg == 1) return launch_pairs8<EV, 1>(g, s);     \
+    if (dbg == 2) return launch_pairs8<EV, 2>(g, s);     \
+    if (dbg == 8) return launch_pairs8<EV, 8>(g, s);     \
+    if (dbg == 9) return launch_pairs8<EV, 9>(g, s);     \
+    if (dbg == 10) return launch_pairs8<EV, 10>(g, s);   \
+  }
+    Q8_DBG_CASE(Q8_F32) Q8_DBG_CASE(Q8_F32_RES) Q8_DBG_CASE(Q8_PAIR_GELU)
+#undef Q8_DBG_CASE
+  }
+#endif
+  switch (epi) {
+    case Q8_F32: return launch_pairs8<Q8_F32>(g, s);
+    case Q8_F32_RES: return launch_pairs8<Q8_F32_RES>(g, s);
+    case Q8_PAIR: return launch_pairs8<Q8_PAIR>(g, s);
+    case Q8_PAIR_GELU: return launch_pairs8<Q8_PAIR_GELU>(g, s);
+    default: return 1;
+  }
+}
+
+}  // namespace tt

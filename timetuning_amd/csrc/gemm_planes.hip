@@ -87,8 +87,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 // it, the compute waves issue only ds_read_b128 + MFMA.  A DMA piece costs its issuing wave 100+ cycles (address VALU, M0, the
 // request itself) - as long as the MFMAs of the k-step it feeds when every wave does both; on its own wave it overlaps the
 // other wave's matrix work instead of delaying it (one loader and one compute wave per SIMD at GM x GN = 2 x 2).
-template <int P, int BK, int WM, int WN, int NBUF, int GM = 2, int GN = 2, int LD = 0>
+// PAIR (round 4): the operands are fp16 PAIRS (common.hpp split_pair; gemm_pairs8.hip) - P = 1, BK = 64: a "row" of 64 16-bit elements is
+// one pair group [hi x 32][lo x 32] of a 32-deep K-tile, g.K counts 16-bit elements (2 x the reduction length), and a term costs three
+// v_mfma_f32_32x32x16_f16 into two accumulator sets (hi hi | hi lo + lo hi, folded with 2^-11 in the epilogue).  The general-shape
+// kernel of the "f16x3" mode: everything the persistent gemm_pairs8_kernel does not take (any M, N % 64 == 0, the projection head,
+// pre-activation outputs, gelu' products, split-K).
+template <int P, int BK, int WM, int WN, int NBUF, int GM = 2, int GN = 2, int LD = 0, bool PAIR = false>
 __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(PlaneArgs g) {
+  static_assert(!PAIR || (P == 1 && BK == 64), "pair operands: one 128-byte row per 32-deep K-tile");
   constexpr int NC = GM * GN;                 // compute waves
   constexpr int NW = LD ? NC : NC;            // waves that share the DMA pieces (the loaders when LD, else everybody)
   constexpr int NT = 64 * NC * (1 + LD);      // threads
@@ -154,12 +160,16 @@ __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(Pl
   };
 
   f32x16 acc[WM][WN];
+  f32x16 acc2[PAIR ? WM : 1][PAIR ? WN : 1];   // PAIR: the cross terms hi lo + lo hi (x 2^11)
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < WN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) {
+        acc[i][j][e] = 0.f;
+        if constexpr (PAIR) acc2[i][j][e] = 0.f;
+      }
 
   // fragment addressing: row offsets are compile-time multiples of 32 rows, the swizzle term depends on (row / WIN) only
   int a_off[WM], b_off[WN], a_sw[WM], b_sw[WN];
@@ -181,6 +191,33 @@ __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(Pl
     return;
 #endif
     const unsigned char* base = smem + buf * BUF;
+    if constexpr (PAIR) {
+      typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ch = 2 * ks + h, cl = 4 + 2 * ks + h;   // 16-byte chunks of the row: hi / lo of this k-step
+        f16x8 ah[WM], al[WM], bh[WN], bl[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          ah[i] = *reinterpret_cast<const f16x8*>(base + a_off[i] + ((ch ^ a_sw[i]) << 4));
+          al[i] = *reinterpret_cast<const f16x8*>(base + a_off[i] + ((cl ^ a_sw[i]) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          bh[j] = *reinterpret_cast<const f16x8*>(base + A_PL + b_off[j] + ((ch ^ b_sw[j]) << 4));
+          bl[j] = *reinterpret_cast<const f16x8*>(base + A_PL + b_off[j] + ((cl ^ b_sw[j]) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc2[i][j], 0, 0, 0);
+            acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc2[i][j], 0, 0, 0);
+          }
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int chunk = 2 * ks + h;
@@ -270,7 +307,8 @@ __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(Pl
         for (int j = 0; j < WN; ++j)
 #pragma unroll
           for (int e = 0; e < 16; ++e)
-            Cs[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDCS + wn * (32 * WN) + j * 32 + r] = acc[i][j][e];
+            Cs[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDCS + wn * (32 * WN) + j * 32 + r] =
+                PAIR ? fmaf(acc2[PAIR ? i : 0][PAIR ? j : 0][e], kPairInvScale, acc[i][j][e]) : acc[i][j][e];
     }
     __syncthreads();
     for (int rr = tid / TPR; rr < CH; rr += RPP) {
@@ -309,7 +347,22 @@ __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(Pl
           *reinterpret_cast<float4*>(c) = *reinterpret_cast<const float4*>(v);
           *reinterpret_cast<float4*>(c + 4) = *reinterpret_cast<const float4*>(v + 4);
         }
-        if (g.po > 0) {
+        if constexpr (PAIR) {
+          if (g.po > 0) {   // pairs [M][2 N]: this thread's 8 columns lie in one group of 32
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+            f16x8 qh, ql;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              _Float16 hi_, lo_;
+              split_pair(v[e], hi_, lo_);
+              qh[e] = hi_;
+              ql[e] = lo_;
+            }
+            _Float16* dst = reinterpret_cast<_Float16*>(g.Cp) + (size_t)m * 2 * g.N + pair_index(n);
+            *reinterpret_cast<f16x8*>(dst) = qh;
+            *reinterpret_cast<f16x8*>(dst + 32) = ql;
+          }
+        } else if (g.po > 0) {
           bf16x8 q0, q1, q2;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -327,11 +380,11 @@ __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(Pl
   }
 }
 
-template <int P, int BK, int WM, int WN, int NBUF = 2, int GM = 2, int GN = 2, int LD = 0>
+template <int P, int BK, int WM, int WN, int NBUF = 2, int GM = 2, int GN = 2, int LD = 0, bool PAIR = false>
 static int launch_planes(const PlaneArgs& g, hipStream_t s) {
   constexpr int BM = 32 * WM * GM, BN = 32 * WN * GN;
   const int tiles = ((g.M + BM - 1) / BM) * (g.N / BN);
-  hipLaunchKernelGGL((gemm_planes_kernel<P, BK, WM, WN, NBUF, GM, GN, LD>), dim3(tiles, g.splits), dim3(64 * GM * GN * (1 + LD)), 0, s, g);
+  hipLaunchKernelGGL((gemm_planes_kernel<P, BK, WM, WN, NBUF, GM, GN, LD, PAIR>), dim3(tiles, g.splits), dim3(64 * GM * GN * (1 + LD)), 0, s, g);
   TT_CHECK_LAUNCH("gemm_planes");
   return TT_OK;
 }
@@ -397,6 +450,43 @@ __global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __re
     if (c < C && r < Rpad) dst[(size_t)c * Rpad + r] = (__bf16)t[tx][i];
   }
 }
+
+// ---- f32 <-> fp16 pairs (common.hpp split_pair): groups of 32 elements as [hi x 32][lo x 32]; a thread converts 8 elements
+__global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long long n8) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    float v[8];
+    *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(src + 8 * i);
+    *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(src + 8 * i + 4);
+    f16x8 qh, ql;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      _Float16 hi_, lo_;
+      split_pair(v[e], hi_, lo_);
+      qh[e] = hi_;
+      ql[e] = lo_;
+    }
+    _Float16* d = dst + pair_index(8 * i);
+    *reinterpret_cast<f16x8*>(d) = qh;
+    *reinterpret_cast<f16x8*>(d + 32) = ql;
+  }
+}
+__global__ __launch_bounds__(256) void join_pairs_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, long long n8) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const _Float16* s = src + pair_index(8 * i);
+    const f16x8 qh = *reinterpret_cast<const f16x8*>(s), ql = *reinterpret_cast<const f16x8*>(s + 32);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = join_pair(qh[e], ql[e]);
+    *reinterpret_cast<float4*>(dst + 8 * i) = *reinterpret_cast<const float4*>(v);
+    *reinterpret_cast<float4*>(dst + 8 * i + 4) = *reinterpret_cast<const float4*>(v + 4);
+  }
+}
+
+int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, void* y_pairs, int M, int N, int K,
+               int act, hipStream_t s);                                                                               // gemm_pairs8.hip
+int pairs8_would_run(int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int has_pairs);
 
 int launch_splitk_reduce(const float* partial, float* out, long long n, int splits, long long stride, hipStream_t s);  // gemm_f32.hip
 int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes, const float* bias,
@@ -617,6 +707,67 @@ static int linear_planes_impl(const void* x_planes, long long x_plane_stride, co
   }
 }
 
+
+// ---- fp16-pair operands (the "f16x3" mode) ------------------------------------------------------------------------------------
+extern "C" int tt_split_pairs(const float* src, void* dst_pairs, long long n, tt_stream_t stream) {
+  TT_REQUIRE(src && dst_pairs && n > 0, "split_pairs: bad arguments");
+  TT_REQUIRE(n % 32 == 0 && aligned16(src) && aligned16(dst_pairs), "split_pairs: n must be a multiple of 32 and the buffers 16-byte aligned");
+  long long blocks = (n / 8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, static_cast<_Float16*>(dst_pairs), n / 8);
+  TT_CHECK_LAUNCH("split_pairs");
+  return TT_OK;
+}
+
+extern "C" int tt_join_pairs(const void* src_pairs, float* dst, long long n, tt_stream_t stream) {
+  TT_REQUIRE(src_pairs && dst && n > 0, "join_pairs: bad arguments");
+  TT_REQUIRE(n % 32 == 0 && aligned16(src_pairs) && aligned16(dst), "join_pairs: n must be a multiple of 32 and the buffers 16-byte aligned");
+  long long blocks = (n / 8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(join_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), static_cast<const _Float16*>(src_pairs), dst, n / 8);
+  TT_CHECK_LAUNCH("join_pairs");
+  return TT_OK;
+}
+
+// y[M,N] = act(x[M,K] @ w[N,K]^T + bias) (+ residual) (* gelu'(gelu_pre)) on pair operands; outputs any of y fp32, pre_out fp32,
+// y_pairs.  splits > 1: plain fp32 partials of a K split (weight gradients).
+static int linear_pairs_impl(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out,
+                             void* y_pairs, int M, int N, int K, int act, const float* gelu_pre, int splits, long long split_stride,
+                             tt_stream_t stream) {
+  TT_REQUIRE(x_pairs && w_pairs && (y || y_pairs), "linear_fwd_pairs: null operand / no output");
+  TT_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 32 == 0, "linear_fwd_pairs: need N %% 64 == 0 and K %% 32 == 0 (got N=%d K=%d)", N, K);
+  auto ok16 = [](const void* p) { return p == nullptr || aligned16(p); };
+  TT_REQUIRE(aligned16(x_pairs) && aligned16(w_pairs) && ok16(y) && ok16(pre_out) && ok16(y_pairs) && ok16(residual) && ok16(bias) && ok16(gelu_pre),
+             "linear_fwd_pairs: buffers must be 16-byte aligned");
+  TT_REQUIRE(splits >= 1 && (splits == 1 || (y && !bias && !residual && !pre_out && !y_pairs && !act && !gelu_pre)),
+             "linear_pairs: a split-K launch writes plain fp32 partials only");
+  hipStream_t s = as_stream(stream);
+  static const bool no8 = getenv("TT_PAIRS_NO8") != nullptr;   // tuning aid: the general kernel everywhere
+  if (!no8 && !pre_out && !gelu_pre && splits == 1) {
+    const int rc = pairs8_try(x_pairs, w_pairs, bias, residual, y, y_pairs, M, N, K, act, s);
+    if (rc <= 0) return rc;
+  }
+  // the general kernel sees rows of 2 K 16-bit elements in K-tiles of 64 (= one pair group)
+  PlaneArgs g{static_cast<const __bf16*>(x_pairs), static_cast<const __bf16*>(w_pairs), 0, 0, M, N, 2 * K, bias, residual, y,
+              pre_out, static_cast<__bf16*>(y_pairs), 0, y_pairs ? 1 : 0, act, gelu_pre, splits, split_stride};
+  const long long t128 = (long long)((M + 127) / 128) * (N / 128);
+  const bool big = (N % 128 == 0) && t128 * splits >= 3 * 256;
+  const bool wide = (N % 128 == 0) && (long long)((M + 63) / 64) * (N / 128) * splits >= 2 * 256;
+  if (big) return launch_planes<1, 64, 2, 2, 2, 2, 2, 0, true>(g, s);
+  if (wide) return launch_planes<1, 64, 1, 2, 2, 2, 2, 0, true>(g, s);
+  return launch_planes<1, 64, 1, 1, 2, 2, 2, 0, true>(g, s);
+}
+
+extern "C" int tt_linear_fwd_pairs_route(int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int has_y_pairs,
+                                         int has_pre_out) {
+  if (has_pre_out || getenv("TT_PAIRS_NO8") != nullptr) return 0;
+  return pairs8_would_run(M, N, K, act, has_bias, has_residual, has_y, has_y_pairs) ? 8 : 0;
+}
+
+extern "C" int tt_linear_fwd_pairs(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out,
+                                   void* y_pairs, int M, int N, int K, int act, tt_stream_t stream) {
+  return linear_pairs_impl(x_pairs, w_pairs, bias, residual, y, pre_out, y_pairs, M, N, K, act, nullptr, 1, 0, stream);
+}
 
 extern "C" size_t tt_patch_embed_planes_workspace_bytes(int F, int C, int H, int W, int P) {
   if (F <= 0 || C <= 0 || P <= 0 || H < P || W < P) return 0;

@@ -62,8 +62,9 @@ extern "C" int tt_vit_forward(const tt_vit_params* p, const float* img, const in
   TT_REQUIRE(H % p->patch == 0 && W % p->patch == 0, "vit_forward: %d x %d input is not a multiple of the patch size %d", H, W, p->patch);
   TT_REQUIRE(p->dim % p->heads == 0, "vit_forward: dim %d not divisible by %d heads", p->dim, p->heads);
   TT_REQUIRE(p->n_blocks == 0 || p->blocks, "vit_forward: null block table");
-  TT_REQUIRE(p->planes == 0 || p->planes == 1 || p->planes == 3, "vit_forward: planes must be 0, 1 or 3 (got %d)", p->planes);
+  TT_REQUIRE(p->planes >= 0 && p->planes <= 3, "vit_forward: planes must be 0, 1, 3 (bf16 planes) or 2 (fp16 pairs) (got %d)", p->planes);
   TT_REQUIRE(p->planes == 0 || p->dim % 64 == 0, "vit_forward: the plane path needs dim %% 64 == 0 (got %d)", p->dim);
+  TT_REQUIRE(p->planes != 2 || p->hidden % 64 == 0, "vit_forward: the pair path needs hidden %% 64 == 0 (got %d)", p->hidden);
   const int D = p->dim, hd = D / p->heads, P = p->planes;
   const int N = 1 + (H / p->patch) * (W / p->patch);
   const long long M = (long long)F * N;
@@ -109,13 +110,26 @@ extern "C" int tt_vit_forward(const tt_vit_params* p, const float* img, const in
       TT_FORWARD(tt_linear_fwd(act, b.fc2_w, b.fc2_b, tokens, tokens, nullptr, (int)M, D, p->hidden, 0, stream));
       continue;
     }
-    // bf16-plane operands: every Linear reads planes its producer wrote; the residual stream stays fp32, in place
+    // bf16-plane / fp16-pair operands: every Linear reads what its producer wrote; the residual stream stays fp32, in place
     TT_REQUIRE(b.qkv_wp && b.proj_wp && b.fc1_wp && b.fc2_wp, "vit_forward: block %d has no weight planes", i);
     const long long MD = M * D;
     void* hp = s.h;
     unsigned char* att_region = big + s.qkv_bytes;
     void* attp = big + s.qkv_bytes + s.att_bytes;
     void* actp = big;
+    if (P == 2) {   // the "f16x3" mode: fp16 pairs (4 bytes per element, the layout of 2 planes x 2 bytes)
+      float* qkv = qkv_out ? qkv_out : reinterpret_cast<float*>(big);
+      float* att = reinterpret_cast<float*>(att_region);
+      TT_FORWARD(tt_layernorm_fwd_pairs(tokens, b.norm1_w, b.norm1_b, hp, nullptr, nullptr, (int)M, D, 1e-6f, 0, stream));
+      TT_FORWARD(tt_linear_fwd_pairs(hp, b.qkv_wp, b.qkv_b, nullptr, qkv, nullptr, nullptr, (int)M, 3 * D, D, 0, stream));
+      TT_FORWARD(tt_attention_fwd(qkv, att, nullptr, probs, F, N, p->heads, hd, scale, stream));
+      TT_FORWARD(tt_split_pairs(att, attp, MD, stream));
+      TT_FORWARD(tt_linear_fwd_pairs(attp, b.proj_wp, b.proj_b, tokens, tokens, nullptr, nullptr, (int)M, D, D, 0, stream));
+      TT_FORWARD(tt_layernorm_fwd_pairs(tokens, b.norm2_w, b.norm2_b, hp, nullptr, nullptr, (int)M, D, 1e-6f, 0, stream));
+      TT_FORWARD(tt_linear_fwd_pairs(hp, b.fc1_wp, b.fc1_b, nullptr, nullptr, nullptr, actp, (int)M, p->hidden, D, 1, stream));
+      TT_FORWARD(tt_linear_fwd_pairs(actp, b.fc2_wp, b.fc2_b, tokens, tokens, nullptr, nullptr, (int)M, D, p->hidden, 0, stream));
+      continue;
+    }
     TT_FORWARD(tt_layernorm_fwd_planes(tokens, b.norm1_w, b.norm1_b, hp, MD, P, nullptr, nullptr, (int)M, D, 1e-6f, 0, stream));
     const void* proj_in;
     if (P == 1 && !qkv_out && !probs && N <= 256 && hd == 64) {

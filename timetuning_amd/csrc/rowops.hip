@@ -219,6 +219,112 @@ __global__ __launch_bounds__(256) void layernorm_fwd_planes_vec_kernel(const flo
   }
 }
 
+// LayerNorm whose result is written as fp16 PAIRS (common.hpp split_pair; the operand format of gemm_pairs8.hip): [rows][2 D] fp16,
+// groups of 32 columns as [hi x 32][lo x 32].  D = 128 NV: 8-byte loads, two columns per lane -> 4-byte hi and lo stores.
+template <int NV, int R>
+__global__ __launch_bounds__(256) void layernorm_fwd_pairs_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ beta, _Float16* __restrict__ y,
+                                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows,
+                                                                      float eps, int skip_group) {
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  constexpr int D = 128 * NV;
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
+  float2 v[R][NV];
+  float s[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    s[r] = 0.f;
+    const int row = row0 + r < rows ? row0 + r : row0;
+    const long long in_row = skip_group ? (long long)(row / (skip_group - 1)) * skip_group + 1 + row % (skip_group - 1) : row;
+    const float2* xr = reinterpret_cast<const float2*>(x + in_row * D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[r][i] = xr[lane + 64 * i];
+      s[r] += v[r][i].x + v[r][i].y;
+    }
+  }
+  float2 gm[NV], bt[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    gm[i] = reinterpret_cast<const float2*>(gamma)[lane + 64 * i];
+    bt[i] = reinterpret_cast<const float2*>(beta)[lane + 64 * i];
+  }
+  // columns 2 lane + 128 i, + 1: group (lane >> 4) + 4 i of the row, position 2 (lane & 15) inside it
+  const int pos = ((lane >> 4) << 6) + 2 * (lane & 15);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (row0 + r >= rows) break;
+    const float mean = wave_sum(s[r]) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float dx = v[r][i].x - mean, dy = v[r][i].y - mean;
+      q += dx * dx + dy * dy;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    _Float16* yr = y + (long long)(row0 + r) * (2 * D) + pos;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float o0 = (v[r][i].x - mean) * rstd * gm[i].x + bt[i].x, o1 = (v[r][i].y - mean) * rstd * gm[i].y + bt[i].y;
+      _Float16 h0, l0, h1, l1;
+      split_pair(o0, h0, l0);
+      split_pair(o1, h1, l1);
+      *reinterpret_cast<f16x2*>(yr + 256 * i) = (f16x2){h0, h1};
+      *reinterpret_cast<f16x2*>(yr + 256 * i + 32) = (f16x2){l0, l1};
+    }
+    if (lane == 0) {
+      if (mean_out) mean_out[row0 + r] = mean;
+      if (rstd_out) rstd_out[row0 + r] = rstd;
+    }
+  }
+}
+
+// any D % 32 == 0 (<= 1024): one column per lane and pass
+__global__ __launch_bounds__(256) void layernorm_fwd_pairs_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, _Float16* __restrict__ y,
+                                                                  float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int D,
+                                                                  float eps, int skip_group) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long long in_row = skip_group ? (long long)(row / (skip_group - 1)) * skip_group + 1 + row % (skip_group - 1) : row;
+  const float* xr = x + in_row * D;
+  float v[kMaxPerLane];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = (c < D) ? xr[c] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    const float d = (c < D) ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  _Float16* yr = y + (long long)row * (2 * D);
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) {
+      _Float16 hi, lo;
+      split_pair((v[i] - mean) * rstd * gamma[c] + beta[c], hi, lo);
+      yr[pair_index(c)] = hi;
+      yr[pair_index(c) + 32] = lo;
+    }
+  }
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+}
+
 // Backward.  Each workgroup owns a contiguous run of rows; its 4 waves walk them, keep per-column partial
 // sums of dgamma/dbeta in registers and combine them through LDS into partial[wg][2][D]; a column-sum
 // pass over the partials finishes (deterministic: no atomics).
@@ -601,6 +707,35 @@ extern "C" int tt_layernorm_fwd_planes(const float* x, const float* gamma, const
   hipLaunchKernelGGL(layernorm_fwd_planes_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta,
                      static_cast<__bf16*>(y_planes), plane_stride, planes, mean, rstd, rows, D, eps, skip_group);
   TT_CHECK_LAUNCH("layernorm_fwd_planes");
+  return TT_OK;
+}
+
+extern "C" int tt_layernorm_fwd_pairs(const float* x, const float* gamma, const float* beta, void* y_pairs, float* mean, float* rstd, int rows,
+                                      int D, float eps, int skip_group, tt_stream_t stream) {
+  TT_REQUIRE(skip_group == 0 || (skip_group >= 2 && rows % (skip_group - 1) == 0), "layernorm_fwd_pairs: rows must be a multiple of skip_group - 1");
+  TT_REQUIRE(x && gamma && beta && y_pairs, "layernorm_fwd_pairs: null pointer");
+  TT_REQUIRE(rows > 0 && D > 0 && D % 32 == 0 && D <= 64 * kMaxPerLane, "layernorm_fwd_pairs: need D %% 32 == 0 and 0 < D <= %d (got %d)",
+             64 * kMaxPerLane, D);
+  const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 7u) == 0 &&
+                  (reinterpret_cast<uintptr_t>(y_pairs) & 3u) == 0;
+  _Float16* yp = static_cast<_Float16*>(y_pairs);
+  hipStream_t s = as_stream(stream);
+  if (al && (D == 384 || D == 768 || D == 128 || D == 256 || D == 512 || D == 1024)) {
+    constexpr int R = 2;
+    const dim3 grid((rows + 4 * R - 1) / (4 * R)), block(256);
+    switch (D / 128) {
+      case 1: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<1, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group); break;
+      case 2: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<2, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group); break;
+      case 3: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<3, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group); break;
+      case 4: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<4, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group); break;
+      case 6: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<6, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group); break;
+      default: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<8, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group); break;
+    }
+    TT_CHECK_LAUNCH("layernorm_fwd_pairs");
+    return TT_OK;
+  }
+  hipLaunchKernelGGL(layernorm_fwd_pairs_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, yp, mean, rstd, rows, D, eps, skip_group);
+  TT_CHECK_LAUNCH("layernorm_fwd_pairs");
   return TT_OK;
 }
 

@@ -36,14 +36,15 @@ def weight_planes(w: torch.nn.Parameter, planes: int) -> torch.Tensor:
     EMA rewrites through raw pointers is split again on every call (a few MB per step)."""
     # staticness is re-derived at use time: a tensor unfrozen after freeze_backbone (a fine-tuning schedule) is updated by the
     # optimizer through raw pointers, whatever its stale flag says
+    split = (lambda t, n: ops.split_pairs(t)) if planes == 2 else ops.split_planes   # 2 = fp16 pairs [N, 2 K] (the "f16x3" mode)
     if w.requires_grad or not getattr(w, "_tt_static", False):
-        return ops.split_planes(w.detach(), planes)
+        return split(w.detach(), planes)
     # the cache lives ON the parameter object (not in a table keyed by id(): a recycled id + recycled storage of a dead model's
     # parameter would otherwise hit), so it dies with it
     hit = getattr(w, "_tt_planes", None)
     tag = (w.data_ptr(), w._version, planes)
     if hit is None or hit[0] != tag:
-        hit = (tag, ops.split_planes(w.detach(), planes))
+        hit = (tag, split(w.detach(), planes))
         w._tt_planes = hit
     return hit[1]
 
@@ -57,6 +58,17 @@ def block_forward_planes(x: torch.Tensor, blk, num_heads: int, planes: int, aux:
     M = Fr * N
     x2d = x.view(M, D)
     at = blk.attn
+    if planes == 2:   # fp16 pairs ("f16x3"): LayerNorm and the fc1 epilogue write pairs, the fp32 attention's output is split for proj
+        h1 = ops.layernorm_fwd_pairs(x, blk.norm1.weight, blk.norm1.bias)
+        qkv = ops.linear_fwd_pairs(h1, weight_planes(at.qkv.weight, 2), at.qkv.bias)["y"]
+        if aux is not None:
+            aux["qkv"] = qkv.view(Fr, N, 3 * D)
+        att32, _, _ = ops.attention_fwd(qkv.view(Fr, N, 3 * D), num_heads)
+        ops.linear_fwd_pairs(ops.split_pairs(att32.view(M, D)), weight_planes(at.proj.weight, 2), at.proj.bias, residual=x2d, out=x2d)
+        h2 = ops.layernorm_fwd_pairs(x, blk.norm2.weight, blk.norm2.bias)
+        a = ops.linear_fwd_pairs(h2, weight_planes(blk.mlp.fc1.weight, 2), blk.mlp.fc1.bias, act=1, out_f32=False, out_pairs=True)["pairs"]
+        ops.linear_fwd_pairs(a, weight_planes(blk.mlp.fc2.weight, 2), blk.mlp.fc2.bias, residual=x2d, out=x2d)
+        return x
     h1 = ops.layernorm_fwd_planes(x, blk.norm1.weight, blk.norm1.bias, planes)
     if planes == 1 and aux is None and N <= 256 and D // num_heads == 64:
         qkv = ops.linear_fwd_planes(h1, weight_planes(at.qkv.weight, 1), at.qkv.bias, out_f32=False, out_planes=1)["planes"]
@@ -80,7 +92,7 @@ def block_forward(x: torch.Tensor, blk, num_heads: int, save: Optional[dict] = N
     ``aux`` (a dict) receives the block's qkv activations [F,N,3D] - what the attention foreground mask reads."""
     Fr, N, D = x.shape
     M = Fr * N
-    if save is None and ops.plane_count() and D % 64 == 0:
+    if save is None and ops.plane_count() and D % 64 == 0 and blk.mlp.fc1.weight.shape[0] % 64 == 0:
         return block_forward_planes(x, blk, num_heads, ops.plane_count(), aux)
     x2d = x.view(M, D)
     if save is not None:
@@ -180,7 +192,7 @@ def vit_params(vit, first: int, last: int, pos: Optional[torch.Tensor] = None):
     from . import _lib
 
     D = vit.patch_embed.proj.weight.shape[0]
-    planes = ops.plane_count() if D % 64 == 0 else 0
+    planes = ops.plane_count() if D % 64 == 0 and vit.blocks[0].mlp.fc1.weight.shape[0] % 64 == 0 else 0
     n = last - first
     arr = (_lib.VitBlockParams * max(n, 1))()
     keep = [arr]

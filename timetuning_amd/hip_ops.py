@@ -39,13 +39,17 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 
 
 # name -> (mode of the C-side switch for tt_linear_fwd, bf16 planes used by the launch sequences for blocks that keep nothing)
-_PRECISIONS = {"f32": (0, 0), "bf16x3": (1, 0), "bf16": (2, 1), "bf16x6": (0, 3)}
+# (2 "planes" = fp16 PAIRS: hi / lo halves of an fp32 value, the "f16x3" mode)
+_PRECISIONS = {"f32": (0, 0), "bf16x3": (1, 0), "bf16": (2, 1), "bf16x6": (0, 3), "f16x3": (0, 2)}
 _precision = "f32"
 
 
 def set_gemm_precision(mode: str) -> None:
     """Arithmetic of the forward nn.Linear products.  Process-wide.
     "f32"     (default) exact fp32 MFMA - every headline / parity number.
+    "f16x3"   fp32-ACCURATE split mode (round 4): operands pre-split by their producers into fp16 PAIRS (hi = fp16(x), lo = fp16((x - hi)
+              2^11): 23 significant bits), three fp16 MFMAs per product term into two fp32 accumulators (gemm_pairs8.hip).  Same blocks
+              as "bf16x6" below; per-op error at or under the f32-MFMA kernels' own.
     "bf16x6"  fp32-ACCURATE split mode: operands pre-split by their producers into three bf16 planes (24 significant bits), six
               bf16 MFMAs per product term (gemm_planes.hip).  Applies to the blocks that keep no activations (frozen blocks,
               teacher, the non-target frames of the trainable blocks); everything with a backward stays exact fp32.
@@ -64,8 +68,13 @@ def get_gemm_precision() -> str:
 
 
 def plane_count() -> int:
-    """bf16 planes the launch sequences use for blocks that keep no activations (0 = fp32 operands)."""
+    """bf16 planes the launch sequences use for blocks that keep no activations (0 = fp32 operands; 2 = fp16 PAIRS, see ``pairs()``)."""
     return _PRECISIONS[_precision][1]
+
+
+def pairs() -> bool:
+    """True in the "f16x3" mode: the blocks that keep nothing run on fp16-pair operands (``linear_fwd_pairs``)."""
+    return _PRECISIONS[_precision][1] == 2
 
 
 # bench.py sets PROFILE to a list to get (layout, tile_choice, flops, start_event, end_event) per GEMM launch,
@@ -775,6 +784,72 @@ def linear_fwd_planes(xp, wp, bias=None, residual=None, act: int = 0, out_f32: b
                                         M, N, K, int(act), _stream()), "tt_linear_fwd_planes")
     _prof_end(e0, f"PLANES8_{P}" if p8 else f"PLANES{P}", M, N, K)
     return dict(y=y, planes=yp, pre=pre)
+
+
+# ---- fp16-pair operands (include/timetuning_hip.h: "fp16-PAIR operands") ------------------------------------------------------
+f16 = torch.float16
+
+
+def split_pairs(x, out=None):
+    """fp32 tensor [..., C] (C % 32 == 0) -> fp16 pairs [..., 2 C]: groups of 32 elements as [hi x 32][lo x 32]."""
+    lib = _lib.load()
+    _chk(x, "x")
+    if x.shape[-1] % 32:
+        raise ValueError("split_pairs: the last dimension must be a multiple of 32")
+    y = out if out is not None else torch.empty((*x.shape[:-1], 2 * x.shape[-1]), dtype=f16, device=x.device)
+    _lib.check(lib.tt_split_pairs(_p(x), _p(y), x.numel(), _stream()), "tt_split_pairs")
+    return y
+
+
+def join_pairs(xp):
+    """fp16 pairs [..., 2 C] -> fp32 [..., C] (hi + lo 2^-11)."""
+    lib = _lib.load()
+    _chk(xp, "xp", f16)
+    y = torch.empty((*xp.shape[:-1], xp.shape[-1] // 2), dtype=f32, device=xp.device)
+    _lib.check(lib.tt_join_pairs(_p(xp), _p(y), y.numel(), _stream()), "tt_join_pairs")
+    return y
+
+
+def layernorm_fwd_pairs(x, gamma, beta, eps=1e-6, save_stats=False, drop_first_token=False):
+    """LayerNorm whose result is written as fp16 pairs [rows, 2 D] (see ``layernorm_fwd`` for the arguments)."""
+    lib = _lib.load()
+    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    skip = 0
+    if drop_first_token:
+        skip = x.shape[-2]
+        rows = rows // skip * (skip - 1)
+    y = torch.empty((rows, 2 * D), dtype=f16, device=x.device)
+    mean = torch.empty((rows,), dtype=f32, device=x.device) if save_stats else None
+    rstd = torch.empty((rows,), dtype=f32, device=x.device) if save_stats else None
+    _lib.check(lib.tt_layernorm_fwd_pairs(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, float(eps), skip, _stream()),
+               "tt_layernorm_fwd_pairs")
+    return (y, mean, rstd) if save_stats else y
+
+
+def linear_fwd_pairs(xp, wp, bias=None, residual=None, act: int = 0, out_f32: bool = True, out_pairs: bool = False, save_pre: bool = False,
+                     out=None):
+    """y = act(x @ w.T + bias) (+ residual) on fp16-pair operands xp [M, 2 K], wp [N, 2 K].  Returns a dict with the requested
+    outputs: ``y`` (fp32 [M,N]), ``pairs`` (fp16 [M, 2 N]), ``pre`` (fp32 pre-activation)."""
+    lib = _lib.load()
+    _chk(xp, "xp", f16); _chk(wp, "wp", f16)
+    M, K2 = xp.shape
+    N = wp.shape[0]
+    K = K2 // 2
+    assert wp.shape[1] == K2, (xp.shape, wp.shape)
+    if bias is not None: _chk(bias, "bias")
+    if residual is not None: _chk(residual, "residual")
+    y = (out if out is not None else torch.empty((M, N), dtype=f32, device=xp.device)) if out_f32 else None
+    yp = torch.empty((M, 2 * N), dtype=f16, device=xp.device) if out_pairs else None
+    pre = torch.empty((M, N), dtype=f32, device=xp.device) if save_pre else None
+    p8 = PROFILE is not None and lib.tt_linear_fwd_pairs_route(M, N, K, int(act), int(bias is not None), int(residual is not None),
+                                                               int(y is not None), int(yp is not None), int(pre is not None)) == 8
+    e0 = _prof_begin()
+    _lib.check(lib.tt_linear_fwd_pairs(_p(xp), _p(wp), _p(bias), _p(residual), _p(y), _p(pre), _p(yp), M, N, K, int(act), _stream()),
+               "tt_linear_fwd_pairs")
+    _prof_end(e0, "PAIRS8" if p8 else "PAIRS", M, N, K)
+    return dict(y=y, pairs=yp, pre=pre)
 
 
 def attention_fwd_bf16(qkv, num_heads: int):
