@@ -34,6 +34,8 @@ F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 TILE_NAMES = {0: "128x128", 1: "64x128", 2: "128x64", 3: "64x64"}
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense v_mfma_f32_32x32x16_bf16 (MI355X_MICROARCH.md)
 ALT_NOTES = {
+    "f16x3": "fp32-accurate split mode: operands pre-split into fp16 pairs (hi, lo x 2^11), 3 fp16 MFMAs per product term (nominal peak "
+             f"{BF16_MATRIX_PEAK_TFLOPS / 3:.0f} TFLOP/s); per-op error under the f32-MFMA kernels' own; same fp32 tolerances in the parity tests",
     "bf16x6": "fp32-accurate split mode: operands pre-split into 3 bf16 planes, 6 bf16 MFMAs per product term (nominal peak "
               f"{BF16_MATRIX_PEAK_TFLOPS / 6:.0f} TFLOP/s) on the blocks that keep no activations; same fp32 tolerances in the parity tests",
     "bf16x3": "2-plane split (~2^-16 per product), fp32 in HBM converted while staging",
@@ -47,6 +49,10 @@ def kernel_label(name, tile):
         return f"gemm_nt_fast_kernel<{TILE_NAMES[tile]}> (forward nn.Linear, whole tiles)"
     if name == "NTbf16":
         return f"gemm_nt_bf16_kernel<{TILE_NAMES[tile]}> (forward nn.Linear, fp32 operands converted while staged)"
+    if name == "PAIRS8":
+        return "gemm_pairs8_kernel (nn.Linear on fp16-pair operands, persistent kernel, 3 MFMAs per term)"
+    if name == "PAIRS":
+        return "gemm_planes_kernel<PAIR> (nn.Linear on fp16-pair operands, general kernel)"
     if name.startswith("PLANES8_"):
         return f"gemm_planes8_kernel<P={name[8:]}> (forward nn.Linear on bf16-plane operands, persistent 8-phase kernel)"
     if name.startswith("PLANES"):
@@ -198,6 +204,7 @@ def roofline_block(prof, step_seconds, precision):
     # peak the dominant kernel is priced against: dense f32 MFMA, or dense bf16 MFMA / the MFMAs it issues per product term
     peak = {"PLANES1": BF16_MATRIX_PEAK_TFLOPS, "PLANES2": BF16_MATRIX_PEAK_TFLOPS / 3, "PLANES3": BF16_MATRIX_PEAK_TFLOPS / 6,
             "PLANES8_1": BF16_MATRIX_PEAK_TFLOPS, "PLANES8_3": BF16_MATRIX_PEAK_TFLOPS / 6,
+            "PAIRS8": BF16_MATRIX_PEAK_TFLOPS / 3, "PAIRS": BF16_MATRIX_PEAK_TFLOPS / 3,
             "NTbf16": BF16_MATRIX_PEAK_TFLOPS / (3 if precision == "bf16x3" else 1)}.get(dom_name, F32_MATRIX_PEAK_TFLOPS)
     # HBM bytes per launch of the dominant kernel from the committed PMC pass (tools/pmc_traffic.py) - only when that pass
     # measured THIS kernel
@@ -277,7 +284,7 @@ def cpu_baseline(fs, K, budget_s=30.0, arch="dino-s16", precision="f32"):
             hip_ops.set_gemm_precision("f32")
         rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
         parity = {"patch_embeddings_rel_err": rel(gf.cpu(), of), "assignment_logits_rel_err": rel(gsc.cpu(), osc), "gpu_precision": precision,
-                  "bound": 1e-3 if precision in ("f32", "bf16x6", "bf16x3") else None}
+                  "bound": 1e-3 if precision in ("f32", "f16x3", "bf16x6", "bf16x3") else None}
         del gm, gf, gsc
         # the second half of the metric on the host: the reference's Sinkhorn (my_utils.py:246-274) at the C2 shape
         sk_in = torch.exp(torch.nn.functional.normalize(torch.randn(6272, 256), dim=1) @ torch.nn.functional.normalize(torch.randn(K, 256), dim=1).t() / 0.05).t()
@@ -392,7 +399,7 @@ def main():
     ap.add_argument("--queue_size", type=int, default=16384, help="global queue rows (the reference's default); each rank holds queue_size // world")
     ap.add_argument("--use_mask", action="store_true", help="time the --use_mask variant (attention foreground masks) instead")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3", "bf16x6", "bf16x3", "bf16"],
                     help="arithmetic of the forward Linears for the TIMED region (default f32 = the headline / parity mode; "
                          "hip_ops.set_gemm_precision documents the others)")
     ap.add_argument("--no_alt_precision", action="store_true", help="skip the secondary bf16x3 / bf16 measurements")

@@ -218,6 +218,26 @@ int tt_layernorm_fwd_pairs(const float* x, const float* gamma, const float* beta
 int tt_linear_fwd_pairs(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out,
                         void* y_pairs, int M, int N, int K, int act, tt_stream_t stream);
 int tt_linear_fwd_pairs_route(int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int has_y_pairs, int has_pre_out);
+
+/* The backward products of an nn.Linear on pair operands (the "f16x3" mode's backward; autograd of dino_vision_transformer.py:94-103,
+ * 115-130 and of the projection head, models.py:915-926):
+ *   tt_split_pairs_dual           fp32 [R][C] -> transposed pairs [C][2 Rpad] (rows R..Rpad-1 zero, Rpad % 32 == 0) and, optionally in the
+ *                                 same pass, row-major pairs [R][2 C] (C % 32 == 0) and the fp32 column sums [C]: a dy is read ONCE for
+ *                                 the operand of its weight-gradient product, the operand of its data-gradient product and its bias
+ *                                 gradient.  workspace (column sums only): ceil(Rpad / 64) x C floats.
+ *   tt_transpose_pairs            pairs [R][2 C] -> transposed pairs [C][2 Rpad]: a saved forward operand for the weight gradient.
+ *   tt_linear_bwd_data_pairs      dx[M,K] = dy[M,N] @ w[N,K] (* gelu'(gelu_pre[M,K])): dy in pairs [M][2 N], the weight transposed in pairs
+ *                                 wT [K][2 N]; N % 32 == 0, K % 64 == 0.
+ *   tt_linear_bwd_weight_pairs    dw[N,K] = dy^T @ x: dyT [N][2 Mpad], xT [K][2 Mpad] (K % 64 == 0); split-K partials in the workspace,
+ *                                 folded in a fixed order. */
+size_t tt_split_pairs_dual_workspace_bytes(int R, int C, int Rpad);
+int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, int R, int C, int Rpad, void* workspace,
+                        size_t workspace_bytes, tt_stream_t stream);
+int tt_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int R, int C, int Rpad, tt_stream_t stream);
+int tt_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, int M, int N, int K, tt_stream_t stream);
+size_t tt_linear_bwd_weight_pairs_workspace_bytes(int N, int K, int Mpad);
+int tt_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, float* dw, int N, int K, int Mpad, void* workspace,
+                               size_t workspace_bytes, tt_stream_t stream);
 /*   The backward products of the same nn.Linear sites on bf16-plane operands (autograd of dino_vision_transformer.py:94-103,
  *   115-130; the bf16 path only - the fp32 modes keep the f32-MFMA backward kernels):
  *   tt_transpose_planes               fp32 [R][C] -> bf16 [C][Rpad], transposed, columns R..Rpad-1 zero (reduction index contiguous)

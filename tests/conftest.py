@@ -43,10 +43,11 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-@pytest.fixture(params=["f32", "bf16x6"])
+@pytest.fixture(params=["f32", "f16x3", "bf16x6"])
 def accurate_precision(request):
-    """The two arithmetic modes that must meet the fp32 contract: exact f32 MFMA (default) and the fp32-accurate split mode
-    (three bf16 planes, six products).  Tests that take this fixture run at their UNCHANGED fp32 tolerances in both."""
+    """The arithmetic modes that must meet the fp32 contract: exact f32 MFMA, and the fp32-accurate split modes - "f16x3" (fp16
+    pairs, three products; round 4) and "bf16x6" (three bf16 planes, six products).  Tests that take this fixture run at their
+    UNCHANGED fp32 tolerances in all of them."""
     from timetuning_amd import hip_ops
 
     hip_ops.set_gemm_precision(request.param)

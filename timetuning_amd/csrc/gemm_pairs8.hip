@@ -70,6 +70,12 @@ __device__ __forceinline__ void q8_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// TT_Q8_TAIL (timing study, round 4): 1 = the LDS-DMA instructions of phase f + 1 are issued behind the MFMAs of phase f (the MFMA
+// part's idle tail: the kernel is bound by its load part, see profiles/r04_q8_ablation.txt) instead of at the head of phase f + 1's
+// load part - half a phase earlier, same order, same counted waits; 2 = in the middle of the MFMAs.
+#ifndef TT_Q8_TAIL
+#define TT_Q8_TAIL 0
+#endif
 // DBG (timing studies only; the shipped instantiations are DBG = 0), a bit mask: 1 no MFMAs, 2 no LDS-DMA, 8 no epilogue
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
   constexpr int ST_TILE = 4;                          // stores a wave issues per 32 x 32 MFMA tile (fp32: 2 passes x 2; pairs: 2 passes x (hi, lo))
   constexpr int ST_FULL = 4 * ST_TILE, ST_HALF = ST_FULL / 2;
   constexpr int S_FULL = ST_FULL < 63 - WFULL ? ST_FULL : 63 - WFULL, S_HALF = ST_HALF < 63 - WFULL ? ST_HALF : 63 - WFULL;
-  constexpr int POST = 2;                             // phases whose window still reaches back across an epilogue
+  constexpr int POST = TT_Q8_TAIL ? 3 : 2;            // phases whose window still reaches back across an epilogue
   static_assert(RING_B + 8 * SCR_B <= 160 * 1024 && CW == 16, "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem[160 * 1024];
 
@@ -215,11 +221,22 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
 
   // order of the load part (gemm_planes8.hip `reads_first`): 0 every wave DMA first, 1 every wave reads first, 2 odd waves read first,
   // 3 waves 2, 3 (6, 7) of a group read first
-  const bool reads_first = g.order_mode == 1 || (g.order_mode == 2 && (wave & 1)) || (g.order_mode == 3 && (wave & 2));
+  const int omode = g.order_mode % 100;   // (+100: diagnostic builds print their stamps)
+  const bool reads_first = omode == 1 || (omode == 2 && (wave & 1)) || (omode == 3 && (wave & 2));
   int post_epi = 0;          // phases left in which the stores of the last epilogue may still be outstanding
   bool post_half = false;
   bool c_half = false;       // the item being computed is a half tile
 
+#ifdef TT_Q8_STAMP   // diagnostic build only (tools/q8_stamp.py): where a wave's steady-state phase goes, s_memtime stamps
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0, tsl = 0;
+  unsigned st_a[2] = {0, 0}, st_b[2] = {0, 0}, st_wait[2] = {0, 0}, st_bar1[2] = {0, 0}, st_lgkm[2] = {0, 0}, st_mfma[2] = {0, 0}, st_bar2[2] = {0, 0}, st_n[2] = {0, 0};
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#define Q8_STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
+#define Q8_STAMP_NOWAIT(t) asm volatile("s_memtime %0" : "=s"(t)::"memory")
+#else
+#define Q8_STAMP(t)
+#define Q8_STAMP_NOWAIT(t)
+#endif
   // ---- one phase: [DMA issue | fragment reads | counted wait] barrier [MFMAs] barrier
   auto phase = [&](auto s_c, auto ha_c) {
     constexpr int S = decltype(s_c)::value, HA = decltype(ha_c)::value;
@@ -266,14 +283,40 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
         }
       }
     };
-    if (!reads_first) dma_issue();
-    __builtin_amdgcn_sched_barrier(0);
-    frag_reads();
-    __builtin_amdgcn_sched_barrier(0);
-    if (reads_first) dma_issue();
+    // what the NEXT phase's load part would issue (TT_Q8_TAIL: issued behind this phase's MFMAs instead)
+    auto dma_issue_next = [&]() {
+      if constexpr (HA == 0) {
+        cursor_next_ktile();                                                                     // -> K-tile t + 2
+        issue(std::integral_constant<int, 0>{}, std::integral_constant<int, (S + 2) % 3>{});
+        issue(std::integral_constant<int, 1>{}, std::integral_constant<int, (S + 2) % 3>{});
+      } else {
+        issue(std::integral_constant<int, 2>{}, std::integral_constant<int, (S + 2) % 3>{});   // X1 of K-tile t + 2 (the cursor's)
+      }
+    };
+    Q8_STAMP(ts0);
+    if constexpr (TT_Q8_TAIL == 0) {
+      if (!reads_first) dma_issue();
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef TT_Q8_STAMP
+      if (!reads_first) Q8_STAMP(ts1);
+#endif
+      frag_reads();
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef TT_Q8_STAMP
+      if (reads_first) Q8_STAMP_NOWAIT(ts1);
+#endif
+      if (reads_first) dma_issue();
+    } else {
+      frag_reads();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    Q8_STAMP_NOWAIT(ts2);
     dma_wait();
+    Q8_STAMP_NOWAIT(ts3);
     __builtin_amdgcn_s_barrier();
+    Q8_STAMP_NOWAIT(ts4);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    Q8_STAMP_NOWAIT(ts5);
     __builtin_amdgcn_sched_barrier(0);
     if (work && !(DBG & 1)) {
 #pragma unroll
@@ -285,7 +328,21 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
         }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) a2[HA][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 + ks], Xf[mt][ks], a2[HA][mt], 0, 0, 0);
+        if constexpr (TT_Q8_TAIL == 2) {
+          if (ks == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            dma_issue_next();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
+    }
+    if constexpr (TT_Q8_TAIL == 2) {
+      if (!work || (DBG & 1)) dma_issue_next();
+    }
+    if constexpr (TT_Q8_TAIL == 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      dma_issue_next();
     }
     if constexpr (DBG & 1) {
       if (work) {
@@ -296,7 +353,18 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    Q8_STAMP_NOWAIT(ts6);   // (all MFMAs issued)
     __builtin_amdgcn_s_barrier();
+#ifdef TT_Q8_STAMP
+    {
+      unsigned long long te;
+      Q8_STAMP(te);
+      if (steady) {
+        st_a[HA] += (unsigned)(ts1 - ts0); st_b[HA] += (unsigned)(ts2 - ts1); st_wait[HA] += (unsigned)(ts3 - ts2); st_bar1[HA] += (unsigned)(ts4 - ts3);
+        st_lgkm[HA] += (unsigned)(ts5 - ts4); st_mfma[HA] += (unsigned)(ts6 - ts5); st_bar2[HA] += (unsigned)(te - ts6); ++st_n[HA];
+      }
+    }
+#endif
   };
 
   // ---- epilogue of one item: per wave, through its private scratch, no workgroup barrier (gemm_planes8.hip).
@@ -425,6 +493,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
     if (DBG & 2) q8_wait_vmcnt<0>();
     else if (d_half || d_done) q8_wait_vmcnt<WGUARD>();   // (d_done: a single K-tile cannot happen, nk >= 3)
     else q8_wait_vmcnt<WFULL>();
+    if constexpr (TT_Q8_TAIL != 0) issue(I2_{}, I1_{});   // ... and X1 of K-tile 1, which the tail of "phase (-1, 1)" would have issued
     __builtin_amdgcn_s_barrier();
   }
 
@@ -449,11 +518,27 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
     if (!grp1) __builtin_amdgcn_s_barrier();  // realign: both groups run their epilogues at the same time
     epilogue(row0, n0, c_half);
   }
+#ifdef TT_Q8_STAMP
+  if (g.order_mode >= 100 && lane == 0 && (wave == 0 || wave == 2 || wave == 5 || wave == 7) && blockIdx.x == 3) {
+    const unsigned long long dt = __builtin_amdgcn_s_memtime() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    for (int ha = 0; ha < 2; ++ha)
+      if (st_n[ha] > 0)
+        printf("q8 stamps: wave %d phase ha=%d  %u steady phases, cycles: first part (DMA issue, or reads when reads-first) %.0f | second part %.0f | counted wait %.0f | "
+               "barrier 1 %.0f | lgkmcnt(0) %.0f | MFMAs issued %.0f | barrier 2 %.0f   [kernel %llu cycles, %.3f GHz]\n", wave, ha, st_n[ha],
+               (double)st_a[ha] / st_n[ha], (double)st_b[ha] / st_n[ha], (double)st_wait[ha] / st_n[ha], (double)st_bar1[ha] / st_n[ha],
+               (double)st_lgkm[ha] / st_n[ha], (double)st_mfma[ha] / st_n[ha], (double)st_bar2[ha] / st_n[ha], dt, (double)dt / (double)dr * 0.1);
+  }
+#endif
 }
 
 static int q8_order_mode() {
+#if defined(TT_Q8_STAMP) || defined(TT_Q8_ABLATE)   // timing-study builds: read per call (A/B in one process)
+  const char* e = getenv("TT_Q8_ORDER");
+  return e ? atoi(e) : 3;
+#else
   static const int mode = [] { const char* e = getenv("TT_Q8_ORDER"); return e ? atoi(e) : 3; }();
   return mode;
+#endif
 }
 
 template <int EPI, int DBG = 0>
@@ -517,6 +602,8 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
     if (dbg == 8) return launch_pairs8<EV, 8>(g, s);     \
     if (dbg == 9) return launch_pairs8<EV, 9>(g, s);     \
     if (dbg == 10) return launch_pairs8<EV, 10>(g, s);   \
+    if (dbg == 3) return launch_pairs8<EV, 3>(g, s);     \
+    if (dbg == 11) return launch_pairs8<EV, 11>(g, s);   \
   }
     Q8_DBG_CASE(Q8_F32) Q8_DBG_CASE(Q8_F32_RES) Q8_DBG_CASE(Q8_PAIR_GELU)
 #undef Q8_DBG_CASE

@@ -488,6 +488,71 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
                int act, hipStream_t s);                                                                               // gemm_pairs8.hip
 int pairs8_would_run(int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int has_pairs);
 
+// ---- transposed pairs: the operands of the backward products in the "f16x3" mode (reduction index contiguous, in pair groups).
+// 64 x 64 tiles through LDS.  out row c holds groups of 32 consecutive r as [hi x 32][lo x 32]; rows R..Rpad-1 are zero (Rpad % 32 == 0).
+//   SRC_PAIRS = false: src fp32 [R][C]; optionally ALSO the row-major pairs [R][2 C] (C % 32 == 0: the dgrad operand of a dy that the
+//   weight gradient needs transposed) and the fp32 column sums of the tile's rows (a bias gradient) - one read of dy for all three.
+//   SRC_PAIRS = true: src pairs [R][2 C] (a saved forward operand): a 16-bit transpose of the hi and the lo halves.
+template <bool SRC_PAIRS, bool ROW, bool SUM>
+__global__ __launch_bounds__(256) void transpose_pairs_kernel(const void* __restrict__ src_, _Float16* __restrict__ dst_t, _Float16* __restrict__ dst_row,
+                                                              int R, int C, int Rpad, float* __restrict__ partial) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  __shared__ _Float16 th[64][66], tl[64][66];   // [r][c] halves of the tile (row stride 132 bytes: conflict-free column walks)
+  __shared__ float red[4][64];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  if constexpr (SRC_PAIRS) {
+    const _Float16* src = static_cast<const _Float16*>(src_);
+    for (int i = ty; i < 64; i += 4) {
+      const int r = r0 + i, c = c0 + tx;
+      _Float16 hi = (_Float16)0.f, lo = (_Float16)0.f;
+      if (r < R && c < C) {
+        const _Float16* p = src + (size_t)r * 2 * C + pair_index(c);
+        hi = p[0];
+        lo = p[32];
+      }
+      th[i][tx] = hi;
+      tl[i][tx] = lo;
+    }
+  } else {
+    const float* src = static_cast<const float*>(src_);
+    float csum = 0.f;
+    for (int i = ty; i < 64; i += 4) {
+      const int r = r0 + i, c = c0 + tx;
+      const float v = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+      _Float16 hi, lo;
+      split_pair(v, hi, lo);
+      th[i][tx] = hi;
+      tl[i][tx] = lo;
+      csum += v;
+      if constexpr (ROW) {
+        if (r < R && c < C) {
+          _Float16* p = dst_row + (size_t)r * 2 * C + pair_index(c);
+          p[0] = hi;
+          p[32] = lo;
+        }
+      }
+    }
+    if constexpr (SUM) red[ty][tx] = csum;
+  }
+  __syncthreads();
+  if constexpr (SUM) {
+    if (ty == 0 && c0 + tx < C) partial[(size_t)blockIdx.x * C + c0 + tx] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  }
+  // out row c: the tile's 64 r = two pair groups; 16 lanes x 4 r per row (8-byte stores), 16 rows per pass
+  const int q = threadIdx.x & 15, cr = threadIdx.x >> 4;
+  for (int i = cr; i < 64; i += 16) {
+    const int c = c0 + i, r = r0 + 4 * q;
+    if (c < C && r < Rpad) {   // (Rpad % 32 == 0: the four r of a quad are inside or outside together)
+      f16x4 vh = {th[4 * q][i], th[4 * q + 1][i], th[4 * q + 2][i], th[4 * q + 3][i]};
+      f16x4 vl = {tl[4 * q][i], tl[4 * q + 1][i], tl[4 * q + 2][i], tl[4 * q + 3][i]};
+      _Float16* p = dst_t + (size_t)c * 2 * Rpad + pair_index(r);
+      *reinterpret_cast<f16x4*>(p) = vh;
+      *reinterpret_cast<f16x4*>(p + 32) = vl;
+    }
+  }
+}
+
 int launch_splitk_reduce(const float* partial, float* out, long long n, int splits, long long stride, hipStream_t s);  // gemm_f32.hip
 int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes, const float* bias,
                 const float* residual, float* y, void* y_planes, long long y_plane_stride, int y_nplanes, int M, int N, int K, int act,
@@ -767,6 +832,76 @@ extern "C" int tt_linear_fwd_pairs_route(int M, int N, int K, int act, int has_b
 extern "C" int tt_linear_fwd_pairs(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out,
                                    void* y_pairs, int M, int N, int K, int act, tt_stream_t stream) {
   return linear_pairs_impl(x_pairs, w_pairs, bias, residual, y, pre_out, y_pairs, M, N, K, act, nullptr, 1, 0, stream);
+}
+
+// fp32 [R][C] -> transposed pairs [C][2 Rpad] (+ row-major pairs [R][2 C], + fp32 column sums); see transpose_pairs_kernel
+extern "C" size_t tt_split_pairs_dual_workspace_bytes(int R, int C, int Rpad) {
+  if (R <= 0 || C <= 0 || Rpad < R) return 0;
+  return (size_t)((Rpad + 63) / 64) * C * sizeof(float);
+}
+
+extern "C" int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, int R, int C, int Rpad, void* workspace,
+                                   size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(src && dst_t_pairs && R > 0 && C > 0 && Rpad >= R && Rpad % 32 == 0, "split_pairs_dual: bad arguments (Rpad must be a multiple of 32)");
+  TT_REQUIRE(!dst_row_pairs || C % 32 == 0, "split_pairs_dual: row-major pairs need C %% 32 == 0 (got %d)", C);
+  TT_REQUIRE(!colsum || (workspace && workspace_bytes >= tt_split_pairs_dual_workspace_bytes(R, C, Rpad)), "split_pairs_dual: workspace too small");
+  TT_REQUIRE((reinterpret_cast<uintptr_t>(dst_t_pairs) & 7u) == 0, "split_pairs_dual: the transposed output must be 8-byte aligned");
+  const dim3 grid((Rpad + 63) / 64, (C + 63) / 64), block(256);
+  hipStream_t s = as_stream(stream);
+  _Float16* dt = static_cast<_Float16*>(dst_t_pairs);
+  _Float16* dr = static_cast<_Float16*>(dst_row_pairs);
+  float* partial = static_cast<float*>(workspace);
+  if (dr && colsum) hipLaunchKernelGGL((transpose_pairs_kernel<false, true, true>), grid, block, 0, s, src, dt, dr, R, C, Rpad, partial);
+  else if (dr) hipLaunchKernelGGL((transpose_pairs_kernel<false, true, false>), grid, block, 0, s, src, dt, dr, R, C, Rpad, nullptr);
+  else if (colsum) hipLaunchKernelGGL((transpose_pairs_kernel<false, false, true>), grid, block, 0, s, src, dt, dr, R, C, Rpad, partial);
+  else hipLaunchKernelGGL((transpose_pairs_kernel<false, false, false>), grid, block, 0, s, src, dt, dr, R, C, Rpad, nullptr);
+  TT_CHECK_LAUNCH("split_pairs_dual");
+  if (colsum) return launch_colsum_fold(partial, colsum, (Rpad + 63) / 64, C, s);
+  return TT_OK;
+}
+
+// pairs [R][2 C] -> transposed pairs [C][2 Rpad]
+extern "C" int tt_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int R, int C, int Rpad, tt_stream_t stream) {
+  TT_REQUIRE(src_pairs && dst_t_pairs && R > 0 && C > 0 && C % 32 == 0 && Rpad >= R && Rpad % 32 == 0,
+             "transpose_pairs: bad arguments (C and Rpad must be multiples of 32)");
+  TT_REQUIRE((reinterpret_cast<uintptr_t>(dst_t_pairs) & 7u) == 0, "transpose_pairs: the output must be 8-byte aligned");
+  hipLaunchKernelGGL((transpose_pairs_kernel<true, false, false>), dim3((Rpad + 63) / 64, (C + 63) / 64), dim3(256), 0, as_stream(stream), src_pairs,
+                     static_cast<_Float16*>(dst_t_pairs), static_cast<_Float16*>(nullptr), R, C, Rpad, static_cast<float*>(nullptr));
+  TT_CHECK_LAUNCH("transpose_pairs");
+  return TT_OK;
+}
+
+// dx[M,K] = dy[M,N] @ w[N,K] (* gelu'(gelu_pre)): dy in pairs [M][2 N], the weight TRANSPOSED in pairs wT [K][2 N]
+extern "C" int tt_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, int M, int N, int K,
+                                        tt_stream_t stream) {
+  TT_REQUIRE(dx, "linear_bwd_data_pairs: null output");
+  return linear_pairs_impl(dy_pairs, wT_pairs, nullptr, nullptr, dx, nullptr, nullptr, M, K, N, 0, gelu_pre, 1, 0, stream);
+}
+
+// dw[N,K] = dy[M,N]^T @ x[M,K]: both operands transposed in pairs, dyT [N][2 Mpad], xT [K][2 Mpad] (zero beyond M).  Split-K over Mpad
+// (few output tiles, long reduction): partials in the workspace, folded in fixed order.
+static int wgrad_pairs_splits(int N, int K, int Mpad) {
+  const long long tiles = (long long)((N + 127) / 128) * ((K + 127) / 128);
+  int s = (int)((640 + tiles - 1) / tiles);
+  const int smax = Mpad / 128;   // >= 4 K-tiles of 32 per slice
+  if (s > smax) s = smax;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : s;
+}
+extern "C" size_t tt_linear_bwd_weight_pairs_workspace_bytes(int N, int K, int Mpad) {
+  const int s = wgrad_pairs_splits(N, K, Mpad);
+  return s > 1 ? (size_t)s * N * K * sizeof(float) : 16;
+}
+extern "C" int tt_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, float* dw, int N, int K, int Mpad, void* workspace,
+                                          size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(dw && workspace, "linear_bwd_weight_pairs: null pointer");
+  TT_REQUIRE(workspace_bytes >= tt_linear_bwd_weight_pairs_workspace_bytes(N, K, Mpad), "linear_bwd_weight_pairs: workspace too small");
+  const int s = wgrad_pairs_splits(N, K, Mpad);
+  if (s == 1) return linear_pairs_impl(dyT_pairs, xT_pairs, nullptr, nullptr, dw, nullptr, nullptr, N, K, Mpad, 0, nullptr, 1, 0, stream);
+  float* part = static_cast<float*>(workspace);
+  const int rc = linear_pairs_impl(dyT_pairs, xT_pairs, nullptr, nullptr, part, nullptr, nullptr, N, K, Mpad, 0, nullptr, s, (long long)N * K, stream);
+  if (rc != TT_OK) return rc;
+  return launch_splitk_reduce(part, dw, (long long)N * K, s, (long long)N * K, as_stream(stream));
 }
 
 extern "C" size_t tt_patch_embed_planes_workspace_bytes(int F, int C, int H, int W, int P) {

@@ -95,6 +95,8 @@ def block_forward(x: torch.Tensor, blk, num_heads: int, save: Optional[dict] = N
     if save is None and ops.plane_count() and D % 64 == 0 and blk.mlp.fc1.weight.shape[0] % 64 == 0:
         return block_forward_planes(x, blk, num_heads, ops.plane_count(), aux)
     x2d = x.view(M, D)
+    if save is not None and ops.pairs() and D % 64 == 0 and blk.mlp.fc1.weight.shape[0] % 64 == 0:
+        return block_forward_pairs_kept(x, blk, num_heads, save, aux)
     if save is not None:
         h1, save["mean1"], save["rstd1"] = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, save_stats=True)
     else:
@@ -115,6 +117,40 @@ def block_forward(x: torch.Tensor, blk, num_heads: int, save: Optional[dict] = N
     if save is not None:
         save.update(x_in=x, h1=h1, qkv=qkv, att=att, lse=lse, x_mid=x_mid, h2=h2, pre=pre, a=a)
     return x_out.view(Fr, N, D)
+
+
+def block_forward_pairs_kept(x: torch.Tensor, blk, num_heads: int, save: dict, aux: Optional[dict] = None) -> torch.Tensor:
+    """A block that KEEPS its activations, in the "f16x3" mode: the Linears run on fp16-pair operands (three fp16 MFMAs per term) and what
+    the backward needs of their inputs is kept AS pairs (h1, att, h2, gelu(fc1)) - the weight-gradient products read them transposed
+    (``ops.transpose_pairs`` in ``block_backward``); the residual streams, qkv, the attention output / lse, the fc1 pre-activation and the
+    LayerNorm statistics are kept in fp32 as in the f32 mode (LayerNorm / attention / GELU backward read them)."""
+    Fr, N, D = x.shape
+    M = Fr * N
+    x2d = x.view(M, D)
+    at, mlp = blk.attn, blk.mlp
+    h1p, save["mean1"], save["rstd1"] = ops.layernorm_fwd_pairs(x, blk.norm1.weight, blk.norm1.bias, save_stats=True)
+    qkv = ops.linear_fwd_pairs(h1p, weight_planes(at.qkv.weight, 2), at.qkv.bias)["y"]
+    if aux is not None:
+        aux["qkv"] = qkv.view(Fr, N, 3 * D)
+    att, lse, _ = ops.attention_fwd(qkv.view(Fr, N, 3 * D), num_heads, save_lse=True)
+    attp = ops.split_pairs(att.view(M, D))
+    x_mid = ops.linear_fwd_pairs(attp, weight_planes(at.proj.weight, 2), at.proj.bias, residual=x2d)["y"]
+    h2p, save["mean2"], save["rstd2"] = ops.layernorm_fwd_pairs(x_mid, blk.norm2.weight, blk.norm2.bias, save_stats=True)
+    o = ops.linear_fwd_pairs(h2p, weight_planes(mlp.fc1.weight, 2), mlp.fc1.bias, act=1, out_f32=False, out_pairs=True, save_pre=True)
+    x_out = ops.linear_fwd_pairs(o["pairs"], weight_planes(mlp.fc2.weight, 2), mlp.fc2.bias, residual=x_mid)["y"]
+    save.update(x_in=x, h1p=h1p, qkv=qkv, att=att, attp=attp, lse=lse, x_mid=x_mid, h2p=h2p, pre=o["pre"], ap=o["pairs"], pairs=True)
+    return x_out.view(Fr, N, D)
+
+
+def weight_pairs_t(w: torch.Tensor) -> torch.Tensor:
+    """[K, 2 N] fp16 pairs of w^T for an nn.Linear weight w [N, K]: the operand of the data-gradient product in the "f16x3" mode
+    (made per use: only trainable weights have a backward, and those change every step)."""
+    return ops.split_pairs_dual(w.detach())[0]
+
+
+def _bwd_both_pairs(dy: torch.Tensor, w: torch.Tensor, xp: torch.Tensor, gelu_pre: Optional[torch.Tensor] = None, need_dx: bool = True):
+    """(dx, dw, db) of an nn.Linear on pair operands: xp = the layer's input as kept by the forward (row-major pairs [M, 2 K])."""
+    return ops.linear_bwd_pairs(dy, weight_pairs_t(w), ops.transpose_pairs(xp), gelu_pre=gelu_pre, need_dx=need_dx)
 
 
 def _bwd_weight(dy: torch.Tensor, x: torch.Tensor, need_bias: bool = True):
@@ -145,6 +181,20 @@ def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int,
     gradients (two thirds of a block's parameters) exist - the data-parallel exchange sends them while the attention half runs."""
     Fr, N, D = sv["x_in"].shape
     r0, r1 = f0 * N, f1 * N
+    if sv.get("pairs"):   # the "f16x3" mode: the four Linears' backward products on pair operands
+        d_pre, grads[blk.mlp.fc2.weight], grads[blk.mlp.fc2.bias] = _bwd_both_pairs(dx_out, blk.mlp.fc2.weight, sv["ap"][r0:r1], sv["pre"][r0:r1])
+        d_h2, grads[blk.mlp.fc1.weight], grads[blk.mlp.fc1.bias] = _bwd_both_pairs(d_pre, blk.mlp.fc1.weight, sv["h2p"][r0:r1])
+        dx_mid, grads[blk.norm2.weight], grads[blk.norm2.bias] = ops.layernorm_bwd(
+            d_h2, sv["x_mid"][r0:r1], blk.norm2.weight, sv["mean2"][r0:r1], sv["rstd2"][r0:r1], dx_accum=dx_out)
+        if after_mlp is not None:
+            after_mlp()
+        d_att, grads[blk.attn.proj.weight], grads[blk.attn.proj.bias] = _bwd_both_pairs(dx_mid, blk.attn.proj.weight, sv["attp"][r0:r1])
+        dqkv = ops.attention_bwd(sv["qkv"].view(Fr, N, 3 * D)[f0:f1], sv["att"][f0:f1], d_att.view(f1 - f0, N, D), sv["lse"][f0:f1], num_heads)
+        d_h1, grads[blk.attn.qkv.weight], grads[blk.attn.qkv.bias] = _bwd_both_pairs(dqkv.view((f1 - f0) * N, 3 * D), blk.attn.qkv.weight,
+                                                                                       sv["h1p"][r0:r1])
+        dx_in, grads[blk.norm1.weight], grads[blk.norm1.bias] = ops.layernorm_bwd(
+            d_h1, sv["x_in"].view(Fr * N, D)[r0:r1], blk.norm1.weight, sv["mean1"][r0:r1], sv["rstd1"][r0:r1], dx_accum=dx_mid)
+        return dx_in if need_dx else None
     a, pre, h2 = sv["a"][r0:r1], sv["pre"][r0:r1], sv["h2"][r0:r1]
     # x_out = x_mid + fc2(gelu(fc1(ln2(x_mid))))
     d_pre, grads[blk.mlp.fc2.weight], grads[blk.mlp.fc2.bias] = _bwd_both(dx_out, blk.mlp.fc2.weight, a, pre)
@@ -317,8 +367,29 @@ def head_linears(head) -> List[torch.nn.Linear]:
     return [m for m in head if isinstance(m, torch.nn.Linear)]
 
 
+def _head_pairs_ok(lins) -> bool:
+    return ops.pairs() and all(l.weight.shape[0] % 64 == 0 and l.weight.shape[1] % 64 == 0 and l.bias is not None for l in lins)
+
+
 def head_forward(x: torch.Tensor, head, save: Optional[dict] = None) -> torch.Tensor:
     lins = head_linears(head)
+    if _head_pairs_ok(lins):   # the "f16x3" mode: every layer on pair operands; the GELU epilogues write the next layer's operand
+        xp = ops.split_pairs(x.contiguous())
+        acts, pres = [xp], []
+        for i, lin in enumerate(lins):
+            last = i == len(lins) - 1
+            o = ops.linear_fwd_pairs(xp, weight_planes(lin.weight, 2), lin.bias, act=0 if last else 1, out_f32=last, out_pairs=not last,
+                                     save_pre=save is not None and not last)
+            if last:
+                x = o["y"]
+            else:
+                xp = o["pairs"]
+                acts.append(xp)
+                if save is not None:
+                    pres.append(o["pre"])
+        if save is not None:
+            save["acts"], save["pres"], save["pairs"] = acts, pres, True
+        return x
     if save is None and not ops.fine_grained():
         return ops.mlp_head_forward(x, [(lin.weight, lin.bias) for lin in lins])   # tt_mlp_head_forward: one call
     acts = [x]
@@ -341,7 +412,8 @@ def head_backward(dz: torch.Tensor, head, sv: dict, grads) -> torch.Tensor:
     d = dz
     for i in range(len(lins) - 1, -1, -1):
         lin = lins[i]
-        d, grads[lin.weight], grads[lin.bias] = _bwd_both(d, lin.weight, sv["acts"][i], sv["pres"][i - 1] if i > 0 else None)
+        both = _bwd_both_pairs if sv.get("pairs") else _bwd_both
+        d, grads[lin.weight], grads[lin.bias] = both(d, lin.weight, sv["acts"][i], sv["pres"][i - 1] if i > 0 else None)
     return d
 
 

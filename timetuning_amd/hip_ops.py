@@ -852,6 +852,64 @@ def linear_fwd_pairs(xp, wp, bias=None, residual=None, act: int = 0, out_f32: bo
     return dict(y=y, pairs=yp, pre=pre)
 
 
+def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad: Optional[int] = None):
+    """fp32 [R, C] -> (transposed pairs [C, 2 Rpad], row-major pairs [R, 2 C] or None, column sums [C] or None) in ONE pass
+    (tt_split_pairs_dual): what the backward of an nn.Linear needs of its dy."""
+    lib = _lib.load()
+    _chk(x, "x")
+    R, Cc = x.shape
+    rpad = (R + 31) // 32 * 32 if rpad is None else rpad
+    t = torch.empty((Cc, 2 * rpad), dtype=f16, device=x.device)
+    row = torch.empty((R, 2 * Cc), dtype=f16, device=x.device) if want_row else None
+    sums = torch.empty((Cc,), dtype=f32, device=x.device) if want_colsum else None
+    nb = lib.tt_split_pairs_dual_workspace_bytes(R, Cc, rpad) if want_colsum else 0
+    ws = _ws(nb, x.device) if want_colsum else None
+    _lib.check(lib.tt_split_pairs_dual(_p(x), _p(t), _p(row), _p(sums), R, Cc, rpad, _p(ws), nb, _stream()), "tt_split_pairs_dual")
+    return t, row, sums
+
+
+def transpose_pairs(xp, rpad: Optional[int] = None):
+    """pairs [R, 2 C] -> transposed pairs [C, 2 Rpad] (zero beyond R)."""
+    lib = _lib.load()
+    _chk(xp, "xp", f16)
+    R, C2 = xp.shape
+    rpad = (R + 31) // 32 * 32 if rpad is None else rpad
+    t = torch.empty((C2 // 2, 2 * rpad), dtype=f16, device=xp.device)
+    _lib.check(lib.tt_transpose_pairs(_p(xp), _p(t), R, C2 // 2, rpad, _stream()), "tt_transpose_pairs")
+    return t
+
+
+def bwd_pairs_ok(M: int, N: int, K: int) -> bool:
+    """Shapes the pair backward products take (dy [M,N], w [N,K])."""
+    return N % 64 == 0 and K % 64 == 0
+
+
+def linear_bwd_pairs(dy, wT_pairs, xT_pairs, gelu_pre=None, need_bias: bool = True, need_dx: bool = True):
+    """(dx, dw, db) of an nn.Linear on pair operands: dy fp32 [M,N] is split here (ONE pass: transposed pairs for the weight gradient, row
+    pairs for the data gradient, column sums = the bias gradient); wT_pairs [K, 2 N] = the weight transposed in pairs, xT_pairs [K, 2 Mpad] =
+    the layer's input transposed in pairs."""
+    lib = _lib.load()
+    _chk(dy, "dy"); _chk(wT_pairs, "wT_pairs", f16); _chk(xT_pairs, "xT_pairs", f16)
+    M, N = dy.shape
+    K, Mpad = xT_pairs.shape[0], xT_pairs.shape[1] // 2
+    assert wT_pairs.shape == (K, 2 * N) and Mpad >= M, (dy.shape, wT_pairs.shape, xT_pairs.shape)
+    dyT, dy_row, db = split_pairs_dual(dy, want_row=need_dx, want_colsum=need_bias, rpad=Mpad)
+    dw = torch.empty((N, K), dtype=f32, device=dy.device)
+    nb = lib.tt_linear_bwd_weight_pairs_workspace_bytes(N, K, Mpad)
+    ws = _ws(nb, dy.device)
+    e0 = _prof_begin()
+    _lib.check(lib.tt_linear_bwd_weight_pairs(_p(dyT), _p(xT_pairs), _p(dw), N, K, Mpad, _p(ws), nb, _stream()), "tt_linear_bwd_weight_pairs")
+    _prof_end(e0, "PAIRS", N, K, M)
+    dx = None
+    if need_dx:
+        if gelu_pre is not None: _chk(gelu_pre, "gelu_pre")
+        dx = torch.empty((M, K), dtype=f32, device=dy.device)
+        e0 = _prof_begin()
+        _lib.check(lib.tt_linear_bwd_data_pairs(_p(dy_row), _p(wT_pairs), _p(gelu_pre), _p(dx), M, N, K, _stream()), "tt_linear_bwd_data_pairs")
+        _prof_end(e0, "PAIRS", M, K, N)
+    return dx, dw, db
+
+
 def attention_fwd_bf16(qkv, num_heads: int):
     """qkv [F,N,3*D] bf16 -> out [F,N,D] bf16 (N <= 256, head_dim 64)."""
     lib = _lib.load()

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""A/B of tt_linear_fwd_pairs between library builds in one process (tools/build_variant.sh) on the ViT-S/16 and ViT-B/16 block shapes;
+outputs compared bit for bit.  usage: ab_pairs.py libA.so libB.so ..."""
+import ctypes as C, os, statistics, sys, torch
+vp, ll, i32 = C.c_void_p, C.c_longlong, C.c_int
+def load(p):
+    lib = C.CDLL(os.path.abspath(p))
+    lib.tt_linear_fwd_pairs.restype = C.c_int
+    lib.tt_linear_fwd_pairs.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.tt_split_pairs.restype = C.c_int
+    lib.tt_split_pairs.argtypes = [vp, vp, ll, vp]
+    return lib
+libs = [(os.path.basename(p), load(p)) for p in sys.argv[1:]]
+st = torch.cuda.current_stream().cuda_stream
+def split(x):
+    out = torch.empty((x.shape[0], 2 * x.shape[1]), device="cuda", dtype=torch.float16)
+    assert libs[0][1].tt_split_pairs(x.data_ptr(), out.data_ptr(), x.numel(), st) == 0
+    return out
+cases = [(25216, 1152, 384, 0, 0, 0, "qkv"), (25216, 384, 384, 0, 0, 1, "proj"), (25216, 1536, 384, 1, 1, 0, "fc1"), (25216, 384, 1536, 0, 0, 1, "fc2"),
+         (25216, 2304, 768, 0, 0, 0, "B qkv"), (25216, 768, 768, 0, 0, 1, "B proj"), (25216, 3072, 768, 1, 1, 0, "B fc1"), (25216, 768, 3072, 0, 0, 1, "B fc2"),
+         (6304, 1536, 384, 1, 1, 0, "kept fc1"), (6500, 384, 384, 0, 0, 1, "ragged")]
+tot = {n: 0.0 for n, _ in libs}
+for M, N, K, act, po, res, name in cases:
+    x = split(torch.randn(M, K, device="cuda")); w = split(torch.randn(N, K, device="cuda") * 0.05)
+    b = torch.randn(N, device="cuda"); r0 = torch.randn(M, N, device="cuda") if res else None
+    r = r0.clone() if res else None
+    y = r if res else (torch.empty(M, N, device="cuda") if not po else None)
+    yp = torch.empty(M, 2 * N, device="cuda", dtype=torch.float16) if po else None
+    def go(lib):
+        rc = lib.tt_linear_fwd_pairs(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, y.data_ptr() if y is not None else None, None,
+                                     yp.data_ptr() if po else None, M, N, K, act, st)
+        assert rc == 0, rc
+    ts = {n: [] for n, _ in libs}
+    for rd in range(8):
+        for n, lib in libs:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): go(lib)
+            e1.record(); torch.cuda.synchronize()
+            if rd >= 2: ts[n].append(e0.elapsed_time(e1) * 1e2)
+    outs = {}
+    for n, lib in libs:
+        reps = []
+        for _ in range(3):
+            if res: r.copy_(r0)
+            go(lib); torch.cuda.synchronize(); reps.append((y if y is not None else yp).clone())
+        assert all(torch.equal(reps[0], q) for q in reps), f"{n}: run-to-run difference on {name}"
+        outs[n] = reps[0]
+    same = all(torch.equal(outs[n], outs[libs[0][0]]) for n, _ in libs)
+    for n, _ in libs:
+        if name in ("qkv", "proj", "fc1", "fc2"): tot[n] += statistics.median(ts[n])
+    print(f"{name:9s} M={M} N={N} K={K}: " + " | ".join(f"{n} {statistics.median(ts[n]):7.1f}" for n, _ in libs) + f"  us   bits {'equal' if same else 'DIFFER'}", flush=True)
+print("ViT-S/16 block (qkv + proj + fc1 + fc2): " + " | ".join(f"{n} {v:7.1f}" for n, v in tot.items()) + "  us")
