@@ -219,6 +219,12 @@ int tt_linear_fwd_pairs(const void* x_pairs, const void* w_pairs, const float* b
                         void* y_pairs, int M, int N, int K, int act, tt_stream_t stream);
 int tt_linear_fwd_pairs_route(int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int has_y_pairs, int has_pre_out);
 
+/* The fused attention core on pair operands (dino_vision_transformer.py:120-132): qkv [F N][2 x 3 H 64] in pairs (the qkv Linear's y_pairs) ->
+ * any of out_pairs [F N][2 H 64] (the proj Linear's operand), out_f32 [F, N, H 64] and lse [F, H, N] (what tt_attention_bwd recomputes from).
+ * Both products take three fp16 MFMAs per term, as the pair GEMMs do; fp32 scores, softmax and accumulation.  N <= 256, head_dim 64. */
+int tt_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, float* out_f32, float* lse, int F, int N, int H, int head_dim, float scale,
+                           tt_stream_t stream);
+
 /* The backward products of an nn.Linear on pair operands (the "f16x3" mode's backward; autograd of dino_vision_transformer.py:94-103,
  * 115-130 and of the projection head, models.py:915-926):
  *   tt_split_pairs_dual           fp32 [R][C] -> transposed pairs [C][2 Rpad] (rows R..Rpad-1 zero, Rpad % 32 == 0) and, optionally in the

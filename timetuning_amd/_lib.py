@@ -77,6 +77,7 @@ SIGNATURES = {
     "tt_layernorm_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_i, c_vp]),
     "tt_linear_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "tt_linear_fwd_pairs_route": (c_i, [c_i] * 9),
+    "tt_attention_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp]),
     "tt_split_pairs_dual_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_split_pairs_dual": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_transpose_pairs": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp]),

@@ -1,0 +1,241 @@
+// Fused attention forward on fp16-PAIR operands (dino_vision_transformer.py:120-132) - the attention of the fp32-accurate split mode
+// "f16x3" (round 4): qkv [F N][2 x 3 H 64] in pairs as the qkv Linear's epilogue left it (common.hpp split_pair: groups of 32 columns as
+// [hi x 32][lo x 32] fp16, a head's 64 dims = 256 contiguous bytes) -> the attention output in pairs [F N][2 H 64] (the proj Linear's
+// operand) and / or in fp32 (+ the log-sum-exp rows the backward recomputes from).  N <= 256, head_dim 64.
+//
+// Both matrix products take three v_mfma_f32_32x32x16_f16 per term, as the pair GEMMs do (gemm_pairs8.hip): S = K Q^T as kh qh into one
+// accumulator and kh ql + kl qh into a second one, folded with the exact 2^-11 per key tile; the probabilities p = 2^(s c - m c) in (0, 1] are
+// split into (hi, lo) on their way into O^T = V^T P^T, which runs the same way.  fp32 scores, softmax statistics and accumulation.
+//
+// Structure: that of attention_bf16.hip - ONE 8-wave workgroup per (frame, head); K and V of that head go HBM -> LDS once, by LDS-DMA, and stay:
+//   K image  [key][256 B]: 16-byte chunks XOR-swizzled by key & 15 -> conflict-free ds_read_b128 A fragments (rows of 256 B are whole bank rows)
+//   V image  [key][256 B]: the four 64-byte quarters (hi / lo of dims 0-31, 32-63) XOR-swizzled by key & 3 -> conflict-free
+//            ds_read_b64_tr_b16: V stays row-major (coalesced DMA) and is consumed transposed, as V^T fragments.
+// A wave owns one 32-query tile (7 of the 8 waves work at 197 tokens).  S^T = K Q^T puts a query's score row in one lane column (2 lanes):
+// register-local softmax plus one cross-half exchange, and P^T is the B operand of the second product as it stands (the accumulator-as-operand
+// map of the 32 x 32 C layout: element j of lane half h of k-step s is key 16 s + 8 (j >> 2) + 4 h + (j & 3)); the V^T fragments are gathered
+// in that key order by transposed LDS reads.  Keys >= N are clamped on load and masked to -inf.
+#include "common.hpp"
+
+namespace tt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int NKT>
+__global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out_pairs,
+                                                                  float* __restrict__ out_f32, float* __restrict__ lse, int N, int H, float scale) {
+  constexpr int KROWS = NKT * 32;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KROWS * 256 + 8 * 4096];
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + KROWS * 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* Os = smem + 2 * KROWS * 256 + wave * 4096;   // this wave's output staging: 32 queries x 128 B
+  const int r = lane & 31, h = lane >> 5;
+  const int fh = blockIdx.x, f = fh / H, hd = fh - f * H;
+  const int Dm = H * 64;
+  const long long RS = 6ll * Dm;                                // fp16 elements per qkv row (2 x 3 D)
+  const _Float16* base = qkv + (long long)f * N * RS + hd * 128;   // q of this head; k: + 2 Dm, v: + 4 Dm
+
+  // ---- K and V: 4 keys x 256 B per DMA piece; lane -> (key, slot of 16), source chunk = slot ^ swizzle(key)
+  {
+    const int l_row = lane >> 4, l_slot = lane & 15;
+    for (int piece = wave; piece < KROWS / 4; piece += 8) {
+      const int key = piece * 4 + l_row;
+      const int krow = key < N ? key : N - 1;
+      const _Float16* src = base + (long long)krow * RS;
+      const int kc = l_slot ^ (key & 15);
+      const int vc = l_slot ^ ((key & 3) << 2);
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + 2 * Dm + kc * 8),
+                                       (void __attribute__((address_space(3)))*)(Ks + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + 4 * Dm + vc * 8),
+                                       (void __attribute__((address_space(3)))*)(Vs + piece * 1024), 16, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  const int nqt = (N + 31) / 32;   // <= 8: one query tile per wave, no loop (a loop lets the compiler hoist - and spill - a hundred loop invariants)
+  const int qt = wave;
+  if (qt < nqt) {
+    // Q fragments (B operand): lane (query r, half h) holds Q[query][16 ks + 8 h + j], hi and lo
+    const int query = qt * 32 + r;
+    const int qrow = query < N ? query : N - 1;
+    f16x8 qh[4], ql[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const _Float16* p = base + (long long)qrow * RS + (ks >> 1) * 64 + (ks & 1) * 16 + 8 * h;
+      qh[ks] = *reinterpret_cast<const f16x8*>(p);
+      ql[ks] = *reinterpret_cast<const f16x8*>(p + 32);
+    }
+
+    // K fragment addresses: row kt * 32 + r -> a per-lane base (r) + an immediate (kt); the swizzle term depends on r & 15 only
+    int kofs[8];   // [ks] hi, [4 + ks] lo
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int ch = (ks >> 1) * 8 + 2 * (ks & 1) + h;   // chunk of the hi half of this k-step; lo: + 4
+      kofs[ks] = r * 256 + ((ch ^ (r & 15)) << 4);
+      kofs[4 + ks] = r * 256 + (((ch + 4) ^ (r & 15)) << 4);
+    }
+    f32x16 sacc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x16 s1, s2;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f16x8 kfh = *reinterpret_cast<const f16x8*>(Ks + kt * 8192 + kofs[ks]);
+        const f16x8 kfl = *reinterpret_cast<const f16x8*>(Ks + kt * 8192 + kofs[4 + ks]);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, qh[ks], s1, 0, 0, 0);
+        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, ql[ks], s2, 0, 0, 0);
+        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl, qh[ks], s2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[kt][e] = fmaf(s2[e], kPairInvScale, s1[e]);
+      __builtin_amdgcn_sched_barrier(0);   // one key tile at a time: the compiler otherwise hoists the next tiles' reads and spills
+    }
+    // softmax over the keys of this lane column (attention_bf16.hip): p = 2^(s c - m c), c = scale log2(e)
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+      if (kt * 32 + 31 >= N) {   // (uniform) a key tile that reaches past N: masked to -inf before the max
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= N) sacc[kt][e] = -INFINITY;
+        }
+      }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float c = scale * 1.44269504088896340736f;
+    const float mc = mx * c;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], c, -mc));
+        sacc[kt][e] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    if (lse && h == 0 && query < N) lse[((long long)f * H + hd) * N + query] = (mc + __log2f(sum)) * 0.69314718055994530942f;   // natural-log units
+
+    // the probabilities as MFMA operands: P^T is the B operand of O^T = V^T P^T as it stands (k-step s of key tile kt = registers 8 s .. 8 s + 7),
+    // split into (hi, lo) once - the scores' registers are dead from here on
+    f16x8 ph[NKT][2], pl[NKT][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          _Float16 hi_, lo_;
+          split_pair(sacc[kt][8 * s + j], hi_, lo_);
+          ph[kt][s][j] = hi_;
+          pl[kt][s][j] = lo_;
+        }
+    const int g16 = (lane >> 4) & 1, q4 = (lane >> 2) & 3, p4 = lane & 3;   // position inside the 16-lane transpose group
+    // V^T gather addresses: block rows = keys key0 .. key0 + 3 (this lane supplies row q4), block columns = 16 dims of one 64-byte quarter
+    // (hi or lo of a 32-dim group).  key0 = kt * 32 + 16 s + 4 h (+ 8) is a multiple of 4, so the quarter swizzle is q4 for every block:
+    // four per-lane bases (quarter) + immediates (kt, s, the + 8 keys).
+    int vofs[4];   // [2 dt + plane]
+#pragma unroll
+    for (int qn = 0; qn < 4; ++qn) vofs[qn] = (4 * h + q4) * 256 + ((qn ^ q4) << 6) + (16 * g16 + 4 * p4) * 2;
+    const int c8 = lane & 7;
+    // O^T [64 d x 32 queries] = V^T P^T, three products per term; one 32-dim group (dt) at a time
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      f32x16 o1, o2;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { o1[e] = 0.f; o2[e] = 0.f; }
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const unsigned char* vrow = Vs + (kt * 32 + 16 * s) * 256;
+          union { s16x4 s2[2]; f16x8 v; } vh, vl;
+          vh.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + vofs[2 * dt]));
+          vh.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + 2048 + vofs[2 * dt]));
+          vl.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + vofs[2 * dt + 1]));
+          vl.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + 2048 + vofs[2 * dt + 1]));
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[kt][s], o1, 0, 0, 0);
+          o2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[kt][s], o2, 0, 0, 0);
+          o2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[kt][s], o2, 0, 0, 0);
+        }
+      }
+      // The output tile leaves through the wave's private LDS scratch so that a store instruction writes eight whole 128-byte rows (16 B
+      // per lane): this 32-dim group as pairs [hi x 32][lo x 32] and / or as 32 floats.  Chunk c of row q sits at c ^ (q & 7).
+      float o[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[e] = fmaf(o2[e], kPairInvScale, o1[e]) * inv;   // d = (e & 3) + 8 (e >> 2) + 4 h of this group
+      if (out_pairs) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f16x4 vh4, vl4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            _Float16 hi_, lo_;
+            split_pair(o[4 * g4 + e], hi_, lo_);
+            vh4[e] = hi_;
+            vl4[e] = lo_;
+          }
+          // dims 8 g4 + 4 h .. + 3: hi at byte 16 g4 + 8 h, lo 64 bytes on
+          *reinterpret_cast<f16x4*>(Os + r * 128 + ((g4 ^ (r & 7)) << 4) + 8 * h) = vh4;
+          *reinterpret_cast<f16x4*>(Os + r * 128 + (((4 + g4) ^ (r & 7)) << 4) + 8 * h) = vl4;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (lane >> 3) + 8 * i;
+          const f16x8 v = *reinterpret_cast<const f16x8*>(Os + row * 128 + ((c8 ^ (row & 7)) << 4));
+          const int q = qt * 32 + row;
+          if (q < N) *reinterpret_cast<f16x8*>(out_pairs + ((long long)f * N + q) * (2 * Dm) + hd * 128 + dt * 64 + 8 * c8) = v;
+        }
+      }
+      if (out_f32) {
+        // fp32 [32 queries][32 dims]: dims 8 g4 + 4 h .. + 3 = 16-byte chunk 2 g4 + h
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 v = {o[4 * g4], o[4 * g4 + 1], o[4 * g4 + 2], o[4 * g4 + 3]};
+          *reinterpret_cast<f32x4*>(Os + r * 128 + (((2 * g4 + h) ^ (r & 7)) << 4)) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (lane >> 3) + 8 * i;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(Os + row * 128 + ((c8 ^ (row & 7)) << 4));
+          const int q = qt * 32 + row;
+          if (q < N) *reinterpret_cast<f32x4*>(out_f32 + ((long long)f * N + q) * Dm + hd * 64 + dt * 32 + 4 * c8) = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" int tt_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, float* out_f32, float* lse, int F, int N, int H, int head_dim,
+                                      float scale, tt_stream_t stream) {
+  TT_REQUIRE(qkv_pairs && (out_pairs || out_f32), "attention_fwd_pairs: null input / no output");
+  TT_REQUIRE(F > 0 && N > 0 && H > 0 && scale > 0.f, "attention_fwd_pairs: bad shape / non-positive scale");
+  TT_REQUIRE(head_dim == 64, "attention_fwd_pairs: head_dim must be 64 (got %d)", head_dim);
+  TT_REQUIRE(N <= 256, "attention_fwd_pairs: N <= 256 tokens (got %d); longer sequences use the fp32 kernel", N);
+  TT_REQUIRE(aligned16(qkv_pairs) && (!out_pairs || aligned16(out_pairs)) && (!out_f32 || aligned16(out_f32)),
+             "attention_fwd_pairs: buffers must be 16-byte aligned");
+  hipStream_t s = as_stream(stream);
+  const _Float16* q = static_cast<const _Float16*>(qkv_pairs);
+  _Float16* o = static_cast<_Float16*>(out_pairs);
+  if (N <= 224) hipLaunchKernelGGL((attention_fwd_pairs_kernel<7>), dim3(F * H), dim3(512), 0, s, q, o, out_f32, lse, N, H, scale);
+  else hipLaunchKernelGGL((attention_fwd_pairs_kernel<8>), dim3(F * H), dim3(512), 0, s, q, o, out_f32, lse, N, H, scale);
+  TT_CHECK_LAUNCH("attention_fwd_pairs");
+  return TT_OK;
+}

@@ -60,11 +60,17 @@ def block_forward_planes(x: torch.Tensor, blk, num_heads: int, planes: int, aux:
     at = blk.attn
     if planes == 2:   # fp16 pairs ("f16x3"): LayerNorm and the fc1 epilogue write pairs, the fp32 attention's output is split for proj
         h1 = ops.layernorm_fwd_pairs(x, blk.norm1.weight, blk.norm1.bias)
-        qkv = ops.linear_fwd_pairs(h1, weight_planes(at.qkv.weight, 2), at.qkv.bias)["y"]
-        if aux is not None:
-            aux["qkv"] = qkv.view(Fr, N, 3 * D)
-        att32, _, _ = ops.attention_fwd(qkv.view(Fr, N, 3 * D), num_heads)
-        ops.linear_fwd_pairs(ops.split_pairs(att32.view(M, D)), weight_planes(at.proj.weight, 2), at.proj.bias, residual=x2d, out=x2d)
+        if aux is None and ops.attention_pairs_ok(N, D // num_heads):
+            # qkv never exists in fp32: the qkv epilogue writes pairs, the pair attention kernel reads them and writes proj's operand
+            qkvp = ops.linear_fwd_pairs(h1, weight_planes(at.qkv.weight, 2), at.qkv.bias, out_f32=False, out_pairs=True)["pairs"]
+            attp = ops.attention_fwd_pairs(qkvp.view(Fr, N, 6 * D), num_heads)[0].view(M, 2 * D)
+        else:
+            qkv = ops.linear_fwd_pairs(h1, weight_planes(at.qkv.weight, 2), at.qkv.bias)["y"]
+            if aux is not None:
+                aux["qkv"] = qkv.view(Fr, N, 3 * D)
+            att32, _, _ = ops.attention_fwd(qkv.view(Fr, N, 3 * D), num_heads)
+            attp = ops.split_pairs(att32.view(M, D))
+        ops.linear_fwd_pairs(attp, weight_planes(at.proj.weight, 2), at.proj.bias, residual=x2d, out=x2d)
         h2 = ops.layernorm_fwd_pairs(x, blk.norm2.weight, blk.norm2.bias)
         a = ops.linear_fwd_pairs(h2, weight_planes(blk.mlp.fc1.weight, 2), blk.mlp.fc1.bias, act=1, out_f32=False, out_pairs=True)["pairs"]
         ops.linear_fwd_pairs(a, weight_planes(blk.mlp.fc2.weight, 2), blk.mlp.fc2.bias, residual=x2d, out=x2d)
@@ -129,11 +135,19 @@ def block_forward_pairs_kept(x: torch.Tensor, blk, num_heads: int, save: dict, a
     x2d = x.view(M, D)
     at, mlp = blk.attn, blk.mlp
     h1p, save["mean1"], save["rstd1"] = ops.layernorm_fwd_pairs(x, blk.norm1.weight, blk.norm1.bias, save_stats=True)
-    qkv = ops.linear_fwd_pairs(h1p, weight_planes(at.qkv.weight, 2), at.qkv.bias)["y"]
+    if ops.attention_pairs_ok(N, D // num_heads):
+        # qkv leaves the Linear in fp32 (the attention backward reads it) AND in pairs (the pair attention kernel's operand); the attention
+        # writes its output in pairs (proj's operand) and in fp32 + lse (the backward's)
+        o = ops.linear_fwd_pairs(h1p, weight_planes(at.qkv.weight, 2), at.qkv.bias, out_pairs=True)
+        qkv = o["y"]
+        attp, att, lse = ops.attention_fwd_pairs(o["pairs"].view(Fr, N, 6 * D), num_heads, out_f32=True, save_lse=True)
+        attp = attp.view(M, 2 * D)
+    else:
+        qkv = ops.linear_fwd_pairs(h1p, weight_planes(at.qkv.weight, 2), at.qkv.bias)["y"]
+        att, lse, _ = ops.attention_fwd(qkv.view(Fr, N, 3 * D), num_heads, save_lse=True)
+        attp = ops.split_pairs(att.view(M, D))
     if aux is not None:
         aux["qkv"] = qkv.view(Fr, N, 3 * D)
-    att, lse, _ = ops.attention_fwd(qkv.view(Fr, N, 3 * D), num_heads, save_lse=True)
-    attp = ops.split_pairs(att.view(M, D))
     x_mid = ops.linear_fwd_pairs(attp, weight_planes(at.proj.weight, 2), at.proj.bias, residual=x2d)["y"]
     h2p, save["mean2"], save["rstd2"] = ops.layernorm_fwd_pairs(x_mid, blk.norm2.weight, blk.norm2.bias, save_stats=True)
     o = ops.linear_fwd_pairs(h2p, weight_planes(mlp.fc1.weight, 2), mlp.fc1.bias, act=1, out_f32=False, out_pairs=True, save_pre=True)

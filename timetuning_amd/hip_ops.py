@@ -852,6 +852,26 @@ def linear_fwd_pairs(xp, wp, bias=None, residual=None, act: int = 0, out_f32: bo
     return dict(y=y, pairs=yp, pre=pre)
 
 
+def attention_pairs_ok(N: int, head_dim: int) -> bool:
+    """Shapes ``attention_fwd_pairs`` takes."""
+    return N <= 256 and head_dim == 64
+
+
+def attention_fwd_pairs(qkv_pairs, num_heads: int, out_pairs: bool = True, out_f32: bool = False, save_lse: bool = False):
+    """qkv [F, N, 2 * 3D] fp16 pairs -> (out pairs [F, N, 2 D] or None, out fp32 [F, N, D] or None, lse [F, H, N] or None)."""
+    lib = _lib.load()
+    _chk(qkv_pairs, "qkv_pairs", f16)
+    F, N, D6 = qkv_pairs.shape
+    D = D6 // 6
+    hd = D // num_heads
+    op = torch.empty((F, N, 2 * D), dtype=f16, device=qkv_pairs.device) if out_pairs else None
+    of = torch.empty((F, N, D), dtype=f32, device=qkv_pairs.device) if out_f32 else None
+    lse = torch.empty((F, num_heads, N), dtype=f32, device=qkv_pairs.device) if save_lse else None
+    _lib.check(lib.tt_attention_fwd_pairs(_p(qkv_pairs), _p(op), _p(of), _p(lse), F, N, num_heads, hd, float(hd ** -0.5), _stream()),
+               "tt_attention_fwd_pairs")
+    return op, of, lse
+
+
 def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad: Optional[int] = None):
     """fp32 [R, C] -> (transposed pairs [C, 2 Rpad], row-major pairs [R, 2 C] or None, column sums [C] or None) in ONE pass
     (tt_split_pairs_dual): what the backward of an nn.Linear needs of its dy."""
