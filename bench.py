@@ -12,8 +12,13 @@ A step = one full training iteration of BASELINE.json configs[1] (C2): ViT-S/16,
 prototype renormalisation.  Synthetic clips and random-init weights (portable generator), resident in HBM before the
 timed region.  Prints ONE JSON line on rank 0:
   metric/value   clip-frames/sec, whole job (N GPUs x 32 clips x 4 frames per step), weak scaling
-  roofline       the dominant kernel (fp32-MFMA GEMM instantiation with the largest share): algorithmic flops of its
-                 launches in one instrumented step / their HIP-event durations, against the 157.3 TFLOP/s f32 matrix peak
+  dtype          the arithmetic of the timed step.  Default (round 4): "f32-split(f16x3)" - every nn.Linear and attention product of the
+                 step on fp16-pair operands, three fp16 MFMAs per term into fp32 accumulators, per-op error at or under the exact-f32
+                 MFMA kernels' own (tests/test_hip_pairs.py) and every golden / oracle test at unchanged fp32 tolerances; the exact-f32
+                 MFMA step ("f32", rounds 1-3's headline) is reported beside it under ``alt_precision`` with its own roofline block.
+  roofline       the dominant GEMM kernel (largest time share): algorithmic flops of its launches in one instrumented step / their
+                 HIP-event durations, against the peak of the arithmetic it runs in (2.5 PFLOP/s dense fp16 MFMA / 3 products per term
+                 = 833 TFLOP/s for the pair kernels; 157.3 TFLOP/s for the f32 MFMA kernels)
   cpu_baseline   the CPU oracle (reference-faithful structure) timed on this host's cores on a bounded sample
 """
 from __future__ import annotations
@@ -34,6 +39,7 @@ F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 TILE_NAMES = {0: "128x128", 1: "64x128", 2: "128x64", 3: "64x64"}
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense v_mfma_f32_32x32x16_bf16 (MI355X_MICROARCH.md)
 ALT_NOTES = {
+    "f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32) on every matrix product: the headline of rounds 1-3",
     "f16x3": "fp32-accurate split mode: operands pre-split into fp16 pairs (hi, lo x 2^11), 3 fp16 MFMAs per product term (nominal peak "
              f"{BF16_MATRIX_PEAK_TFLOPS / 3:.0f} TFLOP/s); per-op error under the f32-MFMA kernels' own; same fp32 tolerances in the parity tests",
     "bf16x6": "fp32-accurate split mode: operands pre-split into 3 bf16 planes, 6 bf16 MFMAs per product term (nominal peak "
@@ -86,8 +92,12 @@ def train_step(model, opt, x, use_teacher):
     return loss
 
 
+DTYPE_NAMES = {"f16x3": "f32-split(f16x3)", "bf16x6": "f32-split(bf16x6)"}   # (the other modes are named by their mode string)
+
+
 def instrumented_step(model, opt, x, use_teacher):
-    """One more identical step with every GEMM launch bracketed by HIP events on the launch stream."""
+    """One more identical step with every GEMM launch bracketed by HIP events on the launch stream.  Returns ({(kernel, tile): [launches,
+    flops, seconds]}, [the compute stream's waits on collectives in THAT step])."""
     from timetuning_amd import hip_ops
 
     from timetuning_amd import engine
@@ -101,14 +111,14 @@ def instrumented_step(model, opt, x, use_teacher):
     finally:
         hip_ops.PROFILE = None
         waits, engine.RCCL_PROFILE = engine.RCCL_PROFILE, None
-    instrumented_step.rccl = [{"collective": k, "bytes": n, "exposed_wait_ms": round(e0.elapsed_time(e1), 4)} for k, n, e0, e1 in waits]
+    rccl = [{"collective": k, "bytes": n, "exposed_wait_ms": round(e0.elapsed_time(e1), 4)} for k, n, e0, e1 in waits]
     by = {}
     for name, tile, flops, e0, e1 in rec:
         d = by.setdefault((name, tile), [0, 0.0, 0.0])
         d[0] += 1
         d[1] += flops
         d[2] += e0.elapsed_time(e1) * 1e-3
-    return by
+    return by, rccl
 
 
 def by_label(prof, step_seconds):
@@ -162,8 +172,8 @@ def single_rank_exchange_probe_child(a):
     for _ in range(3):
         train_step(model, opt, x, a.use_teacher)
     torch.cuda.synchronize()
-    instrumented_step(model, opt, x, a.use_teacher)
-    out = rccl_report(dist, instrumented_step.rccl)
+    _, waits = instrumented_step(model, opt, x, a.use_teacher)
+    out = rccl_report(dist, waits)
     t0 = time.perf_counter()
     for _ in range(5):
         train_step(model, opt, x, a.use_teacher)
@@ -195,28 +205,38 @@ def single_rank_exchange_probe(argv, timeout_s=240):
     return json.loads(lines[-1])
 
 
+PEAK_BY_KERNEL = {"PLANES1": BF16_MATRIX_PEAK_TFLOPS, "PLANES2": BF16_MATRIX_PEAK_TFLOPS / 3, "PLANES3": BF16_MATRIX_PEAK_TFLOPS / 6,
+                  "PLANES8_1": BF16_MATRIX_PEAK_TFLOPS, "PLANES8_3": BF16_MATRIX_PEAK_TFLOPS / 6,
+                  "PAIRS8": BF16_MATRIX_PEAK_TFLOPS / 3, "PAIRS": BF16_MATRIX_PEAK_TFLOPS / 3}
+
+
 def roofline_block(prof, step_seconds, precision):
-    """The `roofline` object of a line: the GEMM instantiation with the largest time share of the instrumented step, its algorithmic
-    flops / its HIP-event durations, against the peak of the arithmetic it runs in."""
-    (dom_name, dom_tile), (cnt, flops, sec) = max(prof.items(), key=lambda kv: kv[1][2])
+    """The `roofline` object of a line: the GEMM kernel with the largest time share of the instrumented step - keyed by kernel LABEL, the
+    same keying as ``by_kernel`` (tile variants of one kernel are one entry in both) - its algorithmic flops / its HIP-event durations,
+    against the peak of the arithmetic it runs in."""
+    acc = {}
+    for (nm, tl), (c_, f_, s_) in prof.items():
+        d = acc.setdefault(kernel_label(nm, tl), [0, 0.0, 0.0, nm])
+        d[0] += c_
+        d[1] += f_
+        d[2] += s_
+    dom_label, (cnt, flops, sec, dom_name) = max(acc.items(), key=lambda kv: kv[1][2])
     all_flops = sum(v[1] for v in prof.values())
     all_sec = sum(v[2] for v in prof.values())
-    # peak the dominant kernel is priced against: dense f32 MFMA, or dense bf16 MFMA / the MFMAs it issues per product term
-    peak = {"PLANES1": BF16_MATRIX_PEAK_TFLOPS, "PLANES2": BF16_MATRIX_PEAK_TFLOPS / 3, "PLANES3": BF16_MATRIX_PEAK_TFLOPS / 6,
-            "PLANES8_1": BF16_MATRIX_PEAK_TFLOPS, "PLANES8_3": BF16_MATRIX_PEAK_TFLOPS / 6,
-            "PAIRS8": BF16_MATRIX_PEAK_TFLOPS / 3, "PAIRS": BF16_MATRIX_PEAK_TFLOPS / 3,
-            "NTbf16": BF16_MATRIX_PEAK_TFLOPS / (3 if precision == "bf16x3" else 1)}.get(dom_name, F32_MATRIX_PEAK_TFLOPS)
+    # peak the dominant kernel is priced against: dense f32 MFMA, or dense 16-bit MFMA / the MFMAs it issues per product term
+    peak = PEAK_BY_KERNEL.get(dom_name, BF16_MATRIX_PEAK_TFLOPS / 3 if (dom_name == "NTbf16" and precision == "bf16x3") else
+                              BF16_MATRIX_PEAK_TFLOPS if dom_name == "NTbf16" else F32_MATRIX_PEAK_TFLOPS)
     # HBM bytes per launch of the dominant kernel from the committed PMC pass (tools/pmc_traffic.py) - only when that pass
     # measured THIS kernel
     traffic = traffic_git_head = None
     tpath = os.path.join(REPO, "profiles", "dominant_kernel_traffic.json")
     if os.path.isfile(tpath):
         tj = json.load(open(tpath))
-        if tj.get("kernel_label", "gemm_nt_fast_kernel<64x128>") in kernel_label(dom_name, dom_tile):
+        if tj.get("kernel_label", "gemm_nt_fast_kernel<64x128>") in dom_label:
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_git_head = tj.get("git_head")
-    return {"bound": "mfma", "precision": precision,
-            "kernel": kernel_label(dom_name, dom_tile), "launches_per_step": cnt,
+    return {"bound": "mfma", "precision": DTYPE_NAMES.get(precision, precision),
+            "kernel": dom_label, "launches_per_step": cnt,
             "achieved": round(flops / sec / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(flops / sec / 1e12 / peak, 4), "traffic": traffic,
             # NOT a counter of this run: HBM bytes per launch of this kernel from the committed PMC passes
@@ -225,7 +245,7 @@ def roofline_block(prof, step_seconds, precision):
             "avg_launch_us": round(sec / cnt * 1e6, 2),
             "all_gemm_tflops": round(all_flops / all_sec / 1e12, 2),
             "gemm_share_of_step": round(all_sec / step_seconds, 3),
-            # every GEMM family of the step (forward Linears, dgrad "NN", wgrad "TN", patch embed, plane kernels): launches,
+            # every GEMM family of the step (forward Linears, dgrad / wgrad, patch embed, plane / pair kernels): launches,
             # achieved TFLOP/s on algorithmic flops, share of the step - the dominant one is the roofline kernel above
             "by_kernel": by_label(prof, step_seconds)}
 
@@ -276,14 +296,15 @@ def cpu_baseline(fs, K, budget_s=30.0, arch="dino-s16", precision="f32"):
         from timetuning_amd import hip_ops
 
         gm = build_model(arch, K, torch.device("cuda", 0))
+        before = hip_ops.get_gemm_precision()
         hip_ops.set_gemm_precision(precision)
         try:
             gf, _ = gm.feature_extractor(flat.cuda())
             gsc = gm.get_feature_prototype_similarity(gf.reshape(-1, gf.shape[-1]))
         finally:
-            hip_ops.set_gemm_precision("f32")
+            hip_ops.set_gemm_precision(before)
         rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
-        parity = {"patch_embeddings_rel_err": rel(gf.cpu(), of), "assignment_logits_rel_err": rel(gsc.cpu(), osc), "gpu_precision": precision,
+        parity = {"patch_embeddings_rel_err": rel(gf.cpu(), of), "assignment_logits_rel_err": rel(gsc.cpu(), osc), "gpu_precision": DTYPE_NAMES.get(precision, precision),
                   "bound": 1e-3 if precision in ("f32", "f16x3", "bf16x6", "bf16x3") else None}
         del gm, gf, gsc
         # the second half of the metric on the host: the reference's Sinkhorn (my_utils.py:246-274) at the C2 shape
@@ -399,10 +420,11 @@ def main():
     ap.add_argument("--queue_size", type=int, default=16384, help="global queue rows (the reference's default); each rank holds queue_size // world")
     ap.add_argument("--use_mask", action="store_true", help="time the --use_mask variant (attention foreground masks) instead")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3", "bf16x6", "bf16x3", "bf16"],
-                    help="arithmetic of the forward Linears for the TIMED region (default f32 = the headline / parity mode; "
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32", "bf16x6", "bf16x3", "bf16"],
+                    help="arithmetic of the matrix products of the TIMED region (default f16x3 = the fp32-accurate split mode: per-op error "
+                         "under the f32-MFMA kernels' own, every parity test at fp32 tolerances; f32 = exact fp32 MFMA; "
                          "hip_ops.set_gemm_precision documents the others)")
-    ap.add_argument("--no_alt_precision", action="store_true", help="skip the secondary bf16x3 / bf16 measurements")
+    ap.add_argument("--no_alt_precision", action="store_true", help="skip the secondary measurements in the other precision modes")
     ap.add_argument("--no_exchange_probe", action="store_true", help="skip the one-rank RCCL probe of the exchange path (1-GPU runs)")
     ap.add_argument("--exchange_probe_child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
@@ -483,12 +505,12 @@ def main():
 
     out = None
     # the instrumented step contains the step's collectives (score all-gather, gradient all-reduce): EVERY rank runs it
-    prof = instrumented_step(model, opt, x, a.use_teacher)
-    # secondary, clearly-labelled measurements of the opt-in bf16 MFMA modes (same step, forward Linears only change);
-    # `value` above is always the --precision mode (f32 by default).  Every rank takes part (collectives).
+    prof, headline_waits = instrumented_step(model, opt, x, a.use_teacher)
+    # secondary, clearly-labelled measurements of the other arithmetic modes (same step); `value` above is always the --precision
+    # mode.  Every rank takes part (collectives).  The exact-f32 line and the other fp32-accurate split carry their own roofline blocks.
     alt = {}
-    if a.precision == "f32" and not a.no_alt_precision:
-        for mode in ("bf16x6", "bf16x3", "bf16"):
+    if a.precision in ("f16x3", "f32") and not a.no_alt_precision:
+        for mode in [m for m in ("f32", "f16x3", "bf16x6", "bf16") if m != a.precision]:
             hip_ops.set_gemm_precision(mode)
             for _ in range(2):
                 train_step(model, opt, x, a.use_teacher)
@@ -507,12 +529,12 @@ def main():
                 dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
                 dt = float(tt_.item())
             alt[mode] = {"clip_frames_per_sec": round(world * bs * fs * 5 / dt, 1), "ms_per_step": round(dt / 5 * 1e3, 3), "loss": round(float(la.item()), 5),
-                         "note": ALT_NOTES[mode]}
-            if mode == "bf16x6":   # the fp32-accurate mode carries its own roofline block (its dominant kernel is the plane GEMM)
-                aprof = instrumented_step(model, opt, x, a.use_teacher)
+                         "dtype": DTYPE_NAMES.get(mode, mode), "note": ALT_NOTES[mode]}
+            if mode in ("f32", "f16x3", "bf16x6"):
+                aprof, _ = instrumented_step(model, opt, x, a.use_teacher)
                 if rank == 0:
                     alt[mode]["roofline"] = roofline_block(aprof, dt / 5, mode)
-        hip_ops.set_gemm_precision("f32")
+        hip_ops.set_gemm_precision(a.precision)
     if rank == 0:
         roof = roofline_block(prof, elapsed / a.steps, a.precision)
         sk_rate, sk_gbs, sk_swept = sinkhorn_rate(device) if world == 1 else (None, None, None)
@@ -523,7 +545,7 @@ def main():
         out = {
             "metric": "clip-frames/sec", "value": round(world * bs * fs * a.steps / elapsed, 2), "unit": "clip-frames/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAMES.get(a.precision, a.precision), "data": "synthetic",
             "config": {"workload": workload + f"{a.architecture} full TimeT training step (fwd+bwd+AdamW), {fs}-frame 224x224 clips, {bs} clips/GPU, "
                                    f"{K} prototypes" + (", EMA teacher" if a.use_teacher else "") + (f", queue {a.queue_size // world} rows/rank" if a.use_queue else "") +
                                    (", use_mask" if a.use_mask else ""),
@@ -532,7 +554,7 @@ def main():
             "loss": round(final_loss, 5),
             # proof of what carried the exchange: RCCL ("nccl") saw this many ranks (None for the single-process run)
             # with the compute stream's exposed wait per collective in the instrumented step
-            "rccl": rccl_report(dist, instrumented_step.rccl) if world > 1 else None,
+            "rccl": rccl_report(dist, headline_waits) if world > 1 else None,
             "roofline": roof,
             "alt_precision": alt or None,
             "sinkhorn": None if sk_rate is None else {"iters_per_sec": round(sk_rate, 1), "algorithmic_GBps": round(sk_gbs, 1),

@@ -34,7 +34,7 @@ extern "C" {
 typedef void* tt_stream_t;
 
 const char* tt_last_error(void);
-int tt_abi_version(void);   /* 4 = this header (3: before tt_vit_params.patch_wp; 2: before the coarse entry points) */
+int tt_abi_version(void);   /* 5 = this header (4: before the fp16-pair entry points; 3: before tt_vit_params.patch_wp; 2: before the coarse entry points) */
 /* Fills name (<= cap bytes) with the gcnArchName of the current device; returns CU count or <0. */
 int tt_device_info(char* name, int cap);
 

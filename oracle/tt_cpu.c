@@ -837,6 +837,180 @@ typedef struct {
 } tt_cpu_vit_params;
 typedef struct { const float* w; const float* b; int out_features, in_features; } tt_cpu_linear_params;
 
+/* ---- fp16 PAIRS (round 4, the "f16x3" mode): x -> hi = fp16(x), lo = fp16((x - hi) * 2^11), groups of 32 elements as [hi x 32][lo x 32].
+ *      gcc 11 has no _Float16 on x86-64: round-to-nearest-even conversions by hand (subnormals kept, overflow to infinity). */
+static uint16_t tt_cpu_f16(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+  const uint32_t a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);              /* NaN */
+  if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);             /* >= 65520 (incl. inf): rounds to infinity */
+  if (a < 0x33000001u) return sign;                                    /* <= 2^-25: rounds to zero (a tie at 2^-25 goes to even = 0) */
+  const int e = (int)(a >> 23) - 127;
+  uint32_t m = (a & 0x7fffffu) | 0x800000u;                            /* 24-bit significand */
+  int shift = e < -14 ? 13 + (-14 - e) : 13;                           /* bits to drop: 13 for normals, more for subnormals */
+  uint32_t q = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+  if (rem > halfway || (rem == halfway && (q & 1u))) ++q;
+  uint32_t h;
+  if (e < -14) h = q;                                                  /* subnormal (a carry into 0x400 is the smallest normal) */
+  else h = ((uint32_t)(e + 15) << 10) + (q - 0x400u);                  /* a carry out of the significand bumps the exponent */
+  return (uint16_t)(sign | h);
+}
+static float tt_cpu_f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  float v;
+  if (e == 0) v = ldexpf((float)m, -24);
+  else if (e == 31) v = m ? NAN : INFINITY;
+  else v = ldexpf((float)(m | 0x400u), (int)e - 25);
+  return sign ? -v : v;
+}
+static long long pair_index(long long i) { return ((i >> 5) << 6) + (i & 31); }
+static void pair_put(uint16_t* d, long long i, float v) {
+  const uint16_t hi = tt_cpu_f16(v);
+  d[pair_index(i)] = hi;
+  d[pair_index(i) + 32] = tt_cpu_f16((v - tt_cpu_f16_to_f32(hi)) * 2048.0f);
+}
+static double pair_hi(const uint16_t* d, long long i) { return (double)tt_cpu_f16_to_f32(d[pair_index(i)]); }
+static double pair_lo(const uint16_t* d, long long i) { return (double)tt_cpu_f16_to_f32(d[pair_index(i) + 32]) / 2048.0; }
+/* the three products the kernels form per term: hi hi + hi lo + lo hi (lo lo is dropped) */
+static double pair_dot(const uint16_t* a, const uint16_t* b, long long n) {
+  double s = 0.0;
+  for (long long k = 0; k < n; ++k) s += pair_hi(a, k) * pair_hi(b, k) + pair_hi(a, k) * pair_lo(b, k) + pair_lo(a, k) * pair_hi(b, k);
+  return s;
+}
+int tt_cpu_split_pairs(const float* src, void* dst_pairs, long long n, tt_stream_t stream) {
+  (void)stream;
+  for (long long i = 0; i < n; ++i) pair_put((uint16_t*)dst_pairs, i, src[i]);
+  return 0;
+}
+int tt_cpu_join_pairs(const void* src_pairs, float* dst, long long n, tt_stream_t stream) {
+  (void)stream;
+  const uint16_t* s = (const uint16_t*)src_pairs;
+  for (long long i = 0; i < n; ++i) dst[i] = fmaf(tt_cpu_f16_to_f32(s[pair_index(i) + 32]), 0.00048828125f, tt_cpu_f16_to_f32(s[pair_index(i)]));
+  return 0;
+}
+int tt_cpu_layernorm_fwd_pairs(const float* x, const float* gamma, const float* beta, void* y_pairs, float* mean, float* rstd, int rows, int D,
+                               float eps, int skip_group, tt_stream_t stream) {
+  float* y = (float*)malloc((size_t)rows * D * sizeof(float));
+  if (!y) return -3;
+  tt_cpu_layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, eps, skip_group, stream);
+  const int rc = tt_cpu_split_pairs(y, y_pairs, (long long)rows * D, stream);
+  free(y);
+  return rc;
+}
+int tt_cpu_linear_fwd_pairs(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out,
+                            void* y_pairs, int M, int N, int K, int act, tt_stream_t stream) {
+  const uint16_t *xp = (const uint16_t*)x_pairs, *wp = (const uint16_t*)w_pairs;   /* [M][2 K], [N][2 K] */
+  float* tmp = (float*)malloc((size_t)M * N * sizeof(float));
+  if (!tmp) return -3;
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < N; ++n) {
+      float v = (float)((bias ? (double)bias[n] : 0.0) + pair_dot(xp + (size_t)m * 2 * K, wp + (size_t)n * 2 * K, K));
+      if (pre_out) pre_out[(size_t)m * N + n] = v;
+      if (act == 1) v = tt_cpu_gelu(v);
+      if (residual) v += residual[(size_t)m * N + n];
+      tmp[(size_t)m * N + n] = v;
+    }
+  if (y_pairs) tt_cpu_split_pairs(tmp, y_pairs, (long long)M * N, stream);
+  if (y) memcpy(y, tmp, (size_t)M * N * sizeof(float));
+  free(tmp);
+  return 0;
+}
+int tt_cpu_linear_fwd_pairs_route(int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int has_y_pairs, int has_pre_out) {
+  return 0;
+}
+/* softmax(q k^T * scale) v on pair operands: scores and P V as the three-product sums, fp64 accumulation */
+int tt_cpu_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, float* out_f32, float* lse, int F, int N, int H, int head_dim, float scale,
+                               tt_stream_t stream) {
+  const uint16_t* in = (const uint16_t*)qkv_pairs;
+  const int D = H * head_dim;
+  const size_t RS = (size_t)6 * D;
+  double* p = (double*)malloc((size_t)N * sizeof(double));
+  float* o = (float*)malloc((size_t)F * N * D * sizeof(float));
+  if (!p || !o) return -3;
+  for (int f = 0; f < F; ++f)
+    for (int h = 0; h < H; ++h)
+      for (int i = 0; i < N; ++i) {
+        const uint16_t* q = in + ((size_t)f * N + i) * RS + (size_t)h * 2 * head_dim;
+        double mx = -1e300;
+        for (int j = 0; j < N; ++j) {
+          const uint16_t* k = in + ((size_t)f * N + j) * RS + 2 * D + (size_t)h * 2 * head_dim;
+          p[j] = pair_dot(q, k, head_dim) * (double)scale;
+          if (p[j] > mx) mx = p[j];
+        }
+        double sum = 0.0;
+        for (int j = 0; j < N; ++j) { p[j] = exp(p[j] - mx); sum += p[j]; }
+        if (lse) lse[((size_t)f * H + h) * N + i] = (float)(mx + log(sum));
+        for (int d = 0; d < head_dim; ++d) {
+          double acc = 0.0;
+          for (int j = 0; j < N; ++j) {
+            /* the kernel splits the unnormalised p in (0, 1] into (hi, lo) as well */
+            const float pj = (float)p[j];
+            const float ph = tt_cpu_f16_to_f32(tt_cpu_f16(pj));
+            const double plo = (double)tt_cpu_f16_to_f32(tt_cpu_f16((pj - ph) * 2048.0f)) / 2048.0;
+            const uint16_t* v = in + ((size_t)f * N + j) * RS + 4 * D + (size_t)h * 2 * head_dim;
+            acc += (double)ph * pair_hi(v, d) + (double)ph * pair_lo(v, d) + plo * pair_hi(v, d);
+          }
+          o[((size_t)f * N + i) * D + h * head_dim + d] = (float)(acc / sum);
+        }
+      }
+  if (out_f32) memcpy(out_f32, o, (size_t)F * N * D * sizeof(float));
+  if (out_pairs) tt_cpu_split_pairs(o, out_pairs, (long long)F * N * D, stream);
+  free(p); free(o);
+  return 0;
+}
+size_t tt_cpu_split_pairs_dual_workspace_bytes(int R, int C, int Rpad) { return 0; }
+int tt_cpu_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, int R, int C, int Rpad, void* workspace,
+                            size_t workspace_bytes, tt_stream_t stream) {
+  (void)workspace; (void)workspace_bytes;
+  uint16_t* t = (uint16_t*)dst_t_pairs;
+  for (int c = 0; c < C; ++c) {
+    double s = 0.0;
+    for (int r = 0; r < Rpad; ++r) {
+      const float v = r < R ? src[(size_t)r * C + c] : 0.f;
+      pair_put(t + (size_t)c * 2 * Rpad, r, v);
+      s += v;
+    }
+    if (colsum) colsum[c] = (float)s;
+  }
+  if (dst_row_pairs) tt_cpu_split_pairs(src, dst_row_pairs, (long long)R * C, stream);
+  return 0;
+}
+int tt_cpu_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int R, int C, int Rpad, tt_stream_t stream) {
+  (void)stream;
+  const uint16_t* s = (const uint16_t*)src_pairs;
+  uint16_t* t = (uint16_t*)dst_t_pairs;
+  for (int c = 0; c < C; ++c)
+    for (int r = 0; r < Rpad; ++r) {
+      t[(size_t)c * 2 * Rpad + pair_index(r)] = r < R ? s[(size_t)r * 2 * C + pair_index(c)] : 0;
+      t[(size_t)c * 2 * Rpad + pair_index(r) + 32] = r < R ? s[(size_t)r * 2 * C + pair_index(c) + 32] : 0;
+    }
+  return 0;
+}
+int tt_cpu_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, int M, int N, int K,
+                                 tt_stream_t stream) {
+  (void)stream;
+  const uint16_t *dy = (const uint16_t*)dy_pairs, *wT = (const uint16_t*)wT_pairs;   /* dy [M][2 N], wT [K][2 N] */
+  for (int m = 0; m < M; ++m)
+    for (int k = 0; k < K; ++k) {
+      float v = (float)pair_dot(dy + (size_t)m * 2 * N, wT + (size_t)k * 2 * N, N);
+      if (gelu_pre) v *= tt_cpu_gelu_grad(gelu_pre[(size_t)m * K + k]);
+      dx[(size_t)m * K + k] = v;
+    }
+  return 0;
+}
+size_t tt_cpu_linear_bwd_weight_pairs_workspace_bytes(int N, int K, int Mpad) { return 0; }
+int tt_cpu_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, float* dw, int N, int K, int Mpad, void* workspace,
+                                   size_t workspace_bytes, tt_stream_t stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  const uint16_t *dyT = (const uint16_t*)dyT_pairs, *xT = (const uint16_t*)xT_pairs;   /* dyT [N][2 Mpad], xT [K][2 Mpad] */
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) dw[(size_t)n * K + k] = (float)pair_dot(dyT + (size_t)n * 2 * Mpad, xT + (size_t)k * 2 * Mpad, Mpad);
+  return 0;
+}
+
 size_t tt_cpu_vit_forward_workspace_bytes(int F, int N, int D, int hidden, int planes) { return 0; }
 size_t tt_cpu_mlp_head_forward_workspace_bytes(int M, const tt_cpu_linear_params* layers, int n_layers) { return 0; }
 size_t tt_cpu_scores_sinkhorn_workspace_bytes(int B, int queue_rows, int K, int dim) { return 0; }
@@ -878,6 +1052,23 @@ int tt_cpu_vit_forward(const tt_cpu_vit_params* p, const float* img, const int32
       continue;
     }
     const long long MD = (long long)M * D;
+    if (P == 2) {   /* fp16 pairs (4 bytes per element: the PP = 2 buffers above are the right size) */
+      tt_cpu_layernorm_fwd_pairs(tokens, b->norm1_w, b->norm1_b, hp, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
+      if (!(last && last_qkv) && !probs && N <= 256 && hd == 64) {
+        uint16_t* qkvp = (uint16_t*)qkv_own;   /* pairs [M][2 x 3 D] = the bytes of the fp32 qkv buffer */
+        tt_cpu_linear_fwd_pairs(hp, b->qkv_wp, b->qkv_b, NULL, NULL, NULL, qkvp, (int)M, 3 * D, D, 0, stream);
+        tt_cpu_attention_fwd_pairs(qkvp, attp, NULL, NULL, F, N, p->heads, hd, scale, stream);
+      } else {
+        tt_cpu_linear_fwd_pairs(hp, b->qkv_wp, b->qkv_b, NULL, qkv, NULL, NULL, (int)M, 3 * D, D, 0, stream);
+        tt_cpu_attention_fwd(qkv, att, NULL, probs, F, N, p->heads, hd, scale, stream);
+        tt_cpu_split_pairs(att, attp, MD, stream);
+      }
+      tt_cpu_linear_fwd_pairs(attp, b->proj_wp, b->proj_b, tokens, tokens, NULL, NULL, (int)M, D, D, 0, stream);
+      tt_cpu_layernorm_fwd_pairs(tokens, b->norm2_w, b->norm2_b, hp, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
+      tt_cpu_linear_fwd_pairs(hp, b->fc1_wp, b->fc1_b, NULL, NULL, NULL, actp, (int)M, Hd, D, 1, stream);
+      tt_cpu_linear_fwd_pairs(actp, b->fc2_wp, b->fc2_b, tokens, tokens, NULL, NULL, (int)M, D, Hd, 0, stream);
+      continue;
+    }
     tt_cpu_layernorm_fwd_planes(tokens, b->norm1_w, b->norm1_b, hp, MD, P, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
     const void* proj_in;
     if (P == 1 && !(last && last_qkv) && !probs && N <= 256 && hd == 64) {

@@ -43,6 +43,22 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def rel_l2(a, b):
+    """||a - b||_2 / ||b||_2 - the twin of ``rel_err`` that a single large element of b cannot flatter (assertions on
+    embeddings / logits use both)."""
+    a = np.asarray(a.detach().cpu() if hasattr(a, "detach") else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if hasattr(b, "detach") else b, dtype=np.float64)
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
+
+
+def tail_err(a, b, frac=0.1):
+    """Relative L2 error restricted to the ``frac`` smallest-magnitude elements of b: what a max-normalised bound hides."""
+    a = np.asarray(a.detach().cpu() if hasattr(a, "detach") else a, dtype=np.float64).ravel()
+    b = np.asarray(b.detach().cpu() if hasattr(b, "detach") else b, dtype=np.float64).ravel()
+    idx = np.argsort(np.abs(b))[: max(1, int(frac * b.size))]
+    return float(np.linalg.norm(a[idx] - b[idx]) / max(np.linalg.norm(b[idx]), 1e-30))
+
+
 @pytest.fixture(params=["f32", "f16x3", "bf16x6"])
 def accurate_precision(request):
     """The arithmetic modes that must meet the fp32 contract: exact f32 MFMA, and the fp32-accurate split modes - "f16x3" (fp16

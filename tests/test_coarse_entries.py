@@ -71,14 +71,18 @@ def _run_vit(lib, prefix, mem, case, planes, drop_cls=False, want_qkv=False, wan
     nb = len(w["blocks"])
     arr = (L.VitBlockParams * nb)()
     split = getattr(lib, prefix + "split_planes")
+    split_pairs = getattr(lib, prefix + "split_pairs")
     for j, b in enumerate(w["blocks"]):
         for k, v in b.items():
             setattr(arr[j], k, mem(v))
         if planes:
             for k in ("qkv_w", "proj_w", "fc1_w", "fc2_w"):
-                wp = np.empty((planes,) + b[k].shape, np.uint16)
+                wp = np.empty((planes,) + b[k].shape, np.uint16)   # (planes == 2: fp16 pairs [out][2 in] - the same number of bytes)
                 src, dst = mem(b[k]), mem(wp)
-                assert split(src, dst, b[k].size, planes, b[k].size, mem.stream) == 0
+                if planes == 2:
+                    assert split_pairs(src, dst, b[k].size, mem.stream) == 0
+                else:
+                    assert split(src, dst, b[k].size, planes, b[k].size, mem.stream) == 0
                 setattr(arr[j], k + "p", dst)
     vp = L.VitParams()
     vp.patch_w, vp.patch_b, vp.cls, vp.pos = mem(w["patch_w"]), mem(w["patch_b"]), mem(w["cls"]), mem(w["pos"])
@@ -188,6 +192,10 @@ def test_twin_vit_forward_vs_torch(twin):
     assert _re(dropped, normed_ref[:, 1:].reshape(-1, case["D"])) < 2e-6                  # get_features drops the cls token
     tok3, normed3, _, _ = _run_vit(twin, "tt_cpu_", _Mem(), case, 3)                        # three bf16 planes: fp32-accurate
     assert _re(tok3, tok_ref) < 5e-6 and _re(normed3, normed_ref) < 5e-6
+    tok2, normed2, qkv2, _ = _run_vit(twin, "tt_cpu_", _Mem(), case, 2, want_qkv=True)      # fp16 pairs: fp32-accurate (fp32 attention route)
+    assert _re(tok2, tok_ref) < 5e-6 and _re(normed2, normed_ref) < 5e-6 and _re(qkv2, qkv_ref) < 5e-6
+    tok2, normed2, _, _ = _run_vit(twin, "tt_cpu_", _Mem(), case, 2)                        # ... and the pair attention route
+    assert _re(tok2, tok_ref) < 5e-6 and _re(normed2, normed_ref) < 5e-6
     tok1, normed1, _, _ = _run_vit(twin, "tt_cpu_", _Mem(), case, 1)                        # the bf16 path (bf16 attention: hd = 64)
     assert _re(normed1, normed_ref) < 3e-2
     # continuing from a residual stream (img == NULL): the EMA teacher's form
@@ -241,7 +249,10 @@ def test_twin_head_scores_update_vs_torch(twin):
 def test_hip_coarse_entries_equal_their_twins(twin):
     lib = L.load()
     case = _vit_case()
-    for planes, tol in ((0, 2e-5), (3, 2e-5), (1, 3e-2)):
+    a = _run_vit(lib, "tt_", _Mem("cuda"), case, 2)   # fp16 pairs without the last block's qkv: the pair attention kernel's route
+    b = _run_vit(twin, "tt_cpu_", _Mem(), case, 2)
+    assert _re(a[0], b[0]) < 2e-5 and _re(a[1], b[1]) < 2e-5
+    for planes, tol in ((0, 2e-5), (3, 2e-5), (2, 2e-5), (1, 3e-2)):
         a = _run_vit(lib, "tt_", _Mem("cuda"), case, planes, want_qkv=planes != 1, want_probs=planes == 0)
         b = _run_vit(twin, "tt_cpu_", _Mem(), case, planes, want_qkv=planes != 1, want_probs=planes == 0)
         for x, y in zip(a, b):
@@ -262,7 +273,7 @@ def test_hip_coarse_entries_equal_their_twins(twin):
 def test_coarse_entry_argument_checks():
     lib = L.load()
     vp = L.VitParams()
-    vp.dim, vp.heads, vp.hidden, vp.patch, vp.planes, vp.n_blocks = 128, 2, 256, 16, 2, 0
+    vp.dim, vp.heads, vp.hidden, vp.patch, vp.planes, vp.n_blocks = 128, 2, 256, 16, 4, 0
     t = torch.zeros(1, 7, 128, device="cuda")
     assert lib.tt_vit_forward(C.byref(vp), None, None, 1, 3, 32, 48, t.data_ptr(), None, 0, None, None, None, 0, None) == -1
     assert b"planes" in lib.tt_last_error()
@@ -315,7 +326,7 @@ class _fine_grained:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["f32", "bf16x6", "bf16", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "f16x3", "bf16x6", "bf16", "bf16x3"])
 def test_coarse_path_is_bit_identical_to_the_fine_grained_sequence(mode):
     """The same kernels in the same order: extractor outputs, the loss, every gradient, and the state after two full training
     iterations (teacher + queue) must agree BIT FOR BIT between the coarse entry points and the one-call-per-op sequence."""

@@ -670,3 +670,58 @@ def test_hip_library_equals_its_cpu_twin_round2c(twin):
         assert _re(A["mask"][i + 1], B["mask"][i + 1]) < 1e-5
     bad = np.abs(A["lp"][4] - B["lp"][4]).max(-1) > 1e-5 * np.abs(B["lp"][4]).max()
     assert bad.mean() <= 0.01 and (A["lp"][2] != B["lp"][2]).mean() <= 0.03 and np.array_equal(A["lp"][3], A["lp"][4][-1])
+
+
+def test_round4_pair_twins_against_numpy(twin):
+    """The fp16-pair twins (the "f16x3" mode's operand format and products) against NumPy / torch restatements on the CPU."""
+    rs = np.random.RandomState(4)
+    M, N, K = 37, 64, 96
+    x, w, b = rs.randn(M, K).astype(np.float32), (0.1 * rs.randn(N, K)).astype(np.float32), (0.1 * rs.randn(N)).astype(np.float32)
+    xp, wp = np.empty((M, 2 * K), np.uint16), np.empty((N, 2 * K), np.uint16)
+    assert twin.tt_cpu_split_pairs(ptr(x), ptr(xp), M * K, None) == 0 and twin.tt_cpu_split_pairs(ptr(w), ptr(wp), N * K, None) == 0
+    # layout and values: groups of 32 as [hi x 32][lo x 32]; hi = fp16(x) (torch's own conversion), lo = fp16((x - hi) 2^11)
+    g = xp.reshape(M, K // 32, 2, 32)
+    hi_ref = torch.from_numpy(x).to(torch.float16)
+    assert np.array_equal(g[:, :, 0, :].reshape(M, K), hi_ref.numpy().view(np.uint16))
+    lo_ref = ((torch.from_numpy(x) - hi_ref.float()) * 2048).to(torch.float16)
+    assert np.array_equal(g[:, :, 1, :].reshape(M, K), lo_ref.numpy().view(np.uint16))
+    back = np.empty((M, K), np.float32)
+    assert twin.tt_cpu_join_pairs(ptr(xp), ptr(back), M * K, None) == 0
+    assert np.abs(back - x).max() <= 2.0 ** -22 * np.abs(x).max()
+    y, pre, yp = np.empty((M, N), np.float32), np.empty((M, N), np.float32), np.empty((M, 2 * N), np.uint16)
+    assert twin.tt_cpu_linear_fwd_pairs(ptr(xp), ptr(wp), ptr(b), None, ptr(y), ptr(pre), ptr(yp), M, N, K, 1, None) == 0
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    assert np.abs(pre - ref).max() / np.abs(ref).max() < 5e-7
+    assert np.abs(y - F.gelu(torch.from_numpy(ref)).numpy()).max() / np.abs(ref).max() < 5e-7
+    # transposes: zero padding beyond R, the same bits as splitting the transposed matrix
+    t, row, sums = np.empty((K, 2 * 64), np.uint16), np.empty((M, 2 * K), np.uint16), np.empty(K, np.float32)
+    assert twin.tt_cpu_split_pairs_dual(ptr(x), ptr(t), ptr(row), ptr(sums), M, K, 64, None, 0, None) == 0
+    xt = np.zeros((K, 64), np.float32); xt[:, :M] = x.T
+    tref = np.empty((K, 128), np.uint16)
+    assert twin.tt_cpu_split_pairs(ptr(xt), ptr(tref), K * 64, None) == 0
+    assert np.array_equal(t, tref) and np.array_equal(row, xp) and np.allclose(sums, x.sum(0), atol=1e-5)
+    t2 = np.empty((K, 128), np.uint16)
+    assert twin.tt_cpu_transpose_pairs(ptr(xp), ptr(t2), M, K, 64, None) == 0 and np.array_equal(t2, t)
+    # backward products
+    dy = (1e-3 * rs.randn(M, N)).astype(np.float32)
+    dyT, dyr = np.empty((N, 128), np.uint16), np.empty((M, 2 * N), np.uint16)
+    assert twin.tt_cpu_split_pairs_dual(ptr(dy), ptr(dyT), ptr(dyr), None, M, N, 64, None, 0, None) == 0
+    wT = np.empty((K, 2 * N), np.uint16)
+    assert twin.tt_cpu_split_pairs_dual(ptr(w), ptr(wT), None, None, N, K, N, None, 0, None) == 0
+    dx, dw = np.empty((M, K), np.float32), np.empty((N, K), np.float32)
+    assert twin.tt_cpu_linear_bwd_data_pairs(ptr(dyr), ptr(wT), None, ptr(dx), M, N, K, None) == 0
+    assert twin.tt_cpu_linear_bwd_weight_pairs(ptr(dyT), ptr(t), ptr(dw), N, K, 64, None, 0, None) == 0
+    dx_ref, dw_ref = dy.astype(np.float64) @ w, dy.astype(np.float64).T @ x
+    assert np.abs(dx - dx_ref).max() / np.abs(dx_ref).max() < 5e-7 and np.abs(dw - dw_ref).max() / np.abs(dw_ref).max() < 5e-7
+    # attention on pairs against torch in fp64
+    Fr, Nn, H = 2, 19, 2
+    D = 64 * H
+    qkv = rs.randn(Fr, Nn, 3 * D).astype(np.float32)
+    qp = np.empty((Fr * Nn, 6 * D), np.uint16)
+    assert twin.tt_cpu_split_pairs(ptr(qkv), ptr(qp), qkv.size, None) == 0
+    of, lse, op = np.empty((Fr, Nn, D), np.float32), np.empty((Fr, H, Nn), np.float32), np.empty((Fr * Nn, 2 * D), np.uint16)
+    assert twin.tt_cpu_attention_fwd_pairs(ptr(qp), ptr(op), ptr(of), ptr(lse), Fr, Nn, H, 64, 0.125, None) == 0
+    q, k, v = torch.from_numpy(qkv).double().view(Fr, Nn, 3, H, 64).permute(2, 0, 3, 1, 4)
+    sc = q @ k.transpose(-1, -2) * 0.125
+    ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(Fr, Nn, D).numpy()
+    assert np.abs(of - ref).max() / np.abs(ref).max() < 1e-6 and np.abs(lse - torch.logsumexp(sc, -1).numpy()).max() < 1e-5

@@ -5,11 +5,26 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import rel_err, rel_l2, tail_err
 from timetuning_amd import synth
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3  # north-star bound: 1e-3 relative fp32 on patch embeddings and assignment logits
+
+
+def assert_close(a, b, tol, what="", guard=3e-5):
+    """The north-star quantities (patch embeddings, assignment logits) in three measures: max-normalised (``rel_err``), relative L2
+    (a single large reference element cannot flatter it) and relative L2 over the 10 % smallest-magnitude reference elements (what a
+    max-normalised bound hides; their own scale is ~1/20 of the tensor's, hence the factor).  ``tol`` is the contract (north-star: 1e-3);
+    ``guard`` is a regression tripwire on the relative L2 error: the fp32-class modes measure 3e-7 ... 1e-5 here (round 4, printed with
+    TT_TEST_PRINT_ERRORS=1), so an arithmetic regression of 3x - 100x fails the test long before the contract is in danger."""
+    e, l2, tl = rel_err(a, b), rel_l2(a, b), tail_err(a, b)
+    assert l2 < guard, (what, "regression guard", l2, guard)
+    import os
+    if os.environ.get("TT_TEST_PRINT_ERRORS"):
+        print(f"[errors] {what}: max-norm {e:.2e}  rel-L2 {l2:.2e}  tail-L2 {tl:.2e}  (bound {tol:.0e})")
+    assert e < tol and l2 < tol and tl < 20 * tol, (what, e, l2, tl)
+
 
 
 def _build(g, teacher=False, queue=0):
@@ -46,8 +61,8 @@ def test_extractor_tiny(golden, accurate_precision):
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1)).view(bs * fs, 3, 224, 224).cuda()
     f, attn = model.feature_extractor(x)
     bf, _ = model.feature_extractor(x, use_head=False)
-    assert rel_err(f.cpu(), g["features"]) < 1e-4
-    assert rel_err(bf.cpu(), g["backbone_features"]) < 1e-4
+    assert_close(f.cpu(), g["features"], 1e-4, "tiny patch embeddings")
+    assert_close(bf.cpu(), g["backbone_features"], 1e-4, "tiny backbone features")
     assert rel_err(attn[:, :, 0, :].cpu(), g["attn_cls_row"]) < 1e-4
     f2, _ = model(x)  # TimeT.forward(train=False): the extractor under no_grad
     with torch.no_grad():
@@ -90,8 +105,8 @@ def test_loss_internals_tiny(golden, accurate_precision):
         # flipped one of ours; the propagation's labels are compared separately
         loss = model.get_loss(x, target_labels=g["labels"].reshape(bs, -1))
     aux = model.last_aux
-    assert rel_err(aux["q"].cpu(), g["q"]) < TOL
-    assert rel_err(aux["target_scores"].cpu(), g["target_scores"]) < TOL
+    assert rel_err(aux["q"].cpu(), g["q"]) < TOL and rel_l2(aux["q"].cpu(), g["q"]) < TOL
+    assert_close(aux["target_scores"].cpu(), g["target_scores"], TOL, "tiny assignment logits")
     mism = aux["labels"].cpu().numpy() != g["labels"].reshape(bs, -1)
     assert mism.mean() <= 0.01
     assert abs(loss.item() - float(t["loss0"])) < 1e-4
@@ -149,19 +164,19 @@ def test_training_steps_tiny(golden, accurate_precision):
     _run_steps(golden("timet_tiny"), False, 0)
 
 
-def test_training_steps_tiny_300_prototypes(golden):
+def test_training_steps_tiny_300_prototypes(golden, accurate_precision):
     """K = 300 prototypes against the reference's own run: the K > 256 instances of the label-propagation, Sinkhorn and
     cross-entropy kernels (BASELINE C4 has 400) and a score GEMM whose width is not a multiple of 64."""
     _run_steps(golden("timet_tiny_k300"), False, 0)
 
 
-def test_training_steps_tiny_six_frames(golden):
+def test_training_steps_tiny_six_frames(golden, accurate_precision):
     """Six-frame clips against the reference's own run: up to five context frames per target in the label propagation (the
     similarities of all 15 (target, context) pairs in 6 batched launches, the 8-context instance of the wave-per-query kernel)."""
     _run_steps(golden("timet_tiny_f6"), False, 0)
 
 
-def test_training_steps_tiny_patch8(golden):
+def test_training_steps_tiny_patch8(golden, accurate_precision):
     """Patch size 8 (BASELINE C5's shape: 785 tokens - the KV-tiled attention, the general patch-embedding kernel, the 28 x 28
     propagation grid) against the REFERENCE's own run on a narrow ViT (head dim 64): extractor outputs, then loss, gradients
     and parameters over two optimizer steps."""
@@ -178,7 +193,7 @@ def test_training_steps_tiny_teacher_queue(golden, accurate_precision):
     _run_steps(golden("timet_tiny_tq"), True, 40)
 
 
-def test_training_steps_tiny_use_mask(golden):
+def test_training_steps_tiny_use_mask(golden, accurate_precision):
     """--use_mask: attention foreground masks on features and loss against the reference's numbers."""
     _run_steps(golden("timet_tiny_mask"), False, 0)
 
@@ -195,8 +210,8 @@ def test_full_size_c1(golden, accurate_precision):
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1)).cuda()
     f, _ = model.feature_extractor(x.view(bs * fs, 3, 224, 224))
     bf, _ = model.feature_extractor(x.view(bs * fs, 3, 224, 224), use_head=False)
-    assert rel_err(f[:, ::49, ::16].cpu(), g["features_slice"]) < TOL
-    assert rel_err(bf[:, ::49, ::16].cpu(), g["backbone_features_slice"]) < TOL
+    assert_close(f[:, ::49, ::16].cpu(), g["features_slice"], TOL, "C1 patch embeddings (slice)")
+    assert_close(bf[:, ::49, ::16].cpu(), g["backbone_features_slice"], TOL, "C1 backbone features (slice)")
     assert abs(f.double().norm().item() / float(g["features_norm"]) - 1) < 1e-4
     loss = model.get_loss(x)
     assert abs(loss.item() - float(g["loss0"])) < 2e-4
@@ -235,7 +250,7 @@ def test_c2_size_properties():
     with torch.no_grad():
         of, _ = om.feature_extractor(sub, faithful=False)
     mf, _ = model.feature_extractor(sub.cuda())
-    assert rel_err(mf.cpu(), of) < TOL
+    assert_close(mf.cpu(), of, TOL, "C2 patch embeddings (2-clip sub-batch)")
     g = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
     assert torch.isfinite(g).all() and g.abs().max() > 0
 
@@ -260,8 +275,8 @@ def test_c2_full_step_vs_oracle(accurate_precision):
     oloss.backward()
     loss = model.get_loss(x.cuda(), target_labels=aux["labels"].reshape(bs, -1))
     loss.backward()
-    assert rel_err(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL
-    assert rel_err(model.last_aux["target_scores"].cpu(), aux["target_scores"].detach()) < TOL
+    assert rel_err(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL and rel_l2(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL
+    assert_close(model.last_aux["target_scores"].cpu(), aux["target_scores"].detach(), TOL, "C2 assignment logits")
     mism = (model.last_aux["labels"].cpu() != aux["labels"].reshape(bs, -1)).float().mean().item()
     assert mism <= 0.01, mism
     assert abs(loss.item() - oloss.item()) < 2e-4, (loss.item(), oloss.item())
@@ -648,6 +663,48 @@ def test_other_architectures_vs_oracle(arch, K, bs, fs):
         assert rel_err(dict(model.named_parameters())[name].grad.cpu(), og[name].grad) < TOL, name
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("arch,K,bs,fs,mode,ftol", [("dino-b16", 400, 16, 8, "f16x3", TOL), ("dino-b16", 400, 16, 8, "bf16", 1.5e-2),
+                                                    ("dino-s8", 200, 16, 4, "f16x3", TOL), ("dino-s8", 200, 16, 4, "f32", TOL)])
+def test_c4_c5_full_per_gpu_batch(arch, K, bs, fs, mode, ftol):
+    """BASELINE C4 (ViT-B/16, 8-frame clips, 400 prototypes) and C5 (ViT-S/8, 785 tokens) at the FULL per-GPU batch the bench times
+    (16 clips): too big for the CPU oracle as a whole, so - as ``test_c2_size_properties`` does for C2 - the training step is checked
+    through size-independent properties (assignment rows sum to one, prototypes equally loaded, finite non-zero gradients, a loss
+    near ln K) and the extractor against the oracle on a 2-clip sub-batch (per-clip computations are independent), in the precision
+    mode the bench line of that config runs in."""
+    from oracle import timet_oracle as O
+    from timetuning_amd import hip_ops
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    fe = FeatureExtractor(arch, "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="stress", return_attention=False)
+    model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, 256))).cuda()
+    n = fe.spatial_resolution ** 2
+    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=7))
+    try:
+        hip_ops.set_gemm_precision(mode)
+        loss = model.get_loss(x.cuda())
+        loss.backward()
+        q = model.last_aux["q"].reshape(bs * n, K)
+        assert rel_err(q.sum(1).cpu(), torch.ones(bs * n)) < 1e-5
+        col = q.double().sum(0)
+        assert (col.max() / col.min()).item() < 1.05
+        assert np.isfinite(loss.item()) and abs(loss.item() - np.log(K)) < 1.5
+        g = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+        assert torch.isfinite(g).all() and g.abs().max() > 0
+        om = O.build_oracle(arch, K, (1024, 1024, 512, 256), mode="stress")
+        sub = x[:2].reshape(2 * fs, 3, 224, 224)
+        with torch.no_grad():
+            of, _ = om.feature_extractor(sub, faithful=False)
+            mf, _ = model.feature_extractor(sub.cuda())
+        if mode == "bf16":
+            assert rel_err(mf.cpu(), of) < ftol and rel_l2(mf.cpu(), of) < ftol
+        else:
+            assert_close(mf.cpu(), of, ftol, f"{arch} patch embeddings (2-clip sub-batch, {mode})")
+    finally:
+        hip_ops.set_gemm_precision("f32")
+
+
 def test_c4_shape_in_bf16_mode():
     """BASELINE config C4 names the "MFMA bf16 path": ViT-B/16, 8-frame clips, 400 prototypes.  One clip of that shape in the
     opt-in "bf16" mode of the forward Linears against the fp32 oracle, held to a bf16-sized bound (the mode cannot meet the
@@ -667,7 +724,8 @@ def test_c4_shape_in_bf16_mode():
         oloss, aux = om.get_loss(x, faithful=False, return_aux=True)
     olabels = aux["labels"].reshape(bs, -1)
     try:
-        for mode, ftol, ltol, flips in (("bf16x6", 1e-4, 2e-4, 0.01), ("bf16x3", 1e-3, 2e-3, 0.03), ("bf16", 8e-2, 0.15, 0.5)):
+        # (bf16: 3 x the error the bench line measures on this shape, 4.5e-3)
+        for mode, ftol, ltol, flips in (("f16x3", 1e-4, 2e-4, 0.01), ("bf16x6", 1e-4, 2e-4, 0.01), ("bf16x3", 1e-3, 2e-3, 0.03), ("bf16", 1.5e-2, 0.15, 0.5)):
             hip_ops.set_gemm_precision(mode)
             with torch.no_grad():
                 f, _ = model.feature_extractor(x.view(bs * fs, 3, 224, 224).cuda())
@@ -803,8 +861,8 @@ def test_bf16x3_full_size_c1(golden):
         loss = model.get_loss(x)
     finally:
         hip_ops.set_gemm_precision("f32")
-    assert rel_err(f[:, ::49, ::16].cpu(), g["features_slice"]) < TOL
-    assert rel_err(bf[:, ::49, ::16].cpu(), g["backbone_features_slice"]) < TOL
+    assert_close(f[:, ::49, ::16].cpu(), g["features_slice"], TOL, "C1 patch embeddings (slice)")
+    assert_close(bf[:, ::49, ::16].cpu(), g["backbone_features_slice"], TOL, "C1 backbone features (slice)")
     assert abs(loss.item() - float(g["loss0"])) < 1e-3 * float(g["loss0"])
 
 

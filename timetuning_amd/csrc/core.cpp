@@ -28,7 +28,7 @@ int device_cu_count() {
 }  // namespace tt
 
 extern "C" const char* tt_last_error(void) { return tt::g_err; }
-extern "C" int tt_abi_version(void) { return 4; }   // 4: tt_vit_params.patch_wp; 3: the coarse entry points (tt_vit_forward, ...) and their parameter structs
+extern "C" int tt_abi_version(void) { return 5; }   // 5: the fp16-pair entry points (tt_*_pairs*), tt_vit_params.planes == 2; 4: tt_vit_params.patch_wp; 3: the coarse entry points (tt_vit_forward, ...) and their parameter structs
 
 extern "C" int tt_device_info(char* name, int cap) {
   int dev = 0;
