@@ -58,29 +58,53 @@ def _worker(rank, W, port, ret, backend="gloo"):
     x = torch.from_numpy(synth.make_clips(BS, FS, 224, seed=11 + rank)).cuda()
     from timetuning_amd import engine
 
-    engine.RCCL_PROFILE = []   # every wait of the compute stream on a collective: (kind, payload bytes, events)
+    # step 1 flattens its buckets by hand and records their layout; step 2 (same data, gradients cleared) must give the same numbers with
+    # the backward kernels writing the persistent flat buckets directly (engine.GradArena) - and no torch.cat
+    inner = model.get_non_ddp_model()
+    params = dict(inner.named_parameters())
     loss = model(x, None, True, False)
     loss.backward()
+    first = {n: params[n].grad.clone() for n in WATCH}
+    inner.zero_grad(set_to_none=True)
+    cats = {"n": 0}
+    real_cat = torch.cat
+
+    def counting_cat(*a, **k):
+        cats["n"] += 1
+        return real_cat(*a, **k)
+
+    engine.RCCL_PROFILE = []   # every wait of the compute stream on a collective: (kind, payload bytes, events)
+    torch.cat = counting_cat
+    try:
+        loss = model(x, None, True, False)
+        loss.backward()
+    finally:
+        torch.cat = real_cat
     torch.cuda.synchronize()
     waits, engine.RCCL_PROFILE = engine.RCCL_PROFILE, None
-    params = dict(model.get_non_ddp_model().named_parameters())
+    arena = inner._grad_arena
+    lo, hi = arena.flat.data_ptr(), arena.flat.data_ptr() + arena.flat.numel() * 4
     ret[rank] = dict(loss=float(loss.item()), grads={n: params[n].grad.cpu().numpy() for n in WATCH},
                      q=model.last_aux["q"].cpu().numpy(), waits=[(k, n, e0.elapsed_time(e1)) for k, n, e0, e1 in waits],
-                     trainable=sum(p.numel() for p in model.get_non_ddp_model().parameters() if p.requires_grad))
+                     trainable=sum(p.numel() for p in inner.parameters() if p.requires_grad),
+                     same_as_first=all(torch.equal(params[n].grad, first[n]) for n in WATCH), cats=cats["n"],
+                     in_arena=all(lo <= p.grad.data_ptr() < hi for p in inner.parameters() if p.requires_grad),
+                     arena_floats=arena.flat.numel(), bucket_sizes=[e - s_ for s_, e, _ in arena.buckets])
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("backend", ["gloo", "nccl"])
-def test_two_ranks_equal_single_process_on_concatenated_batch(backend):
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("backend,W", [("gloo", 2), ("gloo", 4), ("gloo", 8), ("nccl", 2)])
+def test_two_ranks_equal_single_process_on_concatenated_batch(backend, W):
+    """W ranks (2, and a 4- / 8-rank soak on the shared device) against ONE process on the concatenated batch: loss, assignment, gradients;
+    the exchange each rank issued (bucket order, bytes); and the persistent flat buckets of the second step."""
     import torch.multiprocessing as mp
 
     from timetuning_amd import synth
 
     if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("the RCCL two-rank run needs two GPUs (one rank per device)")
-    W = 2
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     ret = mgr.dict()
@@ -97,13 +121,17 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(backend):
         assert waits[0][1] == W * BS * 196 * K * 4
         assert sum(n for _, n, _ in waits[1:]) == 4 * ret[r]["trainable"]
         assert all(ms >= 0 for _, _, ms in waits)
+        # step 2 ran on the persistent arena: every trainable float once, bucket by bucket in the order of the waits, the gradients the
+        # optimizer sees are views of it, nothing was concatenated, and the numbers equal step 1's bit for bit
+        assert ret[r]["arena_floats"] == ret[r]["trainable"] and [4 * b for b in ret[r]["bucket_sizes"]] == [n for _, n, _ in waits[1:]]
+        assert ret[r]["in_arena"] and ret[r]["cats"] == 0 and ret[r]["same_as_first"], (ret[r]["in_arena"], ret[r]["cats"], ret[r]["same_as_first"])
 
     model = _model()
     x_all = torch.from_numpy(np.concatenate([synth.make_clips(BS, FS, 224, seed=11 + r) for r in range(W)], axis=0)).cuda()
     loss = model.get_loss(x_all)
     loss.backward()
     params = dict(model.named_parameters())
-    assert abs(loss.item() - 0.5 * (ret[0]["loss"] + ret[1]["loss"])) < 1e-5
+    assert abs(loss.item() - sum(ret[r]["loss"] for r in range(W)) / W) < 1e-5
     q_all = model.last_aux["q"].cpu().numpy()
     for r in range(W):
         assert np.abs(q_all[r * BS:(r + 1) * BS] - ret[r]["q"]).max() < 1e-6 * max(1.0, np.abs(q_all).max())

@@ -104,6 +104,12 @@ def test_linear_pairs_epilogues(M, N, K):
     assert o3["y"].data_ptr() == rc.data_ptr() and rel_err(rc.cpu(), pre_ref + res.double()) < TOL_F32
     o4 = ops.linear_fwd_pairs(xp, wp, None)
     assert rel_err(o4["y"].cpu(), pre_ref - b.double()) < TOL_F32
+    # what a forward that keeps its backward's operands asks for: the fp32 pre-activation + GELU in pairs; fp32 y + the same in pairs
+    o5 = ops.linear_fwd_pairs(xp, wp, b.cuda(), act=1, out_f32=False, out_pairs=True, save_pre=True)
+    assert o5["y"] is None and rel_err(o5["pre"].cpu(), pre_ref) < TOL_F32 and rel_err(join(o5["pairs"].cpu()), F.gelu(pre_ref)) < TOL_F32
+    assert rel_err(join(o5["pairs"].cpu()), F.gelu(o5["pre"].cpu().double())) < 2e-6     # the pairs are GELU of THAT pre-activation
+    o6 = ops.linear_fwd_pairs(xp, wp, b.cuda(), out_pairs=True)
+    assert rel_err(o6["y"].cpu(), pre_ref) < TOL_F32 and rel_err(join(o6["pairs"].cpu()), o6["y"].cpu().double()) <= 2.0 ** -22
 
 
 @pytest.mark.parametrize("Fr,N,H", [(3, 197, 6), (2, 50, 2), (1, 256, 12), (2, 225, 3), (5, 17, 1)])

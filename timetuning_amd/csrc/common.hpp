@@ -109,7 +109,10 @@ __device__ __forceinline__ float join_pair(_Float16 hi, _Float16 lo) { return fm
 __host__ __device__ __forceinline__ long long pair_index(long long i) { return ((i >> 5) << 6) + (i & 31); }
 
 // epilogue kinds of gemm_pairs8_kernel
-enum { Q8_F32 = 0, Q8_F32_RES = 1, Q8_PAIR = 2, Q8_PAIR_GELU = 3 };
+// F32 / F32_RES: fp32 y (+ residual); PAIR / PAIR_GELU: y in pairs (after GELU); F32_GELUGRAD: fp32 y * gelu'(pre[m][n]) (a data-gradient
+// product); BOTH: fp32 y AND the same value in pairs; BOTH_GELU: the fp32 PRE-activation and GELU of it in pairs (a forward that keeps
+// what its backward needs)
+enum { Q8_F32 = 0, Q8_F32_RES = 1, Q8_PAIR = 2, Q8_PAIR_GELU = 3, Q8_F32_GELUGRAD = 4, Q8_BOTH = 5, Q8_BOTH_GELU = 6 };
 
 // XCD-aware bijective remap of a linear workgroup id (guide T1): the dispatcher deals consecutive
 // ids round-robin over the 8 XCDs; this hands each XCD a contiguous run of logical tiles so that

@@ -43,10 +43,10 @@ struct Q8Args {
   const _Float16* X;   // pairs [M][2 K]
   const _Float16* W;   // pairs [N][2 K]
   int M, N, K;         // K: reduction length in elements (K % 96 == 0)
-  const float* bias;      // [N]
-  const float* residual;  // [M][N] (Q8_F32_RES; may alias C)
-  float* C;               // [M][N] fp32 (Q8_F32*)
-  _Float16* Cp;           // pairs [M][2 N] (Q8_PAIR*)
+  const float* bias;      // [N] or null
+  const float* residual;  // [M][N] (Q8_F32_RES: added, may alias C; Q8_F32_GELUGRAD: the pre-activation whose gelu' multiplies the result)
+  float* C;               // [M][N] fp32 (Q8_F32*, Q8_BOTH: y; Q8_BOTH_GELU: the pre-activation)
+  _Float16* Cp;           // pairs [M][2 N] (Q8_PAIR*, Q8_BOTH*)
   int ntn, ntiles, ncu;   // column tiles, whole tiles, workgroups launched
   int n_full, n_half;     // as gemm_planes8.hip: n_full whole tiles per workgroup, then n_half half tiles; both 0: round-robin
   int order_mode;         // order of the load part (see `reads_first`)
@@ -92,11 +92,15 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
   constexpr int CW = SCR_B / 128;                    // columns of a 32-row MFMA tile staged per pass (16)
   constexpr int NPASS = 32 / CW;
   constexpr int BN = 128;
-  constexpr bool F32OUT = EPI == Q8_F32 || EPI == Q8_F32_RES, RES = EPI == Q8_F32_RES, ACT = EPI == Q8_PAIR_GELU;
+  constexpr bool F32OUT = EPI == Q8_F32 || EPI == Q8_F32_RES || EPI == Q8_F32_GELUGRAD;   // the 4-columns-per-lane read-back
+  constexpr bool RES = EPI == Q8_F32_RES || EPI == Q8_F32_GELUGRAD;                       // an [M][N] fp32 operand, prefetched two tiles ahead
+  constexpr bool GG = EPI == Q8_F32_GELUGRAD;
+  constexpr bool BOTH = EPI == Q8_BOTH || EPI == Q8_BOTH_GELU;                            // pairs AND fp32
+  constexpr bool ACT = EPI == Q8_PAIR_GELU || EPI == Q8_BOTH_GELU;
   constexpr int L = 3;                                // chunks a wait leaves in flight
   constexpr int WFULL = L * GCH;                      // 6
   constexpr int WGUARD = 2 * GCH;                     // a window that may hold a half tile's K-tile (no X1 chunk): W, X0 only
-  constexpr int ST_TILE = 4;                          // stores a wave issues per 32 x 32 MFMA tile (fp32: 2 passes x 2; pairs: 2 passes x (hi, lo))
+  constexpr int ST_TILE = BOTH ? 8 : 4;               // stores a wave issues per 32 x 32 MFMA tile (fp32: 2 passes x 2; pairs: 2 passes x (hi, lo))
   constexpr int ST_FULL = 4 * ST_TILE, ST_HALF = ST_FULL / 2;
   constexpr int S_FULL = ST_FULL < 63 - WFULL ? ST_FULL : 63 - WFULL, S_HALF = ST_HALF < 63 - WFULL ? ST_HALF : 63 - WFULL;
   constexpr int POST = TT_Q8_TAIL ? 3 : 2;            // phases whose window still reaches back across an epilogue
@@ -398,8 +402,9 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
       const int n = nbase + q * CW + (F32OUT ? 4 : 8) * cc;
-      bias_lo[q] = *reinterpret_cast<const f32x4*>(g.bias + n);
-      if constexpr (!F32OUT) bias_hi[q] = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      bias_lo[q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : zero;
+      if constexpr (!F32OUT) bias_hi[q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n + 4) : zero;
     }
     f32x4 rres[3][RES ? NLD : 1];
     auto prefetch = [&](int j, int slot) {
@@ -444,7 +449,12 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
             if constexpr (F32OUT) {
               f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + ((cc ^ (row & (CPRW - 1))) << 4));
               v += bias_lo[q];
-              if constexpr (RES) v += rres[j % 3][q * NRB + i];
+              if constexpr (GG) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast_f(rres[j % 3][q * NRB + i][e]);
+              } else if constexpr (RES) {
+                v += rres[j % 3][q * NRB + i];
+              }
               const unsigned off = ((unsigned)m * (unsigned)g.N + (unsigned)(nbase + q * CW + 4 * cc)) * 4u;
               q8_st128(g.C, out_bytes, off, __builtin_bit_cast(u32x4, v));
             } else {
@@ -453,6 +463,11 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
               v0 += bias_lo[q];
               v1 += bias_hi[q];
               float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+              if constexpr (BOTH) {   // the fp32 value (before the activation): 8 columns = two 16-byte stores
+                const unsigned offc = ((unsigned)m * (unsigned)g.N + (unsigned)(nbase + q * CW + 8 * cc)) * 4u;
+                q8_st128(g.C, out_bytes, offc, __builtin_bit_cast(u32x4, v0));
+                q8_st128(g.C, out_bytes, offc + 16u, __builtin_bit_cast(u32x4, v1));
+              }
               if constexpr (ACT) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
@@ -550,13 +565,24 @@ static int launch_pairs8(const Q8Args& g, hipStream_t s) {
 
 
 // Shape / epilogue eligibility and the work decomposition.  Returns the epilogue kind or -1.
-static int pairs8_plan(bool has_bias, bool has_residual, bool has_y, bool has_pairs, int M, int N, int K, int act, int* ntn_out,
+static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_pre, bool has_gelu_pre, int M, int N, int K, int act, int* ntn_out,
                        long long* ntiles_out, int* ncu_out, int* n_full_out, int* n_half_out) {
-  if (N % 128 != 0 || K % 96 != 0 || M < 256 || !has_bias) return -1;
+  if (N % 128 != 0 || K % 96 != 0 || M < 256) return -1;
   int epi = -1;
-  if (has_y && !has_pairs && !act) epi = has_residual ? Q8_F32_RES : Q8_F32;
-  else if (!has_y && has_pairs && !has_residual) epi = act ? Q8_PAIR_GELU : Q8_PAIR;
+  if (has_gelu_pre) {
+    if (has_y && !has_pairs && !has_pre && !has_residual && !act) epi = Q8_F32_GELUGRAD;
+  } else if (has_pre) {
+    if (!has_y && has_pairs && act && !has_residual) epi = Q8_BOTH_GELU;
+  } else if (has_y && has_pairs) {
+    if (!act && !has_residual) epi = Q8_BOTH;
+  } else if (has_y) {
+    if (!act) epi = has_residual ? Q8_F32_RES : Q8_F32;
+  } else if (has_pairs && !has_residual) {
+    epi = act ? Q8_PAIR_GELU : Q8_PAIR;
+  }
   if (epi < 0) return -1;
+  static const bool no_kept = getenv("TT_PAIRS8_NO_KEPT") != nullptr;   // tuning aid: the round-4 epilogues off (A/B of the kept-frame routes)
+  if (no_kept && epi >= Q8_F32_GELUGRAD) return -1;
   // 32-bit buffer offsets
   if ((long long)M * K * 4 >= 0x7fffffffLL || (long long)N * K * 4 >= 0x7fffffffLL || (long long)M * N * 4 >= 0x7fffffffLL) return -1;
   const int ntm = (M + 255) / 256, ntn = N / 128;
@@ -574,23 +600,25 @@ static int pairs8_plan(bool has_bias, bool has_residual, bool has_y, bool has_pa
   return epi;
 }
 
-int pairs8_would_run(int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int has_pairs) {
+int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, int has_pairs, int has_pre, int has_gelu_pre) {
   int ntn, ncu, n_full, n_half;
   long long ntiles;
-  return pairs8_plan(has_bias != 0, has_residual != 0, has_y != 0, has_pairs != 0, M, N, K, act, &ntn, &ntiles, &ncu, &n_full, &n_half) >= 0;
+  return pairs8_plan(has_residual != 0, has_y != 0, has_pairs != 0, has_pre != 0, has_gelu_pre != 0, M, N, K, act, &ntn, &ntiles, &ncu, &n_full,
+                     &n_half) >= 0;
 }
 
-// Called by tt_linear_fwd_pairs (gemm_planes.hip).  Returns TT_OK after a launch, 1 when the shape / epilogue is not this kernel's (the caller
-// then takes the general kernel), < 0 on a launch error.
-int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, void* y_pairs, int M, int N, int K,
-               int act, hipStream_t s) {
+// Called by linear_pairs_impl (gemm_planes.hip).  Returns TT_OK after a launch, 1 when the shape / epilogue is not this kernel's (the caller
+// then takes the general kernel), < 0 on a launch error.  pre_out: the fp32 pre-activation of a GELU layer (its y must then be pairs only);
+// gelu_pre: the pre-activation whose gelu' multiplies a data-gradient product.
+int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out, void* y_pairs,
+               const float* gelu_pre, int M, int N, int K, int act, hipStream_t s) {
   int ntn, ncu, n_full, n_half;
   long long ntiles;
-  const int epi = pairs8_plan(bias != nullptr, residual != nullptr, y != nullptr, y_pairs != nullptr, M, N, K, act, &ntn, &ntiles, &ncu, &n_full,
-                              &n_half);
+  const int epi = pairs8_plan(residual != nullptr, y != nullptr, y_pairs != nullptr, pre_out != nullptr, gelu_pre != nullptr, M, N, K, act, &ntn,
+                              &ntiles, &ncu, &n_full, &n_half);
   if (epi < 0) return 1;
-  Q8Args g{static_cast<const _Float16*>(x_pairs), static_cast<const _Float16*>(w_pairs), M, N, K, bias, residual, y, static_cast<_Float16*>(y_pairs),
-           ntn, (int)ntiles, ncu, n_full, n_half, q8_order_mode()};
+  Q8Args g{static_cast<const _Float16*>(x_pairs), static_cast<const _Float16*>(w_pairs), M, N, K, bias, gelu_pre ? gelu_pre : residual,
+           pre_out ? pre_out : y, static_cast<_Float16*>(y_pairs), ntn, (int)ntiles, ncu, n_full, n_half, q8_order_mode()};
 #ifdef TT_Q8_ABLATE   // timing-study build only: TT_Q8_DBG selects a crippled instantiation
   {
     const char* e = getenv("TT_Q8_DBG");
@@ -614,6 +642,9 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
     case Q8_F32_RES: return launch_pairs8<Q8_F32_RES>(g, s);
     case Q8_PAIR: return launch_pairs8<Q8_PAIR>(g, s);
     case Q8_PAIR_GELU: return launch_pairs8<Q8_PAIR_GELU>(g, s);
+    case Q8_F32_GELUGRAD: return launch_pairs8<Q8_F32_GELUGRAD>(g, s);
+    case Q8_BOTH: return launch_pairs8<Q8_BOTH>(g, s);
+    case Q8_BOTH_GELU: return launch_pairs8<Q8_BOTH_GELU>(g, s);
     default: return 1;
   }
 }

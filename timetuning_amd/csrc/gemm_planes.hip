@@ -484,9 +484,9 @@ __global__ __launch_bounds__(256) void join_pairs_kernel(const _Float16* __restr
   }
 }
 
-int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, void* y_pairs, int M, int N, int K,
-               int act, hipStream_t s);                                                                               // gemm_pairs8.hip
-int pairs8_would_run(int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int has_pairs);
+int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out, void* y_pairs,
+               const float* gelu_pre, int M, int N, int K, int act, hipStream_t s);                                   // gemm_pairs8.hip
+int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, int has_pairs, int has_pre, int has_gelu_pre);
 
 // ---- transposed pairs: the operands of the backward products in the "f16x3" mode (reduction index contiguous, in pair groups).
 // 64 x 64 tiles through LDS.  out row c holds groups of 32 consecutive r as [hi x 32][lo x 32]; rows R..Rpad-1 are zero (Rpad % 32 == 0).
@@ -808,8 +808,8 @@ static int linear_pairs_impl(const void* x_pairs, const void* w_pairs, const flo
              "linear_pairs: a split-K launch writes plain fp32 partials only");
   hipStream_t s = as_stream(stream);
   static const bool no8 = getenv("TT_PAIRS_NO8") != nullptr;   // tuning aid: the general kernel everywhere
-  if (!no8 && !pre_out && !gelu_pre && splits == 1) {
-    const int rc = pairs8_try(x_pairs, w_pairs, bias, residual, y, y_pairs, M, N, K, act, s);
+  if (!no8 && splits == 1) {
+    const int rc = pairs8_try(x_pairs, w_pairs, bias, residual, y, pre_out, y_pairs, gelu_pre, M, N, K, act, s);
     if (rc <= 0) return rc;
   }
   // the general kernel sees rows of 2 K 16-bit elements in K-tiles of 64 (= one pair group)
@@ -825,8 +825,9 @@ static int linear_pairs_impl(const void* x_pairs, const void* w_pairs, const flo
 
 extern "C" int tt_linear_fwd_pairs_route(int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int has_y_pairs,
                                          int has_pre_out) {
-  if (has_pre_out || getenv("TT_PAIRS_NO8") != nullptr) return 0;
-  return pairs8_would_run(M, N, K, act, has_bias, has_residual, has_y, has_y_pairs) ? 8 : 0;
+  (void)has_bias;
+  if (getenv("TT_PAIRS_NO8") != nullptr) return 0;
+  return pairs8_would_run(M, N, K, act, has_residual, has_y, has_y_pairs, has_pre_out, 0) ? 8 : 0;
 }
 
 extern "C" int tt_linear_fwd_pairs(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out,

@@ -162,9 +162,10 @@ def weight_pairs_t(w: torch.Tensor) -> torch.Tensor:
     return ops.split_pairs_dual(w.detach())[0]
 
 
-def _bwd_both_pairs(dy: torch.Tensor, w: torch.Tensor, xp: torch.Tensor, gelu_pre: Optional[torch.Tensor] = None, need_dx: bool = True):
+def _bwd_both_pairs(dy: torch.Tensor, w: torch.Tensor, xp: torch.Tensor, gelu_pre: Optional[torch.Tensor] = None, need_dx: bool = True,
+                    dw_out=None, db_out=None):
     """(dx, dw, db) of an nn.Linear on pair operands: xp = the layer's input as kept by the forward (row-major pairs [M, 2 K])."""
-    return ops.linear_bwd_pairs(dy, weight_pairs_t(w), ops.transpose_pairs(xp), gelu_pre=gelu_pre, need_dx=need_dx)
+    return ops.linear_bwd_pairs(dy, weight_pairs_t(w), ops.transpose_pairs(xp), gelu_pre=gelu_pre, need_dx=need_dx, dw_out=dw_out, db_out=db_out)
 
 
 def _bwd_weight(dy: torch.Tensor, x: torch.Tensor, need_bias: bool = True):
@@ -180,56 +181,64 @@ def _bwd_data(dy: torch.Tensor, w: torch.Tensor, gelu_pre: Optional[torch.Tensor
     return ops.linear_bwd_data(dy, w, gelu_pre=gelu_pre)
 
 
-def _bwd_both(dy: torch.Tensor, w: torch.Tensor, x: torch.Tensor, gelu_pre: Optional[torch.Tensor] = None):
-    """(dx, dw, db) of an nn.Linear whose input gradient is needed too: one launch for both products in the f32 mode."""
+def _bwd_both(dy: torch.Tensor, w: torch.Tensor, x: torch.Tensor, gelu_pre: Optional[torch.Tensor] = None, dw_out=None, db_out=None):
+    """(dx, dw, db) of an nn.Linear whose input gradient is needed too: one launch for both products in the f32 mode.  ``dw_out`` /
+    ``db_out``: destinations in the exchange's flat buckets (the "bf16" mode's products allocate their own; the exchange copies those in)."""
     if ops.plane_count() == 1:
         dw, db = _bwd_weight(dy, x)
         return _bwd_data(dy, w, gelu_pre), dw, db
-    return ops.linear_bwd(dy, w, x, gelu_pre=gelu_pre)
+    return ops.linear_bwd(dy, w, x, gelu_pre=gelu_pre, dw_out=dw_out, db_out=db_out)
 
 
 def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int, f1: int, grads: Dict[torch.nn.Parameter, torch.Tensor],
-                   need_dx: bool = True, after_mlp=None) -> Optional[torch.Tensor]:
+                   need_dx: bool = True, after_mlp=None, out=None) -> Optional[torch.Tensor]:
     """Backward of one block restricted to frames [f0, f1) of the saved activations.  dx_out [(f1-f0)*N, D]
     is consumed (overwritten).  Writes parameter gradients into ``grads``.  ``after_mlp()`` is called once the MLP's
-    gradients (two thirds of a block's parameters) exist - the data-parallel exchange sends them while the attention half runs."""
+    gradients (two thirds of a block's parameters) exist - the data-parallel exchange sends them while the attention half runs.
+    ``out(param)`` -> a caller-owned destination for that parameter's gradient or None (``GradExchange.out``: the kernels then write the
+    exchange's flat buckets directly)."""
     Fr, N, D = sv["x_in"].shape
     r0, r1 = f0 * N, f1 * N
+    out = out or (lambda p: None)
+    o = lambda lin: dict(dw_out=out(lin.weight), db_out=out(lin.bias))
+    oln = lambda ln: dict(dg_out=out(ln.weight), db_out=out(ln.bias))
     if sv.get("pairs"):   # the "f16x3" mode: the four Linears' backward products on pair operands
-        d_pre, grads[blk.mlp.fc2.weight], grads[blk.mlp.fc2.bias] = _bwd_both_pairs(dx_out, blk.mlp.fc2.weight, sv["ap"][r0:r1], sv["pre"][r0:r1])
-        d_h2, grads[blk.mlp.fc1.weight], grads[blk.mlp.fc1.bias] = _bwd_both_pairs(d_pre, blk.mlp.fc1.weight, sv["h2p"][r0:r1])
+        d_pre, grads[blk.mlp.fc2.weight], grads[blk.mlp.fc2.bias] = _bwd_both_pairs(dx_out, blk.mlp.fc2.weight, sv["ap"][r0:r1], sv["pre"][r0:r1],
+                                                                                     **o(blk.mlp.fc2))
+        d_h2, grads[blk.mlp.fc1.weight], grads[blk.mlp.fc1.bias] = _bwd_both_pairs(d_pre, blk.mlp.fc1.weight, sv["h2p"][r0:r1], **o(blk.mlp.fc1))
         dx_mid, grads[blk.norm2.weight], grads[blk.norm2.bias] = ops.layernorm_bwd(
-            d_h2, sv["x_mid"][r0:r1], blk.norm2.weight, sv["mean2"][r0:r1], sv["rstd2"][r0:r1], dx_accum=dx_out)
+            d_h2, sv["x_mid"][r0:r1], blk.norm2.weight, sv["mean2"][r0:r1], sv["rstd2"][r0:r1], dx_accum=dx_out, **oln(blk.norm2))
         if after_mlp is not None:
             after_mlp()
-        d_att, grads[blk.attn.proj.weight], grads[blk.attn.proj.bias] = _bwd_both_pairs(dx_mid, blk.attn.proj.weight, sv["attp"][r0:r1])
+        d_att, grads[blk.attn.proj.weight], grads[blk.attn.proj.bias] = _bwd_both_pairs(dx_mid, blk.attn.proj.weight, sv["attp"][r0:r1],
+                                                                                        **o(blk.attn.proj))
         dqkv = ops.attention_bwd(sv["qkv"].view(Fr, N, 3 * D)[f0:f1], sv["att"][f0:f1], d_att.view(f1 - f0, N, D), sv["lse"][f0:f1], num_heads)
         d_h1, grads[blk.attn.qkv.weight], grads[blk.attn.qkv.bias] = _bwd_both_pairs(dqkv.view((f1 - f0) * N, 3 * D), blk.attn.qkv.weight,
-                                                                                       sv["h1p"][r0:r1])
+                                                                                       sv["h1p"][r0:r1], **o(blk.attn.qkv))
         dx_in, grads[blk.norm1.weight], grads[blk.norm1.bias] = ops.layernorm_bwd(
-            d_h1, sv["x_in"].view(Fr * N, D)[r0:r1], blk.norm1.weight, sv["mean1"][r0:r1], sv["rstd1"][r0:r1], dx_accum=dx_mid)
+            d_h1, sv["x_in"].view(Fr * N, D)[r0:r1], blk.norm1.weight, sv["mean1"][r0:r1], sv["rstd1"][r0:r1], dx_accum=dx_mid, **oln(blk.norm1))
         return dx_in if need_dx else None
     a, pre, h2 = sv["a"][r0:r1], sv["pre"][r0:r1], sv["h2"][r0:r1]
     # x_out = x_mid + fc2(gelu(fc1(ln2(x_mid))))
-    d_pre, grads[blk.mlp.fc2.weight], grads[blk.mlp.fc2.bias] = _bwd_both(dx_out, blk.mlp.fc2.weight, a, pre)
-    d_h2, grads[blk.mlp.fc1.weight], grads[blk.mlp.fc1.bias] = _bwd_both(d_pre, blk.mlp.fc1.weight, h2)
+    d_pre, grads[blk.mlp.fc2.weight], grads[blk.mlp.fc2.bias] = _bwd_both(dx_out, blk.mlp.fc2.weight, a, pre, **o(blk.mlp.fc2))
+    d_h2, grads[blk.mlp.fc1.weight], grads[blk.mlp.fc1.bias] = _bwd_both(d_pre, blk.mlp.fc1.weight, h2, **o(blk.mlp.fc1))
     dx_mid, grads[blk.norm2.weight], grads[blk.norm2.bias] = ops.layernorm_bwd(
-        d_h2, sv["x_mid"][r0:r1], blk.norm2.weight, sv["mean2"][r0:r1], sv["rstd2"][r0:r1], dx_accum=dx_out)
+        d_h2, sv["x_mid"][r0:r1], blk.norm2.weight, sv["mean2"][r0:r1], sv["rstd2"][r0:r1], dx_accum=dx_out, **oln(blk.norm2))
     if after_mlp is not None:
         after_mlp()
     # x_mid = x_in + proj(attention(qkv(ln1(x_in))))
     att = sv["att"].view(Fr * N, D)[r0:r1]
-    d_att, grads[blk.attn.proj.weight], grads[blk.attn.proj.bias] = _bwd_both(dx_mid, blk.attn.proj.weight, att)
+    d_att, grads[blk.attn.proj.weight], grads[blk.attn.proj.bias] = _bwd_both(dx_mid, blk.attn.proj.weight, att, **o(blk.attn.proj))
     qkv = sv["qkv"].view(Fr, N, 3 * D)[f0:f1]
     # (the "bf16" mode - BASELINE C4's path - runs the attention backward's products on bf16 MFMA like its dgrad / wgrad products)
     dqkv = ops.attention_bwd(qkv, sv["att"][f0:f1], d_att.view(f1 - f0, N, D), sv["lse"][f0:f1], num_heads,
                              bf16_products=ops.plane_count() == 1 and D // num_heads == 64)
     dqkv2 = dqkv.view((f1 - f0) * N, 3 * D)
     h1 = sv["h1"].view(Fr * N, D)[r0:r1]
-    d_h1, grads[blk.attn.qkv.weight], grads[blk.attn.qkv.bias] = _bwd_both(dqkv2, blk.attn.qkv.weight, h1)
+    d_h1, grads[blk.attn.qkv.weight], grads[blk.attn.qkv.bias] = _bwd_both(dqkv2, blk.attn.qkv.weight, h1, **o(blk.attn.qkv))
     x_in = sv["x_in"].view(Fr * N, D)[r0:r1]
     dx_in, grads[blk.norm1.weight], grads[blk.norm1.bias] = ops.layernorm_bwd(
-        d_h1, x_in, blk.norm1.weight, sv["mean1"][r0:r1], sv["rstd1"][r0:r1], dx_accum=dx_mid)
+        d_h1, x_in, blk.norm1.weight, sv["mean1"][r0:r1], sv["rstd1"][r0:r1], dx_accum=dx_mid, **oln(blk.norm1))
     return dx_in if need_dx else None
 
 
@@ -421,13 +430,15 @@ def head_forward(x: torch.Tensor, head, save: Optional[dict] = None) -> torch.Te
     return x
 
 
-def head_backward(dz: torch.Tensor, head, sv: dict, grads) -> torch.Tensor:
+def head_backward(dz: torch.Tensor, head, sv: dict, grads, out=None) -> torch.Tensor:
     lins = head_linears(head)
+    out = out or (lambda p: None)
     d = dz
     for i in range(len(lins) - 1, -1, -1):
         lin = lins[i]
         both = _bwd_both_pairs if sv.get("pairs") else _bwd_both
-        d, grads[lin.weight], grads[lin.bias] = both(d, lin.weight, sv["acts"][i], sv["pres"][i - 1] if i > 0 else None)
+        d, grads[lin.weight], grads[lin.bias] = both(d, lin.weight, sv["acts"][i], sv["pres"][i - 1] if i > 0 else None,
+                                                     dw_out=out(lin.weight), db_out=out(lin.bias))
     return d
 
 
@@ -435,14 +446,15 @@ def head_backward(dz: torch.Tensor, head, sv: dict, grads) -> torch.Tensor:
 # scores / assignment
 # ------------------------------------------------------------------------------------------------
 
-def prototype_scores(z: torch.Tensor, prototypes: torch.Tensor, save: Optional[dict] = None) -> torch.Tensor:
-    """normalize(z) @ prototypes.T (time_tuning.py:130-141)."""
+def prototype_scores(z: torch.Tensor, prototypes: torch.Tensor, save: Optional[dict] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """normalize(z) @ prototypes.T (time_tuning.py:130-141).  ``out``: a caller-owned [rows, K] destination (a row range of the
+    batch + queue score matrix)."""
     if save is not None:
         zn, inv = ops.l2norm_fwd(z, save_inv=True)
         save["zn"], save["inv"] = zn, inv
     else:
         zn = ops.l2norm_fwd(z)
-    return ops.linear_fwd(zn, prototypes)
+    return ops.linear_fwd(zn, prototypes, out=out)
 
 
 def exchange_group():
@@ -478,6 +490,22 @@ def wait_collective(work, kind: str, nbytes: int, device) -> None:
     RCCL_PROFILE.append((kind, int(nbytes), e0, e1))
 
 
+_GATHER_BUFFERS: Dict[tuple, torch.Tensor] = {}
+
+
+def _gather_buffer(rows: int, cols: int, device) -> torch.Tensor:
+    """The all-gather's destination, kept across steps (one per shape and device: a training run has one or two - with / without the
+    queue rows): the exchange allocates nothing per step.  Safe to reuse: the assignment that reads it is consumed (label propagation,
+    cross entropy) before the next step's gather is enqueued on the same stream order."""
+    key = (rows, cols, str(device))
+    buf = _GATHER_BUFFERS.get(key)
+    if buf is None:
+        if len(_GATHER_BUFFERS) >= 8:
+            _GATHER_BUFFERS.clear()
+        buf = _GATHER_BUFFERS[key] = torch.empty((rows, cols), dtype=f32, device=device)
+    return buf
+
+
 def global_sinkhorn_begin(scores_local: torch.Tensor):
     """Starts the all-gather of the local score rows (asynchronous: RCCL moves them on its own stream while the caller
     keeps launching work that does not need the assignment) and returns the context ``global_sinkhorn_end`` consumes."""
@@ -486,7 +514,7 @@ def global_sinkhorn_begin(scores_local: torch.Tensor):
         return (scores_local, None, None)
     W = dist.get_world_size()
     local = scores_local.contiguous()
-    gathered = torch.empty((W * local.shape[0], local.shape[1]), dtype=f32, device=local.device)
+    gathered = _gather_buffer(W * local.shape[0], local.shape[1], local.device)
     try:
         work = dist.all_gather_into_tensor(gathered, local, async_op=True)
     except RuntimeError:  # backends without the flat all-gather (gloo on device tensors, used by the 1-GPU 2-rank test)
@@ -517,20 +545,69 @@ def global_sinkhorn(scores_local: torch.Tensor, rows_out: int, eps: float, iters
     return global_sinkhorn_end(global_sinkhorn_begin(scores_local), rows_out, eps, iters, solver)
 
 
+class GradArena:
+    """Persistent flat fp32 buffer that holds every gradient the exchange sends, laid out in the order the fused backward produces them,
+    one contiguous range per bucket: the backward kernels write their dw / db straight into it (``GradExchange.out``), a bucket's
+    all-reduce runs on a slice of it, and the averaged gradients are handed out as views - no ``torch.cat``, no allocation per step
+    (what DDP's ``gradient_as_bucket_view`` does for the reference's wrapper, models.py:1295).  Built from the first step's buckets;
+    rebuilt if a later step produces a different set or order of gradients (a changed ``requires_grad``)."""
+
+    def __init__(self):
+        self.flat: Optional[torch.Tensor] = None
+        self.slots: Dict[torch.nn.Parameter, torch.Tensor] = {}     # param -> its view of ``flat``
+        self.buckets: List[tuple] = []                                # (start, end, [params])
+
+    def build(self, buckets: List[List[torch.nn.Parameter]], device) -> None:
+        total = sum(p.numel() for keys in buckets for p in keys)
+        self.flat = torch.empty((total,), dtype=f32, device=device)
+        self.slots, self.buckets, off = {}, [], 0
+        for keys in buckets:
+            start = off
+            for p in keys:
+                self.slots[p] = self.flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            self.buckets.append((start, off, list(keys)))
+
+    def reset(self) -> None:
+        self.flat, self.slots, self.buckets = None, {}, []
+
+    def detach_stale_grads(self) -> None:
+        """A ``.grad`` that still aliases the arena (autograd adopts the views it is handed) would be overwritten by the next backward
+        before a caller that accumulates over several backward calls has used it: give such a gradient its own storage first."""
+        for p, view in self.slots.items():
+            if p.grad is not None and p.grad.data_ptr() == view.data_ptr():
+                p.grad = p.grad.clone()
+
+
 class GradExchange:
     """The data-parallel gradient exchange, bucketed in the order the fused backward produces gradients (what DDP's
-    bucketed all-reduce does in the reference, models.py:1295).  ``push(grads)`` flattens the gradients that exist so far
-    and not yet sent into one buffer and starts an asynchronous all-reduce (SUM) on it - RCCL runs it on its own stream
+    bucketed all-reduce does in the reference, models.py:1295).  ``push(grads)`` takes the gradients that exist so far
+    and are not yet sent and starts an asynchronous all-reduce (SUM) on their bucket - RCCL runs it on its own stream
     while the backward of the earlier blocks continues on the compute stream; ``finish(grads)`` sends the rest, waits for
     every bucket and returns the averaged gradients as views into the flat buffers.  Without an initialised process group
     (or with one rank) both are no-ops.  At C2 sizes the four buckets are prototypes + head (2.2 M floats), final norm +
     blocks.11 (1.8 M), the MLP half of blocks.10 (1.2 M, sent from inside that block's backward) and its attention half (0.6 M):
-    only the last one is exposed."""
+    only the last one is exposed.
 
-    def __init__(self):
+    ``arena`` (a ``GradArena`` owned by the model): from the second step on the buckets are slices of ONE persistent buffer that the
+    backward kernels write directly (``out``); the first step - and any step whose gradients differ from the recorded layout -
+    flattens with ``torch.cat`` and records the layout."""
+
+    def __init__(self, arena: Optional[GradArena] = None):
         self.dist = exchange_group()
         self.sent = set()
         self.buckets = []  # (keys, flat, work)
+        self.arena = arena if self.dist is not None else None
+        self.use_arena = self.arena is not None and self.arena.flat is not None
+        if self.use_arena:
+            self.arena.detach_stale_grads()
+        self.recorded: List[List[torch.nn.Parameter]] = []
+
+    def out(self, p) -> Optional[torch.Tensor]:
+        """The destination a backward kernel should write ``p``'s gradient to (its slice of the flat bucket), or None."""
+        if not self.use_arena or p is None:
+            return None
+        return self.arena.slots.get(p)
 
     def push(self, grads: Dict[torch.nn.Parameter, torch.Tensor]) -> None:
         if self.dist is None:
@@ -538,7 +615,22 @@ class GradExchange:
         keys = [k for k in grads if k not in self.sent and k.requires_grad]
         if not keys:
             return
-        flat = torch.cat([grads[k].reshape(-1) for k in keys])
+        self.recorded.append(keys)
+        flat = None
+        if self.use_arena:
+            i = len(self.buckets)
+            same = i < len(self.arena.buckets) and len(self.arena.buckets[i][2]) == len(keys) and all(a is b for a, b in zip(self.arena.buckets[i][2], keys))
+            if same:
+                start, end, _ = self.arena.buckets[i]
+                for k in keys:   # (a kernel that could not take a destination left its own tensor: one small copy, still no cat)
+                    view = self.arena.slots[k]
+                    if grads[k].data_ptr() != view.data_ptr():
+                        view.copy_(grads[k].reshape(view.shape))
+                flat = self.arena.flat[start:end]
+            else:
+                self.use_arena = False   # a different set / order of gradients: this step flattens by hand, the layout is rebuilt at finish
+        if flat is None:
+            flat = torch.cat([grads[k].reshape(-1) for k in keys])
         work = self.dist.all_reduce(flat, async_op=True)
         self.sent.update(keys)
         self.buckets.append((keys, flat, work))
@@ -570,5 +662,7 @@ class GradExchange:
             for k in keys:
                 grads[k] = flat[off:off + k.numel()].view(k.shape)
                 off += k.numel()
+        if self.arena is not None and not self.use_arena and self.buckets and self.buckets[0][1].is_cuda:
+            self.arena.build(self.recorded, self.buckets[0][1].device)   # the layout the next steps write into
         self.buckets = []
         return grads

@@ -161,9 +161,10 @@ def linear_bwd_weight(dy, x, need_bias=True, dw_out=None, db_out=None):
     return dw, db
 
 
-def linear_bwd(dy, w, x, gelu_pre=None, need_bias=True):
+def linear_bwd(dy, w, x, gelu_pre=None, need_bias=True, dw_out=None, db_out=None):
     """Both backward products of an nn.Linear: dx = dy @ w (* gelu'(gelu_pre)), dw = dy.T @ x, db = dy.sum(0) - ONE launch for the
-    two GEMMs where the lean kernels apply (tt_linear_bwd), bit-identical to linear_bwd_data + linear_bwd_weight."""
+    two GEMMs where the lean kernels apply (tt_linear_bwd), bit-identical to linear_bwd_data + linear_bwd_weight.  ``dw_out`` / ``db_out``:
+    caller-owned destinations (the data-parallel exchange's flat gradient buckets)."""
     lib = _lib.load()
     _chk(dy, "dy"); _chk(w, "w"); _chk(x, "x")
     M, N = dy.shape
@@ -171,8 +172,8 @@ def linear_bwd(dy, w, x, gelu_pre=None, need_bias=True):
     assert w.shape[0] == N and tuple(x.shape) == (M, K), (dy.shape, w.shape, x.shape)
     if gelu_pre is not None: _chk(gelu_pre, "gelu_pre")
     dx = torch.empty((M, K), dtype=f32, device=dy.device)
-    dw = torch.empty((N, K), dtype=f32, device=dy.device)
-    db = torch.empty((N,), dtype=f32, device=dy.device) if need_bias else None
+    dw = _chk(dw_out, "dw_out") if dw_out is not None else torch.empty((N, K), dtype=f32, device=dy.device)
+    db = (_chk(db_out, "db_out") if db_out is not None else torch.empty((N,), dtype=f32, device=dy.device)) if need_bias else None
     nb = lib.tt_linear_bwd_weight_workspace_bytes(M, N, K)
     ws = _ws(nb, dy.device)
     e0 = _prof_begin()   # booked as ONE entry: both products (4 M N K flops) and the split-K fold they end in
@@ -307,7 +308,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6, save_stats=False, out=None, drop_fir
     return (y, mean, rstd) if save_stats else y
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, dx_accum=None, drop_first_token=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, dx_accum=None, drop_first_token=False, dg_out=None, db_out=None):
     """Returns (dx, dgamma, dbeta).  dx_accum: tensor to accumulate dx into (residual branch).
     drop_first_token: dy is [F*(N-1), D] against x [F,N,D]; dx is [F,N,D] with zero cls rows."""
     lib = _lib.load()
@@ -321,8 +322,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, dx_accum=None, drop
         dx = torch.zeros_like(x)
     else:
         dx = torch.empty_like(x)
-    dg = torch.empty((D,), dtype=f32, device=x.device) if need_wgrad else None
-    db = torch.empty((D,), dtype=f32, device=x.device) if need_wgrad else None
+    dg = (_chk(dg_out, "dg_out") if dg_out is not None else torch.empty((D,), dtype=f32, device=x.device)) if need_wgrad else None
+    db = (_chk(db_out, "db_out") if db_out is not None else torch.empty((D,), dtype=f32, device=x.device)) if need_wgrad else None
     nb = lib.tt_layernorm_bwd_workspace_bytes(rows, D)
     ws = _ws(nb, x.device)
     _lib.check(lib.tt_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), rows, D,
@@ -872,7 +873,7 @@ def attention_fwd_pairs(qkv_pairs, num_heads: int, out_pairs: bool = True, out_f
     return op, of, lse
 
 
-def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad: Optional[int] = None):
+def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad: Optional[int] = None, colsum_out=None):
     """fp32 [R, C] -> (transposed pairs [C, 2 Rpad], row-major pairs [R, 2 C] or None, column sums [C] or None) in ONE pass
     (tt_split_pairs_dual): what the backward of an nn.Linear needs of its dy."""
     lib = _lib.load()
@@ -881,7 +882,7 @@ def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad:
     rpad = (R + 31) // 32 * 32 if rpad is None else rpad
     t = torch.empty((Cc, 2 * rpad), dtype=f16, device=x.device)
     row = torch.empty((R, 2 * Cc), dtype=f16, device=x.device) if want_row else None
-    sums = torch.empty((Cc,), dtype=f32, device=x.device) if want_colsum else None
+    sums = (_chk(colsum_out, "colsum_out") if colsum_out is not None else torch.empty((Cc,), dtype=f32, device=x.device)) if want_colsum else None
     nb = lib.tt_split_pairs_dual_workspace_bytes(R, Cc, rpad) if want_colsum else 0
     ws = _ws(nb, x.device) if want_colsum else None
     _lib.check(lib.tt_split_pairs_dual(_p(x), _p(t), _p(row), _p(sums), R, Cc, rpad, _p(ws), nb, _stream()), "tt_split_pairs_dual")
@@ -904,7 +905,7 @@ def bwd_pairs_ok(M: int, N: int, K: int) -> bool:
     return N % 64 == 0 and K % 64 == 0
 
 
-def linear_bwd_pairs(dy, wT_pairs, xT_pairs, gelu_pre=None, need_bias: bool = True, need_dx: bool = True):
+def linear_bwd_pairs(dy, wT_pairs, xT_pairs, gelu_pre=None, need_bias: bool = True, need_dx: bool = True, dw_out=None, db_out=None):
     """(dx, dw, db) of an nn.Linear on pair operands: dy fp32 [M,N] is split here (ONE pass: transposed pairs for the weight gradient, row
     pairs for the data gradient, column sums = the bias gradient); wT_pairs [K, 2 N] = the weight transposed in pairs, xT_pairs [K, 2 Mpad] =
     the layer's input transposed in pairs."""
@@ -913,8 +914,8 @@ def linear_bwd_pairs(dy, wT_pairs, xT_pairs, gelu_pre=None, need_bias: bool = Tr
     M, N = dy.shape
     K, Mpad = xT_pairs.shape[0], xT_pairs.shape[1] // 2
     assert wT_pairs.shape == (K, 2 * N) and Mpad >= M, (dy.shape, wT_pairs.shape, xT_pairs.shape)
-    dyT, dy_row, db = split_pairs_dual(dy, want_row=need_dx, want_colsum=need_bias, rpad=Mpad)
-    dw = torch.empty((N, K), dtype=f32, device=dy.device)
+    dyT, dy_row, db = split_pairs_dual(dy, want_row=need_dx, want_colsum=need_bias, rpad=Mpad, colsum_out=db_out)
+    dw = _chk(dw_out, "dw_out") if dw_out is not None else torch.empty((N, K), dtype=f32, device=dy.device)
     nb = lib.tt_linear_bwd_weight_pairs_workspace_bytes(N, K, Mpad)
     ws = _ws(nb, dy.device)
     e0 = _prof_begin()
@@ -924,9 +925,11 @@ def linear_bwd_pairs(dy, wT_pairs, xT_pairs, gelu_pre=None, need_bias: bool = Tr
     if need_dx:
         if gelu_pre is not None: _chk(gelu_pre, "gelu_pre")
         dx = torch.empty((M, K), dtype=f32, device=dy.device)
+        # (label: the persistent kernel takes a data-gradient product under the shape rules of its fp32 (+ operand) epilogues)
+        p8 = PROFILE is not None and lib.tt_linear_fwd_pairs_route(M, K, N, 0, 0, int(gelu_pre is not None), 1, 0, 0) == 8
         e0 = _prof_begin()
         _lib.check(lib.tt_linear_bwd_data_pairs(_p(dy_row), _p(wT_pairs), _p(gelu_pre), _p(dx), M, N, K, _stream()), "tt_linear_bwd_data_pairs")
-        _prof_end(e0, "PAIRS", M, K, N)
+        _prof_end(e0, "PAIRS8" if p8 else "PAIRS", M, K, N)
     return dx, dw, db
 
 

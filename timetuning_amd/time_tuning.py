@@ -421,16 +421,30 @@ class TimeT(nn.Module):
         if self.queue is not None:  # time_tuning.py:250-261 (before scoring, so the batch is also in the queue)
             m = min(bs * 10, self.queue.shape[0])
             perm = hp["queue_perm"]
-            perm = torch.randperm(bs * n) if perm is None else torch.as_tensor(perm)
+            # the reference draws the permutation from torch's CPU generator (time_tuning.py:259) - kept, for seed-for-seed reproducibility -
+            # into a persistent PINNED buffer, and its first m entries travel to the device asynchronously (no pageable staging copy)
+            pin = getattr(self, "_queue_perm_pinned", None)
+            if pin is None or pin.numel() != bs * n:
+                pin = self._queue_perm_pinned = torch.empty(bs * n, dtype=torch.int64).pin_memory() if dev.type == "cuda" else torch.empty(bs * n, dtype=torch.int64)
+                self._queue_perm_dev = torch.empty(bs * n, dtype=torch.int64, device=dev)
+            if perm is None:
+                torch.randperm(bs * n, out=pin)
+            else:
+                pin.copy_(torch.as_tensor(perm).to(torch.int64).reshape(-1)[: bs * n])
+            idx = self._queue_perm_dev[:m]
+            idx.copy_(pin[:m], non_blocking=True)
             foreign = self._queue_seen is None or self._queue_seen != self._queue_signature()
             if foreign:
                 self.queue_is_full()   # somebody else wrote the queue: read its state from the device before this push hides it
-            ops.queue_push_(self.queue, z_q, perm[:m].to(device=dev, dtype=torch.int64))
+            ops.queue_push_(self.queue, z_q, idx)
             self._queue_pushed(m)
 
-        scores_q = engine.prototype_scores(z_q, protos_q)
-        if self.queue_is_full():
-            scores_q = torch.cat([scores_q, engine.prototype_scores(self.queue, protos_q)], dim=0)
+        if self.queue_is_full():   # time_tuning.py:207-211: batch rows, then the queue rows - both products write ONE score matrix
+            scores_q = torch.empty((z_q.shape[0] + self.queue.shape[0], protos_q.shape[0]), dtype=torch.float32, device=dev)
+            engine.prototype_scores(z_q, protos_q, out=scores_q[: z_q.shape[0]])
+            engine.prototype_scores(self.queue, protos_q, out=scores_q[z_q.shape[0]:])
+        else:
+            scores_q = engine.prototype_scores(z_q, protos_q)
         gather = engine.global_sinkhorn_begin(scores_q)  # W > 1: the score rows travel while the target head runs
 
         # ---- target frames: head + scores (with grad)
@@ -455,19 +469,28 @@ class TimeT(nn.Module):
 
         # ---- backward on the target frames only
         grads: Dict[nn.Parameter, torch.Tensor] = {}
-        exchange = engine.GradExchange()  # the data-parallel exchange: bucketed all-reduce (mean) over RCCL, overlapped with backward
+        # the data-parallel exchange: bucketed all-reduce (mean) over RCCL, overlapped with backward; from the second step on the backward
+        # kernels write their dw / db straight into its persistent flat buckets (``exchange.out``)
+        if getattr(self, "_grad_arena", None) is None:
+            self._grad_arena = engine.GradArena()
+        exchange = engine.GradExchange(self._grad_arena)
+        out = exchange.out
         prescaled = exchange.prescale_(dscores)   # 1 / W once, on the 5 MB loss gradient, instead of on every bucket
-        grads[self.prototypes], _ = ops.linear_bwd_weight(dscores, sv_sc["zn"], need_bias=False)
+        grads[self.prototypes], _ = ops.linear_bwd_weight(dscores, sv_sc["zn"], need_bias=False, dw_out=out(self.prototypes))
         dz = ops.l2norm_bwd(ops.linear_bwd_data(dscores, self.prototypes.data), sv_sc["zn"], sv_sc["inv"])
         if use_mask:
             ops.scale_rows_(dz, mask_tgt)  # backward of features * mask
-        d_feats = engine.head_backward(dz, fe.head, sv_head, grads) if fe.head is not None else dz
+        d_feats = engine.head_backward(dz, fe.head, sv_head, grads, out=out) if fe.head is not None else dz
         exchange.push(grads)  # prototypes + head
-        if train_ids:
-            wg = vit.norm.weight.requires_grad
-            dx, dg, db = ops.layernorm_bwd(d_feats, tok_hi, vit.norm.weight, mean_f, rstd_f, need_wgrad=wg, drop_first_token=True)
+        #  the final norm's backward also runs when ONLY that norm is trainable, and its parameter gradients are built when
+        # either of them asks for one
+        wg = vit.norm.weight.requires_grad or vit.norm.bias.requires_grad
+        if train_ids or wg:
+            dx, dg, db = ops.layernorm_bwd(d_feats, tok_hi, vit.norm.weight, mean_f, rstd_f, need_wgrad=wg, drop_first_token=True,
+                                           dg_out=out(vit.norm.weight) if wg else None, db_out=out(vit.norm.bias) if wg else None)
             if wg:
                 grads[vit.norm.weight], grads[vit.norm.bias] = dg, db
+        if train_ids:
             dx = dx.view(bs * N, D)
             # kept activations: the target frames only (two-stream pass: rows [0, bs)) or all frames (rows [f0, Fr))
             kept = save[first]["x_in"].shape[0]
@@ -476,7 +499,7 @@ class TimeT(nn.Module):
                 # the LAST block of the backward has nothing after it to hide its bucket behind: its MLP gradients (two thirds of
                 # the block) leave as soon as they exist, so only the attention third is exposed
                 dx = engine.block_backward(dx, vit.blocks[i], vit.num_heads, save[i], b0, b1, grads, need_dx=i > first,
-                                           after_mlp=(lambda: exchange.push(grads)) if i == first else None)
+                                           after_mlp=(lambda: exchange.push(grads)) if i == first else None, out=out)
                 if i > first:
                     exchange.push(grads)  # this block's gradients travel while the next block's backward runs
         grads = {p: g for p, g in grads.items() if p.requires_grad}
