@@ -199,3 +199,21 @@ def test_hip_pair_ops_equal_their_cpu_twins():
     a, c = run(hip, "tt_", True), run(twin, "tt_cpu_", False)
     assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and torch.equal(a[5], c[5])          # conversions and transposes: bit for bit
     assert rel_err(a[2], c[2]) < TOL_F32 and rel_err(a[4], c[4]) < TOL_F32 and rel_err(join(a[3]), join(c[3])) < TOL_F32
+
+
+def test_pairs8_load_part_orders_give_the_same_bits():
+    """TT_Q8_ORDER only moves a wave's DMA instructions relative to its fragment reads inside a phase of gemm_pairs8_kernel: every order
+    must leave the same bits (a hazard in the counted-vmcnt schedule would show here or as a run-to-run difference)."""
+    from timetuning_amd import hip_ops as ops
+
+    M, N, K = 25216, 384, 384
+    xp, wp = ops.split_pairs(rnd("ord.x", M, K).cuda()), ops.split_pairs(rnd("ord.w", N, K, scale=0.05).cuda())
+    b = rnd("ord.b", N).cuda()
+    outs = []
+    try:
+        for order in (3, 0, 1, 2):
+            ops.set_tuning_knob("TT_Q8_ORDER", order)
+            outs.append(ops.linear_fwd_pairs(xp, wp, b, act=1, out_f32=False, out_pairs=True)["pairs"].clone())
+    finally:
+        ops.set_tuning_knob("TT_Q8_ORDER", 3)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])

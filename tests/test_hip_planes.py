@@ -176,15 +176,17 @@ def test_linear_planes8_every_epilogue(planes, case, monkeypatch):
             o = ops.linear_fwd_planes(xp, wp, b, residual=rr, act=e["act"], out_f32=e["po"] == 0, out_planes=e["po"], out=rr)
             return o["y"] if e["po"] == 0 else o["planes"]
 
-        monkeypatch.delenv("TT_PLANES_VARIANT", raising=False)
+        ops.set_tuning_knob("TT_PLANES_VARIANT", 0)
         assert lib.tt_linear_fwd_planes_route(planes, M, N, K, e["act"], 1, int(e["res"]), int(e["po"] == 0), e["po"], 0) == 8, (case, e)
         new = run()
         again = run()
         assert torch.equal(new, again), (case, e)
-        monkeypatch.setenv("TT_PLANES_VARIANT", "10")
-        assert lib.tt_linear_fwd_planes_route(planes, M, N, K, e["act"], 1, int(e["res"]), int(e["po"] == 0), e["po"], 0) == 0
-        old = run()
-        monkeypatch.delenv("TT_PLANES_VARIANT")
+        try:
+            ops.set_tuning_knob("TT_PLANES_VARIANT", 10)   # (the library reads its knobs once; tests flip them through the setter)
+            assert lib.tt_linear_fwd_planes_route(planes, M, N, K, e["act"], 1, int(e["res"]), int(e["po"] == 0), e["po"], 0) == 0
+            old = run()
+        finally:
+            ops.set_tuning_knob("TT_PLANES_VARIANT", 0)
         want = torch.nn.functional.gelu(ref) if e["act"] else ref
         if e["res"]:
             want = want + r.double()[idx]
@@ -195,7 +197,7 @@ def test_linear_planes8_every_epilogue(planes, case, monkeypatch):
         if planes == 1 and not e["act"]:
             assert torch.equal(a, c), (case, e)                            # same products in the same order: identical bits
         else:
-            lim = 1e-2 if planes == 1 else 2e-6                            # P = 1 GELU: tanh form vs erf, then bf16 rounding
+            lim = 4e-3 if planes == 1 else 2e-6                            # P = 1 GELU: the SAME tanh form on both routes (round 4); at most a flipped bf16 rounding (2^-8)
             assert ((a - c).abs().max() / c.abs().max()).item() < lim, (case, e)
 
 
@@ -247,7 +249,7 @@ def test_patch_embed_on_bf16_operands(Fr, D, route):
 
 @pytest.mark.parametrize("planes", [1, 3])
 def test_planes8_load_part_orders_give_the_same_bits(planes, monkeypatch):
-    """TT_P8_ORDER only moves a wave's DMA instructions relative to its fragment reads inside a phase (gemm_planes8.hip `reads_first`):
+    """TT_P8_ORDER (a tuning knob: ops.set_tuning_knob) only moves a wave's DMA instructions relative to its fragment reads inside a phase (gemm_planes8.hip `reads_first`):
     every order must leave the same bits; the default (3) is checked against fp64 by test_linear_planes8_every_epilogue."""
     from timetuning_amd import hip_ops as ops
 
@@ -256,9 +258,12 @@ def test_planes8_load_part_orders_give_the_same_bits(planes, monkeypatch):
     xp, wp = ops.split_planes(rnd("ord.x", M, K).cuda(), planes), ops.split_planes(rnd("ord.w", N, K, scale=0.05).cuda(), planes)
     b = rnd("ord.b", N).cuda()
     outs = []
-    for order in ("3", "0", "1", "2"):
-        monkeypatch.setenv("TT_P8_ORDER", order)
-        outs.append(ops.linear_fwd_planes(xp, wp, b, act=1, out_f32=False, out_planes=planes)["planes"].clone())
+    try:
+        for order in (3, 0, 1, 2):
+            ops.set_tuning_knob("TT_P8_ORDER", order)
+            outs.append(ops.linear_fwd_planes(xp, wp, b, act=1, out_f32=False, out_planes=planes)["planes"].clone())
+    finally:
+        ops.set_tuning_knob("TT_P8_ORDER", 3)
     assert all(torch.equal(o, outs[0]) for o in outs[1:])
 
 

@@ -47,6 +47,7 @@ class LinearParams(C.Structure):
 SIGNATURES = {
     "tt_last_error": (C.c_char_p, []),
     "tt_abi_version": (c_i, []),
+    "tt_set_tuning_knob": (c_i, [C.c_char_p, c_i]),
     "tt_device_info": (c_i, [C.c_char_p, c_i]),
     "tt_linear_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "tt_linear_bwd_data": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp]),

@@ -35,6 +35,9 @@ inline hipStream_t as_stream(tt_stream_t s) { return reinterpret_cast<hipStream_
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int device_cu_count();   // core.cpp: multiprocessors of the CURRENT device (looked up once per device id)
+// core.cpp: tuning knobs, read once from the environment (TT_<NAME>) and settable through tt_set_tuning_knob (A/B tools, tests)
+enum { KNOB_PLANES_VARIANT = 0, KNOB_P8_ORDER, KNOB_P8_NO_HALF, KNOB_P8_CLOCK_PRINT, KNOB_Q8_ORDER, KNOB_PAIRS_NO8, KNOB_PAIRS8_NO_KEPT, KNOB_COUNT };
+int tuning_knob(int which);
 
 // ---- device helpers -------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -1,6 +1,9 @@
 // Error reporting and device query for libtimetuning_hip.so.
 #include "common.hpp"
 #include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
 
 namespace tt {
 static thread_local char g_err[512] = "";
@@ -25,7 +28,37 @@ int device_cu_count() {
   cache[dev].store(n, std::memory_order_relaxed);
   return n;
 }
+
+// ---- tuning knobs: read ONCE from the environment into atomics - a launch path never calls getenv (not safe against a
+// concurrent setenv from another Python thread, and a knob must not flip under a production run) - with an explicit setter for the A/B
+// tools and tests that compare settings inside one process.
+static const char* const kKnobNames[KNOB_COUNT] = {"TT_PLANES_VARIANT", "TT_P8_ORDER", "TT_P8_NO_HALF", "TT_P8_CLOCK_PRINT",
+                                                   "TT_Q8_ORDER",       "TT_PAIRS_NO8", "TT_PAIRS8_NO_KEPT"};
+static const int kKnobDefaults[KNOB_COUNT] = {0, 3, 0, 0, 3, 0, 0};
+static std::atomic<int> g_knobs[KNOB_COUNT];
+static std::once_flag g_knobs_once;
+static void knobs_init() {
+  for (int i = 0; i < KNOB_COUNT; ++i) {
+    const char* e = getenv(kKnobNames[i]);
+    g_knobs[i].store(e ? (*e ? atoi(e) : 1) : kKnobDefaults[i], std::memory_order_relaxed);
+  }
+}
+int tuning_knob(int which) {
+  std::call_once(g_knobs_once, knobs_init);
+  return g_knobs[which].load(std::memory_order_relaxed);
+}
 }  // namespace tt
+
+extern "C" int tt_set_tuning_knob(const char* name, int value) {
+  std::call_once(tt::g_knobs_once, tt::knobs_init);
+  for (int i = 0; i < tt::KNOB_COUNT; ++i)
+    if (name && strcmp(name, tt::kKnobNames[i]) == 0) {
+      tt::g_knobs[i].store(value, std::memory_order_relaxed);
+      return TT_OK;
+    }
+  tt::set_error("set_tuning_knob: unknown knob '%s'", name ? name : "(null)");
+  return TT_EINVAL;
+}
 
 extern "C" const char* tt_last_error(void) { return tt::g_err; }
 extern "C" int tt_abi_version(void) { return 5; }   // 5: the fp16-pair entry points (tt_*_pairs*), tt_vit_params.planes == 2; 4: tt_vit_params.patch_wp; 3: the coarse entry points (tt_vit_forward, ...) and their parameter structs

@@ -76,6 +76,9 @@ __device__ __forceinline__ void q8_wait_vmcnt() {
 #ifndef TT_Q8_TAIL
 #define TT_Q8_TAIL 0
 #endif
+#if TT_Q8_TAIL != 0
+#error "TT_Q8_TAIL was a round-4 timing study (profiles/r04_q8_dma_placement_ab.txt: no gain / 2x slower); the half-item schedule no longer supports it"
+#endif
 // DBG (timing studies only; the shipped instantiations are DBG = 0), a bit mask: 1 no MFMAs, 2 no LDS-DMA, 8 no epilogue
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
@@ -107,6 +110,9 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
   static_assert(RING_B + 8 * SCR_B <= 160 * 1024 && CW == 16, "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem[160 * 1024];
 
+#ifdef TT_Q8_CLOCK   // diagnostic build only: the clock the chip holds under this kernel (s_memtime ticks per 100 MHz s_memrealtime tick)
+  const unsigned long long clk0_t = __builtin_amdgcn_s_memtime(), clk0_r = __builtin_amdgcn_s_memrealtime();
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool grp1 = wave >= 4;
@@ -245,7 +251,10 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
   auto phase = [&](auto s_c, auto ha_c) {
     constexpr int S = decltype(s_c)::value, HA = decltype(ha_c)::value;
     constexpr int base = S * SLOT_B;
-    const bool work = !(HA == 1 && c_half);   // a half item has no second x half
+    // a half item has no second x half: its (t, 1) phases only issue DMA and synchronise.  (Dropping them altogether - one phase per
+    // K-tile - was tried in round 4 and is a WAR race on the 3-slot ring: consecutive K-tiles would be ONE phase apart, and the DMA into
+    // slot (t + 2) mod 3 must trail the last read of K-tile t - 1 by two.)
+    const bool work = !(HA == 1 && c_half);
     auto frag_reads = [&]() {
       if (work) {
         if constexpr (HA == 0) {
@@ -322,6 +331,31 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     Q8_STAMP_NOWAIT(ts5);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DBG & 16) {
+      // timing study (wrong numbers): every 32x32x16 MFMA replaced by TWO 16x16x32 MFMAs on the same operand registers - the same issue
+      // cycles and flops - to see what the MFMA shape alone does to the clock the chip holds under this kernel ('DVFS give-back' item 7)
+      if (work) {
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        auto two16 = [&](const f16x8& a, const f16x8& b, f32x16& c) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            f32x4_ c4 = {c[8 * q], c[8 * q + 1], c[8 * q + 2], c[8 * q + 3]};
+            c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c4, 0, 0, 0);
+            c[8 * q] = c4[0]; c[8 * q + 1] = c4[1]; c[8 * q + 2] = c4[2]; c[8 * q + 3] = c4[3];
+          }
+        };
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            two16(Wf[ks], Xf[mt][ks], a1[HA][mt]);
+            two16(Wf[ks], Xf[mt][2 + ks], a2[HA][mt]);
+          }
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) two16(Wf[2 + ks], Xf[mt][ks], a2[HA][mt]);
+        }
+      }
+    } else
     if (work && !(DBG & 1)) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -533,6 +567,12 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
     if (!grp1) __builtin_amdgcn_s_barrier();  // realign: both groups run their epilogues at the same time
     epilogue(row0, n0, c_half);
   }
+#ifdef TT_Q8_CLOCK
+  if (g.order_mode >= 100 && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 101 || blockIdx.x == 202)) {
+    const unsigned long long dt = __builtin_amdgcn_s_memtime() - clk0_t, dr = __builtin_amdgcn_s_memrealtime() - clk0_r;
+    printf("q8 clock: block %d  %llu cycles in %llu x 10 ns = %.3f GHz\n", (int)blockIdx.x, dt, dr, (double)dt / (double)dr * 0.1);
+  }
+#endif
 #ifdef TT_Q8_STAMP
   if (g.order_mode >= 100 && lane == 0 && (wave == 0 || wave == 2 || wave == 5 || wave == 7) && blockIdx.x == 3) {
     const unsigned long long dt = __builtin_amdgcn_s_memtime() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
@@ -546,15 +586,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
 #endif
 }
 
-static int q8_order_mode() {
-#if defined(TT_Q8_STAMP) || defined(TT_Q8_ABLATE)   // timing-study builds: read per call (A/B in one process)
-  const char* e = getenv("TT_Q8_ORDER");
-  return e ? atoi(e) : 3;
-#else
-  static const int mode = [] { const char* e = getenv("TT_Q8_ORDER"); return e ? atoi(e) : 3; }();
-  return mode;
-#endif
-}
+static int q8_order_mode() { return tuning_knob(KNOB_Q8_ORDER); }   // (+100: the stamp builds print)
 
 template <int EPI, int DBG = 0>
 static int launch_pairs8(const Q8Args& g, hipStream_t s) {
@@ -581,8 +613,7 @@ static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_p
     epi = act ? Q8_PAIR_GELU : Q8_PAIR;
   }
   if (epi < 0) return -1;
-  static const bool no_kept = getenv("TT_PAIRS8_NO_KEPT") != nullptr;   // tuning aid: the round-4 epilogues off (A/B of the kept-frame routes)
-  if (no_kept && epi >= Q8_F32_GELUGRAD) return -1;
+  if (tuning_knob(KNOB_PAIRS8_NO_KEPT) != 0 && epi >= Q8_F32_GELUGRAD) return -1;   // tuning aid: A/B of the kept-frame routes
   // 32-bit buffer offsets
   if ((long long)M * K * 4 >= 0x7fffffffLL || (long long)N * K * 4 >= 0x7fffffffLL || (long long)M * N * 4 >= 0x7fffffffLL) return -1;
   const int ntm = (M + 255) / 256, ntn = N / 128;
@@ -591,7 +622,7 @@ static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_p
   if (ntiles < ncu_dev / 2) return -1;   // a persistent grid that cannot fill the chip: the small-tile kernel does better
   int ncu = (int)(ntiles < ncu_dev ? ntiles : ncu_dev), n_full = 0, n_half = 0;
   const long long R = ntiles / ncu_dev, rem = ntiles - R * ncu_dev;
-  if (rem > 0 && 2 * rem <= ncu_dev) {
+  if (rem > 0 && 2 * rem <= ncu_dev && tuning_knob(KNOB_P8_NO_HALF) == 0) {
     ncu = ncu_dev;
     n_full = (int)R;
     n_half = (int)(2 * rem);
@@ -632,6 +663,7 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
     if (dbg == 10) return launch_pairs8<EV, 10>(g, s);   \
     if (dbg == 3) return launch_pairs8<EV, 3>(g, s);     \
     if (dbg == 11) return launch_pairs8<EV, 11>(g, s);   \
+    if (dbg == 16) return launch_pairs8<EV, 16>(g, s);   \
   }
     Q8_DBG_CASE(Q8_F32) Q8_DBG_CASE(Q8_F32_RES) Q8_DBG_CASE(Q8_PAIR_GELU)
 #undef Q8_DBG_CASE

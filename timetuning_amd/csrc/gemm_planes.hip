@@ -325,8 +325,12 @@ __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(Pl
           *reinterpret_cast<float4*>(g.pre_out + off + 4) = *reinterpret_cast<const float4*>(v + 4);
         }
         if (g.act == 1) {
+          // ONE GELU formula per route of the "bf16" mode: a bf16-only output (P = 1, no fp32 y, no pre-activation - the
+          // frozen blocks' fc1) takes the tanh form here exactly as gemm_planes8_kernel<1> does, so the numbers do not depend on which of
+          // the two kernels the tile count selects; every fp32-accurate output keeps the erf form.
+          const bool tanh_form = P == 1 && !PAIR && g.C == nullptr && g.pre_out == nullptr;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
+          for (int e = 0; e < 8; ++e) v[e] = tanh_form ? gelu_bf16_f(v[e]) : gelu_fast_f(v[e]);
         }
         if (g.gelu_pre) {
           float pr[8];
@@ -647,8 +651,7 @@ static int linear_planes_impl(const void* x_planes, long long x_plane_stride, co
 
 extern "C" int tt_linear_fwd_planes_route(int planes, int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int y_nplanes,
                                           int has_pre_out) {
-  const char* e = getenv("TT_PLANES_VARIANT");
-  if ((e && atoi(e) != 0) || has_pre_out) return 0;
+  if (tuning_knob(KNOB_PLANES_VARIANT) != 0 || has_pre_out) return 0;
   return planes8_would_run(planes, M, N, K, act, has_bias, has_residual, has_y, y_nplanes) ? 8 : 0;
 }
 
@@ -715,7 +718,7 @@ static int linear_planes_impl(const void* x_planes, long long x_plane_stride, co
   PlaneArgs g{static_cast<const __bf16*>(x_planes), static_cast<const __bf16*>(w_planes), x_plane_stride, w_plane_stride, M, N, K, bias, residual, y,
               pre_out, static_cast<__bf16*>(y_planes), y_plane_stride, y_nplanes, act, gelu_pre, splits, split_stride};
   hipStream_t s = as_stream(stream);
-  const int variant = [] { const char* e = getenv("TT_PLANES_VARIANT"); return e ? atoi(e) : 0; }();  // tuning aid (read per call: A/B in one process)
+  const int variant = tuning_knob(KNOB_PLANES_VARIANT);   // tuning aid (tt_set_tuning_knob: A/B in one process)
   // whole-tile forward products on a grid that fills the chip: the persistent 8-phase kernel (gemm_planes8.hip)
   if (variant == 0 && !pre_out && !gelu_pre && splits == 1) {
     const int rc = planes8_try(x_planes, x_plane_stride, w_planes, w_plane_stride, planes, bias, residual, y, y_planes, y_plane_stride, y_nplanes, M, N,
@@ -807,7 +810,7 @@ static int linear_pairs_impl(const void* x_pairs, const void* w_pairs, const flo
   TT_REQUIRE(splits >= 1 && (splits == 1 || (y && !bias && !residual && !pre_out && !y_pairs && !act && !gelu_pre)),
              "linear_pairs: a split-K launch writes plain fp32 partials only");
   hipStream_t s = as_stream(stream);
-  static const bool no8 = getenv("TT_PAIRS_NO8") != nullptr;   // tuning aid: the general kernel everywhere
+  const bool no8 = tuning_knob(KNOB_PAIRS_NO8) != 0;   // tuning aid: the general kernel everywhere
   if (!no8 && splits == 1) {
     const int rc = pairs8_try(x_pairs, w_pairs, bias, residual, y, pre_out, y_pairs, gelu_pre, M, N, K, act, s);
     if (rc <= 0) return rc;
@@ -826,7 +829,7 @@ static int linear_pairs_impl(const void* x_pairs, const void* w_pairs, const flo
 extern "C" int tt_linear_fwd_pairs_route(int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int has_y_pairs,
                                          int has_pre_out) {
   (void)has_bias;
-  if (getenv("TT_PAIRS_NO8") != nullptr) return 0;
+  if (tuning_knob(KNOB_PAIRS_NO8) != 0) return 0;
   return pairs8_would_run(M, N, K, act, has_residual, has_y, has_y_pairs, has_pre_out, 0) ? 8 : 0;
 }
 

@@ -721,10 +721,7 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
 #endif
 }
 
-static int p8_order_mode() {   // read per call: tools A/B the orders in one process
-  const char* e = getenv("TT_P8_ORDER");
-  return e ? atoi(e) : 3;
-}
+static int p8_order_mode() { return tuning_knob(KNOB_P8_ORDER); }   // (tools A/B the orders in one process through tt_set_tuning_knob)
 
 template <int P, int EPI, int DBG = 0>
 static int launch_planes8(const P8Args& g, hipStream_t s) {
@@ -750,18 +747,13 @@ static int planes8_plan(long long x_plane_stride, long long w_plane_stride, int 
   if ((long long)M * N * 4 >= 0x7fffffffLL) return -1;
   const int ntm = (M + 255) / 256, ntn = N / BN;
   const long long ntiles = (long long)ntm * ntn;
-  static const int ncu_dev = [] {
-    hipDeviceProp_t p;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
-    return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-  }();
+  const int ncu_dev = device_cu_count();   // (of the CURRENT device)
   if (ntiles < ncu_dev / 2) return -1;   // a persistent grid that cannot fill the chip: the small-tile kernel does better
   // decomposition: R whole rounds of tiles over the CUs; the r tiles left over are cut into 2 r half tiles (one per workgroup)
   // when that is a shorter tail than another whole round (2 r <= CUs), else all tiles are dealt round-robin
   int ncu = (int)(ntiles < ncu_dev ? ntiles : ncu_dev), n_full = 0, n_half = 0;
   const long long R = ntiles / ncu_dev, rem = ntiles - R * ncu_dev;
-  const bool no_half = getenv("TT_P8_NO_HALF") != nullptr;   // tuning aid (read per call: A/B in one process)
+  const bool no_half = tuning_knob(KNOB_P8_NO_HALF) != 0;   // tuning aid
   if (!no_half && rem > 0 && 2 * rem <= ncu_dev) {
     ncu = ncu_dev;
     n_full = (int)R;
@@ -792,7 +784,7 @@ int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_pl
                                                  y_planes ? y_nplanes : 0, M, N, K, act, &ntn, &ntiles, &ncu, &n_full, &n_half);
   if (epi < 0) return 1;
   P8Args g{static_cast<const __bf16*>(x_planes), static_cast<const __bf16*>(w_planes), x_plane_stride, w_plane_stride, M, N, K, bias, residual, y,
-           static_cast<__bf16*>(y_planes), y_plane_stride, ntn, (int)ntiles, ncu, n_full, n_half, getenv("TT_P8_CLOCK_PRINT") != nullptr, p8_order_mode()};
+           static_cast<__bf16*>(y_planes), y_plane_stride, ntn, (int)ntiles, ncu, n_full, n_half, tuning_knob(KNOB_P8_CLOCK_PRINT), p8_order_mode()};
 #ifdef TT_P8_ABLATE   // timing-study build only (tools/build_variant.sh -DTT_P8_ABLATE): TT_P8_DBG selects a crippled instantiation
   {
     const char* e = getenv("TT_P8_DBG");

@@ -63,6 +63,11 @@ def set_gemm_precision(mode: str) -> None:
     _precision = mode
 
 
+def set_tuning_knob(name: str, value: int) -> None:
+    """A dispatcher tuning knob (``TT_<NAME>``; the library reads them once from the environment): A/B tools and tests only."""
+    _lib.check(_lib.load().tt_set_tuning_knob(name.encode(), int(value)), "tt_set_tuning_knob")
+
+
 def get_gemm_precision() -> str:
     return _precision
 

@@ -7,8 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from timetuning_amd import hip_ops as ops
 
+knob = ops.set_tuning_knob   # the library reads its tuning knobs once: flip them through its setter
+
 def run(xp, wp, b, res, act, po, variant):
-    os.environ["TT_PLANES_VARIANT"] = str(variant)
+    knob("TT_PLANES_VARIANT", variant)
     r = res.clone() if res is not None else None
     o = ops.linear_fwd_planes(xp, wp, b, residual=r, act=act, out_f32=(po == 0 or res is not None), out_planes=po, out=r)
     return o
@@ -72,14 +74,14 @@ def timeit():
             ts = {k: [] for k in variants}
             for rd in range(10):
                 for k, env in variants.items():
-                    os.environ.pop("TT_P8_NO_HALF", None)
-                    os.environ.update(env)
+                    knob("TT_P8_NO_HALF", 0)
+                    for name_, val_ in env.items(): knob(name_, int(val_))
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(10): ops.linear_fwd_planes(xp, wp, b, residual=r, act=act, out_f32=(po == 0 or res), out_planes=po, out=r)
                     e1.record(); torch.cuda.synchronize()
                     if rd >= 3: ts[k].append(e0.elapsed_time(e1) * 1e2)
-            os.environ.pop("TT_P8_NO_HALF", None)
+            knob("TT_P8_NO_HALF", 0)
             nprod = P * (P + 1) // 2
             print(f"P={P} {name:5s} N={N:5d} K={K:5d}: " + " | ".join(f"{k} {statistics.median(v):7.1f} us ({2.0 * M * N * K * nprod / statistics.median(v) / 1e6:5.0f})" for k, v in ts.items()) + "   (TF/s raw bf16)", flush=True)
 

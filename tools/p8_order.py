@@ -4,6 +4,9 @@ import ctypes as C, os, statistics, sys, torch
 vp, ll, i32 = C.c_void_p, C.c_longlong, C.c_int
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = C.CDLL(os.path.join(root, "timetuning_amd", "libtimetuning_hip.so"))
+def knob(name, value):   # the library reads its tuning knobs once: flip them through its setter
+    lib.tt_set_tuning_knob.argtypes = [C.c_char_p, C.c_int]
+    assert lib.tt_set_tuning_knob(name.encode(), int(value)) == 0
 lib.tt_linear_fwd_planes.restype = C.c_int
 lib.tt_linear_fwd_planes.argtypes = [vp, ll, vp, ll, i32, vp, vp, vp, vp, vp, ll, i32, i32, i32, i32, i32, vp]
 lib.tt_split_planes.restype = C.c_int
@@ -25,7 +28,7 @@ for P, M, N, K, act, po, res, name in cases:
     outs = {}
     for rd in range(8):
         for d in ORDERS:
-            os.environ["TT_P8_ORDER"] = str(d)
+            knob("TT_P8_ORDER", d)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
@@ -36,7 +39,7 @@ for P, M, N, K, act, po, res, name in cases:
             if rd >= 2: ts[d].append(e0.elapsed_time(e1) * 1e2)
     if not res:   # same bits whatever the order
         for d in ORDERS:
-            os.environ["TT_P8_ORDER"] = str(d)
+            knob("TT_P8_ORDER", d)
             lib.tt_linear_fwd_planes(x.data_ptr(), M * K, w.data_ptr(), N * K, P, b.data_ptr(), None, y.data_ptr() if y is not None else None, None,
                                      yp.data_ptr() if po else None, M * N, po, M, N, K, act, st)
             torch.cuda.synchronize(); outs[d] = (y if y is not None else yp).clone()

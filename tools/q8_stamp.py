@@ -5,6 +5,9 @@ one workgroup; printed by the last of a burst of back-to-back launches.  The sta
 import ctypes as C, os, sys, torch
 vp, ll, i32 = C.c_void_p, C.c_longlong, C.c_int
 lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libq8stamp.so"))
+def knob(name, value):   # the library reads its tuning knobs once: flip them through its setter
+    lib.tt_set_tuning_knob.argtypes = [C.c_char_p, C.c_int]
+    assert lib.tt_set_tuning_knob(name.encode(), int(value)) == 0
 lib.tt_linear_fwd_pairs.restype = C.c_int
 lib.tt_linear_fwd_pairs.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
 lib.tt_split_pairs.restype = C.c_int
@@ -21,9 +24,9 @@ for M, N, K, name in ((25216, 1152, 384, "ViT-S/16 qkv"), (25216, 384, 1536, "Vi
         print(f"== {name}, order mode {order}", flush=True)
         def go():
             assert lib.tt_linear_fwd_pairs(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), None, None, M, N, K, 0, st) == 0
-        os.environ["TT_Q8_ORDER"] = str(order)
+        knob("TT_Q8_ORDER", order)
         for _ in range(1500): go()
-        os.environ["TT_Q8_ORDER"] = str(100 + order)
+        knob("TT_Q8_ORDER", 100 + order)
         go()
         torch.cuda.synchronize()
         sys.stdout.flush()
