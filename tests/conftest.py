@@ -67,5 +67,7 @@ def accurate_precision(request):
     from timetuning_amd import hip_ops
 
     hip_ops.set_gemm_precision(request.param)
+    keep, hip_ops.PAIRS_MIN_ROWS = hip_ops.PAIRS_MIN_ROWS, 0   # the pair kernels at EVERY size: the tiny golden models would otherwise dispatch to f32
     yield request.param
+    hip_ops.PAIRS_MIN_ROWS = keep
     hip_ops.set_gemm_precision("f32")

@@ -98,10 +98,11 @@ def block_forward(x: torch.Tensor, blk, num_heads: int, save: Optional[dict] = N
     ``aux`` (a dict) receives the block's qkv activations [F,N,3D] - what the attention foreground mask reads."""
     Fr, N, D = x.shape
     M = Fr * N
-    if save is None and ops.plane_count() and D % 64 == 0 and blk.mlp.fc1.weight.shape[0] % 64 == 0:
-        return block_forward_planes(x, blk, num_heads, ops.plane_count(), aux)
+    planes = ops.plane_count_for(M)
+    if save is None and planes and D % 64 == 0 and blk.mlp.fc1.weight.shape[0] % 64 == 0:
+        return block_forward_planes(x, blk, num_heads, planes, aux)
     x2d = x.view(M, D)
-    if save is not None and ops.pairs() and D % 64 == 0 and blk.mlp.fc1.weight.shape[0] % 64 == 0:
+    if save is not None and planes == 2 and D % 64 == 0 and blk.mlp.fc1.weight.shape[0] % 64 == 0:
         return block_forward_pairs_kept(x, blk, num_heads, save, aux)
     if save is not None:
         h1, save["mean1"], save["rstd1"] = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, save_stats=True)
@@ -390,13 +391,13 @@ def head_linears(head) -> List[torch.nn.Linear]:
     return [m for m in head if isinstance(m, torch.nn.Linear)]
 
 
-def _head_pairs_ok(lins) -> bool:
-    return ops.pairs() and all(l.weight.shape[0] % 64 == 0 and l.weight.shape[1] % 64 == 0 and l.bias is not None for l in lins)
+def _head_pairs_ok(lins, rows: int) -> bool:
+    return ops.plane_count_for(rows) == 2 and all(l.weight.shape[0] % 64 == 0 and l.weight.shape[1] % 64 == 0 and l.bias is not None for l in lins)
 
 
 def head_forward(x: torch.Tensor, head, save: Optional[dict] = None) -> torch.Tensor:
     lins = head_linears(head)
-    if _head_pairs_ok(lins):   # the "f16x3" mode: every layer on pair operands; the GELU epilogues write the next layer's operand
+    if _head_pairs_ok(lins, x.shape[0]):   # the "f16x3" mode: every layer on pair operands; the GELU epilogues write the next layer's operand
         xp = ops.split_pairs(x.contiguous())
         acts, pres = [xp], []
         for i, lin in enumerate(lins):

@@ -82,6 +82,19 @@ def pairs() -> bool:
     return _PRECISIONS[_precision][1] == 2
 
 
+# The "f16x3" mode is a DISPATCH decision between two fp32-class arithmetics: below this many token rows per launch the pair kernels'
+# extra passes (operand splits, transposes) cost more than three-MFMA products save - BASELINE C1 (4 frames, 788 rows) runs 3.45 ms on
+# pairs against 3.11 ms on the exact-f32 MFMA kernels - so small launches keep the f32 kernels.  Tests set it to 0 to drive the pair
+# kernels with tiny models.
+PAIRS_MIN_ROWS = 1536
+
+
+def plane_count_for(rows: int) -> int:
+    """``plane_count()`` for a launch sequence over ``rows`` token rows: the pair mode applies from PAIRS_MIN_ROWS rows on."""
+    n = _PRECISIONS[_precision][1]
+    return 0 if (n == 2 and rows < PAIRS_MIN_ROWS) else n
+
+
 # bench.py sets PROFILE to a list to get (layout, tile_choice, flops, start_event, end_event) per GEMM launch,
 # recorded with HIP events on the stream the kernel is launched on.
 PROFILE = None
@@ -1030,6 +1043,8 @@ def vit_forward(params, n_blocks: int, tokens, img=None, frame_map=None, normed_
     _chk(tokens, "tokens")
     F, N, D = tokens.shape
     vp.n_blocks = int(n_blocks)
+    if vp.planes == 2 and F * N < PAIRS_MIN_ROWS:
+        vp.planes = 0   # a small launch sequence keeps the exact-f32 kernels (PAIRS_MIN_ROWS); the fp32 weights are in the table anyway
     dev = tokens.device
     if img is not None:
         _chk(img, "img")

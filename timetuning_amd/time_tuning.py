@@ -373,7 +373,7 @@ class TimeT(nn.Module):
         # (in the default f32 mode the two streams would run the same kernels on smaller launches: split only when a bf16-plane
         # mode gives the stream that keeps nothing a faster path)
         tok, _ = engine.vit_tokens(vit, xf, self._frame_map(bs, fs, dev), save, last_block_aux=s_aux, tap=tap,
-                                   save_from_frame=f0 if ops.plane_count() else 0)
+                                   save_from_frame=f0 if ops.plane_count_for(f0 * (1 + fe.spatial_resolution ** 2)) else 0)
         tok_lo, tok_hi = tok if isinstance(tok, tuple) else (tok[:f0], tok[f0:])
         N, D = tok_hi.shape[1], tok_hi.shape[2]
         n = N - 1
