@@ -30,21 +30,25 @@ f32 = torch.float32
 # ViT blocks
 # ------------------------------------------------------------------------------------------------
 
+def _param_tag(w: torch.Tensor, kind) -> tuple:
+    """What a cached operand derived from ``w`` is valid for: the storage, torch's version counter (in-place edits through ATen) and the
+    epoch of raw-pointer parameter updates (``hip_ops.PARAM_EPOCH``: AdamW / EMA / prototype renormalisation write through data_ptr and do
+    not advance the version counter)."""
+    # a tensor marked static (``_tt_static``: the student's frozen parameters, FeatureExtractor.freeze_backbone) and still frozen is never
+    # rewritten through raw pointers: its operands are made once; staticness is re-derived at use time (a tensor unfrozen later is trainable)
+    static = getattr(w, "_tt_static", False) and not w.requires_grad
+    return (w.data_ptr(), w._version, 0 if static else ops.PARAM_EPOCH, kind)
+
+
 def weight_planes(w: torch.nn.Parameter, planes: int) -> torch.Tensor:
-    """[planes, N, K] bf16 planes of a Linear weight.  Tensors marked static (``_tt_static``: the student's frozen parameters,
-    FeatureExtractor.freeze_backbone) are split once and cached against (storage, version, planes); anything that training or the
-    EMA rewrites through raw pointers is split again on every call (a few MB per step)."""
-    # staticness is re-derived at use time: a tensor unfrozen after freeze_backbone (a fine-tuning schedule) is updated by the
-    # optimizer through raw pointers, whatever its stale flag says
-    split = (lambda t, n: ops.split_pairs(t)) if planes == 2 else ops.split_planes   # 2 = fp16 pairs [N, 2 K] (the "f16x3" mode)
-    if w.requires_grad or not getattr(w, "_tt_static", False):
-        return split(w.detach(), planes)
-    # the cache lives ON the parameter object (not in a table keyed by id(): a recycled id + recycled storage of a dead model's
-    # parameter would otherwise hit), so it dies with it
+    """[planes, N, K] bf16 planes (planes = 2: [N, 2 K] fp16 pairs, the "f16x3" mode) of a Linear weight, cached ON the parameter object
+    (not in a table keyed by id(): a recycled id + recycled storage of a dead model's parameter would otherwise hit) against
+    ``_param_tag``: a frozen tensor is split once, a trainable or EMA'd one once per optimizer / EMA update - not once per use (the two
+    streams of a trainable block, the source and target rows of the head)."""
     hit = getattr(w, "_tt_planes", None)
-    tag = (w.data_ptr(), w._version, planes)
+    tag = _param_tag(w, planes)
     if hit is None or hit[0] != tag:
-        hit = (tag, split(w.detach(), planes))
+        hit = (tag, ops.split_pairs(w.detach()) if planes == 2 else ops.split_planes(w.detach(), planes))
         w._tt_planes = hit
     return hit[1]
 
@@ -158,9 +162,19 @@ def block_forward_pairs_kept(x: torch.Tensor, blk, num_heads: int, save: dict, a
 
 
 def weight_pairs_t(w: torch.Tensor) -> torch.Tensor:
-    """[K, 2 N] fp16 pairs of w^T for an nn.Linear weight w [N, K]: the operand of the data-gradient product in the "f16x3" mode
-    (made per use: only trainable weights have a backward, and those change every step)."""
-    return ops.split_pairs_dual(w.detach())[0]
+    """[K, 2 N] fp16 pairs of w^T for an nn.Linear weight w [N, K]: the operand of the data-gradient product in the "f16x3" mode, cached
+    per parameter update like ``weight_planes`` (and made in the same pass as the forward operand when that is not cached yet)."""
+    hit = getattr(w, "_tt_pairs_t", None)
+    tag = _param_tag(w, "T")
+    if hit is None or hit[0] != tag:
+        fwd = getattr(w, "_tt_planes", None)
+        need_row = fwd is None or fwd[0] != _param_tag(w, 2)
+        t, row, _ = ops.split_pairs_dual(w.detach(), want_row=need_row)
+        if need_row:
+            w._tt_planes = (_param_tag(w, 2), row)
+        hit = (tag, t)
+        w._tt_pairs_t = hit
+    return hit[1]
 
 
 def _bwd_both_pairs(dy: torch.Tensor, w: torch.Tensor, xp: torch.Tensor, gelu_pre: Optional[torch.Tensor] = None, need_dx: bool = True,

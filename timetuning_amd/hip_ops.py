@@ -95,6 +95,17 @@ def plane_count_for(rows: int) -> int:
     return 0 if (n == 2 and rows < PAIRS_MIN_ROWS) else n
 
 
+# Bumped by every op that rewrites parameters through raw pointers (AdamW, EMA, prototype renormalisation): tensors touched that way do not
+# advance torch's version counter, so caches of derived operands (engine.weight_planes: the per-step pair split of a TRAINABLE weight)
+# key on this as well.
+PARAM_EPOCH = 0
+
+
+def _bump_param_epoch() -> None:
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
+
+
 # bench.py sets PROFILE to a list to get (layout, tile_choice, flops, start_event, end_event) per GEMM launch,
 # recorded with HIP events on the stream the kernel is launched on.
 PROFILE = None
@@ -404,6 +415,7 @@ def l2norm_bwd(dxn, xn, inv):
 
 
 def normalize_rows_(w):
+    _bump_param_epoch()
     lib = _lib.load()
     _chk(w, "w")
     _lib.check(lib.tt_normalize_rows_inplace(_p(w), w.shape[0], w.shape[1], _stream()), "tt_normalize_rows_inplace")
@@ -695,6 +707,7 @@ def queue_push_(queue, feats, idx):
 
 def adamw_step_(entries: Sequence[tuple], step: int, beta1=0.9, beta2=0.999, eps=1e-8):
     """entries: (param, grad, exp_avg, exp_avg_sq, lr, weight_decay) tuples, all fp32 GPU contiguous."""
+    _bump_param_epoch()
     lib = _lib.load()
     cap = 40
     for i in range(0, len(entries), cap):
@@ -723,6 +736,7 @@ def scale_tensors_(tensors: Sequence[torch.Tensor], scale: torch.Tensor):
 
 def ema_update_(teacher, student, momentum: float):
     """teacher <- teacher * (1 - m) + student * m  (time_tuning.py:113-115)."""
+    _bump_param_epoch()
     lib = _lib.load()
     _chk(teacher, "teacher"); _chk(student, "student")
     assert teacher.numel() == student.numel()
@@ -1106,6 +1120,7 @@ def adamw_ema_step_(entries: Sequence[tuple], step: int, beta1=0.9, beta2=0.999,
                     student_flat=None, teacher_prototypes=None, momentum: float = 0.0):
     """``tt_adamw_ema_step``: AdamW over ``entries`` (as ``adamw_step_``), prototypes renormalised, then the EMA teacher update of
     the flat parameter buffers and the teacher prototypes (each part skipped when its tensors are None)."""
+    _bump_param_epoch()
     lib = _lib.load()
     arr = (_lib.AdamwTensor * max(len(entries), 1))()
     for j, (p, g, m, v, lr, wd) in enumerate(entries):

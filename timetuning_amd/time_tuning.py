@@ -642,7 +642,8 @@ def build_parser() -> argparse.ArgumentParser:
     --size_mask_neighborhood --epochs --dataset_path --destination_path`` are parsed but never reach ``get_loss``,
     which uses its signature defaults (eps 0.05, 10 iterations, 7 frames, radius 6, top-5).
     Added (not in the reference): ``--dataset synthetic`` / ``--steps_per_epoch`` / ``--eval_clips`` because the dataset
-    loaders are out of scope here, and ``--eval_every`` (the reference hard-codes 4)."""
+    loaders are out of scope here, ``--eval_every`` (the reference hard-codes 4) and ``--precision`` (the arithmetic mode of the
+    matrix products; the library-level default of ``hip_ops.set_gemm_precision`` stays "f32", the training driver's is "f16x3")."""
     p = argparse.ArgumentParser()
     p.add_argument("--architecture", type=str, default="dino-s16")
     p.add_argument("--model_path", type=str, default="vits16_800ep.pth.tar")
@@ -683,6 +684,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--steps_per_epoch", default=8, type=int, help="synthetic data only")
     p.add_argument("--eval_every", default=4, type=int, help="epochs between rank-0 evaluations (the reference hard-codes 4; 0 = never)")
     p.add_argument("--eval_clips", default=8, type=int, help="synthetic evaluation set size")
+    p.add_argument("--precision", default="f16x3", choices=["f16x3", "f32", "bf16x6", "bf16x3", "bf16"],
+                   help="arithmetic of the matrix products (hip_ops.set_gemm_precision): f16x3 = the fp32-accurate fp16-pair split (per-op error "
+                        "under the exact-f32 MFMA kernels', 1.7x their speed), f32 = exact fp32 MFMA, bf16 = BASELINE C4's bf16 path")
     return p
 
 
@@ -778,6 +782,7 @@ def time_tuning(gpu=0, args=None):
         gpu = 0
     device = torch.device("cuda", gpu)
     torch.cuda.set_device(device)
+    ops.set_gemm_precision(getattr(args, "precision", "f16x3"))   # the driver's default: the fp32-accurate fp16-pair split
     if world_size > 1 and not dist.is_initialized():
         dist.init_process_group(backend=os.environ.get("TT_DIST_BACKEND", "nccl"), init_method="env://", world_size=world_size, rank=rank)
     if args.use_projection_head:

@@ -24,7 +24,7 @@ def case(name, match):
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
             per_simd = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * CUS)  # counts cycles, summed over the SIMDs of the chip
             d["mfma_busy_cycles_per_simd"] = round(per_simd)
-            d["matrix_pipe_busy_frac"] = round(per_simd / kc, 3)
+            d["matrix_pipe_busy_frac(of a wave's lifetime: = of the kernel for the persistent GEMM, one workgroup per CU)"] = round(per_simd / kc, 3)
     if "TCC_HIT_sum" in c:
         d["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0), 3)
     if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
@@ -36,7 +36,11 @@ def case(name, match):
     if "WRITE_SIZE" in c:
         d["hbm_write_bytes(WRITE_SIZE*1024)"] = round(c["WRITE_SIZE"] * 1024)
     if "GRBM_GUI_ACTIVE" in c:
-        d["GRBM_GUI_ACTIVE_per_XCD"] = round(c["GRBM_GUI_ACTIVE"] / 8)
+        d["GRBM_GUI_ACTIVE_per_XCD"] = round(c["GRBM_GUI_ACTIVE"] / 8)   # the dispatch's duration in GPU clocks (sum over the 8 XCDs / 8)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+            # against the whole dispatch (launch ramp and tail included; THE figure for a kernel whose workgroups come in several rounds,
+            # where a wave's lifetime is a fraction of the dispatch: the attention kernel runs 3 rounds of 768 workgroups)
+            d["matrix_pipe_busy_frac_of_dispatch(GRBM)"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * CUS) / (c["GRBM_GUI_ACTIVE"] / 8), 3)
     return {"counters": {k: round(v) for k, v in sorted(c.items())}, "derived": d}
 
 
