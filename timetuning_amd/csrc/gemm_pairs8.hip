@@ -79,6 +79,12 @@ __device__ __forceinline__ void q8_wait_vmcnt() {
 #if TT_Q8_TAIL != 0
 #error "TT_Q8_TAIL was a round-4 timing study (profiles/r04_q8_dma_placement_ab.txt: no gain / 2x slower); the half-item schedule no longer supports it"
 #endif
+// TT_Q8_SQ: the wave tile.  0 = 128 (x) x 32 (w) - waves 2 x 4, a K-tile costs a wave 4 + 8 + 8 = 20 fragment reads; 1 = 64 x 64 - waves
+// 4 x 2, 8 (W, kept for both phases) + 4 + 4 = 16 reads for the same 24 MFMAs: the load part is the long part of a phase and the LDS
+// the busiest unit of the CU (160 KB of fragment reads + 48 KB of DMA writes per K-tile at 128 B / clk against 1536 cycles of MFMAs).
+#ifndef TT_Q8_SQ
+#define TT_Q8_SQ 1
+#endif
 // DBG (timing studies only; the shipped instantiations are DBG = 0), a bit mask: 1 no MFMAs, 2 no LDS-DMA, 8 no epilogue
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
@@ -116,7 +122,8 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool grp1 = wave >= 4;
-  const int wr = wave >> 2, wc = wave & 3;
+  constexpr bool SQ = TT_Q8_SQ != 0;
+  const int wr = SQ ? (wave & 3) : (wave >> 2), wc = SQ ? (wave >> 2) : (wave & 3);   // SQ: 4 x 2 waves of 64 x 64; else 2 x 4 of 128 x 32
   const int r = lane & 31, h = lane >> 5;
   const int K4 = g.K * 4, nk = g.K / 32;   // bytes per operand row; K-tiles
 
@@ -218,16 +225,16 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
   int fo[4];   // 0, 1: hi of k-steps 0, 1; 2, 3: lo
 #pragma unroll
   for (int c4 = 0; c4 < 4; ++c4) fo[c4] = r * ROWB + (((2 * c4 + h) ^ f_sw) << 4);
-  const int x_slice = wr * 64 * ROWB, w_slice = wc * 32 * ROWB;
+  const int x_slice = wr * (SQ ? 32 : 64) * ROWB, w_slice = wc * (SQ ? 64 : 32) * ROWB;   // within a chunk (X0 / X1: per x half)
 
-  f32x16 a1[2][2], a2[2][2];   // [x half][MFMA tile]: hi hi | hi lo + lo hi (x 2^11)
+  f32x16 a1[2][2], a2[2][2];   // [x half][MFMA tile: SQ the w 32-row block, else the x 32-row block]: hi hi | hi lo + lo hi (x 2^11)
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int e = 0; e < 16; ++e) { a1[a][m][e] = 0.f; a2[a][m][e] = 0.f; }
-  f16x8 Wf[4], Xf[2][4];
+  f16x8 One[4], Two[2][4];   // fragments [hi k-step 0, 1, lo k-step 0, 1]: One = the operand with ONE 32-row block per phase (W; SQ: X), Two = two blocks
 
   // order of the load part (gemm_planes8.hip `reads_first`): 0 every wave DMA first, 1 every wave reads first, 2 odd waves read first,
   // 3 waves 2, 3 (6, 7) of a group read first
@@ -257,16 +264,28 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
     const bool work = !(HA == 1 && c_half);
     auto frag_reads = [&]() {
       if (work) {
-        if constexpr (HA == 0) {
+        if constexpr (SQ) {   // W: two blocks, read in phase 0 and kept; X: one block per phase
+          if constexpr (HA == 0) {
 #pragma unroll
-          for (int c4 = 0; c4 < 4; ++c4) Wf[c4] = *reinterpret_cast<const f16x8*>(smem + base + w_slice + fo[c4]);
-          __builtin_amdgcn_sched_barrier(0);
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+              for (int c4 = 0; c4 < 4; ++c4) Two[mt][c4] = *reinterpret_cast<const f16x8*>(smem + base + w_slice + mt * 32 * ROWB + fo[c4]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) One[c4] = *reinterpret_cast<const f16x8*>(smem + base + (1 + HA) * CHUNK_B + x_slice + fo[c4]);
+        } else {
+          if constexpr (HA == 0) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) One[c4] = *reinterpret_cast<const f16x8*>(smem + base + w_slice + fo[c4]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4)
+              Two[mt][c4] = *reinterpret_cast<const f16x8*>(smem + base + (1 + HA) * CHUNK_B + x_slice + mt * 32 * ROWB + fo[c4]);
         }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int c4 = 0; c4 < 4; ++c4)
-            Xf[mt][c4] = *reinterpret_cast<const f16x8*>(smem + base + (1 + HA) * CHUNK_B + x_slice + mt * 32 * ROWB + fo[c4]);
       }
     };
     auto dma_issue = [&]() {
@@ -348,11 +367,11 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) {
-            two16(Wf[ks], Xf[mt][ks], a1[HA][mt]);
-            two16(Wf[ks], Xf[mt][2 + ks], a2[HA][mt]);
+            two16(One[ks], Two[mt][ks], a1[HA][mt]);
+            two16(One[ks], Two[mt][2 + ks], a2[HA][mt]);
           }
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) two16(Wf[2 + ks], Xf[mt][ks], a2[HA][mt]);
+          for (int mt = 0; mt < 2; ++mt) two16(One[2 + ks], Two[mt][ks], a2[HA][mt]);
         }
       }
     } else
@@ -360,12 +379,20 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          a1[HA][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[ks], Xf[mt][ks], a1[HA][mt], 0, 0, 0);
-          a2[HA][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[ks], Xf[mt][2 + ks], a2[HA][mt], 0, 0, 0);
+        for (int mt = 0; mt < 2; ++mt) {   // the A operand is always the W fragment (swapped operands: an output row on a lane)
+          if constexpr (SQ) {
+            a1[HA][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Two[mt][ks], One[ks], a1[HA][mt], 0, 0, 0);
+            a2[HA][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Two[mt][ks], One[2 + ks], a2[HA][mt], 0, 0, 0);
+          } else {
+            a1[HA][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(One[ks], Two[mt][ks], a1[HA][mt], 0, 0, 0);
+            a2[HA][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(One[ks], Two[mt][2 + ks], a2[HA][mt], 0, 0, 0);
+          }
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) a2[HA][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 + ks], Xf[mt][ks], a2[HA][mt], 0, 0, 0);
+        for (int mt = 0; mt < 2; ++mt) {
+          if constexpr (SQ) a2[HA][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Two[mt][2 + ks], One[ks], a2[HA][mt], 0, 0, 0);
+          else a2[HA][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(One[2 + ks], Two[mt][ks], a2[HA][mt], 0, 0, 0);
+        }
         if constexpr (TT_Q8_TAIL == 2) {
           if (ks == 0) {
             __builtin_amdgcn_sched_barrier(0);
@@ -386,7 +413,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
       if (work) {
         float keep = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) keep += (float)Wf[i][0] + (float)Xf[0][i][0] + (float)Xf[1][i][0];
+        for (int i = 0; i < 4; ++i) keep += (float)One[i][0] + (float)Two[0][i][0] + (float)Two[1][i][0];
         a1[0][0][0] += keep;
       }
     }
@@ -416,6 +443,13 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
   constexpr int NRB = 32 / RPW;                   // read-back instructions per pass
   constexpr int NLD = NPASS * NRB;                // ... per MFMA tile (fp32: 4)
   const int rr = lane / LPR, cc = lane % LPR;
+  // swizzle of the staged rows (64 bytes = 4 chunks each; an LDS pass serves 16 lanes x 16 bytes = one 256-byte bank window = 4 rows):
+  // rows r, r + 4, r + 8, r + 12 fall into the same quarter of the window and must differ in their chunk -> the row's bits 2..3
+  // (bits 0..1 - round 3's choice - left the 16 lanes of a write pass 4-way conflicted: 14 % of the kernel's LDS cycles by PMC)
+#ifndef TT_Q8_ESW
+#define TT_Q8_ESW 1
+#endif
+  auto esw = [](int row) { return TT_Q8_ESW ? ((row >> 2) & (CPRW - 1)) : (row & (CPRW - 1)); };
   const unsigned out_bytes = (unsigned)g.M * (unsigned)g.N * 4u;   // fp32 [M][N] and pairs [M][2 N] fp16 alike
   auto epilogue = [&](int row0, int n0, bool half) {
     if constexpr (DBG & 8) {
@@ -431,19 +465,24 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
     }
     constexpr int NT = 4;   // MFMA tiles in the order (ha, mt): a half item ends after the first two
     const int nt = half ? NT / 2 : NT;
-    const int nbase = n0 + wc * 32;
-    f32x4 bias_lo[NPASS], bias_hi[NPASS];
+    // MFMA tile j = (ha, mt): output rows mrow(j) .., columns ncol(j) .. (+ 32 each)
+    auto mrow = [&](int j) { return row0 + (j >> 1) * 128 + (SQ ? wr * 32 : wr * 64 + (j & 1) * 32); };
+    auto ncol = [&](int j) { return n0 + (SQ ? wc * 64 + (j & 1) * 32 : wc * 32); };
+    constexpr int NB = SQ ? 2 : 1;   // distinct column blocks of a wave
+    f32x4 bias_lo[NB][NPASS], bias_hi[NB][NPASS];
 #pragma unroll
-    for (int q = 0; q < NPASS; ++q) {
-      const int n = nbase + q * CW + (F32OUT ? 4 : 8) * cc;
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      bias_lo[q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : zero;
-      if constexpr (!F32OUT) bias_hi[q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n + 4) : zero;
-    }
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q) {
+        const int n = ncol(b) + q * CW + (F32OUT ? 4 : 8) * cc;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        bias_lo[b][q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : zero;
+        if constexpr (!F32OUT) bias_hi[b][q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n + 4) : zero;
+      }
     f32x4 rres[3][RES ? NLD : 1];
     auto prefetch = [&](int j, int slot) {
       if constexpr (RES) {
-        const int mbase = row0 + (j >> 1) * 128 + wr * 64 + (j & 1) * 32;
+        const int mbase = mrow(j), nbase = ncol(j);
 #pragma unroll
         for (int q = 0; q < NPASS; ++q)
 #pragma unroll
@@ -461,7 +500,9 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
     for (int j = 0; j < NT; ++j) {
       if (j < nt) {
         const int ha = j >> 1, mt = j & 1;
-        const int mbase = row0 + ha * 128 + wr * 64 + mt * 32;
+        const int mbase = mrow(j), nbase = ncol(j);
+        constexpr int BI = 0;
+        const int bi = SQ ? mt : BI;
         if constexpr (RES) {
           if (j + 2 < nt) prefetch(j + 2, (j + 2) % 3);
         }
@@ -470,7 +511,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
 #pragma unroll
           for (int gg = 0; gg < CW / 8; ++gg) {
             const int gi = q * (CW / 8) + gg;
-            const int phys = (2 * gg + h) ^ (r & (CPRW - 1));
+            const int phys = (2 * gg + h) ^ esw(r);
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaf(a2[ha][mt][4 * gi + e], 0.00048828125f, a1[ha][mt][4 * gi + e]);   // exact 2^-11
@@ -481,8 +522,8 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
             const int row = i * RPW + rr;
             const int m = mbase + row;
             if constexpr (F32OUT) {
-              f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + ((cc ^ (row & (CPRW - 1))) << 4));
-              v += bias_lo[q];
+              f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + ((cc ^ esw(row)) << 4));
+              v += bias_lo[bi][q];
               if constexpr (GG) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast_f(rres[j % 3][q * NRB + i][e]);
@@ -492,10 +533,10 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
               const unsigned off = ((unsigned)m * (unsigned)g.N + (unsigned)(nbase + q * CW + 4 * cc)) * 4u;
               q8_st128(g.C, out_bytes, off, __builtin_bit_cast(u32x4, v));
             } else {
-              f32x4 v0 = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + (((2 * cc) ^ (row & (CPRW - 1))) << 4));
-              f32x4 v1 = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + (((2 * cc + 1) ^ (row & (CPRW - 1))) << 4));
-              v0 += bias_lo[q];
-              v1 += bias_hi[q];
+              f32x4 v0 = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + (((2 * cc) ^ esw(row)) << 4));
+              f32x4 v1 = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + (((2 * cc + 1) ^ esw(row)) << 4));
+              v0 += bias_lo[bi][q];
+              v1 += bias_hi[bi][q];
               float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
               if constexpr (BOTH) {   // the fp32 value (before the activation): 8 columns = two 16-byte stores
                 const unsigned offc = ((unsigned)m * (unsigned)g.N + (unsigned)(nbase + q * CW + 8 * cc)) * 4u;
