@@ -1054,7 +1054,7 @@ int tt_cpu_vit_forward(const tt_cpu_vit_params* p, const float* img, const int32
     const long long MD = (long long)M * D;
     if (P == 2) {   /* fp16 pairs (4 bytes per element: the PP = 2 buffers above are the right size) */
       tt_cpu_layernorm_fwd_pairs(tokens, b->norm1_w, b->norm1_b, hp, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
-      if (!(last && last_qkv) && !probs && N <= 256 && hd == 64) {
+      if (!(last && last_qkv) && !probs && hd == 64) {
         uint16_t* qkvp = (uint16_t*)qkv_own;   /* pairs [M][2 x 3 D] = the bytes of the fp32 qkv buffer */
         tt_cpu_linear_fwd_pairs(hp, b->qkv_wp, b->qkv_b, NULL, NULL, NULL, qkvp, (int)M, 3 * D, D, 0, stream);
         tt_cpu_attention_fwd_pairs(qkvp, attp, NULL, NULL, F, N, p->heads, hd, scale, stream);

@@ -112,9 +112,22 @@ def test_linear_pairs_epilogues(M, N, K):
     assert rel_err(o6["y"].cpu(), pre_ref) < TOL_F32 and rel_err(join(o6["pairs"].cpu()), o6["y"].cpu().double()) <= 2.0 ** -22
 
 
-@pytest.mark.parametrize("Fr,N,H", [(3, 197, 6), (2, 50, 2), (1, 256, 12), (2, 225, 3), (5, 17, 1)])
-def test_attention_pairs(Fr, N, H):
+@pytest.mark.parametrize("Fr,N,H,flash", [(3, 197, 6, 0), (2, 50, 2, 0), (1, 256, 12, 0), (2, 225, 3, 0), (5, 17, 1, 0),
+                                          # the KV-tiled kernel: beyond 256 tokens (785 = C5's 448 x 448 frames: 7 + 6 + 6 + 6 query tiles; ragged
+                                          # last stages; one stage + one key), and forced at the sizes of the resident kernel
+                                          (2, 785, 6, 0), (2, 300, 2, 0), (1, 257, 1, 0), (1, 1030, 2, 0), (1, 513, 3, 0),
+                                          (3, 197, 6, 1), (5, 17, 1, 1), (2, 128, 2, 1), (2, 129, 2, 1), (1, 256, 3, 1), (2, 65, 1, 1)])
+def test_attention_pairs(Fr, N, H, flash):
     from timetuning_amd import hip_ops as ops
+
+    ops.set_tuning_knob("TT_ATTN_PAIRS_FLASH", flash)
+    try:
+        _attention_pairs_case(ops, Fr, N, H)
+    finally:
+        ops.set_tuning_knob("TT_ATTN_PAIRS_FLASH", 0)
+
+
+def _attention_pairs_case(ops, Fr, N, H):
 
     D = 64 * H
     qkv = rnd(f"att.{Fr}.{N}.{H}", Fr, N, 3 * D) * 1.5

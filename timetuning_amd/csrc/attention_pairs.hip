@@ -1,7 +1,8 @@
 // Fused attention forward on fp16-PAIR operands (dino_vision_transformer.py:120-132) - the attention of the fp32-accurate split mode
 // "f16x3" (round 4): qkv [F N][2 x 3 H 64] in pairs as the qkv Linear's epilogue left it (common.hpp split_pair: groups of 32 columns as
 // [hi x 32][lo x 32] fp16, a head's 64 dims = 256 contiguous bytes) -> the attention output in pairs [F N][2 H 64] (the proj Linear's
-// operand) and / or in fp32 (+ the log-sum-exp rows the backward recomputes from).  N <= 256, head_dim 64.
+// operand) and / or in fp32 (+ the log-sum-exp rows the backward recomputes from).  head_dim 64; N <= 256: the kernel below with K / V of a
+// head resident in LDS; any N: the KV-tiled kernel at the end of this file.
 //
 // Both matrix products take three v_mfma_f32_32x32x16_f16 per term, as the pair GEMMs do (gemm_pairs8.hip): S = K Q^T as kh qh into one
 // accumulator and kh ql + kl qh into a second one, folded with the exact 2^-11 per key tile; the probabilities p = 2^(s c - m c) in (0, 1] are
@@ -219,6 +220,233 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
   }
 }
 
+
+// ---- Any N: the KV-tiled ("flash") form.  One 8-wave workgroup per (frame, head, query block); a wave owns one 32-query tile and keeps
+// its running max / sum / O^T accumulators (64 registers: two 32-dim groups x the two accumulators of the split) across the key loop;
+// K and V stream through LDS in stages of 128 keys (the images of the kernel above: 32 KB + 32 KB), double-buffered by LDS-DMA - the
+// stage t + 1 loads run under the products of stage t, one workgroup barrier per stage.  A stage is consumed as two 64-key steps
+// (32 score + 32 probability registers live): S^T = K Q^T (3 MFMAs per term), the online-softmax update (the rescale of O^T is a
+// per-lane scalar: a query is a lane column of both S^T and O^T), P split into pairs, O^T += V^T P^T.  Query tiles are dealt to the
+// ceil(tiles / 8) blocks evenly (785 tokens: 25 tiles -> 7 + 6 + 6 + 6).
+__global__ __launch_bounds__(512) void attention_fwd_pairs_flash_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out_pairs,
+                                                                        float* __restrict__ out_f32, float* __restrict__ lse, int N, int H, float scale,
+                                                                        int nb, int nqt) {
+  constexpr int SK = 128;                 // keys per stage
+  constexpr int STAGE_B = 2 * SK * 256;   // K image + V image
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B + 8 * 4096];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* Os = smem + 2 * STAGE_B + wave * 4096;
+  const int r = lane & 31, h = lane >> 5;
+  const int blk = blockIdx.x % nb, fh = blockIdx.x / nb, f = fh / H, hd = fh - f * H;
+  const int Dm = H * 64;
+  const long long RS = 6ll * Dm;
+  const _Float16* base = qkv + (long long)f * N * RS + hd * 128;
+  const int nst = (N + SK - 1) / SK;
+
+  // K / V of stage st -> buffer st & 1: 32 + 32 pieces of 4 keys x 256 B, four of each per wave
+  const int l_row = lane >> 4, l_slot = lane & 15;
+  auto issue_stage = [&](int st) {
+    unsigned char* Kd = smem + (st & 1) * STAGE_B;
+    unsigned char* Vd = Kd + SK * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = wave + 8 * i;
+      const int key = st * SK + piece * 4 + l_row;
+      const int krow = key < N ? key : N - 1;
+      const _Float16* src = base + (long long)krow * RS;
+      const int kc = l_slot ^ (key & 15);
+      const int vc = l_slot ^ ((key & 3) << 2);
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + 2 * Dm + kc * 8),
+                                       (void __attribute__((address_space(3)))*)(Kd + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + 4 * Dm + vc * 8),
+                                       (void __attribute__((address_space(3)))*)(Vd + piece * 1024), 16, 0, 0);
+    }
+  };
+  issue_stage(0);
+
+  const int t0 = blk * nqt / nb, t1 = (blk + 1) * nqt / nb;
+  const int qt = t0 + wave;
+  const bool active = qt < t1;
+  const int query = qt * 32 + r;
+  const int qrow = query < N ? query : N - 1;
+  f16x8 qh[4], ql[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const _Float16* p = base + (long long)qrow * RS + (ks >> 1) * 64 + (ks & 1) * 16 + 8 * h;
+    qh[ks] = *reinterpret_cast<const f16x8*>(p);
+    ql[ks] = *reinterpret_cast<const f16x8*>(p + 32);
+  }
+  int kofs[8];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int ch = (ks >> 1) * 8 + 2 * (ks & 1) + h;
+    kofs[ks] = r * 256 + ((ch ^ (r & 15)) << 4);
+    kofs[4 + ks] = r * 256 + (((ch + 4) ^ (r & 15)) << 4);
+  }
+  const int g16 = (lane >> 4) & 1, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  int vofs[4];
+#pragma unroll
+  for (int qn = 0; qn < 4; ++qn) vofs[qn] = (4 * h + q4) * 256 + ((qn ^ q4) << 6) + (16 * g16 + 4 * p4) * 2;
+
+  const float c = scale * 1.44269504088896340736f;
+  float m_run = -INFINITY, l_run = 0.f;   // running max (raw score units, both lanes of a query agree) and this lane's share of the sum
+  f32x16 o1[2], o2[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o1[dt][e] = 0.f; o2[dt][e] = 0.f; }
+
+  for (int st = 0; st < nst; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // stage st has landed for every wave; every wave is done with the buffer stage st + 1 goes into
+    if (st + 1 < nst) issue_stage(st + 1);
+    if (active) {
+      const unsigned char* Ks = smem + (st & 1) * STAGE_B;
+      const unsigned char* Vs = Ks + SK * 256;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const int key0 = st * SK + sub * 64;
+        if (key0 < N) {                       // (uniform)
+          const bool two = key0 + 32 < N;     // the second 32-key tile of this step holds a real key
+          f32x16 sacc[2];
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            if (kt == 0 || two) {
+              f32x16 s1, s2;
+#pragma unroll
+              for (int e = 0; e < 16; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) {
+                const f16x8 kfh = *reinterpret_cast<const f16x8*>(Ks + (sub * 2 + kt) * 8192 + kofs[ks]);
+                const f16x8 kfl = *reinterpret_cast<const f16x8*>(Ks + (sub * 2 + kt) * 8192 + kofs[4 + ks]);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, qh[ks], s1, 0, 0, 0);
+                s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, ql[ks], s2, 0, 0, 0);
+                s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl, qh[ks], s2, 0, 0, 0);
+              }
+#pragma unroll
+              for (int e = 0; e < 16; ++e) sacc[kt][e] = fmaf(s2[e], kPairInvScale, s1[e]);
+              if (key0 + kt * 32 + 31 >= N) {   // (uniform) the tile reaches past N
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                  const int key = key0 + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                  if (key >= N) sacc[kt][e] = -INFINITY;
+                }
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 16; ++e) sacc[kt][e] = -INFINITY;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          float mx = m_run;
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          // finite: key0 < N and the first keys of the step sit in lane half 0 / 1 alike
+          const float mc = mx * c;
+          const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));   // 0 at the first step (m_run = -inf)
+          m_run = mx;
+          float sum = 0.f;
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], c, -mc));
+              sacc[kt][e] = p;
+              sum += p;
+            }
+          l_run = fmaf(l_run, alpha, sum);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { o1[dt][e] *= alpha; o2[dt][e] *= alpha; }
+          f16x8 ph[2][2], pl[2][2];
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                _Float16 hi_, lo_;
+                split_pair(sacc[kt][8 * s + j], hi_, lo_);
+                ph[kt][s][j] = hi_;
+                pl[kt][s][j] = lo_;
+              }
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+              if (kt == 0 || two) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                  const unsigned char* vrow = Vs + ((sub * 2 + kt) * 32 + 16 * s) * 256;
+                  union { s16x4 s2[2]; f16x8 v; } vh, vl;
+                  vh.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + vofs[2 * dt]));
+                  vh.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + 2048 + vofs[2 * dt]));
+                  vl.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + vofs[2 * dt + 1]));
+                  vl.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + 2048 + vofs[2 * dt + 1]));
+                  o1[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[kt][s], o1[dt], 0, 0, 0);
+                  o2[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[kt][s], o2[dt], 0, 0, 0);
+                  o2[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[kt][s], o2[dt], 0, 0, 0);
+                }
+              }
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  if (!active) return;
+  const float lsum = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = __builtin_amdgcn_rcpf(lsum);
+  if (lse && h == 0 && query < N) lse[((long long)f * H + hd) * N + query] = (m_run * c + __log2f(lsum)) * 0.69314718055994530942f;
+  const int c8 = lane & 7;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    float o[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = fmaf(o2[dt][e], kPairInvScale, o1[dt][e]) * inv;
+    if (out_pairs) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f16x4 vh4, vl4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 hi_, lo_;
+          split_pair(o[4 * g4 + e], hi_, lo_);
+          vh4[e] = hi_;
+          vl4[e] = lo_;
+        }
+        *reinterpret_cast<f16x4*>(Os + r * 128 + ((g4 ^ (r & 7)) << 4) + 8 * h) = vh4;
+        *reinterpret_cast<f16x4*>(Os + r * 128 + (((4 + g4) ^ (r & 7)) << 4) + 8 * h) = vl4;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (lane >> 3) + 8 * i;
+        const f16x8 v = *reinterpret_cast<const f16x8*>(Os + row * 128 + ((c8 ^ (row & 7)) << 4));
+        const int q = qt * 32 + row;
+        if (q < N) *reinterpret_cast<f16x8*>(out_pairs + ((long long)f * N + q) * (2 * Dm) + hd * 128 + dt * 64 + 8 * c8) = v;
+      }
+    }
+    if (out_f32) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 v = {o[4 * g4], o[4 * g4 + 1], o[4 * g4 + 2], o[4 * g4 + 3]};
+        *reinterpret_cast<f32x4*>(Os + r * 128 + (((2 * g4 + h) ^ (r & 7)) << 4)) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (lane >> 3) + 8 * i;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Os + row * 128 + ((c8 ^ (row & 7)) << 4));
+        const int q = qt * 32 + row;
+        if (q < N) *reinterpret_cast<f32x4*>(out_f32 + ((long long)f * N + q) * Dm + hd * 64 + dt * 32 + 4 * c8) = v;
+      }
+    }
+  }
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -228,14 +456,21 @@ extern "C" int tt_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, fl
   TT_REQUIRE(qkv_pairs && (out_pairs || out_f32), "attention_fwd_pairs: null input / no output");
   TT_REQUIRE(F > 0 && N > 0 && H > 0 && scale > 0.f, "attention_fwd_pairs: bad shape / non-positive scale");
   TT_REQUIRE(head_dim == 64, "attention_fwd_pairs: head_dim must be 64 (got %d)", head_dim);
-  TT_REQUIRE(N <= 256, "attention_fwd_pairs: N <= 256 tokens (got %d); longer sequences use the fp32 kernel", N);
   TT_REQUIRE(aligned16(qkv_pairs) && (!out_pairs || aligned16(out_pairs)) && (!out_f32 || aligned16(out_f32)),
              "attention_fwd_pairs: buffers must be 16-byte aligned");
   hipStream_t s = as_stream(stream);
   const _Float16* q = static_cast<const _Float16*>(qkv_pairs);
   _Float16* o = static_cast<_Float16*>(out_pairs);
-  if (N <= 224) hipLaunchKernelGGL((attention_fwd_pairs_kernel<7>), dim3(F * H), dim3(512), 0, s, q, o, out_f32, lse, N, H, scale);
-  else hipLaunchKernelGGL((attention_fwd_pairs_kernel<8>), dim3(F * H), dim3(512), 0, s, q, o, out_f32, lse, N, H, scale);
+  const bool resident = tuning_knob(KNOB_ATTN_PAIRS_FLASH) == 0;   // (knob 1: the KV-tiled kernel at every N - tests and A/B)
+  if (N <= 224 && resident) {
+    hipLaunchKernelGGL((attention_fwd_pairs_kernel<7>), dim3(F * H), dim3(512), 0, s, q, o, out_f32, lse, N, H, scale);
+  } else if (N <= 256 && resident) {
+    hipLaunchKernelGGL((attention_fwd_pairs_kernel<8>), dim3(F * H), dim3(512), 0, s, q, o, out_f32, lse, N, H, scale);
+  } else {
+    const int nqt = (N + 31) / 32, nb = (nqt + 7) / 8;
+    TT_REQUIRE((long long)F * H * nb < 0x7fffffffLL, "attention_fwd_pairs: grid too large");
+    hipLaunchKernelGGL(attention_fwd_pairs_flash_kernel, dim3(F * H * nb), dim3(512), 0, s, q, o, out_f32, lse, N, H, scale, nb, nqt);
+  }
   TT_CHECK_LAUNCH("attention_fwd_pairs");
   return TT_OK;
 }

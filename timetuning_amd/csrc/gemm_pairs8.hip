@@ -30,6 +30,8 @@
 // two waves per SIMD.
 #include "common.hpp"
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 namespace tt {
 
@@ -50,6 +52,12 @@ struct Q8Args {
   int ntn, ntiles, ncu;   // column tiles, whole tiles, workgroups launched
   int n_full, n_half;     // as gemm_planes8.hip: n_full whole tiles per workgroup, then n_half half tiles; both 0: round-robin
   int order_mode;         // order of the load part (see `reads_first`)
+  // K-split of the tiles beyond the last whole round (ks_S >= 2; then n_half == 0): tile n_full * ncu + j, j < ks_R, is computed by the
+  // ks_S workgroups cu = j * ks_S + s, each over a contiguous range of K-tile triples; every WAVE leaves the fp32 partial of its 64 x 64
+  // sub-tile in ks_ws, and the wave that arrives last at the (tile, wave) counter adds the partials in slice order and runs the epilogue
+  int ks_S, ks_R;
+  float* ks_ws;           // [ks_R][ks_S][8 waves][4096]
+  int* ks_cnt;            // [ks_R][8], zero between launches (the finishing wave resets its counter)
 };
 
 __device__ __forceinline__ void q8_dma16(const void* base, unsigned char* lds_dst, int voffset, int soffset) {
@@ -63,6 +71,16 @@ __device__ __forceinline__ f32x4 q8_ld128(const void* base, unsigned nbytes, uns
 __device__ __forceinline__ void q8_st128(void* base, unsigned nbytes, unsigned voff, u32x4 v) {
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, nbytes, 0x00020000);
   __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+}
+// sc0 sc1 accesses (aux bits 0 and 4): write-through / read-around of the XCD's L2 - how the K-split partials travel between workgroups
+// that may sit on different XCDs without an L2 write-back + invalidate per wave (measured: agent-scope fences cost ~75 us per launch)
+__device__ __forceinline__ f32x4 q8_ld128_sys(const void* base, unsigned nbytes, unsigned voff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, nbytes, 0x00020000);
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 17));
+}
+__device__ __forceinline__ void q8_st128_sys(void* base, unsigned nbytes, unsigned voff, u32x4 v) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, nbytes, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 17);
 }
 template <int N>
 __device__ __forceinline__ void q8_wait_vmcnt() {
@@ -133,22 +151,32 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
   if ((g.ncu & 7) == 0) cu = (blockIdx.x & 7) * (g.ncu >> 3) + (blockIdx.x >> 3);
   int n_whole;
   bool has_half = false;
-  if (g.n_full > 0 || g.n_half > 0) {
+  const bool ksplit = g.ks_S >= 2;
+  if (g.n_full > 0 || g.n_half > 0 || ksplit) {
     n_whole = g.n_full;
-    has_half = cu < g.n_half;
+    has_half = !ksplit && cu < g.n_half;
   } else {
     n_whole = cu < g.ntiles ? (g.ntiles - cu + g.ncu - 1) / g.ncu : 0;
   }
-  const int n_items = n_whole + (has_half ? 1 : 0);
+  const bool has_slice = ksplit && cu < g.ks_R * g.ks_S;   // the last item: a K range of one of the left-over tiles
+  const int n_items = n_whole + (has_half || has_slice ? 1 : 0);
   if (n_items == 0) return;   // whole workgroup
   const bool half_first = has_half && (cu & 1) && n_whole > 0;
-  auto item = [&](int it, int& row0, int& n0, bool& half) {
+  // item -> output tile origin, half flag, K-tile range [kt0, kend) (a multiple of 3 K-tiles long)
+  auto item = [&](int it, int& row0, int& n0, bool& half, int& kt0, int& kend) {
     int tile;
+    kt0 = 0;
+    kend = nk;
     half = has_half && (half_first ? it == 0 : it == n_whole);
     int hsel = 0;
     if (half) {
       tile = g.n_full * g.ncu + (cu >> 1);
       hsel = cu & 1;
+    } else if (has_slice && it == n_whole) {
+      const int j = cu / g.ks_S, sl = cu - j * g.ks_S, U = nk / 3;
+      tile = g.n_full * g.ncu + j;
+      kt0 = 3 * (sl * U / g.ks_S);
+      kend = 3 * ((sl + 1) * U / g.ks_S);
     } else {
       tile = (half_first ? it - 1 : it) * g.ncu + cu;
     }
@@ -164,7 +192,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
   const int w_voff = d_row0 * K4 + d_chunk * 16;
 
   // DMA cursor: the K-tile whose chunks are issued next (scalar state + the X voffsets of its item; rows beyond M are clamped)
-  int d_item = 0, d_kt = 0;
+  int d_item = 0, d_kt = 0, d_kend = 0;
   bool d_done = false, d_half = false;
   int half_guard = 0;   // > 0: the DMA window may hold a K-tile of a half item: the counted waits take the smaller count
   int d_kofs = 0;       // d_kt * ROWB
@@ -172,7 +200,8 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
   int x_voff[2][JPW];
   auto cursor_item = [&]() {
     int row0, n0;
-    item(d_item, row0, n0, d_half);
+    item(d_item, row0, n0, d_half, d_kt, d_kend);
+    d_kofs = d_kt * ROWB;
     d_wbase = n0 * K4;
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha)
@@ -187,9 +216,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
   auto cursor_next_ktile = [&]() {
     ++d_kt;
     d_kofs += ROWB;
-    if (d_kt == nk) {
-      d_kt = 0;
-      d_kofs = 0;
+    if (d_kt == d_kend) {
       ++d_item;
       if (d_item >= n_items) {
         d_done = true;
@@ -573,6 +600,66 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
     post_half = half;
   };
 
+  // ---- K-split item: this wave's partial -> workspace; the wave arriving last at the (tile, wave) counter sums the slices' partials in
+  // slice order (its own from registers, in its place: the result does not depend on who finishes) into a1 and goes on to the epilogue.
+  // The slices of a tile may run on different XCDs (separate L2s): the partials are stored write-through and loaded around the L2
+  // (sc0 sc1), the stores are complete (vmcnt 0) before the wave's agent-scope increment of the counter.
+  auto slice_reduce = [&]() -> bool {
+    const int j = cu / g.ks_S, sl = cu - j * g.ks_S;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { a1[a][m][e] = fmaf(a2[a][m][e], 0.00048828125f, a1[a][m][e]); a2[a][m][e] = 0.f; }
+    // this (tile, wave)'s partials: slice t at byte t * 128 KB, 64 values per lane as 16 lane-contiguous 16-byte pieces
+    float* wbase = g.ks_ws + ((size_t)j * g.ks_S * 8 + wave) * 4096;
+    const unsigned wbytes = (unsigned)g.ks_S * 8u * 4096u * 4u;
+    const unsigned sstride = 8u * 4096u * 4u;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {a1[a][m][4 * q], a1[a][m][4 * q + 1], a1[a][m][4 * q + 2], a1[a][m][4 * q + 3]};
+          q8_st128_sys(wbase, wbytes, (unsigned)sl * sstride + (unsigned)(((a * 2 + m) * 4 + q) * 1024 + lane * 16), __builtin_bit_cast(u32x4, v));
+        }
+    q8_wait_vmcnt<0>();
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(g.ks_cnt + j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != g.ks_S - 1) return false;
+    if (lane == 0) __hip_atomic_store(g.ks_cnt + j * 8 + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every slice's partial (its own too: the sum is in slice order whoever finishes) back from memory, 16 loads in flight per slice;
+    // a2 is the landing buffer, a1 the running sum.  (Two slices in flight - a second 64-register landing buffer - spills.)
+    for (int t = 0; t < g.ks_S; ++t) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = q8_ld128_sys(wbase, wbytes, (unsigned)t * sstride + (unsigned)(((a * 2 + m) * 4 + q) * 1024 + lane * 16));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a2[a][m][4 * q + e] = v[e];
+          }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) a1[a][m][e] = t == 0 ? a2[a][m][e] : a1[a][m][e] + a2[a][m][e];
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a2[a][m][e] = 0.f;
+    return true;
+  };
+
   // ---- prologue: K-tile 0 whole, W and X0 of K-tile 1 (what phases -3 .. -1 of the steady schedule would have issued, in its order)
   {
     using I0_ = std::integral_constant<int, 0>; using I1_ = std::integral_constant<int, 1>; using I2_ = std::integral_constant<int, 2>;
@@ -589,15 +676,15 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
 
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
   for (int it = 0; it < n_items; ++it) {
-    int row0, n0;
-    item(it, row0, n0, c_half);
+    int row0, n0, c_kt0, c_kend;
+    item(it, row0, n0, c_half, c_kt0, c_kend);
     if (grp1) __builtin_amdgcn_s_barrier();   // the second group runs one barrier interval behind
-    for (int kk = 0; kk < nk; kk += 3) {
+    for (int kk = c_kt0; kk < c_kend; kk += 3) {
       // steady for these 6 phases?  The cursor advances three K-tiles in them: it must stay in whole tiles and short of the end.
       steady = post_epi == 0 && half_guard == 0 && !c_half && !d_half && !d_done;
-      if (steady && d_kt + 3 >= nk) {   // it crosses into the next item
+      if (steady && d_kt + 3 >= d_kend) {   // it crosses into the next item
         bool nhalf = false;
-        if (d_item + 1 < n_items) { int r0_, n0_; item(d_item + 1, r0_, n0_, nhalf); }
+        if (d_item + 1 < n_items) { int r0_, n0_, k0_, k1_; item(d_item + 1, r0_, n0_, nhalf, k0_, k1_); }
         steady = d_item + 1 < n_items && !nhalf;
       }
       phase(I0{}, I0{}); phase(I0{}, I1{});
@@ -606,6 +693,9 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
     }
     steady = false;
     if (!grp1) __builtin_amdgcn_s_barrier();  // realign: both groups run their epilogues at the same time
+    if (has_slice && it == n_whole) {
+      if (!slice_reduce()) continue;   // (the last item: nothing follows)
+    }
     epilogue(row0, n0, c_half);
   }
 #ifdef TT_Q8_CLOCK
@@ -638,8 +728,11 @@ static int launch_pairs8(const Q8Args& g, hipStream_t s) {
 
 
 // Shape / epilogue eligibility and the work decomposition.  Returns the epilogue kind or -1.
-static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_pre, bool has_gelu_pre, int M, int N, int K, int act, int* ntn_out,
-                       long long* ntiles_out, int* ncu_out, int* n_full_out, int* n_half_out) {
+struct Q8Plan {
+  int ntn, ncu, n_full, n_half, ks_S, ks_R;
+  long long ntiles;
+};
+static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_pre, bool has_gelu_pre, int M, int N, int K, int act, Q8Plan* pl) {
   if (N % 128 != 0 || K % 96 != 0 || M < 256) return -1;
   int epi = -1;
   if (has_gelu_pre) {
@@ -660,23 +753,70 @@ static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_p
   const int ntm = (M + 255) / 256, ntn = N / 128;
   const long long ntiles = (long long)ntm * ntn;
   const int ncu_dev = device_cu_count();
-  if (ntiles < ncu_dev / 2) return -1;   // a persistent grid that cannot fill the chip: the small-tile kernel does better
-  int ncu = (int)(ntiles < ncu_dev ? ntiles : ncu_dev), n_full = 0, n_half = 0;
   const long long R = ntiles / ncu_dev, rem = ntiles - R * ncu_dev;
-  if (rem > 0 && 2 * rem <= ncu_dev && tuning_knob(KNOB_P8_NO_HALF) == 0) {
+  // K-split of the rem left-over tiles (Q8Args::ks_S): S = the workgroups available per tile, at most one K-tile triple each and at most 6
+  // (the finishing wave reads S - 1 partials).  Taken when its estimated last-round time - the longest slice + the partial traffic, in
+  // microseconds - beats the half tiles' (0.86 of a tile, tools/q8_nohalf.py) or the round-robin's whole tile by 10 %; knob
+  // TT_Q8_KSPLIT = mode + 10 * cap: mode 0 off, 1 (default) only behind whole rounds, 2 also for grids of less than one round (which
+  // without it go to the small-tile kernel below half a round; measured: no gain); cap = most slices per tile (0: 6).
+  const int ksplit_knob = tuning_knob(KNOB_Q8_KSPLIT) % 10, ksplit_cap = tuning_knob(KNOB_Q8_KSPLIT) / 10;
+  int ks_S = 0;
+  if (ksplit_knob != 0 && rem > 0 && (R > 0 || ksplit_knob >= 2)) {
+    const int U = K / 96, nk = K / 32;
+    int S = (int)(ncu_dev / rem);
+    if (S > U) S = U;
+    if (S > (ksplit_cap > 0 ? ksplit_cap : 6)) S = ksplit_cap > 0 ? ksplit_cap : 6;
+    if (S >= 2) {
+      // microseconds (tools/q8_ksplit.py): 1.3 per K-tile + 3 for the epilogue; the exchange ~ 9 + 1 per slice (store, counter, the partials)
+      const double t_tile = 1.3 * nk + 3.0;
+      const double t_slice = 1.3 * 3 * ((U + S - 1) / S) + 3.0 + 9.0 + 1.0 * S;
+      const double t_else = (2 * rem <= ncu_dev && tuning_knob(KNOB_P8_NO_HALF) == 0) ? 0.86 * t_tile : t_tile;
+      if (t_slice < 0.9 * t_else && (R > 0 || rem * S >= ncu_dev / 2)) ks_S = S;
+    }
+  }
+  if (ntiles < ncu_dev / 2 && ks_S == 0) return -1;   // a persistent grid that cannot fill the chip: the small-tile kernel does better
+  int ncu = (int)(ntiles < ncu_dev ? ntiles : ncu_dev), n_full = 0, n_half = 0;
+  if (ks_S >= 2) {
+    ncu = R > 0 ? ncu_dev : (int)rem * ks_S;
+    n_full = (int)R;
+  } else if (rem > 0 && 2 * rem <= ncu_dev && tuning_knob(KNOB_P8_NO_HALF) == 0) {
     ncu = ncu_dev;
     n_full = (int)R;
     n_half = (int)(2 * rem);
   }
-  *ntn_out = ntn; *ntiles_out = ntiles; *ncu_out = ncu; *n_full_out = n_full; *n_half_out = n_half;
+  pl->ntn = ntn; pl->ntiles = ntiles; pl->ncu = ncu; pl->n_full = n_full; pl->n_half = n_half; pl->ks_S = ks_S; pl->ks_R = ks_S ? (int)rem : 0;
   return epi;
 }
 
+// The K-split workspace: one per (device, stream), allocated at the first launch that needs it and kept (32 MB + the counters).
+struct Q8Ws { int dev; hipStream_t s; float* ws; int* cnt; };
+static std::mutex q8_ws_mu;
+static std::vector<Q8Ws> q8_ws_list;
+static int q8_workspace(hipStream_t s, float** ws, int** cnt) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("gemm_pairs8: hipGetDevice failed"); return TT_ELAUNCH; }
+  std::lock_guard<std::mutex> lock(q8_ws_mu);
+  for (const Q8Ws& b : q8_ws_list)
+    if (b.dev == dev && b.s == s) { *ws = b.ws; *cnt = b.cnt; return TT_OK; }
+  Q8Ws b{dev, s, nullptr, nullptr};
+  const size_t slices = (size_t)device_cu_count();   // ks_R * ks_S <= CUs
+  if (hipMalloc(reinterpret_cast<void**>(&b.ws), slices * 8 * 4096 * sizeof(float)) != hipSuccess) {
+    set_error("gemm_pairs8: cannot allocate the K-split workspace");
+    return TT_ELAUNCH;
+  }
+  if (hipMalloc(reinterpret_cast<void**>(&b.cnt), slices * 8 * sizeof(int)) != hipSuccess || hipMemset(b.cnt, 0, slices * 8 * sizeof(int)) != hipSuccess) {
+    (void)hipFree(b.ws);
+    set_error("gemm_pairs8: cannot allocate the K-split counters");
+    return TT_ELAUNCH;
+  }
+  q8_ws_list.push_back(b);
+  *ws = b.ws; *cnt = b.cnt;
+  return TT_OK;
+}
+
 int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, int has_pairs, int has_pre, int has_gelu_pre) {
-  int ntn, ncu, n_full, n_half;
-  long long ntiles;
-  return pairs8_plan(has_residual != 0, has_y != 0, has_pairs != 0, has_pre != 0, has_gelu_pre != 0, M, N, K, act, &ntn, &ntiles, &ncu, &n_full,
-                     &n_half) >= 0;
+  Q8Plan pl;
+  return pairs8_plan(has_residual != 0, has_y != 0, has_pairs != 0, has_pre != 0, has_gelu_pre != 0, M, N, K, act, &pl) >= 0;
 }
 
 // Called by linear_pairs_impl (gemm_planes.hip).  Returns TT_OK after a launch, 1 when the shape / epilogue is not this kernel's (the caller
@@ -684,13 +824,18 @@ int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, 
 // gelu_pre: the pre-activation whose gelu' multiplies a data-gradient product.
 int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out, void* y_pairs,
                const float* gelu_pre, int M, int N, int K, int act, hipStream_t s) {
-  int ntn, ncu, n_full, n_half;
-  long long ntiles;
-  const int epi = pairs8_plan(residual != nullptr, y != nullptr, y_pairs != nullptr, pre_out != nullptr, gelu_pre != nullptr, M, N, K, act, &ntn,
-                              &ntiles, &ncu, &n_full, &n_half);
+  Q8Plan pl;
+  const int epi = pairs8_plan(residual != nullptr, y != nullptr, y_pairs != nullptr, pre_out != nullptr, gelu_pre != nullptr, M, N, K, act, &pl);
   if (epi < 0) return 1;
+  float* ks_ws = nullptr;
+  int* ks_cnt = nullptr;
+  if (pl.ks_S >= 2) {
+    const int rc = q8_workspace(s, &ks_ws, &ks_cnt);
+    if (rc != TT_OK) return rc;
+  }
   Q8Args g{static_cast<const _Float16*>(x_pairs), static_cast<const _Float16*>(w_pairs), M, N, K, bias, gelu_pre ? gelu_pre : residual,
-           pre_out ? pre_out : y, static_cast<_Float16*>(y_pairs), ntn, (int)ntiles, ncu, n_full, n_half, q8_order_mode()};
+           pre_out ? pre_out : y, static_cast<_Float16*>(y_pairs), pl.ntn, (int)pl.ntiles, pl.ncu, pl.n_full, pl.n_half, q8_order_mode(),
+           pl.ks_S, pl.ks_R, ks_ws, ks_cnt};
 #ifdef TT_Q8_ABLATE   // timing-study build only: TT_Q8_DBG selects a crippled instantiation
   {
     const char* e = getenv("TT_Q8_DBG");

@@ -121,7 +121,7 @@ extern "C" int tt_vit_forward(const tt_vit_params* p, const float* img, const in
       float* qkv = qkv_out ? qkv_out : reinterpret_cast<float*>(big);
       float* att = reinterpret_cast<float*>(att_region);
       TT_FORWARD(tt_layernorm_fwd_pairs(tokens, b.norm1_w, b.norm1_b, hp, nullptr, nullptr, (int)M, D, 1e-6f, 0, stream));
-      if (!qkv_out && !probs && N <= 256 && hd == 64) {
+      if (!qkv_out && !probs && hd == 64) {
         // qkv in pairs [M][2 x 3 D] (the bytes of the fp32 qkv region), the pair attention kernel, its output in pairs (the fp32 att region)
         TT_FORWARD(tt_linear_fwd_pairs(hp, b.qkv_wp, b.qkv_b, nullptr, nullptr, nullptr, big, (int)M, 3 * D, D, 0, stream));
         TT_FORWARD(tt_attention_fwd_pairs(big, att_region, nullptr, nullptr, F, N, p->heads, hd, scale, stream));

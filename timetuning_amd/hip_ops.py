@@ -886,8 +886,8 @@ def linear_fwd_pairs(xp, wp, bias=None, residual=None, act: int = 0, out_f32: bo
 
 
 def attention_pairs_ok(N: int, head_dim: int) -> bool:
-    """Shapes ``attention_fwd_pairs`` takes."""
-    return N <= 256 and head_dim == 64
+    """Shapes ``attention_fwd_pairs`` takes (any N: K / V resident in LDS up to 256 tokens, the KV-tiled kernel beyond)."""
+    return head_dim == 64
 
 
 def attention_fwd_pairs(qkv_pairs, num_heads: int, out_pairs: bool = True, out_f32: bool = False, save_lse: bool = False):
