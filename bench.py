@@ -57,6 +57,8 @@ def kernel_label(name, tile):
         return f"gemm_nt_bf16_kernel<{TILE_NAMES[tile]}> (forward nn.Linear, fp32 operands converted while staged)"
     if name == "PAIRS8":
         return "gemm_pairs8_kernel (nn.Linear on fp16-pair operands, persistent kernel, 3 MFMAs per term)"
+    if name == "PAIRS_TN":
+        return "gemm_pairs_tn_kernel (weight gradient from row pairs, transposing LDS reads) + fold"
     if name == "PAIRS":
         return "gemm_planes_kernel<PAIR> (nn.Linear on fp16-pair operands, general kernel)"
     if name.startswith("PLANES8_"):
@@ -207,7 +209,8 @@ def single_rank_exchange_probe(argv, timeout_s=240):
 
 PEAK_BY_KERNEL = {"PLANES1": BF16_MATRIX_PEAK_TFLOPS, "PLANES2": BF16_MATRIX_PEAK_TFLOPS / 3, "PLANES3": BF16_MATRIX_PEAK_TFLOPS / 6,
                   "PLANES8_1": BF16_MATRIX_PEAK_TFLOPS, "PLANES8_3": BF16_MATRIX_PEAK_TFLOPS / 6,
-                  "PAIRS8": BF16_MATRIX_PEAK_TFLOPS / 3, "PAIRS": BF16_MATRIX_PEAK_TFLOPS / 3}
+                  "PAIRS8": BF16_MATRIX_PEAK_TFLOPS / 3, "PAIRS": BF16_MATRIX_PEAK_TFLOPS / 3,
+                  "PAIRS_TN": BF16_MATRIX_PEAK_TFLOPS / 3}
 
 
 def roofline_block(prof, step_seconds, precision):

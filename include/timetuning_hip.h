@@ -234,12 +234,17 @@ int tt_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, float* out_f3
  *   tt_split_pairs_dual           fp32 [R][C] -> transposed pairs [C][2 Rpad] (rows R..Rpad-1 zero, Rpad % 32 == 0) and, optionally in the
  *                                 same pass, row-major pairs [R][2 C] (C % 32 == 0) and the fp32 column sums [C]: a dy is read ONCE for
  *                                 the operand of its weight-gradient product, the operand of its data-gradient product and its bias
- *                                 gradient.  workspace (column sums only): ceil(Rpad / 64) x C floats.
+ *                                 gradient.  workspace (column sums only): ceil(Rpad / 64) x C floats.  dst_t_pairs may be null (row
+ *                                 pairs + column sums only: all the transpose-free weight gradient below needs).
  *   tt_transpose_pairs            pairs [R][2 C] -> transposed pairs [C][2 Rpad]: a saved forward operand for the weight gradient.
  *   tt_linear_bwd_data_pairs      dx[M,K] = dy[M,N] @ w[N,K] (* gelu'(gelu_pre[M,K])): dy in pairs [M][2 N], the weight transposed in pairs
  *                                 wT [K][2 N]; N % 32 == 0, K % 64 == 0.
  *   tt_linear_bwd_weight_pairs    dw[N,K] = dy^T @ x: dyT [N][2 Mpad], xT [K][2 Mpad] (K % 64 == 0); split-K partials in the workspace,
- *                                 folded in a fixed order. */
+ *                                 folded in a fixed order.
+ *   tt_linear_bwd_weight_pairs_tn the same product from ROW pairs - dy [M][2 N] (the data-gradient product's operand) and the layer's
+ *                                 input x [M][2 K] as the forward kept it: no transposed copies (gemm_pairs_tn.hip: the fragments are
+ *                                 gathered by transposing LDS reads).  N % 128 == 0, K % 128 == 0, any M (_ok says whether a shape is
+ *                                 taken); partials of the split m range in the workspace, folded in a fixed order. */
 size_t tt_split_pairs_dual_workspace_bytes(int R, int C, int Rpad);
 int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, int R, int C, int Rpad, void* workspace,
                         size_t workspace_bytes, tt_stream_t stream);
@@ -248,6 +253,10 @@ int tt_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const f
 size_t tt_linear_bwd_weight_pairs_workspace_bytes(int N, int K, int Mpad);
 int tt_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, float* dw, int N, int K, int Mpad, void* workspace,
                                size_t workspace_bytes, tt_stream_t stream);
+int tt_linear_bwd_weight_pairs_tn_ok(int N, int K, int M);
+size_t tt_linear_bwd_weight_pairs_tn_workspace_bytes(int N, int K, int M);
+int tt_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, float* dw, int N, int K, int M, void* workspace,
+                                  size_t workspace_bytes, tt_stream_t stream);
 /*   The backward products of the same nn.Linear sites on bf16-plane operands (autograd of dino_vision_transformer.py:94-103,
  *   115-130; the bf16 path only - the fp32 modes keep the f32-MFMA backward kernels):
  *   tt_transpose_planes               fp32 [R][C] -> bf16 [C][Rpad], transposed, columns R..Rpad-1 zero (reduction index contiguous)

@@ -970,7 +970,7 @@ int tt_cpu_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_p
     double s = 0.0;
     for (int r = 0; r < Rpad; ++r) {
       const float v = r < R ? src[(size_t)r * C + c] : 0.f;
-      pair_put(t + (size_t)c * 2 * Rpad, r, v);
+      if (t) pair_put(t + (size_t)c * 2 * Rpad, r, v);
       s += v;
     }
     if (colsum) colsum[c] = (float)s;
@@ -1008,6 +1008,25 @@ int tt_cpu_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, 
   const uint16_t *dyT = (const uint16_t*)dyT_pairs, *xT = (const uint16_t*)xT_pairs;   /* dyT [N][2 Mpad], xT [K][2 Mpad] */
   for (int n = 0; n < N; ++n)
     for (int k = 0; k < K; ++k) dw[(size_t)n * K + k] = (float)pair_dot(dyT + (size_t)n * 2 * Mpad, xT + (size_t)k * 2 * Mpad, Mpad);
+  return 0;
+}
+
+/* gemm_pairs_tn.hip: the same product from row pairs dy [M][2 N], x [M][2 K] */
+int tt_cpu_linear_bwd_weight_pairs_tn_ok(int N, int K, int M) { return N > 0 && K > 0 && M > 0 && N % 128 == 0 && K % 128 == 0; }
+size_t tt_cpu_linear_bwd_weight_pairs_tn_workspace_bytes(int N, int K, int M) { return 0; }
+int tt_cpu_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, float* dw, int N, int K, int M, void* workspace,
+                                      size_t workspace_bytes, tt_stream_t stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  const uint16_t *dy = (const uint16_t*)dy_pairs, *x = (const uint16_t*)x_pairs;
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) {
+      double s = 0.0;
+      for (int m = 0; m < M; ++m) {
+        const uint16_t *a = dy + (size_t)m * 2 * N, *b = x + (size_t)m * 2 * K;
+        s += pair_hi(a, n) * pair_hi(b, k) + pair_hi(a, n) * pair_lo(b, k) + pair_lo(a, n) * pair_hi(b, k);
+      }
+      dw[(size_t)n * K + k] = (float)s;
+    }
   return 0;
 }
 

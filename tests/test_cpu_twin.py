@@ -713,6 +713,14 @@ def test_round4_pair_twins_against_numpy(twin):
     assert twin.tt_cpu_linear_bwd_weight_pairs(ptr(dyT), ptr(t), ptr(dw), N, K, 64, None, 0, None) == 0
     dx_ref, dw_ref = dy.astype(np.float64) @ w, dy.astype(np.float64).T @ x
     assert np.abs(dx - dx_ref).max() / np.abs(dx_ref).max() < 5e-7 and np.abs(dw - dw_ref).max() / np.abs(dw_ref).max() < 5e-7
+    # the same weight gradient from ROW pairs (gemm_pairs_tn.hip's twin); the column sums without a transposed output
+    dw_tn = np.empty((N, K), np.float32)
+    assert twin.tt_cpu_linear_bwd_weight_pairs_tn(ptr(dyr), ptr(xp), ptr(dw_tn), N, K, M, None, 0, None) == 0
+    assert np.abs(dw_tn - dw_ref).max() / np.abs(dw_ref).max() < 5e-7 and np.abs(dw_tn - dw).max() <= 1e-6 * np.abs(dw).max()
+    assert twin.tt_cpu_linear_bwd_weight_pairs_tn_ok(128, 256, 5) == 1 and twin.tt_cpu_linear_bwd_weight_pairs_tn_ok(64, 256, 5) == 0
+    dyr2, cs = np.empty((M, 2 * N), np.uint16), np.empty((N,), np.float32)
+    assert twin.tt_cpu_split_pairs_dual(ptr(dy), None, ptr(dyr2), ptr(cs), M, N, 64, None, 0, None) == 0
+    assert np.array_equal(dyr2, dyr) and np.allclose(cs, dy.sum(0), atol=1e-6)
     # attention on pairs against torch in fp64
     Fr, Nn, H = 2, 19, 2
     D = 64 * H

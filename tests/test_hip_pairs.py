@@ -145,16 +145,26 @@ def _attention_pairs_case(ops, Fr, N, H):
     assert torch.equal(only_pairs, op)
 
 
-@pytest.mark.parametrize("M,N,K", [(6304, 1536, 384), (6304, 384, 1152), (591, 256, 512), (3152, 768, 3072)])
-def test_backward_products_on_pairs(M, N, K):
+@pytest.mark.parametrize("tn", [True, False])
+@pytest.mark.parametrize("M,N,K", [(6304, 1536, 384), (6304, 384, 1152), (591, 256, 512), (3152, 768, 3072), (6299, 384, 384), (45, 128, 256)])
+def test_backward_products_on_pairs(M, N, K, tn):
     """dx = dy @ w (* gelu'(pre)), dw = dy^T @ x and db = dy.sum(0) of an nn.Linear on pair operands (the "f16x3" mode's backward): against
-    fp64 at the f32 bound, not worse than the f32-MFMA backward kernels, split-K fold included."""
+    fp64 at the f32 bound, not worse than the f32-MFMA backward kernels, split-K fold included.  tn: the weight gradient from ROW pairs
+    (gemm_pairs_tn.hip: ragged M read as zeros) / from transposed pairs (the route of the shapes that kernel does not take)."""
     from timetuning_amd import engine, hip_ops as ops
 
     dy, w, x = rnd(f"bwd.dy{M}.{N}", M, N, scale=1e-3), rnd(f"bwd.w{N}.{K}", N, K, scale=0.05), rnd(f"bwd.x{M}.{K}", M, K)
     pre = rnd(f"bwd.pre{M}.{K}", M, K)
     xp = ops.split_pairs(x.cuda())
-    dx, dw, db = engine._bwd_both_pairs(dy.cuda(), w.cuda(), xp, pre.cuda())
+    assert ops.TN_WGRAD
+    ops.TN_WGRAD = tn
+    try:
+        assert ops.bwd_weight_pairs_tn_ok(M, N, K) == (tn and N % 128 == 0 and K % 128 == 0)
+        dx, dw, db = engine._bwd_both_pairs(dy.cuda(), w.cuda(), xp, pre.cuda())
+        if tn and ops.bwd_weight_pairs_tn_ok(M, N, K):   # run-to-run bit equality (fixed fold order)
+            assert torch.equal(engine._bwd_both_pairs(dy.cuda(), w.cuda(), xp, pre.cuda())[1], dw)
+    finally:
+        ops.TN_WGRAD = True
     from oracle import timet_oracle as O  # noqa: F401  (the checker's GELU' is torch's own below)
 
     pd = pre.double().requires_grad_(True)

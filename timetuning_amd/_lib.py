@@ -85,6 +85,9 @@ SIGNATURES = {
     "tt_linear_bwd_data_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp]),
     "tt_linear_bwd_weight_pairs_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_linear_bwd_weight_pairs": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "tt_linear_bwd_weight_pairs_tn_ok": (c_i, [c_i, c_i, c_i]),
+    "tt_linear_bwd_weight_pairs_tn_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "tt_linear_bwd_weight_pairs_tn": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_transpose_planes": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp]),
     "tt_transpose_planes_colsum_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_transpose_planes_colsum": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp, c_vp, c_sz, c_vp]),

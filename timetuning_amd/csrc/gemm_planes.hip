@@ -544,6 +544,7 @@ __global__ __launch_bounds__(256) void transpose_pairs_kernel(const void* __rest
     if (ty == 0 && c0 + tx < C) partial[(size_t)blockIdx.x * C + c0 + tx] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
   }
   // out row c: the tile's 64 r = two pair groups; 16 lanes x 4 r per row (8-byte stores), 16 rows per pass
+  if (!dst_t) return;   // (uniform) row pairs / column sums only
   const int q = threadIdx.x & 15, cr = threadIdx.x >> 4;
   for (int i = cr; i < 64; i += 16) {
     const int c = c0 + i, r = r0 + 4 * q;
@@ -846,7 +847,8 @@ extern "C" size_t tt_split_pairs_dual_workspace_bytes(int R, int C, int Rpad) {
 
 extern "C" int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, int R, int C, int Rpad, void* workspace,
                                    size_t workspace_bytes, tt_stream_t stream) {
-  TT_REQUIRE(src && dst_t_pairs && R > 0 && C > 0 && Rpad >= R && Rpad % 32 == 0, "split_pairs_dual: bad arguments (Rpad must be a multiple of 32)");
+  TT_REQUIRE(src && (dst_t_pairs || dst_row_pairs) && R > 0 && C > 0 && Rpad >= R && Rpad % 32 == 0,
+             "split_pairs_dual: bad arguments (an output, Rpad a multiple of 32)");
   TT_REQUIRE(!dst_row_pairs || C % 32 == 0, "split_pairs_dual: row-major pairs need C %% 32 == 0 (got %d)", C);
   TT_REQUIRE(!colsum || (workspace && workspace_bytes >= tt_split_pairs_dual_workspace_bytes(R, C, Rpad)), "split_pairs_dual: workspace too small");
   TT_REQUIRE((reinterpret_cast<uintptr_t>(dst_t_pairs) & 7u) == 0, "split_pairs_dual: the transposed output must be 8-byte aligned");

@@ -180,7 +180,7 @@ def weight_pairs_t(w: torch.Tensor) -> torch.Tensor:
 def _bwd_both_pairs(dy: torch.Tensor, w: torch.Tensor, xp: torch.Tensor, gelu_pre: Optional[torch.Tensor] = None, need_dx: bool = True,
                     dw_out=None, db_out=None):
     """(dx, dw, db) of an nn.Linear on pair operands: xp = the layer's input as kept by the forward (row-major pairs [M, 2 K])."""
-    return ops.linear_bwd_pairs(dy, weight_pairs_t(w), ops.transpose_pairs(xp), gelu_pre=gelu_pre, need_dx=need_dx, dw_out=dw_out, db_out=db_out)
+    return ops.linear_bwd_pairs(dy, weight_pairs_t(w), gelu_pre=gelu_pre, need_dx=need_dx, dw_out=dw_out, db_out=db_out, x_pairs=xp)
 
 
 def _bwd_weight(dy: torch.Tensor, x: torch.Tensor, need_bias: bool = True):

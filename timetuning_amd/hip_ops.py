@@ -87,6 +87,7 @@ def pairs() -> bool:
 # pairs against 3.11 ms on the exact-f32 MFMA kernels - so small launches keep the f32 kernels.  Tests set it to 0 to drive the pair
 # kernels with tiny models.
 PAIRS_MIN_ROWS = 1536
+TN_WGRAD = True   # weight gradients of the "f16x3" mode from row pairs (gemm_pairs_tn.hip); False: the transposed-operand route (A/B, tests)
 
 
 def plane_count_for(rows: int) -> int:
@@ -905,14 +906,15 @@ def attention_fwd_pairs(qkv_pairs, num_heads: int, out_pairs: bool = True, out_f
     return op, of, lse
 
 
-def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad: Optional[int] = None, colsum_out=None):
-    """fp32 [R, C] -> (transposed pairs [C, 2 Rpad], row-major pairs [R, 2 C] or None, column sums [C] or None) in ONE pass
+def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad: Optional[int] = None, colsum_out=None, want_t: bool = True):
+    """fp32 [R, C] -> (transposed pairs [C, 2 Rpad] or None, row-major pairs [R, 2 C] or None, column sums [C] or None) in ONE pass
     (tt_split_pairs_dual): what the backward of an nn.Linear needs of its dy."""
     lib = _lib.load()
     _chk(x, "x")
     R, Cc = x.shape
     rpad = (R + 31) // 32 * 32 if rpad is None else rpad
-    t = torch.empty((Cc, 2 * rpad), dtype=f16, device=x.device)
+    assert want_t or want_row
+    t = torch.empty((Cc, 2 * rpad), dtype=f16, device=x.device) if want_t else None
     row = torch.empty((R, 2 * Cc), dtype=f16, device=x.device) if want_row else None
     sums = (_chk(colsum_out, "colsum_out") if colsum_out is not None else torch.empty((Cc,), dtype=f32, device=x.device)) if want_colsum else None
     nb = lib.tt_split_pairs_dual_workspace_bytes(R, Cc, rpad) if want_colsum else 0
@@ -937,22 +939,53 @@ def bwd_pairs_ok(M: int, N: int, K: int) -> bool:
     return N % 64 == 0 and K % 64 == 0
 
 
-def linear_bwd_pairs(dy, wT_pairs, xT_pairs, gelu_pre=None, need_bias: bool = True, need_dx: bool = True, dw_out=None, db_out=None):
-    """(dx, dw, db) of an nn.Linear on pair operands: dy fp32 [M,N] is split here (ONE pass: transposed pairs for the weight gradient, row
-    pairs for the data gradient, column sums = the bias gradient); wT_pairs [K, 2 N] = the weight transposed in pairs, xT_pairs [K, 2 Mpad] =
-    the layer's input transposed in pairs."""
+def bwd_weight_pairs_tn_ok(M: int, N: int, K: int) -> bool:
+    """Shapes the transpose-free weight-gradient kernel takes (dy [M,N], x [M,K] in row pairs)."""
+    return bool(TN_WGRAD) and bool(_lib.load().tt_linear_bwd_weight_pairs_tn_ok(N, K, M))
+
+
+def linear_bwd_weight_pairs_tn(dy_pairs, x_pairs, dw_out=None):
+    """dw [N,K] = dy^T @ x from ROW pairs dy [M, 2 N], x [M, 2 K] (gemm_pairs_tn.hip: no transposed copies)."""
     lib = _lib.load()
-    _chk(dy, "dy"); _chk(wT_pairs, "wT_pairs", f16); _chk(xT_pairs, "xT_pairs", f16)
-    M, N = dy.shape
-    K, Mpad = xT_pairs.shape[0], xT_pairs.shape[1] // 2
-    assert wT_pairs.shape == (K, 2 * N) and Mpad >= M, (dy.shape, wT_pairs.shape, xT_pairs.shape)
-    dyT, dy_row, db = split_pairs_dual(dy, want_row=need_dx, want_colsum=need_bias, rpad=Mpad, colsum_out=db_out)
-    dw = _chk(dw_out, "dw_out") if dw_out is not None else torch.empty((N, K), dtype=f32, device=dy.device)
-    nb = lib.tt_linear_bwd_weight_pairs_workspace_bytes(N, K, Mpad)
-    ws = _ws(nb, dy.device)
+    _chk(dy_pairs, "dy_pairs", f16); _chk(x_pairs, "x_pairs", f16)
+    M, N, K = dy_pairs.shape[0], dy_pairs.shape[1] // 2, x_pairs.shape[1] // 2
+    assert x_pairs.shape[0] == M, (dy_pairs.shape, x_pairs.shape)
+    dw = _chk(dw_out, "dw_out") if dw_out is not None else torch.empty((N, K), dtype=f32, device=dy_pairs.device)
+    nb = lib.tt_linear_bwd_weight_pairs_tn_workspace_bytes(N, K, M)
+    ws = _ws(nb, dy_pairs.device)
     e0 = _prof_begin()
-    _lib.check(lib.tt_linear_bwd_weight_pairs(_p(dyT), _p(xT_pairs), _p(dw), N, K, Mpad, _p(ws), nb, _stream()), "tt_linear_bwd_weight_pairs")
-    _prof_end(e0, "PAIRS", N, K, M)
+    _lib.check(lib.tt_linear_bwd_weight_pairs_tn(_p(dy_pairs), _p(x_pairs), _p(dw), N, K, M, _p(ws), nb, _stream()), "tt_linear_bwd_weight_pairs_tn")
+    _prof_end(e0, "PAIRS_TN", N, K, M)
+    return dw
+
+
+def linear_bwd_pairs(dy, wT_pairs, xT_pairs=None, gelu_pre=None, need_bias: bool = True, need_dx: bool = True, dw_out=None, db_out=None, x_pairs=None):
+    """(dx, dw, db) of an nn.Linear on pair operands: dy fp32 [M,N] is split here in ONE pass (row pairs for both gradient products, column
+    sums = the bias gradient); wT_pairs [K, 2 N] = the weight transposed in pairs.  The layer's input comes as ``x_pairs`` [M, 2 K] (row
+    pairs as the forward kept them: the transpose-free weight-gradient kernel) or, for the shapes that kernel does not take, as
+    ``xT_pairs`` [K, 2 Mpad] (``transpose_pairs``; dy's transposed pairs are then made in the same pass)."""
+    lib = _lib.load()
+    _chk(dy, "dy"); _chk(wT_pairs, "wT_pairs", f16)
+    M, N = dy.shape
+    K = wT_pairs.shape[0]
+    if x_pairs is not None and bwd_weight_pairs_tn_ok(M, N, K):
+        _chk(x_pairs, "x_pairs", f16)
+        assert wT_pairs.shape == (K, 2 * N) and x_pairs.shape == (M, 2 * K), (dy.shape, wT_pairs.shape, x_pairs.shape)
+        _, dy_row, db = split_pairs_dual(dy, want_row=True, want_colsum=need_bias, colsum_out=db_out, want_t=False)
+        dw = linear_bwd_weight_pairs_tn(dy_row, x_pairs, dw_out)
+    else:
+        if xT_pairs is None:
+            xT_pairs = transpose_pairs(x_pairs)
+        _chk(xT_pairs, "xT_pairs", f16)
+        Mpad = xT_pairs.shape[1] // 2
+        assert wT_pairs.shape == (K, 2 * N) and xT_pairs.shape[0] == K and Mpad >= M, (dy.shape, wT_pairs.shape, xT_pairs.shape)
+        dyT, dy_row, db = split_pairs_dual(dy, want_row=need_dx, want_colsum=need_bias, rpad=Mpad, colsum_out=db_out)
+        dw = _chk(dw_out, "dw_out") if dw_out is not None else torch.empty((N, K), dtype=f32, device=dy.device)
+        nb = lib.tt_linear_bwd_weight_pairs_workspace_bytes(N, K, Mpad)
+        ws = _ws(nb, dy.device)
+        e0 = _prof_begin()
+        _lib.check(lib.tt_linear_bwd_weight_pairs(_p(dyT), _p(xT_pairs), _p(dw), N, K, Mpad, _p(ws), nb, _stream()), "tt_linear_bwd_weight_pairs")
+        _prof_end(e0, "PAIRS", N, K, M)
     dx = None
     if need_dx:
         if gelu_pre is not None: _chk(gelu_pre, "gelu_pre")
