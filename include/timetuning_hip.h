@@ -249,6 +249,11 @@ size_t tt_split_pairs_dual_workspace_bytes(int R, int C, int Rpad);
 int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, int R, int C, int Rpad, void* workspace,
                         size_t workspace_bytes, tt_stream_t stream);
 int tt_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int R, int C, int Rpad, tt_stream_t stream);
+/* tt_split_pairs_dual (without column sums) for n matrices in ONE launch per 32 of them: host arrays of n pointers / sizes; dst_t_pairs[i] or
+ * dst_row_pairs[i] may be null.  What a training step needs of every weight the optimizer rewrote (row pairs: forward and weight-gradient
+ * operand; transposed pairs: the data-gradient operand). */
+int tt_split_pairs_dual_multi(const float* const* src, void* const* dst_t_pairs, void* const* dst_row_pairs, const int* R, const int* C,
+                              const int* Rpad, int n, tt_stream_t stream);
 int tt_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, int M, int N, int K, tt_stream_t stream);
 size_t tt_linear_bwd_weight_pairs_workspace_bytes(int N, int K, int Mpad);
 int tt_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, float* dw, int N, int K, int Mpad, void* workspace,

@@ -978,6 +978,14 @@ int tt_cpu_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_p
   if (dst_row_pairs) tt_cpu_split_pairs(src, dst_row_pairs, (long long)R * C, stream);
   return 0;
 }
+int tt_cpu_split_pairs_dual_multi(const float* const* src, void* const* dst_t_pairs, void* const* dst_row_pairs, const int* R, const int* C,
+                                  const int* Rpad, int n, tt_stream_t stream) {
+  for (int i = 0; i < n; ++i) {
+    const int rc = tt_cpu_split_pairs_dual(src[i], dst_t_pairs[i], dst_row_pairs[i], NULL, R[i], C[i], Rpad[i], NULL, 0, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
 int tt_cpu_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int R, int C, int Rpad, tt_stream_t stream) {
   (void)stream;
   const uint16_t* s = (const uint16_t*)src_pairs;

@@ -718,6 +718,13 @@ def test_round4_pair_twins_against_numpy(twin):
     assert twin.tt_cpu_linear_bwd_weight_pairs_tn(ptr(dyr), ptr(xp), ptr(dw_tn), N, K, M, None, 0, None) == 0
     assert np.abs(dw_tn - dw_ref).max() / np.abs(dw_ref).max() < 5e-7 and np.abs(dw_tn - dw).max() <= 1e-6 * np.abs(dw).max()
     assert twin.tt_cpu_linear_bwd_weight_pairs_tn_ok(128, 256, 5) == 1 and twin.tt_cpu_linear_bwd_weight_pairs_tn_ok(64, 256, 5) == 0
+    import ctypes as C
+    m_t, m_row = np.empty((K, 128), np.uint16), np.empty((M, 2 * K), np.uint16)
+    arr = lambda *ps: (C.c_void_p * len(ps))(*[C.c_void_p(p_) if p_ is not None else None for p_ in ps])
+    ints = lambda *v: (C.c_int * len(v))(*v)
+    assert twin.tt_cpu_split_pairs_dual_multi(arr(x.ctypes.data, x.ctypes.data), arr(m_t.ctypes.data, None), arr(None, m_row.ctypes.data),
+                                              ints(M, M), ints(K, K), ints(64, 64), 2, None) == 0
+    assert np.array_equal(m_t, t) and np.array_equal(m_row, xp)
     dyr2, cs = np.empty((M, 2 * N), np.uint16), np.empty((N,), np.float32)
     assert twin.tt_cpu_split_pairs_dual(ptr(dy), None, ptr(dyr2), ptr(cs), M, N, 64, None, 0, None) == 0
     assert np.array_equal(dyr2, dyr) and np.allclose(cs, dy.sum(0), atol=1e-6)

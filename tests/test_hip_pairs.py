@@ -240,3 +240,30 @@ def test_pairs8_load_part_orders_give_the_same_bits():
     finally:
         ops.set_tuning_knob("TT_Q8_ORDER", 3)
     assert all(torch.equal(o, outs[0]) for o in outs[1:])
+
+
+def test_batched_weight_operand_refresh():
+    """engine.refresh_pair_operands: the row pairs and transposed pairs of every stale weight in ONE launch, written into the existing
+    buffers, equal to the lazy per-weight conversions bit for bit; operands that were never made are not made."""
+    from timetuning_amd import engine, hip_ops as ops
+
+    shapes = [(384, 384), (1152, 384), (1536, 384), (384, 1536), (200, 256), (65, 96)]
+    ws = [torch.nn.Parameter(rnd(f"refresh.w{i}", n, k, scale=0.05).cuda()) for i, (n, k) in enumerate(shapes)]
+    ws[4].requires_grad_(False)
+    never = torch.nn.Parameter(rnd("refresh.never", 128, 64).cuda())
+    rows = [engine.weight_planes(w, 2) for w in ws]
+    ts = [engine.weight_pairs_t(w) if w.requires_grad else None for w in ws]
+    assert engine.refresh_pair_operands(ws + [never]) == 0                      # nothing stale
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5).add_(0.01)                                               # (advances the version counter: every tag is stale)
+    assert engine.refresh_pair_operands(ws + [never]) == len(ws)
+    assert getattr(never, "_tt_planes", None) is None and getattr(never, "_tt_pairs_t", None) is None
+    for w, row, t in zip(ws, rows, ts):
+        assert engine.weight_planes(w, 2).data_ptr() == row.data_ptr()          # the cache answers, same buffer
+        assert torch.equal(row, ops.split_pairs(w.detach()))
+        if t is not None:
+            assert engine.weight_pairs_t(w).data_ptr() == t.data_ptr()
+            assert torch.equal(t, ops.split_pairs_dual(w.detach())[0])
+    ops._bump_param_epoch()                                                      # a raw-pointer update (AdamW / EMA): trainable + non-static frozen alike
+    assert engine.refresh_pair_operands(ws) == len(ws)

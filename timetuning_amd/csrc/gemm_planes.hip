@@ -498,12 +498,12 @@ int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, 
 //   weight gradient needs transposed) and the fp32 column sums of the tile's rows (a bias gradient) - one read of dy for all three.
 //   SRC_PAIRS = true: src pairs [R][2 C] (a saved forward operand): a 16-bit transpose of the hi and the lo halves.
 template <bool SRC_PAIRS, bool ROW, bool SUM>
-__global__ __launch_bounds__(256) void transpose_pairs_kernel(const void* __restrict__ src_, _Float16* __restrict__ dst_t, _Float16* __restrict__ dst_row,
-                                                              int R, int C, int Rpad, float* __restrict__ partial) {
+__device__ __forceinline__ void transpose_pairs_tile(const void* __restrict__ src_, _Float16* __restrict__ dst_t, _Float16* __restrict__ dst_row,
+                                                     int R, int C, int Rpad, float* __restrict__ partial, int bx, int by) {
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   __shared__ _Float16 th[64][66], tl[64][66];   // [r][c] halves of the tile (row stride 132 bytes: conflict-free column walks)
   __shared__ float red[4][64];
-  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int r0 = bx * 64, c0 = by * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   if constexpr (SRC_PAIRS) {
     const _Float16* src = static_cast<const _Float16*>(src_);
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void transpose_pairs_kernel(const void* __rest
   }
   __syncthreads();
   if constexpr (SUM) {
-    if (ty == 0 && c0 + tx < C) partial[(size_t)blockIdx.x * C + c0 + tx] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    if (ty == 0 && c0 + tx < C) partial[(size_t)bx * C + c0 + tx] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
   }
   // out row c: the tile's 64 r = two pair groups; 16 lanes x 4 r per row (8-byte stores), 16 rows per pass
   if (!dst_t) return;   // (uniform) row pairs / column sums only
@@ -556,6 +556,30 @@ __global__ __launch_bounds__(256) void transpose_pairs_kernel(const void* __rest
       *reinterpret_cast<f16x4*>(p + 32) = vl;
     }
   }
+}
+template <bool SRC_PAIRS, bool ROW, bool SUM>
+__global__ __launch_bounds__(256) void transpose_pairs_kernel(const void* __restrict__ src_, _Float16* __restrict__ dst_t, _Float16* __restrict__ dst_row,
+                                                              int R, int C, int Rpad, float* __restrict__ partial) {
+  transpose_pairs_tile<SRC_PAIRS, ROW, SUM>(src_, dst_t, dst_row, R, C, Rpad, partial, blockIdx.x, blockIdx.y);
+}
+
+// The same for a TABLE of fp32 matrices in one launch: the pair operands (row pairs for the forward / weight-gradient products, transposed
+// pairs for the data-gradient product) of every weight the optimizer just rewrote - two dozen small launches per step otherwise.
+struct PairTable {
+  enum { MAXN = 32 };
+  const float* src[MAXN];
+  _Float16* row[MAXN];   // may be null
+  _Float16* t[MAXN];     // may be null
+  int R[MAXN], C[MAXN], Rpad[MAXN];
+  int tile0[MAXN + 1];   // first workgroup of each entry
+  int n;
+};
+__global__ __launch_bounds__(256) void split_pairs_dual_multi_kernel(PairTable tb) {
+  int e = 0;
+  while (e + 1 < tb.n && (int)blockIdx.x >= tb.tile0[e + 1]) ++e;
+  const int tile = blockIdx.x - tb.tile0[e], tr = (tb.Rpad[e] + 63) / 64;
+  if (tb.row[e]) transpose_pairs_tile<false, true, false>(tb.src[e], tb.t[e], tb.row[e], tb.R[e], tb.C[e], tb.Rpad[e], nullptr, tile % tr, tile / tr);
+  else transpose_pairs_tile<false, false, false>(tb.src[e], tb.t[e], nullptr, tb.R[e], tb.C[e], tb.Rpad[e], nullptr, tile % tr, tile / tr);
 }
 
 int launch_splitk_reduce(const float* partial, float* out, long long n, int splits, long long stride, hipStream_t s);  // gemm_f32.hip
@@ -863,6 +887,35 @@ extern "C" int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* ds
   else hipLaunchKernelGGL((transpose_pairs_kernel<false, false, false>), grid, block, 0, s, src, dt, dr, R, C, Rpad, nullptr);
   TT_CHECK_LAUNCH("split_pairs_dual");
   if (colsum) return launch_colsum_fold(partial, colsum, (Rpad + 63) / 64, C, s);
+  return TT_OK;
+}
+
+// n fp32 matrices [R_i][C_i] -> row pairs and / or transposed pairs [C_i][2 Rpad_i] each, ONE launch per 32 of them
+extern "C" int tt_split_pairs_dual_multi(const float* const* src, void* const* dst_t_pairs, void* const* dst_row_pairs, const int* R, const int* C,
+                                         const int* Rpad, int n, tt_stream_t stream) {
+  TT_REQUIRE(src && dst_t_pairs && dst_row_pairs && R && C && Rpad && n >= 0, "split_pairs_dual_multi: bad arguments");
+  for (int i0 = 0; i0 < n; i0 += PairTable::MAXN) {
+    PairTable tb;
+    tb.n = n - i0 < PairTable::MAXN ? n - i0 : PairTable::MAXN;
+    int tiles = 0;
+    for (int i = 0; i < tb.n; ++i) {
+      const int j = i0 + i;
+      TT_REQUIRE(src[j] && (dst_t_pairs[j] || dst_row_pairs[j]) && R[j] > 0 && C[j] > 0 && Rpad[j] >= R[j] && Rpad[j] % 32 == 0,
+                 "split_pairs_dual_multi: entry %d: bad arguments (an output, Rpad a multiple of 32)", j);
+      TT_REQUIRE(!dst_row_pairs[j] || C[j] % 32 == 0, "split_pairs_dual_multi: entry %d: row-major pairs need C %% 32 == 0 (got %d)", j, C[j]);
+      TT_REQUIRE((reinterpret_cast<uintptr_t>(dst_t_pairs[j]) & 7u) == 0, "split_pairs_dual_multi: entry %d: the transposed output must be 8-byte aligned", j);
+      tb.src[i] = src[j];
+      tb.t[i] = static_cast<_Float16*>(dst_t_pairs[j]);
+      tb.row[i] = static_cast<_Float16*>(dst_row_pairs[j]);
+      tb.R[i] = R[j]; tb.C[i] = C[j]; tb.Rpad[i] = Rpad[j];
+      tb.tile0[i] = tiles;
+      tiles += ((Rpad[j] + 63) / 64) * ((C[j] + 63) / 64);
+    }
+    tb.tile0[tb.n] = tiles;
+    if (tiles == 0) continue;
+    hipLaunchKernelGGL(split_pairs_dual_multi_kernel, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), tb);
+    TT_CHECK_LAUNCH("split_pairs_dual_multi");
+  }
   return TT_OK;
 }
 

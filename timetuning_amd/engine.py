@@ -53,6 +53,42 @@ def weight_planes(w: torch.nn.Parameter, planes: int) -> torch.Tensor:
     return hit[1]
 
 
+def refresh_pair_operands(weights) -> int:
+    """The fp16-pair operands of Linear weights in ONE launch: for every 2-D weight in ``weights`` whose cached operands are stale (the
+    optimizer / EMA update rewrote it: ``_param_tag``) the row pairs (``weight_planes(w, 2)``) and, for a trainable one, the transposed pairs
+    (``weight_pairs_t(w)``) are rewritten IN their existing buffers and the caches re-tagged - where the lazy per-use route costs two small
+    launches per weight and step.  Only operands that exist already are refreshed (a weight's first use makes them lazily: what no kernel
+    ever read in pairs is never converted).  Returns the number of weights converted."""
+    items, fix = [], []
+    for w in weights:
+        if w.dim() != 2 or w.shape[1] % 32 != 0 or w.dtype != torch.float32:
+            continue
+        tag_row, tag_t = _param_tag(w, 2), _param_tag(w, "T")
+        hit_row, hit_t = getattr(w, "_tt_planes", None), getattr(w, "_tt_pairs_t", None)
+        need_row = hit_row is not None and hit_row[0][3] == 2 and hit_row[0] != tag_row
+        need_t = hit_t is not None and hit_t[0] != tag_t
+        if not (need_row or need_t):
+            continue
+        N, K = w.shape
+        row = t = None
+        if need_row:
+            old = hit_row[1] if hit_row is not None else None
+            row = old if (old is not None and old.dtype == torch.float16 and old.shape == (N, 2 * K)) else torch.empty((N, 2 * K), dtype=torch.float16, device=w.device)
+        if need_t:
+            npad = (N + 31) // 32 * 32
+            old = hit_t[1] if hit_t is not None else None
+            t = old if (old is not None and old.shape == (K, 2 * npad)) else torch.empty((K, 2 * npad), dtype=torch.float16, device=w.device)
+        items.append((w.detach(), row, t))
+        fix.append((w, tag_row if need_row else None, row, tag_t if need_t else None, t))
+    ops.split_pairs_dual_multi(items)
+    for w, tag_row, row, tag_t, t in fix:
+        if tag_row is not None:
+            w._tt_planes = (tag_row, row)
+        if tag_t is not None:
+            w._tt_pairs_t = (tag_t, t)
+    return len(items)
+
+
 def block_forward_planes(x: torch.Tensor, blk, num_heads: int, planes: int, aux: Optional[dict] = None) -> torch.Tensor:
     """A block that keeps nothing, on bf16-plane operands (hip_ops.set_gemm_precision "bf16" / "bf16x6"): every Linear reads
     planes its producer wrote (LayerNorm, the fc1 / attention epilogues) - no conversion on the GEMMs' path.  The residual

@@ -923,6 +923,29 @@ def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad:
     return t, row, sums
 
 
+def split_pairs_dual_multi(items) -> None:
+    """``items``: (x fp32 [R, C], row pairs out [R, 2 C] or None, transposed pairs out [C, 2 Rpad] or None) - every matrix converted in ONE
+    launch per 32 of them (tt_split_pairs_dual_multi): the pair operands of all the weights an optimizer / EMA update rewrote."""
+    import ctypes as C
+    lib = _lib.load()
+    n = len(items)
+    if n == 0:
+        return
+    src, dt, dr = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    Rs, Cs, Rp = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
+    for i, (x, row, t) in enumerate(items):
+        _chk(x, "x")
+        R, Cc = x.shape
+        rpad = (R + 31) // 32 * 32
+        if row is not None:
+            _chk(row, "row", f16); assert row.shape == (R, 2 * Cc), (row.shape, x.shape)
+        if t is not None:
+            _chk(t, "t", f16); assert t.shape == (Cc, 2 * rpad), (t.shape, x.shape)
+        src[i], dr[i], dt[i] = _p(x), _p(row), _p(t)
+        Rs[i], Cs[i], Rp[i] = R, Cc, rpad
+    _lib.check(lib.tt_split_pairs_dual_multi(src, dt, dr, Rs, Cs, Rp, n, _stream()), "tt_split_pairs_dual_multi")
+
+
 def transpose_pairs(xp, rpad: Optional[int] = None):
     """pairs [R, 2 C] -> transposed pairs [C, 2 Rpad] (zero beyond R)."""
     lib = _lib.load()

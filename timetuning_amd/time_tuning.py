@@ -363,6 +363,17 @@ class TimeT(nn.Module):
         t_first = (min(all_train_ids) if all_train_ids else depth) if self.teacher_shares_frozen_blocks() else 0
         tap: Optional[dict] = {"block": t_first, "rows": bs} if t_first > 0 else None
 
+        if ops.pairs():   # "f16x3": every pair operand the last optimizer / EMA update made stale, in one launch
+            if getattr(self, "_pair_weight_list", None) is None:
+                mods = [self] + ([self.teacher] if getattr(self, "teacher", None) is not None else [])
+                seen, lst = set(), []
+                for m in mods:
+                    for p_ in m.parameters():
+                        if p_.dim() == 2 and id(p_) not in seen:
+                            seen.add(id(p_)); lst.append(p_)
+                self._pair_weight_list = lst
+            engine.refresh_pair_operands(self._pair_weight_list)
+
         # ---- student: one pass over all frames, time-major
         use_mask = hp.get("mask_features", False)
         g = fe.spatial_resolution
