@@ -26,6 +26,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// TT_AP_DBG (timing studies only, tools/ap_ablate.py; 0 in the shipped build), a bit mask: 1 no score MFMAs, 2 no exp / split of the
+// probabilities, 4 no P V MFMAs, 8 no V fragment reads, 16 no K fragment reads, 32 no K / V DMA
+#ifndef TT_AP_DBG
+#define TT_AP_DBG 0
+#endif
 template <int NKT>
 __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out_pairs,
                                                                   float* __restrict__ out_f32, float* __restrict__ lse, int N, int H, float scale) {
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
   const _Float16* base = qkv + (long long)f * N * RS + hd * 128;   // q of this head; k: + 2 Dm, v: + 4 Dm
 
   // ---- K and V: 4 keys x 256 B per DMA piece; lane -> (key, slot of 16), source chunk = slot ^ swizzle(key)
-  {
+  if (!(TT_AP_DBG & 32)) {
     const int l_row = lane >> 4, l_slot = lane & 15;
     for (int piece = wave; piece < KROWS / 4; piece += 8) {
       const int key = piece * 4 + l_row;
@@ -89,11 +94,18 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
       for (int e = 0; e < 16; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const f16x8 kfh = *reinterpret_cast<const f16x8*>(Ks + kt * 8192 + kofs[ks]);
-        const f16x8 kfl = *reinterpret_cast<const f16x8*>(Ks + kt * 8192 + kofs[4 + ks]);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, qh[ks], s1, 0, 0, 0);
-        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, ql[ks], s2, 0, 0, 0);
-        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl, qh[ks], s2, 0, 0, 0);
+        f16x8 kfh, kfl;
+        if constexpr (TT_AP_DBG & 16) { kfh = qh[(ks + kt) & 3]; kfl = ql[(ks + kt) & 3]; }
+        else {
+          kfh = *reinterpret_cast<const f16x8*>(Ks + kt * 8192 + kofs[ks]);
+          kfl = *reinterpret_cast<const f16x8*>(Ks + kt * 8192 + kofs[4 + ks]);
+        }
+        if constexpr (TT_AP_DBG & 1) { s1[ks] += (float)kfh[0]; s2[ks] += (float)kfl[0]; }
+        else {
+          s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, qh[ks], s1, 0, 0, 0);
+          s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, ql[ks], s2, 0, 0, 0);
+          s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl, qh[ks], s2, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) sacc[kt][e] = fmaf(s2[e], kPairInvScale, s1[e]);
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], c, -mc));
+        const float p = (TT_AP_DBG & 2) ? sacc[kt][e] : __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], c, -mc));
         sacc[kt][e] = p;
         sum += p;
       }
@@ -140,7 +152,8 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           _Float16 hi_, lo_;
-          split_pair(sacc[kt][8 * s + j], hi_, lo_);
+          if constexpr (TT_AP_DBG & 2) { hi_ = (_Float16)sacc[kt][8 * s + j]; lo_ = hi_; }
+          else split_pair(sacc[kt][8 * s + j], hi_, lo_);
           ph[kt][s][j] = hi_;
           pl[kt][s][j] = lo_;
         }
@@ -164,13 +177,19 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
         for (int s = 0; s < 2; ++s) {
           const unsigned char* vrow = Vs + (kt * 32 + 16 * s) * 256;
           union { s16x4 s2[2]; f16x8 v; } vh, vl;
-          vh.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + vofs[2 * dt]));
-          vh.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + 2048 + vofs[2 * dt]));
-          vl.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + vofs[2 * dt + 1]));
-          vl.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + 2048 + vofs[2 * dt + 1]));
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[kt][s], o1, 0, 0, 0);
-          o2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[kt][s], o2, 0, 0, 0);
-          o2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[kt][s], o2, 0, 0, 0);
+          if constexpr (TT_AP_DBG & 8) { vh.v = ph[kt][s ^ 1]; vl.v = pl[kt][s ^ 1]; }
+          else {
+            vh.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + vofs[2 * dt]));
+            vh.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + 2048 + vofs[2 * dt]));
+            vl.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + vofs[2 * dt + 1]));
+            vl.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + 2048 + vofs[2 * dt + 1]));
+          }
+          if constexpr (TT_AP_DBG & 4) { o1[s] += (float)vh.v[0] * (float)ph[kt][s][0]; o2[s] += (float)vl.v[0] * (float)pl[kt][s][0]; }
+          else {
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[kt][s], o1, 0, 0, 0);
+            o2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[kt][s], o2, 0, 0, 0);
+            o2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[kt][s], o2, 0, 0, 0);
+          }
         }
       }
       // The output tile leaves through the wave's private LDS scratch so that a store instruction writes eight whole 128-byte rows (16 B
