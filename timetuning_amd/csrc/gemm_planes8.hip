@@ -48,6 +48,8 @@
 // 17-43 % of the launches.
 #include "common.hpp"
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 namespace tt {
 
@@ -76,6 +78,12 @@ struct P8Args {
   int n_half;             // half tiles that follow (tiles [n_full * ncu, ntiles) cut in two): workgroup h < n_half takes half h
   int clock_print;        // TT_P8_CLOCK diagnostic builds only
   int order_mode;         // order of the load part, see `reads_first`
+  // K-split of the tiles beyond the last whole round (P = 1 only; gemm_pairs8.hip has the description): ks_S >= 2 workgroups per left-over
+  // tile over contiguous ranges of K-tile pairs; per-wave fp32 partials through ks_ws, the last wave to arrive at the (tile, wave) counter
+  // sums them in slice order and runs the epilogue
+  int ks_S, ks_R;
+  float* ks_ws;           // [ks_R][ks_S][8 waves][128 x 64 floats]
+  int* ks_cnt;            // [ks_R][8], zero between launches
 };
 
 // Device helpers at namespace scope: the buffer builtins inside a generic lambda of the kernel template make clang's HOST pass
@@ -91,6 +99,15 @@ __device__ __forceinline__ f32x4 p8_ld128(const void* base, unsigned nbytes, uns
 __device__ __forceinline__ void p8_st128(void* base, unsigned nbytes, unsigned voff, u32x4 v) {
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, nbytes, 0x00020000);
   __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+}
+// sc0 sc1 accesses (write-through / around the XCD's L2): the K-split partials, whose slices may run on different XCDs
+__device__ __forceinline__ f32x4 p8_ld128_sys(const void* base, unsigned nbytes, unsigned voff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, nbytes, 0x00020000);
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 17));
+}
+__device__ __forceinline__ void p8_st128_sys(void* base, unsigned nbytes, unsigned voff, u32x4 v) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, nbytes, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 17);
 }
 
 // SHIFT0 (see `phase`): phase 3 issues phase 0's DMA chunk as well.  Measured per plane count (tools/ab_planes.py, interleaved, bit-identical):
@@ -217,23 +234,32 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   // row blocks: round-3 PMC, L2 hit rate 63 %).
   int n_whole;
   bool has_half = false;
-  if (g.n_full > 0 || g.n_half > 0) {
+  const bool ksplit = P == 1 && g.ks_S >= 2;
+  if (g.n_full > 0 || g.n_half > 0 || ksplit) {
     n_whole = g.n_full;
-    has_half = cu < g.n_half;
+    has_half = !ksplit && cu < g.n_half;
   } else {
     n_whole = cu < g.ntiles ? (g.ntiles - cu + g.ncu - 1) / g.ncu : 0;
   }
-  const int n_items = n_whole + (has_half ? 1 : 0);
+  const bool has_slice = ksplit && cu < g.ks_R * g.ks_S;   // the last item: a K range of one of the left-over tiles
+  const int n_items = n_whole + (has_half || has_slice ? 1 : 0);
   if (n_items == 0) return;   // whole workgroup
   const bool half_first = has_half && (cu & 1) && n_whole > 0;
-  // item -> first row, first column, half?
-  auto item = [&](int it, int& row0, int& n0, bool& half) {
+  // item -> first row, first column, half?, K-tile range [kt0, kend) (an even number of K-tiles)
+  auto item = [&](int it, int& row0, int& n0, bool& half, int& kt0, int& kend) {
     int tile;
+    kt0 = 0;
+    kend = nk;
     half = has_half && (half_first ? it == 0 : it == n_whole);
     int hsel = 0;
     if (half) {
       tile = g.n_full * g.ncu + (cu >> 1);
       hsel = cu & 1;
+    } else if (has_slice && it == n_whole) {
+      const int j = cu / g.ks_S, sl = cu - j * g.ks_S, U = nk / 2;
+      tile = g.n_full * g.ncu + j;
+      kt0 = 2 * (sl * U / g.ks_S);
+      kend = 2 * ((sl + 1) * U / g.ks_S);
     } else {
       tile = (half_first ? it - 1 : it) * g.ncu + cu;
     }
@@ -250,7 +276,7 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   const int xps = (int)(g.x_stride * 2), wps = (int)(g.w_stride * 2);     // plane strides in bytes
 
   // DMA cursor (scalar state + the X voffsets of its item; rows beyond M are clamped to M - 1 and dropped at the store)
-  int d_item = 0, d_kt = 0;
+  int d_item = 0, d_kt = 0, d_kend = 0;
   bool d_done = false, d_half = false;
   int half_guard = 0;   // > 0: the DMA window may hold a slot of a half tile (no X1 chunk): the counted waits take the smaller count
   int d_kofs = 0;       // d_kt * ROWB
@@ -258,7 +284,8 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   int x_voff[2][JPW];
   auto cursor_item = [&]() {
     int row0, n0;
-    item(d_item, row0, n0, d_half);
+    item(d_item, row0, n0, d_half, d_kt, d_kend);
+    d_kofs = d_kt * ROWB;
     if constexpr (DBG & 32) row0 = 0, n0 = 0;   // (ablation) every workgroup streams the SAME operand tile: the DMA stream from a warm L2
     d_wbase = n0 * K2;
 #pragma unroll
@@ -274,9 +301,7 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   auto cursor_next_ktile = [&]() {
     ++d_kt;
     d_kofs += ROWB;
-    if (d_kt == nk) {
-      d_kt = 0;
-      d_kofs = 0;
+    if (d_kt == d_kend) {
       ++d_item;
       if (d_item >= n_items) {
         d_done = true;
@@ -662,6 +687,58 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     post_half = half;
   };
 
+  // ---- K-split item (P = 1): this wave's partial (128 values per lane, 32 KB) -> workspace; the wave arriving last at the (tile, wave)
+  // counter sums the slices' partials in slice order - its own read back too: the sum does not depend on who finishes - one 128-row
+  // half at a time (acc[0] the running sum, acc[1] the landing buffer: the accumulators are all the registers there are) and runs the
+  // epilogue of that half as a half item.  Write-through stores / loads around the L2 (the slices may sit on different XCDs), stores
+  // complete (vmcnt 0) before the agent-scope increment.
+  auto slice_finish = [&](int row0, int n0) {
+    if constexpr (P == 1) {
+      const int j = cu / g.ks_S, sl = cu - j * g.ks_S;
+      float* wbase = g.ks_ws + ((size_t)j * g.ks_S * 8 + wave) * (128 * 64);
+      const unsigned sstride = 8u * 128u * 64u * 4u, wbytes = (unsigned)g.ks_S * sstride;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NHW; ++b)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 v = {acc[a][b][m][4 * q], acc[a][b][m][4 * q + 1], acc[a][b][m][4 * q + 2], acc[a][b][m][4 * q + 3]};
+              p8_st128_sys(wbase, wbytes, (unsigned)sl * sstride + (unsigned)(((((a * NHW + b) * 2 + m) * 4 + q) * 1024) + lane * 16), __builtin_bit_cast(u32x4, v));
+            }
+      p8_wait_vmcnt<0>();
+      int old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add(g.ks_cnt + j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __builtin_amdgcn_readfirstlane(old);
+      if (old != g.ks_S - 1) return;
+      if (lane == 0) __hip_atomic_store(g.ks_cnt + j * 8 + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+      for (int hh = 0; hh < 2; ++hh) {
+        for (int t = 0; t < g.ks_S; ++t) {
+#pragma unroll
+          for (int b = 0; b < NHW; ++b)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 v = p8_ld128_sys(wbase, wbytes, (unsigned)t * sstride + (unsigned)(((((hh * NHW + b) * 2 + m) * 4 + q) * 1024) + lane * 16));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[1][b][m][4 * q + e] = v[e];
+              }
+#pragma unroll
+          for (int b = 0; b < NHW; ++b)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) acc[0][b][m][e] = t == 0 ? acc[1][b][m][e] : acc[0][b][m][e] + acc[1][b][m][e];
+        }
+        epilogue(row0 + hh * 128, n0, true);
+      }
+    }
+  };
+
   // ---- prologue: chunks 0 .. D - 1 of the stream
   {
     auto pro = [&](auto c_c) {
@@ -689,15 +766,15 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
   for (int it = 0; it < n_items; ++it) {
-    int row0, n0;
-    item(it, row0, n0, c_half);
+    int row0, n0, c_kt0, c_kend;
+    item(it, row0, n0, c_half, c_kt0, c_kend);
     if (grp1) __builtin_amdgcn_s_barrier();   // the second group runs one barrier interval behind
-    for (int kk = 0; kk < nk; kk += 2) {
+    for (int kk = c_kt0; kk < c_kend; kk += 2) {
       // steady for these 8 phases?  The cursor advances two K-tiles in them: it must stay in whole tiles and short of the end.
       steady = post_epi == 0 && half_guard == 0 && !c_half && !d_half && !d_done;
-      if (steady && d_kt + 2 >= nk) {   // it crosses into the next item
+      if (steady && d_kt + 2 >= d_kend) {   // it crosses into the next item
         bool nhalf = false;
-        if (d_item + 1 < n_items) { int r0_, n0_; item(d_item + 1, r0_, n0_, nhalf); }
+        if (d_item + 1 < n_items) { int r0_, n0_, k0_, k1_; item(d_item + 1, r0_, n0_, nhalf, k0_, k1_); }
         steady = d_item + 1 < n_items && !nhalf;
       }
       phase(I0{}, I0{}); phase(I0{}, I1{}); phase(I0{}, I2{}); phase(I0{}, I3{});
@@ -705,6 +782,12 @@ __global__ __launch_bounds__(512) void gemm_planes8_kernel(P8Args g) {
     }
     steady = false;
     if (!grp1) __builtin_amdgcn_s_barrier();  // realign: both groups run their epilogues at the same time
+    if constexpr (P == 1) {
+      if (has_slice && it == n_whole) {   // (the last item: nothing follows)
+        slice_finish(row0, n0);
+        continue;
+      }
+    }
     epilogue(row0, n0, c_half);
   }
 #ifdef TT_P8_STAMP
@@ -732,7 +815,8 @@ static int launch_planes8(const P8Args& g, hipStream_t s) {
 
 // Shape / epilogue eligibility and the work decomposition.  Returns the epilogue kind or -1.
 static int planes8_plan(long long x_plane_stride, long long w_plane_stride, int planes, bool has_bias, bool has_residual, bool has_y, int y_nplanes,
-                        int M, int N, int K, int act, int* ntn_out, long long* ntiles_out, int* ncu_out, int* n_full_out, int* n_half_out) {
+                        int M, int N, int K, int act, int* ntn_out, long long* ntiles_out, int* ncu_out, int* n_full_out, int* n_half_out,
+                        int* ks_S_out = nullptr) {
   if (planes != 1 && planes != 3) return -1;
   const int BN = planes == 1 ? 256 : 128, BK = planes == 1 ? 64 : 32;
   if (N % BN != 0 || K % (2 * BK) != 0 || M < 256 || !has_bias) return -1;
@@ -754,11 +838,27 @@ static int planes8_plan(long long x_plane_stride, long long w_plane_stride, int 
   int ncu = (int)(ntiles < ncu_dev ? ntiles : ncu_dev), n_full = 0, n_half = 0;
   const long long R = ntiles / ncu_dev, rem = ntiles - R * ncu_dev;
   const bool no_half = tuning_knob(KNOB_P8_NO_HALF) != 0;   // tuning aid
-  if (!no_half && rem > 0 && 2 * rem <= ncu_dev) {
+  // K-split of the left-over tiles (P = 1, behind whole rounds; gemm_pairs8.hip's rule in this kernel's microseconds: ~ 2 us per 64-deep
+  // K-tile of a 256 x 256 tile, the exchange ~ 12 + 4 per slice - two halves of S load rounds each)
+  int ks_S = 0;
+  if (ks_S_out && planes == 1 && tuning_knob(KNOB_Q8_KSPLIT) % 10 != 0 && R > 0 && rem > 0) {
+    const int U = K / (2 * BK), nk = K / BK;
+    int S = (int)(ncu_dev / rem);
+    if (S > U) S = U;
+    if (S > 6) S = 6;
+    if (S >= 2) {
+      const double t_tile = 2.0 * nk + 5.0;
+      const double t_slice = 2.0 * 2 * ((U + S - 1) / S) + 5.0 + 12.0 + 4.0 * S;
+      const double t_else = (!no_half && 2 * rem <= ncu_dev) ? 0.86 * t_tile : t_tile;
+      if (t_slice < 0.9 * t_else) ks_S = S;
+    }
+  }
+  if (ks_S >= 2) {
     ncu = ncu_dev;
     n_full = (int)R;
-    n_half = (int)(2 * rem);
+    n_half = 0;
   }
+  if (ks_S_out) *ks_S_out = ks_S;
   *ntn_out = ntn; *ntiles_out = ntiles; *ncu_out = ncu; *n_full_out = n_full; *n_half_out = n_half;
   return epi;
 }
@@ -773,18 +873,51 @@ int planes8_would_run(int planes, int M, int N, int K, int act, int has_bias, in
 
 // Called by linear_planes_impl (gemm_planes.hip).  Returns TT_OK after a launch, 1 when the shape / epilogue is not this kernel's
 // (the caller then takes gemm_planes_kernel), < 0 on a launch error.
+// The K-split workspace: one per (device, stream), allocated at the first launch that needs it and kept (64 MB + the counters).
+struct P8Ws { int dev; hipStream_t s; float* ws; int* cnt; };
+static std::mutex p8_ws_mu;
+static std::vector<P8Ws> p8_ws_list;
+static int p8_workspace(hipStream_t s, float** ws, int** cnt) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("gemm_planes8: hipGetDevice failed"); return TT_ELAUNCH; }
+  std::lock_guard<std::mutex> lock(p8_ws_mu);
+  for (const P8Ws& b : p8_ws_list)
+    if (b.dev == dev && b.s == s) { *ws = b.ws; *cnt = b.cnt; return TT_OK; }
+  P8Ws b{dev, s, nullptr, nullptr};
+  const size_t slices = (size_t)device_cu_count();   // ks_R * ks_S <= CUs
+  if (hipMalloc(reinterpret_cast<void**>(&b.ws), slices * 8 * 128 * 64 * sizeof(float)) != hipSuccess) {
+    set_error("gemm_planes8: cannot allocate the K-split workspace");
+    return TT_ELAUNCH;
+  }
+  if (hipMalloc(reinterpret_cast<void**>(&b.cnt), slices * 8 * sizeof(int)) != hipSuccess || hipMemset(b.cnt, 0, slices * 8 * sizeof(int)) != hipSuccess) {
+    (void)hipFree(b.ws);
+    set_error("gemm_planes8: cannot allocate the K-split counters");
+    return TT_ELAUNCH;
+  }
+  p8_ws_list.push_back(b);
+  *ws = b.ws; *cnt = b.cnt;
+  return TT_OK;
+}
+
 int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes, const float* bias,
                 const float* residual, float* y, void* y_planes, long long y_plane_stride, int y_nplanes, int M, int N, int K, int act,
                 hipStream_t s) {
-  int ntn, ncu, n_full, n_half;
+  int ntn, ncu, n_full, n_half, ks_S = 0;
   long long ntiles;
   if ((y != nullptr) == (y_planes != nullptr) && y) {}   // (y together with planes is not an epilogue of this kernel: the plan rejects it below)
   const int epi = (y && y_planes) ? -1
                                   : planes8_plan(x_plane_stride, w_plane_stride, planes, bias != nullptr, residual != nullptr, y != nullptr,
-                                                 y_planes ? y_nplanes : 0, M, N, K, act, &ntn, &ntiles, &ncu, &n_full, &n_half);
+                                                 y_planes ? y_nplanes : 0, M, N, K, act, &ntn, &ntiles, &ncu, &n_full, &n_half, &ks_S);
   if (epi < 0) return 1;
+  float* ks_ws = nullptr;
+  int* ks_cnt = nullptr;
+  if (ks_S >= 2) {
+    const int rc = p8_workspace(s, &ks_ws, &ks_cnt);
+    if (rc != TT_OK) return rc;
+  }
   P8Args g{static_cast<const __bf16*>(x_planes), static_cast<const __bf16*>(w_planes), x_plane_stride, w_plane_stride, M, N, K, bias, residual, y,
-           static_cast<__bf16*>(y_planes), y_plane_stride, ntn, (int)ntiles, ncu, n_full, n_half, tuning_knob(KNOB_P8_CLOCK_PRINT), p8_order_mode()};
+           static_cast<__bf16*>(y_planes), y_plane_stride, ntn, (int)ntiles, ncu, n_full, n_half, tuning_knob(KNOB_P8_CLOCK_PRINT), p8_order_mode(),
+           ks_S, ks_S >= 2 ? (int)(ntiles - (long long)n_full * ncu) : 0, ks_ws, ks_cnt};
 #ifdef TT_P8_ABLATE   // timing-study build only (tools/build_variant.sh -DTT_P8_ABLATE): TT_P8_DBG selects a crippled instantiation
   {
     const char* e = getenv("TT_P8_DBG");
