@@ -225,7 +225,8 @@ int tt_linear_fwd_pairs_route(int M, int N, int K, int act, int has_bias, int ha
 
 /* The fused attention core on pair operands (dino_vision_transformer.py:120-132): qkv [F N][2 x 3 H 64] in pairs (the qkv Linear's y_pairs) ->
  * any of out_pairs [F N][2 H 64] (the proj Linear's operand), out_f32 [F, N, H 64] and lse [F, H, N] (what tt_attention_bwd recomputes from).
- * Both products take three fp16 MFMAs per term, as the pair GEMMs do; fp32 scores, softmax and accumulation.  N <= 256, head_dim 64. */
+ * Both products take three fp16 MFMAs per term, as the pair GEMMs do; fp32 scores, softmax and accumulation.  head_dim 64; any N (K / V of a
+ * head resident in LDS up to 256 tokens, KV-tiled with an online softmax beyond). */
 int tt_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, float* out_f32, float* lse, int F, int N, int H, int head_dim, float scale,
                            tt_stream_t stream);
 

@@ -267,3 +267,34 @@ def test_batched_weight_operand_refresh():
             assert torch.equal(t, ops.split_pairs_dual(w.detach())[0])
     ops._bump_param_epoch()                                                      # a raw-pointer update (AdamW / EMA): trainable + non-static frozen alike
     assert engine.refresh_pair_operands(ws) == len(ws)
+
+
+def test_ksplit_partial_exchange_soak():
+    """The K-split of gemm_pairs8's left-over tiles exchanges fp32 partials between workgroups (write-through stores, a per-(tile, wave) counter,
+    the last arriver sums in slice order and resets the counter): 60 back-to-back launches alternating between two split shapes and an
+    unsplit one must reproduce their first results bit for bit (a stale partial, a counter left non-zero or an order that depends on the
+    finisher would show), and agree with the unsplit kernel to fp32 rounding."""
+    from timetuning_amd import hip_ops as ops
+
+    lib = ops._lib.load()
+    cases = []
+    for i, (M, N, K) in enumerate([(25216, 384, 1536), (25216, 768, 3072), (25216, 1152, 384)]):
+        x, w, b = rnd(f"soak.x{i}", M, K).cuda(), rnd(f"soak.w{i}", N, K, scale=0.05).cuda(), rnd(f"soak.b{i}", N, scale=0.1).cuda()
+        r0 = rnd(f"soak.r{i}", M, N).cuda()
+        cases.append((ops.split_pairs(x), ops.split_pairs(w), b, r0))
+    def run(c):
+        xp, wp, b, r0 = c
+        r = r0.clone()
+        return ops.linear_fwd_pairs(xp, wp, b, residual=r, out=r)["y"]
+    first = [run(c) for c in cases]
+    for it in range(20):
+        for c, f in zip(cases, first):
+            assert torch.equal(run(c), f), f"launch {it}: result differs from the first one"
+    ops.set_tuning_knob("TT_Q8_KSPLIT", 0)
+    try:
+        for c, f in zip(cases[:2], first[:2]):
+            ref = run(c)
+            assert (ref - f).abs().max() <= 2e-6 * ref.abs().max()
+    finally:
+        ops.set_tuning_knob("TT_Q8_KSPLIT", 1)
+    torch.cuda.synchronize()

@@ -10,6 +10,8 @@ sum "$O/prof_c2/c2_kernel_stats.csv" 26 "steps incl. warm-up and the profiled-GE
 cp "$O/prof_c2/c2_kernel_stats.csv" "profiles/${R}_bench_c2_kernel_stats.csv"
 sum "$O/prof_c2f32/c2f32_kernel_stats.csv" 26 "steps incl. warm-up and the profiled-GEMM pass; --precision f32" > "profiles/${R}_bench_c2_f32_kernel_stats.txt"
 sum "$O/prof_c4/c4_kernel_stats.csv" 14 "steps incl. warm-up and the profiled-GEMM pass; f32-split(f16x3)" > "profiles/${R}_bench_c4_kernel_stats.txt"
+sum "$O/prof_c5/c5_kernel_stats.csv" 9 "steps incl. warm-up and the profiled-GEMM pass; C5 per-GPU share (16 clips), f32-split(f16x3)" > "profiles/${R}_bench_c5_kernel_stats.txt"
+sum "$O/prof_c4bf16/c4bf16_kernel_stats.csv" 14 "steps incl. warm-up and the profiled-GEMM pass; --precision bf16" > "profiles/${R}_bench_c4_bf16_kernel_stats.txt"
 sum "$O/prof_c1/c1_kernel_stats.csv" 61 "steps incl. warm-up and the profiled-GEMM pass" > "profiles/${R}_bench_c1_kernel_stats.txt"
 F=$(find "$O/pmc_fetch" -name "*counter_collection.csv" | head -1); W=$(find "$O/pmc_write" -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_traffic.py "$F" "$W" profiles/dominant_kernel_traffic.json "$(git rev-parse --short HEAD)" | head -12

@@ -21,6 +21,8 @@ P="--no_cpu_baseline --no_alt_precision --no_exchange_probe"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c2" -o c2 -- python3 "$R/bench.py" --steps 20 --warmup 5 $P > "$O/prof_c2.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c2f32" -o c2f32 -- python3 "$R/bench.py" --steps 20 --warmup 5 --precision f32 $P > "$O/prof_c2f32.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c4" -o c4 -- python3 "$R/bench.py" --steps 10 --warmup 3 --architecture dino-b16 --num_frames 8 --num_clusters 400 --batch_size 16 $P > "$O/prof_c4.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c5" -o c5 -- python3 "$R/bench.py" --steps 6 --warmup 2 --architecture dino-s8 --batch_size 16 $P > "$O/prof_c5.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c4bf16" -o c4bf16 -- python3 "$R/bench.py" --steps 10 --warmup 3 --architecture dino-b16 --num_frames 8 --num_clusters 400 --batch_size 16 --precision bf16 $P > "$O/prof_c4bf16.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c1" -o c1 -- python3 "$R/bench.py" --steps 50 --warmup 10 --batch_size 2 --num_frames 2 --num_clusters 50 $P > "$O/prof_c1.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch" -o f -- python3 "$R/bench.py" --steps 3 --warmup 1 $P > "$O/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write" -o w -- python3 "$R/bench.py" --steps 3 --warmup 1 $P > "$O/pmc_write.log" 2>&1

@@ -24,7 +24,11 @@ def case(name, match):
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
             per_simd = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * CUS)  # counts cycles, summed over the SIMDs of the chip
             d["mfma_busy_cycles_per_simd"] = round(per_simd)
-            d["matrix_pipe_busy_frac(of a wave's lifetime: = of the kernel for the persistent GEMM, one workgroup per CU)"] = round(per_simd / kc, 3)
+            # one 8-wave workgroup per CU at a time in both kernels: rounds = workgroups a CU runs one after the other (1 for the
+            # persistent GEMM, 3 for the attention's 768 workgroups); the busy cycles are summed over them, the lifetime is one's
+            rounds = max(1.0, c["SQ_WAVES"] / (8.0 * CUS))
+            d["workgroup_rounds_per_cu"] = round(rounds, 2)
+            d["matrix_pipe_busy_frac(of the workgroups' lifetimes)"] = round(per_simd / (kc * rounds), 3)
     if "TCC_HIT_sum" in c:
         d["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0), 3)
     if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
