@@ -173,6 +173,20 @@ int tt_normalize_rows_inplace(float* w, int rows, int D, tt_stream_t stream);
 int tt_sinkhorn(const float* scores, float* q_out, int B_total, int K, int row0, int rows_out, float eps,
                 int iters, void* workspace, size_t workspace_bytes, tt_stream_t stream);
 size_t tt_sinkhorn_workspace_bytes(int B_total, int K);
+/*   The reference's own DISTRIBUTED form (my_utils.py:250-272: the columns stay on their rank, the K row sums are all-reduced once per
+ *   iteration), one rank's share in steps - the caller all-reduces u[K] (sum) between them and passes the SAME workspace to all three:
+ *     tt_sinkhorn_local_begin   scores [B_loc, K] -> E = exp(scores / eps) in the workspace, u_out[k] = the local row sums
+ *     tt_sinkhorn_local_step    u_in = the all-reduced row sums: row step, column step with c = 1 / B_total, u_out = the next local row sums
+ *     tt_sinkhorn_local_end     the last row step (u_in NULL: none - zero iterations) + final column normalisation -> q_out [rows_out, K]
+ *   iters iterations = begin, (all-reduce, step) x (iters - 1), all-reduce, end.  Equal to tt_sinkhorn on the gathered rows up to fp32
+ *   rounding (the sums fold in a different order). */
+size_t tt_sinkhorn_local_workspace_bytes(int B_loc, int K);
+int tt_sinkhorn_local_begin(const float* scores, float* u_out, int B_loc, int K, float eps, void* workspace, size_t workspace_bytes,
+                            tt_stream_t stream);
+int tt_sinkhorn_local_step(const float* u_in, float* u_out, int B_loc, int B_total, int K, void* workspace, size_t workspace_bytes,
+                           tt_stream_t stream);
+int tt_sinkhorn_local_end(const float* u_in, float* q_out, int B_loc, int rows_out, int K, void* workspace, size_t workspace_bytes,
+                          tt_stream_t stream);
 /*   The reference-signature entry, my_utils.sinkhorn(Q, nmb_iters, world_size) (my_utils.py:246): takes the POSITIVE matrix
  *   exp(scores / eps) itself (no log / exp round trip) - as Q [K, B_total] (transposed = 0: the reference's layout) or as
  *   Q^T [B_total, K] (transposed = 1: what an all-gather of the ranks' columns yields; read in place).  Same iterations,

@@ -55,6 +55,65 @@ int tt_cpu_sinkhorn(const float* scores, float* q_out, int B_total, int K, int r
   return 0;
 }
 
+/* ---- my_utils.py:250-272, one rank's share in steps (the caller all-reduces u between them): Q [K][B_loc] lives in the workspace as
+ *      E[b][k] and is rescaled IN PLACE as the reference does.  (The reference first divides Q by its all-reduced total mass: a common
+ *      factor that the first row step removes - not applied here, as in the HIP path.) */
+size_t tt_cpu_sinkhorn_local_workspace_bytes(int B_loc, int K) { return (size_t)B_loc * K * sizeof(float); }
+static void sk_local_rowsums(const float* Q, float* u, int B, int K) {
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += Q[(size_t)b * K + k];
+    u[k] = s;
+  }
+}
+int tt_cpu_sinkhorn_local_begin(const float* scores, float* u_out, int B_loc, int K, float eps, void* workspace, size_t workspace_bytes,
+                                tt_stream_t stream) {
+  (void)stream;
+  if (!workspace || workspace_bytes < tt_cpu_sinkhorn_local_workspace_bytes(B_loc, K)) return -1;
+  float* Q = (float*)workspace;
+  for (size_t i = 0; i < (size_t)B_loc * K; ++i) Q[i] = expf(scores[i] / eps);
+  sk_local_rowsums(Q, u_out, B_loc, K);
+  return 0;
+}
+int tt_cpu_sinkhorn_local_step(const float* u_in, float* u_out, int B_loc, int B_total, int K, void* workspace, size_t workspace_bytes,
+                               tt_stream_t stream) {
+  (void)stream;
+  if (!workspace || workspace_bytes < tt_cpu_sinkhorn_local_workspace_bytes(B_loc, K)) return -1;
+  float* Q = (float*)workspace;
+  const float r = 1.0f / (float)K, c = 1.0f / (float)B_total;
+  for (int k = 0; k < K; ++k) {              /* Q *= (r / u)[:, None], u all-reduced */
+    const float f = r / u_in[k];
+    for (int b = 0; b < B_loc; ++b) Q[(size_t)b * K + k] *= f;
+  }
+  for (int b = 0; b < B_loc; ++b) {          /* Q *= (c / colsum(Q))[None, :] */
+    float v = 0.f;
+    for (int k = 0; k < K; ++k) v += Q[(size_t)b * K + k];
+    const float f = c / v;
+    for (int k = 0; k < K; ++k) Q[(size_t)b * K + k] *= f;
+  }
+  sk_local_rowsums(Q, u_out, B_loc, K);
+  return 0;
+}
+int tt_cpu_sinkhorn_local_end(const float* u_in, float* q_out, int B_loc, int rows_out, int K, void* workspace, size_t workspace_bytes,
+                              tt_stream_t stream) {
+  (void)stream;
+  if (!workspace || workspace_bytes < tt_cpu_sinkhorn_local_workspace_bytes(B_loc, K)) return -1;
+  float* Q = (float*)workspace;
+  const float r = 1.0f / (float)K;
+  if (u_in)
+    for (int k = 0; k < K; ++k) {
+      const float f = r / u_in[k];
+      for (int b = 0; b < B_loc; ++b) Q[(size_t)b * K + k] *= f;
+    }
+  for (int b = 0; b < rows_out; ++b) {       /* (Q / colsum(Q)).T */
+    const float* row = Q + (size_t)b * K;
+    float v = 0.f;
+    for (int k = 0; k < K; ++k) v += row[k];
+    for (int k = 0; k < K; ++k) q_out[(size_t)b * K + k] = row[k] / v;
+  }
+  return 0;
+}
+
 /* ---- time_tuning.py:296-302 (+ :226-227,298-300 with row_weight): mean over rows of weight * CE(scores / T, label), and
  *      its gradient with respect to scores. */
 int tt_cpu_ce_loss_fwd_bwd(const float* scores, const int64_t* labels, const float* row_weight, float* loss_out, float* dscores, int rows,

@@ -58,6 +58,31 @@ def _worker(rank, W, port, ret):
 
     q_r = O.sinkhorn(torch.exp(local / 0.05).t(), int(g["iters"]), world_size=W, all_reduce=allreduce)
     out["q_err_vs_allreduce_form"] = float((q - q_r).abs().max())
+    # (1b) the product's OWN all-reduce variant (engine.global_sinkhorn_allreduce, --sinkhorn_exchange allreduce): the reference's
+    # pattern - columns stay on their rank, the K row sums are all-reduced per iteration; the CPU twin stands in for the HIP kernels
+    from oracle import cpu_twin
+
+    n_coll = [0]
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        n_coll[0] += 1
+        return real_all_reduce(t, *a, **k)
+
+    dist.all_reduce = counting_all_reduce
+    try:
+        q_own = engine.global_sinkhorn_allreduce(local, B, 0.05, int(g["iters"]), lib=cpu_twin.load())
+        engine.SINKHORN_EXCHANGE = "allreduce"          # ... and through the begin / end pair the training step uses
+        ctx = engine.global_sinkhorn_begin(local)
+        out["allreduce_ctx_is_local"] = ctx[1] is None and ctx[2] == "allreduce"
+    finally:
+        dist.all_reduce = real_all_reduce
+        engine.SINKHORN_EXCHANGE = "allgather"
+    out["allreduce_variant_collectives"] = n_coll[0] - int(g["iters"])   # 0: exactly one K-vector all-reduce per iteration
+    out["q_own_allreduce_err_vs_reference"] = float((q_own - torch.from_numpy(g["q"][rank * B:(rank + 1) * B])).abs().max())
+    q0 = engine.global_sinkhorn_allreduce(local, B, 0.05, 0, lib=cpu_twin.load())   # zero iterations: the column-normalised exp(scores / eps)
+    e0 = torch.exp(local / 0.05)
+    out["q_own_allreduce_iters0_err"] = float((q0 - e0 / e0.sum(1, keepdim=True)).abs().max())
 
     # (2) flat gradient all-reduce == mean of the per-rank gradients
     torch.manual_seed(0)
@@ -110,6 +135,9 @@ def test_world_size_2_gloo():
         assert o["bucket_err"] < 1e-6 and o["bucket_count_ok"], o
         assert o["q_err_vs_reference"] < 2e-6, o
         assert o["q_err_vs_allreduce_form"] < 2e-6, o
+        # the product's own all-reduce variant: the reference's numbers, exactly `iters` K-vector all-reduces, the begin / end pair routes to it
+        assert o["q_own_allreduce_err_vs_reference"] < 2e-6 and o["q_own_allreduce_iters0_err"] < 1e-6, o
+        assert o["allreduce_variant_collectives"] == 0 and o["allreduce_ctx_is_local"], o
         assert o["grad_err"] < 1e-6, o
         assert o["bcast_err"] == 0.0 and o["bcast_err_w"] == 0.0, o
         assert o["passthrough"], o

@@ -17,6 +17,7 @@ import torch
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 K, HEAD, BS, FS = 20, (128, 128, 64, 32), 2, 2
+SK_ITERS = 10   # get_loss default (time_tuning.py:327)
 WATCH = ("prototypes", "feature_extractor.head.6.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight",
          "feature_extractor.backbone.blocks.11.norm2.bias")
 
@@ -84,7 +85,21 @@ def _worker(rank, W, port, ret, backend="gloo"):
     waits, engine.RCCL_PROFILE = engine.RCCL_PROFILE, None
     arena = inner._grad_arena
     lo, hi = arena.flat.data_ptr(), arena.flat.data_ptr() + arena.flat.numel() * 4
-    ret[rank] = dict(loss=float(loss.item()), grads={n: params[n].grad.cpu().numpy() for n in WATCH},
+    # step 3, forward only: the reference's own exchange pattern for the assignment (--sinkhorn_exchange allreduce, my_utils.py:250-272) -
+    # the HIP kernels of one rank's share (tt_sinkhorn_local_*) with the K row sums all-reduced once per iteration
+    q_gather = model.last_aux["q"].clone()
+    engine.SINKHORN_EXCHANGE = "allreduce"
+    engine.RCCL_PROFILE = []
+    try:
+        with torch.no_grad():
+            loss_r = model(x, None, True, False)
+    finally:
+        engine.SINKHORN_EXCHANGE = "allgather"
+    torch.cuda.synchronize()
+    waits_r, engine.RCCL_PROFILE = engine.RCCL_PROFILE, None
+    ret[rank] = dict(loss=float(loss.item()), loss_allreduce=float(loss_r.item()),
+                     q_allreduce_err=float((model.last_aux["q"] - q_gather).abs().max()),
+                     waits_allreduce=[(k, n) for k, n, _, _ in waits_r if "sinkhorn" in k or "gather" in k], grads={n: params[n].grad.cpu().numpy() for n in WATCH},
                      q=model.last_aux["q"].cpu().numpy(), waits=[(k, n, e0.elapsed_time(e1)) for k, n, e0, e1 in waits],
                      trainable=sum(p.numel() for p in inner.parameters() if p.requires_grad),
                      same_as_first=all(torch.equal(params[n].grad, first[n]) for n in WATCH), cats=cats["n"],
@@ -125,6 +140,9 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(backend, W):
         # optimizer sees are views of it, nothing was concatenated, and the numbers equal step 1's bit for bit
         assert ret[r]["arena_floats"] == ret[r]["trainable"] and [4 * b for b in ret[r]["bucket_sizes"]] == [n for _, n, _ in waits[1:]]
         assert ret[r]["in_arena"] and ret[r]["cats"] == 0 and ret[r]["same_as_first"], (ret[r]["in_arena"], ret[r]["cats"], ret[r]["same_as_first"])
+        # the all-reduce variant of the assignment: no all-gather, one K-float all-reduce per Sinkhorn iteration, the same assignment and loss
+        assert ret[r]["waits_allreduce"] == [("all_reduce(sinkhorn row sums)", K * 4)] * SK_ITERS, ret[r]["waits_allreduce"]
+        assert ret[r]["q_allreduce_err"] < 2e-6 and abs(ret[r]["loss_allreduce"] - ret[r]["loss"]) < 1e-5, (ret[r]["q_allreduce_err"], ret[r]["loss_allreduce"], ret[r]["loss"])
 
     model = _model()
     x_all = torch.from_numpy(np.concatenate([synth.make_clips(BS, FS, 224, seed=11 + r) for r in range(W)], axis=0)).cuda()

@@ -220,6 +220,54 @@ def test_sinkhorn_c3_global_problem_vs_reference(ops, golden, rank):
     assert rel_err(q.sum(1), torch.ones(6272)) < 1e-5
 
 
+@pytest.mark.parametrize("W", [2, 8])
+def test_sinkhorn_allreduce_form_vs_reference(ops, golden, W):
+    """The reference's own distributed pattern (my_utils.py:250-272) on the HIP kernels of one rank's share (tt_sinkhorn_local_begin / step /
+    end): W ranks emulated in one process - each keeps its own columns, the K row sums are summed across the ranks between the steps (what
+    the all-reduce does) - against the reference's W-rank gloo fixtures (W = 2: the whole q; W = 8: BASELINE C3's 8 x 8320 rows, every
+    52nd row), against tt_sinkhorn on the gathered rows, and the plain-C twin of the same three calls."""
+    from oracle import cpu_twin
+    from timetuning_amd import hip_ops, synth
+
+    if W == 2:
+        g = golden("sinkhorn_w2")
+        scores = torch.from_numpy(g["scores"]).contiguous()
+        iters, Bl, rows_out = int(g["iters"]), scores.shape[0] // 2, scores.shape[0] // 2
+        expect = [torch.from_numpy(g["q"][r * Bl:(r + 1) * Bl]) for r in range(W)]
+        keep = torch.arange(0, Bl)
+    else:
+        g = golden("sinkhorn_w8")
+        scores = torch.from_numpy(synth.make_sinkhorn_w8_scores())
+        iters, Bl, rows_out = int(g["iters"]), int(g["rows_per_rank"]), 6272
+        keep = torch.arange(0, rows_out, int(g["stride"]))
+        expect = [torch.from_numpy(g["q"][r][: len(keep)]) for r in range(W)]
+    K = scores.shape[1]
+
+    def solve(lib, device):
+        parts = [scores[r * Bl:(r + 1) * Bl].contiguous().to(device) for r in range(W)]
+        sks = [hip_ops.SinkhornLocal(Bl, W * Bl, K, device, lib=lib) for _ in range(W)]
+        us = [sk.begin(p_, 0.05) for sk, p_ in zip(sks, parts)]
+        for it in range(iters):
+            u = torch.stack(us).sum(0)                      # the all-reduce
+            if it + 1 < iters:
+                us = [sk.step(u) for sk in sks]
+        return [sk.end(u, rows_out).cpu() for sk in sks]
+
+    qs = solve(None, "cuda")
+    for r in range(W):
+        assert rel_err(qs[r][keep], expect[r]) < 5e-5, r
+        assert rel_err(qs[r].sum(1), torch.ones(rows_out)) < 1e-5
+    q_gathered = ops.sinkhorn(dev(scores), iters, row0=Bl, rows_out=rows_out).cpu()     # rank 1's rows of the all-gather variant
+    assert rel_err(qs[1], q_gathered) < 5e-6
+    if W == 2:
+        qt = solve(cpu_twin.load(), "cpu")
+        assert all(rel_err(qs[r], qt[r]) < 5e-6 for r in range(W))
+        sk0 = hip_ops.SinkhornLocal(Bl, W * Bl, K, "cuda")                               # zero iterations: column-normalised exp(scores / eps)
+        sk0.begin(dev(scores[:Bl]), 0.05)
+        e0 = torch.exp(scores[:Bl].double() / 0.05)
+        assert rel_err(sk0.end(None).cpu(), e0 / e0.sum(1, keepdim=True)) < 1e-5
+
+
 def test_sinkhorn_c2_size_vs_oracle(ops):
     """BASELINE C2: K=200, B=6272 (+ queue rows variant), checked against the oracle and by invariants."""
     for B in (6272, 6272 + 2048):

@@ -103,6 +103,10 @@ SIGNATURES = {
     "tt_normalize_rows_inplace": (c_i, [c_vp, c_i, c_i, c_vp]),
     "tt_sinkhorn": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_i, c_vp, c_sz, c_vp]),
     "tt_sinkhorn_workspace_bytes": (c_sz, [c_i, c_i]),
+    "tt_sinkhorn_local_workspace_bytes": (c_sz, [c_i, c_i]),
+    "tt_sinkhorn_local_begin": (c_i, [c_vp, c_vp, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
+    "tt_sinkhorn_local_step": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "tt_sinkhorn_local_end": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_sinkhorn_from_q": (c_i, [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_label_propagate": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
     "tt_label_propagate_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),

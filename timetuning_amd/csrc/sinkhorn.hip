@@ -118,7 +118,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_init_from_e_kernel(const float*
 template <bool LAST>
 __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __restrict__ E, const float* __restrict__ partial_in,
                                                              float* __restrict__ partial_out, float* __restrict__ q_out, int B, int K,
-                                                             int nwg_in, int rows_per_wg, int row0, int rows_out, int uniform_a) {
+                                                             int nwg_in, int rows_per_wg, int row0, int rows_out, int uniform_a, int b_norm) {
   __shared__ float a_s[64 * SK_KPL];
   __shared__ float red[SK_WAVES][64 * SK_KPL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __rest
     r0 = blockIdx.x * rows_per_wg;
     r1 = min(B, r0 + rows_per_wg);
   }
-  const float c = 1.0f / (float)B;
+  const float c = 1.0f / (float)b_norm;   // 1 / (B W): B rows here, b_norm rows over all ranks (my_utils.py:257)
   // two rows per wave in flight: their loads overlap each other's reduction latency
   for (int b = r0 + wave; b < r1; b += 2 * SK_WAVES) {
     const int b2 = b + SK_WAVES;
@@ -281,15 +281,80 @@ static int sinkhorn_impl(const float* scores, const float* Q, int q_rows_are_col
   int cur = 0;
   for (int it = 0; it + 1 < iters; ++it) {  // iterations 1 .. iters-1 (each prepares the next row step)
     hipLaunchKernelGGL((sk_iter_kernel<false>), dim3(wgs), dim3(SK_THREADS), 0, s, E, part[cur], part[cur ^ 1], (float*)nullptr,
-                       B_total, K, wgs, rpw, 0, 0, 0);
+                       B_total, K, wgs, rpw, 0, 0, 0, B_total);
     cur ^= 1;
   }
   // last iteration's row step + column normalisation, written straight to q for the requested rows
   const int owgs = sk_wgs(rows_out);
   const int orpw = (rows_out + owgs - 1) / owgs;
   hipLaunchKernelGGL((sk_iter_kernel<true>), dim3(owgs), dim3(SK_THREADS), 0, s, E, part[cur], (float*)nullptr, q_out, B_total, K, wgs,
-                     orpw, row0, rows_out, iters == 0 ? 1 : 0);
+                     orpw, row0, rows_out, iters == 0 ? 1 : 0, B_total);
   TT_CHECK_LAUNCH("sinkhorn");
+  return TT_OK;
+}
+
+// ---- The reference's own distributed form (my_utils.py:250-272): the columns (patches) stay on their rank, only the K row sums are
+// all-reduced, once per iteration.  One rank's share of a solve in steps; the caller all-reduces u between them:
+//   begin   E = exp(scores / eps) (kept in the workspace), u_out[k] = sum over the LOCAL rows of E[b][k]
+//   step    a = (1/K) / u_in (u_in: the all-reduced row sums), column step with c = 1 / B_total, u_out = the local row sums that follow
+//   end     the last row step (u_in null: none, the 0-iteration case) + the final column normalisation -> q [B_loc][K]
+// A solve of `iters` iterations = begin, (all-reduce, step) x (iters - 1), all-reduce, end: `iters` all-reduces of K floats (the
+// reference issues two more: the total mass, which cancels in the first row step, and a last row-sum nobody reads).
+__global__ __launch_bounds__(256) void sk_fold_kernel(const float* __restrict__ partial, float* __restrict__ u, int nwg, int K) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int w = 0; w < nwg; ++w) s += partial[(long long)w * K + k];   // fixed order
+  u[k] = s;
+}
+
+extern "C" size_t tt_sinkhorn_local_workspace_bytes(int B_loc, int K) { return tt_sinkhorn_workspace_bytes(B_loc, K); }
+
+static int sk_local_check(const void* workspace, size_t workspace_bytes, int B_loc, int K) {
+  TT_REQUIRE(workspace, "sinkhorn_local: null workspace");
+  TT_REQUIRE(B_loc > 0 && K > 0 && K <= 64 * SK_KPL, "sinkhorn_local: need 0 < K <= %d (got %d), B_loc > 0", 64 * SK_KPL, K);
+  TT_REQUIRE(workspace_bytes >= tt_sinkhorn_local_workspace_bytes(B_loc, K), "sinkhorn_local: workspace too small");
+  return TT_OK;
+}
+
+extern "C" int tt_sinkhorn_local_begin(const float* scores, float* u_out, int B_loc, int K, float eps, void* workspace, size_t workspace_bytes,
+                                       tt_stream_t stream) {
+  TT_REQUIRE(scores && u_out && eps > 0.f, "sinkhorn_local_begin: null pointer / bad eps");
+  if (const int rc = sk_local_check(workspace, workspace_bytes, B_loc, K)) return rc;
+  hipStream_t s = as_stream(stream);
+  float* E = static_cast<float*>(workspace);
+  float* part = E + (size_t)B_loc * K;
+  const int wgs = sk_wgs(B_loc), rpw = (B_loc + wgs - 1) / wgs;
+  hipLaunchKernelGGL(sk_init_kernel, dim3(wgs), dim3(SK_THREADS), 0, s, scores, E, part, B_loc, K, eps, rpw);
+  hipLaunchKernelGGL(sk_fold_kernel, dim3((K + 255) / 256), dim3(256), 0, s, part, u_out, wgs, K);
+  TT_CHECK_LAUNCH("sinkhorn_local_begin");
+  return TT_OK;
+}
+
+extern "C" int tt_sinkhorn_local_step(const float* u_in, float* u_out, int B_loc, int B_total, int K, void* workspace, size_t workspace_bytes,
+                                      tt_stream_t stream) {
+  TT_REQUIRE(u_in && u_out && B_total >= B_loc, "sinkhorn_local_step: null pointer / B_total < B_loc");
+  if (const int rc = sk_local_check(workspace, workspace_bytes, B_loc, K)) return rc;
+  hipStream_t s = as_stream(stream);
+  float* E = static_cast<float*>(workspace);
+  float* part = E + (size_t)B_loc * K;
+  const int wgs = sk_wgs(B_loc), rpw = (B_loc + wgs - 1) / wgs;
+  hipLaunchKernelGGL((sk_iter_kernel<false>), dim3(wgs), dim3(SK_THREADS), 0, s, E, u_in, part, (float*)nullptr, B_loc, K, 1, rpw, 0, 0, 0, B_total);
+  hipLaunchKernelGGL(sk_fold_kernel, dim3((K + 255) / 256), dim3(256), 0, s, part, u_out, wgs, K);
+  TT_CHECK_LAUNCH("sinkhorn_local_step");
+  return TT_OK;
+}
+
+extern "C" int tt_sinkhorn_local_end(const float* u_in, float* q_out, int B_loc, int rows_out, int K, void* workspace, size_t workspace_bytes,
+                                     tt_stream_t stream) {
+  TT_REQUIRE(q_out && rows_out > 0 && rows_out <= B_loc, "sinkhorn_local_end: null pointer / rows_out outside (0, B_loc]");
+  if (const int rc = sk_local_check(workspace, workspace_bytes, B_loc, K)) return rc;
+  hipStream_t s = as_stream(stream);
+  const float* E = static_cast<const float*>(workspace);
+  const int owgs = sk_wgs(rows_out), orpw = (rows_out + owgs - 1) / owgs;
+  hipLaunchKernelGGL((sk_iter_kernel<true>), dim3(owgs), dim3(SK_THREADS), 0, s, E, u_in, (float*)nullptr, q_out, B_loc, K, 1, orpw, 0, rows_out,
+                     u_in ? 0 : 1, B_loc);
+  TT_CHECK_LAUNCH("sinkhorn_local_end");
   return TT_OK;
 }
 

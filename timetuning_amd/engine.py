@@ -557,12 +557,47 @@ def _gather_buffer(rows: int, cols: int, device) -> torch.Tensor:
     return buf
 
 
+# How a W > 1 solve exchanges: "allgather" (default: ONE all-gather of the score rows, every rank solves the global problem) or
+# "allreduce" - the reference's own pattern (my_utils.py:250-272): the columns stay on their rank, the K row sums are all-reduced once
+# per iteration (``iters`` small latency-bound collectives, a solve of B_loc instead of W B_loc columns).  ``--sinkhorn_exchange``.
+SINKHORN_EXCHANGE = "allgather"
+_SK_LOCAL: Dict[tuple, "ops.SinkhornLocal"] = {}
+
+
+def global_sinkhorn_allreduce(scores_local: torch.Tensor, rows_out: int, eps: float, iters: int, lib=None) -> torch.Tensor:
+    """The reference's distributed Sinkhorn as it stands (my_utils.py:250-272): each rank keeps its own columns, ``iters`` all-reduces
+    of the K row sums (the reference's two further collectives - the total mass, which cancels in the first row step, and a last row
+    sum nobody reads - are not issued).  ``lib``: the CPU twin for the gloo tests (the HIP library otherwise)."""
+    dist = exchange_group()
+    W = dist.get_world_size() if dist is not None else 1
+    local = scores_local.contiguous()
+    B_loc, K = local.shape
+    key = (B_loc, W, K, str(local.device), id(lib))
+    sk = _SK_LOCAL.get(key)
+    if sk is None:
+        if len(_SK_LOCAL) >= 8:
+            _SK_LOCAL.clear()
+        sk = _SK_LOCAL[key] = ops.SinkhornLocal(B_loc, B_loc * W, K, local.device, lib=lib)
+    u = sk.begin(local, eps)
+    if iters <= 0:
+        return sk.end(None, rows_out)
+    for it in range(iters):
+        if dist is not None:
+            work = dist.all_reduce(u, async_op=True)
+            wait_collective(work, "all_reduce(sinkhorn row sums)", u.numel() * 4, u.device)
+        if it + 1 < iters:
+            u = sk.step(u)
+    return sk.end(u, rows_out)
+
+
 def global_sinkhorn_begin(scores_local: torch.Tensor):
     """Starts the all-gather of the local score rows (asynchronous: RCCL moves them on its own stream while the caller
     keeps launching work that does not need the assignment) and returns the context ``global_sinkhorn_end`` consumes."""
     dist = exchange_group()
     if dist is None:
         return (scores_local, None, None)
+    if SINKHORN_EXCHANGE == "allreduce":
+        return (scores_local, None, "allreduce")   # nothing travels ahead: the row sums are exchanged inside the solve
     W = dist.get_world_size()
     local = scores_local.contiguous()
     gathered = _gather_buffer(W * local.shape[0], local.shape[1], local.device)
@@ -578,6 +613,8 @@ def global_sinkhorn_end(ctx, rows_out: int, eps: float, iters: int, solver=None)
 
     solver = ops.sinkhorn if solver is None else solver
     local, gathered, work = ctx
+    if gathered is None and work == "allreduce":
+        return global_sinkhorn_allreduce(local, rows_out, eps, iters)
     if gathered is None:
         return solver(local, iters, eps, row0=0, rows_out=rows_out)
     wait_collective(work, "all_gather(scores)", gathered.numel() * 4, gathered.device)

@@ -436,6 +436,49 @@ def sinkhorn(scores, iters: int, eps: float = 0.05, row0: int = 0, rows_out: Opt
     return q
 
 
+class SinkhornLocal:
+    """One rank's share of a DISTRIBUTED solve in the reference's own form (my_utils.py:250-272): the columns stay on their rank, the K
+    row sums are all-reduced once per iteration by the caller - ``u = begin(scores)``; ``iters - 1`` times ``u = step(all_reduce(u))``;
+    ``q = end(all_reduce(u))`` (``end(None)`` for zero iterations).  ``lib``: the HIP library (default) or the CPU twin (tests)."""
+
+    def __init__(self, B_loc: int, B_total: int, K: int, device, lib=None):
+        self.lib = _lib.load() if lib is None else lib
+        self.pre = "tt_" if lib is None else "tt_cpu_"
+        self.B_loc, self.B_total, self.K = int(B_loc), int(B_total), int(K)
+        self.nb = getattr(self.lib, self.pre + "sinkhorn_local_workspace_bytes")(self.B_loc, self.K)
+        self.ws = torch.empty((self.nb + 3) // 4, dtype=f32, device=device)   # owned: it holds E between the calls
+        self.device = device
+
+    def _stream(self):
+        return _stream() if torch.device(self.device).type == "cuda" else None
+
+    def _ck(self, rc: int, what: str) -> None:
+        if rc != 0:
+            if self.pre == "tt_":
+                _lib.check(rc, "tt_" + what)
+            raise RuntimeError(f"{self.pre}{what} failed (code {rc})")
+
+    def begin(self, scores, eps: float):
+        assert scores.shape == (self.B_loc, self.K) and scores.dtype == f32 and scores.is_contiguous()
+        u = torch.empty((self.K,), dtype=f32, device=scores.device)
+        self._ck(getattr(self.lib, self.pre + "sinkhorn_local_begin")(_p(scores), _p(u), self.B_loc, self.K, float(eps), _p(self.ws), self.nb, self._stream()),
+                 "sinkhorn_local_begin")
+        return u
+
+    def step(self, u_global):
+        u = torch.empty_like(u_global)
+        self._ck(getattr(self.lib, self.pre + "sinkhorn_local_step")(_p(u_global), _p(u), self.B_loc, self.B_total, self.K, _p(self.ws), self.nb, self._stream()),
+                 "sinkhorn_local_step")
+        return u
+
+    def end(self, u_global, rows_out: Optional[int] = None):
+        rows_out = self.B_loc if rows_out is None else int(rows_out)
+        q = torch.empty((rows_out, self.K), dtype=f32, device=self.ws.device)
+        self._ck(getattr(self.lib, self.pre + "sinkhorn_local_end")(_p(u_global), _p(q), self.B_loc, rows_out, self.K, _p(self.ws), self.nb, self._stream()),
+                 "sinkhorn_local_end")
+        return q
+
+
 def sinkhorn_from_q(Q, iters: int, row0: int = 0, rows_out: Optional[int] = None, transposed: bool = False):
     """Q positive = exp(scores / eps): [K, B_total] as my_utils.sinkhorn receives it, or [B_total, K] with ``transposed``
     -> q [rows_out, K]."""

@@ -698,6 +698,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--precision", default="f16x3", choices=["f16x3", "f32", "bf16x6", "bf16x3", "bf16"],
                    help="arithmetic of the matrix products (hip_ops.set_gemm_precision): f16x3 = the fp32-accurate fp16-pair split (per-op error "
                         "under the exact-f32 MFMA kernels', 1.7x their speed), f32 = exact fp32 MFMA, bf16 = BASELINE C4's bf16 path")
+    p.add_argument("--sinkhorn_exchange", default="allgather", choices=["allgather", "allreduce"],
+                   help="W > 1: allgather = one all-gather of the score rows, every rank solves the global problem (default); allreduce = the "
+                        "reference's own pattern (my_utils.py:250-272): columns stay on their rank, the K row sums are all-reduced per iteration")
     return p
 
 
@@ -794,6 +797,7 @@ def time_tuning(gpu=0, args=None):
     device = torch.device("cuda", gpu)
     torch.cuda.set_device(device)
     ops.set_gemm_precision(getattr(args, "precision", "f16x3"))   # the driver's default: the fp32-accurate fp16-pair split
+    engine.SINKHORN_EXCHANGE = getattr(args, "sinkhorn_exchange", "allgather")
     if world_size > 1 and not dist.is_initialized():
         dist.init_process_group(backend=os.environ.get("TT_DIST_BACKEND", "nccl"), init_method="env://", world_size=world_size, rank=rank)
     if args.use_projection_head:
