@@ -118,4 +118,46 @@ for it in range(rounds):
         ref8 = F.linear(xp8.double().sum(0).cpu(), wp8.double().sum(0).cpu(), b8.double())
         if res8 is not None: ref8 = ref8 + res8.double()
         note(f"linear_fwd_planes (large M) P={P8}", rel(out8, ref8), 3e-5, (P8, M8, N8, K8, res8 is not None))
+    # ---- round 4: the fp16-pair kernels ("f16x3")
+    # general pair kernel: ragged M, N multiple of 64, K multiple of 32, every output combination
+    Mq, Nq, Kq = int(rng.integers(1, 900)), 64 * int(rng.integers(1, 7)), 32 * int(rng.integers(1, 13))
+    xq, wq_, bq_ = torch.randn(Mq, Kq), torch.randn(Nq, Kq) * 0.1, torch.randn(Nq)
+    xpq, wpq = ops.split_pairs(dev(xq)), ops.split_pairs(dev(wq_))
+    resq = torch.randn(Mq, Nq) if rng.random() < 0.5 else None
+    actq = int(resq is None and rng.random() < 0.5)
+    refq2 = F.linear(xq.double(), wq_.double(), bq_.double())
+    oq = ops.linear_fwd_pairs(xpq, wpq, dev(bq_), residual=dev(resq) if resq is not None else None, act=actq, out_f32=True, out_pairs=(resq is None),
+                              save_pre=bool(actq))
+    refy = (F.gelu(refq2) if actq else refq2) + (resq.double() if resq is not None else 0)
+    note("linear_fwd_pairs (general)", rel(oq["y"], refy), 2e-6, (Mq, Nq, Kq, actq, resq is not None))
+    if oq["pairs"] is not None: note("linear_fwd_pairs pairs out", rel(ops.join_pairs(oq["pairs"]), refy), 2e-6, (Mq, Nq, Kq, actq))
+    if actq: note("linear_fwd_pairs pre", rel(oq["pre"], refq2), 2e-6, (Mq, Nq, Kq))
+    # pair attention: any token count (resident kernel up to 256, KV-tiled beyond and forced), any head count
+    Fp, Np, Hp = int(rng.integers(1, 4)), int(rng.integers(1, 900)), int(rng.integers(1, 4))
+    qf = torch.randn(Fp, Np, 3 * Hp * 64) * 0.8
+    qpp = ops.split_pairs(dev(qf.view(Fp * Np, -1))).view(Fp, Np, -1)
+    q_, k_, v_ = qf.double().view(Fp, Np, 3, Hp, 64).permute(2, 0, 3, 1, 4)
+    scp = q_ @ k_.transpose(-1, -2) * 0.125
+    refap = (torch.softmax(scp, -1) @ v_).permute(0, 2, 1, 3).reshape(Fp, Np, Hp * 64)
+    for forced in ((0, 1) if Np <= 256 else (0,)):
+        ops.set_tuning_knob("TT_ATTN_PAIRS_FLASH", forced)
+        op_, of_, lse_ = ops.attention_fwd_pairs(qpp, Hp, out_pairs=True, out_f32=True, save_lse=True)
+        ops.set_tuning_knob("TT_ATTN_PAIRS_FLASH", 0)
+        note(f"attention_fwd_pairs ({'KV-tiled' if (forced or Np > 256) else 'resident'})", max(rel(of_, refap), rel(ops.join_pairs(op_.view(Fp * Np, -1)).view(Fp, Np, -1), refap)),
+             3e-6, (Fp, Np, Hp))
+        note("attention_fwd_pairs lse", rel(lse_, torch.logsumexp(scp, -1)), 1e-5, (Fp, Np, Hp))
+    # weight gradient from row pairs (transposing LDS reads): any M, N and K multiples of 128
+    Mt, Nt_, Kt = int(rng.integers(1, 9000)), 128 * int(rng.integers(1, 5)), 128 * int(rng.integers(1, 5))
+    dyt, xt = torch.randn(Mt, Nt_) * 0.05, torch.randn(Mt, Kt)
+    dwt = ops.linear_bwd_weight_pairs_tn(ops.split_pairs(dev(dyt)), ops.split_pairs(dev(xt)))
+    note("linear_bwd_weight_pairs_tn", rel(dwt, dyt.double().t() @ xt.double()), 2e-6, (Mt, Nt_, Kt))
+    if it % 4 == 0:
+        # the persistent pair GEMM: large ragged M, every tile-count regime (round-robin, half tiles, K-split) by chance
+        M8, N8, K8 = int(rng.integers(9000, 40000)), 128 * int(rng.integers(1, 13)), 96 * int(rng.integers(1, 17))
+        x8, w8, b8 = torch.randn(M8, K8), torch.randn(N8, K8) * 0.1, torch.randn(N8)
+        res8 = torch.randn(M8, N8) if rng.random() < 0.5 else None
+        o8 = ops.linear_fwd_pairs(ops.split_pairs(dev(x8)), ops.split_pairs(dev(w8)), dev(b8), residual=dev(res8) if res8 is not None else None)["y"]
+        ref8 = F.linear(x8.double(), w8.double(), b8.double()) + (res8.double() if res8 is not None else 0)
+        route8 = ops._lib.load().tt_linear_fwd_pairs_route(M8, N8, K8, 0, 1, int(res8 is not None), 1, 0, 0)
+        note(f"linear_fwd_pairs (large M, route {route8})", rel(o8, ref8), 2e-6, (M8, N8, K8, res8 is not None))
 print("fuzz ok:", {k: f"{v:.2e}" for k, v in worst.items()})
