@@ -34,7 +34,7 @@ extern "C" {
 typedef void* tt_stream_t;
 
 const char* tt_last_error(void);
-int tt_abi_version(void);   /* 5 = this header (4: before the fp16-pair entry points; 3: before tt_vit_params.patch_wp; 2: before the coarse entry points) */
+int tt_abi_version(void);   /* 6 = this header (5: before the transpose-free weight gradient, the batched operand refresh and the distributed Sinkhorn steps; 4: before the fp16-pair entry points; 3: before tt_vit_params.patch_wp; 2: before the coarse entry points) */
 /* Tuning knobs of the dispatchers (TT_PLANES_VARIANT, TT_P8_ORDER, TT_P8_NO_HALF, TT_P8_CLOCK_PRINT, TT_Q8_ORDER, TT_PAIRS_NO8,
  * TT_PAIRS8_NO_KEPT) are read ONCE from the environment; this setter changes one afterwards - for the A/B tools and tests only. */
 int tt_set_tuning_knob(const char* name, int value);

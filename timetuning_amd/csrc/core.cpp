@@ -61,7 +61,7 @@ extern "C" int tt_set_tuning_knob(const char* name, int value) {
 }
 
 extern "C" const char* tt_last_error(void) { return tt::g_err; }
-extern "C" int tt_abi_version(void) { return 5; }   // 5: the fp16-pair entry points (tt_*_pairs*), tt_vit_params.planes == 2; 4: tt_vit_params.patch_wp; 3: the coarse entry points (tt_vit_forward, ...) and their parameter structs
+extern "C" int tt_abi_version(void) { return 6; }   // 6: tt_linear_bwd_weight_pairs_tn*, tt_split_pairs_dual_multi, tt_sinkhorn_local_*, pair attention at any N; 5: the fp16-pair entry points (tt_*_pairs*), tt_vit_params.planes == 2; 4: tt_vit_params.patch_wp; 3: the coarse entry points (tt_vit_forward, ...) and their parameter structs
 
 extern "C" int tt_device_info(char* name, int cap) {
   int dev = 0;
