@@ -174,6 +174,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(or `make -C timetuning_amd/csrc`). There is no CPU fallback for the HIP path.")
+    # torch first: it brings ITS libamdhip64 into the process.  Loaded before torch, this library pulls /opt/rocm's copy in, the process
+    # then holds two HIP runtimes and the first kernel launch fails with "no ROCm-capable device is detected" (build() followed by
+    # smoke() in one interpreter, round 4).  The streams and buffers every entry point receives come from torch anyway.
+    import torch  # noqa: F401
+
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
