@@ -249,8 +249,13 @@ int tt_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, float* out_f3
  *   tt_split_pairs_dual           fp32 [R][C] -> transposed pairs [C][2 Rpad] (rows R..Rpad-1 zero, Rpad % 32 == 0) and, optionally in the
  *                                 same pass, row-major pairs [R][2 C] (C % 32 == 0) and the fp32 column sums [C]: a dy is read ONCE for
  *                                 the operand of its weight-gradient product, the operand of its data-gradient product and its bias
- *                                 gradient.  workspace (column sums only): ceil(Rpad / 64) x C floats.  dst_t_pairs may be null (row
- *                                 pairs + column sums only: all the transpose-free weight gradient below needs).
+ *                                 gradient.  workspace (tt_split_pairs_dual_workspace_bytes; needed for column sums / a scale).
+ *                                 dst_t_pairs may be null (row pairs + column sums only: all the transpose-free weight gradient
+ *                                 below needs).  scale_out (device float, or null): a gradient's whole magnitude may sit below fp16's
+ *                                 normal range (2^-14: a C2 step's dy tensors peak at 1e-3 .. 1e-6) - the source is then multiplied
+ *                                 by the power of two S that brings max |src| into [2^13, 2^14) before the split (exact), S is
+ *                                 written to *scale_out, and the products below divide by it (their dy_scale argument, a DEVICE
+ *                                 pointer: no host round trip).  The column sums are those of the unscaled source.
  *   tt_transpose_pairs            pairs [R][2 C] -> transposed pairs [C][2 Rpad]: a saved forward operand for the weight gradient.
  *   tt_linear_bwd_data_pairs      dx[M,K] = dy[M,N] @ w[N,K] (* gelu'(gelu_pre[M,K])): dy in pairs [M][2 N], the weight transposed in pairs
  *                                 wT [K][2 N]; N % 32 == 0, K % 64 == 0.
@@ -261,21 +266,22 @@ int tt_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, float* out_f3
  *                                 gathered by transposing LDS reads).  N % 128 == 0, K % 128 == 0, any M (_ok says whether a shape is
  *                                 taken); partials of the split m range in the workspace, folded in a fixed order. */
 size_t tt_split_pairs_dual_workspace_bytes(int R, int C, int Rpad);
-int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, int R, int C, int Rpad, void* workspace,
-                        size_t workspace_bytes, tt_stream_t stream);
+int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, float* scale_out, int R, int C, int Rpad,
+                        void* workspace, size_t workspace_bytes, tt_stream_t stream);
 int tt_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int R, int C, int Rpad, tt_stream_t stream);
 /* tt_split_pairs_dual (without column sums) for n matrices in ONE launch per 32 of them: host arrays of n pointers / sizes; dst_t_pairs[i] or
  * dst_row_pairs[i] may be null.  What a training step needs of every weight the optimizer rewrote (row pairs: forward and weight-gradient
  * operand; transposed pairs: the data-gradient operand). */
 int tt_split_pairs_dual_multi(const float* const* src, void* const* dst_t_pairs, void* const* dst_row_pairs, const int* R, const int* C,
                               const int* Rpad, int n, tt_stream_t stream);
-int tt_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, int M, int N, int K, tt_stream_t stream);
+int tt_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, const float* dy_scale, int M, int N, int K,
+                             tt_stream_t stream);
 size_t tt_linear_bwd_weight_pairs_workspace_bytes(int N, int K, int Mpad);
-int tt_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, float* dw, int N, int K, int Mpad, void* workspace,
+int tt_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, float* dw, const float* dy_scale, int N, int K, int Mpad, void* workspace,
                                size_t workspace_bytes, tt_stream_t stream);
 int tt_linear_bwd_weight_pairs_tn_ok(int N, int K, int M);
 size_t tt_linear_bwd_weight_pairs_tn_workspace_bytes(int N, int K, int M);
-int tt_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, float* dw, int N, int K, int M, void* workspace,
+int tt_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, float* dw, const float* dy_scale, int N, int K, int M, void* workspace,
                                   size_t workspace_bytes, tt_stream_t stream);
 /*   The backward products of the same nn.Linear sites on bf16-plane operands (autograd of dino_vision_transformer.py:94-103,
  *   115-130; the bf16 path only - the fp32 modes keep the f32-MFMA backward kernels):

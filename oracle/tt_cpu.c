@@ -1021,26 +1021,39 @@ int tt_cpu_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, float* ou
   return 0;
 }
 size_t tt_cpu_split_pairs_dual_workspace_bytes(int R, int C, int Rpad) { return 0; }
-int tt_cpu_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, int R, int C, int Rpad, void* workspace,
-                            size_t workspace_bytes, tt_stream_t stream) {
-  (void)workspace; (void)workspace_bytes;
-  uint16_t* t = (uint16_t*)dst_t_pairs;
+/* the power of two that brings amax into [2^13, 2^14) (gemm_planes.hip pair_scale_of); 1 for 0 / inf / nan */
+static float pair_scale_of(float amax) {
+  if (!(amax > 0.f) || !(amax < INFINITY)) return 1.0f;
+  int e = 13 - ilogbf(amax);
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return ldexpf(1.0f, e);
+}
+int tt_cpu_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, float* scale_out, int R, int C, int Rpad,
+                            void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  uint16_t *t = (uint16_t*)dst_t_pairs, *row = (uint16_t*)dst_row_pairs;
+  float S = 1.0f;
+  if (scale_out) {   /* a gradient: scaled by a power of two before the split, the consumers divide by it */
+    float amax = 0.f;
+    for (size_t i = 0; i < (size_t)R * C; ++i) amax = fmaxf(amax, fabsf(src[i]));
+    S = *scale_out = pair_scale_of(amax);
+  }
   for (int c = 0; c < C; ++c) {
     double s = 0.0;
     for (int r = 0; r < Rpad; ++r) {
       const float v = r < R ? src[(size_t)r * C + c] : 0.f;
-      if (t) pair_put(t + (size_t)c * 2 * Rpad, r, v);
+      if (t) pair_put(t + (size_t)c * 2 * Rpad, r, v * S);
+      if (row && r < R) pair_put(row + (size_t)r * 2 * C, c, v * S);
       s += v;
     }
     if (colsum) colsum[c] = (float)s;
   }
-  if (dst_row_pairs) tt_cpu_split_pairs(src, dst_row_pairs, (long long)R * C, stream);
   return 0;
 }
 int tt_cpu_split_pairs_dual_multi(const float* const* src, void* const* dst_t_pairs, void* const* dst_row_pairs, const int* R, const int* C,
                                   const int* Rpad, int n, tt_stream_t stream) {
   for (int i = 0; i < n; ++i) {
-    const int rc = tt_cpu_split_pairs_dual(src[i], dst_t_pairs[i], dst_row_pairs[i], NULL, R[i], C[i], Rpad[i], NULL, 0, stream);
+    const int rc = tt_cpu_split_pairs_dual(src[i], dst_t_pairs[i], dst_row_pairs[i], NULL, NULL, R[i], C[i], Rpad[i], NULL, 0, stream);
     if (rc) return rc;
   }
   return 0;
@@ -1056,35 +1069,38 @@ int tt_cpu_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int R, int 
     }
   return 0;
 }
-int tt_cpu_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, int M, int N, int K,
-                                 tt_stream_t stream) {
+int tt_cpu_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, const float* dy_scale, int M, int N,
+                                 int K, tt_stream_t stream) {
   (void)stream;
   const uint16_t *dy = (const uint16_t*)dy_pairs, *wT = (const uint16_t*)wT_pairs;   /* dy [M][2 N], wT [K][2 N] */
+  const double inv_s = dy_scale ? 1.0 / (double)*dy_scale : 1.0;
   for (int m = 0; m < M; ++m)
     for (int k = 0; k < K; ++k) {
-      float v = (float)pair_dot(dy + (size_t)m * 2 * N, wT + (size_t)k * 2 * N, N);
+      float v = (float)(pair_dot(dy + (size_t)m * 2 * N, wT + (size_t)k * 2 * N, N) * inv_s);
       if (gelu_pre) v *= tt_cpu_gelu_grad(gelu_pre[(size_t)m * K + k]);
       dx[(size_t)m * K + k] = v;
     }
   return 0;
 }
 size_t tt_cpu_linear_bwd_weight_pairs_workspace_bytes(int N, int K, int Mpad) { return 0; }
-int tt_cpu_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, float* dw, int N, int K, int Mpad, void* workspace,
-                                   size_t workspace_bytes, tt_stream_t stream) {
+int tt_cpu_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, float* dw, const float* dy_scale, int N, int K, int Mpad,
+                                   void* workspace, size_t workspace_bytes, tt_stream_t stream) {
   (void)workspace; (void)workspace_bytes; (void)stream;
   const uint16_t *dyT = (const uint16_t*)dyT_pairs, *xT = (const uint16_t*)xT_pairs;   /* dyT [N][2 Mpad], xT [K][2 Mpad] */
+  const double inv_s = dy_scale ? 1.0 / (double)*dy_scale : 1.0;
   for (int n = 0; n < N; ++n)
-    for (int k = 0; k < K; ++k) dw[(size_t)n * K + k] = (float)pair_dot(dyT + (size_t)n * 2 * Mpad, xT + (size_t)k * 2 * Mpad, Mpad);
+    for (int k = 0; k < K; ++k) dw[(size_t)n * K + k] = (float)(pair_dot(dyT + (size_t)n * 2 * Mpad, xT + (size_t)k * 2 * Mpad, Mpad) * inv_s);
   return 0;
 }
 
 /* gemm_pairs_tn.hip: the same product from row pairs dy [M][2 N], x [M][2 K] */
 int tt_cpu_linear_bwd_weight_pairs_tn_ok(int N, int K, int M) { return N > 0 && K > 0 && M > 0 && N % 128 == 0 && K % 128 == 0; }
 size_t tt_cpu_linear_bwd_weight_pairs_tn_workspace_bytes(int N, int K, int M) { return 0; }
-int tt_cpu_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, float* dw, int N, int K, int M, void* workspace,
-                                      size_t workspace_bytes, tt_stream_t stream) {
+int tt_cpu_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, float* dw, const float* dy_scale, int N, int K, int M,
+                                      void* workspace, size_t workspace_bytes, tt_stream_t stream) {
   (void)workspace; (void)workspace_bytes; (void)stream;
   const uint16_t *dy = (const uint16_t*)dy_pairs, *x = (const uint16_t*)x_pairs;
+  const double inv_s = dy_scale ? 1.0 / (double)*dy_scale : 1.0;
   for (int n = 0; n < N; ++n)
     for (int k = 0; k < K; ++k) {
       double s = 0.0;
@@ -1092,7 +1108,7 @@ int tt_cpu_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs,
         const uint16_t *a = dy + (size_t)m * 2 * N, *b = x + (size_t)m * 2 * K;
         s += pair_hi(a, n) * pair_hi(b, k) + pair_hi(a, n) * pair_lo(b, k) + pair_lo(a, n) * pair_hi(b, k);
       }
-      dw[(size_t)n * K + k] = (float)s;
+      dw[(size_t)n * K + k] = (float)(s * inv_s);
     }
   return 0;
 }

@@ -695,7 +695,7 @@ def test_round4_pair_twins_against_numpy(twin):
     assert np.abs(y - F.gelu(torch.from_numpy(ref)).numpy()).max() / np.abs(ref).max() < 5e-7
     # transposes: zero padding beyond R, the same bits as splitting the transposed matrix
     t, row, sums = np.empty((K, 2 * 64), np.uint16), np.empty((M, 2 * K), np.uint16), np.empty(K, np.float32)
-    assert twin.tt_cpu_split_pairs_dual(ptr(x), ptr(t), ptr(row), ptr(sums), M, K, 64, None, 0, None) == 0
+    assert twin.tt_cpu_split_pairs_dual(ptr(x), ptr(t), ptr(row), ptr(sums), None, M, K, 64, None, 0, None) == 0
     xt = np.zeros((K, 64), np.float32); xt[:, :M] = x.T
     tref = np.empty((K, 128), np.uint16)
     assert twin.tt_cpu_split_pairs(ptr(xt), ptr(tref), K * 64, None) == 0
@@ -705,17 +705,17 @@ def test_round4_pair_twins_against_numpy(twin):
     # backward products
     dy = (1e-3 * rs.randn(M, N)).astype(np.float32)
     dyT, dyr = np.empty((N, 128), np.uint16), np.empty((M, 2 * N), np.uint16)
-    assert twin.tt_cpu_split_pairs_dual(ptr(dy), ptr(dyT), ptr(dyr), None, M, N, 64, None, 0, None) == 0
+    assert twin.tt_cpu_split_pairs_dual(ptr(dy), ptr(dyT), ptr(dyr), None, None, M, N, 64, None, 0, None) == 0
     wT = np.empty((K, 2 * N), np.uint16)
-    assert twin.tt_cpu_split_pairs_dual(ptr(w), ptr(wT), None, None, N, K, N, None, 0, None) == 0
+    assert twin.tt_cpu_split_pairs_dual(ptr(w), ptr(wT), None, None, None, N, K, N, None, 0, None) == 0
     dx, dw = np.empty((M, K), np.float32), np.empty((N, K), np.float32)
-    assert twin.tt_cpu_linear_bwd_data_pairs(ptr(dyr), ptr(wT), None, ptr(dx), M, N, K, None) == 0
-    assert twin.tt_cpu_linear_bwd_weight_pairs(ptr(dyT), ptr(t), ptr(dw), N, K, 64, None, 0, None) == 0
+    assert twin.tt_cpu_linear_bwd_data_pairs(ptr(dyr), ptr(wT), None, ptr(dx), None, M, N, K, None) == 0
+    assert twin.tt_cpu_linear_bwd_weight_pairs(ptr(dyT), ptr(t), ptr(dw), None, N, K, 64, None, 0, None) == 0
     dx_ref, dw_ref = dy.astype(np.float64) @ w, dy.astype(np.float64).T @ x
     assert np.abs(dx - dx_ref).max() / np.abs(dx_ref).max() < 5e-7 and np.abs(dw - dw_ref).max() / np.abs(dw_ref).max() < 5e-7
     # the same weight gradient from ROW pairs (gemm_pairs_tn.hip's twin); the column sums without a transposed output
     dw_tn = np.empty((N, K), np.float32)
-    assert twin.tt_cpu_linear_bwd_weight_pairs_tn(ptr(dyr), ptr(xp), ptr(dw_tn), N, K, M, None, 0, None) == 0
+    assert twin.tt_cpu_linear_bwd_weight_pairs_tn(ptr(dyr), ptr(xp), ptr(dw_tn), None, N, K, M, None, 0, None) == 0
     assert np.abs(dw_tn - dw_ref).max() / np.abs(dw_ref).max() < 5e-7 and np.abs(dw_tn - dw).max() <= 1e-6 * np.abs(dw).max()
     assert twin.tt_cpu_linear_bwd_weight_pairs_tn_ok(128, 256, 5) == 1 and twin.tt_cpu_linear_bwd_weight_pairs_tn_ok(64, 256, 5) == 0
     import ctypes as C
@@ -726,8 +726,26 @@ def test_round4_pair_twins_against_numpy(twin):
                                               ints(M, M), ints(K, K), ints(64, 64), 2, None) == 0
     assert np.array_equal(m_t, t) and np.array_equal(m_row, xp)
     dyr2, cs = np.empty((M, 2 * N), np.uint16), np.empty((N,), np.float32)
-    assert twin.tt_cpu_split_pairs_dual(ptr(dy), None, ptr(dyr2), ptr(cs), M, N, 64, None, 0, None) == 0
+    assert twin.tt_cpu_split_pairs_dual(ptr(dy), None, ptr(dyr2), ptr(cs), None, M, N, 64, None, 0, None) == 0
     assert np.array_equal(dyr2, dyr) and np.allclose(cs, dy.sum(0), atol=1e-6)
+    # a gradient far below fp16's normal range: the scaled split (a power of two S that brings max |dy| into [2^13, 2^14), the products
+    # divided by S) keeps fp32-class accuracy where the plain split is left with fp16 subnormals
+    tiny = (dy * 1e-4).astype(np.float32)                                  # |tiny| ~ 1e-7
+    ref_dw, ref_dx = tiny.astype(np.float64).T @ x, tiny.astype(np.float64) @ w
+    S = np.zeros(1, np.float32)
+    tr, cs2 = np.empty((M, 2 * N), np.uint16), np.empty((N,), np.float32)
+    assert twin.tt_cpu_split_pairs_dual(ptr(tiny), None, ptr(tr), ptr(cs2), ptr(S), M, N, 64, None, 0, None) == 0
+    amax = np.abs(tiny).max()
+    assert S[0] == 2.0 ** (13 - np.floor(np.log2(amax))) and 2 ** 13 <= amax * S[0] < 2 ** 14 and np.allclose(cs2, tiny.sum(0), rtol=1e-5, atol=0)
+    dws, dxs = np.empty((N, K), np.float32), np.empty((M, K), np.float32)
+    assert twin.tt_cpu_linear_bwd_weight_pairs_tn(ptr(tr), ptr(xp), ptr(dws), ptr(S), N, K, M, None, 0, None) == 0
+    assert twin.tt_cpu_linear_bwd_data_pairs(ptr(tr), ptr(wT), None, ptr(dxs), ptr(S), M, N, K, None) == 0
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    assert rel(dws, ref_dw) < 5e-7 and rel(dxs, ref_dx) < 5e-7
+    tu, dwu = np.empty((M, 2 * N), np.uint16), np.empty((N, K), np.float32)
+    assert twin.tt_cpu_split_pairs_dual(ptr(tiny), None, ptr(tu), None, None, M, N, 64, None, 0, None) == 0
+    assert twin.tt_cpu_linear_bwd_weight_pairs_tn(ptr(tu), ptr(xp), ptr(dwu), None, N, K, M, None, 0, None) == 0
+    assert rel(dwu, ref_dw) > 20 * rel(dws, ref_dw)                        # (what the scale is for)
     # attention on pairs against torch in fp64
     Fr, Nn, H = 2, 19, 2
     D = 64 * H

@@ -56,6 +56,8 @@ struct Q8Args {
   // ks_S workgroups cu = j * ks_S + s, each over a contiguous range of K-tile triples; every WAVE leaves the fp32 partial of its 64 x 64
   // sub-tile in ks_ws, and the wave that arrives last at the (tile, wave) counter adds the partials in slice order and runs the epilogue
   int ks_S, ks_R;
+  const float* out_scale; // device scalar S (a power of two) one operand was scaled by before its split (a gradient) - the product is
+                          // divided by it; null: none
   float* ks_ws;           // [ks_R][ks_S][8 waves][4096]
   int* ks_cnt;            // [ks_R][8], zero between launches (the finishing wave resets its counter)
 };
@@ -492,6 +494,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
     }
     constexpr int NT = 4;   // MFMA tiles in the order (ha, mt): a half item ends after the first two
     const int nt = half ? NT / 2 : NT;
+    const float inv_s = g.out_scale ? 1.0f / *g.out_scale : 1.0f;   // exact: S is a power of two
     // MFMA tile j = (ha, mt): output rows mrow(j) .., columns ncol(j) .. (+ 32 each)
     auto mrow = [&](int j) { return row0 + (j >> 1) * 128 + (SQ ? wr * 32 : wr * 64 + (j & 1) * 32); };
     auto ncol = [&](int j) { return n0 + (SQ ? wc * 64 + (j & 1) * 32 : wc * 32); };
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
             const int phys = (2 * gg + h) ^ esw(r);
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(a2[ha][mt][4 * gi + e], 0.00048828125f, a1[ha][mt][4 * gi + e]);   // exact 2^-11
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(a2[ha][mt][4 * gi + e], 0.00048828125f, a1[ha][mt][4 * gi + e]) * inv_s;   // exact 2^-11
             *reinterpret_cast<f32x4*>(scr + r * (CW * 4) + phys * 16) = v;
           }
 #pragma unroll
@@ -823,7 +826,7 @@ int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, 
 // then takes the general kernel), < 0 on a launch error.  pre_out: the fp32 pre-activation of a GELU layer (its y must then be pairs only);
 // gelu_pre: the pre-activation whose gelu' multiplies a data-gradient product.
 int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out, void* y_pairs,
-               const float* gelu_pre, int M, int N, int K, int act, hipStream_t s) {
+               const float* gelu_pre, const float* out_scale, int M, int N, int K, int act, hipStream_t s) {
   Q8Plan pl;
   const int epi = pairs8_plan(residual != nullptr, y != nullptr, y_pairs != nullptr, pre_out != nullptr, gelu_pre != nullptr, M, N, K, act, &pl);
   if (epi < 0) return 1;
@@ -835,7 +838,7 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
   }
   Q8Args g{static_cast<const _Float16*>(x_pairs), static_cast<const _Float16*>(w_pairs), M, N, K, bias, gelu_pre ? gelu_pre : residual,
            pre_out ? pre_out : y, static_cast<_Float16*>(y_pairs), pl.ntn, (int)pl.ntiles, pl.ncu, pl.n_full, pl.n_half, q8_order_mode(),
-           pl.ks_S, pl.ks_R, ks_ws, ks_cnt};
+           pl.ks_S, pl.ks_R, out_scale, ks_ws, ks_cnt};
 #ifdef TT_Q8_ABLATE   // timing-study build only: TT_Q8_DBG selects a crippled instantiation
   {
     const char* e = getenv("TT_Q8_DBG");

@@ -29,6 +29,7 @@ struct TnArgs {
   const _Float16* A;   // dy, row pairs [M][2 N]
   const _Float16* B;   // x, row pairs [M][2 K]
   float* C;            // [splits][N][K] (splits == 1: dW itself)
+  const float* a_scale;   // device scalar S the dy pairs were scaled by (tt_split_pairs_dual) or null: the product is divided by it
   int M, N, K;
   int ntk, ntiles, splits, nchunks;   // tiles along K, tiles, splits of the m range, 32-row chunks
 };
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs_tn_kernel(TnArgs g) {
   // ---- C[n][k]: lane -> column k = lane & 31 of the group, register e -> row n = (e & 3) + 8 (e >> 2) + 4 h: 128-byte row pieces
   float* out = g.C + (size_t)split * g.N * g.K;
   const int r = lane & 31;
+  const float inv_s = g.a_scale ? 1.0f / *g.a_scale : 1.0f;   // exact: S is a power of two
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs_tn_kernel(TnArgs g) {
       for (int e = 0; e < 16; ++e) {
         const int n = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         const int k = k0 + wk * 64 + j * 32 + r;
-        out[(size_t)n * g.K + k] = fmaf(a2[i][j][e], kPairInvScale, a1[i][j][e]);
+        out[(size_t)n * g.K + k] = fmaf(a2[i][j][e], kPairInvScale, a1[i][j][e]) * inv_s;
       }
 }
 
@@ -156,14 +158,14 @@ extern "C" size_t tt_linear_bwd_weight_pairs_tn_workspace_bytes(int N, int K, in
   const int s = tn_splits(N, K, M);
   return s > 1 ? (size_t)s * N * K * sizeof(float) : 16;
 }
-extern "C" int tt_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, float* dw, int N, int K, int M, void* workspace,
-                                             size_t workspace_bytes, tt_stream_t stream) {
+extern "C" int tt_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, float* dw, const float* dy_scale, int N, int K, int M,
+                                             void* workspace, size_t workspace_bytes, tt_stream_t stream) {
   TT_REQUIRE(dy_pairs && x_pairs && dw && workspace, "linear_bwd_weight_pairs_tn: null pointer");
   TT_REQUIRE(tt_linear_bwd_weight_pairs_tn_ok(N, K, M), "linear_bwd_weight_pairs_tn: need N %% 128 == 0, K %% 128 == 0, operands under 4 GB (N %d K %d M %d)", N, K, M);
   TT_REQUIRE(workspace_bytes >= tt_linear_bwd_weight_pairs_tn_workspace_bytes(N, K, M), "linear_bwd_weight_pairs_tn: workspace too small");
   TT_REQUIRE(aligned16(dy_pairs) && aligned16(x_pairs) && aligned16(dw) && aligned16(workspace), "linear_bwd_weight_pairs_tn: buffers must be 16-byte aligned");
   const int s = tn_splits(N, K, M);
-  TnArgs g{static_cast<const _Float16*>(dy_pairs), static_cast<const _Float16*>(x_pairs), s > 1 ? static_cast<float*>(workspace) : dw, M, N, K,
+  TnArgs g{static_cast<const _Float16*>(dy_pairs), static_cast<const _Float16*>(x_pairs), s > 1 ? static_cast<float*>(workspace) : dw, dy_scale, M, N, K,
            K / 128, (N / 128) * (K / 128), s, (M + 31) / 32};
   hipLaunchKernelGGL(gemm_pairs_tn_kernel, dim3((unsigned)(g.ntiles * s)), dim3(256), 0, as_stream(stream), g);
   TT_CHECK_LAUNCH("gemm_pairs_tn");

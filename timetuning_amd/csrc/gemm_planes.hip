@@ -61,6 +61,8 @@ struct PlaneArgs {
   const float* gelu_pre;  // backward-data use: y *= gelu'(gelu_pre[m][n]) (dino_vision_transformer.py:100 through autograd) or null
   int splits;             // split-K: grid.y slices of the reduction, slice z writes plain fp32 partials to C + z * split_stride
   long long split_stride;
+  const float* out_scale; // PAIR: device scalar S (a power of two) by which an operand was scaled before its split (a gradient: see
+                          // transpose_pairs_tile) - the product is divided by it; null: none
 };
 
 // x -> up to three bf16 planes with x = p0 + p1 + p2 (exact when 3 planes are taken and no exponent underflow)
@@ -298,6 +300,7 @@ __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(Pl
   float bias8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = g.bias ? g.bias[n + e] : 0.f;
+  const float inv_s = (PAIR && g.out_scale) ? 1.0f / *g.out_scale : 1.0f;   // exact: S is a power of two
 #pragma unroll
   for (int wmi = 0; wmi < GM; ++wmi) {
     if (computes && wm == wmi) {
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(Pl
 #pragma unroll
           for (int e = 0; e < 16; ++e)
             Cs[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDCS + wn * (32 * WN) + j * 32 + r] =
-                PAIR ? fmaf(acc2[PAIR ? i : 0][PAIR ? j : 0][e], kPairInvScale, acc[i][j][e]) : acc[i][j][e];
+                PAIR ? fmaf(acc2[PAIR ? i : 0][PAIR ? j : 0][e], kPairInvScale, acc[i][j][e]) * inv_s : acc[i][j][e];
     }
     __syncthreads();
     for (int rr = tid / TPR; rr < CH; rr += RPP) {
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(256) void join_pairs_kernel(const _Float16* __restr
 }
 
 int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out, void* y_pairs,
-               const float* gelu_pre, int M, int N, int K, int act, hipStream_t s);                                   // gemm_pairs8.hip
+               const float* gelu_pre, const float* out_scale, int M, int N, int K, int act, hipStream_t s);          // gemm_pairs8.hip
 int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, int has_pairs, int has_pre, int has_gelu_pre);
 
 // ---- transposed pairs: the operands of the backward products in the "f16x3" mode (reduction index contiguous, in pair groups).
@@ -497,9 +500,40 @@ int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, 
 //   SRC_PAIRS = false: src fp32 [R][C]; optionally ALSO the row-major pairs [R][2 C] (C % 32 == 0: the dgrad operand of a dy that the
 //   weight gradient needs transposed) and the fp32 column sums of the tile's rows (a bias gradient) - one read of dy for all three.
 //   SRC_PAIRS = true: src pairs [R][2 C] (a saved forward operand): a 16-bit transpose of the hi and the lo halves.
+// amax -> the power of two S that brings it into [2^13, 2^14) (fp16: max 65504, smallest normal 2^-14); 1 for 0 / inf / nan
+__device__ __forceinline__ float pair_scale_of(float amax) {
+  if (!(amax > 0.f) || !(amax < INFINITY)) return 1.0f;
+  int e = 13 - ilogbf(amax);
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return ldexpf(1.0f, e);
+}
+// per-workgroup maxima of |x| (stage 1 of the gradient scale: every consumer folds the <= 256 partials itself - max is order-independent)
+__global__ __launch_bounds__(256) void amax_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4*>(x + i);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    } else {
+      for (long long j = i; j < n; ++j) m = fmaxf(m, fabsf(x[j]));
+    }
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// amax_part / n_part (fp32 source only): the source is a GRADIENT whose whole magnitude may sit below fp16's normal range (a C2 step's
+// dy tensors peak at 1e-3 .. 1e-6 with medians down to 2e-8: split as they are, hi is an fp16 subnormal and the pair keeps ~15 bits) -
+// it is multiplied by the power of two S = pair_scale_of(max |src|) before the split (exact) and the consumers divide their product by S
+// (PlaneArgs::out_scale).  The column sums are taken of the unscaled values.  Workgroup (0, 0) publishes S.
 template <bool SRC_PAIRS, bool ROW, bool SUM>
 __device__ __forceinline__ void transpose_pairs_tile(const void* __restrict__ src_, _Float16* __restrict__ dst_t, _Float16* __restrict__ dst_row,
-                                                     int R, int C, int Rpad, float* __restrict__ partial, int bx, int by) {
+                                                     int R, int C, int Rpad, float* __restrict__ partial, int bx, int by,
+                                                     const float* __restrict__ amax_part = nullptr, int n_part = 0,
+                                                     float* __restrict__ scale_out = nullptr) {
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   __shared__ _Float16 th[64][66], tl[64][66];   // [r][c] halves of the tile (row stride 132 bytes: conflict-free column walks)
   __shared__ float red[4][64];
@@ -520,12 +554,22 @@ __device__ __forceinline__ void transpose_pairs_tile(const void* __restrict__ sr
     }
   } else {
     const float* src = static_cast<const float*>(src_);
+    float S = 1.0f;
+    if (amax_part) {   // (uniform) fold of the <= 256 partial maxima: one per thread, then across the four waves
+      __shared__ float sred[4];
+      float m = (int)threadIdx.x < n_part ? amax_part[threadIdx.x] : 0.f;
+      m = wave_max(m);
+      if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = m;
+      __syncthreads();
+      S = pair_scale_of(fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3])));
+      if (scale_out && bx == 0 && by == 0 && threadIdx.x == 0) *scale_out = S;
+    }
     float csum = 0.f;
     for (int i = ty; i < 64; i += 4) {
       const int r = r0 + i, c = c0 + tx;
       const float v = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
       _Float16 hi, lo;
-      split_pair(v, hi, lo);
+      split_pair(v * S, hi, lo);
       th[i][tx] = hi;
       tl[i][tx] = lo;
       csum += v;
@@ -559,8 +603,9 @@ __device__ __forceinline__ void transpose_pairs_tile(const void* __restrict__ sr
 }
 template <bool SRC_PAIRS, bool ROW, bool SUM>
 __global__ __launch_bounds__(256) void transpose_pairs_kernel(const void* __restrict__ src_, _Float16* __restrict__ dst_t, _Float16* __restrict__ dst_row,
-                                                              int R, int C, int Rpad, float* __restrict__ partial) {
-  transpose_pairs_tile<SRC_PAIRS, ROW, SUM>(src_, dst_t, dst_row, R, C, Rpad, partial, blockIdx.x, blockIdx.y);
+                                                              int R, int C, int Rpad, float* __restrict__ partial,
+                                                              const float* __restrict__ amax_part, int n_part, float* __restrict__ scale_out) {
+  transpose_pairs_tile<SRC_PAIRS, ROW, SUM>(src_, dst_t, dst_row, R, C, Rpad, partial, blockIdx.x, blockIdx.y, amax_part, n_part, scale_out);
 }
 
 // The same for a TABLE of fp32 matrices in one launch: the pair operands (row pairs for the forward / weight-gradient products, transposed
@@ -741,7 +786,7 @@ static int linear_planes_impl(const void* x_planes, long long x_plane_stride, co
              "linear_planes: a split-K launch writes plain fp32 partials only");
   TT_REQUIRE(gelu_pre == nullptr || aligned16(gelu_pre), "linear_planes: gelu_pre must be 16-byte aligned");
   PlaneArgs g{static_cast<const __bf16*>(x_planes), static_cast<const __bf16*>(w_planes), x_plane_stride, w_plane_stride, M, N, K, bias, residual, y,
-              pre_out, static_cast<__bf16*>(y_planes), y_plane_stride, y_nplanes, act, gelu_pre, splits, split_stride};
+              pre_out, static_cast<__bf16*>(y_planes), y_plane_stride, y_nplanes, act, gelu_pre, splits, split_stride, nullptr};
   hipStream_t s = as_stream(stream);
   const int variant = tuning_knob(KNOB_PLANES_VARIANT);   // tuning aid (tt_set_tuning_knob: A/B in one process)
   // whole-tile forward products on a grid that fills the chip: the persistent 8-phase kernel (gemm_planes8.hip)
@@ -826,7 +871,7 @@ extern "C" int tt_join_pairs(const void* src_pairs, float* dst, long long n, tt_
 // y_pairs.  splits > 1: plain fp32 partials of a K split (weight gradients).
 static int linear_pairs_impl(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out,
                              void* y_pairs, int M, int N, int K, int act, const float* gelu_pre, int splits, long long split_stride,
-                             tt_stream_t stream) {
+                             tt_stream_t stream, const float* out_scale = nullptr) {
   TT_REQUIRE(x_pairs && w_pairs && (y || y_pairs), "linear_fwd_pairs: null operand / no output");
   TT_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 32 == 0, "linear_fwd_pairs: need N %% 64 == 0 and K %% 32 == 0 (got N=%d K=%d)", N, K);
   auto ok16 = [](const void* p) { return p == nullptr || aligned16(p); };
@@ -837,12 +882,12 @@ static int linear_pairs_impl(const void* x_pairs, const void* w_pairs, const flo
   hipStream_t s = as_stream(stream);
   const bool no8 = tuning_knob(KNOB_PAIRS_NO8) != 0;   // tuning aid: the general kernel everywhere
   if (!no8 && splits == 1) {
-    const int rc = pairs8_try(x_pairs, w_pairs, bias, residual, y, pre_out, y_pairs, gelu_pre, M, N, K, act, s);
+    const int rc = pairs8_try(x_pairs, w_pairs, bias, residual, y, pre_out, y_pairs, gelu_pre, out_scale, M, N, K, act, s);
     if (rc <= 0) return rc;
   }
   // the general kernel sees rows of 2 K 16-bit elements in K-tiles of 64 (= one pair group)
   PlaneArgs g{static_cast<const __bf16*>(x_pairs), static_cast<const __bf16*>(w_pairs), 0, 0, M, N, 2 * K, bias, residual, y,
-              pre_out, static_cast<__bf16*>(y_pairs), 0, y_pairs ? 1 : 0, act, gelu_pre, splits, split_stride};
+              pre_out, static_cast<__bf16*>(y_pairs), 0, y_pairs ? 1 : 0, act, gelu_pre, splits, split_stride, out_scale};
   const long long t128 = (long long)((M + 127) / 128) * (N / 128);
   const bool big = (N % 128 == 0) && t128 * splits >= 3 * 256;
   const bool wide = (N % 128 == 0) && (long long)((M + 63) / 64) * (N / 128) * splits >= 2 * 256;
@@ -863,28 +908,40 @@ extern "C" int tt_linear_fwd_pairs(const void* x_pairs, const void* w_pairs, con
   return linear_pairs_impl(x_pairs, w_pairs, bias, residual, y, pre_out, y_pairs, M, N, K, act, nullptr, 1, 0, stream);
 }
 
-// fp32 [R][C] -> transposed pairs [C][2 Rpad] (+ row-major pairs [R][2 C], + fp32 column sums); see transpose_pairs_kernel
+// fp32 [R][C] -> transposed pairs [C][2 Rpad] (+ row-major pairs [R][2 C], + fp32 column sums); see transpose_pairs_kernel.
+// scale_out (a gradient: see transpose_pairs_tile): the pairs hold src * S, S = the power of two written to *scale_out.
+constexpr int kAmaxParts = 256;
 extern "C" size_t tt_split_pairs_dual_workspace_bytes(int R, int C, int Rpad) {
   if (R <= 0 || C <= 0 || Rpad < R) return 0;
-  return (size_t)((Rpad + 63) / 64) * C * sizeof(float);
+  return ((size_t)((Rpad + 63) / 64) * C + kAmaxParts) * sizeof(float);
 }
 
-extern "C" int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, int R, int C, int Rpad, void* workspace,
-                                   size_t workspace_bytes, tt_stream_t stream) {
+extern "C" int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, float* scale_out, int R, int C, int Rpad,
+                                   void* workspace, size_t workspace_bytes, tt_stream_t stream) {
   TT_REQUIRE(src && (dst_t_pairs || dst_row_pairs) && R > 0 && C > 0 && Rpad >= R && Rpad % 32 == 0,
              "split_pairs_dual: bad arguments (an output, Rpad a multiple of 32)");
   TT_REQUIRE(!dst_row_pairs || C % 32 == 0, "split_pairs_dual: row-major pairs need C %% 32 == 0 (got %d)", C);
-  TT_REQUIRE(!colsum || (workspace && workspace_bytes >= tt_split_pairs_dual_workspace_bytes(R, C, Rpad)), "split_pairs_dual: workspace too small");
+  TT_REQUIRE(!(colsum || scale_out) || (workspace && workspace_bytes >= tt_split_pairs_dual_workspace_bytes(R, C, Rpad)),
+             "split_pairs_dual: workspace too small");
   TT_REQUIRE((reinterpret_cast<uintptr_t>(dst_t_pairs) & 7u) == 0, "split_pairs_dual: the transposed output must be 8-byte aligned");
+  TT_REQUIRE(!scale_out || aligned16(src), "split_pairs_dual: a scaled split needs a 16-byte aligned source");
   const dim3 grid((Rpad + 63) / 64, (C + 63) / 64), block(256);
   hipStream_t s = as_stream(stream);
   _Float16* dt = static_cast<_Float16*>(dst_t_pairs);
   _Float16* dr = static_cast<_Float16*>(dst_row_pairs);
   float* partial = static_cast<float*>(workspace);
-  if (dr && colsum) hipLaunchKernelGGL((transpose_pairs_kernel<false, true, true>), grid, block, 0, s, src, dt, dr, R, C, Rpad, partial);
-  else if (dr) hipLaunchKernelGGL((transpose_pairs_kernel<false, true, false>), grid, block, 0, s, src, dt, dr, R, C, Rpad, nullptr);
-  else if (colsum) hipLaunchKernelGGL((transpose_pairs_kernel<false, false, true>), grid, block, 0, s, src, dt, dr, R, C, Rpad, partial);
-  else hipLaunchKernelGGL((transpose_pairs_kernel<false, false, false>), grid, block, 0, s, src, dt, dr, R, C, Rpad, nullptr);
+  float* amax_part = nullptr;
+  int n_part = 0;
+  if (scale_out) {
+    amax_part = partial + (size_t)((Rpad + 63) / 64) * C;
+    const long long n = (long long)R * C;
+    n_part = (int)((n + 4095) / 4096 < kAmaxParts ? (n + 4095) / 4096 : kAmaxParts);
+    hipLaunchKernelGGL(amax_partial_kernel, dim3(n_part), dim3(256), 0, s, src, n, amax_part);
+  }
+  if (dr && colsum) hipLaunchKernelGGL((transpose_pairs_kernel<false, true, true>), grid, block, 0, s, src, dt, dr, R, C, Rpad, partial, amax_part, n_part, scale_out);
+  else if (dr) hipLaunchKernelGGL((transpose_pairs_kernel<false, true, false>), grid, block, 0, s, src, dt, dr, R, C, Rpad, nullptr, amax_part, n_part, scale_out);
+  else if (colsum) hipLaunchKernelGGL((transpose_pairs_kernel<false, false, true>), grid, block, 0, s, src, dt, dr, R, C, Rpad, partial, amax_part, n_part, scale_out);
+  else hipLaunchKernelGGL((transpose_pairs_kernel<false, false, false>), grid, block, 0, s, src, dt, dr, R, C, Rpad, nullptr, amax_part, n_part, scale_out);
   TT_CHECK_LAUNCH("split_pairs_dual");
   if (colsum) return launch_colsum_fold(partial, colsum, (Rpad + 63) / 64, C, s);
   return TT_OK;
@@ -925,16 +982,18 @@ extern "C" int tt_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int 
              "transpose_pairs: bad arguments (C and Rpad must be multiples of 32)");
   TT_REQUIRE((reinterpret_cast<uintptr_t>(dst_t_pairs) & 7u) == 0, "transpose_pairs: the output must be 8-byte aligned");
   hipLaunchKernelGGL((transpose_pairs_kernel<true, false, false>), dim3((Rpad + 63) / 64, (C + 63) / 64), dim3(256), 0, as_stream(stream), src_pairs,
-                     static_cast<_Float16*>(dst_t_pairs), static_cast<_Float16*>(nullptr), R, C, Rpad, static_cast<float*>(nullptr));
+                     static_cast<_Float16*>(dst_t_pairs), static_cast<_Float16*>(nullptr), R, C, Rpad, static_cast<float*>(nullptr),
+                     static_cast<const float*>(nullptr), 0, static_cast<float*>(nullptr));
   TT_CHECK_LAUNCH("transpose_pairs");
   return TT_OK;
 }
 
-// dx[M,K] = dy[M,N] @ w[N,K] (* gelu'(gelu_pre)): dy in pairs [M][2 N], the weight TRANSPOSED in pairs wT [K][2 N]
-extern "C" int tt_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, int M, int N, int K,
-                                        tt_stream_t stream) {
+// dx[M,K] = dy[M,N] @ w[N,K] (* gelu'(gelu_pre)): dy in pairs [M][2 N], the weight TRANSPOSED in pairs wT [K][2 N].
+// dy_scale (device scalar or null): the pairs hold dy * S (tt_split_pairs_dual's scale_out) - the product is divided by S.
+extern "C" int tt_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, const float* dy_scale, int M,
+                                        int N, int K, tt_stream_t stream) {
   TT_REQUIRE(dx, "linear_bwd_data_pairs: null output");
-  return linear_pairs_impl(dy_pairs, wT_pairs, nullptr, nullptr, dx, nullptr, nullptr, M, K, N, 0, gelu_pre, 1, 0, stream);
+  return linear_pairs_impl(dy_pairs, wT_pairs, nullptr, nullptr, dx, nullptr, nullptr, M, K, N, 0, gelu_pre, 1, 0, stream, dy_scale);
 }
 
 // dw[N,K] = dy[M,N]^T @ x[M,K]: both operands transposed in pairs, dyT [N][2 Mpad], xT [K][2 Mpad] (zero beyond M).  Split-K over Mpad
@@ -951,14 +1010,15 @@ extern "C" size_t tt_linear_bwd_weight_pairs_workspace_bytes(int N, int K, int M
   const int s = wgrad_pairs_splits(N, K, Mpad);
   return s > 1 ? (size_t)s * N * K * sizeof(float) : 16;
 }
-extern "C" int tt_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, float* dw, int N, int K, int Mpad, void* workspace,
-                                          size_t workspace_bytes, tt_stream_t stream) {
+extern "C" int tt_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, float* dw, const float* dy_scale, int N, int K, int Mpad,
+                                          void* workspace, size_t workspace_bytes, tt_stream_t stream) {
   TT_REQUIRE(dw && workspace, "linear_bwd_weight_pairs: null pointer");
   TT_REQUIRE(workspace_bytes >= tt_linear_bwd_weight_pairs_workspace_bytes(N, K, Mpad), "linear_bwd_weight_pairs: workspace too small");
   const int s = wgrad_pairs_splits(N, K, Mpad);
-  if (s == 1) return linear_pairs_impl(dyT_pairs, xT_pairs, nullptr, nullptr, dw, nullptr, nullptr, N, K, Mpad, 0, nullptr, 1, 0, stream);
+  if (s == 1) return linear_pairs_impl(dyT_pairs, xT_pairs, nullptr, nullptr, dw, nullptr, nullptr, N, K, Mpad, 0, nullptr, 1, 0, stream, dy_scale);
   float* part = static_cast<float*>(workspace);
-  const int rc = linear_pairs_impl(dyT_pairs, xT_pairs, nullptr, nullptr, part, nullptr, nullptr, N, K, Mpad, 0, nullptr, s, (long long)N * K, stream);
+  const int rc = linear_pairs_impl(dyT_pairs, xT_pairs, nullptr, nullptr, part, nullptr, nullptr, N, K, Mpad, 0, nullptr, s, (long long)N * K, stream,
+                                   dy_scale);
   if (rc != TT_OK) return rc;
   return launch_splitk_reduce(part, dw, (long long)N * K, s, (long long)N * K, as_stream(stream));
 }

@@ -7,6 +7,7 @@ the library is unavailable - there is no eager fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -87,6 +88,7 @@ def pairs() -> bool:
 # pairs against 3.11 ms on the exact-f32 MFMA kernels - so small launches keep the f32 kernels.  Tests set it to 0 to drive the pair
 # kernels with tiny models.
 PAIRS_MIN_ROWS = 1536
+GRAD_SCALE = os.environ.get("TT_NO_GRAD_SCALE") != "1"   # gradients are scaled by a power of two before their pair split (A/B aid: off)
 TN_WGRAD = True   # weight gradients of the "f16x3" mode from row pairs (gemm_pairs_tn.hip); False: the transposed-operand route (A/B, tests)
 
 
@@ -949,9 +951,12 @@ def attention_fwd_pairs(qkv_pairs, num_heads: int, out_pairs: bool = True, out_f
     return op, of, lse
 
 
-def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad: Optional[int] = None, colsum_out=None, want_t: bool = True):
+def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad: Optional[int] = None, colsum_out=None, want_t: bool = True,
+                     scaled: bool = False):
     """fp32 [R, C] -> (transposed pairs [C, 2 Rpad] or None, row-major pairs [R, 2 C] or None, column sums [C] or None) in ONE pass
-    (tt_split_pairs_dual): what the backward of an nn.Linear needs of its dy."""
+    (tt_split_pairs_dual): what the backward of an nn.Linear needs of its dy.  ``scaled`` (a GRADIENT, whose whole magnitude may sit
+    below fp16's normal range): the pairs hold x * S with S the power of two that brings max |x| into [2^13, 2^14); a fourth value is
+    returned, the DEVICE scalar S, which the products take as ``dy_scale`` and divide by (no host round trip)."""
     lib = _lib.load()
     _chk(x, "x")
     R, Cc = x.shape
@@ -960,10 +965,12 @@ def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad:
     t = torch.empty((Cc, 2 * rpad), dtype=f16, device=x.device) if want_t else None
     row = torch.empty((R, 2 * Cc), dtype=f16, device=x.device) if want_row else None
     sums = (_chk(colsum_out, "colsum_out") if colsum_out is not None else torch.empty((Cc,), dtype=f32, device=x.device)) if want_colsum else None
-    nb = lib.tt_split_pairs_dual_workspace_bytes(R, Cc, rpad) if want_colsum else 0
-    ws = _ws(nb, x.device) if want_colsum else None
-    _lib.check(lib.tt_split_pairs_dual(_p(x), _p(t), _p(row), _p(sums), R, Cc, rpad, _p(ws), nb, _stream()), "tt_split_pairs_dual")
-    return t, row, sums
+    need_ws = want_colsum or scaled
+    nb = lib.tt_split_pairs_dual_workspace_bytes(R, Cc, rpad) if need_ws else 0
+    ws = _ws(nb, x.device) if need_ws else None
+    scale = torch.empty((1,), dtype=f32, device=x.device) if scaled else None
+    _lib.check(lib.tt_split_pairs_dual(_p(x), _p(t), _p(row), _p(sums), _p(scale), R, Cc, rpad, _p(ws), nb, _stream()), "tt_split_pairs_dual")
+    return (t, row, sums, scale) if scaled else (t, row, sums)
 
 
 def split_pairs_dual_multi(items) -> None:
@@ -1010,8 +1017,9 @@ def bwd_weight_pairs_tn_ok(M: int, N: int, K: int) -> bool:
     return bool(TN_WGRAD) and bool(_lib.load().tt_linear_bwd_weight_pairs_tn_ok(N, K, M))
 
 
-def linear_bwd_weight_pairs_tn(dy_pairs, x_pairs, dw_out=None):
-    """dw [N,K] = dy^T @ x from ROW pairs dy [M, 2 N], x [M, 2 K] (gemm_pairs_tn.hip: no transposed copies)."""
+def linear_bwd_weight_pairs_tn(dy_pairs, x_pairs, dw_out=None, dy_scale=None):
+    """dw [N,K] = dy^T @ x from ROW pairs dy [M, 2 N], x [M, 2 K] (gemm_pairs_tn.hip: no transposed copies); ``dy_scale``: the device
+    scalar a scaled split of dy returned."""
     lib = _lib.load()
     _chk(dy_pairs, "dy_pairs", f16); _chk(x_pairs, "x_pairs", f16)
     M, N, K = dy_pairs.shape[0], dy_pairs.shape[1] // 2, x_pairs.shape[1] // 2
@@ -1020,7 +1028,7 @@ def linear_bwd_weight_pairs_tn(dy_pairs, x_pairs, dw_out=None):
     nb = lib.tt_linear_bwd_weight_pairs_tn_workspace_bytes(N, K, M)
     ws = _ws(nb, dy_pairs.device)
     e0 = _prof_begin()
-    _lib.check(lib.tt_linear_bwd_weight_pairs_tn(_p(dy_pairs), _p(x_pairs), _p(dw), N, K, M, _p(ws), nb, _stream()), "tt_linear_bwd_weight_pairs_tn")
+    _lib.check(lib.tt_linear_bwd_weight_pairs_tn(_p(dy_pairs), _p(x_pairs), _p(dw), _p(dy_scale), N, K, M, _p(ws), nb, _stream()), "tt_linear_bwd_weight_pairs_tn")
     _prof_end(e0, "PAIRS_TN", N, K, M)
     return dw
 
@@ -1037,20 +1045,22 @@ def linear_bwd_pairs(dy, wT_pairs, xT_pairs=None, gelu_pre=None, need_bias: bool
     if x_pairs is not None and bwd_weight_pairs_tn_ok(M, N, K):
         _chk(x_pairs, "x_pairs", f16)
         assert wT_pairs.shape == (K, 2 * N) and x_pairs.shape == (M, 2 * K), (dy.shape, wT_pairs.shape, x_pairs.shape)
-        _, dy_row, db = split_pairs_dual(dy, want_row=True, want_colsum=need_bias, colsum_out=db_out, want_t=False)
-        dw = linear_bwd_weight_pairs_tn(dy_row, x_pairs, dw_out)
+        r4 = split_pairs_dual(dy, want_row=True, want_colsum=need_bias, colsum_out=db_out, want_t=False, scaled=GRAD_SCALE)
+        dy_row, db, dy_scale = r4[1], r4[2], (r4[3] if GRAD_SCALE else None)
+        dw = linear_bwd_weight_pairs_tn(dy_row, x_pairs, dw_out, dy_scale)
     else:
         if xT_pairs is None:
             xT_pairs = transpose_pairs(x_pairs)
         _chk(xT_pairs, "xT_pairs", f16)
         Mpad = xT_pairs.shape[1] // 2
         assert wT_pairs.shape == (K, 2 * N) and xT_pairs.shape[0] == K and Mpad >= M, (dy.shape, wT_pairs.shape, xT_pairs.shape)
-        dyT, dy_row, db = split_pairs_dual(dy, want_row=need_dx, want_colsum=need_bias, rpad=Mpad, colsum_out=db_out)
+        r4 = split_pairs_dual(dy, want_row=need_dx, want_colsum=need_bias, rpad=Mpad, colsum_out=db_out, scaled=GRAD_SCALE)
+        dyT, dy_row, db, dy_scale = r4[0], r4[1], r4[2], (r4[3] if GRAD_SCALE else None)
         dw = _chk(dw_out, "dw_out") if dw_out is not None else torch.empty((N, K), dtype=f32, device=dy.device)
         nb = lib.tt_linear_bwd_weight_pairs_workspace_bytes(N, K, Mpad)
         ws = _ws(nb, dy.device)
         e0 = _prof_begin()
-        _lib.check(lib.tt_linear_bwd_weight_pairs(_p(dyT), _p(xT_pairs), _p(dw), N, K, Mpad, _p(ws), nb, _stream()), "tt_linear_bwd_weight_pairs")
+        _lib.check(lib.tt_linear_bwd_weight_pairs(_p(dyT), _p(xT_pairs), _p(dw), _p(dy_scale), N, K, Mpad, _p(ws), nb, _stream()), "tt_linear_bwd_weight_pairs")
         _prof_end(e0, "PAIRS", N, K, M)
     dx = None
     if need_dx:
@@ -1059,7 +1069,7 @@ def linear_bwd_pairs(dy, wT_pairs, xT_pairs=None, gelu_pre=None, need_bias: bool
         # (label: the persistent kernel takes a data-gradient product under the shape rules of its fp32 (+ operand) epilogues)
         p8 = PROFILE is not None and lib.tt_linear_fwd_pairs_route(M, K, N, 0, 0, int(gelu_pre is not None), 1, 0, 0) == 8
         e0 = _prof_begin()
-        _lib.check(lib.tt_linear_bwd_data_pairs(_p(dy_row), _p(wT_pairs), _p(gelu_pre), _p(dx), M, N, K, _stream()), "tt_linear_bwd_data_pairs")
+        _lib.check(lib.tt_linear_bwd_data_pairs(_p(dy_row), _p(wT_pairs), _p(gelu_pre), _p(dx), _p(dy_scale), M, N, K, _stream()), "tt_linear_bwd_data_pairs")
         _prof_end(e0, "PAIRS8" if p8 else "PAIRS", M, K, N)
     return dx, dw, db
 

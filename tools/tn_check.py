@@ -23,7 +23,7 @@ for M, N, K in [(6304, 1152, 384), (6304, 384, 384), (6304, 1536, 384), (6304, 3
         Mpad = xT.shape[1] // 2
         dw = torch.empty((N, K), device="cuda")
         nb = lib.tt_linear_bwd_weight_pairs_workspace_bytes(N, K, Mpad); ws = ops._ws(nb, dy.device)
-        ops._lib.check(lib.tt_linear_bwd_weight_pairs(ops._p(dyT), ops._p(xT), ops._p(dw), N, K, Mpad, ops._p(ws), nb, ops._stream()), "wgrad")
+        ops._lib.check(lib.tt_linear_bwd_weight_pairs(ops._p(dyT), ops._p(xT), ops._p(dw), None, N, K, Mpad, ops._p(ws), nb, ops._stream()), "wgrad")
         return dw, db
     dw, db = route_tn()
     dw2, db2 = route_t()
