@@ -283,6 +283,12 @@ int tt_linear_bwd_weight_pairs_tn_ok(int N, int K, int M);
 size_t tt_linear_bwd_weight_pairs_tn_workspace_bytes(int N, int K, int M);
 int tt_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, float* dw, const float* dy_scale, int N, int K, int M, void* workspace,
                                   size_t workspace_bytes, tt_stream_t stream);
+/*   prepare_tokens (dino_vision_transformer.py:166-171,236-247) on pair operands: tt_patch_embed_fwd with the conv weight in pairs
+ *   [D][2 C P P] (tt_split_pairs of patch_w viewed [D, C P P]); the patches are split into pairs on their way into an im2col buffer
+ *   (workspace), ONE pair GEMM over all F (n + 1) rows leaves the tokens.  P % 4 == 0, W % 4 == 0, C P P % 32 == 0, D % 64 == 0. */
+size_t tt_patch_embed_pairs_workspace_bytes(int F, int C, int H, int W, int P);
+int tt_patch_embed_fwd_pairs(const float* img, const int32_t* frame_map, const void* w_pairs, const float* bias, const float* cls, const float* pos,
+                             float* tokens, int F, int C, int H, int W, int P, int D, void* workspace, size_t workspace_bytes, tt_stream_t stream);
 /*   The backward products of the same nn.Linear sites on bf16-plane operands (autograd of dino_vision_transformer.py:94-103,
  *   115-130; the bf16 path only - the fp32 modes keep the f32-MFMA backward kernels):
  *   tt_transpose_planes               fp32 [R][C] -> bf16 [C][Rpad], transposed, columns R..Rpad-1 zero (reduction index contiguous)
@@ -478,8 +484,10 @@ typedef struct {
                                                    (tt_linear_fwd_planes; 1 = BASELINE C4's bf16 path, 3 = fp32-accurate), D % 64 == 0;
                                                    2: fp16 PAIRS (tt_linear_fwd_pairs, the fp32-accurate "f16x3" mode; *_wp are
                                                    tt_split_pairs of the weights), D % 64 == 0 and hidden % 64 == 0 */
-  const void* patch_wp;                         /* planes == 1, optional: patch_w as one bf16 plane [D, C P P] - prepare_tokens then runs
-                                                   tt_patch_embed_fwd_planes where its shape rules hold (ABI 4) */
+  const void* patch_wp;                         /* optional.  planes == 1: patch_w as one bf16 plane [D, C P P] - prepare_tokens then runs
+                                                   tt_patch_embed_fwd_planes where its shape rules hold (ABI 4); planes == 2: patch_w in
+                                                   pairs [D][2 C P P] - tt_patch_embed_fwd_pairs where ITS rules hold and C P P <= 3 D
+                                                   (the rows then fit the scratch) (ABI 6) */
 } tt_vit_params;
 typedef struct {
   const float* w;   /* [out_features, in_features] */

@@ -1113,6 +1113,34 @@ int tt_cpu_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs,
   return 0;
 }
 
+/* prepare_tokens on pair operands (tt_patch_embed_fwd_pairs): patches and weight as (hi, lo) pairs, three products per term */
+size_t tt_cpu_patch_embed_pairs_workspace_bytes(int F, int C, int H, int W, int P) { return 0; }
+int tt_cpu_patch_embed_fwd_pairs(const float* img, const int32_t* frame_map, const void* w_pairs, const float* bias, const float* cls,
+                                 const float* pos, float* tokens, int F, int C, int H, int W, int P, int D, void* workspace,
+                                 size_t workspace_bytes, tt_stream_t stream) {
+  (void)stream; (void)workspace; (void)workspace_bytes;
+  const uint16_t* wp = (const uint16_t*)w_pairs;
+  const int gh = H / P, gw = W / P, n = gh * gw, K = C * P * P;
+  uint16_t* patch = (uint16_t*)malloc((size_t)K * 4);
+  if (!patch) return -3;
+  for (int f = 0; f < F; ++f) {
+    const float* src = img + (size_t)(frame_map ? frame_map[f] : f) * C * H * W;
+    float* tok = tokens + (size_t)f * (n + 1) * D;
+    for (int d = 0; d < D; ++d) tok[d] = (cls[d] + pos[d] - bias[d]) + bias[d];   /* the zero row meets the bias in the GEMM's epilogue */
+    for (int py = 0; py < gh; ++py)
+      for (int px = 0; px < gw; ++px) {
+        for (int c = 0; c < C; ++c)
+          for (int y = 0; y < P; ++y)
+            for (int x = 0; x < P; ++x) pair_put(patch, (c * P + y) * P + x, src[((size_t)c * H + py * P + y) * W + px * P + x]);
+        for (int d = 0; d < D; ++d)
+          tok[(size_t)(1 + py * gw + px) * D + d] =
+              ((float)pair_dot(patch, wp + (size_t)d * 2 * K, K) + bias[d]) + pos[(size_t)(1 + py * gw + px) * D + d];
+      }
+  }
+  free(patch);
+  return 0;
+}
+
 size_t tt_cpu_vit_forward_workspace_bytes(int F, int N, int D, int hidden, int planes) { return 0; }
 size_t tt_cpu_mlp_head_forward_workspace_bytes(int M, const tt_cpu_linear_params* layers, int n_layers) { return 0; }
 size_t tt_cpu_scores_sinkhorn_workspace_bytes(int B, int queue_rows, int K, int dim) { return 0; }
@@ -1129,6 +1157,8 @@ int tt_cpu_vit_forward(const tt_cpu_vit_params* p, const float* img, const int32
     /* (C P P <= 9 D: the HIP side keeps the im2col rows in the attention phase of its scratch) */
     if (P == 1 && p->patch_wp && p->patch % 4 == 0 && W % 4 == 0 && (C * p->patch * p->patch) % 64 == 0 && D % 64 == 0 && C * p->patch * p->patch <= 9 * D)
       tt_cpu_patch_embed_fwd_planes(img, frame_map, p->patch_wp, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, NULL, 0, stream);
+    else if (P == 2 && p->patch_wp && p->patch % 4 == 0 && W % 4 == 0 && (C * p->patch * p->patch) % 32 == 0 && D % 64 == 0 && C * p->patch * p->patch <= 3 * D)
+      tt_cpu_patch_embed_fwd_pairs(img, frame_map, p->patch_wp, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, NULL, 0, stream);
     else
       tt_cpu_patch_embed_fwd(img, frame_map, p->patch_w, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, stream);
   }

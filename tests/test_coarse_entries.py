@@ -88,6 +88,11 @@ def _run_vit(lib, prefix, mem, case, planes, drop_cls=False, want_qkv=False, wan
     vp.patch_w, vp.patch_b, vp.cls, vp.pos = mem(w["patch_w"]), mem(w["patch_b"]), mem(w["cls"]), mem(w["pos"])
     vp.blocks, vp.n_blocks, vp.norm_w, vp.norm_b = arr, nb, mem(w["norm_w"]), mem(w["norm_b"])
     vp.dim, vp.heads, vp.hidden, vp.patch, vp.planes = D, case["heads"], case["hidden"], case["patch"], planes
+    if planes == 2 and w["patch_w"].size // D % 32 == 0:   # prepare_tokens on pairs too (where tt_vit_forward's shape rules hold; else it falls back)
+        pwp = np.empty((D, 2 * (w["patch_w"].size // D)), np.uint16)
+        dst = mem(pwp)
+        assert split_pairs(vp.patch_w, dst, w["patch_w"].size, mem.stream) == 0   # (the copy mem() made above: a second mem() of it would free that one)
+        vp.patch_wp = dst
     tokens = np.empty((Fr, N, D), np.float32) if from_tokens is None else from_tokens.copy()
     normed = np.empty((Fr * (N - 1), D) if drop_cls else (Fr, N, D), np.float32)
     qkv = np.empty((Fr, N, 3 * D), np.float32) if want_qkv else None
@@ -251,6 +256,10 @@ def test_hip_coarse_entries_equal_their_twins(twin):
     case = _vit_case()
     a = _run_vit(lib, "tt_", _Mem("cuda"), case, 2)   # fp16 pairs without the last block's qkv: the pair attention kernel's route
     b = _run_vit(twin, "tt_cpu_", _Mem(), case, 2)
+    assert _re(a[0], b[0]) < 2e-5 and _re(a[1], b[1]) < 2e-5
+    case8 = _vit_case(patch=8)                         # C P P = 192 <= 3 D: prepare_tokens on pair operands as well (tt_patch_embed_fwd_pairs)
+    a = _run_vit(lib, "tt_", _Mem("cuda"), case8, 2)
+    b = _run_vit(twin, "tt_cpu_", _Mem(), case8, 2)
     assert _re(a[0], b[0]) < 2e-5 and _re(a[1], b[1]) < 2e-5
     for planes, tol in ((0, 2e-5), (3, 2e-5), (2, 2e-5), (1, 3e-2)):
         a = _run_vit(lib, "tt_", _Mem("cuda"), case, planes, want_qkv=planes != 1, want_probs=planes == 0)

@@ -438,6 +438,14 @@ def _round2b_cases(side):
     wsp = np.empty(nbp, np.uint8)
     side.run("patch_embed_fwd_planes", img, fmap, wpl, b, cls, pos, tok, Fp, C, Hh, Ww, P, Dm, wsp, nbp, st, outs=(tok,))
     R["patch_bf16"] = (img, fmap, w, wpl.copy(), b, cls, pos, tok.copy())
+    # ... and on fp16-pair operands
+    wpr = np.empty((Dm, 2 * C * P * P), np.uint16)
+    side.run("split_pairs", w, wpr, Dm * C * P * P, st, outs=(wpr,))
+    tokp = np.empty((Fp, 7, Dm), np.float32)
+    nbq = max(int(getattr(side.lib, side.prefix + "patch_embed_pairs_workspace_bytes")(Fp, C, Hh, Ww, P)), 16)
+    wsq = np.empty(nbq, np.uint8)
+    side.run("patch_embed_fwd_pairs", img, fmap, wpr, b, cls, pos, tokp, Fp, C, Hh, Ww, P, Dm, wsq, nbq, st, outs=(tokp,))
+    R["patch_pairs"] = (tok.copy(), tokp.copy())
     return R
 
 
@@ -503,6 +511,9 @@ def test_round2b_twins_against_torch(twin):
     assert _re(tok, ref.numpy()) < 1e-6
     full = F.conv2d(torch.from_numpy(img[fmap]).double(), torch.from_numpy(w).double().view(64, 3, 16, 16), torch.from_numpy(b).double(), stride=16)
     assert _re(tok[:, 1:], (full.flatten(2).transpose(1, 2) + torch.from_numpy(pos).double()[1:]).numpy()) < 1e-2     # bf16 operands
+    tokp = R["patch_pairs"][1]                                                                                          # pair operands: fp32-class
+    assert _re(tokp[:, 1:], (full.flatten(2).transpose(1, 2) + torch.from_numpy(pos).double()[1:]).numpy()) < 1e-6
+    assert np.abs(tokp[:, 0] - (cls + pos[0])).max() < 1e-6
 
 
 @pytest.mark.gpu
@@ -524,6 +535,7 @@ def test_hip_library_equals_its_cpu_twin_round2b(twin):
             assert _re(A["plane_gemm"][4][P_][i], B["plane_gemm"][4][P_][i]) < 2e-5, (P_, i)
     assert _re(_bf(A["att_bf16"][1]), _bf(B["att_bf16"][1])) < 1.5e-2
     assert np.array_equal(A["patch_bf16"][3], B["patch_bf16"][3]) and _re(A["patch_bf16"][7], B["patch_bf16"][7]) < 2e-5
+    assert _re(A["patch_pairs"][1], B["patch_pairs"][1]) < 2e-6
 
 
 # ---- third batch: generic GEMM, position-table resampling, evaluator resampling, k-means sums, plane backward products, the

@@ -301,3 +301,26 @@ def test_ksplit_partial_exchange_soak():
     finally:
         ops.set_tuning_knob("TT_Q8_KSPLIT", 1)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("Fr,D,patch,route", [(3, 384, 16, 0), (128, 384, 16, 8), (64, 768, 16, 8), (5, 384, 8, 0)])
+def test_patch_embed_on_pairs(Fr, D, patch, route):
+    """tt_patch_embed_fwd_pairs (prepare_tokens of the "f16x3" mode, dino_vision_transformer.py:166-171,236-247) against the fp64 conv: at
+    the f32 bound and not worse than the f32-MFMA patch embedding; with a frame map; the large cases run on the persistent pair kernel."""
+    from timetuning_amd import _lib, hip_ops as ops
+
+    Hh = Ww = 224 if patch == 16 else 64
+    n = (Hh // patch) * (Ww // patch)
+    K = 3 * patch * patch
+    img, w, b = rnd(f"pep.img{Fr}.{Hh}", Fr + 1, 3, Hh, Ww), rnd(f"pep.w{D}.{K}", D, K, scale=0.05), rnd(f"pep.b{D}", D)
+    cls, pos = rnd(f"pep.cls{D}", D), rnd(f"pep.pos{n}.{D}", n + 1, D)
+    fmap = torch.arange(Fr, dtype=torch.int32).flip(0) + 1
+    assert _lib.load().tt_linear_fwd_pairs_route(Fr * (n + 1), D, K, 0, 1, 1, 1, 0, 0) == route
+    tok = ops.patch_embed_fwd_pairs(img.cuda(), ops.split_pairs(w.cuda()), b.cuda(), cls.cuda(), pos.cuda(), patch, fmap.cuda()).cpu()
+    src = img[fmap.long()]
+    conv = F.conv2d(src.double(), w.double().view(D, 3, patch, patch), b.double(), stride=patch)
+    ref = torch.cat([cls.double().expand(Fr, 1, D), conv.flatten(2).transpose(1, 2)], 1) + pos.double()
+    assert rel_err(tok, ref) < TOL_F32 and rel_l2(tok, ref) < TOL_L2
+    assert (tok[:, 0] - (cls + pos[0])).abs().max().item() < 1e-6          # the class row: cls + pos[0] (- bias + bias in fp32)
+    tok32 = ops.patch_embed_fwd(img.cuda(), w.cuda(), b.cuda(), cls.cuda(), pos.cuda(), patch, fmap.cuda()).cpu()
+    assert rel_l2(tok, ref) <= rel_l2(tok32, ref)

@@ -86,6 +86,8 @@ SIGNATURES = {
     "tt_linear_bwd_weight_pairs_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_linear_bwd_weight_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_split_pairs_dual_multi": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp]),
+    "tt_patch_embed_pairs_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "tt_patch_embed_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_linear_bwd_weight_pairs_tn_ok": (c_i, [c_i, c_i, c_i]),
     "tt_linear_bwd_weight_pairs_tn_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_linear_bwd_weight_pairs_tn": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),

@@ -670,6 +670,42 @@ __global__ __launch_bounds__(256) void patch_rows_planes_kernel(const float* __r
   for (int i = threadIdx.x; i < D / 4; i += 256) trow[i] = prow[i];
 }
 
+// The same rows for the fp16-PAIR path ("f16x3"): a [F (n + 1)][2 C P P] fp16 in pairs (groups of 32 k as [hi x 32][lo x 32]), the class
+// token's row zero; tokens prefilled as above.  ONE pair GEMM over all rows (residual = y = tokens) then leaves prepare_tokens' result.
+__global__ __launch_bounds__(256) void patch_rows_pairs_kernel(const float* __restrict__ img, const int* __restrict__ frame_map,
+                                                                 const float* __restrict__ bias, const float* __restrict__ cls,
+                                                                 const float* __restrict__ pos, _Float16* __restrict__ a,
+                                                                 float* __restrict__ tokens, int C, int H, int W, int P, int D, int gw, int n) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const int m = blockIdx.x, f = m / (n + 1), t = m - f * (n + 1);
+  const int K = C * P * P;
+  _Float16* arow = a + (long long)m * 2 * K;
+  float4* trow = reinterpret_cast<float4*>(tokens + (long long)m * D);
+  const float4* prow = reinterpret_cast<const float4*>(pos + (long long)t * D);
+  if (t == 0) {
+    for (int i = threadIdx.x; i < K / 2; i += 256) reinterpret_cast<f16x4*>(arow)[i] = (f16x4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    for (int i = threadIdx.x; i < D / 4; i += 256) {
+      const float4 c = reinterpret_cast<const float4*>(cls)[i], b = reinterpret_cast<const float4*>(bias)[i], q = prow[i];
+      trow[i] = make_float4(c.x + q.x - b.x, c.y + q.y - b.y, c.z + q.z - b.z, c.w + q.w - b.w);
+    }
+    return;
+  }
+  const int src = frame_map ? frame_map[f] : f;
+  const int gy = (t - 1) / gw, gx = (t - 1) - gy * gw;
+  const float* base = img + ((long long)src * C * H + gy * P) * W + gx * P;
+  const int P4 = P / 4;
+  for (int i = threadIdx.x; i < K / 4; i += 256) {
+    const int x4 = i % P4, cy = i / P4, y = cy % P, c = cy / P;
+    const float4 v = *reinterpret_cast<const float4*>(base + ((long long)c * H + y) * W + 4 * x4);
+    _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
+    split_pair(v.x, h0, l0); split_pair(v.y, h1, l1); split_pair(v.z, h2, l2); split_pair(v.w, h3, l3);
+    _Float16* p = arow + pair_index(4 * i);   // k = 4 i .. 4 i + 3 lie in one group of 32
+    *reinterpret_cast<f16x4*>(p) = (f16x4){h0, h1, h2, h3};
+    *reinterpret_cast<f16x4*>(p + 32) = (f16x4){l0, l1, l2, l3};
+  }
+  for (int i = threadIdx.x; i < D / 4; i += 256) trow[i] = prow[i];
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -1044,4 +1080,28 @@ extern "C" int tt_patch_embed_fwd_planes(const float* img, const int32_t* frame_
                      static_cast<__bf16*>(workspace), tokens, C, H, W, P, D, W / P, n);
   TT_CHECK_LAUNCH("patch_embed_planes.rows");
   return tt_linear_fwd_planes(workspace, M * K, w_planes, (long long)D * K, 1, bias, tokens, tokens, nullptr, nullptr, 0, 0, (int)M, D, K, 0, stream);
+}
+
+// prepare_tokens on fp16-pair operands (the "f16x3" mode): w_pairs [D][2 C P P]; workspace: the im2col rows in pairs, F (n + 1) x C P P x 4 bytes
+extern "C" size_t tt_patch_embed_pairs_workspace_bytes(int F, int C, int H, int W, int P) {
+  if (F <= 0 || C <= 0 || P <= 0 || H < P || W < P) return 0;
+  return (size_t)F * (1 + (size_t)(H / P) * (W / P)) * C * P * P * 4;
+}
+
+extern "C" int tt_patch_embed_fwd_pairs(const float* img, const int32_t* frame_map, const void* w_pairs, const float* bias, const float* cls,
+                                        const float* pos, float* tokens, int F, int C, int H, int W, int P, int D, void* workspace,
+                                        size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(img && w_pairs && bias && cls && pos && tokens && workspace, "patch_embed_pairs: null pointer");
+  TT_REQUIRE(F > 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0, "patch_embed_pairs: H, W must be multiples of the patch size");
+  const int n = (H / P) * (W / P), K = C * P * P;
+  const long long M = (long long)F * (n + 1);
+  TT_REQUIRE(P % 4 == 0 && W % 4 == 0 && K % 32 == 0 && D % 64 == 0, "patch_embed_pairs: need P %% 4 == 0, W %% 4 == 0, C P P %% 32 == 0, D %% 64 == 0");
+  TT_REQUIRE(aligned16(img) && aligned16(bias) && aligned16(cls) && aligned16(pos) && aligned16(tokens) && aligned16(workspace) && aligned16(w_pairs),
+             "patch_embed_pairs: buffers must be 16-byte aligned");
+  TT_REQUIRE(M * (long long)(K > D ? K : D) < (1ll << 31), "patch_embed_pairs: F (n + 1) max(C P P, D) exceeds the int range");
+  TT_REQUIRE(workspace_bytes >= tt_patch_embed_pairs_workspace_bytes(F, C, H, W, P), "patch_embed_pairs: workspace too small");
+  hipLaunchKernelGGL(patch_rows_pairs_kernel, dim3((unsigned)M), dim3(256), 0, as_stream(stream), img, frame_map, bias, cls, pos,
+                     static_cast<_Float16*>(workspace), tokens, C, H, W, P, D, W / P, n);
+  TT_CHECK_LAUNCH("patch_embed_pairs.rows");
+  return linear_pairs_impl(workspace, w_pairs, bias, tokens, tokens, nullptr, nullptr, (int)M, D, K, 0, nullptr, 1, 0, stream);
 }

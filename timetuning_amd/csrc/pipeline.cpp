@@ -86,6 +86,11 @@ extern "C" int tt_vit_forward(const tt_vit_params* p, const float* img, const in
         Kp <= 9 * D) {
       TT_FORWARD(tt_patch_embed_fwd_planes(img, frame_map, p->patch_wp, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, s.big,
                                            a_bytes, stream));
+    } else if (P == 2 && p->patch_wp && workspace && workspace_bytes >= s.bytes && p->patch % 4 == 0 && W % 4 == 0 && Kp % 32 == 0 &&
+               D % 64 == 0 && Kp <= 3 * D) {
+      // the pair path likewise: the im2col rows in pairs (4 bytes per element) fit the qkv region of the scratch when C P P <= 3 D
+      TT_FORWARD(tt_patch_embed_fwd_pairs(img, frame_map, p->patch_wp, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, s.big,
+                                          tt_patch_embed_pairs_workspace_bytes(F, C, H, W, p->patch), stream));
     } else {
       TT_FORWARD(tt_patch_embed_fwd(img, frame_map, p->patch_w, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, stream));
     }

@@ -298,6 +298,29 @@ def patch_weight_planes(pe) -> torch.Tensor:
     return weight_planes(pe.weight, 1).view(1, pe.weight.shape[0], -1)
 
 
+PATCH_PAIRS = __import__("os").environ.get("TT_NO_PATCH_PAIRS") != "1"   # "f16x3": prepare_tokens on pair operands too (A/B aid: off)
+
+
+def patch_weight_pairs(pe) -> torch.Tensor:
+    """The conv weight of the patch embedding viewed [D, C P P] in fp16 pairs ("f16x3"), cached on the parameter like ``weight_planes``."""
+    w = pe.weight
+    hit = getattr(w, "_tt_planes", None)
+    tag = _param_tag(w, 2)
+    if hit is None or hit[0] != tag:
+        hit = (tag, ops.split_pairs(w.detach().view(w.shape[0], -1)))
+        w._tt_planes = hit
+    return hit[1]
+
+
+def patch_pairs_ok(vit, img: torch.Tensor) -> bool:
+    """True when prepare_tokens runs on pair operands: the "f16x3" mode (above its row threshold), the pair GEMM's shape rules, and
+    C P P <= 3 D (the im2col rows then fit tt_vit_forward's scratch) - tt_vit_forward's own rule, followed by the op-level path too."""
+    pe = vit.patch_embed.proj
+    D = pe.weight.shape[0]
+    K = pe.weight[0].numel()
+    return ops.pairs() and PATCH_PAIRS and K <= 3 * D and ops.patch_embed_pairs_ok(vit.patch_embed.patch_size, img.shape[-1], K, D)
+
+
 def patch_planes_ok(vit, img: torch.Tensor) -> bool:
     """True when prepare_tokens runs on bf16 operands: the "bf16" mode, the plane GEMM's shape rules, and C P P <= 9 D (the im2col
     rows then fit tt_vit_forward's scratch) - tt_vit_forward's own rule, followed by the op-level path too so that both give the
@@ -345,6 +368,10 @@ def vit_params(vit, first: int, last: int, pos: Optional[torch.Tensor] = None):
         wp = patch_weight_planes(pe)
         keep.append(wp)
         vp.patch_wp = wp.data_ptr()
+    elif planes == 2 and PATCH_PAIRS and pos is not None and pe.weight[0].numel() % 32 == 0:   # (... and those of patch_pairs_ok)
+        wp = patch_weight_pairs(pe)
+        keep.append(wp)
+        vp.patch_wp = wp.data_ptr()
     keep.append(pos)
     return vp, keep
 
@@ -374,6 +401,8 @@ def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None,
     if ops.fine_grained():
         if patch_planes_ok(vit, img):   # the same decision tt_vit_forward makes from VitParams.patch_wp
             x = ops.patch_embed_fwd_planes(img, patch_weight_planes(pe), pe.bias, vit.cls_token.view(D), pos, vit.patch_embed.patch_size, frame_map)
+        elif patch_pairs_ok(vit, img) and ops.plane_count_for((img.shape[0] if frame_map is None else frame_map.numel()) * pos.shape[0]) == 2:
+            x = ops.patch_embed_fwd_pairs(img, patch_weight_pairs(pe), pe.bias, vit.cls_token.view(D), pos, vit.patch_embed.patch_size, frame_map)
         else:
             x = ops.patch_embed_fwd(img, pe.weight.view(D, -1), pe.bias, vit.cls_token.view(D), pos, vit.patch_embed.patch_size, frame_map)
     else:

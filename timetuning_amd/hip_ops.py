@@ -283,6 +283,37 @@ def patch_embed_planes_ok(patch: int, W: int, K: int, D: int) -> bool:
     return patch % 4 == 0 and W % 4 == 0 and K % 64 == 0 and D % 64 == 0
 
 
+def patch_embed_pairs_ok(patch: int, W: int, K: int, D: int) -> bool:
+    """Shapes ``patch_embed_fwd_pairs`` takes (tt_patch_embed_fwd_pairs)."""
+    return patch % 4 == 0 and W % 4 == 0 and K % 32 == 0 and D % 64 == 0
+
+
+def patch_embed_fwd_pairs(img, w_pairs, bias, cls, pos, patch: int, frame_map=None):
+    """``patch_embed_fwd`` on fp16-pair operands (the "f16x3" mode): w_pairs [D, 2 C P P] = ``split_pairs`` of the conv weight viewed
+    [D, C P P]; the patches are split into pairs on their way into an im2col buffer, ONE pair GEMM over all token rows."""
+    lib = _lib.load()
+    _chk(img, "img"); _chk(w_pairs, "w_pairs", f16); _chk(bias, "bias"); _chk(cls, "cls"); _chk(pos, "pos")
+    Fs, Cc, H, W = img.shape
+    D = w_pairs.shape[0]
+    F = Fs if frame_map is None else frame_map.numel()
+    if frame_map is not None: _chk(frame_map, "frame_map", torch.int32)
+    n = (H // patch) * (W // patch)
+    K = Cc * patch * patch
+    assert w_pairs.shape == (D, 2 * K), (w_pairs.shape, D, K)
+    if pos.numel() != (n + 1) * D:
+        raise ValueError("pos_embed does not match the token grid: pass VisionTransformer.pos_table(H, W)")
+    tokens = torch.empty((F, n + 1, D), dtype=f32, device=img.device)
+    nb = lib.tt_patch_embed_pairs_workspace_bytes(F, Cc, H, W, patch)
+    ws = _ws(nb, img.device)
+    M = F * (n + 1)
+    p8 = PROFILE is not None and lib.tt_linear_fwd_pairs_route(M, D, K, 0, 1, 1, 1, 0, 0) == 8
+    e0 = _prof_begin()
+    _lib.check(lib.tt_patch_embed_fwd_pairs(_p(img), _p(frame_map), _p(w_pairs), _p(bias), _p(cls), _p(pos), _p(tokens), F, Cc, H, W, patch, D,
+                                            _p(ws), nb, _stream()), "tt_patch_embed_fwd_pairs")
+    _prof_end(e0, "PAIRS8" if p8 else "PAIRS", M, D, K)
+    return tokens
+
+
 def patch_embed_fwd_planes(img, w_planes, bias, cls, pos, patch: int, frame_map=None):
     """``patch_embed_fwd`` on bf16 operands (the "bf16" precision mode, BASELINE C4's path): w_planes [1, D, C*P*P] bf16 =
     ``split_planes(w, 1)``; the patches are rounded to bf16 on their way into an im2col buffer, fp32 accumulation, fp32 tokens."""
