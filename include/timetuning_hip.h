@@ -264,7 +264,9 @@ int tt_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, float* out_f3
  *   tt_linear_bwd_weight_pairs_tn the same product from ROW pairs - dy [M][2 N] (the data-gradient product's operand) and the layer's
  *                                 input x [M][2 K] as the forward kept it: no transposed copies (gemm_pairs_tn.hip: the fragments are
  *                                 gathered by transposing LDS reads).  N % 128 == 0, K % 128 == 0, any M (_ok says whether a shape is
- *                                 taken); partials of the split m range in the workspace, folded in a fixed order. */
+ *                                 taken); partials of the split m range in the workspace, folded in a fixed order.
+ *   dy_scale (all three products)  device scalar S or NULL: the dy pairs hold dy * S (tt_split_pairs_dual's scale_out) - the result is
+ *                                 divided by S in the epilogue (exact: S is a power of two). */
 size_t tt_split_pairs_dual_workspace_bytes(int R, int C, int Rpad);
 int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, float* scale_out, int R, int C, int Rpad,
                         void* workspace, size_t workspace_bytes, tt_stream_t stream);
