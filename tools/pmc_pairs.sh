@@ -25,3 +25,5 @@ run proj gemm 25216 384 384 res
 run fc1 gemm 25216 1536 384 gelu
 run fc2 gemm 25216 384 1536 res
 run attn attn 128 197 6
+run attn785 attn 64 785 6
+run tn tn 6304 1536 384

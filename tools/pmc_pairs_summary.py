@@ -57,6 +57,11 @@ for name in ("qkv", "proj", "fc1", "fc2"):
 json.dump(g, open(gemm_out, "w"), indent=1)
 a = {"note": note + "  attention_fwd_pairs_kernel, 128 frames x 197 tokens x 6 heads (one ViT-S/16 layer of the C2 step), pairs in / pairs out.",
      "attn_pairs": case("attn", "attention_fwd_pairs_kernel")}
+if os.path.isdir(os.path.join(root, "attn785")):
+    a["attn_pairs_kv_tiled_785_tokens(64 frames x 6 heads: a C5 layer)"] = case("attn785", "attention_fwd_pairs_flash_kernel")
+if os.path.isdir(os.path.join(root, "tn")):
+    g["wgrad_tn(6304 rows, dW 1536 x 384: gemm_pairs_tn_kernel, two 4-wave workgroups per CU - its busy fraction counts 8-wave rounds)"] = case("tn", "gemm_pairs_tn_kernel")
+    json.dump(g, open(gemm_out, "w"), indent=1)
 json.dump(a, open(attn_out, "w"), indent=1)
-for k, v in list(g.items())[1:] + [("attn_pairs", a["attn_pairs"])]:
+for k, v in list(g.items())[1:] + list(a.items())[1:]:
     print(k, v["derived"])
