@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
 // ceil(tiles / 8) blocks evenly (785 tokens: 25 tiles -> 7 + 6 + 6 + 6).
 __global__ __launch_bounds__(512) void attention_fwd_pairs_flash_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out_pairs,
                                                                         float* __restrict__ out_f32, float* __restrict__ lse, int N, int H, float scale,
-                                                                        int nb, int nqt) {
+                                                                        int nb, int nqt, int FH) {
   constexpr int SK = 128;                 // keys per stage
   constexpr int STAGE_B = 2 * SK * 256;   // K image + V image
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B + 8 * 4096];
@@ -257,7 +257,12 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_flash_kernel(const _F
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned char* Os = smem + 2 * STAGE_B + wave * 4096;
   const int r = lane & 31, h = lane >> 5;
-  const int blk = blockIdx.x % nb, fh = blockIdx.x / nb, f = fh / H, hd = fh - f * H;
+  // the query blocks of one (frame, head) stream the SAME K / V: they take consecutive dispatch slots of ONE XCD (common.hpp
+  // xcd_group_decode), so that K / V come out of that L2 after the first fetch (PMC before: L2 hit rate 0.09, 714 MB fetched per
+  // launch of 64 frames x 6 heads x 785 tokens for 231 MB of qkv)
+  int blk, fh;
+  if (!xcd_group_decode(blockIdx.x, nb, FH, fh, blk)) return;   // (padding workgroups of the last group of eight)
+  const int f = fh / H, hd = fh - f * H;
   const int Dm = H * 64;
   const long long RS = 6ll * Dm;
   const _Float16* base = qkv + (long long)f * N * RS + hd * 128;
@@ -488,7 +493,8 @@ extern "C" int tt_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, fl
   } else {
     const int nqt = (N + 31) / 32, nb = (nqt + 7) / 8;
     TT_REQUIRE((long long)F * H * nb < 0x7fffffffLL, "attention_fwd_pairs: grid too large");
-    hipLaunchKernelGGL(attention_fwd_pairs_flash_kernel, dim3(F * H * nb), dim3(512), 0, s, q, o, out_f32, lse, N, H, scale, nb, nqt);
+    hipLaunchKernelGGL(attention_fwd_pairs_flash_kernel, dim3(xcd_group_grid(F * H, nb)), dim3(512), 0, s, q, o, out_f32, lse, N, H, scale, nb, nqt,
+                       F * H);
   }
   TT_CHECK_LAUNCH("attention_fwd_pairs");
   return TT_OK;

@@ -7,7 +7,8 @@ def load(p):
     lib.tt_attention_fwd_pairs.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp]; return lib
 libs = [(os.path.basename(p), load(p)) for p in sys.argv[1:]]
 st = torch.cuda.current_stream().cuda_stream
-for F, N, H, allout in [(128, 197, 6, 0), (128, 197, 6, 1), (128, 197, 12, 0), (32, 197, 6, 1), (64, 256, 6, 0), (3, 50, 2, 1)]:
+for F, N, H, allout in [(128, 197, 6, 0), (128, 197, 6, 1), (128, 197, 12, 0), (32, 197, 6, 1), (64, 256, 6, 0), (3, 50, 2, 1),
+                        (64, 785, 6, 0), (16, 785, 6, 1), (128, 785, 6, 0), (5, 300, 3, 1), (64, 785, 12, 0)]:   # (> 256 tokens: the KV-tiled kernel)
     qkvp = (torch.randn(F, N, 6 * H * 64, device="cuda") * 0.5).half()
     out = torch.empty(F, N, 2 * H * 64, device="cuda", dtype=torch.float16)
     o32 = torch.empty(F, N, H * 64, device="cuda") if allout else None
