@@ -11,7 +11,9 @@
  *   - every pointer is a DEVICE pointer to fp32 (row-major, contiguous unless a leading
  *     dimension is passed) unless the parameter says otherwise;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls enqueue work
- *     and return, they never synchronise, allocate or free;
+ *     and return, they never synchronise, allocate or free (ABI 7: also true of the K-split
+ *     workspace of the persistent GEMMs, which is the caller's - tt_linear_ksplit_workspace_*);
+ *     every call can be captured into a hipGraph;
  *   - return value: 0 on success, a negative TT_E* code otherwise; tt_last_error() returns a
  *     thread-local message for the last failing call;
  *   - workspaces are caller-owned; the matching *_workspace_bytes() gives the size.
@@ -34,12 +36,25 @@ extern "C" {
 typedef void* tt_stream_t;
 
 const char* tt_last_error(void);
-int tt_abi_version(void);   /* 6 = this header (5: before the transpose-free weight gradient, the batched operand refresh and the distributed Sinkhorn steps; 4: before the fp16-pair entry points; 3: before tt_vit_params.patch_wp; 2: before the coarse entry points) */
+int tt_abi_version(void);   /* 7 = this header (6: before the caller-owned K-split workspace and the range flag; 5: before the transpose-free weight gradient, the batched operand refresh and the distributed Sinkhorn steps; 4: before the fp16-pair entry points; 3: before tt_vit_params.patch_wp; 2: before the coarse entry points) */
 /* Tuning knobs of the dispatchers (TT_PLANES_VARIANT, TT_P8_ORDER, TT_P8_NO_HALF, TT_P8_CLOCK_PRINT, TT_Q8_ORDER, TT_PAIRS_NO8,
  * TT_PAIRS8_NO_KEPT) are read ONCE from the environment; this setter changes one afterwards - for the A/B tools and tests only. */
 int tt_set_tuning_knob(const char* name, int value);
 /* Fills name (<= cap bytes) with the gcnArchName of the current device; returns CU count or <0. */
 int tt_device_info(char* name, int cap);
+
+/* ---- ABI 7: the K-split workspace of the persistent GEMM kernels (gemm_pairs8.hip / gemm_planes8.hip behind tt_linear_fwd_pairs,
+ * tt_linear_fwd_planes, tt_linear_bwd_data_pairs, tt_linear_bwd_data_planes).  The output tiles beyond the last whole round over the CUs
+ * are split along K over several workgroups, which exchange fp32 partials and (tile, wave) arrival counters through this buffer.
+ *   tt_linear_ksplit_workspace_bytes   its size for the current device (counters + partials; 64 MB + 8 KB on MI355X);
+ *   tt_linear_ksplit_workspace_init    zeroes the counter block (a hipMemsetAsync on `stream`): ONCE after allocation - every launch
+ *                                      leaves the counters zero again - and again after a launch that was aborted.
+ * One buffer serves any sequence of launches on ONE stream (launches on different streams may overlap: give each stream its own).
+ * workspace == NULL (or too small): such a call never splits K - the left-over tiles are cut into half tiles or dealt round-robin;
+ * same arithmetic per output element, a different summation order across the K-tiles of those tiles (results may differ in the last bit
+ * from a call with a workspace). */
+size_t tt_linear_ksplit_workspace_bytes(void);
+int tt_linear_ksplit_workspace_init(void* workspace, size_t workspace_bytes, tt_stream_t stream);
 
 /* ---- k4,k6,k7,k8,k9: nn.Linear forward  (dino_vision_transformer.py:94-103,115-117,122,130;
  *      models.py:915-926,1075-1077)
@@ -213,7 +228,8 @@ int tt_layernorm_fwd_planes(const float* x, const float* gamma, const float* bet
                             tt_stream_t stream);
 int tt_linear_fwd_planes(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes,
                          const float* bias, const float* residual, float* y, float* pre_out, void* y_planes,
-                         long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, tt_stream_t stream);
+                         long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, void* workspace, size_t workspace_bytes,
+                         tt_stream_t stream);   /* workspace: tt_linear_ksplit_workspace_bytes() or NULL (ABI 7) */
 int tt_attention_fwd_bf16(const void* qkv, void* out, int F, int N, int H, int head_dim, float scale, tt_stream_t stream);
 
 /* ---- fp16-PAIR operands: the fp32-accurate split mode "f16x3" (round 4) of the forward nn.Linear sites
@@ -222,6 +238,11 @@ int tt_attention_fwd_bf16(const void* qkv, void* out, int F, int N, int H, int h
  *   as [hi x 32][lo x 32] fp16 - 4 bytes per element, rows as long as in fp32.  A product term costs three fp16 MFMAs (hi hi into one
  *   fp32 accumulator, hi lo + lo hi into a second one folded in with the exact 2^-11); the dropped lo lo term is <= 2^-22 relative.
  *   Operands must lie in fp16's range (|x| <= 65504: beyond it the result is inf / NaN, as an fp16 autocast's would be).
+ *   The RANGE FLAG (ABI 7): every entry point that PRODUCES pairs from fp32 values - tt_split_pairs, tt_layernorm_fwd_pairs,
+ *   tt_linear_fwd_pairs (y_pairs), tt_split_pairs_dual(_multi), tt_patch_embed_fwd_pairs, tt_vit_params.range_flag - takes `range_flag`, a
+ *   DEVICE int (or NULL): the kernel stores 1 to it when a value it splits is beyond fp16's range or not finite (hi = inf / NaN) and never
+ *   clears it.  The caller zeroes it, reads it at its own synchronisation points and decides (the Python host raises PairRangeError and names
+ *   --precision f32; tests/test_hip_pairs.py).  tt_attention_fwd_pairs needs none: its outputs are convex combinations of v.
  *   tt_split_pairs          fp32 [n] -> pairs, n % 32 == 0 (weights; activations produced by fp32 kernels).  tt_join_pairs: back.
  *   tt_layernorm_fwd_pairs  tt_layernorm_fwd with the result in pairs [rows][2 D] (D % 32 == 0; optional mean / rstd as there).
  *   tt_linear_fwd_pairs     y = act(x @ w^T + bias) (+ residual): x [M,K], w [N,K] in pairs.  Outputs, any of: y fp32 [M,N], pre_out
@@ -229,12 +250,13 @@ int tt_attention_fwd_bf16(const void* qkv, void* out, int F, int N, int H, int h
  *   tt_linear_fwd_pairs_route  which kernel such a call runs: 8 = the persistent gemm_pairs8_kernel (N % 128 == 0, K % 96 == 0,
  *                           M >= 256, a grid of at least half the CUs; every epilogue incl. pre_out + GELU pairs), 0 = the general
  *                           kernel.  Profilers' labels only. */
-int tt_split_pairs(const float* src, void* dst_pairs, long long n, tt_stream_t stream);
+int tt_split_pairs(const float* src, void* dst_pairs, long long n, int* range_flag, tt_stream_t stream);
 int tt_join_pairs(const void* src_pairs, float* dst, long long n, tt_stream_t stream);
 int tt_layernorm_fwd_pairs(const float* x, const float* gamma, const float* beta, void* y_pairs, float* mean, float* rstd, int rows, int D,
-                           float eps, int skip_group, tt_stream_t stream);
+                           float eps, int skip_group, int* range_flag, tt_stream_t stream);
 int tt_linear_fwd_pairs(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out,
-                        void* y_pairs, int M, int N, int K, int act, tt_stream_t stream);
+                        void* y_pairs, int M, int N, int K, int act, void* workspace, size_t workspace_bytes, int* range_flag,
+                        tt_stream_t stream);   /* workspace: tt_linear_ksplit_workspace_bytes() or NULL (ABI 7) */
 int tt_linear_fwd_pairs_route(int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int has_y_pairs, int has_pre_out);
 
 /* The fused attention core on pair operands (dino_vision_transformer.py:120-132): qkv [F N][2 x 3 H 64] in pairs (the qkv Linear's y_pairs) ->
@@ -269,15 +291,15 @@ int tt_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, float* out_f3
  *                                 divided by S in the epilogue (exact: S is a power of two). */
 size_t tt_split_pairs_dual_workspace_bytes(int R, int C, int Rpad);
 int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, float* scale_out, int R, int C, int Rpad,
-                        void* workspace, size_t workspace_bytes, tt_stream_t stream);
+                        void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream);
 int tt_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int R, int C, int Rpad, tt_stream_t stream);
 /* tt_split_pairs_dual (without column sums) for n matrices in ONE launch per 32 of them: host arrays of n pointers / sizes; dst_t_pairs[i] or
  * dst_row_pairs[i] may be null.  What a training step needs of every weight the optimizer rewrote (row pairs: forward and weight-gradient
  * operand; transposed pairs: the data-gradient operand). */
 int tt_split_pairs_dual_multi(const float* const* src, void* const* dst_t_pairs, void* const* dst_row_pairs, const int* R, const int* C,
-                              const int* Rpad, int n, tt_stream_t stream);
+                              const int* Rpad, int n, int* range_flag, tt_stream_t stream);
 int tt_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, const float* dy_scale, int M, int N, int K,
-                             tt_stream_t stream);
+                             void* workspace, size_t workspace_bytes, tt_stream_t stream);   /* workspace: the K-split block or NULL (ABI 7) */
 size_t tt_linear_bwd_weight_pairs_workspace_bytes(int N, int K, int Mpad);
 int tt_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, float* dw, const float* dy_scale, int N, int K, int Mpad, void* workspace,
                                size_t workspace_bytes, tt_stream_t stream);
@@ -287,10 +309,12 @@ int tt_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, flo
                                   size_t workspace_bytes, tt_stream_t stream);
 /*   prepare_tokens (dino_vision_transformer.py:166-171,236-247) on pair operands: tt_patch_embed_fwd with the conv weight in pairs
  *   [D][2 C P P] (tt_split_pairs of patch_w viewed [D, C P P]); the patches are split into pairs on their way into an im2col buffer
- *   (workspace), ONE pair GEMM over all F (n + 1) rows leaves the tokens.  P % 4 == 0, W % 4 == 0, C P P % 32 == 0, D % 64 == 0. */
+ *   (workspace: the rows, then the GEMM's K-split block, whose counters the call zeroes itself), ONE pair GEMM over all F (n + 1) rows
+ *   leaves the tokens.  P % 4 == 0, W % 4 == 0, C P P % 32 == 0, D % 64 == 0. */
 size_t tt_patch_embed_pairs_workspace_bytes(int F, int C, int H, int W, int P);
 int tt_patch_embed_fwd_pairs(const float* img, const int32_t* frame_map, const void* w_pairs, const float* bias, const float* cls, const float* pos,
-                             float* tokens, int F, int C, int H, int W, int P, int D, void* workspace, size_t workspace_bytes, tt_stream_t stream);
+                             float* tokens, int F, int C, int H, int W, int P, int D, void* workspace, size_t workspace_bytes, int* range_flag,
+                             tt_stream_t stream);
 /*   The backward products of the same nn.Linear sites on bf16-plane operands (autograd of dino_vision_transformer.py:94-103,
  *   115-130; the bf16 path only - the fp32 modes keep the f32-MFMA backward kernels):
  *   tt_transpose_planes               fp32 [R][C] -> bf16 [C][Rpad], transposed, columns R..Rpad-1 zero (reduction index contiguous)
@@ -305,7 +329,8 @@ size_t tt_transpose_planes_colsum_workspace_bytes(int R, int C, int Rpad);
 int tt_transpose_planes_colsum(const float* src, void* dst, int R, int C, int Rpad, float* colsum, void* workspace, size_t workspace_bytes,
                                tt_stream_t stream);
 int tt_linear_bwd_data_planes(const void* dy_planes, long long dy_plane_stride, const void* wT_planes, long long wT_plane_stride,
-                              int planes, const float* gelu_pre, float* dx, int M, int N, int K, tt_stream_t stream);
+                              int planes, const float* gelu_pre, float* dx, int M, int N, int K, void* workspace, size_t workspace_bytes,
+                              tt_stream_t stream);   /* workspace: the K-split block or NULL (ABI 7) */
 int tt_linear_bwd_weight_planes(const void* dyT_planes, long long dyT_plane_stride, const void* xT_planes, long long xT_plane_stride,
                                 int planes, float* dw, int N, int K, int Mpad, void* workspace, size_t workspace_bytes,
                                 tt_stream_t stream);
@@ -490,6 +515,7 @@ typedef struct {
                                                    tt_patch_embed_fwd_planes where its shape rules hold (ABI 4); planes == 2: patch_w in
                                                    pairs [D][2 C P P] - tt_patch_embed_fwd_pairs where ITS rules hold and C P P <= 3 D
                                                    (the rows then fit the scratch) (ABI 6) */
+  int* range_flag;                              /* planes == 2: the pair producers' range flag (device int or NULL; ABI 7) */
 } tt_vit_params;
 typedef struct {
   const float* w;   /* [out_features, in_features] */

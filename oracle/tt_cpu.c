@@ -783,7 +783,8 @@ int tt_cpu_layernorm_fwd_planes(const float* x, const float* gamma, const float*
 }
 int tt_cpu_linear_fwd_planes(const void* x_planes, long long xs, const void* w_planes, long long wsd, int planes, const float* bias,
                              const float* residual, float* y, float* pre_out, void* y_planes, long long ys, int y_nplanes, int M, int N,
-                             int K, int act, tt_stream_t stream) {
+                             int K, int act, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  (void)workspace; (void)workspace_bytes;   /* (the K-split block of the persistent HIP kernels: ABI 7) */
   const uint16_t* xp = (const uint16_t*)x_planes;
   const uint16_t* wp = (const uint16_t*)w_planes;
   float* tmp = (float*)malloc((size_t)M * N * sizeof(float));
@@ -893,6 +894,7 @@ typedef struct {
   int dim, heads, hidden, patch;
   int planes;
   const void* patch_wp;
+  int* range_flag;
 } tt_cpu_vit_params;
 typedef struct { const float* w; const float* b; int out_features, in_features; } tt_cpu_linear_params;
 
@@ -939,8 +941,15 @@ static double pair_dot(const uint16_t* a, const uint16_t* b, long long n) {
   for (long long k = 0; k < n; ++k) s += pair_hi(a, k) * pair_hi(b, k) + pair_hi(a, k) * pair_lo(b, k) + pair_lo(a, k) * pair_hi(b, k);
   return s;
 }
-int tt_cpu_split_pairs(const float* src, void* dst_pairs, long long n, tt_stream_t stream) {
+/* the range flag (ABI 7): set when a value that is split lies beyond fp16's range (|x| > 65504 rounds to inf) or is not finite */
+static void pair_range_check(const float* v, long long n, int* range_flag) {
+  if (!range_flag) return;
+  for (long long i = 0; i < n; ++i)
+    if (!(fabsf(v[i]) < 65520.0f)) { *range_flag = 1; return; }   /* 65520 = the round-to-nearest-even boundary between 65504 and inf */
+}
+int tt_cpu_split_pairs(const float* src, void* dst_pairs, long long n, int* range_flag, tt_stream_t stream) {
   (void)stream;
+  pair_range_check(src, n, range_flag);
   for (long long i = 0; i < n; ++i) pair_put((uint16_t*)dst_pairs, i, src[i]);
   return 0;
 }
@@ -951,16 +960,18 @@ int tt_cpu_join_pairs(const void* src_pairs, float* dst, long long n, tt_stream_
   return 0;
 }
 int tt_cpu_layernorm_fwd_pairs(const float* x, const float* gamma, const float* beta, void* y_pairs, float* mean, float* rstd, int rows, int D,
-                               float eps, int skip_group, tt_stream_t stream) {
+                               float eps, int skip_group, int* range_flag, tt_stream_t stream) {
   float* y = (float*)malloc((size_t)rows * D * sizeof(float));
   if (!y) return -3;
   tt_cpu_layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, eps, skip_group, stream);
-  const int rc = tt_cpu_split_pairs(y, y_pairs, (long long)rows * D, stream);
+  const int rc = tt_cpu_split_pairs(y, y_pairs, (long long)rows * D, range_flag, stream);
   free(y);
   return rc;
 }
 int tt_cpu_linear_fwd_pairs(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out,
-                            void* y_pairs, int M, int N, int K, int act, tt_stream_t stream) {
+                            void* y_pairs, int M, int N, int K, int act, void* workspace, size_t workspace_bytes, int* range_flag,
+                            tt_stream_t stream) {
+  (void)workspace; (void)workspace_bytes;
   const uint16_t *xp = (const uint16_t*)x_pairs, *wp = (const uint16_t*)w_pairs;   /* [M][2 K], [N][2 K] */
   float* tmp = (float*)malloc((size_t)M * N * sizeof(float));
   if (!tmp) return -3;
@@ -972,7 +983,7 @@ int tt_cpu_linear_fwd_pairs(const void* x_pairs, const void* w_pairs, const floa
       if (residual) v += residual[(size_t)m * N + n];
       tmp[(size_t)m * N + n] = v;
     }
-  if (y_pairs) tt_cpu_split_pairs(tmp, y_pairs, (long long)M * N, stream);
+  if (y_pairs) tt_cpu_split_pairs(tmp, y_pairs, (long long)M * N, range_flag, stream);
   if (y) memcpy(y, tmp, (size_t)M * N * sizeof(float));
   free(tmp);
   return 0;
@@ -1016,7 +1027,7 @@ int tt_cpu_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, float* ou
         }
       }
   if (out_f32) memcpy(out_f32, o, (size_t)F * N * D * sizeof(float));
-  if (out_pairs) tt_cpu_split_pairs(o, out_pairs, (long long)F * N * D, stream);
+  if (out_pairs) tt_cpu_split_pairs(o, out_pairs, (long long)F * N * D, NULL, stream);
   free(p); free(o);
   return 0;
 }
@@ -1029,7 +1040,7 @@ static float pair_scale_of(float amax) {
   return ldexpf(1.0f, e);
 }
 int tt_cpu_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, float* scale_out, int R, int C, int Rpad,
-                            void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+                            void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream) {
   (void)workspace; (void)workspace_bytes; (void)stream;
   uint16_t *t = (uint16_t*)dst_t_pairs, *row = (uint16_t*)dst_row_pairs;
   float S = 1.0f;
@@ -1041,7 +1052,8 @@ int tt_cpu_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_p
   for (int c = 0; c < C; ++c) {
     double s = 0.0;
     for (int r = 0; r < Rpad; ++r) {
-      const float v = r < R ? src[(size_t)r * C + c] : 0.f;
+      const float v = r < R ? src[(size_t)r * C + c] : 0.f, vs = v * S;
+      pair_range_check(&vs, 1, range_flag);
       if (t) pair_put(t + (size_t)c * 2 * Rpad, r, v * S);
       if (row && r < R) pair_put(row + (size_t)r * 2 * C, c, v * S);
       s += v;
@@ -1051,9 +1063,9 @@ int tt_cpu_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_p
   return 0;
 }
 int tt_cpu_split_pairs_dual_multi(const float* const* src, void* const* dst_t_pairs, void* const* dst_row_pairs, const int* R, const int* C,
-                                  const int* Rpad, int n, tt_stream_t stream) {
+                                  const int* Rpad, int n, int* range_flag, tt_stream_t stream) {
   for (int i = 0; i < n; ++i) {
-    const int rc = tt_cpu_split_pairs_dual(src[i], dst_t_pairs[i], dst_row_pairs[i], NULL, NULL, R[i], C[i], Rpad[i], NULL, 0, stream);
+    const int rc = tt_cpu_split_pairs_dual(src[i], dst_t_pairs[i], dst_row_pairs[i], NULL, NULL, R[i], C[i], Rpad[i], NULL, 0, range_flag, stream);
     if (rc) return rc;
   }
   return 0;
@@ -1070,8 +1082,8 @@ int tt_cpu_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int R, int 
   return 0;
 }
 int tt_cpu_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, const float* dy_scale, int M, int N,
-                                 int K, tt_stream_t stream) {
-  (void)stream;
+                                 int K, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  (void)stream; (void)workspace; (void)workspace_bytes;
   const uint16_t *dy = (const uint16_t*)dy_pairs, *wT = (const uint16_t*)wT_pairs;   /* dy [M][2 N], wT [K][2 N] */
   const double inv_s = dy_scale ? 1.0 / (double)*dy_scale : 1.0;
   for (int m = 0; m < M; ++m)
@@ -1117,7 +1129,7 @@ int tt_cpu_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs,
 size_t tt_cpu_patch_embed_pairs_workspace_bytes(int F, int C, int H, int W, int P) { return 0; }
 int tt_cpu_patch_embed_fwd_pairs(const float* img, const int32_t* frame_map, const void* w_pairs, const float* bias, const float* cls,
                                  const float* pos, float* tokens, int F, int C, int H, int W, int P, int D, void* workspace,
-                                 size_t workspace_bytes, tt_stream_t stream) {
+                                 size_t workspace_bytes, int* range_flag, tt_stream_t stream) {
   (void)stream; (void)workspace; (void)workspace_bytes;
   const uint16_t* wp = (const uint16_t*)w_pairs;
   const int gh = H / P, gw = W / P, n = gh * gw, K = C * P * P;
@@ -1131,7 +1143,10 @@ int tt_cpu_patch_embed_fwd_pairs(const float* img, const int32_t* frame_map, con
       for (int px = 0; px < gw; ++px) {
         for (int c = 0; c < C; ++c)
           for (int y = 0; y < P; ++y)
-            for (int x = 0; x < P; ++x) pair_put(patch, (c * P + y) * P + x, src[((size_t)c * H + py * P + y) * W + px * P + x]);
+            for (int x = 0; x < P; ++x) {
+              pair_range_check(&src[((size_t)c * H + py * P + y) * W + px * P + x], 1, range_flag);
+              pair_put(patch, (c * P + y) * P + x, src[((size_t)c * H + py * P + y) * W + px * P + x]);
+            }
         for (int d = 0; d < D; ++d)
           tok[(size_t)(1 + py * gw + px) * D + d] =
               ((float)pair_dot(patch, wp + (size_t)d * 2 * K, K) + bias[d]) + pos[(size_t)(1 + py * gw + px) * D + d];
@@ -1158,7 +1173,7 @@ int tt_cpu_vit_forward(const tt_cpu_vit_params* p, const float* img, const int32
     if (P == 1 && p->patch_wp && p->patch % 4 == 0 && W % 4 == 0 && (C * p->patch * p->patch) % 64 == 0 && D % 64 == 0 && C * p->patch * p->patch <= 9 * D)
       tt_cpu_patch_embed_fwd_planes(img, frame_map, p->patch_wp, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, NULL, 0, stream);
     else if (P == 2 && p->patch_wp && p->patch % 4 == 0 && W % 4 == 0 && (C * p->patch * p->patch) % 32 == 0 && D % 64 == 0 && C * p->patch * p->patch <= 3 * D)
-      tt_cpu_patch_embed_fwd_pairs(img, frame_map, p->patch_wp, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, NULL, 0, stream);
+      tt_cpu_patch_embed_fwd_pairs(img, frame_map, p->patch_wp, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, NULL, 0, p->range_flag, stream);
     else
       tt_cpu_patch_embed_fwd(img, frame_map, p->patch_w, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, stream);
   }
@@ -1185,40 +1200,40 @@ int tt_cpu_vit_forward(const tt_cpu_vit_params* p, const float* img, const int32
     }
     const long long MD = (long long)M * D;
     if (P == 2) {   /* fp16 pairs (4 bytes per element: the PP = 2 buffers above are the right size) */
-      tt_cpu_layernorm_fwd_pairs(tokens, b->norm1_w, b->norm1_b, hp, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
+      tt_cpu_layernorm_fwd_pairs(tokens, b->norm1_w, b->norm1_b, hp, NULL, NULL, (int)M, D, 1e-6f, 0, p->range_flag, stream);
       if (!(last && last_qkv) && !probs && hd == 64) {
         uint16_t* qkvp = (uint16_t*)qkv_own;   /* pairs [M][2 x 3 D] = the bytes of the fp32 qkv buffer */
-        tt_cpu_linear_fwd_pairs(hp, b->qkv_wp, b->qkv_b, NULL, NULL, NULL, qkvp, (int)M, 3 * D, D, 0, stream);
+        tt_cpu_linear_fwd_pairs(hp, b->qkv_wp, b->qkv_b, NULL, NULL, NULL, qkvp, (int)M, 3 * D, D, 0, NULL, 0, p->range_flag, stream);
         tt_cpu_attention_fwd_pairs(qkvp, attp, NULL, NULL, F, N, p->heads, hd, scale, stream);
       } else {
-        tt_cpu_linear_fwd_pairs(hp, b->qkv_wp, b->qkv_b, NULL, qkv, NULL, NULL, (int)M, 3 * D, D, 0, stream);
+        tt_cpu_linear_fwd_pairs(hp, b->qkv_wp, b->qkv_b, NULL, qkv, NULL, NULL, (int)M, 3 * D, D, 0, NULL, 0, p->range_flag, stream);
         tt_cpu_attention_fwd(qkv, att, NULL, probs, F, N, p->heads, hd, scale, stream);
-        tt_cpu_split_pairs(att, attp, MD, stream);
+        tt_cpu_split_pairs(att, attp, MD, p->range_flag, stream);
       }
-      tt_cpu_linear_fwd_pairs(attp, b->proj_wp, b->proj_b, tokens, tokens, NULL, NULL, (int)M, D, D, 0, stream);
-      tt_cpu_layernorm_fwd_pairs(tokens, b->norm2_w, b->norm2_b, hp, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
-      tt_cpu_linear_fwd_pairs(hp, b->fc1_wp, b->fc1_b, NULL, NULL, NULL, actp, (int)M, Hd, D, 1, stream);
-      tt_cpu_linear_fwd_pairs(actp, b->fc2_wp, b->fc2_b, tokens, tokens, NULL, NULL, (int)M, D, Hd, 0, stream);
+      tt_cpu_linear_fwd_pairs(attp, b->proj_wp, b->proj_b, tokens, tokens, NULL, NULL, (int)M, D, D, 0, NULL, 0, p->range_flag, stream);
+      tt_cpu_layernorm_fwd_pairs(tokens, b->norm2_w, b->norm2_b, hp, NULL, NULL, (int)M, D, 1e-6f, 0, p->range_flag, stream);
+      tt_cpu_linear_fwd_pairs(hp, b->fc1_wp, b->fc1_b, NULL, NULL, NULL, actp, (int)M, Hd, D, 1, NULL, 0, p->range_flag, stream);
+      tt_cpu_linear_fwd_pairs(actp, b->fc2_wp, b->fc2_b, tokens, tokens, NULL, NULL, (int)M, D, Hd, 0, NULL, 0, p->range_flag, stream);
       continue;
     }
     tt_cpu_layernorm_fwd_planes(tokens, b->norm1_w, b->norm1_b, hp, MD, P, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
     const void* proj_in;
     if (P == 1 && !(last && last_qkv) && !probs && N <= 256 && hd == 64) {
-      tt_cpu_linear_fwd_planes(hp, MD, b->qkv_wp, 3ll * D * D, 1, b->qkv_b, NULL, NULL, NULL, qkvb, (long long)M * 3 * D, 1, (int)M, 3 * D, D, 0,
+      tt_cpu_linear_fwd_planes(hp, MD, b->qkv_wp, 3ll * D * D, 1, b->qkv_b, NULL, NULL, NULL, qkvb, (long long)M * 3 * D, 1, (int)M, 3 * D, D, 0, NULL, 0,
                                stream);
       tt_cpu_attention_fwd_bf16(qkvb, attp, F, N, p->heads, hd, scale, stream);
     } else {
-      tt_cpu_linear_fwd_planes(hp, MD, b->qkv_wp, 3ll * D * D, P, b->qkv_b, NULL, qkv, NULL, NULL, 0, 0, (int)M, 3 * D, D, 0, stream);
+      tt_cpu_linear_fwd_planes(hp, MD, b->qkv_wp, 3ll * D * D, P, b->qkv_b, NULL, qkv, NULL, NULL, 0, 0, (int)M, 3 * D, D, 0, NULL, 0, stream);
       tt_cpu_attention_fwd(qkv, att, NULL, probs, F, N, p->heads, hd, scale, stream);
       tt_cpu_split_planes(att, attp, MD, P, MD, stream);
     }
     proj_in = attp;
-    tt_cpu_linear_fwd_planes(proj_in, MD, b->proj_wp, (long long)D * D, P, b->proj_b, tokens, tokens, NULL, NULL, 0, 0, (int)M, D, D, 0, stream);
+    tt_cpu_linear_fwd_planes(proj_in, MD, b->proj_wp, (long long)D * D, P, b->proj_b, tokens, tokens, NULL, NULL, 0, 0, (int)M, D, D, 0, NULL, 0, stream);
     tt_cpu_layernorm_fwd_planes(tokens, b->norm2_w, b->norm2_b, hp, MD, P, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
-    tt_cpu_linear_fwd_planes(hp, MD, b->fc1_wp, (long long)Hd * D, P, b->fc1_b, NULL, NULL, NULL, actp, (long long)M * Hd, P, (int)M, Hd, D, 1,
+    tt_cpu_linear_fwd_planes(hp, MD, b->fc1_wp, (long long)Hd * D, P, b->fc1_b, NULL, NULL, NULL, actp, (long long)M * Hd, P, (int)M, Hd, D, 1, NULL, 0,
                              stream);
     tt_cpu_linear_fwd_planes(actp, (long long)M * Hd, b->fc2_wp, (long long)Hd * D, P, b->fc2_b, tokens, tokens, NULL, NULL, 0, 0, (int)M, D, Hd,
-                             0, stream);
+                             0, NULL, 0, stream);
   }
   free(h); free(qkv_own); free(att); free(act); free(hp); free(qkvb); free(attp); free(actp);
   if (normed) {
@@ -1404,7 +1419,8 @@ int tt_cpu_kmeans_accumulate(const float* x, const int32_t* labels, double* sums
 
 /* ---- backward products of the nn.Linear sites on bf16-plane operands (autograd of dino_vision_transformer.py:94-103,115-130) */
 int tt_cpu_linear_bwd_data_planes(const void* dy_planes, long long dys, const void* wT_planes, long long wts, int planes, const float* gelu_pre,
-                                  float* dx, int M, int N, int K, tt_stream_t stream) {
+                                  float* dx, int M, int N, int K, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  (void)workspace; (void)workspace_bytes;
   const uint16_t *dy = (const uint16_t*)dy_planes, *wT = (const uint16_t*)wT_planes;   /* dy [P][M][N], wT [P][K][N] */
   for (int m = 0; m < M; ++m)
     for (int k = 0; k < K; ++k) {

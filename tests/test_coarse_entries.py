@@ -80,7 +80,7 @@ def _run_vit(lib, prefix, mem, case, planes, drop_cls=False, want_qkv=False, wan
                 wp = np.empty((planes,) + b[k].shape, np.uint16)   # (planes == 2: fp16 pairs [out][2 in] - the same number of bytes)
                 src, dst = mem(b[k]), mem(wp)
                 if planes == 2:
-                    assert split_pairs(src, dst, b[k].size, mem.stream) == 0
+                    assert split_pairs(src, dst, b[k].size, None, mem.stream) == 0
                 else:
                     assert split(src, dst, b[k].size, planes, b[k].size, mem.stream) == 0
                 setattr(arr[j], k + "p", dst)
@@ -91,7 +91,7 @@ def _run_vit(lib, prefix, mem, case, planes, drop_cls=False, want_qkv=False, wan
     if planes == 2 and w["patch_w"].size // D % 32 == 0:   # prepare_tokens on pairs too (where tt_vit_forward's shape rules hold; else it falls back)
         pwp = np.empty((D, 2 * (w["patch_w"].size // D)), np.uint16)
         dst = mem(pwp)
-        assert split_pairs(vp.patch_w, dst, w["patch_w"].size, mem.stream) == 0   # (the copy mem() made above: a second mem() of it would free that one)
+        assert split_pairs(vp.patch_w, dst, w["patch_w"].size, None, mem.stream) == 0   # (the copy mem() made above: a second mem() of it would free that one)
         vp.patch_wp = dst
     tokens = np.empty((Fr, N, D), np.float32) if from_tokens is None else from_tokens.copy()
     normed = np.empty((Fr * (N - 1), D) if drop_cls else (Fr, N, D), np.float32)
@@ -296,7 +296,7 @@ def test_coarse_entry_argument_checks():
     # the bf16 patch embedding: shape rules and the workspace size are checked, nothing is launched on a bad call
     big = torch.zeros(1 << 20, device="cuda")
     p_ = big.data_ptr()
-    assert lib.tt_patch_embed_planes_workspace_bytes(2, 3, 32, 48, 16) == 2 * 7 * 768 * 2
+    assert lib.tt_patch_embed_planes_workspace_bytes(2, 3, 32, 48, 16) == 2 * 7 * 768 * 2 + lib.tt_linear_ksplit_workspace_bytes()   # rows + the K-split block (ABI 7)
     assert lib.tt_patch_embed_fwd_planes(p_, None, p_, p_, p_, p_, p_, 2, 3, 32, 48, 16, 100, p_, 1 << 22, None) == -1 and b"D % 64" in lib.tt_last_error()
     assert lib.tt_patch_embed_fwd_planes(p_, None, p_, p_, p_, p_, p_, 2, 3, 32, 48, 16, 128, p_, 100, None) == -1 and b"workspace too small" in lib.tt_last_error()
     assert lib.tt_patch_embed_fwd_planes(p_, None, p_, p_, p_, p_, p_, 2, 3, 30, 48, 16, 128, p_, 1 << 22, None) == -1

@@ -419,7 +419,7 @@ def _round2b_cases(side):
         side.run("split_planes", xs_, xp, M * K, P_, M * K, st, outs=(xp,))
         side.run("split_planes", w_, wp, N * K, P_, N * K, st, outs=(wp,))
         y, pre, yp = np.empty((M, N), np.float32), np.empty((M, N), np.float32), np.empty((P_, M, N), np.uint16)
-        side.run("linear_fwd_planes", xp, M * K, wp, N * K, P_, bb, rr, y, pre, yp, M * N, P_, M, N, K, 1, st, outs=(y, pre, yp))
+        side.run("linear_fwd_planes", xp, M * K, wp, N * K, P_, bb, rr, y, pre, yp, M * N, P_, M, N, K, 1, None, 0, st, outs=(y, pre, yp))
         res[P_] = (xp.copy(), wp.copy(), y.copy(), pre.copy(), yp.copy())
     R["plane_gemm"] = (xs_, w_, bb, rr, res)
     qb = np.empty((2, 21, 3 * 128), np.uint16)
@@ -440,11 +440,11 @@ def _round2b_cases(side):
     R["patch_bf16"] = (img, fmap, w, wpl.copy(), b, cls, pos, tok.copy())
     # ... and on fp16-pair operands
     wpr = np.empty((Dm, 2 * C * P * P), np.uint16)
-    side.run("split_pairs", w, wpr, Dm * C * P * P, st, outs=(wpr,))
+    side.run("split_pairs", w, wpr, Dm * C * P * P, None, st, outs=(wpr,))
     tokp = np.empty((Fp, 7, Dm), np.float32)
     nbq = max(int(getattr(side.lib, side.prefix + "patch_embed_pairs_workspace_bytes")(Fp, C, Hh, Ww, P)), 16)
     wsq = np.empty(nbq, np.uint8)
-    side.run("patch_embed_fwd_pairs", img, fmap, wpr, b, cls, pos, tokp, Fp, C, Hh, Ww, P, Dm, wsq, nbq, st, outs=(tokp,))
+    side.run("patch_embed_fwd_pairs", img, fmap, wpr, b, cls, pos, tokp, Fp, C, Hh, Ww, P, Dm, wsq, nbq, None, st, outs=(tokp,))
     R["patch_pairs"] = (tok.copy(), tokp.copy())
     return R
 
@@ -580,7 +580,7 @@ def _round2c_cases(side):
     side.run("split_planes", dy, dyp, M2 * N2, 1, M2 * N2, st, outs=(dyp,))
     side.run("transpose_planes", w, wT, N2, K2, N2, st, outs=(wT,))
     dx = np.empty((M2, K2), np.float32)
-    side.run("linear_bwd_data_planes", dyp, M2 * N2, wT, K2 * N2, 1, pre, dx, M2, N2, K2, st, outs=(dx,))
+    side.run("linear_bwd_data_planes", dyp, M2 * N2, wT, K2 * N2, 1, pre, dx, M2, N2, K2, None, 0, st, outs=(dx,))
     dyT, xT = np.empty((N2, Mpad), np.uint16), np.empty((K2, Mpad), np.uint16)
     side.run("transpose_planes", dy, dyT, M2, N2, Mpad, st, outs=(dyT,))
     side.run("transpose_planes", xx, xT, M2, K2, Mpad, st, outs=(xT,))
@@ -690,7 +690,7 @@ def test_round4_pair_twins_against_numpy(twin):
     M, N, K = 37, 64, 96
     x, w, b = rs.randn(M, K).astype(np.float32), (0.1 * rs.randn(N, K)).astype(np.float32), (0.1 * rs.randn(N)).astype(np.float32)
     xp, wp = np.empty((M, 2 * K), np.uint16), np.empty((N, 2 * K), np.uint16)
-    assert twin.tt_cpu_split_pairs(ptr(x), ptr(xp), M * K, None) == 0 and twin.tt_cpu_split_pairs(ptr(w), ptr(wp), N * K, None) == 0
+    assert twin.tt_cpu_split_pairs(ptr(x), ptr(xp), M * K, None, None) == 0 and twin.tt_cpu_split_pairs(ptr(w), ptr(wp), N * K, None, None) == 0
     # layout and values: groups of 32 as [hi x 32][lo x 32]; hi = fp16(x) (torch's own conversion), lo = fp16((x - hi) 2^11)
     g = xp.reshape(M, K // 32, 2, 32)
     hi_ref = torch.from_numpy(x).to(torch.float16)
@@ -701,27 +701,27 @@ def test_round4_pair_twins_against_numpy(twin):
     assert twin.tt_cpu_join_pairs(ptr(xp), ptr(back), M * K, None) == 0
     assert np.abs(back - x).max() <= 2.0 ** -22 * np.abs(x).max()
     y, pre, yp = np.empty((M, N), np.float32), np.empty((M, N), np.float32), np.empty((M, 2 * N), np.uint16)
-    assert twin.tt_cpu_linear_fwd_pairs(ptr(xp), ptr(wp), ptr(b), None, ptr(y), ptr(pre), ptr(yp), M, N, K, 1, None) == 0
+    assert twin.tt_cpu_linear_fwd_pairs(ptr(xp), ptr(wp), ptr(b), None, ptr(y), ptr(pre), ptr(yp), M, N, K, 1, None, 0, None, None) == 0
     ref = x.astype(np.float64) @ w.astype(np.float64).T + b
     assert np.abs(pre - ref).max() / np.abs(ref).max() < 5e-7
     assert np.abs(y - F.gelu(torch.from_numpy(ref)).numpy()).max() / np.abs(ref).max() < 5e-7
     # transposes: zero padding beyond R, the same bits as splitting the transposed matrix
     t, row, sums = np.empty((K, 2 * 64), np.uint16), np.empty((M, 2 * K), np.uint16), np.empty(K, np.float32)
-    assert twin.tt_cpu_split_pairs_dual(ptr(x), ptr(t), ptr(row), ptr(sums), None, M, K, 64, None, 0, None) == 0
+    assert twin.tt_cpu_split_pairs_dual(ptr(x), ptr(t), ptr(row), ptr(sums), None, M, K, 64, None, 0, None, None) == 0
     xt = np.zeros((K, 64), np.float32); xt[:, :M] = x.T
     tref = np.empty((K, 128), np.uint16)
-    assert twin.tt_cpu_split_pairs(ptr(xt), ptr(tref), K * 64, None) == 0
+    assert twin.tt_cpu_split_pairs(ptr(xt), ptr(tref), K * 64, None, None) == 0
     assert np.array_equal(t, tref) and np.array_equal(row, xp) and np.allclose(sums, x.sum(0), atol=1e-5)
     t2 = np.empty((K, 128), np.uint16)
     assert twin.tt_cpu_transpose_pairs(ptr(xp), ptr(t2), M, K, 64, None) == 0 and np.array_equal(t2, t)
     # backward products
     dy = (1e-3 * rs.randn(M, N)).astype(np.float32)
     dyT, dyr = np.empty((N, 128), np.uint16), np.empty((M, 2 * N), np.uint16)
-    assert twin.tt_cpu_split_pairs_dual(ptr(dy), ptr(dyT), ptr(dyr), None, None, M, N, 64, None, 0, None) == 0
+    assert twin.tt_cpu_split_pairs_dual(ptr(dy), ptr(dyT), ptr(dyr), None, None, M, N, 64, None, 0, None, None) == 0
     wT = np.empty((K, 2 * N), np.uint16)
-    assert twin.tt_cpu_split_pairs_dual(ptr(w), ptr(wT), None, None, None, N, K, N, None, 0, None) == 0
+    assert twin.tt_cpu_split_pairs_dual(ptr(w), ptr(wT), None, None, None, N, K, N, None, 0, None, None) == 0
     dx, dw = np.empty((M, K), np.float32), np.empty((N, K), np.float32)
-    assert twin.tt_cpu_linear_bwd_data_pairs(ptr(dyr), ptr(wT), None, ptr(dx), None, M, N, K, None) == 0
+    assert twin.tt_cpu_linear_bwd_data_pairs(ptr(dyr), ptr(wT), None, ptr(dx), None, M, N, K, None, 0, None) == 0
     assert twin.tt_cpu_linear_bwd_weight_pairs(ptr(dyT), ptr(t), ptr(dw), None, N, K, 64, None, 0, None) == 0
     dx_ref, dw_ref = dy.astype(np.float64) @ w, dy.astype(np.float64).T @ x
     assert np.abs(dx - dx_ref).max() / np.abs(dx_ref).max() < 5e-7 and np.abs(dw - dw_ref).max() / np.abs(dw_ref).max() < 5e-7
@@ -735,10 +735,10 @@ def test_round4_pair_twins_against_numpy(twin):
     arr = lambda *ps: (C.c_void_p * len(ps))(*[C.c_void_p(p_) if p_ is not None else None for p_ in ps])
     ints = lambda *v: (C.c_int * len(v))(*v)
     assert twin.tt_cpu_split_pairs_dual_multi(arr(x.ctypes.data, x.ctypes.data), arr(m_t.ctypes.data, None), arr(None, m_row.ctypes.data),
-                                              ints(M, M), ints(K, K), ints(64, 64), 2, None) == 0
+                                              ints(M, M), ints(K, K), ints(64, 64), 2, None, None) == 0
     assert np.array_equal(m_t, t) and np.array_equal(m_row, xp)
     dyr2, cs = np.empty((M, 2 * N), np.uint16), np.empty((N,), np.float32)
-    assert twin.tt_cpu_split_pairs_dual(ptr(dy), None, ptr(dyr2), ptr(cs), None, M, N, 64, None, 0, None) == 0
+    assert twin.tt_cpu_split_pairs_dual(ptr(dy), None, ptr(dyr2), ptr(cs), None, M, N, 64, None, 0, None, None) == 0
     assert np.array_equal(dyr2, dyr) and np.allclose(cs, dy.sum(0), atol=1e-6)
     # a gradient far below fp16's normal range: the scaled split (a power of two S that brings max |dy| into [2^13, 2^14), the products
     # divided by S) keeps fp32-class accuracy where the plain split is left with fp16 subnormals
@@ -746,16 +746,16 @@ def test_round4_pair_twins_against_numpy(twin):
     ref_dw, ref_dx = tiny.astype(np.float64).T @ x, tiny.astype(np.float64) @ w
     S = np.zeros(1, np.float32)
     tr, cs2 = np.empty((M, 2 * N), np.uint16), np.empty((N,), np.float32)
-    assert twin.tt_cpu_split_pairs_dual(ptr(tiny), None, ptr(tr), ptr(cs2), ptr(S), M, N, 64, None, 0, None) == 0
+    assert twin.tt_cpu_split_pairs_dual(ptr(tiny), None, ptr(tr), ptr(cs2), ptr(S), M, N, 64, None, 0, None, None) == 0
     amax = np.abs(tiny).max()
     assert S[0] == 2.0 ** (13 - np.floor(np.log2(amax))) and 2 ** 13 <= amax * S[0] < 2 ** 14 and np.allclose(cs2, tiny.sum(0), rtol=1e-5, atol=0)
     dws, dxs = np.empty((N, K), np.float32), np.empty((M, K), np.float32)
     assert twin.tt_cpu_linear_bwd_weight_pairs_tn(ptr(tr), ptr(xp), ptr(dws), ptr(S), N, K, M, None, 0, None) == 0
-    assert twin.tt_cpu_linear_bwd_data_pairs(ptr(tr), ptr(wT), None, ptr(dxs), ptr(S), M, N, K, None) == 0
+    assert twin.tt_cpu_linear_bwd_data_pairs(ptr(tr), ptr(wT), None, ptr(dxs), ptr(S), M, N, K, None, 0, None) == 0
     rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
     assert rel(dws, ref_dw) < 5e-7 and rel(dxs, ref_dx) < 5e-7
     tu, dwu = np.empty((M, 2 * N), np.uint16), np.empty((N, K), np.float32)
-    assert twin.tt_cpu_split_pairs_dual(ptr(tiny), None, ptr(tu), None, None, M, N, 64, None, 0, None) == 0
+    assert twin.tt_cpu_split_pairs_dual(ptr(tiny), None, ptr(tu), None, None, M, N, 64, None, 0, None, None) == 0
     assert twin.tt_cpu_linear_bwd_weight_pairs_tn(ptr(tu), ptr(xp), ptr(dwu), None, N, K, M, None, 0, None) == 0
     assert rel(dwu, ref_dw) > 20 * rel(dws, ref_dw)                        # (what the scale is for)
     # attention on pairs against torch in fp64
@@ -763,7 +763,7 @@ def test_round4_pair_twins_against_numpy(twin):
     D = 64 * H
     qkv = rs.randn(Fr, Nn, 3 * D).astype(np.float32)
     qp = np.empty((Fr * Nn, 6 * D), np.uint16)
-    assert twin.tt_cpu_split_pairs(ptr(qkv), ptr(qp), qkv.size, None) == 0
+    assert twin.tt_cpu_split_pairs(ptr(qkv), ptr(qp), qkv.size, None, None) == 0
     of, lse, op = np.empty((Fr, Nn, D), np.float32), np.empty((Fr, H, Nn), np.float32), np.empty((Fr * Nn, 2 * D), np.uint16)
     assert twin.tt_cpu_attention_fwd_pairs(ptr(qp), ptr(op), ptr(of), ptr(lse), Fr, Nn, H, 64, 0.125, None) == 0
     q, k, v = torch.from_numpy(qkv).double().view(Fr, Nn, 3, H, 64).permute(2, 0, 3, 1, 4)

@@ -36,7 +36,7 @@ class VitBlockParams(C.Structure):
 class VitParams(C.Structure):
     _fields_ = [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
                 ("blocks", C.POINTER(VitBlockParams)), ("n_blocks", C.c_int), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
-                ("dim", C.c_int), ("heads", C.c_int), ("hidden", C.c_int), ("patch", C.c_int), ("planes", C.c_int), ("patch_wp", C.c_void_p)]
+                ("dim", C.c_int), ("heads", C.c_int), ("hidden", C.c_int), ("patch", C.c_int), ("planes", C.c_int), ("patch_wp", C.c_void_p), ("range_flag", C.c_void_p)]
 
 
 class LinearParams(C.Structure):
@@ -49,6 +49,8 @@ SIGNATURES = {
     "tt_abi_version": (c_i, []),
     "tt_set_tuning_knob": (c_i, [C.c_char_p, c_i]),
     "tt_device_info": (c_i, [C.c_char_p, c_i]),
+    "tt_linear_ksplit_workspace_bytes": (c_sz, []),
+    "tt_linear_ksplit_workspace_init": (c_i, [c_vp, c_sz, c_vp]),
     "tt_linear_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "tt_linear_bwd_data": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp]),
     "tt_linear_bwd_weight": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
@@ -71,30 +73,30 @@ SIGNATURES = {
     "tt_attention_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp]),
     "tt_split_planes": (c_i, [c_vp, c_vp, c_ll, c_i, c_ll, c_vp]),
     "tt_layernorm_fwd_planes": (c_i, [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_vp, c_vp, c_i, c_i, c_f, c_i, c_vp]),
-    "tt_linear_fwd_planes": (c_i, [c_vp, c_ll, c_vp, c_ll, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "tt_linear_fwd_planes": (c_i, [c_vp, c_ll, c_vp, c_ll, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_attention_fwd_bf16": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp]),
-    "tt_split_pairs": (c_i, [c_vp, c_vp, c_ll, c_vp]),
+    "tt_split_pairs": (c_i, [c_vp, c_vp, c_ll, c_vp, c_vp]),
     "tt_join_pairs": (c_i, [c_vp, c_vp, c_ll, c_vp]),
-    "tt_layernorm_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_i, c_vp]),
-    "tt_linear_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
+    "tt_layernorm_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_i, c_vp, c_vp]),
+    "tt_linear_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp, c_vp]),
     "tt_linear_fwd_pairs_route": (c_i, [c_i] * 9),
     "tt_attention_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp]),
     "tt_split_pairs_dual_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
-    "tt_split_pairs_dual": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "tt_split_pairs_dual": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp, c_vp]),
     "tt_transpose_pairs": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp]),
-    "tt_linear_bwd_data_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp]),
+    "tt_linear_bwd_data_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_linear_bwd_weight_pairs_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_linear_bwd_weight_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
-    "tt_split_pairs_dual_multi": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp]),
+    "tt_split_pairs_dual_multi": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_vp]),
     "tt_patch_embed_pairs_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
-    "tt_patch_embed_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "tt_patch_embed_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp, c_vp]),
     "tt_linear_bwd_weight_pairs_tn_ok": (c_i, [c_i, c_i, c_i]),
     "tt_linear_bwd_weight_pairs_tn_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_linear_bwd_weight_pairs_tn": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_transpose_planes": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp]),
     "tt_transpose_planes_colsum_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_transpose_planes_colsum": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp, c_vp, c_sz, c_vp]),
-    "tt_linear_bwd_data_planes": (c_i, [c_vp, c_ll, c_vp, c_ll, c_i, c_vp, c_vp, c_i, c_i, c_i, c_vp]),
+    "tt_linear_bwd_data_planes": (c_i, [c_vp, c_ll, c_vp, c_ll, c_i, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_linear_bwd_weight_planes": (c_i, [c_vp, c_ll, c_vp, c_ll, c_i, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_linear_bwd_weight_planes_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_attention_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),

@@ -39,6 +39,15 @@ int device_cu_count();   // core.cpp: multiprocessors of the CURRENT device (loo
 enum { KNOB_PLANES_VARIANT = 0, KNOB_P8_ORDER, KNOB_P8_NO_HALF, KNOB_P8_CLOCK_PRINT, KNOB_Q8_ORDER, KNOB_PAIRS_NO8, KNOB_PAIRS8_NO_KEPT, KNOB_Q8_KSPLIT, KNOB_ATTN_PAIRS_FLASH, KNOB_TN_WGS, KNOB_TN_XCD, KNOB_COUNT };
 int tuning_knob(int which);
 
+// The K-split workspace of the persistent GEMMs (gemm_pairs8.hip / gemm_planes8.hip: fp32 partials of the left-over tiles + one arrival
+// counter per (tile, wave)).  CALLER-owned since ABI 7 (tt_linear_ksplit_workspace_bytes / tt_linear_ksplit_workspace_init): the counter block
+// sits at the start of the buffer and must be zero when a launch begins - the init call zeroes it once, every launch leaves it zero (the
+// wave that arrives last resets its counter).  A launch given no (or too small a) workspace does not split along K.
+struct KsplitWs { float* partials; int* counters; };
+size_t ksplit_ws_bytes();                                          // core.cpp: for the CURRENT device
+size_t ksplit_ws_counter_bytes();
+bool ksplit_ws_carve(void* ws, size_t bytes, KsplitWs* out);       // false: absent / too small / misaligned
+
 // ---- device helpers -------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -106,6 +115,12 @@ constexpr float kPairScale = 2048.0f, kPairInvScale = 0.00048828125f;
 __device__ __forceinline__ void split_pair(float v, _Float16& hi, _Float16& lo) {
   hi = (_Float16)v;
   lo = (_Float16)((v - (float)hi) * kPairScale);
+}
+// hi of a value beyond fp16's range (|x| > 65504) or of a non-finite one is an infinity / a NaN: the one way the "f16x3" mode can differ
+// from fp32 arithmetic.  Every kernel that PRODUCES pairs ORs this into the caller's range flag (include/timetuning_hip.h, "range flag").
+__device__ __forceinline__ bool pair_hi_bad(_Float16 hi) { return (__builtin_bit_cast(unsigned short, hi) & 0x7fffu) >= 0x7c00u; }
+__device__ __forceinline__ void range_flag_raise(int* flag, bool bad) {
+  if (flag && bad) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float join_pair(_Float16 hi, _Float16 lo) { return fmaf((float)lo, kPairInvScale, (float)hi); }
 // index of element i of a row-major array whose length is a multiple of 32, in the pair layout: hi at pair_index(i), lo 32 further

@@ -29,6 +29,17 @@ int device_cu_count() {
   return n;
 }
 
+// ---- the K-split workspace of the persistent GEMMs (common.hpp): [counters: CUs x 8 ints, padded to 256 bytes][partials: CUs x 8 waves x
+// 128 x 64 floats - the larger of the two kernels' wave tiles (gemm_planes8: 128 x 64, gemm_pairs8: 64 x 64)]
+size_t ksplit_ws_counter_bytes() { return (((size_t)device_cu_count() * 8 * sizeof(int)) + 255) / 256 * 256; }
+size_t ksplit_ws_bytes() { return ksplit_ws_counter_bytes() + (size_t)device_cu_count() * 8 * 128 * 64 * sizeof(float); }
+bool ksplit_ws_carve(void* ws, size_t bytes, KsplitWs* out) {
+  if (!ws || bytes < ksplit_ws_bytes() || !aligned16(ws)) return false;
+  out->counters = static_cast<int*>(ws);
+  out->partials = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + ksplit_ws_counter_bytes());
+  return true;
+}
+
 // ---- tuning knobs: read ONCE from the environment into atomics - a launch path never calls getenv (not safe against a
 // concurrent setenv from another Python thread, and a knob must not flip under a production run) - with an explicit setter for the A/B
 // tools and tests that compare settings inside one process.
@@ -61,7 +72,18 @@ extern "C" int tt_set_tuning_knob(const char* name, int value) {
 }
 
 extern "C" const char* tt_last_error(void) { return tt::g_err; }
-extern "C" int tt_abi_version(void) { return 6; }   // 6: tt_linear_bwd_weight_pairs_tn*, tt_split_pairs_dual_multi, tt_sinkhorn_local_*, pair attention at any N; 5: the fp16-pair entry points (tt_*_pairs*), tt_vit_params.planes == 2; 4: tt_vit_params.patch_wp; 3: the coarse entry points (tt_vit_forward, ...) and their parameter structs
+extern "C" int tt_abi_version(void) { return 7; }   // 7: caller-owned K-split workspace (tt_linear_ksplit_workspace_*; workspace arguments of tt_linear_fwd_pairs / _planes / tt_linear_bwd_data_pairs / _planes), the pair producers' range flag; 6: tt_linear_bwd_weight_pairs_tn*, tt_split_pairs_dual_multi, tt_sinkhorn_local_*, pair attention at any N; 5: the fp16-pair entry points (tt_*_pairs*), tt_vit_params.planes == 2; 4: tt_vit_params.patch_wp; 3: the coarse entry points (tt_vit_forward, ...) and their parameter structs
+
+extern "C" size_t tt_linear_ksplit_workspace_bytes(void) { return tt::ksplit_ws_bytes(); }
+extern "C" int tt_linear_ksplit_workspace_init(void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  tt::KsplitWs k;
+  TT_REQUIRE(tt::ksplit_ws_carve(workspace, workspace_bytes, &k), "linear_ksplit_workspace_init: null, misaligned or smaller than tt_linear_ksplit_workspace_bytes()");
+  if (hipMemsetAsync(k.counters, 0, tt::ksplit_ws_counter_bytes(), tt::as_stream(stream)) != hipSuccess) {
+    tt::set_error("linear_ksplit_workspace_init: hipMemsetAsync failed");
+    return TT_ELAUNCH;
+  }
+  return TT_OK;
+}
 
 extern "C" int tt_device_info(char* name, int cap) {
   int dev = 0;

@@ -30,8 +30,6 @@
 // two waves per SIMD.
 #include "common.hpp"
 #include <cstdlib>
-#include <mutex>
-#include <vector>
 
 namespace tt {
 
@@ -60,6 +58,7 @@ struct Q8Args {
                           // divided by it; null: none
   float* ks_ws;           // [ks_R][ks_S][8 waves][4096]
   int* ks_cnt;            // [ks_R][8], zero between launches (the finishing wave resets its counter)
+  int* range_flag;        // device word or null: set to 1 when a pair output's hi leaves fp16's range (common.hpp: pair_hi_bad)
 };
 
 __device__ __forceinline__ void q8_dma16(const void* base, unsigned char* lds_dst, int voffset, int soffset) {
@@ -494,6 +493,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
     }
     constexpr int NT = 4;   // MFMA tiles in the order (ha, mt): a half item ends after the first two
     const int nt = half ? NT / 2 : NT;
+    bool range_bad = false;
     const float inv_s = g.out_scale ? 1.0f / *g.out_scale : 1.0f;   // exact: S is a power of two
     // MFMA tile j = (ha, mt): output rows mrow(j) .., columns ncol(j) .. (+ 32 each)
     auto mrow = [&](int j) { return row0 + (j >> 1) * 128 + (SQ ? wr * 32 : wr * 64 + (j & 1) * 32); };
@@ -584,6 +584,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
                 split_pair(v[e], hi_, lo_);
                 qh[e] = hi_;
                 ql[e] = lo_;
+                if (m < g.M) range_bad |= pair_hi_bad(hi_);   // (rows beyond M are dropped by the store's range check)
               }
               // pair group of this wave's 32 columns: byte offset of (m, nbase) = (m * 2 N + 2 nbase) * 2; hi then lo (64 bytes on)
               const unsigned off = ((unsigned)m * (unsigned)g.N + (unsigned)nbase) * 4u + (unsigned)(q * CW + 8 * cc) * 2u;
@@ -601,6 +602,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
     // bound of what was really issued (allowing fewer only waits for a few of the oldest epilogue operations as well).
     post_epi = POST;
     post_half = half;
+    if constexpr (!F32OUT) range_flag_raise(g.range_flag, range_bad);
   };
 
   // ---- K-split item: this wave's partial -> workspace; the wave arriving last at the (tile, wave) counter sums the slices' partials in
@@ -735,7 +737,8 @@ struct Q8Plan {
   int ntn, ncu, n_full, n_half, ks_S, ks_R;
   long long ntiles;
 };
-static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_pre, bool has_gelu_pre, int M, int N, int K, int act, Q8Plan* pl) {
+static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_pre, bool has_gelu_pre, int M, int N, int K, int act, Q8Plan* pl,
+                       bool allow_ksplit = true) {
   if (N % 128 != 0 || K % 96 != 0 || M < 256) return -1;
   int epi = -1;
   if (has_gelu_pre) {
@@ -764,7 +767,7 @@ static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_p
   // without it go to the small-tile kernel below half a round; measured: no gain); cap = most slices per tile (0: 6).
   const int ksplit_knob = tuning_knob(KNOB_Q8_KSPLIT) % 10, ksplit_cap = tuning_knob(KNOB_Q8_KSPLIT) / 10;
   int ks_S = 0;
-  if (ksplit_knob != 0 && rem > 0 && (R > 0 || ksplit_knob >= 2)) {
+  if (allow_ksplit && ksplit_knob != 0 && rem > 0 && (R > 0 || ksplit_knob >= 2)) {
     const int U = K / 96, nk = K / 32;
     int S = (int)(ncu_dev / rem);
     if (S > U) S = U;
@@ -791,32 +794,6 @@ static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_p
   return epi;
 }
 
-// The K-split workspace: one per (device, stream), allocated at the first launch that needs it and kept (32 MB + the counters).
-struct Q8Ws { int dev; hipStream_t s; float* ws; int* cnt; };
-static std::mutex q8_ws_mu;
-static std::vector<Q8Ws> q8_ws_list;
-static int q8_workspace(hipStream_t s, float** ws, int** cnt) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { set_error("gemm_pairs8: hipGetDevice failed"); return TT_ELAUNCH; }
-  std::lock_guard<std::mutex> lock(q8_ws_mu);
-  for (const Q8Ws& b : q8_ws_list)
-    if (b.dev == dev && b.s == s) { *ws = b.ws; *cnt = b.cnt; return TT_OK; }
-  Q8Ws b{dev, s, nullptr, nullptr};
-  const size_t slices = (size_t)device_cu_count();   // ks_R * ks_S <= CUs
-  if (hipMalloc(reinterpret_cast<void**>(&b.ws), slices * 8 * 4096 * sizeof(float)) != hipSuccess) {
-    set_error("gemm_pairs8: cannot allocate the K-split workspace");
-    return TT_ELAUNCH;
-  }
-  if (hipMalloc(reinterpret_cast<void**>(&b.cnt), slices * 8 * sizeof(int)) != hipSuccess || hipMemset(b.cnt, 0, slices * 8 * sizeof(int)) != hipSuccess) {
-    (void)hipFree(b.ws);
-    set_error("gemm_pairs8: cannot allocate the K-split counters");
-    return TT_ELAUNCH;
-  }
-  q8_ws_list.push_back(b);
-  *ws = b.ws; *cnt = b.cnt;
-  return TT_OK;
-}
-
 int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, int has_pairs, int has_pre, int has_gelu_pre) {
   Q8Plan pl;
   return pairs8_plan(has_residual != 0, has_y != 0, has_pairs != 0, has_pre != 0, has_gelu_pre != 0, M, N, K, act, &pl) >= 0;
@@ -826,19 +803,20 @@ int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, 
 // then takes the general kernel), < 0 on a launch error.  pre_out: the fp32 pre-activation of a GELU layer (its y must then be pairs only);
 // gelu_pre: the pre-activation whose gelu' multiplies a data-gradient product.
 int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out, void* y_pairs,
-               const float* gelu_pre, const float* out_scale, int M, int N, int K, int act, hipStream_t s) {
+               const float* gelu_pre, const float* out_scale, int M, int N, int K, int act, void* ksplit_ws, size_t ksplit_ws_bytes_, int* range_flag,
+               hipStream_t s) {
   Q8Plan pl;
-  const int epi = pairs8_plan(residual != nullptr, y != nullptr, y_pairs != nullptr, pre_out != nullptr, gelu_pre != nullptr, M, N, K, act, &pl);
+  // the K-split needs the caller's workspace (tt_linear_ksplit_workspace_bytes, counters zeroed by tt_linear_ksplit_workspace_init);
+  // without one the left-over tiles are cut into halves / dealt round-robin
+  KsplitWs kw{nullptr, nullptr};
+  const bool have_ws = ksplit_ws_carve(ksplit_ws, ksplit_ws_bytes_, &kw);
+  const int epi = pairs8_plan(residual != nullptr, y != nullptr, y_pairs != nullptr, pre_out != nullptr, gelu_pre != nullptr, M, N, K, act, &pl, have_ws);
   if (epi < 0) return 1;
-  float* ks_ws = nullptr;
-  int* ks_cnt = nullptr;
-  if (pl.ks_S >= 2) {
-    const int rc = q8_workspace(s, &ks_ws, &ks_cnt);
-    if (rc != TT_OK) return rc;
-  }
+  float* ks_ws = pl.ks_S >= 2 ? kw.partials : nullptr;
+  int* ks_cnt = pl.ks_S >= 2 ? kw.counters : nullptr;
   Q8Args g{static_cast<const _Float16*>(x_pairs), static_cast<const _Float16*>(w_pairs), M, N, K, bias, gelu_pre ? gelu_pre : residual,
            pre_out ? pre_out : y, static_cast<_Float16*>(y_pairs), pl.ntn, (int)pl.ntiles, pl.ncu, pl.n_full, pl.n_half, q8_order_mode(),
-           pl.ks_S, pl.ks_R, out_scale, ks_ws, ks_cnt};
+           pl.ks_S, pl.ks_R, out_scale, ks_ws, ks_cnt, range_flag};
 #ifdef TT_Q8_ABLATE   // timing-study build only: TT_Q8_DBG selects a crippled instantiation
   {
     const char* e = getenv("TT_Q8_DBG");

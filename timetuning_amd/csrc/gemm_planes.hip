@@ -63,6 +63,7 @@ struct PlaneArgs {
   long long split_stride;
   const float* out_scale; // PAIR: device scalar S (a power of two) by which an operand was scaled before its split (a gradient: see
                           // transpose_pairs_tile) - the product is divided by it; null: none
+  int* range_flag;        // PAIR outputs: device word set to 1 when an output's hi leaves fp16's range (common.hpp pair_hi_bad); null: none
 };
 
 // x -> up to three bf16 planes with x = p0 + p1 + p2 (exact when 3 planes are taken and no exponent underflow)
@@ -358,16 +359,19 @@ __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(Pl
           if (g.po > 0) {   // pairs [M][2 N]: this thread's 8 columns lie in one group of 32
             typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
             f16x8 qh, ql;
+            bool bad = false;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               _Float16 hi_, lo_;
               split_pair(v[e], hi_, lo_);
               qh[e] = hi_;
               ql[e] = lo_;
+              bad |= pair_hi_bad(hi_);
             }
             _Float16* dst = reinterpret_cast<_Float16*>(g.Cp) + (size_t)m * 2 * g.N + pair_index(n);
             *reinterpret_cast<f16x8*>(dst) = qh;
             *reinterpret_cast<f16x8*>(dst + 32) = ql;
+            range_flag_raise(g.range_flag, bad);
           }
         } else if (g.po > 0) {
           bf16x8 q0, q1, q2;
@@ -459,8 +463,9 @@ __global__ __launch_bounds__(256) void transpose_planes_kernel(const float* __re
 }
 
 // ---- f32 <-> fp16 pairs (common.hpp split_pair): groups of 32 elements as [hi x 32][lo x 32]; a thread converts 8 elements
-__global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long long n8) {
+__global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long long n8, int* range_flag) {
   typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  bool bad = false;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
     float v[8];
     *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(src + 8 * i);
@@ -472,11 +477,13 @@ __global__ __launch_bounds__(256) void split_pairs_kernel(const float* __restric
       split_pair(v[e], hi_, lo_);
       qh[e] = hi_;
       ql[e] = lo_;
+      bad |= pair_hi_bad(hi_);
     }
     _Float16* d = dst + pair_index(8 * i);
     *reinterpret_cast<f16x8*>(d) = qh;
     *reinterpret_cast<f16x8*>(d + 32) = ql;
   }
+  range_flag_raise(range_flag, bad);
 }
 __global__ __launch_bounds__(256) void join_pairs_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, long long n8) {
   typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -492,7 +499,8 @@ __global__ __launch_bounds__(256) void join_pairs_kernel(const _Float16* __restr
 }
 
 int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out, void* y_pairs,
-               const float* gelu_pre, const float* out_scale, int M, int N, int K, int act, hipStream_t s);          // gemm_pairs8.hip
+               const float* gelu_pre, const float* out_scale, int M, int N, int K, int act, void* ksplit_ws, size_t ksplit_ws_bytes_, int* range_flag,
+               hipStream_t s);                                                                                        // gemm_pairs8.hip
 int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, int has_pairs, int has_pre, int has_gelu_pre);
 
 // ---- transposed pairs: the operands of the backward products in the "f16x3" mode (reduction index contiguous, in pair groups).
@@ -533,7 +541,7 @@ template <bool SRC_PAIRS, bool ROW, bool SUM>
 __device__ __forceinline__ void transpose_pairs_tile(const void* __restrict__ src_, _Float16* __restrict__ dst_t, _Float16* __restrict__ dst_row,
                                                      int R, int C, int Rpad, float* __restrict__ partial, int bx, int by,
                                                      const float* __restrict__ amax_part = nullptr, int n_part = 0,
-                                                     float* __restrict__ scale_out = nullptr) {
+                                                     float* __restrict__ scale_out = nullptr, int* range_flag = nullptr) {
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   __shared__ _Float16 th[64][66], tl[64][66];   // [r][c] halves of the tile (row stride 132 bytes: conflict-free column walks)
   __shared__ float red[4][64];
@@ -565,11 +573,13 @@ __device__ __forceinline__ void transpose_pairs_tile(const void* __restrict__ sr
       if (scale_out && bx == 0 && by == 0 && threadIdx.x == 0) *scale_out = S;
     }
     float csum = 0.f;
+    bool bad = false;
     for (int i = ty; i < 64; i += 4) {
       const int r = r0 + i, c = c0 + tx;
       const float v = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
       _Float16 hi, lo;
       split_pair(v * S, hi, lo);
+      bad |= pair_hi_bad(hi);
       th[i][tx] = hi;
       tl[i][tx] = lo;
       csum += v;
@@ -582,6 +592,7 @@ __device__ __forceinline__ void transpose_pairs_tile(const void* __restrict__ sr
       }
     }
     if constexpr (SUM) red[ty][tx] = csum;
+    range_flag_raise(range_flag, bad);
   }
   __syncthreads();
   if constexpr (SUM) {
@@ -604,8 +615,9 @@ __device__ __forceinline__ void transpose_pairs_tile(const void* __restrict__ sr
 template <bool SRC_PAIRS, bool ROW, bool SUM>
 __global__ __launch_bounds__(256) void transpose_pairs_kernel(const void* __restrict__ src_, _Float16* __restrict__ dst_t, _Float16* __restrict__ dst_row,
                                                               int R, int C, int Rpad, float* __restrict__ partial,
-                                                              const float* __restrict__ amax_part, int n_part, float* __restrict__ scale_out) {
-  transpose_pairs_tile<SRC_PAIRS, ROW, SUM>(src_, dst_t, dst_row, R, C, Rpad, partial, blockIdx.x, blockIdx.y, amax_part, n_part, scale_out);
+                                                              const float* __restrict__ amax_part, int n_part, float* __restrict__ scale_out,
+                                                              int* range_flag) {
+  transpose_pairs_tile<SRC_PAIRS, ROW, SUM>(src_, dst_t, dst_row, R, C, Rpad, partial, blockIdx.x, blockIdx.y, amax_part, n_part, scale_out, range_flag);
 }
 
 // The same for a TABLE of fp32 matrices in one launch: the pair operands (row pairs for the forward / weight-gradient products, transposed
@@ -618,19 +630,20 @@ struct PairTable {
   int R[MAXN], C[MAXN], Rpad[MAXN];
   int tile0[MAXN + 1];   // first workgroup of each entry
   int n;
+  int* range_flag;
 };
 __global__ __launch_bounds__(256) void split_pairs_dual_multi_kernel(PairTable tb) {
   int e = 0;
   while (e + 1 < tb.n && (int)blockIdx.x >= tb.tile0[e + 1]) ++e;
   const int tile = blockIdx.x - tb.tile0[e], tr = (tb.Rpad[e] + 63) / 64;
-  if (tb.row[e]) transpose_pairs_tile<false, true, false>(tb.src[e], tb.t[e], tb.row[e], tb.R[e], tb.C[e], tb.Rpad[e], nullptr, tile % tr, tile / tr);
-  else transpose_pairs_tile<false, false, false>(tb.src[e], tb.t[e], nullptr, tb.R[e], tb.C[e], tb.Rpad[e], nullptr, tile % tr, tile / tr);
+  if (tb.row[e]) transpose_pairs_tile<false, true, false>(tb.src[e], tb.t[e], tb.row[e], tb.R[e], tb.C[e], tb.Rpad[e], nullptr, tile % tr, tile / tr, nullptr, 0, nullptr, tb.range_flag);
+  else transpose_pairs_tile<false, false, false>(tb.src[e], tb.t[e], nullptr, tb.R[e], tb.C[e], tb.Rpad[e], nullptr, tile % tr, tile / tr, nullptr, 0, nullptr, tb.range_flag);
 }
 
 int launch_splitk_reduce(const float* partial, float* out, long long n, int splits, long long stride, hipStream_t s);  // gemm_f32.hip
 int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes, const float* bias,
                 const float* residual, float* y, void* y_planes, long long y_plane_stride, int y_nplanes, int M, int N, int K, int act,
-                hipStream_t s);                                                                                       // gemm_planes8.hip
+                void* ksplit_ws, size_t ksplit_ws_bytes_, hipStream_t s);                                             // gemm_planes8.hip
 int planes8_would_run(int planes, int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int y_nplanes);
 
 
@@ -675,7 +688,8 @@ __global__ __launch_bounds__(256) void patch_rows_planes_kernel(const float* __r
 __global__ __launch_bounds__(256) void patch_rows_pairs_kernel(const float* __restrict__ img, const int* __restrict__ frame_map,
                                                                  const float* __restrict__ bias, const float* __restrict__ cls,
                                                                  const float* __restrict__ pos, _Float16* __restrict__ a,
-                                                                 float* __restrict__ tokens, int C, int H, int W, int P, int D, int gw, int n) {
+                                                                 float* __restrict__ tokens, int C, int H, int W, int P, int D, int gw, int n,
+                                                                 int* range_flag) {
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   const int m = blockIdx.x, f = m / (n + 1), t = m - f * (n + 1);
   const int K = C * P * P;
@@ -694,15 +708,18 @@ __global__ __launch_bounds__(256) void patch_rows_pairs_kernel(const float* __re
   const int gy = (t - 1) / gw, gx = (t - 1) - gy * gw;
   const float* base = img + ((long long)src * C * H + gy * P) * W + gx * P;
   const int P4 = P / 4;
+  bool bad = false;
   for (int i = threadIdx.x; i < K / 4; i += 256) {
     const int x4 = i % P4, cy = i / P4, y = cy % P, c = cy / P;
     const float4 v = *reinterpret_cast<const float4*>(base + ((long long)c * H + y) * W + 4 * x4);
     _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
     split_pair(v.x, h0, l0); split_pair(v.y, h1, l1); split_pair(v.z, h2, l2); split_pair(v.w, h3, l3);
+    bad = bad || pair_hi_bad(h0) || pair_hi_bad(h1) || pair_hi_bad(h2) || pair_hi_bad(h3);
     _Float16* p = arow + pair_index(4 * i);   // k = 4 i .. 4 i + 3 lie in one group of 32
     *reinterpret_cast<f16x4*>(p) = (f16x4){h0, h1, h2, h3};
     *reinterpret_cast<f16x4*>(p + 32) = (f16x4){l0, l1, l2, l3};
   }
+  range_flag_raise(range_flag, bad);
   for (int i = threadIdx.x; i < D / 4; i += 256) trow[i] = prow[i];
 }
 
@@ -753,7 +770,7 @@ extern "C" int tt_split_planes(const float* src, void* dst_planes, long long pla
 static int linear_planes_impl(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes,
                               const float* bias, const float* residual, float* y, float* pre_out, void* y_planes,
                               long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, const float* gelu_pre, int splits,
-                              long long split_stride, tt_stream_t stream);
+                              long long split_stride, tt_stream_t stream, void* ksplit_ws = nullptr, size_t ksplit_ws_bytes_ = 0);
 
 extern "C" int tt_linear_fwd_planes_route(int planes, int M, int N, int K, int act, int has_bias, int has_residual, int has_y, int y_nplanes,
                                           int has_pre_out) {
@@ -763,17 +780,19 @@ extern "C" int tt_linear_fwd_planes_route(int planes, int M, int N, int K, int a
 
 extern "C" int tt_linear_fwd_planes(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes,
                                     const float* bias, const float* residual, float* y, float* pre_out, void* y_planes,
-                                    long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, tt_stream_t stream) {
+                                    long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, void* workspace, size_t workspace_bytes,
+                                    tt_stream_t stream) {
   return linear_planes_impl(x_planes, x_plane_stride, w_planes, w_plane_stride, planes, bias, residual, y, pre_out, y_planes, y_plane_stride,
-                            y_nplanes, M, N, K, act, nullptr, 1, 0, stream);
+                            y_nplanes, M, N, K, act, nullptr, 1, 0, stream, workspace, workspace_bytes);
 }
 
 // dx[M,K] = dy[M,N] @ w[N,K] (* gelu'(gelu_pre)): dy in planes [M][N], the weight TRANSPOSED in planes wT [K][N] (tt_transpose_planes)
 extern "C" int tt_linear_bwd_data_planes(const void* dy_planes, long long dy_plane_stride, const void* wT_planes, long long wT_plane_stride,
-                                         int planes, const float* gelu_pre, float* dx, int M, int N, int K, tt_stream_t stream) {
+                                         int planes, const float* gelu_pre, float* dx, int M, int N, int K, void* workspace, size_t workspace_bytes,
+                                         tt_stream_t stream) {
   TT_REQUIRE(dx, "linear_bwd_data_planes: null output");
   return linear_planes_impl(dy_planes, dy_plane_stride, wT_planes, wT_plane_stride, planes, nullptr, nullptr, dx, nullptr, nullptr, 0, 0, M, K, N, 0,
-                            gelu_pre, 1, 0, stream);
+                            gelu_pre, 1, 0, stream, workspace, workspace_bytes);
 }
 
 // dw[N,K] = dy[M,N]^T @ x[M,K]: both operands TRANSPOSED and zero-padded along the reduction, dyT [N][Mpad], xT [K][Mpad].
@@ -809,7 +828,7 @@ extern "C" int tt_linear_bwd_weight_planes(const void* dyT_planes, long long dyT
 static int linear_planes_impl(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes,
                               const float* bias, const float* residual, float* y, float* pre_out, void* y_planes,
                               long long y_plane_stride, int y_nplanes, int M, int N, int K, int act, const float* gelu_pre, int splits,
-                              long long split_stride, tt_stream_t stream) {
+                              long long split_stride, tt_stream_t stream, void* ksplit_ws, size_t ksplit_ws_bytes_) {
   TT_REQUIRE(x_planes && w_planes && (y || y_planes), "linear_fwd_planes: null operand / no output");
   TT_REQUIRE(planes >= 1 && planes <= 3 && y_nplanes >= 0 && y_nplanes <= 3 && (y_nplanes == 0) == (y_planes == nullptr),
              "linear_fwd_planes: planes must be 1..3 and y_nplanes 0..3 (0 iff y_planes is null)");
@@ -828,7 +847,7 @@ static int linear_planes_impl(const void* x_planes, long long x_plane_stride, co
   // whole-tile forward products on a grid that fills the chip: the persistent 8-phase kernel (gemm_planes8.hip)
   if (variant == 0 && !pre_out && !gelu_pre && splits == 1) {
     const int rc = planes8_try(x_planes, x_plane_stride, w_planes, w_plane_stride, planes, bias, residual, y, y_planes, y_plane_stride, y_nplanes, M, N,
-                               K, act, s);
+                               K, act, ksplit_ws, ksplit_ws_bytes_, s);
     if (rc <= 0) return rc;
   }
   // tile: 128 x 128 when the grid still fills the chip more than twice over, else 64-row / 64-column tiles (ViT-S/16's N = 384
@@ -883,12 +902,12 @@ static int linear_planes_impl(const void* x_planes, long long x_plane_stride, co
 
 
 // ---- fp16-pair operands (the "f16x3" mode) ------------------------------------------------------------------------------------
-extern "C" int tt_split_pairs(const float* src, void* dst_pairs, long long n, tt_stream_t stream) {
+extern "C" int tt_split_pairs(const float* src, void* dst_pairs, long long n, int* range_flag, tt_stream_t stream) {
   TT_REQUIRE(src && dst_pairs && n > 0, "split_pairs: bad arguments");
   TT_REQUIRE(n % 32 == 0 && aligned16(src) && aligned16(dst_pairs), "split_pairs: n must be a multiple of 32 and the buffers 16-byte aligned");
   long long blocks = (n / 8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(split_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, static_cast<_Float16*>(dst_pairs), n / 8);
+  hipLaunchKernelGGL(split_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, static_cast<_Float16*>(dst_pairs), n / 8, range_flag);
   TT_CHECK_LAUNCH("split_pairs");
   return TT_OK;
 }
@@ -907,7 +926,8 @@ extern "C" int tt_join_pairs(const void* src_pairs, float* dst, long long n, tt_
 // y_pairs.  splits > 1: plain fp32 partials of a K split (weight gradients).
 static int linear_pairs_impl(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out,
                              void* y_pairs, int M, int N, int K, int act, const float* gelu_pre, int splits, long long split_stride,
-                             tt_stream_t stream, const float* out_scale = nullptr) {
+                             tt_stream_t stream, const float* out_scale = nullptr, void* ksplit_ws = nullptr, size_t ksplit_ws_bytes_ = 0,
+                             int* range_flag = nullptr) {
   TT_REQUIRE(x_pairs && w_pairs && (y || y_pairs), "linear_fwd_pairs: null operand / no output");
   TT_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 32 == 0, "linear_fwd_pairs: need N %% 64 == 0 and K %% 32 == 0 (got N=%d K=%d)", N, K);
   auto ok16 = [](const void* p) { return p == nullptr || aligned16(p); };
@@ -918,12 +938,13 @@ static int linear_pairs_impl(const void* x_pairs, const void* w_pairs, const flo
   hipStream_t s = as_stream(stream);
   const bool no8 = tuning_knob(KNOB_PAIRS_NO8) != 0;   // tuning aid: the general kernel everywhere
   if (!no8 && splits == 1) {
-    const int rc = pairs8_try(x_pairs, w_pairs, bias, residual, y, pre_out, y_pairs, gelu_pre, out_scale, M, N, K, act, s);
+    const int rc = pairs8_try(x_pairs, w_pairs, bias, residual, y, pre_out, y_pairs, gelu_pre, out_scale, M, N, K, act, ksplit_ws, ksplit_ws_bytes_,
+                              range_flag, s);
     if (rc <= 0) return rc;
   }
   // the general kernel sees rows of 2 K 16-bit elements in K-tiles of 64 (= one pair group)
   PlaneArgs g{static_cast<const __bf16*>(x_pairs), static_cast<const __bf16*>(w_pairs), 0, 0, M, N, 2 * K, bias, residual, y,
-              pre_out, static_cast<__bf16*>(y_pairs), 0, y_pairs ? 1 : 0, act, gelu_pre, splits, split_stride, out_scale};
+              pre_out, static_cast<__bf16*>(y_pairs), 0, y_pairs ? 1 : 0, act, gelu_pre, splits, split_stride, out_scale, range_flag};
   const long long t128 = (long long)((M + 127) / 128) * (N / 128);
   const bool big = (N % 128 == 0) && t128 * splits >= 3 * 256;
   const bool wide = (N % 128 == 0) && (long long)((M + 63) / 64) * (N / 128) * splits >= 2 * 256;
@@ -940,8 +961,10 @@ extern "C" int tt_linear_fwd_pairs_route(int M, int N, int K, int act, int has_b
 }
 
 extern "C" int tt_linear_fwd_pairs(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out,
-                                   void* y_pairs, int M, int N, int K, int act, tt_stream_t stream) {
-  return linear_pairs_impl(x_pairs, w_pairs, bias, residual, y, pre_out, y_pairs, M, N, K, act, nullptr, 1, 0, stream);
+                                   void* y_pairs, int M, int N, int K, int act, void* workspace, size_t workspace_bytes, int* range_flag,
+                                   tt_stream_t stream) {
+  return linear_pairs_impl(x_pairs, w_pairs, bias, residual, y, pre_out, y_pairs, M, N, K, act, nullptr, 1, 0, stream, nullptr, workspace, workspace_bytes,
+                           range_flag);
 }
 
 // fp32 [R][C] -> transposed pairs [C][2 Rpad] (+ row-major pairs [R][2 C], + fp32 column sums); see transpose_pairs_kernel.
@@ -953,7 +976,7 @@ extern "C" size_t tt_split_pairs_dual_workspace_bytes(int R, int C, int Rpad) {
 }
 
 extern "C" int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, float* scale_out, int R, int C, int Rpad,
-                                   void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+                                   void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream) {
   TT_REQUIRE(src && (dst_t_pairs || dst_row_pairs) && R > 0 && C > 0 && Rpad >= R && Rpad % 32 == 0,
              "split_pairs_dual: bad arguments (an output, Rpad a multiple of 32)");
   TT_REQUIRE(!dst_row_pairs || C % 32 == 0, "split_pairs_dual: row-major pairs need C %% 32 == 0 (got %d)", C);
@@ -974,10 +997,10 @@ extern "C" int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* ds
     n_part = (int)((n + 4095) / 4096 < kAmaxParts ? (n + 4095) / 4096 : kAmaxParts);
     hipLaunchKernelGGL(amax_partial_kernel, dim3(n_part), dim3(256), 0, s, src, n, amax_part);
   }
-  if (dr && colsum) hipLaunchKernelGGL((transpose_pairs_kernel<false, true, true>), grid, block, 0, s, src, dt, dr, R, C, Rpad, partial, amax_part, n_part, scale_out);
-  else if (dr) hipLaunchKernelGGL((transpose_pairs_kernel<false, true, false>), grid, block, 0, s, src, dt, dr, R, C, Rpad, nullptr, amax_part, n_part, scale_out);
-  else if (colsum) hipLaunchKernelGGL((transpose_pairs_kernel<false, false, true>), grid, block, 0, s, src, dt, dr, R, C, Rpad, partial, amax_part, n_part, scale_out);
-  else hipLaunchKernelGGL((transpose_pairs_kernel<false, false, false>), grid, block, 0, s, src, dt, dr, R, C, Rpad, nullptr, amax_part, n_part, scale_out);
+  if (dr && colsum) hipLaunchKernelGGL((transpose_pairs_kernel<false, true, true>), grid, block, 0, s, src, dt, dr, R, C, Rpad, partial, amax_part, n_part, scale_out, range_flag);
+  else if (dr) hipLaunchKernelGGL((transpose_pairs_kernel<false, true, false>), grid, block, 0, s, src, dt, dr, R, C, Rpad, nullptr, amax_part, n_part, scale_out, range_flag);
+  else if (colsum) hipLaunchKernelGGL((transpose_pairs_kernel<false, false, true>), grid, block, 0, s, src, dt, dr, R, C, Rpad, partial, amax_part, n_part, scale_out, range_flag);
+  else hipLaunchKernelGGL((transpose_pairs_kernel<false, false, false>), grid, block, 0, s, src, dt, dr, R, C, Rpad, nullptr, amax_part, n_part, scale_out, range_flag);
   TT_CHECK_LAUNCH("split_pairs_dual");
   if (colsum) return launch_colsum_fold(partial, colsum, (Rpad + 63) / 64, C, s);
   return TT_OK;
@@ -985,11 +1008,12 @@ extern "C" int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* ds
 
 // n fp32 matrices [R_i][C_i] -> row pairs and / or transposed pairs [C_i][2 Rpad_i] each, ONE launch per 32 of them
 extern "C" int tt_split_pairs_dual_multi(const float* const* src, void* const* dst_t_pairs, void* const* dst_row_pairs, const int* R, const int* C,
-                                         const int* Rpad, int n, tt_stream_t stream) {
+                                         const int* Rpad, int n, int* range_flag, tt_stream_t stream) {
   TT_REQUIRE(src && dst_t_pairs && dst_row_pairs && R && C && Rpad && n >= 0, "split_pairs_dual_multi: bad arguments");
   for (int i0 = 0; i0 < n; i0 += PairTable::MAXN) {
     PairTable tb;
     tb.n = n - i0 < PairTable::MAXN ? n - i0 : PairTable::MAXN;
+    tb.range_flag = range_flag;
     int tiles = 0;
     for (int i = 0; i < tb.n; ++i) {
       const int j = i0 + i;
@@ -1019,7 +1043,7 @@ extern "C" int tt_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int 
   TT_REQUIRE((reinterpret_cast<uintptr_t>(dst_t_pairs) & 7u) == 0, "transpose_pairs: the output must be 8-byte aligned");
   hipLaunchKernelGGL((transpose_pairs_kernel<true, false, false>), dim3((Rpad + 63) / 64, (C + 63) / 64), dim3(256), 0, as_stream(stream), src_pairs,
                      static_cast<_Float16*>(dst_t_pairs), static_cast<_Float16*>(nullptr), R, C, Rpad, static_cast<float*>(nullptr),
-                     static_cast<const float*>(nullptr), 0, static_cast<float*>(nullptr));
+                     static_cast<const float*>(nullptr), 0, static_cast<float*>(nullptr), static_cast<int*>(nullptr));
   TT_CHECK_LAUNCH("transpose_pairs");
   return TT_OK;
 }
@@ -1027,9 +1051,9 @@ extern "C" int tt_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int 
 // dx[M,K] = dy[M,N] @ w[N,K] (* gelu'(gelu_pre)): dy in pairs [M][2 N], the weight TRANSPOSED in pairs wT [K][2 N].
 // dy_scale (device scalar or null): the pairs hold dy * S (tt_split_pairs_dual's scale_out) - the product is divided by S.
 extern "C" int tt_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, const float* dy_scale, int M,
-                                        int N, int K, tt_stream_t stream) {
+                                        int N, int K, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
   TT_REQUIRE(dx, "linear_bwd_data_pairs: null output");
-  return linear_pairs_impl(dy_pairs, wT_pairs, nullptr, nullptr, dx, nullptr, nullptr, M, K, N, 0, gelu_pre, 1, 0, stream, dy_scale);
+  return linear_pairs_impl(dy_pairs, wT_pairs, nullptr, nullptr, dx, nullptr, nullptr, M, K, N, 0, gelu_pre, 1, 0, stream, dy_scale, workspace, workspace_bytes);
 }
 
 // dw[N,K] = dy[M,N]^T @ x[M,K]: both operands transposed in pairs, dyT [N][2 Mpad], xT [K][2 Mpad] (zero beyond M).  Split-K over Mpad
@@ -1059,9 +1083,20 @@ extern "C" int tt_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_
   return launch_splitk_reduce(part, dw, (long long)N * K, s, (long long)N * K, as_stream(stream));
 }
 
+// workspace: the im2col rows (256-byte rounded), then the GEMM's K-split block (common.hpp KsplitWs; its counters are zeroed by the call)
+static size_t patch_rows_bytes(int F, int C, int H, int W, int P, int elem) {
+  return ((size_t)F * (1 + (size_t)(H / P) * (W / P)) * C * P * P * elem + 255) / 256 * 256;
+}
+static int patch_ksplit_init(void* ws, tt_stream_t stream) {
+  if (hipMemsetAsync(ws, 0, ksplit_ws_counter_bytes(), as_stream(stream)) != hipSuccess) {
+    set_error("patch_embed: hipMemsetAsync of the K-split counters failed");
+    return TT_ELAUNCH;
+  }
+  return TT_OK;
+}
 extern "C" size_t tt_patch_embed_planes_workspace_bytes(int F, int C, int H, int W, int P) {
   if (F <= 0 || C <= 0 || P <= 0 || H < P || W < P) return 0;
-  return (size_t)F * (1 + (size_t)(H / P) * (W / P)) * C * P * P * 2;
+  return patch_rows_bytes(F, C, H, W, P, 2) + ksplit_ws_bytes();
 }
 
 extern "C" int tt_patch_embed_fwd_planes(const float* img, const int32_t* frame_map, const void* w_planes, const float* bias, const float* cls,
@@ -1079,18 +1114,23 @@ extern "C" int tt_patch_embed_fwd_planes(const float* img, const int32_t* frame_
   hipLaunchKernelGGL(patch_rows_planes_kernel, dim3((unsigned)M), dim3(256), 0, as_stream(stream), img, frame_map, bias, cls, pos,
                      static_cast<__bf16*>(workspace), tokens, C, H, W, P, D, W / P, n);
   TT_CHECK_LAUNCH("patch_embed_planes.rows");
-  return tt_linear_fwd_planes(workspace, M * K, w_planes, (long long)D * K, 1, bias, tokens, tokens, nullptr, nullptr, 0, 0, (int)M, D, K, 0, stream);
+  void* kws = static_cast<unsigned char*>(workspace) + patch_rows_bytes(F, C, H, W, P, 2);
+  const int rc = patch_ksplit_init(kws, stream);
+  if (rc != TT_OK) return rc;
+  return tt_linear_fwd_planes(workspace, M * K, w_planes, (long long)D * K, 1, bias, tokens, tokens, nullptr, nullptr, 0, 0, (int)M, D, K, 0, kws,
+                              ksplit_ws_bytes(), stream);
 }
 
-// prepare_tokens on fp16-pair operands (the "f16x3" mode): w_pairs [D][2 C P P]; workspace: the im2col rows in pairs, F (n + 1) x C P P x 4 bytes
+// prepare_tokens on fp16-pair operands (the "f16x3" mode): w_pairs [D][2 C P P]; workspace: the im2col rows in pairs, F (n + 1) x C P P x 4 bytes,
+// then the GEMM's K-split block
 extern "C" size_t tt_patch_embed_pairs_workspace_bytes(int F, int C, int H, int W, int P) {
   if (F <= 0 || C <= 0 || P <= 0 || H < P || W < P) return 0;
-  return (size_t)F * (1 + (size_t)(H / P) * (W / P)) * C * P * P * 4;
+  return patch_rows_bytes(F, C, H, W, P, 4) + ksplit_ws_bytes();
 }
 
 extern "C" int tt_patch_embed_fwd_pairs(const float* img, const int32_t* frame_map, const void* w_pairs, const float* bias, const float* cls,
                                         const float* pos, float* tokens, int F, int C, int H, int W, int P, int D, void* workspace,
-                                        size_t workspace_bytes, tt_stream_t stream) {
+                                        size_t workspace_bytes, int* range_flag, tt_stream_t stream) {
   TT_REQUIRE(img && w_pairs && bias && cls && pos && tokens && workspace, "patch_embed_pairs: null pointer");
   TT_REQUIRE(F > 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0, "patch_embed_pairs: H, W must be multiples of the patch size");
   const int n = (H / P) * (W / P), K = C * P * P;
@@ -1101,7 +1141,10 @@ extern "C" int tt_patch_embed_fwd_pairs(const float* img, const int32_t* frame_m
   TT_REQUIRE(M * (long long)(K > D ? K : D) < (1ll << 31), "patch_embed_pairs: F (n + 1) max(C P P, D) exceeds the int range");
   TT_REQUIRE(workspace_bytes >= tt_patch_embed_pairs_workspace_bytes(F, C, H, W, P), "patch_embed_pairs: workspace too small");
   hipLaunchKernelGGL(patch_rows_pairs_kernel, dim3((unsigned)M), dim3(256), 0, as_stream(stream), img, frame_map, bias, cls, pos,
-                     static_cast<_Float16*>(workspace), tokens, C, H, W, P, D, W / P, n);
+                     static_cast<_Float16*>(workspace), tokens, C, H, W, P, D, W / P, n, range_flag);
   TT_CHECK_LAUNCH("patch_embed_pairs.rows");
-  return linear_pairs_impl(workspace, w_pairs, bias, tokens, tokens, nullptr, nullptr, (int)M, D, K, 0, nullptr, 1, 0, stream);
+  void* kws = static_cast<unsigned char*>(workspace) + patch_rows_bytes(F, C, H, W, P, 4);
+  const int rc = patch_ksplit_init(kws, stream);
+  if (rc != TT_OK) return rc;
+  return linear_pairs_impl(workspace, w_pairs, bias, tokens, tokens, nullptr, nullptr, (int)M, D, K, 0, nullptr, 1, 0, stream, nullptr, kws, ksplit_ws_bytes());
 }

@@ -48,8 +48,6 @@
 // 17-43 % of the launches.
 #include "common.hpp"
 #include <cstdlib>
-#include <mutex>
-#include <vector>
 
 namespace tt {
 
@@ -857,6 +855,10 @@ static int planes8_plan(long long x_plane_stride, long long w_plane_stride, int 
     ncu = ncu_dev;
     n_full = (int)R;
     n_half = 0;
+  } else if (!no_half && rem > 0 && 2 * rem <= ncu_dev) {   // (round 5: this branch had been dropped when the K-split went in - every P = 3
+    ncu = ncu_dev;                                          // shape and every P = 1 shape without a K-split ran its tail as whole tiles)
+    n_full = (int)R;
+    n_half = (int)(2 * rem);
   }
   if (ks_S_out) *ks_S_out = ks_S;
   *ntn_out = ntn; *ntiles_out = ntiles; *ncu_out = ncu; *n_full_out = n_full; *n_half_out = n_half;
@@ -873,48 +875,21 @@ int planes8_would_run(int planes, int M, int N, int K, int act, int has_bias, in
 
 // Called by linear_planes_impl (gemm_planes.hip).  Returns TT_OK after a launch, 1 when the shape / epilogue is not this kernel's
 // (the caller then takes gemm_planes_kernel), < 0 on a launch error.
-// The K-split workspace: one per (device, stream), allocated at the first launch that needs it and kept (64 MB + the counters).
-struct P8Ws { int dev; hipStream_t s; float* ws; int* cnt; };
-static std::mutex p8_ws_mu;
-static std::vector<P8Ws> p8_ws_list;
-static int p8_workspace(hipStream_t s, float** ws, int** cnt) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { set_error("gemm_planes8: hipGetDevice failed"); return TT_ELAUNCH; }
-  std::lock_guard<std::mutex> lock(p8_ws_mu);
-  for (const P8Ws& b : p8_ws_list)
-    if (b.dev == dev && b.s == s) { *ws = b.ws; *cnt = b.cnt; return TT_OK; }
-  P8Ws b{dev, s, nullptr, nullptr};
-  const size_t slices = (size_t)device_cu_count();   // ks_R * ks_S <= CUs
-  if (hipMalloc(reinterpret_cast<void**>(&b.ws), slices * 8 * 128 * 64 * sizeof(float)) != hipSuccess) {
-    set_error("gemm_planes8: cannot allocate the K-split workspace");
-    return TT_ELAUNCH;
-  }
-  if (hipMalloc(reinterpret_cast<void**>(&b.cnt), slices * 8 * sizeof(int)) != hipSuccess || hipMemset(b.cnt, 0, slices * 8 * sizeof(int)) != hipSuccess) {
-    (void)hipFree(b.ws);
-    set_error("gemm_planes8: cannot allocate the K-split counters");
-    return TT_ELAUNCH;
-  }
-  p8_ws_list.push_back(b);
-  *ws = b.ws; *cnt = b.cnt;
-  return TT_OK;
-}
-
 int planes8_try(const void* x_planes, long long x_plane_stride, const void* w_planes, long long w_plane_stride, int planes, const float* bias,
                 const float* residual, float* y, void* y_planes, long long y_plane_stride, int y_nplanes, int M, int N, int K, int act,
-                hipStream_t s) {
+                void* ksplit_ws, size_t ksplit_ws_bytes_, hipStream_t s) {
   int ntn, ncu, n_full, n_half, ks_S = 0;
+  // the K-split needs the caller's workspace (tt_linear_ksplit_workspace_bytes / _init); without one the left-over tiles are cut into halves
+  KsplitWs kw{nullptr, nullptr};
+  const bool have_ws = ksplit_ws_carve(ksplit_ws, ksplit_ws_bytes_, &kw);
   long long ntiles;
   if ((y != nullptr) == (y_planes != nullptr) && y) {}   // (y together with planes is not an epilogue of this kernel: the plan rejects it below)
   const int epi = (y && y_planes) ? -1
                                   : planes8_plan(x_plane_stride, w_plane_stride, planes, bias != nullptr, residual != nullptr, y != nullptr,
-                                                 y_planes ? y_nplanes : 0, M, N, K, act, &ntn, &ntiles, &ncu, &n_full, &n_half, &ks_S);
+                                                 y_planes ? y_nplanes : 0, M, N, K, act, &ntn, &ntiles, &ncu, &n_full, &n_half, have_ws ? &ks_S : nullptr);
   if (epi < 0) return 1;
-  float* ks_ws = nullptr;
-  int* ks_cnt = nullptr;
-  if (ks_S >= 2) {
-    const int rc = p8_workspace(s, &ks_ws, &ks_cnt);
-    if (rc != TT_OK) return rc;
-  }
+  float* ks_ws = ks_S >= 2 ? kw.partials : nullptr;
+  int* ks_cnt = ks_S >= 2 ? kw.counters : nullptr;
   P8Args g{static_cast<const __bf16*>(x_planes), static_cast<const __bf16*>(w_planes), x_plane_stride, w_plane_stride, M, N, K, bias, residual, y,
            static_cast<__bf16*>(y_planes), y_plane_stride, ntn, (int)ntiles, ncu, n_full, n_half, tuning_knob(KNOB_P8_CLOCK_PRINT), p8_order_mode(),
            ks_S, ks_S >= 2 ? (int)(ntiles - (long long)n_full * ncu) : 0, ks_ws, ks_cnt};

@@ -20,6 +20,8 @@ struct Carver {   // hands out 256-byte aligned pieces of the caller's workspace
 struct VitScratch {
   void* h;        // LayerNorm output: fp32 [M, D] or bf16 planes [P, M, D]
   void* big;      // qkv | attention output (| its planes), overlaid by the MLP activation
+  void* ks;       // planes > 0: the K-split block of the persistent GEMMs (common.hpp KsplitWs), directly behind `big`
+  size_t ks_bytes;
   size_t bytes;
   size_t qkv_bytes, att_bytes;
 };
@@ -35,6 +37,8 @@ static VitScratch carve_vit(void* ws, long long M, int D, int hidden, int planes
   const size_t attn_phase = s.qkv_bytes + s.att_bytes + (P ? (P * M * D * 2 + 255) / 256 * 256 : 0);
   const size_t mlp_phase = P ? P * M * hidden * 2 : (size_t)M * hidden * 4;
   s.big = c.take(attn_phase > mlp_phase ? attn_phase : mlp_phase);
+  s.ks_bytes = P ? ksplit_ws_bytes() : 0;
+  s.ks = P ? c.take(s.ks_bytes) : nullptr;
   s.bytes = c.off;
   return s;
 }
@@ -73,24 +77,30 @@ extern "C" int tt_vit_forward(const tt_vit_params* p, const float* img, const in
   TT_REQUIRE(p->n_blocks == 0 || (workspace && workspace_bytes >= s.bytes), "vit_forward: workspace too small (%zu < %zu)", workspace_bytes,
              s.bytes);
   const float scale = 1.0f / sqrtf((float)hd);
+  int* const rf = p->range_flag;
+  void* const ks = (workspace && workspace_bytes >= s.bytes) ? s.ks : nullptr;   // (p->n_blocks == 0 without a workspace: no K-split)
+  const size_t ksb = ks ? s.ks_bytes : 0;
+  if (ks) TT_FORWARD(tt_linear_ksplit_workspace_init(ks, ksb, stream));           // the counters: zero before the first launch that counts
 
   if (img) {
     TT_REQUIRE(p->patch_w && p->patch_b && p->cls && p->pos, "vit_forward: null patch-embedding parameter");
     // the bf16 path (planes == 1) embeds the patches on bf16 operands too where the plane GEMM's shape rules hold and the scratch
     // (the blocks' qkv / MLP region, idle now) holds the im2col rows; anything else: the fp32 conv
-    const size_t a_bytes = tt_patch_embed_planes_workspace_bytes(F, C, H, W, p->patch);
     const int Kp = C * p->patch * p->patch;
+    // the patch-embedding entry points take [im2col rows | K-split block] as ONE workspace: the rows are placed at the END of `big`, so that
+    // the K-split block behind it is theirs too
+    const size_t a_bytes = tt_patch_embed_planes_workspace_bytes(F, C, H, W, p->patch), q_bytes = tt_patch_embed_pairs_workspace_bytes(F, C, H, W, p->patch);
     // (C P P <= 9 D: the rows then fit the attention phase of the scratch, 18 M D bytes at planes == 1, whatever the MLP width - a
     // rule on shapes alone, so that callers sequencing the op-level entry points themselves can make the same decision)
     if (P == 1 && p->patch_wp && workspace && workspace_bytes >= s.bytes && p->patch % 4 == 0 && W % 4 == 0 && Kp % 64 == 0 && D % 64 == 0 &&
         Kp <= 9 * D) {
-      TT_FORWARD(tt_patch_embed_fwd_planes(img, frame_map, p->patch_wp, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, s.big,
-                                           a_bytes, stream));
+      TT_FORWARD(tt_patch_embed_fwd_planes(img, frame_map, p->patch_wp, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D,
+                                           static_cast<unsigned char*>(s.ks) - (a_bytes - s.ks_bytes), a_bytes, stream));
     } else if (P == 2 && p->patch_wp && workspace && workspace_bytes >= s.bytes && p->patch % 4 == 0 && W % 4 == 0 && Kp % 32 == 0 &&
                D % 64 == 0 && Kp <= 3 * D) {
       // the pair path likewise: the im2col rows in pairs (4 bytes per element) fit the qkv region of the scratch when C P P <= 3 D
-      TT_FORWARD(tt_patch_embed_fwd_pairs(img, frame_map, p->patch_wp, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, s.big,
-                                          tt_patch_embed_pairs_workspace_bytes(F, C, H, W, p->patch), stream));
+      TT_FORWARD(tt_patch_embed_fwd_pairs(img, frame_map, p->patch_wp, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D,
+                                          static_cast<unsigned char*>(s.ks) - (q_bytes - s.ks_bytes), q_bytes, rf, stream));
     } else {
       TT_FORWARD(tt_patch_embed_fwd(img, frame_map, p->patch_w, p->patch_b, p->cls, p->pos, tokens, F, C, H, W, p->patch, D, stream));
     }
@@ -125,21 +135,21 @@ extern "C" int tt_vit_forward(const tt_vit_params* p, const float* img, const in
     if (P == 2) {   // the "f16x3" mode: fp16 pairs (4 bytes per element, the layout of 2 planes x 2 bytes)
       float* qkv = qkv_out ? qkv_out : reinterpret_cast<float*>(big);
       float* att = reinterpret_cast<float*>(att_region);
-      TT_FORWARD(tt_layernorm_fwd_pairs(tokens, b.norm1_w, b.norm1_b, hp, nullptr, nullptr, (int)M, D, 1e-6f, 0, stream));
+      TT_FORWARD(tt_layernorm_fwd_pairs(tokens, b.norm1_w, b.norm1_b, hp, nullptr, nullptr, (int)M, D, 1e-6f, 0, rf, stream));
       if (!qkv_out && !probs && hd == 64) {
         // qkv in pairs [M][2 x 3 D] (the bytes of the fp32 qkv region), the pair attention kernel, its output in pairs (the fp32 att region)
-        TT_FORWARD(tt_linear_fwd_pairs(hp, b.qkv_wp, b.qkv_b, nullptr, nullptr, nullptr, big, (int)M, 3 * D, D, 0, stream));
+        TT_FORWARD(tt_linear_fwd_pairs(hp, b.qkv_wp, b.qkv_b, nullptr, nullptr, nullptr, big, (int)M, 3 * D, D, 0, ks, ksb, rf, stream));
         TT_FORWARD(tt_attention_fwd_pairs(big, att_region, nullptr, nullptr, F, N, p->heads, hd, scale, stream));
-        TT_FORWARD(tt_linear_fwd_pairs(att_region, b.proj_wp, b.proj_b, tokens, tokens, nullptr, nullptr, (int)M, D, D, 0, stream));
+        TT_FORWARD(tt_linear_fwd_pairs(att_region, b.proj_wp, b.proj_b, tokens, tokens, nullptr, nullptr, (int)M, D, D, 0, ks, ksb, rf, stream));
       } else {
-        TT_FORWARD(tt_linear_fwd_pairs(hp, b.qkv_wp, b.qkv_b, nullptr, qkv, nullptr, nullptr, (int)M, 3 * D, D, 0, stream));
+        TT_FORWARD(tt_linear_fwd_pairs(hp, b.qkv_wp, b.qkv_b, nullptr, qkv, nullptr, nullptr, (int)M, 3 * D, D, 0, ks, ksb, rf, stream));
         TT_FORWARD(tt_attention_fwd(qkv, att, nullptr, probs, F, N, p->heads, hd, scale, stream));
-        TT_FORWARD(tt_split_pairs(att, attp, MD, stream));
-        TT_FORWARD(tt_linear_fwd_pairs(attp, b.proj_wp, b.proj_b, tokens, tokens, nullptr, nullptr, (int)M, D, D, 0, stream));
+        TT_FORWARD(tt_split_pairs(att, attp, MD, rf, stream));
+        TT_FORWARD(tt_linear_fwd_pairs(attp, b.proj_wp, b.proj_b, tokens, tokens, nullptr, nullptr, (int)M, D, D, 0, ks, ksb, rf, stream));
       }
-      TT_FORWARD(tt_layernorm_fwd_pairs(tokens, b.norm2_w, b.norm2_b, hp, nullptr, nullptr, (int)M, D, 1e-6f, 0, stream));
-      TT_FORWARD(tt_linear_fwd_pairs(hp, b.fc1_wp, b.fc1_b, nullptr, nullptr, nullptr, actp, (int)M, p->hidden, D, 1, stream));
-      TT_FORWARD(tt_linear_fwd_pairs(actp, b.fc2_wp, b.fc2_b, tokens, tokens, nullptr, nullptr, (int)M, D, p->hidden, 0, stream));
+      TT_FORWARD(tt_layernorm_fwd_pairs(tokens, b.norm2_w, b.norm2_b, hp, nullptr, nullptr, (int)M, D, 1e-6f, 0, rf, stream));
+      TT_FORWARD(tt_linear_fwd_pairs(hp, b.fc1_wp, b.fc1_b, nullptr, nullptr, nullptr, actp, (int)M, p->hidden, D, 1, ks, ksb, rf, stream));
+      TT_FORWARD(tt_linear_fwd_pairs(actp, b.fc2_wp, b.fc2_b, tokens, tokens, nullptr, nullptr, (int)M, D, p->hidden, 0, ks, ksb, rf, stream));
       continue;
     }
     TT_FORWARD(tt_layernorm_fwd_planes(tokens, b.norm1_w, b.norm1_b, hp, MD, P, nullptr, nullptr, (int)M, D, 1e-6f, 0, stream));
@@ -147,25 +157,25 @@ extern "C" int tt_vit_forward(const tt_vit_params* p, const float* img, const in
     if (P == 1 && !qkv_out && !probs && N <= 256 && hd == 64) {
       void* qkvb = big;   // bf16 [M, 3D]
       TT_FORWARD(tt_linear_fwd_planes(hp, MD, b.qkv_wp, 3ll * D * D, 1, b.qkv_b, nullptr, nullptr, nullptr, qkvb, M * 3 * D, 1, (int)M, 3 * D, D,
-                                      0, stream));
+                                      0, ks, ksb, stream));
       TT_FORWARD(tt_attention_fwd_bf16(qkvb, att_region, F, N, p->heads, hd, scale, stream));
       proj_in = att_region;
     } else {
       float* qkv = qkv_out ? qkv_out : reinterpret_cast<float*>(big);
       float* att = reinterpret_cast<float*>(att_region);
       TT_FORWARD(tt_linear_fwd_planes(hp, MD, b.qkv_wp, 3ll * D * D, P, b.qkv_b, nullptr, qkv, nullptr, nullptr, 0, 0, (int)M, 3 * D, D, 0,
-                                      stream));
+                                      ks, ksb, stream));
       TT_FORWARD(tt_attention_fwd(qkv, att, nullptr, probs, F, N, p->heads, hd, scale, stream));
       TT_FORWARD(tt_split_planes(att, attp, MD, P, MD, stream));
       proj_in = attp;
     }
     TT_FORWARD(tt_linear_fwd_planes(proj_in, MD, b.proj_wp, (long long)D * D, P, b.proj_b, tokens, tokens, nullptr, nullptr, 0, 0, (int)M, D, D, 0,
-                                    stream));
+                                    ks, ksb, stream));
     TT_FORWARD(tt_layernorm_fwd_planes(tokens, b.norm2_w, b.norm2_b, hp, MD, P, nullptr, nullptr, (int)M, D, 1e-6f, 0, stream));
     TT_FORWARD(tt_linear_fwd_planes(hp, MD, b.fc1_wp, (long long)p->hidden * D, P, b.fc1_b, nullptr, nullptr, nullptr, actp, M * p->hidden, P,
-                                    (int)M, p->hidden, D, 1, stream));
+                                    (int)M, p->hidden, D, 1, ks, ksb, stream));
     TT_FORWARD(tt_linear_fwd_planes(actp, M * p->hidden, b.fc2_wp, (long long)p->hidden * D, P, b.fc2_b, tokens, tokens, nullptr, nullptr, 0, 0,
-                                    (int)M, D, p->hidden, 0, stream));
+                                    (int)M, D, p->hidden, 0, ks, ksb, stream));
   }
   if (normed) {
     TT_REQUIRE(p->norm_w && p->norm_b, "vit_forward: null final-norm parameter");

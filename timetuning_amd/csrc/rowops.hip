@@ -225,8 +225,9 @@ template <int NV, int R>
 __global__ __launch_bounds__(256) void layernorm_fwd_pairs_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                       const float* __restrict__ beta, _Float16* __restrict__ y,
                                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows,
-                                                                      float eps, int skip_group) {
+                                                                      float eps, int skip_group, int* range_flag) {
   typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  bool bad = false;
   constexpr int D = 128 * NV;
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_pairs_vec_kernel(const floa
       _Float16 h0, l0, h1, l1;
       split_pair(o0, h0, l0);
       split_pair(o1, h1, l1);
+      bad = bad || pair_hi_bad(h0) || pair_hi_bad(h1);
       *reinterpret_cast<f16x2*>(yr + 256 * i) = (f16x2){h0, h1};
       *reinterpret_cast<f16x2*>(yr + 256 * i + 32) = (f16x2){l0, l1};
     }
@@ -279,18 +281,20 @@ __global__ __launch_bounds__(256) void layernorm_fwd_pairs_vec_kernel(const floa
       if (rstd_out) rstd_out[row0 + r] = rstd;
     }
   }
+  range_flag_raise(range_flag, bad);
 }
 
 // any D % 32 == 0 (<= 1024): one column per lane and pass
 __global__ __launch_bounds__(256) void layernorm_fwd_pairs_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, _Float16* __restrict__ y,
                                                                   float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int D,
-                                                                  float eps, int skip_group) {
+                                                                  float eps, int skip_group, int* range_flag) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const long long in_row = skip_group ? (long long)(row / (skip_group - 1)) * skip_group + 1 + row % (skip_group - 1) : row;
   const float* xr = x + in_row * D;
+  bool bad = false;
   float v[kMaxPerLane];
   float s = 0.f;
 #pragma unroll
@@ -315,10 +319,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_pairs_kernel(const float* _
     if (c < D) {
       _Float16 hi, lo;
       split_pair((v[i] - mean) * rstd * gamma[c] + beta[c], hi, lo);
+      bad |= pair_hi_bad(hi);
       yr[pair_index(c)] = hi;
       yr[pair_index(c) + 32] = lo;
     }
   }
+  range_flag_raise(range_flag, bad);
   if (lane == 0) {
     if (mean_out) mean_out[row] = mean;
     if (rstd_out) rstd_out[row] = rstd;
@@ -711,7 +717,7 @@ extern "C" int tt_layernorm_fwd_planes(const float* x, const float* gamma, const
 }
 
 extern "C" int tt_layernorm_fwd_pairs(const float* x, const float* gamma, const float* beta, void* y_pairs, float* mean, float* rstd, int rows,
-                                      int D, float eps, int skip_group, tt_stream_t stream) {
+                                      int D, float eps, int skip_group, int* range_flag, tt_stream_t stream) {
   TT_REQUIRE(skip_group == 0 || (skip_group >= 2 && rows % (skip_group - 1) == 0), "layernorm_fwd_pairs: rows must be a multiple of skip_group - 1");
   TT_REQUIRE(x && gamma && beta && y_pairs, "layernorm_fwd_pairs: null pointer");
   TT_REQUIRE(rows > 0 && D > 0 && D % 32 == 0 && D <= 64 * kMaxPerLane, "layernorm_fwd_pairs: need D %% 32 == 0 and 0 < D <= %d (got %d)",
@@ -724,17 +730,17 @@ extern "C" int tt_layernorm_fwd_pairs(const float* x, const float* gamma, const 
     constexpr int R = 2;
     const dim3 grid((rows + 4 * R - 1) / (4 * R)), block(256);
     switch (D / 128) {
-      case 1: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<1, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group); break;
-      case 2: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<2, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group); break;
-      case 3: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<3, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group); break;
-      case 4: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<4, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group); break;
-      case 6: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<6, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group); break;
-      default: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<8, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group); break;
+      case 1: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<1, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group, range_flag); break;
+      case 2: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<2, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group, range_flag); break;
+      case 3: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<3, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group, range_flag); break;
+      case 4: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<4, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group, range_flag); break;
+      case 6: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<6, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group, range_flag); break;
+      default: hipLaunchKernelGGL((layernorm_fwd_pairs_vec_kernel<8, R>), grid, block, 0, s, x, gamma, beta, yp, mean, rstd, rows, eps, skip_group, range_flag); break;
     }
     TT_CHECK_LAUNCH("layernorm_fwd_pairs");
     return TT_OK;
   }
-  hipLaunchKernelGGL(layernorm_fwd_pairs_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, yp, mean, rstd, rows, D, eps, skip_group);
+  hipLaunchKernelGGL(layernorm_fwd_pairs_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, yp, mean, rstd, rows, D, eps, skip_group, range_flag);
   TT_CHECK_LAUNCH("layernorm_fwd_pairs");
   return TT_OK;
 }

@@ -39,6 +39,63 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+# ---- ABI 7: the K-split workspace of the persistent GEMMs is the CALLER's (tt_linear_ksplit_workspace_bytes / _init).  This front end keeps
+# one per (device, stream) - launches on one stream are ordered, so they can share the partials and the self-resetting counters - allocated
+# and initialised at its first use, OUTSIDE any launch path of the library (under a hipGraph capture of a step the buffer already exists:
+# ``ksplit_workspace()`` is called once before capturing).
+_KSPLIT_WS: dict = {}
+
+
+def ksplit_workspace(device=None) -> torch.Tensor:
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
+    ws = _KSPLIT_WS.get(key)
+    if ws is None:
+        lib = _lib.load()
+        with torch.cuda.device(key[0]):
+            nb = int(lib.tt_linear_ksplit_workspace_bytes())
+            ws = torch.empty(nb, dtype=torch.uint8, device=torch.device("cuda", key[0]))
+            _lib.check(lib.tt_linear_ksplit_workspace_init(_p(ws), nb, _stream()), "tt_linear_ksplit_workspace_init")
+        _KSPLIT_WS[key] = ws
+    return ws
+
+
+class PairRangeError(_lib.HipLibraryError):
+    """An operand of the "f16x3" mode left fp16's range (|x| > 65504) or was not finite: the one way the mode differs from fp32."""
+
+
+# The pair producers' range flag (include/timetuning_hip.h, "RANGE FLAG"): one device int per device, passed to every entry point that
+# splits fp32 values into pairs.  ``check_pair_range`` reads it (a synchronisation: call it where the host synchronises anyway - the
+# training driver does when it prints the loss, TimeT.train_update does every RANGE_CHECK_EVERY steps) and raises PairRangeError.
+_RANGE_FLAG: dict = {}
+RANGE_CHECK = True
+
+
+def range_flag(device=None) -> Optional[torch.Tensor]:
+    if not RANGE_CHECK:
+        return None
+    idx = torch.cuda.current_device() if device is None else (torch.device(device).index if torch.device(device).index is not None
+                                                              else torch.cuda.current_device())
+    f = _RANGE_FLAG.get(idx)
+    if f is None:
+        f = _RANGE_FLAG[idx] = torch.zeros(4, dtype=torch.int32, device=torch.device("cuda", idx))
+    return f
+
+
+def check_pair_range(device=None, reset: bool = True) -> None:
+    """Raises PairRangeError if any pair producer since the last check saw a value beyond fp16's range.  Synchronises."""
+    f = range_flag(device)
+    if f is None:
+        return
+    bad = int(f[0].item())
+    if bad:
+        if reset:
+            f.zero_()
+        raise PairRangeError('an operand of the "f16x3" arithmetic is beyond fp16\'s range (|x| > 65504) or not finite; its products are '
+                             "inf / NaN where fp32 arithmetic would not be.  Use --precision f32 (hip_ops.set_gemm_precision('f32')) "
+                             "for this model / input.")
+
+
 # name -> (mode of the C-side switch for tt_linear_fwd, bf16 planes used by the launch sequences for blocks that keep nothing)
 # (2 "planes" = fp16 PAIRS: hi / lo halves of an fp32 value, the "f16x3" mode)
 _PRECISIONS = {"f32": (0, 0), "bf16x3": (1, 0), "bf16": (2, 1), "bf16x6": (0, 3), "f16x3": (0, 2)}
@@ -311,7 +368,7 @@ def patch_embed_fwd_pairs(img, w_pairs, bias, cls, pos, patch: int, frame_map=No
     p8 = PROFILE is not None and lib.tt_linear_fwd_pairs_route(M, D, K, 0, 1, 1, 1, 0, 0) == 8
     e0 = _prof_begin()
     _lib.check(lib.tt_patch_embed_fwd_pairs(_p(img), _p(frame_map), _p(w_pairs), _p(bias), _p(cls), _p(pos), _p(tokens), F, Cc, H, W, patch, D,
-                                            _p(ws), nb, _stream()), "tt_patch_embed_fwd_pairs")
+                                            _p(ws), nb, _p(range_flag(img.device)), _stream()), "tt_patch_embed_fwd_pairs")
     _prof_end(e0, "PAIRS8" if p8 else "PAIRS", M, D, K)
     return tokens
 
@@ -892,8 +949,9 @@ def linear_fwd_planes(xp, wp, bias=None, residual=None, act: int = 0, out_f32: b
     p8 = PROFILE is not None and lib.tt_linear_fwd_planes_route(P, M, N, K, int(act), int(bias is not None), int(residual is not None),
                                                                 int(y is not None), int(out_planes), int(pre is not None)) == 8
     e0 = _prof_begin()
+    kws = ksplit_workspace(xp.device)
     _lib.check(lib.tt_linear_fwd_planes(_p(xp), M * K, _p(wp), N * K, P, _p(bias), _p(residual), _p(y), _p(pre), _p(yp), M * N, int(out_planes),
-                                        M, N, K, int(act), _stream()), "tt_linear_fwd_planes")
+                                        M, N, K, int(act), _p(kws), kws.numel(), _stream()), "tt_linear_fwd_planes")
     _prof_end(e0, f"PLANES8_{P}" if p8 else f"PLANES{P}", M, N, K)
     return dict(y=y, planes=yp, pre=pre)
 
@@ -909,7 +967,7 @@ def split_pairs(x, out=None):
     if x.shape[-1] % 32:
         raise ValueError("split_pairs: the last dimension must be a multiple of 32")
     y = out if out is not None else torch.empty((*x.shape[:-1], 2 * x.shape[-1]), dtype=f16, device=x.device)
-    _lib.check(lib.tt_split_pairs(_p(x), _p(y), x.numel(), _stream()), "tt_split_pairs")
+    _lib.check(lib.tt_split_pairs(_p(x), _p(y), x.numel(), _p(range_flag(x.device)), _stream()), "tt_split_pairs")
     return y
 
 
@@ -935,8 +993,8 @@ def layernorm_fwd_pairs(x, gamma, beta, eps=1e-6, save_stats=False, drop_first_t
     y = torch.empty((rows, 2 * D), dtype=f16, device=x.device)
     mean = torch.empty((rows,), dtype=f32, device=x.device) if save_stats else None
     rstd = torch.empty((rows,), dtype=f32, device=x.device) if save_stats else None
-    _lib.check(lib.tt_layernorm_fwd_pairs(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, float(eps), skip, _stream()),
-               "tt_layernorm_fwd_pairs")
+    _lib.check(lib.tt_layernorm_fwd_pairs(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, float(eps), skip,
+                                          _p(range_flag(x.device)), _stream()), "tt_layernorm_fwd_pairs")
     return (y, mean, rstd) if save_stats else y
 
 
@@ -958,8 +1016,9 @@ def linear_fwd_pairs(xp, wp, bias=None, residual=None, act: int = 0, out_f32: bo
     p8 = PROFILE is not None and lib.tt_linear_fwd_pairs_route(M, N, K, int(act), int(bias is not None), int(residual is not None),
                                                                int(y is not None), int(yp is not None), int(pre is not None)) == 8
     e0 = _prof_begin()
-    _lib.check(lib.tt_linear_fwd_pairs(_p(xp), _p(wp), _p(bias), _p(residual), _p(y), _p(pre), _p(yp), M, N, K, int(act), _stream()),
-               "tt_linear_fwd_pairs")
+    kws = ksplit_workspace(xp.device)
+    _lib.check(lib.tt_linear_fwd_pairs(_p(xp), _p(wp), _p(bias), _p(residual), _p(y), _p(pre), _p(yp), M, N, K, int(act), _p(kws), kws.numel(),
+                                       _p(range_flag(xp.device)) if yp is not None else None, _stream()), "tt_linear_fwd_pairs")
     _prof_end(e0, "PAIRS8" if p8 else "PAIRS", M, N, K)
     return dict(y=y, pairs=yp, pre=pre)
 
@@ -1002,7 +1061,8 @@ def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad:
     nb = lib.tt_split_pairs_dual_workspace_bytes(R, Cc, rpad) if need_ws else 0
     ws = _ws(nb, x.device) if need_ws else None
     scale = torch.empty((1,), dtype=f32, device=x.device) if scaled else None
-    _lib.check(lib.tt_split_pairs_dual(_p(x), _p(t), _p(row), _p(sums), _p(scale), R, Cc, rpad, _p(ws), nb, _stream()), "tt_split_pairs_dual")
+    _lib.check(lib.tt_split_pairs_dual(_p(x), _p(t), _p(row), _p(sums), _p(scale), R, Cc, rpad, _p(ws), nb, _p(range_flag(x.device)), _stream()),
+               "tt_split_pairs_dual")
     return (t, row, sums, scale) if scaled else (t, row, sums)
 
 
@@ -1026,7 +1086,7 @@ def split_pairs_dual_multi(items) -> None:
             _chk(t, "t", f16); assert t.shape == (Cc, 2 * rpad), (t.shape, x.shape)
         src[i], dr[i], dt[i] = _p(x), _p(row), _p(t)
         Rs[i], Cs[i], Rp[i] = R, Cc, rpad
-    _lib.check(lib.tt_split_pairs_dual_multi(src, dt, dr, Rs, Cs, Rp, n, _stream()), "tt_split_pairs_dual_multi")
+    _lib.check(lib.tt_split_pairs_dual_multi(src, dt, dr, Rs, Cs, Rp, n, _p(range_flag()), _stream()), "tt_split_pairs_dual_multi")
 
 
 def transpose_pairs(xp, rpad: Optional[int] = None):
@@ -1102,7 +1162,9 @@ def linear_bwd_pairs(dy, wT_pairs, xT_pairs=None, gelu_pre=None, need_bias: bool
         # (label: the persistent kernel takes a data-gradient product under the shape rules of its fp32 (+ operand) epilogues)
         p8 = PROFILE is not None and lib.tt_linear_fwd_pairs_route(M, K, N, 0, 0, int(gelu_pre is not None), 1, 0, 0) == 8
         e0 = _prof_begin()
-        _lib.check(lib.tt_linear_bwd_data_pairs(_p(dy_row), _p(wT_pairs), _p(gelu_pre), _p(dx), _p(dy_scale), M, N, K, _stream()), "tt_linear_bwd_data_pairs")
+        kws = ksplit_workspace(dx.device)
+        _lib.check(lib.tt_linear_bwd_data_pairs(_p(dy_row), _p(wT_pairs), _p(gelu_pre), _p(dx), _p(dy_scale), M, N, K, _p(kws), kws.numel(), _stream()),
+                   "tt_linear_bwd_data_pairs")
         _prof_end(e0, "PAIRS8" if p8 else "PAIRS", M, K, N)
     return dx, dw, db
 
@@ -1154,7 +1216,8 @@ def linear_bwd_data_planes(dy, w, gelu_pre=None):
     dx = torch.empty((M, K), dtype=f32, device=dy.device)
     if gelu_pre is not None: _chk(gelu_pre, "gelu_pre")
     e0 = _prof_begin()
-    _lib.check(lib.tt_linear_bwd_data_planes(_p(dyp), M * N, _p(wT), K * N, 1, _p(gelu_pre), _p(dx), M, N, K, _stream()),
+    kws = ksplit_workspace(dx.device)
+    _lib.check(lib.tt_linear_bwd_data_planes(_p(dyp), M * N, _p(wT), K * N, 1, _p(gelu_pre), _p(dx), M, N, K, _p(kws), kws.numel(), _stream()),
                "tt_linear_bwd_data_planes")
     _prof_end(e0, "PLANES1", M, K, N)
     return dx
@@ -1199,9 +1262,12 @@ def vit_forward(params, n_blocks: int, tokens, img=None, frame_map=None, normed_
     _chk(tokens, "tokens")
     F, N, D = tokens.shape
     vp.n_blocks = int(n_blocks)
+    planes_given = vp.planes   # (the caller's struct is restored below - a cached (vp, keep) must not stay in f32 for later launches)
     if vp.planes == 2 and F * N < PAIRS_MIN_ROWS:
         vp.planes = 0   # a small launch sequence keeps the exact-f32 kernels (PAIRS_MIN_ROWS); the fp32 weights are in the table anyway
     dev = tokens.device
+    rf = range_flag(dev) if vp.planes == 2 else None
+    vp.range_flag = _p(rf)
     if img is not None:
         _chk(img, "img")
         C_, H, W = img.shape[1], img.shape[2], img.shape[3]
@@ -1216,8 +1282,11 @@ def vit_forward(params, n_blocks: int, tokens, img=None, frame_map=None, normed_
     probs = torch.empty((F, vp.heads, N, N), dtype=f32, device=dev) if last_probs else None
     nb = lib.tt_vit_forward_workspace_bytes(F, N, D, vp.hidden, vp.planes) if n_blocks else 0
     ws = _ws(nb, dev)
-    _lib.check(lib.tt_vit_forward(vp, _p(img), _p(frame_map), F, C_, H, W, _p(tokens), _p(normed), int(bool(drop_cls)), _p(qkv), _p(probs),
-                                  _p(ws), nb, _stream()), "tt_vit_forward")
+    try:
+        _lib.check(lib.tt_vit_forward(vp, _p(img), _p(frame_map), F, C_, H, W, _p(tokens), _p(normed), int(bool(drop_cls)), _p(qkv), _p(probs),
+                                      _p(ws), nb, _stream()), "tt_vit_forward")
+    finally:
+        vp.planes = planes_given
     return normed, qkv, probs
 
 

@@ -2,19 +2,25 @@
 """A/B of tt_linear_fwd_pairs between library builds in one process (tools/build_variant.sh) on the ViT-S/16 and ViT-B/16 block shapes;
 outputs compared bit for bit.  usage: ab_pairs.py libA.so libB.so ..."""
 import ctypes as C, os, statistics, sys, torch
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _ksws import ksplit_ws
+_KS = {}
+def _ks(lib, st):
+    if id(lib) not in _KS: _KS[id(lib)] = ksplit_ws(lib, st)
+    return _KS[id(lib)]
 vp, ll, i32 = C.c_void_p, C.c_longlong, C.c_int
 def load(p):
     lib = C.CDLL(os.path.abspath(p))
     lib.tt_linear_fwd_pairs.restype = C.c_int
-    lib.tt_linear_fwd_pairs.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.tt_linear_fwd_pairs.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, C.c_size_t, vp, vp]   # ABI 7: + K-split workspace, range flag
     lib.tt_split_pairs.restype = C.c_int
-    lib.tt_split_pairs.argtypes = [vp, vp, ll, vp]
+    lib.tt_split_pairs.argtypes = [vp, vp, ll, vp, vp]
     return lib
 libs = [(os.path.basename(p), load(p)) for p in sys.argv[1:]]
 st = torch.cuda.current_stream().cuda_stream
 def split(x):
     out = torch.empty((x.shape[0], 2 * x.shape[1]), device="cuda", dtype=torch.float16)
-    assert libs[0][1].tt_split_pairs(x.data_ptr(), out.data_ptr(), x.numel(), st) == 0
+    assert libs[0][1].tt_split_pairs(x.data_ptr(), out.data_ptr(), x.numel(), None, st) == 0
     return out
 cases = [(25216, 1152, 384, 0, 0, 0, "qkv"), (25216, 384, 384, 0, 0, 1, "proj"), (25216, 1536, 384, 1, 1, 0, "fc1"), (25216, 384, 1536, 0, 0, 1, "fc2"),
          (25216, 2304, 768, 0, 0, 0, "B qkv"), (25216, 768, 768, 0, 0, 1, "B proj"), (25216, 3072, 768, 1, 1, 0, "B fc1"), (25216, 768, 3072, 0, 0, 1, "B fc2"),
@@ -28,7 +34,7 @@ for M, N, K, act, po, res, name in cases:
     yp = torch.empty(M, 2 * N, device="cuda", dtype=torch.float16) if po else None
     def go(lib):
         rc = lib.tt_linear_fwd_pairs(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, y.data_ptr() if y is not None else None, None,
-                                     yp.data_ptr() if po else None, M, N, K, act, st)
+                                     yp.data_ptr() if po else None, M, N, K, act, _ks(lib, st)[1], _ks(lib, st)[2], None, st)
         assert rc == 0, rc
     ts = {n: [] for n, _ in libs}
     for rd in range(8):

@@ -2,11 +2,17 @@
 """A/B of tt_linear_fwd_planes between library builds in one process (tools/build_variant.sh) on the ViT-B/16 (P = 1) and ViT-S/16 (P = 3)
 block shapes; outputs compared bit for bit.  usage: ab_planes.py libA.so libB.so ..."""
 import ctypes as C, os, statistics, sys, torch
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _ksws import ksplit_ws
+_KS = {}
+def _ks(lib, st):
+    if id(lib) not in _KS: _KS[id(lib)] = ksplit_ws(lib, st)
+    return _KS[id(lib)]
 vp, ll, i32 = C.c_void_p, C.c_longlong, C.c_int
 def load(p):
     lib = C.CDLL(os.path.abspath(p))
     lib.tt_linear_fwd_planes.restype = C.c_int
-    lib.tt_linear_fwd_planes.argtypes = [vp, ll, vp, ll, i32, vp, vp, vp, vp, vp, ll, i32, i32, i32, i32, i32, vp]
+    lib.tt_linear_fwd_planes.argtypes = [vp, ll, vp, ll, i32, vp, vp, vp, vp, vp, ll, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]   # ABI 7: + K-split workspace
     lib.tt_split_planes.restype = C.c_int
     lib.tt_split_planes.argtypes = [vp, vp, ll, i32, ll, vp]
     return lib
@@ -26,7 +32,7 @@ for P, M, N, K, act, po, res, name in cases:
     yp = torch.empty(po, M, N, device="cuda", dtype=torch.bfloat16) if po else None
     def go(lib):
         rc = lib.tt_linear_fwd_planes(x.data_ptr(), M * K, w.data_ptr(), N * K, P, b.data_ptr(), r.data_ptr() if res else None,
-                                      y.data_ptr() if y is not None else None, None, yp.data_ptr() if po else None, M * N, po, M, N, K, act, st)
+                                      y.data_ptr() if y is not None else None, None, yp.data_ptr() if po else None, M * N, po, M, N, K, act, _ks(lib, st)[1], _ks(lib, st)[2], st)
         assert rc == 0, rc
     ts = {n: [] for n, _ in libs}
     for rd in range(8):

@@ -3,10 +3,16 @@
 -DTT_P8_ABLATE; TT_P8_DBG bit mask: 1 no MFMAs, 2 no LDS-DMA, 4 no fragment reads, 8 no epilogue, 16 epilogue without global traffic)
 on shapes with an exact tile count per CU (16384 x 2048) and on the ViT-B/16 / ViT-S/16 block shapes."""
 import ctypes as C, os, statistics, sys, torch
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _ksws import ksplit_ws
+_KS = {}
+def _ks(lib, st):
+    if id(lib) not in _KS: _KS[id(lib)] = ksplit_ws(lib, st)
+    return _KS[id(lib)]
 vp, ll, i32 = C.c_void_p, C.c_longlong, C.c_int
 lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libp8ablate.so"))
 lib.tt_linear_fwd_planes.restype = C.c_int
-lib.tt_linear_fwd_planes.argtypes = [vp, ll, vp, ll, i32, vp, vp, vp, vp, vp, ll, i32, i32, i32, i32, i32, vp]
+lib.tt_linear_fwd_planes.argtypes = [vp, ll, vp, ll, i32, vp, vp, vp, vp, vp, ll, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]   # ABI 7: + K-split workspace
 lib.tt_split_planes.restype = C.c_int
 lib.tt_split_planes.argtypes = [vp, vp, ll, i32, ll, vp]
 st = torch.cuda.current_stream().cuda_stream
@@ -34,7 +40,7 @@ for P, M, N, K, act, po, res, name in cases:
             e0.record()
             for _ in range(10):
                 rc = lib.tt_linear_fwd_planes(x.data_ptr(), M * K, w.data_ptr(), N * K, P, b.data_ptr(), r.data_ptr() if res else None,
-                                              y.data_ptr() if y is not None else None, None, yp.data_ptr() if po else None, M * N, po, M, N, K, act, st)
+                                              y.data_ptr() if y is not None else None, None, yp.data_ptr() if po else None, M * N, po, M, N, K, act, _ks(lib, st)[1], _ks(lib, st)[2], st)
                 assert rc == 0, rc
             e1.record(); torch.cuda.synchronize()
             if rd >= 2: ts[d].append(e0.elapsed_time(e1) * 1e2)

@@ -3,17 +3,23 @@
 -DTT_Q8_ABLATE; TT_Q8_DBG bit mask: 1 no MFMAs, 2 no LDS-DMA, 8 no epilogue) on the ViT-S/16 / ViT-B/16 block shapes and on a shape with
 an exact tile count per CU."""
 import ctypes as C, os, statistics, sys, torch
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _ksws import ksplit_ws
+_KS = {}
+def _ks(lib, st):
+    if id(lib) not in _KS: _KS[id(lib)] = ksplit_ws(lib, st)
+    return _KS[id(lib)]
 vp, ll, i32 = C.c_void_p, C.c_longlong, C.c_int
 lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libq8ablate.so"))
 lib.tt_linear_fwd_pairs.restype = C.c_int
-lib.tt_linear_fwd_pairs.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+lib.tt_linear_fwd_pairs.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, C.c_size_t, vp, vp]   # ABI 7: + K-split workspace, range flag
 lib.tt_split_pairs.restype = C.c_int
-lib.tt_split_pairs.argtypes = [vp, vp, ll, vp]
+lib.tt_split_pairs.argtypes = [vp, vp, ll, vp, vp]
 st = torch.cuda.current_stream().cuda_stream
 NAMES = {0: "full", 1: "noMFMA", 2: "noDMA", 8: "noEpi", 9: "noEpi+noMFMA", 10: "noEpi+noDMA", 3: "noMFMA+noDMA", 11: "reads+barriers only"}
 def split(x):
     out = torch.empty((x.shape[0], 2 * x.shape[1]), device="cuda", dtype=torch.float16)
-    assert lib.tt_split_pairs(x.data_ptr(), out.data_ptr(), x.numel(), st) == 0
+    assert lib.tt_split_pairs(x.data_ptr(), out.data_ptr(), x.numel(), None, st) == 0
     return out
 # (M, N, K, act, pairs out, residual, name)
 cases = [(16384, 1024, 384, 0, 0, 0, "ideal 2 tiles/CU K384 f32out"), (16384, 1024, 1536, 0, 0, 1, "ideal 2 tiles/CU K1536 f32+res"),
@@ -34,7 +40,7 @@ for M, N, K, act, po, res, name in cases:
             e0.record()
             for _ in range(10):
                 rc = lib.tt_linear_fwd_pairs(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, y.data_ptr() if y is not None else None,
-                                             None, yp.data_ptr() if po else None, M, N, K, act, st)
+                                             None, yp.data_ptr() if po else None, M, N, K, act, _ks(lib, st)[1], _ks(lib, st)[2], None, st)
                 assert rc == 0, rc
             e1.record(); torch.cuda.synchronize()
             if rd >= 2: ts[d].append(e0.elapsed_time(e1) * 1e2)
