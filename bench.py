@@ -429,6 +429,8 @@ def main():
                          "hip_ops.set_gemm_precision documents the others)")
     ap.add_argument("--no_alt_precision", action="store_true", help="skip the secondary measurements in the other precision modes")
     ap.add_argument("--no_exchange_probe", action="store_true", help="skip the one-rank RCCL probe of the exchange path (1-GPU runs)")
+    ap.add_argument("--no_exchange_autotune", action="store_true",
+                    help="N > 1: keep the default exchange (all-gather Sinkhorn, 4 gradient buckets) instead of timing the variants first")
     ap.add_argument("--exchange_probe_child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     global USE_MASK
@@ -486,6 +488,21 @@ def main():
     from timetuning_amd import hip_ops
 
     hip_ops.set_gemm_precision(a.precision)
+    from timetuning_amd import engine
+
+    if world > 1 and not a.no_exchange_autotune:
+        # which Sinkhorn exchange / gradient bucketing is faster on THIS node's links is measured, once, before the warm-up (outside the
+        # timed region): forward + backward of the real step, no update (engine.autotune_exchange; the choice is printed under `rccl`)
+        q_keep = model.queue.clone() if getattr(model, "queue", None) is not None else None
+
+        def _probe_step():
+            model.zero_grad(set_to_none=True)
+            model(x, None, True, USE_MASK).backward()
+
+        engine.autotune_exchange(_probe_step, device, log=(lambda m: print(m, file=sys.stderr, flush=True)))
+        model.zero_grad(set_to_none=True)
+        if q_keep is not None:
+            model.set_queue(q_keep)
     for _ in range(a.warmup):
         train_step(model, opt, x, a.use_teacher)
     torch.cuda.synchronize()
@@ -557,7 +574,7 @@ def main():
             "loss": round(final_loss, 5),
             # proof of what carried the exchange: RCCL ("nccl") saw this many ranks (None for the single-process run)
             # with the compute stream's exposed wait per collective in the instrumented step
-            "rccl": rccl_report(dist, headline_waits) if world > 1 else None,
+            "rccl": dict(rccl_report(dist, headline_waits), exchange_autotune=engine.EXCHANGE_CHOICE) if world > 1 else None,
             "roofline": roof,
             "alt_precision": alt or None,
             "sinkhorn": None if sk_rate is None else {"iters_per_sec": round(sk_rate, 1), "algorithmic_GBps": round(sk_gbs, 1),

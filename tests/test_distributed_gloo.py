@@ -103,6 +103,60 @@ def _worker(rank, W, port, ret):
     out["bucket_err"] = max(float((fin[p] - e).abs().max()) for p, e in zip(params, expect))
     out["bucket_count_ok"] = bool(len(ex.sent) == 3)
 
+    # (2c) round 5: the exchange decides ITSELF on the first multi-rank run (engine.autotune_exchange): both Sinkhorn exchanges and the
+    # 4- / 1-bucket gradient exchange are timed on the step, MAX over ranks, and a variant replaces the default only when it is faster by
+    # more than 3 %.  The step here is the product's collective logic on CPU tensors (oracle / CPU twin as the solvers) plus a sleep that
+    # makes one configuration slow ON ONE RANK ONLY - every rank must still take the same decision.
+    import time
+
+    twin_lib = cpu_twin.load()
+    n_red = [0]
+
+    def make_step(slow):
+        def step():
+            if engine.SINKHORN_EXCHANGE == "allreduce":
+                engine.global_sinkhorn_allreduce(local, B, 0.05, 3, lib=twin_lib)
+            else:
+                engine.global_sinkhorn(local, B, 0.05, 3, solver=_oracle_solver)
+            ex_ = engine.GradExchange()
+            st_ = {}
+            for p_ in params:
+                st_[p_] = grads[p_].clone()
+                ex_.push(st_)
+            fin_ = ex_.finish(st_)
+            out["last_step_bucket_err"] = max(float((fin_[p_] - e_).abs().max()) for p_, e_ in zip(params, expect))
+            if slow(engine.SINKHORN_EXCHANGE, engine.GRAD_BUCKETS) and rank == 1:
+                time.sleep(0.03)
+        return step
+
+    def counting2(t, *a, **k):
+        n_red[0] += 1
+        return real_all_reduce(t, *a, **k)
+
+    # (i) the default is slow on rank 1 -> both variants win, on BOTH ranks
+    c1 = engine.autotune_exchange(make_step(lambda sk, nb: sk == "allgather" or nb == 0), "cpu", reps=2)
+    out["auto_1"] = (c1["sinkhorn_exchange"], c1["grad_buckets"], engine.SINKHORN_EXCHANGE, engine.GRAD_BUCKETS, sorted(c1["ms_per_step"]))
+    # with one bucket the whole exchange is ONE all-reduce, issued by finish()
+    dist.all_reduce = counting2
+    try:
+        n0 = n_red[0]
+        ex1 = engine.GradExchange()
+        st1 = {}
+        for p_ in params:
+            st1[p_] = grads[p_].clone()
+            ex1.push(st1)
+        pushed = n_red[0] - n0
+        f1 = ex1.finish(st1)
+        out["one_bucket"] = (pushed, n_red[0] - n0, max(float((f1[p_] - e_).abs().max()) for p_, e_ in zip(params, expect)))
+    finally:
+        dist.all_reduce = real_all_reduce
+    # (ii) the variants are the slow ones -> the default stays
+    engine.SINKHORN_EXCHANGE, engine.GRAD_BUCKETS, engine.EXCHANGE_CHOICE = "allgather", 0, None
+    c2 = engine.autotune_exchange(make_step(lambda sk, nb: sk == "allreduce" or nb == 1), "cpu", reps=2)
+    out["auto_2"] = (c2["sinkhorn_exchange"], c2["grad_buckets"], engine.SINKHORN_EXCHANGE, engine.GRAD_BUCKETS)
+    out["auto_err"] = out["last_step_bucket_err"]
+    engine.SINKHORN_EXCHANGE, engine.GRAD_BUCKETS, engine.EXCHANGE_CHOICE = "allgather", 0, None
+
     # (3) the wrapper broadcasts rank 0's parameters and passes attribute access through
     cfg = synth.ARCHS["tiny-s16"]
     fe = FeatureExtractor("dino-s16", "", [128, 128, 64, 32], unfreeze_layers=["blocks.11", "blocks.10"], vit_cfg=cfg, init="stress", seed=1 + rank)
@@ -139,5 +193,10 @@ def test_world_size_2_gloo():
         assert o["q_own_allreduce_err_vs_reference"] < 2e-6 and o["q_own_allreduce_iters0_err"] < 1e-6, o
         assert o["allreduce_variant_collectives"] == 0 and o["allreduce_ctx_is_local"], o
         assert o["grad_err"] < 1e-6, o
+        # the self-deciding exchange: same decision on every rank, recorded with its measurements; one bucket = one all-reduce at the end
+        assert o["auto_1"] == ("allreduce", 1, "allreduce", 1, ["allgather/4", "allreduce/1", "allreduce/4"]), o["auto_1"]
+        assert o["auto_2"] == ("allgather", 4, "allgather", 0), o["auto_2"]
+        assert o["one_bucket"][0] == 0 and o["one_bucket"][1] == 1 and o["one_bucket"][2] < 1e-6, o["one_bucket"]
+        assert o["auto_err"] < 1e-6, o
         assert o["bcast_err"] == 0.0 and o["bcast_err_w"] == 0.0, o
         assert o["passthrough"], o

@@ -97,7 +97,23 @@ def _worker(rank, W, port, ret, backend="gloo"):
         engine.SINKHORN_EXCHANGE = "allgather"
     torch.cuda.synchronize()
     waits_r, engine.RCCL_PROFILE = engine.RCCL_PROFILE, None
-    ret[rank] = dict(loss=float(loss.item()), loss_allreduce=float(loss_r.item()),
+    # step 4 ...: the exchange decides for itself (engine.autotune_exchange, what time_tuning() / bench.py run on the first multi-rank batch):
+    # the three configurations are timed on the real step, every rank must arrive at the same choice, and a step under the chosen
+    # configuration (whichever it is - one bucket, the all-reduce Sinkhorn) still gives step 1's loss and gradients
+    def _probe():
+        inner.zero_grad(set_to_none=True)
+        model(x, None, True, False).backward()
+
+    choice = engine.autotune_exchange(_probe, torch.device("cuda", dev), reps=2)
+    inner.zero_grad(set_to_none=True)
+    loss_c = model(x, None, True, False)
+    loss_c.backward()
+    torch.cuda.synchronize()
+    auto = dict(choice=(choice["sinkhorn_exchange"], choice["grad_buckets"]), keys=sorted(choice["ms_per_step"]),
+                set=(engine.SINKHORN_EXCHANGE, engine.GRAD_BUCKETS), loss=float(loss_c.item()),
+                grad_err=max(float((params[n].grad - first[n]).abs().max() / first[n].abs().max()) for n in WATCH))
+    engine.SINKHORN_EXCHANGE, engine.GRAD_BUCKETS, engine.EXCHANGE_CHOICE = "allgather", 0, None
+    ret[rank] = dict(auto=auto, loss=float(loss.item()), loss_allreduce=float(loss_r.item()),
                      q_allreduce_err=float((model.last_aux["q"] - q_gather).abs().max()),
                      waits_allreduce=[(k, n) for k, n, _, _ in waits_r if "sinkhorn" in k or "gather" in k], grads={n: params[n].grad.cpu().numpy() for n in WATCH},
                      q=model.last_aux["q"].cpu().numpy(), waits=[(k, n, e0.elapsed_time(e1)) for k, n, e0, e1 in waits],
@@ -143,6 +159,11 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(backend, W):
         # the all-reduce variant of the assignment: no all-gather, one K-float all-reduce per Sinkhorn iteration, the same assignment and loss
         assert ret[r]["waits_allreduce"] == [("all_reduce(sinkhorn row sums)", K * 4)] * SK_ITERS, ret[r]["waits_allreduce"]
         assert ret[r]["q_allreduce_err"] < 2e-6 and abs(ret[r]["loss_allreduce"] - ret[r]["loss"]) < 1e-5, (ret[r]["q_allreduce_err"], ret[r]["loss_allreduce"], ret[r]["loss"])
+        # the self-deciding exchange: one decision for the whole job, consistent state, unchanged numbers under it
+        au = ret[r]["auto"]
+        assert au["choice"] == ret[0]["auto"]["choice"] and au["choice"][0] in ("allgather", "allreduce") and au["choice"][1] in (1, 4), au
+        assert au["set"] == (au["choice"][0], 0 if au["choice"][1] == 4 else 1) and len(au["keys"]) == 3 and au["keys"][0] == "allgather/4", au
+        assert abs(au["loss"] - ret[r]["loss"]) < 1e-5 and au["grad_err"] < 1e-4, au
 
     model = _model()
     x_all = torch.from_numpy(np.concatenate([synth.make_clips(BS, FS, 224, seed=11 + r) for r in range(W)], axis=0)).cuda()

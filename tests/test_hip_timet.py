@@ -27,6 +27,89 @@ def assert_close(a, b, tol, what="", guard=3e-5):
 
 
 
+def assert_all_grads(mg, og, what, tol_l2=1e-4, tol_max=TOL):
+    """EVERY trainable tensor's gradient against the oracle's (the full-size tests used to look at three of the 33): relative
+    L2 < 1e-4 - the fp32-class modes measure 1e-6 ... 2e-5 here; 2.5e-5 was what the unscaled fp16 split of the dy tensors cost in round
+    4 - and the max-normalised contract bound beside it.  ``og``: name -> gradient (tensor) of the oracle."""
+    import os
+    names = [n for n, p_ in mg.items() if p_.requires_grad]
+    assert len(names) >= 10 and set(names) <= set(og), (len(names), sorted(set(names) - set(og))[:3])
+    worst = ("", 0.0)
+    for n in names:
+        assert mg[n].grad is not None, (what, n, "no gradient")
+        l2, e = rel_l2(mg[n].grad.cpu(), og[n]), rel_err(mg[n].grad.cpu(), og[n])
+        if l2 > worst[1]:
+            worst = (n, l2)
+        assert l2 < tol_l2 and e < tol_max, (what, n, l2, e)
+    if os.environ.get("TT_TEST_PRINT_ERRORS"):
+        print(f"[errors] {what}: {len(names)} gradients, worst rel-L2 {worst[1]:.2e} ({worst[0]})")
+    return len(names)
+
+
+# The CPU oracle's full-size steps take minutes on the host and do not depend on the GPU's arithmetic mode: computed ONCE per session and
+# shared by the three fp32-class modes (VERDICT r4: C3's 32-clip batch had been skipped in the headline mode for the oracle's cost).
+_ORACLE_CACHE: dict = {}
+
+
+def _c2_oracle_step():
+    if "c2" not in _ORACLE_CACHE:
+        from oracle import timet_oracle as O
+
+        bs, fs, K = 32, 4, 200
+        torch.set_num_threads(min(32, torch.get_num_threads()))
+        om = O.build_oracle("dino-s16", K, (1024, 1024, 512, 256), mode="stress")
+        x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=3))
+        oloss, aux = om.get_loss(x, faithful=False, return_aux=True)
+        oloss.backward()
+        _ORACLE_CACHE["c2"] = dict(x=x, loss=oloss.item(), batch_q=aux["batch_q"].detach().clone(), target_scores=aux["target_scores"].detach().clone(),
+                                   labels=aux["labels"].reshape(bs, -1).clone(),
+                                   grads={n: p_.grad.detach().clone() for n, p_ in om.named_parameters() if p_.grad is not None})
+    return _ORACLE_CACHE["c2"]
+
+
+C3_WATCH = ("prototypes", "feature_extractor.head.6.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight",
+            "feature_extractor.backbone.blocks.11.mlp.fc2.weight")
+
+
+def _c3_oracle_steps(bs, steps):
+    """C3's per-rank work on the oracle: per step the inputs' seeds, the loss, the assignment, the labels, EVERY gradient, and the state
+    after the optimizer / prototype / teacher update (watched parameters, queue, teacher prototypes, a teacher weight)."""
+    key = ("c3", bs, steps)
+    if key not in _ORACLE_CACHE:
+        from oracle import timet_oracle as O
+
+        fs, K, Q, E, I = 4, 200, 2048, 1, 4
+        torch.set_num_threads(min(32, torch.get_num_threads()))
+        om = O.build_oracle("dino-s16", K, (1024, 1024, 512, 256), mode="stress")
+        oopt = O.SwavOptimizerOracle(om, 1e-5, 1e-4, O.cosine_scheduler(0.04, 0.4, E, I), I, E)
+        om.init_momentum_teacher()
+        om.set_momentum_teacher_schedular_params(0.995, 1.0, E, I)
+        om.init_queue(Q)
+        om.queue.copy_(_c3_queue_fill(Q))
+        recs = []
+        for s_ in range(steps):
+            x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=70 + s_))
+            perm = torch.randperm(bs * 196, generator=torch.Generator().manual_seed(s_)).numpy()
+            oloss, aux = om.get_loss(x, faithful=False, return_aux=True, queue_perm=perm)
+            oopt.zero_grad()
+            oloss.backward()
+            rec = dict(perm=perm, loss=oloss.item(), batch_q=aux["batch_q"].detach().clone(), labels=aux["labels"].reshape(bs, -1).clone(),
+                       grads={n: p_.grad.detach().clone() for n, p_ in om.named_parameters() if p_.grad is not None})
+            oopt.step()
+            om.normalize_prototypes()
+            om.update_momentum_teacher(oopt.global_step)
+            og = dict(om.named_parameters())
+            rec.update(params={n: og[n].detach().clone() for n in C3_WATCH}, queue=om.queue.clone(), teacher_prototypes=om.teacher_prototypes.clone(),
+                       teacher_fc2=om.teacher.backbone["blocks.11.mlp.fc2.weight"].clone())
+            recs.append(rec)
+        _ORACLE_CACHE[key] = recs
+    return _ORACLE_CACHE[key]
+
+
+def _c3_queue_fill(Q):
+    return torch.nn.functional.normalize(torch.from_numpy(synth.normal("c3.queue", (Q, 256))), dim=1) * 3.0
+
+
 def _build(g, teacher=False, queue=0):
     from timetuning_amd.models import FeatureExtractor
     from timetuning_amd.my_utils import cosine_scheduler
@@ -259,30 +342,25 @@ def test_c2_size_properties():
 def test_c2_full_step_vs_oracle(accurate_precision):
     """BASELINE C2 at FULL size (ViT-S/16, 32 clips x 4 frames, 200 prototypes): the whole training step against the CPU oracle
     (one pass per frame, ``faithful=False``: same arithmetic as the reference's four) - Sinkhorn assignment of all 6272 source
-    patches, hard labels, loss, and the gradients of the prototypes, a head weight and a blocks.10 weight."""
-    from oracle import timet_oracle as O
+    patches, hard labels, loss, and the gradient of EVERY trainable tensor (prototypes, head, blocks 10 / 11, final norm) in
+    relative L2.  The oracle's step is computed once per session and shared by the three modes."""
     from timetuning_amd.models import FeatureExtractor
     from timetuning_amd.time_tuning import TimeT
 
     bs, fs, K = 32, 4, 200
-    torch.set_num_threads(min(32, torch.get_num_threads()))
     fe = FeatureExtractor("dino-s16", "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="stress",
                           return_attention=False)
     model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, 256))).cuda()
-    om = O.build_oracle("dino-s16", K, (1024, 1024, 512, 256), mode="stress")
-    x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=3))
-    oloss, aux = om.get_loss(x, faithful=False, return_aux=True)
-    oloss.backward()
-    loss = model.get_loss(x.cuda(), target_labels=aux["labels"].reshape(bs, -1))
+    o = _c2_oracle_step()
+    loss = model.get_loss(o["x"].cuda(), target_labels=o["labels"])
     loss.backward()
-    assert rel_err(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL and rel_l2(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL
-    assert_close(model.last_aux["target_scores"].cpu(), aux["target_scores"].detach(), TOL, "C2 assignment logits")
-    mism = (model.last_aux["labels"].cpu() != aux["labels"].reshape(bs, -1)).float().mean().item()
+    assert rel_err(model.last_aux["q"].cpu(), o["batch_q"]) < TOL and rel_l2(model.last_aux["q"].cpu(), o["batch_q"]) < TOL
+    assert_close(model.last_aux["target_scores"].cpu(), o["target_scores"], TOL, "C2 assignment logits")
+    mism = (model.last_aux["labels"].cpu() != o["labels"]).float().mean().item()
     assert mism <= 0.01, mism
-    assert abs(loss.item() - oloss.item()) < 2e-4, (loss.item(), oloss.item())
-    og, mg = dict(om.named_parameters()), dict(model.named_parameters())
-    for name in ("prototypes", "feature_extractor.head.6.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight"):
-        assert rel_err(mg[name].grad.cpu(), og[name].grad) < TOL, name
+    assert abs(loss.item() - o["loss"]) < 2e-4, (loss.item(), o["loss"])
+    n = assert_all_grads(dict(model.named_parameters()), o["grads"], f"C2 full step [{accurate_precision}]")
+    assert n == 33, n   # prototypes + 8 head tensors + 2 x 12 block tensors (the final norm is frozen with the rest of the backbone)
 
 
 @pytest.mark.timeout(1500)
@@ -291,59 +369,41 @@ def test_c3_per_rank_workload_vs_oracle(accurate_precision, bs, steps):
     """BASELINE C3's per-rank work at ViT-S/16 size: EMA teacher + a pre-filled 2048-row queue (16384 // 8 ranks,
     time_tuning.py:618) + 200 prototypes against the oracle: assignment, labels, loss, gradients, updated parameters, teacher
     and queue.  4 clips x TWO optimizer steps (the teacher used by step 2 is an EMA product and the queue has been shifted once), and
-    C3's FULL per-rank batch - 32 clips, the 6272 + 2048-row Sinkhorn problem - for one step (f32 only: the oracle's step takes
-    minutes on the host)."""
-    from oracle import timet_oracle as O
+    C3's FULL per-rank batch - 32 clips, the 6272 + 2048-row Sinkhorn problem - for one step, in EVERY fp32-class mode (round 5: the
+    oracle's steps are computed once per session); every trainable gradient in relative L2."""
     from timetuning_amd.models import FeatureExtractor
     from timetuning_amd.my_utils import cosine_scheduler
     from timetuning_amd.time_tuning import SwavOptimizer, TimeT
 
-    if bs == 32 and accurate_precision != "f32":
-        pytest.skip("full C3 batch is checked in the f32 mode; bf16x6 runs the 4-clip variant and the full C2 step")
     fs, K, Q, E, I = 4, 200, 2048, 1, 4
-    torch.set_num_threads(min(32, torch.get_num_threads()))
     fe = FeatureExtractor("dino-s16", "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="stress",
                           return_attention=False)
     model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, 256))).cuda()
     opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, E, I), I, E)
-    om = O.build_oracle("dino-s16", K, (1024, 1024, 512, 256), mode="stress")
-    oopt = O.SwavOptimizerOracle(om, 1e-5, 1e-4, O.cosine_scheduler(0.04, 0.4, E, I), I, E)
-    for m_ in (model, om):
-        m_.init_momentum_teacher()
-        m_.set_momentum_teacher_schedular_params(0.995, 1.0, E, I)
-        m_.init_queue(Q)
-    fill = torch.nn.functional.normalize(torch.from_numpy(synth.normal("c3.queue", (Q, 256))), dim=1) * 3.0
-    model.queue.copy_(fill)
-    om.queue.copy_(fill)
+    model.init_momentum_teacher()
+    model.set_momentum_teacher_schedular_params(0.995, 1.0, E, I)
+    model.init_queue(Q)
+    model.queue.copy_(_c3_queue_fill(Q))
     assert model.queue_is_full()
-    watch = ("prototypes", "feature_extractor.head.6.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight",
-             "feature_extractor.backbone.blocks.11.mlp.fc2.weight")
-    for s_ in range(steps):
+    recs = _c3_oracle_steps(bs, steps)   # (once per session: shared by the three modes)
+    for s_, o in enumerate(recs):
         x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=70 + s_))
-        perm = torch.randperm(bs * 196, generator=torch.Generator().manual_seed(s_)).numpy()
-        oloss, aux = om.get_loss(x, faithful=False, return_aux=True, queue_perm=perm)
-        oopt.zero_grad()
-        oloss.backward()
-        loss = model.get_loss(x.cuda(), queue_perm=perm, target_labels=aux["labels"].reshape(bs, -1))
-        assert rel_err(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL, s_
-        mism = (model.last_aux["labels"].cpu() != aux["labels"].reshape(bs, -1)).float().mean().item()
+        loss = model.get_loss(x.cuda(), queue_perm=o["perm"], target_labels=o["labels"])
+        assert rel_err(model.last_aux["q"].cpu(), o["batch_q"]) < TOL, s_
+        mism = (model.last_aux["labels"].cpu() != o["labels"]).float().mean().item()
         assert mism <= 0.01, (s_, mism)
         opt.step(loss)
-        assert abs(loss.item() - oloss.item()) < 2e-4, (s_, loss.item(), oloss.item())
-        og, mg = dict(om.named_parameters()), dict(model.named_parameters())
-        for name in watch:
-            assert rel_err(mg[name].grad.cpu(), og[name].grad) < TOL, (s_, name)
-        oopt.step()
+        assert abs(loss.item() - o["loss"]) < 2e-4, (s_, loss.item(), o["loss"])
+        mg = dict(model.named_parameters())
+        assert_all_grads(mg, o["grads"], f"C3 bs={bs} step {s_} [{accurate_precision}]")
         model.normalize_prototypes()
-        om.normalize_prototypes()
         model.update_momentum_teacher(opt.global_step)
-        om.update_momentum_teacher(oopt.global_step)
-        for name in watch:
-            assert rel_err(mg[name].detach().cpu(), og[name].detach()) < 1e-4, (s_, name)
-        assert rel_err(model.queue.cpu(), om.queue) < 1e-4
-        assert rel_err(model.teacher_prototypes.detach().cpu(), om.teacher_prototypes) < 1e-4
+        for name in C3_WATCH:
+            assert rel_err(mg[name].detach().cpu(), o["params"][name]) < 1e-4, (s_, name)
+        assert rel_err(model.queue.cpu(), o["queue"]) < 1e-4
+        assert rel_err(model.teacher_prototypes.detach().cpu(), o["teacher_prototypes"]) < 1e-4
         tw = dict(model.teacher.named_parameters())["backbone.blocks.11.mlp.fc2.weight"].detach().cpu()
-        assert rel_err(tw, om.teacher.backbone["blocks.11.mlp.fc2.weight"]) < 1e-4
+        assert rel_err(tw, o["teacher_fc2"]) < 1e-4
 
 
 def test_use_mask_full_size_vs_oracle():
@@ -652,15 +712,21 @@ def test_other_architectures_vs_oracle(arch, K, bs, fs):
     assert rel_err(bf.cpu(), obf) < TOL
     oloss, aux = om.get_loss(x, faithful=False, return_aux=True)
     oloss.backward()
-    loss = model.get_loss(x.cuda(), target_labels=aux["labels"].reshape(bs, -1))   # the oracle's hard labels feed the CE
-    loss.backward()
-    mism = (model.last_aux["labels"].cpu() != aux["labels"].reshape(bs, -1)).float().mean().item()
-    assert mism <= 0.01
-    assert rel_err(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL
-    assert abs(loss.item() - oloss.item()) < 2e-4
-    og = dict(om.named_parameters())
-    for name in ("prototypes", "feature_extractor.head.0.weight", "feature_extractor.backbone.blocks.10.attn.qkv.weight"):
-        assert rel_err(dict(model.named_parameters())[name].grad.cpu(), og[name].grad) < TOL, name
+    og = {n_: p_.grad for n_, p_ in om.named_parameters() if p_.grad is not None}
+    from timetuning_amd import hip_ops
+    for mode in ("f32", "f16x3"):   # the exact-f32 kernels and the headline arithmetic (launches of >= PAIRS_MIN_ROWS rows on pairs), one oracle step
+        try:
+            hip_ops.set_gemm_precision(mode)
+            model.zero_grad(set_to_none=True)
+            loss = model.get_loss(x.cuda(), target_labels=aux["labels"].reshape(bs, -1))   # the oracle's hard labels feed the CE
+            loss.backward()
+        finally:
+            hip_ops.set_gemm_precision("f32")
+        mism = (model.last_aux["labels"].cpu() != aux["labels"].reshape(bs, -1)).float().mean().item()
+        assert mism <= 0.01
+        assert rel_err(model.last_aux["q"].cpu(), aux["batch_q"]) < TOL
+        assert abs(loss.item() - oloss.item()) < 2e-4
+        assert_all_grads(dict(model.named_parameters()), og, f"{arch} K={K} fs={fs} [{mode}]")   # all 33 trainable tensors, relative L2
 
 
 @pytest.mark.timeout(900)

@@ -164,7 +164,9 @@ static int tn_splits(int N, int K, int M) {
 using namespace tt;
 
 extern "C" int tt_linear_bwd_weight_pairs_tn_ok(int N, int K, int M) {
-  return N > 0 && K > 0 && M > 0 && N % 128 == 0 && K % 128 == 0 && (long long)M * N * 4 < 0xffffffffLL && (long long)M * K * 4 < 0xffffffffLL;
+  // 32-bit byte offsets into both operands, the last 32-row chunk included (rows M .. M + 31 are formed before the buffer's range check
+  // zeroes them: ADVICE r4 - within 32 rows of 4 GiB the offset wrapped back INTO the buffer); the bound of the other pair kernels
+  return N > 0 && K > 0 && M > 0 && N % 128 == 0 && K % 128 == 0 && ((long long)M + 32) * N * 4 < 0x7fffffffLL && ((long long)M + 32) * K * 4 < 0x7fffffffLL;
 }
 extern "C" size_t tt_linear_bwd_weight_pairs_tn_workspace_bytes(int N, int K, int M) {
   if (!tt_linear_bwd_weight_pairs_tn_ok(N, K, M)) return 0;
@@ -174,7 +176,7 @@ extern "C" size_t tt_linear_bwd_weight_pairs_tn_workspace_bytes(int N, int K, in
 extern "C" int tt_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, float* dw, const float* dy_scale, int N, int K, int M,
                                              void* workspace, size_t workspace_bytes, tt_stream_t stream) {
   TT_REQUIRE(dy_pairs && x_pairs && dw && workspace, "linear_bwd_weight_pairs_tn: null pointer");
-  TT_REQUIRE(tt_linear_bwd_weight_pairs_tn_ok(N, K, M), "linear_bwd_weight_pairs_tn: need N %% 128 == 0, K %% 128 == 0, operands under 4 GB (N %d K %d M %d)", N, K, M);
+  TT_REQUIRE(tt_linear_bwd_weight_pairs_tn_ok(N, K, M), "linear_bwd_weight_pairs_tn: need N %% 128 == 0, K %% 128 == 0, operands under 2 GB (N %d K %d M %d)", N, K, M);
   TT_REQUIRE(workspace_bytes >= tt_linear_bwd_weight_pairs_tn_workspace_bytes(N, K, M), "linear_bwd_weight_pairs_tn: workspace too small");
   TT_REQUIRE(aligned16(dy_pairs) && aligned16(x_pairs) && aligned16(dw) && aligned16(workspace), "linear_bwd_weight_pairs_tn: buffers must be 16-byte aligned");
   const int s = tn_splits(N, K, M);

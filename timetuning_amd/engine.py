@@ -591,6 +591,66 @@ def _gather_buffer(rows: int, cols: int, device) -> torch.Tensor:
 # per iteration (``iters`` small latency-bound collectives, a solve of B_loc instead of W B_loc columns).  ``--sinkhorn_exchange``.
 SINKHORN_EXCHANGE = "allgather"
 _SK_LOCAL: Dict[tuple, "ops.SinkhornLocal"] = {}
+# Gradient exchange: 0 = a bucket per ``GradExchange.push`` (the four the fused backward produces, each hidden behind the backward that
+# follows it), 1 = ONE all-reduce of all gradients at the end of the backward (fewer latency-bound collectives, nothing hidden).
+GRAD_BUCKETS = 0
+# What ``autotune_exchange`` measured and chose on THIS communicator (None: defaults / flags, nothing measured); bench.py prints it.
+EXCHANGE_CHOICE: Optional[dict] = None
+
+
+def autotune_exchange(run_step, device, reps: int = 3, margin: float = 0.97, log=None) -> Optional[dict]:
+    """Which of the two Sinkhorn exchanges ("allgather": one 6.7 MB all-gather + a W-times-larger redundant solve; "allreduce": the
+    reference's ``iters`` K-float all-reduces, my_utils.py:250-272) and which gradient exchange (four buckets behind the backward, or one
+    at its end) is faster over THIS node's links is a property of the machine (xGMI ring latency against the solve's size) that no
+    1-GPU box can tell: with more than one rank it is MEASURED, once, on the training step itself.  ``run_step()`` runs one forward +
+    backward of the real workload (no parameter update); three configurations are timed in the same order on every rank - ``reps``
+    steps each behind one warm-up step, barrier + synchronise on both sides, MAX over ranks so that every rank sees the same numbers and
+    takes the same decision - and a variant replaces the default only when it is faster by more than ``1 - margin`` (3 %).
+    Sets ``SINKHORN_EXCHANGE`` / ``GRAD_BUCKETS``, records the measurements in ``EXCHANGE_CHOICE`` and returns it; a no-op (None) without
+    a process group of more than one rank."""
+    import time
+
+    global SINKHORN_EXCHANGE, GRAD_BUCKETS, EXCHANGE_CHOICE
+    dist = exchange_group()
+    if dist is None or dist.get_world_size() < 2:
+        return None
+    dev = torch.device(device)
+    cuda = dev.type == "cuda"
+
+    def timed(sk: str, buckets: int) -> float:
+        global SINKHORN_EXCHANGE, GRAD_BUCKETS
+        SINKHORN_EXCHANGE, GRAD_BUCKETS = sk, buckets
+        run_step()                                   # warm-up: buffers, communicator channels, the arena's layout for this bucket count
+        if cuda:
+            torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run_step()
+        if cuda:
+            torch.cuda.synchronize(dev)
+        t = torch.tensor([(time.perf_counter() - t0) * 1e3 / reps], dtype=torch.float64, device=dev if cuda else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    keep = (SINKHORN_EXCHANGE, GRAD_BUCKETS)
+    ms = {}
+    try:
+        ms["allgather/4"] = timed("allgather", 0)
+        ms["allreduce/4"] = timed("allreduce", 0)
+        sk = "allreduce" if ms["allreduce/4"] < margin * ms["allgather/4"] else "allgather"
+        ms[f"{sk}/1"] = timed(sk, 1)
+        buckets = 1 if ms[f"{sk}/1"] < margin * ms[f"{sk}/4"] else 0
+    except Exception:
+        SINKHORN_EXCHANGE, GRAD_BUCKETS = keep
+        raise
+    SINKHORN_EXCHANGE, GRAD_BUCKETS = sk, buckets
+    EXCHANGE_CHOICE = dict(sinkhorn_exchange=sk, grad_buckets=4 if buckets == 0 else 1, ms_per_step=ms, reps=reps, world_size=dist.get_world_size(),
+                           rule=f"a variant replaces the default (allgather, 4 buckets) when faster by > {100 * (1 - margin):.0f} %")
+    if log is not None and dist.get_rank() == 0:
+        log(f"exchange autotune (W = {dist.get_world_size()}): " + ", ".join(f"{k} {v:.3f} ms" for k, v in ms.items())
+            + f" -> sinkhorn {sk}, {EXCHANGE_CHOICE['grad_buckets']} gradient bucket(s)")
+    return EXCHANGE_CHOICE
 
 
 def global_sinkhorn_allreduce(scores_local: torch.Tensor, rows_out: int, eps: float, iters: int, lib=None) -> torch.Tensor:
@@ -674,15 +734,20 @@ class GradArena:
         self.slots: Dict[torch.nn.Parameter, torch.Tensor] = {}     # param -> its view of ``flat``
         self.buckets: List[tuple] = []                                # (start, end, [params])
 
+    ALIGN = 4   # floats: the backward kernels write dw / db through 16-byte stores (tt_linear_bwd_weight_pairs_tn rejects anything else)
+
     def build(self, buckets: List[List[torch.nn.Parameter]], device) -> None:
-        total = sum(p.numel() for keys in buckets for p in keys)
-        self.flat = torch.empty((total,), dtype=f32, device=device)
+        # every slot starts on a 16-byte boundary (a tensor whose numel is not a multiple of 4 - an odd bias, a custom head
+        # width - misaligned every slot behind it); the padding floats stay zero and travel with their bucket, which is harmless
+        pad = lambda n: (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        total = sum(pad(p.numel()) for keys in buckets for p in keys)
+        self.flat = torch.zeros((total,), dtype=f32, device=device)
         self.slots, self.buckets, off = {}, [], 0
         for keys in buckets:
             start = off
             for p in keys:
                 self.slots[p] = self.flat[off:off + p.numel()].view(p.shape)
-                off += p.numel()
+                off += pad(p.numel())
             self.buckets.append((start, off, list(keys)))
 
     def reset(self) -> None:
@@ -713,7 +778,7 @@ class GradExchange:
     def __init__(self, arena: Optional[GradArena] = None):
         self.dist = exchange_group()
         self.sent = set()
-        self.buckets = []  # (keys, flat, work)
+        self.buckets = []  # (keys, flat, work, in_arena)
         self.arena = arena if self.dist is not None else None
         self.use_arena = self.arena is not None and self.arena.flat is not None
         if self.use_arena:
@@ -726,9 +791,11 @@ class GradExchange:
             return None
         return self.arena.slots.get(p)
 
-    def push(self, grads: Dict[torch.nn.Parameter, torch.Tensor]) -> None:
+    def push(self, grads: Dict[torch.nn.Parameter, torch.Tensor], final: bool = False) -> None:
         if self.dist is None:
             return
+        if GRAD_BUCKETS == 1 and not final:
+            return                                   # one all-reduce of everything, issued by ``finish``
         keys = [k for k in grads if k not in self.sent and k.requires_grad]
         if not keys:
             return
@@ -746,11 +813,12 @@ class GradExchange:
                 flat = self.arena.flat[start:end]
             else:
                 self.use_arena = False   # a different set / order of gradients: this step flattens by hand, the layout is rebuilt at finish
+        in_arena = flat is not None
         if flat is None:
             flat = torch.cat([grads[k].reshape(-1) for k in keys])
         work = self.dist.all_reduce(flat, async_op=True)
         self.sent.update(keys)
-        self.buckets.append((keys, flat, work))
+        self.buckets.append((keys, flat, work, in_arena))
 
     def prescale_(self, root_grad: torch.Tensor) -> bool:
         """Applies the 1 / world_size of the mean at the ROOT of the backward (the loss gradient, one small tensor) instead of to
@@ -765,9 +833,9 @@ class GradExchange:
     def finish(self, grads: Dict[torch.nn.Parameter, torch.Tensor], scale: bool = True) -> Dict[torch.nn.Parameter, torch.Tensor]:
         if self.dist is None:
             return grads
-        self.push(grads)
+        self.push(grads, final=True)
         inv = torch.full((1,), 1.0 / self.dist.get_world_size(), dtype=f32, device=self.buckets[0][1].device) if self.buckets and scale else None
-        for b_i, (keys, flat, work) in enumerate(self.buckets):
+        for b_i, (keys, flat, work, in_arena) in enumerate(self.buckets):
             wait_collective(work, f"all_reduce(grad bucket {b_i})", flat.numel() * 4, flat.device)
             if not scale:
                 pass                                 # (already the mean: prescale_)
@@ -777,7 +845,8 @@ class GradExchange:
                 flat *= inv                          # (CPU tensors: only the gloo tests of the collective logic)
             off = 0
             for k in keys:
-                grads[k] = flat[off:off + k.numel()].view(k.shape)
+                # (an arena bucket: the parameter's own 16-byte aligned slot - the slots are padded; a hand-flattened one: back to back)
+                grads[k] = self.arena.slots[k] if in_arena else flat[off:off + k.numel()].view(k.shape)
                 off += k.numel()
         if self.arena is not None and not self.use_arena and self.buckets and self.buckets[0][1].is_cuda:
             self.arena.build(self.recorded, self.buckets[0][1].device)   # the layout the next steps write into

@@ -956,6 +956,29 @@ def linear_fwd_planes(xp, wp, bias=None, residual=None, act: int = 0, out_f32: b
     return dict(y=y, planes=yp, pre=pre)
 
 
+_RANGE_PENDING: dict = {}
+
+
+def poll_pair_range(device=None) -> None:
+    """``check_pair_range`` without a synchronisation, for the per-step path: the flag travels to a pinned host word asynchronously, and the
+    call raises PairRangeError when a PREVIOUS poll's copy has landed with the flag set (detection lags by one step)."""
+    f = range_flag(device)
+    if f is None:
+        return
+    idx = f.device.index
+    pend = _RANGE_PENDING.get(idx)
+    if pend is None:
+        pend = _RANGE_PENDING[idx] = dict(host=torch.zeros(4, dtype=torch.int32).pin_memory(), event=None)
+    if pend["event"] is not None and pend["event"].query():
+        pend["event"] = None
+        if int(pend["host"][0]) != 0:
+            check_pair_range(device)   # (synchronises, resets, raises)
+    if pend["event"] is None:
+        pend["host"].copy_(f, non_blocking=True)
+        pend["event"] = torch.cuda.Event()
+        pend["event"].record()
+
+
 # ---- fp16-pair operands (include/timetuning_hip.h: "fp16-PAIR operands") ------------------------------------------------------
 f16 = torch.float16
 

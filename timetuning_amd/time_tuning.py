@@ -286,6 +286,14 @@ class TimeT(nn.Module):
             tail.update(teacher_flat=c["t"][:n] if n else None, student_flat=c["s"][:n] if n else None,
                         teacher_prototypes=self.teacher_prototypes.data, momentum=momentum)
         optimizer.step(loss, tail=tail)
+        if ops.pairs():
+            ops.poll_pair_range(self.prototypes.device)   # the "f16x3" mode's range contract, without a synchronisation (one step late)
+
+    def check_pair_range(self) -> None:
+        """The "f16x3" arithmetic has fp32's precision, not its range: raises ``hip_ops.PairRangeError`` if an operand of a step since the
+        last check lay beyond fp16's range (|x| > 65504) or was not finite - where the reference's fp32 arithmetic would have carried on
+        and this mode's products are inf / NaN.  Synchronises: the driver calls it where it reads the loss anyway."""
+        ops.check_pair_range(self.prototypes.device)
 
     # -- reference method names, delegating to the HIP path ------------------------------------------
     def get_feature_prototype_similarity(self, x, use_teacher=False):
@@ -364,15 +372,15 @@ class TimeT(nn.Module):
         tap: Optional[dict] = {"block": t_first, "rows": bs} if t_first > 0 else None
 
         if ops.pairs():   # "f16x3": every pair operand the last optimizer / EMA update made stale, in one launch
-            if getattr(self, "_pair_weight_list", None) is None:
-                mods = [self] + ([self.teacher] if getattr(self, "teacher", None) is not None else [])
-                seen, lst = set(), []
-                for m in mods:
-                    for p_ in m.parameters():
-                        if p_.dim() == 2 and id(p_) not in seen:
-                            seen.add(id(p_)); lst.append(p_)
-                self._pair_weight_list = lst
-            engine.refresh_pair_operands(self._pair_weight_list)
+            # (rebuilt per step - a walk over ~150 parameters: a teacher attached or a head module swapped after the first step is in the
+            # batched refresh at once)
+            mods = [self] + ([self.teacher] if getattr(self, "teacher", None) is not None else [])
+            seen, lst = set(), []
+            for m in mods:
+                for p_ in m.parameters():
+                    if p_.dim() == 2 and id(p_) not in seen:
+                        seen.add(id(p_)); lst.append(p_)
+            engine.refresh_pair_operands(lst)
 
         # ---- student: one pass over all frames, time-major
         use_mask = hp.get("mask_features", False)
@@ -698,9 +706,11 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--precision", default="f16x3", choices=["f16x3", "f32", "bf16x6", "bf16x3", "bf16"],
                    help="arithmetic of the matrix products (hip_ops.set_gemm_precision): f16x3 = the fp32-accurate fp16-pair split (per-op error "
                         "under the exact-f32 MFMA kernels', 1.7x their speed), f32 = exact fp32 MFMA, bf16 = BASELINE C4's bf16 path")
-    p.add_argument("--sinkhorn_exchange", default="allgather", choices=["allgather", "allreduce"],
-                   help="W > 1: allgather = one all-gather of the score rows, every rank solves the global problem (default); allreduce = the "
-                        "reference's own pattern (my_utils.py:250-272): columns stay on their rank, the K row sums are all-reduced per iteration")
+    p.add_argument("--sinkhorn_exchange", default="auto", choices=["auto", "allgather", "allreduce"],
+                   help="W > 1: allgather = one all-gather of the score rows, every rank solves the global problem; allreduce = the "
+                        "reference's own pattern (my_utils.py:250-272): columns stay on their rank, the K row sums are all-reduced per iteration; "
+                        "auto (default) = both - and the 4-bucket against the 1-bucket gradient exchange - are timed on the first batch and the "
+                        "faster is kept (engine.autotune_exchange)")
     return p
 
 
@@ -797,7 +807,8 @@ def time_tuning(gpu=0, args=None):
     device = torch.device("cuda", gpu)
     torch.cuda.set_device(device)
     ops.set_gemm_precision(getattr(args, "precision", "f16x3"))   # the driver's default: the fp32-accurate fp16-pair split
-    engine.SINKHORN_EXCHANGE = getattr(args, "sinkhorn_exchange", "allgather")
+    sk_exchange = getattr(args, "sinkhorn_exchange", "auto")
+    engine.SINKHORN_EXCHANGE = "allgather" if sk_exchange == "auto" else sk_exchange
     if world_size > 1 and not dist.is_initialized():
         dist.init_process_group(backend=os.environ.get("TT_DIST_BACKEND", "nccl"), init_method="env://", world_size=world_size, rank=rank)
     if args.use_projection_head:
@@ -855,11 +866,25 @@ def time_tuning(gpu=0, args=None):
         model.train()
         for i, (data, annotations, label) in enumerate(loader):
             data = data.squeeze(1)
+            if world_size > 1 and sk_exchange == "auto" and engine.EXCHANGE_CHOICE is None:
+                # the first batch decides how this communicator exchanges (forward + backward only: no parameter, queue or teacher update
+                # is kept - the queue is restored below)
+                q_keep = model.queue.clone() if getattr(model, "queue", None) is not None else None
+
+                def _probe_step():
+                    model.zero_grad(set_to_none=True)
+                    model(data, annotations, True, args.use_mask).backward()
+
+                engine.autotune_exchange(_probe_step, device, log=print)
+                model.zero_grad(set_to_none=True)
+                if q_keep is not None:
+                    model.set_queue(q_keep)
             loss = model(data, annotations, True, args.use_mask)
             # optimizer.step(loss); model.normalize_prototypes(); model.update_momentum_teacher(global_step) (:659-663) as one call
             model.train_update(opt, loss, min(opt.global_step + 1, last))
             if rank == 0:
                 print("Iteration: {}/{} loss {:.4f}".format(i, num_itr, loss.item()))
+                model.check_pair_range()   # the "f16x3" mode's range contract (the host has just synchronised for the loss)
     model.eval_scores = scores
     return model
 
