@@ -97,6 +97,9 @@ def _worker(rank, W, port, ret, backend="gloo"):
         engine.SINKHORN_EXCHANGE = "allgather"
     torch.cuda.synchronize()
     waits_r, engine.RCCL_PROFILE = engine.RCCL_PROFILE, None
+    arena_stats = dict(arena_floats=arena.flat.numel(), bucket_sizes=[e - s_ for s_, e, _ in arena.buckets],
+                       in_arena=all(lo <= p.grad.data_ptr() < hi for p in inner.parameters() if p.requires_grad),
+                       same_as_first=all(torch.equal(params[n].grad, first[n]) for n in WATCH))
     # step 4 ...: the exchange decides for itself (engine.autotune_exchange, what time_tuning() / bench.py run on the first multi-rank batch):
     # the three configurations are timed on the real step, every rank must arrive at the same choice, and a step under the chosen
     # configuration (whichever it is - one bucket, the all-reduce Sinkhorn) still gives step 1's loss and gradients
@@ -118,9 +121,7 @@ def _worker(rank, W, port, ret, backend="gloo"):
                      waits_allreduce=[(k, n) for k, n, _, _ in waits_r if "sinkhorn" in k or "gather" in k], grads={n: params[n].grad.cpu().numpy() for n in WATCH},
                      q=model.last_aux["q"].cpu().numpy(), waits=[(k, n, e0.elapsed_time(e1)) for k, n, e0, e1 in waits],
                      trainable=sum(p.numel() for p in inner.parameters() if p.requires_grad),
-                     same_as_first=all(torch.equal(params[n].grad, first[n]) for n in WATCH), cats=cats["n"],
-                     in_arena=all(lo <= p.grad.data_ptr() < hi for p in inner.parameters() if p.requires_grad),
-                     arena_floats=arena.flat.numel(), bucket_sizes=[e - s_ for s_, e, _ in arena.buckets])
+                     cats=cats["n"], **arena_stats)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -280,12 +281,22 @@ def test_bench_gpus_2_through_its_own_launcher():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     rc = out["rccl"]
     assert rc["world_size"] == 2 and rc["backend"] == "gloo"
-    # the exchange of the instrumented step: ONE all-gather of the score rows (2 ranks x 2 clips x 196 patches x 50 prototypes, fp32)
-    # and the gradient buckets' all-reduces (every trainable float exactly once), each with the compute stream's exposed wait
+    # the exchange decided for itself before the warm-up (engine.autotune_exchange): three configurations timed, one kept, recorded
+    au = rc["exchange_autotune"]
+    assert au["world_size"] == 2 and sorted(au["ms_per_step"])[0] == "allgather/4" and len(au["ms_per_step"]) == 3 and all(v > 0 for v in au["ms_per_step"].values())
+    assert au["sinkhorn_exchange"] in ("allgather", "allreduce") and au["grad_buckets"] in (1, 4)
+    # the exchange of the instrumented step under that choice: ONE all-gather of the score rows (2 ranks x 2 clips x 196 patches x 50
+    # prototypes, fp32) or ten K-float all-reduces of the row sums; four gradient buckets or one - every trainable float exactly once -
+    # each with the compute stream's exposed wait
     kinds = [w["collective"] for w in rc["waits"]]
-    assert kinds[0] == "all_gather(scores)" and rc["waits"][0]["bytes"] == 2 * 2 * 196 * 50 * 4
+    if au["sinkhorn_exchange"] == "allgather":
+        assert kinds[0] == "all_gather(scores)" and rc["waits"][0]["bytes"] == 2 * 2 * 196 * 50 * 4
+        n_sk = 1
+    else:
+        assert kinds[:10] == ["all_reduce(sinkhorn row sums)"] * 10 and all(w["bytes"] == 50 * 4 for w in rc["waits"][:10])
+        n_sk = 10
     buckets = [w for w in rc["waits"] if w["collective"].startswith("all_reduce(grad bucket")]
-    assert len(buckets) == 4 and rc["collectives_per_step"] == 5
+    assert len(buckets) == au["grad_buckets"] and rc["collectives_per_step"] == n_sk + au["grad_buckets"]
     assert sum(w["bytes"] for w in buckets) == 4 * (5_700_096 - 200 * 256 + 50 * 256)          # 5.70 M trainable floats at K = 200
     assert all(w["exposed_wait_ms"] >= 0 for w in rc["waits"]) and rc["exposed_wait_ms"] >= 0 and rc["bytes"] > 0
     assert out["value"] > 0 and out["scaling"] == "weak" and np.isfinite(out["loss"])

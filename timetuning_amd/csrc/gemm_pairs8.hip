@@ -722,6 +722,468 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
 #endif
 }
 
+
+// =====================================================================================================================================
+// gemm_pairs8s_kernel (round 5): the same tile, operands, work items and epilogues on a SYMMETRIC, register-prefetched main loop.
+//
+// What round 4's profile said of the kernel above (profiles/r04_gemm_pairs_pmc.json, r04_q8_ablation.txt): matrix pipe busy 0.45 of a
+// workgroup's life on the K = 384 shapes; its two wave groups alternate a "load part" (LDS-DMA issue, then 12 / 8 fragment reads, then a
+// counted wait) with an "MFMA part" of 384 cycles, four barrier intervals per K-tile - and the load part is the LONG one (457 / 527
+// cycles: the four waves of a group hit the texture path with 8 - 16 KB at once, 64 B / clk, then the LDS with 48 KB of reads at once);
+// fragment reads + barriers alone, no MFMAs, no DMA, take 68 k cycles against the MFMAs' 64.5 k.  Here:
+//   * every wave runs the SAME stream, one barrier per K-tile: [wait for the ring | barrier | 24 MFMAs with the 16 fragment reads of the
+//     NEXT phases and the 6 LDS-DMA pieces of later K-tiles issued between them].  The two waves of a SIMD interleave their MFMAs on the
+//     shared matrix pipe (each sees a 64-cycle cadence): a read (16 cycles of the SIMD's LDS return path) or a DMA piece fits in the gap,
+//     and what one wave waits for at the texture path the other covers with MFMAs - the DMA sites of waves 4 - 7 are shifted by two MFMAs
+//     against those of waves 0 - 3 (their SIMD partners), so that at most four 1 KB pieces arrive at the texture path together;
+//   * fragments are prefetched into registers and refreshed IN PLACE, each as soon as the last MFMA of the K-tile that reads it has been
+//     issued: W (both k-steps, hi and lo, of the wave's two 32-row blocks: 32 registers) and X half 0 (16) during phase B (x half 1) of the
+//     K-tile before, X half 1 (16) during phase A.  128 accumulator + 64 fragment registers (a second W set - 96 - was built first:
+//     the allocator spilled accumulators around every item boundary);
+//   * the ring is the same three K-tiles of 48 KB.  Registers free LDS one K-tile earlier, so the DMA runs one K-tile further ahead:
+//     iteration t issues X1 of K-tile t + 2 and W, X0 of K-tile t + 3 (into the slot of K-tile t, whose W / X0 went to registers in
+//     iteration t - 1; its X1 chunk, read in phase A of t, is refilled in iteration t + 1).
+//     RAW: phase A of t reads X1(t), both phases read W / X0(t + 1): issued in iteration t - 2, retired by `vmcnt(6)` (the six pieces of
+//     iteration t - 1 stay in flight) + the barrier at the top of t.  WAR: a chunk is overwritten by a DMA issued after the barrier that
+//     follows the `lgkmcnt(0)` of its last readers: W / X0 of slot(t) were read in iteration t - 1 (complete before barrier t), X1 of
+//     slot(t + 2) = slot(t - 1) in phase A of t - 1 (complete before barrier t).
+//   * the ring slot is a run-time offset and nothing alternates at compile time: any K % 32 == 0 (the kernel above: K % 96 == 0) - the
+//     projection head (K = 1024 / 512 / 256) is taken.
+// Items, half tiles, the K-split exchange and the epilogue are those of the kernel above.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
+  constexpr int ROWB = 128, CPR = 8, WIN = 2, RPI = 8, JPW = 2;
+  constexpr int CHUNK_B = 128 * ROWB;       // 16 KB
+  constexpr int SLOT_B = 3 * CHUNK_B;       // W, X0, X1
+  constexpr int RING_B = 3 * SLOT_B;
+  constexpr int SCR_B = (160 * 1024 - RING_B) / 8;
+  constexpr int CW = SCR_B / 128;
+  constexpr int NPASS = 32 / CW;
+  constexpr int BN = 128;
+  constexpr bool F32OUT = EPI == Q8_F32 || EPI == Q8_F32_RES || EPI == Q8_F32_GELUGRAD;
+  constexpr bool RES = EPI == Q8_F32_RES || EPI == Q8_F32_GELUGRAD;
+  constexpr bool GG = EPI == Q8_F32_GELUGRAD;
+  constexpr bool BOTH = EPI == Q8_BOTH || EPI == Q8_BOTH_GELU;
+  constexpr bool ACT = EPI == Q8_PAIR_GELU || EPI == Q8_BOTH_GELU;
+  constexpr int ST_TILE = BOTH ? 8 : 4;               // stores a wave issues per 32 x 32 MFMA tile
+  constexpr int ST_FULL = 4 * ST_TILE, ST_HALF = ST_FULL / 2;
+  constexpr int S_FULL = ST_FULL < 63 - 6 ? ST_FULL : 63 - 6, S_HALF = ST_HALF < 63 - 6 ? ST_HALF : 63 - 6;
+  static_assert(RING_B + 8 * SCR_B <= 160 * 1024 && CW == 16, "LDS budget");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[160 * 1024];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool late = wave >= 4;                      // the SIMD partners of waves 0 - 3: their DMA sites are two MFMAs later
+  const int wr = wave & 3, wc = wave >> 2;          // 4 x 2 waves of 64 x 64
+  const int r = lane & 31, h = lane >> 5;
+  const int K4 = g.K * 4, nk = g.K / 32;
+
+  // ---- work items (as gemm_pairs8_kernel)
+  int cu = blockIdx.x;
+  if ((g.ncu & 7) == 0) cu = (blockIdx.x & 7) * (g.ncu >> 3) + (blockIdx.x >> 3);
+  int n_whole;
+  bool has_half = false;
+  const bool ksplit = g.ks_S >= 2;
+  if (g.n_full > 0 || g.n_half > 0 || ksplit) {
+    n_whole = g.n_full;
+    has_half = !ksplit && cu < g.n_half;
+  } else {
+    n_whole = cu < g.ntiles ? (g.ntiles - cu + g.ncu - 1) / g.ncu : 0;
+  }
+  const bool has_slice = ksplit && cu < g.ks_R * g.ks_S;
+  const int n_items = n_whole + (has_half || has_slice ? 1 : 0);
+  if (n_items == 0) return;
+  const bool half_first = has_half && (cu & 1) && n_whole > 0;
+  auto item = [&](int it, int& row0, int& n0, bool& half, int& kt0, int& kend) {
+    int tile;
+    kt0 = 0;
+    kend = nk;
+    half = has_half && (half_first ? it == 0 : it == n_whole);
+    int hsel = 0;
+    if (half) {
+      tile = g.n_full * g.ncu + (cu >> 1);
+      hsel = cu & 1;
+    } else if (has_slice && it == n_whole) {
+      const int j = cu / g.ks_S, sl = cu - j * g.ks_S;   // slices: whole K-tiles, at least one each (pairs8_plan, kgroup = 1: ks_S <= nk)
+      tile = g.n_full * g.ncu + j;
+      kt0 = sl * nk / g.ks_S;
+      kend = (sl + 1) * nk / g.ks_S;
+    } else {
+      tile = (half_first ? it - 1 : it) * g.ncu + cu;
+    }
+    const int mb = tile / g.ntn, ns = tile - mb * g.ntn;
+    row0 = mb * 256 + hsel * 128;
+    n0 = ns * BN;
+  };
+
+  // ---- LDS-DMA lane map (as above): lane -> (row, 16-byte slot) of a 1 KB piece, source chunk = slot ^ f(row).  ONE per-lane offset serves
+  // every piece (W and X alike: rows of K4 bytes): the piece's first row and the K-tile are a SCALAR added to it, and the descriptors
+  // carry the operands' true sizes, so that rows beyond M (a ragged last tile) and the pieces of K-tiles that do not exist (the cursor
+  // past its last item: scalar 2^31) are zero-filled by the range check instead of being clamped or branched around - every iteration
+  // issues exactly six pieces, and every counted wait is `vmcnt(6)`.
+  const int l_row = lane / CPR, l_slot = lane % CPR;
+  const int d_row0 = wave * RPI + l_row;
+  const int d_chunk = l_slot ^ ((d_row0 / WIN) & (CPR - 1));
+  const unsigned lane_voff = (unsigned)(d_row0 * K4 + d_chunk * 16);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(g.X), 0, (unsigned)g.M * (unsigned)K4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(g.W), 0, (unsigned)g.N * (unsigned)K4, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  const unsigned piece_step = 8u * RPI * (unsigned)K4;   // 64 rows: the second piece of a chunk
+
+  // ---- DMA cursor: the K-tile whose W / X0 chunks are issued next (three K-tiles ahead of the MFMAs), as scalar byte offsets of its first
+  // W row / first X row + its K-tile; `lag` = the K-tile before it, whose X1 chunk is issued next
+  int d_item = 0, d_kt = 0, d_kend = 0;
+  bool d_done = false, d_half = false;
+  unsigned cur_w = OOB, cur_x = OOB, lag_x1 = OOB;
+  auto cursor_item = [&]() {
+    int row0, n0;
+    item(d_item, row0, n0, d_half, d_kt, d_kend);
+    cur_w = (unsigned)n0 * (unsigned)K4 + (unsigned)d_kt * ROWB;
+    cur_x = (unsigned)row0 * (unsigned)K4 + (unsigned)d_kt * ROWB;
+  };
+  cursor_item();
+  // ring slots (byte offsets) of K-tile t (s0), t + 1 (s1), t + 2 (s2); W / X0 of t + 3 go to s0
+  int s0 = 0, s1 = SLOT_B, s2 = 2 * SLOT_B;
+  auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, int lds_off, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (q8_lds_ptr_t)(smem + lds_off + wave * 1024), 16, lane_voff + soff, 0, 0, 0);
+  };
+  // the six DMA sites of an iteration: X1 0 / 1 of the lag (-> slot_x1), W 0 / 1 and X0 0 / 1 of the cursor (-> slot_wx)
+  auto site = [&](int k, int slot_x1, int slot_wx) {
+    if (k == 0) dma(rs_x, slot_x1 + 2 * CHUNK_B, lag_x1);
+    else if (k == 1) dma(rs_x, slot_x1 + 2 * CHUNK_B + 8 * 1024, lag_x1 + piece_step);
+    else if (k == 2) dma(rs_w, slot_wx, cur_w);
+    else if (k == 3) dma(rs_w, slot_wx + 8 * 1024, cur_w + piece_step);
+    else if (k == 4) dma(rs_x, slot_wx + CHUNK_B, cur_x);
+    else if (k == 5) dma(rs_x, slot_wx + CHUNK_B + 8 * 1024, cur_x + piece_step);
+  };
+  // after the cursor's W / X0 have been issued: it becomes the lag, and moves on
+  auto cursor_advance = [&]() {
+    lag_x1 = (d_done || d_half) ? OOB : cur_x + 128u * (unsigned)K4;
+    if (d_done) return;
+    ++d_kt;
+    cur_w += ROWB;
+    cur_x += ROWB;
+    if (d_kt == d_kend) {
+      ++d_item;
+      if (d_item >= n_items) { d_done = true; cur_w = OOB; cur_x = OOB; }
+      else cursor_item();
+    }
+  };
+
+  // ---- fragment addressing (as above)
+  const int f_sw = (r / WIN) & (CPR - 1);
+  int fo[4];
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) fo[c4] = r * ROWB + (((2 * c4 + h) ^ f_sw) << 4);
+  const int x_slice = wr * 32 * ROWB, w_slice = wc * 64 * ROWB;
+
+  f32x16 a1[2][2], a2[2][2];   // zeroed at the top of every item (not at the end of the epilogue: 128 registers of zeros live across the
+                               // item loop's header were spilled)
+  f16x8 Wf[2][4];      // [w block][hi k-step 0, 1, lo k-step 0, 1]
+  f16x8 Xf[2][4];      // [x half][...]
+  auto rd_w = [&](int slot, int mt, int c4) { Wf[mt][c4] = *reinterpret_cast<const f16x8*>(smem + slot + w_slice + mt * 32 * ROWB + fo[c4]); };
+  auto rd_x = [&](int ha, int slot, int c4) { Xf[ha][c4] = *reinterpret_cast<const f16x8*>(smem + slot + (1 + ha) * CHUNK_B + x_slice + fo[c4]); };
+
+  // counted wait at the top of an iteration: all but the six pieces of the previous iteration (+ the stores of an epilogue that lies
+  // between: a lower bound of their number) are complete
+  int post_epi = 0;         // iterations whose window still reaches back across an epilogue
+  bool post_half = false;
+  auto wait_ring = [&]() {
+    if (post_epi > 0) {
+      --post_epi;
+      if (post_half) q8_wait_vmcnt<6 + S_HALF>();
+      else q8_wait_vmcnt<6 + S_FULL>();
+    } else {
+      q8_wait_vmcnt<6>();
+    }
+  };
+
+  // ---- one K-tile.  LAST: the item's last K-tile (no refresh of the fragments: they would be live across the epilogue); HALF: a half item
+  // (x half 0 only); LATE: waves 4 - 7.  A K-tile is 8 (HALF: 4) "slots" of three MFMAs - one (k-step, w block) pair: hi lo | hi hi | lo hi,
+  // the two that share the cross accumulator apart - with this wave's reads and DMA sites between them: waves 0 - 3 issue a slot's piece
+  // behind its first MFMA, their SIMD partners behind its last one.  Fragments are refreshed IN PLACE, each as soon as the last MFMA of this
+  // K-tile that reads it has been issued (a register is read when its MFMA issues; the LDS data arrives > 64 cycles later):
+  //   phase A (x half 0): X1(t) -> Xf[1], one fragment per slot (phase B of t - 1 was its last reader);
+  //   phase B (x half 1): X0(t + 1) -> Xf[0], one per slot (phase A is over); W(t + 1): the slot's own two fragments behind its last MFMA.
+  // A fragment is next read at least four slots (~ 800 cycles) after its refresh was issued.
+#define Q8S_FENCE() __builtin_amdgcn_sched_barrier(0)
+  auto ktile = [&](auto last_c, auto half_c, auto late_c) {
+    constexpr bool LAST = decltype(last_c)::value, HALF = decltype(half_c)::value, LATE = decltype(late_c)::value;
+    // top: the reads of the previous iteration are in registers (and nobody still reads what this iteration's DMA overwrites); the ring
+    // holds X1(t) and W / X0(t + 1) once every wave has passed its counted wait
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_ring();
+    __builtin_amdgcn_s_barrier();
+    Q8S_FENCE();
+    const int sx1 = s2, swx = s0, sr0 = s0, sr1 = s1;
+    // slot (phase PH, q = (k-step, w block)): k, k2 = its DMA site(s), -1 = none
+    auto slot = [&](auto ph_c, int q, int k, int k2) {
+      constexpr int PH = decltype(ph_c)::value;
+      const int ks = q >> 1, mt = q & 1;
+      a2[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][ks], Xf[PH][2 + ks], a2[PH][mt], 0, 0, 0);
+      Q8S_FENCE();
+      if constexpr (!LATE) { if (k >= 0) site(k, sx1, swx); if (k2 >= 0) site(k2, sx1, swx); }
+      Q8S_FENCE();
+      a1[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][ks], Xf[PH][ks], a1[PH][mt], 0, 0, 0);
+      Q8S_FENCE();
+      if constexpr (!HALF) {
+        if constexpr (PH == 0) rd_x(1, sr0, q);                    // X1(t): phase B's operand
+        else if constexpr (!LAST) rd_x(0, sr1, q);                 // X0(t + 1)
+      }
+      Q8S_FENCE();
+      a2[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][2 + ks], Xf[PH][ks], a2[PH][mt], 0, 0, 0);
+      Q8S_FENCE();
+      if constexpr (!LAST && (HALF || PH == 1)) {                  // the last phase of the K-tile: W(t + 1) in place, this slot's two fragments
+        rd_w(sr1, mt, ks);
+        rd_w(sr1, mt, 2 + ks);
+        if constexpr (HALF) {                                      // ... and X0(t + 1): k-step ks is done once its second w block (mt = 1) is
+          if (mt == 1) { rd_x(0, sr1, ks); rd_x(0, sr1, 2 + ks); }
+        }
+      }
+      Q8S_FENCE();
+      if constexpr (LATE) { if (k >= 0) site(k, sx1, swx); if (k2 >= 0) site(k2, sx1, swx); }
+      Q8S_FENCE();
+    };
+    using PH0 = std::integral_constant<int, 0>; using PH1 = std::integral_constant<int, 1>;
+    if constexpr (HALF) {   // (its X1 pieces are the lag's: out of range for a half item, zero-filled into a chunk nobody reads)
+      slot(PH0{}, 0, 0, 2); slot(PH0{}, 1, 3, -1); slot(PH0{}, 2, 1, 4); slot(PH0{}, 3, 5, -1);
+    } else {
+      slot(PH0{}, 0, 0, -1); slot(PH0{}, 1, 1, -1); slot(PH0{}, 2, 2, -1); slot(PH0{}, 3, -1, -1);
+      slot(PH1{}, 0, 3, -1); slot(PH1{}, 1, 4, -1); slot(PH1{}, 2, 5, -1); slot(PH1{}, 3, -1, -1);
+    }
+    cursor_advance();
+    const int t_ = s0; s0 = s1; s1 = s2; s2 = t_;
+  };
+
+  // ---- epilogue of one item (gemm_pairs8_kernel's, through the wave's private scratch)
+  unsigned char* scr = smem + RING_B + wave * SCR_B;
+  constexpr int CPRW = CW / 4;
+  constexpr int LPR = F32OUT ? CPRW : CPRW / 2;
+  constexpr int RPW = 64 / LPR;
+  constexpr int NRB = 32 / RPW;
+  constexpr int NLD = NPASS * NRB;
+  auto esw = [](int row) { return (row >> 2) & (CPRW - 1); };
+  const unsigned out_bytes = (unsigned)g.M * (unsigned)g.N * 4u;
+  auto epilogue = [&](int row0, int n0, bool half) {
+    constexpr int NT = 4;
+    const int nt = half ? NT / 2 : NT;
+    // every lane-dependent address of the epilogue is formed HERE, from a lane id the compiler cannot see through: hoisted out of the item
+    // loop they would be live across the main loop, whose 224 accumulator + fragment registers leave no room for them (they spilled)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int r = lane_e & 31, h = lane_e >> 5;
+    const int rr = lane_e / LPR, cc = lane_e % LPR;
+    bool range_bad = false;
+    const float inv_s = g.out_scale ? 1.0f / *g.out_scale : 1.0f;
+    auto mrow = [&](int j) { return row0 + (j >> 1) * 128 + wr * 32; };
+    auto ncol = [&](int j) { return n0 + wc * 64 + (j & 1) * 32; };
+    f32x4 bias_lo[2][NPASS], bias_hi[2][NPASS];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q) {
+        const int n = ncol(b) + q * CW + (F32OUT ? 4 : 8) * cc;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        bias_lo[b][q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : zero;
+        if constexpr (!F32OUT) bias_hi[b][q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n + 4) : zero;
+      }
+    f32x4 rres[3][RES ? NLD : 1];
+    auto prefetch = [&](int j, int slot) {
+      if constexpr (RES) {
+        const int mbase = mrow(j), nbase = ncol(j);
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q)
+#pragma unroll
+          for (int i = 0; i < NRB; ++i) {
+            const unsigned off = ((unsigned)(mbase + i * RPW + rr) * (unsigned)g.N + (unsigned)(nbase + q * CW + 4 * cc)) * 4u;
+            rres[slot][q * NRB + i] = q8_ld128(g.residual, out_bytes, off);
+          }
+      }
+    };
+    if constexpr (RES) {
+      prefetch(0, 0);
+      prefetch(1, 1);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (j < nt) {
+        const int ha = j >> 1, mt = j & 1;
+        const int mbase = mrow(j), nbase = ncol(j);
+        if constexpr (RES) {
+          if (j + 2 < nt) prefetch(j + 2, (j + 2) % 3);
+        }
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+#pragma unroll
+          for (int gg = 0; gg < CW / 8; ++gg) {
+            const int gi = q * (CW / 8) + gg;
+            const int phys = (2 * gg + h) ^ esw(r);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(a2[ha][mt][4 * gi + e], 0.00048828125f, a1[ha][mt][4 * gi + e]) * inv_s;
+            *reinterpret_cast<f32x4*>(scr + r * (CW * 4) + phys * 16) = v;
+          }
+#pragma unroll
+          for (int i = 0; i < NRB; ++i) {
+            const int row = i * RPW + rr;
+            const int m = mbase + row;
+            if constexpr (F32OUT) {
+              f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + ((cc ^ esw(row)) << 4));
+              v += bias_lo[mt][q];
+              if constexpr (GG) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast_f(rres[j % 3][q * NRB + i][e]);
+              } else if constexpr (RES) {
+                v += rres[j % 3][q * NRB + i];
+              }
+              const unsigned off = ((unsigned)m * (unsigned)g.N + (unsigned)(nbase + q * CW + 4 * cc)) * 4u;
+              q8_st128(g.C, out_bytes, off, __builtin_bit_cast(u32x4, v));
+            } else {
+              f32x4 v0 = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + (((2 * cc) ^ esw(row)) << 4));
+              f32x4 v1 = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + (((2 * cc + 1) ^ esw(row)) << 4));
+              v0 += bias_lo[mt][q];
+              v1 += bias_hi[mt][q];
+              float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+              if constexpr (BOTH) {
+                const unsigned offc = ((unsigned)m * (unsigned)g.N + (unsigned)(nbase + q * CW + 8 * cc)) * 4u;
+                q8_st128(g.C, out_bytes, offc, __builtin_bit_cast(u32x4, v0));
+                q8_st128(g.C, out_bytes, offc + 16u, __builtin_bit_cast(u32x4, v1));
+              }
+              if constexpr (ACT) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
+              }
+              f16x8 qh, ql;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                _Float16 hi_, lo_;
+                split_pair(v[e], hi_, lo_);
+                qh[e] = hi_;
+                ql[e] = lo_;
+                if (m < g.M) range_bad |= pair_hi_bad(hi_);
+              }
+              const unsigned off = ((unsigned)m * (unsigned)g.N + (unsigned)nbase) * 4u + (unsigned)(q * CW + 8 * cc) * 2u;
+              q8_st128(g.Cp, out_bytes, off, __builtin_bit_cast(u32x4, qh));
+              q8_st128(g.Cp, out_bytes, off + 64u, __builtin_bit_cast(u32x4, ql));
+            }
+          }
+        }
+      }
+    }
+    post_epi = 2;
+    post_half = half;
+    if constexpr (!F32OUT) range_flag_raise(g.range_flag, range_bad);
+  };
+
+  // ---- K-split item (as above)
+  auto slice_reduce = [&]() -> bool {
+    const int j = cu / g.ks_S, sl = cu - j * g.ks_S;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { a1[a][m][e] = fmaf(a2[a][m][e], 0.00048828125f, a1[a][m][e]); a2[a][m][e] = 0.f; }
+    float* wbase = g.ks_ws + ((size_t)j * g.ks_S * 8 + wave) * 4096;
+    const unsigned wbytes = (unsigned)g.ks_S * 8u * 4096u * 4u;
+    const unsigned sstride = 8u * 4096u * 4u;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {a1[a][m][4 * q], a1[a][m][4 * q + 1], a1[a][m][4 * q + 2], a1[a][m][4 * q + 3]};
+          q8_st128_sys(wbase, wbytes, (unsigned)sl * sstride + (unsigned)(((a * 2 + m) * 4 + q) * 1024 + lane * 16), __builtin_bit_cast(u32x4, v));
+        }
+    q8_wait_vmcnt<0>();
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(g.ks_cnt + j * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != g.ks_S - 1) return false;
+    if (lane == 0) __hip_atomic_store(g.ks_cnt + j * 8 + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int t = 0; t < g.ks_S; ++t) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = q8_ld128_sys(wbase, wbytes, (unsigned)t * sstride + (unsigned)(((a * 2 + m) * 4 + q) * 1024 + lane * 16));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a2[a][m][4 * q + e] = v[e];
+          }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) a1[a][m][e] = t == 0 ? a2[a][m][e] : a1[a][m][e] + a2[a][m][e];
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a2[a][m][e] = 0.f;
+    return true;
+  };
+
+  // ---- prologue: what the iterations -3 .. -1 of the steady schedule would have issued, in its order: [X1(-1): none,] W / X0 of K-tile 0 |
+  // X1(0), W / X0 of K-tile 1 | X1(1), W / X0 of K-tile 2 (the pieces of K-tiles that do not exist are out of range: zero-filled)
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {
+    const int sx1 = (v == 2) ? SLOT_B : 0, swx = v * SLOT_B;   // the lag's slot (K-tile v - 1), the cursor's (K-tile v)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) site(k, sx1, swx);
+    cursor_advance();
+  }
+
+  using NO = std::false_type; using YES = std::true_type;
+  for (int it = 0; it < n_items; ++it) {
+    int row0, n0, c_kt0, c_kend;
+    bool c_half;
+    item(it, row0, n0, c_half, c_kt0, c_kend);
+    // the item's first fragments (W and X0 of its first K-tile) are read here, exposed: no fragment is live across an epilogue.  The ring
+    // holds them: the barrier at the top of the previous iteration followed every wave's wait for them (the first item: waited for here).
+    if (it == 0) {
+      q8_wait_vmcnt<6>();
+      __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      rd_w(s0, 0, c4);
+      rd_w(s0, 1, c4);
+      rd_x(0, s0, c4);
+    }
+    const int nkt = c_kend - c_kt0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { a1[a][m][e] = 0.f; a2[a][m][e] = 0.f; }
+    auto run = [&](auto half_c, auto late_c) {
+      for (int t = 0; t + 1 < nkt; ++t) ktile(NO{}, half_c, late_c);
+      ktile(YES{}, half_c, late_c);
+    };
+    if (c_half) { if (late) run(YES{}, YES{}); else run(YES{}, NO{}); }
+    else { if (late) run(NO{}, YES{}); else run(NO{}, NO{}); }
+    if (has_slice && it == n_whole) {
+      if (!slice_reduce()) continue;
+    }
+    epilogue(row0, n0, c_half);
+  }
+#undef Q8S_FENCE
+}
+
+template <int EPI>
+static int launch_pairs8s(const Q8Args& g, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_pairs8s_kernel<EPI>), dim3(g.ncu), dim3(512), 0, s, g);
+  TT_CHECK_LAUNCH("gemm_pairs8s");
+  return TT_OK;
+}
+
 static int q8_order_mode() { return tuning_knob(KNOB_Q8_ORDER); }   // (+100: the stamp builds print)
 
 template <int EPI, int DBG = 0>
@@ -737,9 +1199,11 @@ struct Q8Plan {
   int ntn, ncu, n_full, n_half, ks_S, ks_R;
   long long ntiles;
 };
+// kgroup: the K-tiles a K-tile range must be a multiple of - 3 for gemm_pairs8_kernel (its ring advances three K-tiles per loop trip), 1 for
+// gemm_pairs8s_kernel (run-time ring slots, fragments refreshed in place)
 static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_pre, bool has_gelu_pre, int M, int N, int K, int act, Q8Plan* pl,
-                       bool allow_ksplit = true) {
-  if (N % 128 != 0 || K % 96 != 0 || M < 256) return -1;
+                       bool allow_ksplit = true, int kgroup = 3) {
+  if (N % 128 != 0 || K % (32 * kgroup) != 0 || M < 256) return -1;
   int epi = -1;
   if (has_gelu_pre) {
     if (has_y && !has_pairs && !has_pre && !has_residual && !act) epi = Q8_F32_GELUGRAD;
@@ -768,14 +1232,14 @@ static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_p
   const int ksplit_knob = tuning_knob(KNOB_Q8_KSPLIT) % 10, ksplit_cap = tuning_knob(KNOB_Q8_KSPLIT) / 10;
   int ks_S = 0;
   if (allow_ksplit && ksplit_knob != 0 && rem > 0 && (R > 0 || ksplit_knob >= 2)) {
-    const int U = K / 96, nk = K / 32;
+    const int U = K / (32 * kgroup), nk = K / 32;
     int S = (int)(ncu_dev / rem);
     if (S > U) S = U;
     if (S > (ksplit_cap > 0 ? ksplit_cap : 6)) S = ksplit_cap > 0 ? ksplit_cap : 6;
     if (S >= 2) {
       // microseconds (tools/q8_ksplit.py): 1.3 per K-tile + 3 for the epilogue; the exchange ~ 9 + 1 per slice (store, counter, the partials)
       const double t_tile = 1.3 * nk + 3.0;
-      const double t_slice = 1.3 * 3 * ((U + S - 1) / S) + 3.0 + 9.0 + 1.0 * S;
+      const double t_slice = 1.3 * kgroup * ((U + S - 1) / S) + 3.0 + 9.0 + 1.0 * S;
       const double t_else = (2 * rem <= ncu_dev && tuning_knob(KNOB_P8_NO_HALF) == 0) ? 0.86 * t_tile : t_tile;
       if (t_slice < 0.9 * t_else && (R > 0 || rem * S >= ncu_dev / 2)) ks_S = S;
     }
@@ -794,9 +1258,13 @@ static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_p
   return epi;
 }
 
+// which of the two persistent kernels a call goes to: the symmetric one (round 5: any K % 32 == 0) unless the knob TT_Q8_STREAM is 0 (A/B:
+// the round-4 kernel, K % 96 == 0 only)
+static int q8_kgroup(int K) { (void)K; return tuning_knob(KNOB_Q8_STREAM) != 0 ? 1 : 3; }
+
 int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, int has_pairs, int has_pre, int has_gelu_pre) {
   Q8Plan pl;
-  return pairs8_plan(has_residual != 0, has_y != 0, has_pairs != 0, has_pre != 0, has_gelu_pre != 0, M, N, K, act, &pl) >= 0;
+  return pairs8_plan(has_residual != 0, has_y != 0, has_pairs != 0, has_pre != 0, has_gelu_pre != 0, M, N, K, act, &pl, true, q8_kgroup(K)) >= 0;
 }
 
 // Called by linear_pairs_impl (gemm_planes.hip).  Returns TT_OK after a launch, 1 when the shape / epilogue is not this kernel's (the caller
@@ -810,7 +1278,8 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
   // without one the left-over tiles are cut into halves / dealt round-robin
   KsplitWs kw{nullptr, nullptr};
   const bool have_ws = ksplit_ws_carve(ksplit_ws, ksplit_ws_bytes_, &kw);
-  const int epi = pairs8_plan(residual != nullptr, y != nullptr, y_pairs != nullptr, pre_out != nullptr, gelu_pre != nullptr, M, N, K, act, &pl, have_ws);
+  const int kgroup = q8_kgroup(K);
+  const int epi = pairs8_plan(residual != nullptr, y != nullptr, y_pairs != nullptr, pre_out != nullptr, gelu_pre != nullptr, M, N, K, act, &pl, have_ws, kgroup);
   if (epi < 0) return 1;
   float* ks_ws = pl.ks_S >= 2 ? kw.partials : nullptr;
   int* ks_cnt = pl.ks_S >= 2 ? kw.counters : nullptr;
@@ -836,6 +1305,18 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
 #undef Q8_DBG_CASE
   }
 #endif
+  if (kgroup == 1) {
+    switch (epi) {
+      case Q8_F32: return launch_pairs8s<Q8_F32>(g, s);
+      case Q8_F32_RES: return launch_pairs8s<Q8_F32_RES>(g, s);
+      case Q8_PAIR: return launch_pairs8s<Q8_PAIR>(g, s);
+      case Q8_PAIR_GELU: return launch_pairs8s<Q8_PAIR_GELU>(g, s);
+      case Q8_F32_GELUGRAD: return launch_pairs8s<Q8_F32_GELUGRAD>(g, s);
+      case Q8_BOTH: return launch_pairs8s<Q8_BOTH>(g, s);
+      case Q8_BOTH_GELU: return launch_pairs8s<Q8_BOTH_GELU>(g, s);
+      default: return 1;
+    }
+  }
   switch (epi) {
     case Q8_F32: return launch_pairs8<Q8_F32>(g, s);
     case Q8_F32_RES: return launch_pairs8<Q8_F32_RES>(g, s);

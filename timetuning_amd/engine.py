@@ -846,7 +846,8 @@ class GradExchange:
             off = 0
             for k in keys:
                 # (an arena bucket: the parameter's own 16-byte aligned slot - the slots are padded; a hand-flattened one: back to back)
-                grads[k] = self.arena.slots[k] if in_arena else flat[off:off + k.numel()].view(k.shape)
+                # (a FRESH view object either way: autograd adopts a gradient it holds the only reference to, and clones one it does not)
+                grads[k] = self.arena.slots[k].view(k.shape) if in_arena else flat[off:off + k.numel()].view(k.shape)
                 off += k.numel()
         if self.arena is not None and not self.use_arena and self.buckets and self.buckets[0][1].is_cuda:
             self.arena.build(self.recorded, self.buckets[0][1].device)   # the layout the next steps write into
