@@ -11,7 +11,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtimetuning_hip.so")
+# (TT_LIB_PATH: measurement tools only - a variant build of the library, tools/build_variant.sh)
+LIB_PATH = os.environ.get("TT_LIB_PATH") or os.path.join(_HERE, "libtimetuning_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 c_f32p = C.c_void_p
