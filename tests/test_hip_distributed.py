@@ -163,7 +163,7 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(backend, W):
         # the self-deciding exchange: one decision for the whole job, consistent state, unchanged numbers under it
         au = ret[r]["auto"]
         assert au["choice"] == ret[0]["auto"]["choice"] and au["choice"][0] in ("allgather", "allreduce") and au["choice"][1] in (1, 4), au
-        assert au["set"] == (au["choice"][0], 0 if au["choice"][1] == 4 else 1) and len(au["keys"]) == 3 and au["keys"][0] == "allgather/4", au
+        assert au["set"] == (au["choice"][0], 0 if au["choice"][1] == 4 else 1) and len(au["keys"]) == 3 and "allgather/4" in au["keys"] and "allreduce/4" in au["keys"], au
         assert abs(au["loss"] - ret[r]["loss"]) < 1e-5 and au["grad_err"] < 1e-4, au
 
     model = _model()
@@ -283,7 +283,7 @@ def test_bench_gpus_2_through_its_own_launcher():
     assert rc["world_size"] == 2 and rc["backend"] == "gloo"
     # the exchange decided for itself before the warm-up (engine.autotune_exchange): three configurations timed, one kept, recorded
     au = rc["exchange_autotune"]
-    assert au["world_size"] == 2 and sorted(au["ms_per_step"])[0] == "allgather/4" and len(au["ms_per_step"]) == 3 and all(v > 0 for v in au["ms_per_step"].values())
+    assert au["world_size"] == 2 and "allgather/4" in au["ms_per_step"] and len(au["ms_per_step"]) == 3 and all(v > 0 for v in au["ms_per_step"].values())
     assert au["sinkhorn_exchange"] in ("allgather", "allreduce") and au["grad_buckets"] in (1, 4)
     # the exchange of the instrumented step under that choice: ONE all-gather of the score rows (2 ranks x 2 clips x 196 patches x 50
     # prototypes, fp32) or ten K-float all-reduces of the row sums; four gradient buckets or one - every trainable float exactly once -

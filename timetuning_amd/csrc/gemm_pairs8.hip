@@ -729,13 +729,14 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
 }
 
 
-// TT_Q8S_ST_AUX: cache policy of the epilogue's output stores.  16 = sc1: written through and DROPPED from the XCD's L2 (MI355X_MICROARCH:
-// "sc1 / sc0 sc1 / atomic DROP it").  An output tile is 128 KB that nobody reads again in this launch; kept (plain stores, 0) the 32
-// workgroups of an XCD push 4 MB of output per round through its 4 MB L2 - the cache that has to hold the X row blocks their sibling column
-// tiles re-read (round 4's PMC: L2 hit 0.63 - 0.78, 3.5 x the operand bytes fetched from beyond it; with no MFMA at all the kernel still took
-// 88 % of its time: it is bound by what the memory side delivers per CU, ~ 25 GB/s from beyond L2 against ~ 70 GB/s from L2).
+// TT_Q8S_ST_AUX: cache policy of the epilogue's output stores (timing study).  The kernel is bound by what the memory side delivers per CU
+// (round 4's ablation: with no MFMA at all it still takes 88 % of its time; PMC: L2 hit 0.63 - 0.78, 3.5 x the operand bytes fetched from
+// beyond L2), and an output tile is 128 KB that nobody reads again in this launch - 4 MB per round and XCD through a 4 MB L2 that has to hold
+// the X row blocks the sibling column tiles re-read.  Measured (tools/ab_pairs.py, one box, us: qkv / proj / fc1 / fc2): plain stores (0)
+// 73.0 / 36.6 / 111.5 / 95.4; sc1 (16: written through and dropped from L2) 74.2 / 35.6 / 120.8 / 96.4; nt (2) 73.0 / 37.5 / 186.1 / 95.6 -
+// the 16-byte hi / lo pieces of a pair output are partial lines, which only a write-back L2 merges.  Plain stays.
 #ifndef TT_Q8S_ST_AUX
-#define TT_Q8S_ST_AUX 16
+#define TT_Q8S_ST_AUX 0
 #endif
 // =====================================================================================================================================
 // gemm_pairs8s_kernel (round 5): the same tile, operands, work items and epilogues on a SYMMETRIC, register-prefetched main loop.
@@ -764,7 +765,21 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
 //   * the ring slot is a run-time offset and nothing alternates at compile time: any K % 32 == 0 (the kernel above: K % 96 == 0) - the
 //     projection head (K = 1024 / 512 / 256) is taken.
 // Items, half tiles, the K-split exchange and the epilogue are those of the kernel above.
-template <int EPI>
+// TT_Q8S_LOADER: who issues the LDS-DMA.  0: every wave its own six pieces per K-tile.  1: waves 4 - 7 issue all twelve of their SIMD (their own
+// and those of wave - 4), waves 0 - 3 none.  2: waves 0 - 3 do.  Why (stamps, tools/q8s_stamp.py, qkv shape): the two waves of a SIMD do NOT share the matrix pipe
+// evenly - the older wave (0 - 3) wins the arbitration (priority, then age: MI355X_MICROARCH "Two waves per SIMD" item 2), is through its 24
+// MFMAs after ~ 1050 cycles and parks ~ 900 cycles at the next barrier, while its partner needs ~ 1790: once alone on the SIMD, every one of
+// its DMA-issue stalls and read waits idles the pipe.  With the loader role on the YOUNGER wave its stalls fall into the time in which it
+// would be waiting for pipe slots anyway, and its lone second half is MFMAs and reads only (that was the idea; the measurement says the
+// opposite assignment, 2, is the one that pays - see below).
+// Measured (tools/ab_pairs.py, one box, us: qkv / proj / fc1 / fc2 / ViT-B qkv): 0: 74.6 / 37.0 / 111.7 / 95.3 / 246.1; 1: 75.2 / 37.5 / 111.5 /
+// 95.5 / 249.5; 2: 72.5 / 36.5 / 108.8 / 94.3 / 238.5 - the OLDER wave runs first whatever it does (it wins the matrix pipe), so ITS stalls are
+// the ones the younger wave's MFMAs fill; the younger wave's lone second half should be free of them.  (s_setprio for either half: +- 1 %.)
+#ifndef TT_Q8S_LOADER
+#define TT_Q8S_LOADER 2
+#endif
+// DBG (timing studies only, tools/q8_ablate.py; the shipped instantiations are DBG = 0), a bit mask: 1 no MFMAs, 2 no LDS-DMA, 8 no epilogue
+template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
   constexpr int ROWB = 128, CPR = 8, WIN = 2, RPI = 8;
   constexpr int CHUNK_B = 128 * ROWB;       // 16 KB
@@ -781,10 +796,19 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
   constexpr bool ACT = EPI == Q8_PAIR_GELU || EPI == Q8_BOTH_GELU;
   constexpr int ST_TILE = BOTH ? 8 : 4;               // stores a wave issues per 32 x 32 MFMA tile
   constexpr int ST_FULL = 4 * ST_TILE, ST_HALF = ST_FULL / 2;
-  constexpr int S_FULL = ST_FULL < 63 - 6 ? ST_FULL : 63 - 6, S_HALF = ST_HALF < 63 - 6 ? ST_HALF : 63 - 6;
+  constexpr int NPW = TT_Q8S_LOADER ? 12 : 6;
+  constexpr int S_FULL = ST_FULL < 63 - NPW ? ST_FULL : 63 - NPW, S_HALF = ST_HALF < 63 - NPW ? ST_HALF : 63 - NPW;
   static_assert(RING_B + 8 * SCR_B <= 160 * 1024 && CW == 16, "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem[160 * 1024];
 
+#ifdef TT_Q8S_STAMP   // diagnostic build only (tools/q8s_stamp.py): where a wave's K-tile iteration goes - s_memtime stamps around the top waits
+  unsigned long long sa = 0, sb = 0, sc_ = 0, sd = 0, se = 0;
+  unsigned st_lgkm = 0, st_vm = 0, st_bar = 0, st_body = 0, st_n = 0, st_epi = 0, st_nepi = 0, st_pro = 0;
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#define Q8S_STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
+#else
+#define Q8S_STAMP(t)
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool late = wave >= 4;                      // the SIMD partners of waves 0 - 3: their DMA sites are two MFMAs later
@@ -839,6 +863,10 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
   const int d_row0 = wave * RPI + l_row;
   const int d_chunk = l_slot ^ ((d_row0 / WIN) & (CPR - 1));
   const unsigned lane_voff = (unsigned)(d_row0 * K4 + d_chunk * 16);
+  // (TT_Q8S_LOADER: a loader wave also issues the pieces of its SIMD partner, wave ^ 4: rows 32 further up / down the chunk)
+  const int d_row0b = (wave ^ 4) * RPI + l_row;
+  const unsigned lane_voff_b = (unsigned)(d_row0b * K4 + (l_slot ^ ((d_row0b / WIN) & (CPR - 1))) * 16);
+  constexpr int NP = TT_Q8S_LOADER ? 12 : 6;   // pieces a DMA-issuing wave has in flight per K-tile: the unit of its counted waits
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(g.X), 0, (unsigned)g.M * (unsigned)K4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(g.W), 0, (unsigned)g.N * (unsigned)K4, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
@@ -856,19 +884,27 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
     cur_x = (unsigned)row0 * (unsigned)K4 + (unsigned)d_kt * ROWB;
   };
   cursor_item();
+#ifdef TT_Q8S_PRIO   // timing study: 1 = the younger waves (4 - 7) at priority 1 for the whole kernel (MI355X_MICROARCH "Two waves per SIMD" item 4)
+  if (TT_Q8S_PRIO == 1 && late) __builtin_amdgcn_s_setprio(1);
+  if (TT_Q8S_PRIO == 2 && !late) __builtin_amdgcn_s_setprio(1);
+#endif
   // ring slots (byte offsets) of K-tile t (s0), t + 1 (s1), t + 2 (s2); W / X0 of t + 3 go to s0
   int s0 = 0, s1 = SLOT_B, s2 = 2 * SLOT_B;
-  auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, int lds_off, unsigned soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (q8_lds_ptr_t)(smem + lds_off + wave * 1024), 16, lane_voff + soff, 0, 0, 0);
+  // which: 0 this wave's piece, 1 (TT_Q8S_LOADER, loader waves only) the piece of its partner wave ^ 4, 2 both
+  auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, int lds_off, unsigned soff, int which) {
+    if constexpr (!(DBG & 2)) {
+      if (which != 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (q8_lds_ptr_t)(smem + lds_off + wave * 1024), 16, lane_voff + soff, 0, 0, 0);
+      if (which != 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (q8_lds_ptr_t)(smem + lds_off + (wave ^ 4) * 1024), 16, lane_voff_b + soff, 0, 0, 0);
+    }
   };
   // the six DMA sites of an iteration: X1 0 / 1 of the lag (-> slot_x1), W 0 / 1 and X0 0 / 1 of the cursor (-> slot_wx)
-  auto site = [&](int k, int slot_x1, int slot_wx) {
-    if (k == 0) dma(rs_x, slot_x1 + 2 * CHUNK_B, lag_x1);
-    else if (k == 1) dma(rs_x, slot_x1 + 2 * CHUNK_B + 8 * 1024, lag_x1 + piece_step);
-    else if (k == 2) dma(rs_w, slot_wx, cur_w);
-    else if (k == 3) dma(rs_w, slot_wx + 8 * 1024, cur_w + piece_step);
-    else if (k == 4) dma(rs_x, slot_wx + CHUNK_B, cur_x);
-    else if (k == 5) dma(rs_x, slot_wx + CHUNK_B + 8 * 1024, cur_x + piece_step);
+  auto site = [&](int k, int slot_x1, int slot_wx, int which = 0) {
+    if (k == 0) dma(rs_x, slot_x1 + 2 * CHUNK_B, lag_x1, which);
+    else if (k == 1) dma(rs_x, slot_x1 + 2 * CHUNK_B + 8 * 1024, lag_x1 + piece_step, which);
+    else if (k == 2) dma(rs_w, slot_wx, cur_w, which);
+    else if (k == 3) dma(rs_w, slot_wx + 8 * 1024, cur_w + piece_step, which);
+    else if (k == 4) dma(rs_x, slot_wx + CHUNK_B, cur_x, which);
+    else if (k == 5) dma(rs_x, slot_wx + CHUNK_B + 8 * 1024, cur_x + piece_step, which);
   };
   // after the cursor's W / X0 have been issued: it becomes the lag, and moves on
   auto cursor_advance = [&]() {
@@ -903,12 +939,17 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
   int post_epi = 0;         // iterations whose window still reaches back across an epilogue
   bool post_half = false;
   auto wait_ring = [&]() {
+    if constexpr (DBG & 2) { q8_wait_vmcnt<0>(); return; }
+    if (TT_Q8S_LOADER != 0 && late != (TT_Q8S_LOADER == 1)) {   // not a loader: no DMA of its own, nothing to wait for
+      if (post_epi > 0) --post_epi;
+      return;
+    }
     if (post_epi > 0) {
       --post_epi;
-      if (post_half) q8_wait_vmcnt<6 + S_HALF>();
-      else q8_wait_vmcnt<6 + S_FULL>();
+      if (post_half) q8_wait_vmcnt<NP + S_HALF>();
+      else q8_wait_vmcnt<NP + S_FULL>();
     } else {
-      q8_wait_vmcnt<6>();
+      q8_wait_vmcnt<NP>();
     }
   };
 
@@ -925,27 +966,42 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
     constexpr bool LAST = decltype(last_c)::value, HALF = decltype(half_c)::value, LATE = decltype(late_c)::value;
     // top: the reads of the previous iteration are in registers (and nobody still reads what this iteration's DMA overwrites); the ring
     // holds X1(t) and W / X0(t + 1) once every wave has passed its counted wait
+#ifdef TT_Q8S_STAMP
+    Q8S_STAMP(sa);                       // (its lgkmcnt(0) IS the top's wait for the fragment reads)
+    if (sd) st_body += (unsigned)(sa - sd);
+    Q8S_STAMP(sb);
+    wait_ring();
+    Q8S_STAMP(sc_);
+    __builtin_amdgcn_s_barrier();
+    Q8S_STAMP(sd);
+    st_lgkm += (unsigned)(sb - sa); st_vm += (unsigned)(sc_ - sb); st_bar += (unsigned)(sd - sc_); ++st_n;
+#else
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wait_ring();
     __builtin_amdgcn_s_barrier();
+#endif
     Q8S_FENCE();
     const int sx1 = s2, swx = s0, sr0 = s0, sr1 = s1;
     // slot (phase PH, q = (k-step, w block)): k, k2 = its DMA site(s), -1 = none
     auto slot = [&](auto ph_c, int q, int k, int k2) {
       constexpr int PH = decltype(ph_c)::value;
       const int ks = q >> 1, mt = q & 1;
-      a2[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][ks], Xf[PH][2 + ks], a2[PH][mt], 0, 0, 0);
+      if constexpr (!(DBG & 1)) a2[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][ks], Xf[PH][2 + ks], a2[PH][mt], 0, 0, 0);
+      else asm volatile("" ::"v"(Wf[mt][ks]), "v"(Xf[PH][2 + ks]));
       Q8S_FENCE();
-      if constexpr (!LATE) { if (k >= 0) site(k, sx1, swx); if (k2 >= 0) site(k2, sx1, swx); }
+      if constexpr (!LATE && TT_Q8S_LOADER == 0) { if (k >= 0) site(k, sx1, swx); if (k2 >= 0) site(k2, sx1, swx); }
+      if constexpr (LATE && TT_Q8S_LOADER != 0) { if (k >= 0) site(k, sx1, swx, 0); if (k2 >= 0) site(k2, sx1, swx, 0); }   // (LATE = "is a loader" then) its own piece(s) here, its partner's behind the slot's last MFMA
       Q8S_FENCE();
-      a1[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][ks], Xf[PH][ks], a1[PH][mt], 0, 0, 0);
+      if constexpr (!(DBG & 1)) a1[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][ks], Xf[PH][ks], a1[PH][mt], 0, 0, 0);
+      else asm volatile("" ::"v"(Xf[PH][ks]));
       Q8S_FENCE();
       if constexpr (!HALF) {
         if constexpr (PH == 0) rd_x(1, sr0, q);                    // X1(t): phase B's operand
         else if constexpr (!LAST) rd_x(0, sr1, q);                 // X0(t + 1)
       }
       Q8S_FENCE();
-      a2[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][2 + ks], Xf[PH][ks], a2[PH][mt], 0, 0, 0);
+      if constexpr (!(DBG & 1)) a2[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][2 + ks], Xf[PH][ks], a2[PH][mt], 0, 0, 0);
+      else asm volatile("" ::"v"(Wf[mt][2 + ks]));
       Q8S_FENCE();
       if constexpr (!LAST && (HALF || PH == 1)) {                  // the last phase of the K-tile: W(t + 1) in place, this slot's two fragments
         rd_w(sr1, mt, ks);
@@ -955,7 +1011,8 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
         }
       }
       Q8S_FENCE();
-      if constexpr (LATE) { if (k >= 0) site(k, sx1, swx); if (k2 >= 0) site(k2, sx1, swx); }
+      if constexpr (LATE && TT_Q8S_LOADER == 0) { if (k >= 0) site(k, sx1, swx); if (k2 >= 0) site(k2, sx1, swx); }
+      if constexpr (LATE && TT_Q8S_LOADER != 0) { if (k >= 0) site(k, sx1, swx, 1); if (k2 >= 0) site(k2, sx1, swx, 1); }
       Q8S_FENCE();
     };
     using PH0 = std::integral_constant<int, 0>; using PH1 = std::integral_constant<int, 1>;
@@ -979,6 +1036,17 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
   auto esw = [](int row) { return (row >> 2) & (CPRW - 1); };
   const unsigned out_bytes = (unsigned)g.M * (unsigned)g.N * 4u;
   auto epilogue = [&](int row0, int n0, bool half) {
+    if constexpr (DBG & 8) {
+      float sres = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sres += a1[a][m][e] + a2[a][m][e];
+      if (g.C && sres == 12345.678f) g.C[threadIdx.x] = sres;
+      return;
+    }
     constexpr int NT = 4;
     const int nt = half ? NT / 2 : NT;
     // every lane-dependent address of the epilogue is formed HERE, from a lane id the compiler cannot see through: hoisted out of the item
@@ -987,7 +1055,8 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
     asm volatile("" : "+v"(lane_e));
     const int r = lane_e & 31, h = lane_e >> 5;
     const int rr = lane_e / LPR, cc = lane_e % LPR;
-    bool range_bad = false;
+    // range flag (common.hpp pair_hi_bad) at one VALU op per element: the running maximum of the hi halves' magnitude bits, packed
+    unsigned hi_max = 0;
     const float inv_s = g.out_scale ? 1.0f / *g.out_scale : 1.0f;
     auto mrow = [&](int j) { return row0 + (j >> 1) * 128 + wr * 32; };
     auto ncol = [&](int j) { return n0 + wc * 64 + (j & 1) * 32; };
@@ -1074,7 +1143,15 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
                 split_pair(v[e], hi_, lo_);
                 qh[e] = hi_;
                 ql[e] = lo_;
-                if (m < g.M) range_bad |= pair_hi_bad(hi_);
+              }
+              {
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                const u32x4 hb = __builtin_bit_cast(u32x4, qh);
+                unsigned mx = 0;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4)
+                  mx = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, mx), __builtin_bit_cast(u16x2, hb[w4] & 0x7fff7fffu)));
+                if (m < g.M) hi_max = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, hi_max), __builtin_bit_cast(u16x2, mx)));
               }
               const unsigned off = ((unsigned)m * (unsigned)g.N + (unsigned)nbase) * 4u + (unsigned)(q * CW + 8 * cc) * 2u;
               q8_st128_aux<TT_Q8S_ST_AUX>(g.Cp, out_bytes, off, __builtin_bit_cast(u32x4, qh));
@@ -1086,7 +1163,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
     }
     post_epi = 2;
     post_half = half;
-    if constexpr (!F32OUT) range_flag_raise(g.range_flag, range_bad);
+    if constexpr (!F32OUT) range_flag_raise(g.range_flag, (hi_max & 0xffffu) >= 0x7c00u || (hi_max >> 16) >= 0x7c00u);
   };
 
   // ---- K-split item (as above)
@@ -1148,8 +1225,10 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
 #pragma unroll
   for (int v = 0; v < 3; ++v) {
     const int sx1 = (v == 2) ? SLOT_B : 0, swx = v * SLOT_B;   // the lag's slot (K-tile v - 1), the cursor's (K-tile v)
+    if (TT_Q8S_LOADER == 0 || late == (TT_Q8S_LOADER == 1)) {
 #pragma unroll
-    for (int k = (v == 0 ? 2 : 0); k < 6; ++k) site(k, sx1, swx);   // (v == 0: there is no lag yet)
+      for (int k = (v == 0 ? 2 : 0); k < 6; ++k) site(k, sx1, swx, TT_Q8S_LOADER ? 2 : 0);   // (v == 0: there is no lag yet)
+    }
     cursor_advance();
   }
 
@@ -1161,7 +1240,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
     // the item's first fragments (W and X0 of its first K-tile) are read here, exposed: no fragment is live across an epilogue.  The ring
     // holds them: the barrier at the top of the previous iteration followed every wave's wait for them (the first item: waited for here).
     if (it == 0) {
-      q8_wait_vmcnt<6>();
+      q8_wait_vmcnt<NP>();
       __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
@@ -1181,19 +1260,38 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
       for (int t = 0; t + 1 < nkt; ++t) ktile(NO{}, half_c, late_c);
       ktile(YES{}, half_c, late_c);
     };
-    if (c_half) { if (late) run(YES{}, YES{}); else run(YES{}, NO{}); }
-    else { if (late) run(NO{}, YES{}); else run(NO{}, NO{}); }
+    // (the last template argument: "late sites" without a loader role; "is a loader" with one - 1: waves 4 - 7, 2: waves 0 - 3)
+    const bool role = TT_Q8S_LOADER == 2 ? !late : late;
+    if (c_half) { if (role) run(YES{}, YES{}); else run(YES{}, NO{}); }
+    else { if (role) run(NO{}, YES{}); else run(NO{}, NO{}); }
     if (has_slice && it == n_whole) {
       if (!slice_reduce()) continue;
     }
+#ifdef TT_Q8S_STAMP
+    Q8S_STAMP(se);
+    st_body += (unsigned)(se - sd);
     epilogue(row0, n0, c_half);
+    Q8S_STAMP(sa);
+    st_epi += (unsigned)(sa - se); ++st_nepi;
+    sd = 0;
+#else
+    epilogue(row0, n0, c_half);
+#endif
   }
+#ifdef TT_Q8S_STAMP
+  if (g.order_mode >= 100 && lane == 0 && (wave == 0 || wave == 3 || wave == 4 || wave == 7) && (blockIdx.x == 3 || blockIdx.x == 200)) {
+    const unsigned long long dt = __builtin_amdgcn_s_memtime() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    printf("q8s stamps: block %d wave %d: %u K-tiles, cycles per K-tile: lgkmcnt(0) %.0f | vmcnt wait %.0f | barrier %.0f | body (24 MFMAs + reads + DMA) %.0f ; "
+           "%u epilogues of %.0f cycles ; kernel %llu cycles, %.3f GHz\n", (int)blockIdx.x, wave, st_n, (double)st_lgkm / st_n, (double)st_vm / st_n, (double)st_bar / st_n,
+           (double)st_body / st_n, st_nepi, st_nepi ? (double)st_epi / st_nepi : 0.0, dt, (double)dt / (double)dr * 0.1);
+  }
+#endif
 #undef Q8S_FENCE
 }
 
-template <int EPI>
+template <int EPI, int DBG = 0>
 static int launch_pairs8s(const Q8Args& g, hipStream_t s) {
-  hipLaunchKernelGGL((gemm_pairs8s_kernel<EPI>), dim3(g.ncu), dim3(512), 0, s, g);
+  hipLaunchKernelGGL((gemm_pairs8s_kernel<EPI, DBG>), dim3(g.ncu), dim3(512), 0, s, g);
   TT_CHECK_LAUNCH("gemm_pairs8s");
   return TT_OK;
 }
@@ -1301,7 +1399,7 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
            pre_out ? pre_out : y, static_cast<_Float16*>(y_pairs), pl.ntn, (int)pl.ntiles, pl.ncu, pl.n_full, pl.n_half, q8_order_mode(),
            pl.ks_S, pl.ks_R, out_scale, ks_ws, ks_cnt, range_flag};
 #ifdef TT_Q8_ABLATE   // timing-study build only: TT_Q8_DBG selects a crippled instantiation
-  {
+  if (kgroup == 3) {
     const char* e = getenv("TT_Q8_DBG");
     const int dbg = e ? atoi(e) : 0;
 #define Q8_DBG_CASE(EV)                                  \
@@ -1317,6 +1415,24 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
   }
     Q8_DBG_CASE(Q8_F32) Q8_DBG_CASE(Q8_F32_RES) Q8_DBG_CASE(Q8_PAIR_GELU)
 #undef Q8_DBG_CASE
+  }
+#endif
+#ifdef TT_Q8_ABLATE   // timing-study build only: TT_Q8_DBG selects a crippled instantiation of the symmetric kernel too
+  if (kgroup == 1) {
+    const char* e = getenv("TT_Q8_DBG");
+    const int dbg = e ? atoi(e) : 0;
+#define Q8S_DBG_CASE(EV)                                   \
+  if (epi == EV) {                                         \
+    if (dbg == 1) return launch_pairs8s<EV, 1>(g, s);      \
+    if (dbg == 2) return launch_pairs8s<EV, 2>(g, s);      \
+    if (dbg == 8) return launch_pairs8s<EV, 8>(g, s);      \
+    if (dbg == 9) return launch_pairs8s<EV, 9>(g, s);      \
+    if (dbg == 10) return launch_pairs8s<EV, 10>(g, s);    \
+    if (dbg == 3) return launch_pairs8s<EV, 3>(g, s);      \
+    if (dbg == 11) return launch_pairs8s<EV, 11>(g, s);    \
+  }
+    Q8S_DBG_CASE(Q8_F32) Q8S_DBG_CASE(Q8_F32_RES) Q8S_DBG_CASE(Q8_PAIR_GELU)
+#undef Q8S_DBG_CASE
   }
 #endif
   if (kgroup == 1) {

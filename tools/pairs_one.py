@@ -6,7 +6,8 @@
 import sys
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from timetuning_amd import hip_ops as ops  # noqa: E402
 
 kind = sys.argv[1]

@@ -25,7 +25,15 @@ def split(x):
 cases = [(16384, 1024, 384, 0, 0, 0, "ideal 2 tiles/CU K384 f32out"), (16384, 1024, 1536, 0, 0, 1, "ideal 2 tiles/CU K1536 f32+res"),
          (25216, 1152, 384, 0, 0, 0, "qkv"), (25216, 384, 384, 0, 0, 1, "proj"), (25216, 1536, 384, 1, 1, 0, "fc1"), (25216, 384, 1536, 0, 0, 1, "fc2"),
          (25216, 2304, 768, 0, 0, 0, "B qkv"), (25216, 768, 3072, 0, 0, 1, "B fc2")]
-only = sys.argv[1:]
+# first argument `stream=0|1`: which persistent kernel (TT_Q8_STREAM: 1 = gemm_pairs8s_kernel, round 5; 0 = gemm_pairs8_kernel)
+args = sys.argv[1:]
+if args and args[0].startswith("stream="):
+    lib.tt_set_tuning_knob.restype = C.c_int
+    lib.tt_set_tuning_knob.argtypes = [C.c_char_p, C.c_int]
+    assert lib.tt_set_tuning_knob(b"TT_Q8_STREAM", int(args[0][7:])) == 0
+    print(f"== TT_Q8_STREAM = {args[0][7:]}", flush=True)
+    args = args[1:]
+only = args
 for M, N, K, act, po, res, name in cases:
     if only and name not in only: continue
     x = split(torch.randn(M, K, device="cuda")); w = split(torch.randn(N, K, device="cuda") * 0.05)
