@@ -1356,7 +1356,12 @@ static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_p
       if (t_slice < 0.9 * t_else && (R > 0 || rem * S >= ncu_dev / 2)) ks_S = S;
     }
   }
-  if (ntiles < ncu_dev / 2 && ks_S == 0) return -1;   // a persistent grid that cannot fill the chip: the small-tile kernel does better
+  // a persistent grid that cannot fill the chip: the small-tile kernel does better.  Round 4: below half the CUs.  The symmetric kernel's
+  // half tiles cost ~ 0.55 of a whole one, so a grid of 2 x tiles half items pays a little earlier - knob TT_Q8_MIN_TILES, default 96
+  // (measured, us, persistent / general kernel: 100 tiles [6272 x 512 x 1024, the head's third Linear] 28.7 / 41.7; 75 tiles [6304 x 384 x
+  // 384 / x 1536] 16.0 / 12.9 and 38.7 / 35.2; 50 tiles [6272 x 256 x 512] 16.3 / 10.8)
+  const int min_tiles = kgroup == 1 ? tuning_knob(KNOB_Q8_MIN_TILES) : ncu_dev / 2;
+  if (ntiles < min_tiles && ks_S == 0) return -1;
   int ncu = (int)(ntiles < ncu_dev ? ntiles : ncu_dev), n_full = 0, n_half = 0;
   if (ks_S >= 2) {
     ncu = R > 0 ? ncu_dev : (int)rem * ks_S;

@@ -45,7 +45,10 @@ cases = [(25216, 1152, 384, 0, 0, 0, "qkv"), (25216, 384, 384, 0, 0, 1, "proj"),
          (25216, 2304, 768, 0, 0, 0, "B qkv"), (25216, 768, 768, 0, 0, 1, "B proj"), (25216, 3072, 768, 1, 1, 0, "B fc1"), (25216, 768, 3072, 0, 0, 1, "B fc2"),
          (6304, 1536, 384, 1, 1, 0, "kept fc1"), (6500, 384, 384, 0, 0, 1, "ragged"),
          # the projection head on 6272 rows (K % 96 != 0: the round-4 persistent kernel refused them)
-         (6272, 1024, 384, 1, 1, 0, "head 1"), (6272, 1024, 1024, 1, 1, 0, "head 2"), (6272, 512, 1024, 1, 1, 0, "head 3")]
+         (6272, 1024, 384, 1, 1, 0, "head 1"), (6272, 1024, 1024, 1, 1, 0, "head 2"), (6272, 512, 1024, 1, 1, 0, "head 3"), (6272, 256, 512, 0, 0, 0, "head 4"),
+         # kept-frame launches of the trainable blocks (6304 rows: 75 tiles at N = 384)
+         (6304, 384, 384, 0, 0, 1, "kept proj"), (6304, 384, 1536, 0, 0, 1, "kept fc2"), (6304, 1152, 384, 0, 1, 0, "kept qkv"),
+         (18912, 384, 384, 0, 0, 1, "rest proj"), (18912, 1536, 384, 1, 1, 0, "rest fc1")]
 tot = {n: 0.0 for n, _ in libs}
 for M, N, K, act, po, res, name in cases:
     x = split(torch.randn(M, K, device="cuda")); w = split(torch.randn(N, K, device="cuda") * 0.05)
