@@ -107,10 +107,13 @@ def instrumented_step(model, opt, x, use_teacher):
     rec = []
     hip_ops.PROFILE = rec
     engine.RCCL_PROFILE = []
+    core = model.get_non_ddp_model() if hasattr(model, "get_non_ddp_model") else model
+    graph_on, core._step_graph_on = getattr(core, "_step_graph_on", False), False   # (launch by launch: a graph replay has no per-launch events)
     try:
         train_step(model, opt, x, use_teacher)
         torch.cuda.synchronize()
     finally:
+        core._step_graph_on = graph_on
         hip_ops.PROFILE = None
         waits, engine.RCCL_PROFILE = engine.RCCL_PROFILE, None
     rccl = [{"collective": k, "bytes": n, "exposed_wait_ms": round(e0.elapsed_time(e1), 4)} for k, n, e0, e1 in waits]
@@ -429,6 +432,9 @@ def main():
                          "hip_ops.set_gemm_precision documents the others)")
     ap.add_argument("--no_alt_precision", action="store_true", help="skip the secondary measurements in the other precision modes")
     ap.add_argument("--no_exchange_probe", action="store_true", help="skip the one-rank RCCL probe of the exchange path (1-GPU runs)")
+    ap.add_argument("--step_graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step's launch sequence as ONE captured hipGraph (TimeT.enable_step_graph): auto = in the launch-bound regime "
+                         "(at most 16 frames per GPU: BASELINE C1), one GPU")
     ap.add_argument("--no_exchange_autotune", action="store_true",
                     help="N > 1: keep the default exchange (all-gather Sinkhorn, 4 gradient buckets) instead of timing the variants first")
     ap.add_argument("--exchange_probe_child", action="store_true", help=argparse.SUPPRESS)
@@ -484,6 +490,9 @@ def main():
         model.init_queue(a.queue_size // world)
         model.set_queue(torch.nn.functional.normalize(torch.randn_like(model.queue), dim=1))
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1 + rank)).to(device)  # resident in HBM before timing
+    step_graph = world == 1 and (a.step_graph == "on" or (a.step_graph == "auto" and bs * fs <= 16))
+    if step_graph:
+        model.enable_step_graph()
 
     from timetuning_amd import hip_ops
 
@@ -572,6 +581,7 @@ def main():
                        "clips_per_gpu": bs, "num_frames": fs, "num_clusters": K,
                        "global_batch": bs * world, "parallelism": f"dp{world}"},
             "loss": round(final_loss, 5),
+            "step_graph": bool(step_graph),   # True: the timed steps replay ONE captured hipGraph of the step's launch sequence (+ the eager optimizer call)
             # proof of what carried the exchange: RCCL ("nccl") saw this many ranks (None for the single-process run)
             # with the compute stream's exposed wait per collective in the instrumented step
             "rccl": dict(rccl_report(dist, headline_waits), exchange_autotune=engine.EXCHANGE_CHOICE) if world > 1 else None,

@@ -307,6 +307,56 @@ def test_full_size_c1(golden, accurate_precision):
             assert rel_err(mine, g[key]) < TOL, key
 
 
+@pytest.mark.parametrize("teacher_queue", [False, True])
+def test_step_graph_replays_the_eager_step(accurate_precision, teacher_queue):
+    """``TimeT.enable_step_graph()`` (round 5, BASELINE C1's launch-bound regime): from the second step of a shape on, the step's whole
+    launch sequence is ONE captured hipGraph.  Two models from the same weights train four steps on the same clips (C1's shape: 2 clips x 2
+    frames at ViT-S/16 size) - one eagerly, one through the graph (step 1 eager, step 2 captured + replayed, steps 3 - 4 replayed) - and
+    must stay bit for bit equal: losses, every gradient, every parameter, the queue and the teacher (the same kernels on the same bytes;
+    the queue's permutations come from the same host generator state)."""
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.my_utils import cosine_scheduler
+    from timetuning_amd.time_tuning import SwavOptimizer, TimeT
+
+    bs, fs, K = 2, 2, 50
+
+    def make():
+        fe = FeatureExtractor("dino-s16", "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="stress", return_attention=False)
+        m = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, 256))).cuda()
+        o = SwavOptimizer(m, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, 1, 8), 8, 1)
+        if teacher_queue:
+            m.init_momentum_teacher()
+            m.set_momentum_teacher_schedular_params(0.995, 1.0, 1, 8)
+            m.init_queue(bs * 10 * 3)    # bs * 10 rows are pushed per step (time_tuning.py:250-261): full after three - the graph is captured
+                                         # in the filling state (step 2) and again in the full one (step 5)
+        return m, o
+
+    clips = [torch.from_numpy(synth.make_clips(bs, fs, 224, seed=40 + i)).cuda() for i in range(6)]
+    runs = []
+    for graph in (False, True):
+        m, o = make()
+        if graph:
+            m.enable_step_graph()
+        torch.manual_seed(123)   # (the queue's permutations: torch's CPU generator, as the reference)
+        rec = []
+        for i, x in enumerate(clips):
+            loss = m.get_loss(x)
+            m.train_update(o, loss, min(i + 1, 7))
+            rec.append((loss.item(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+        torch.cuda.synchronize()
+        runs.append((m, rec))
+    (me, re_), (mg, rg) = runs
+    assert len(mg._step_graphs) >= 1, "no step was captured"
+    for i, ((le, ge), (lg, gg)) in enumerate(zip(re_, rg)):
+        assert le == lg, (i, le, lg)
+        assert ge.keys() == gg.keys() and all(torch.equal(ge[n], gg[n]) for n in ge), i
+    pe, pg = dict(me.named_parameters()), dict(mg.named_parameters())
+    assert all(torch.equal(pe[n], pg[n]) for n in pe)
+    if teacher_queue:
+        assert torch.equal(me.queue, mg.queue) and torch.equal(me.teacher_prototypes, mg.teacher_prototypes)
+        assert len(mg._step_graphs) == 2   # filling, then full
+
+
 def test_c2_size_properties():
     """BASELINE C2 (bs 32 x 4 frames, K=200): too big for golden tensors; checked through invariants and against
     the CPU oracle on a sub-batch (per-clip computations are independent except for the Sinkhorn coupling)."""

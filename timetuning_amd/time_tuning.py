@@ -115,6 +115,25 @@ class _FusedLoss(torch.autograd.Function):
         return (None, None, None, None, *out)
 
 
+class _GraphLoss(torch.autograd.Function):
+    """``_FusedLoss`` for a step that lives in a captured hipGraph (``TimeT.enable_step_graph``): forward replays the graph - the whole
+    launch sequence of forward AND backward in one host call - and hands out the loss; backward hands out the graph's static gradient
+    buffers (fresh views: autograd adopts them)."""
+
+    @staticmethod
+    def forward(ctx, model, rec, *params):
+        rec["graph"].replay()
+        ctx.grads = [rec["grads"].get(p) for p in params]
+        return rec["loss"].clone().view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        out, ctx.grads = [None if g is None else g.view(g.shape) for g in ctx.grads], None
+        live = [g for g in out if g is not None]
+        ops.scale_tensors_(live, gout.reshape(1).to(torch.float32).contiguous())
+        return (None, None, *out)
+
+
 class TimeT(nn.Module):
     """``TimeT(feature_extractor, prototype_number=10, prototype_init=None)`` (``time_tuning.py:80-93``)."""
 
@@ -342,7 +361,59 @@ class TimeT(nn.Module):
                   target_labels=target_labels)
         params = [p for p in self.parameters() if p.requires_grad]
         need_grad = torch.is_grad_enabled() and len(params) > 0
+        if getattr(self, "_step_graph_on", False) and need_grad and x.is_cuda and queue_perm is None and target_labels is None \
+                and engine.exchange_group() is None:
+            out = self._graph_step(x, hp, params)
+            if out is not None:
+                return out
         return _FusedLoss.apply(self, x, hp, need_grad, *params)
+
+    # -- the step as ONE captured hipGraph (launch-bound regimes: BASELINE C1's 4 frames are ~230 launches of 5 - 15 us each) ---------
+    def enable_step_graph(self, on: bool = True) -> None:
+        """From the second training step of a given shape on, ``get_loss`` replays a captured hipGraph of the step's whole launch
+        sequence (forward + backward, ~230 launches at C1) instead of issuing it launch by launch: the host then costs one replay
+        (~15 us) instead of ~10 us per launch.  The first step of a shape runs eagerly (lazily made operands, pinned buffers and the
+        K-split workspace exist afterwards), the second one is captured and replayed; a new input shape, a changed set of trainable
+        tensors, arithmetic mode, hyper-parameter or queue state (filling -> full) captures again.  What stays outside the graph: the
+        optimizer (its learning rate / weight decay / step count are kernel ARGUMENTS that change every step) and the host's own
+        bookkeeping - the queue permutation is drawn on the host into the pinned buffer the graph's copy node reads.  Needs ABI 7 (no
+        allocation on a launch path).  One process per GPU without an exchange (W = 1); memory: the graph keeps the step's activations."""
+        self._step_graph_on = bool(on)
+        self._step_graphs = {}
+        self._step_graph_seen = set()
+
+    def _graph_step(self, x, hp, params):
+        bs, fs = x.shape[0], x.shape[1]
+        n = self.feature_extractor.spatial_resolution ** 2
+        full = self.queue_is_full() if self.queue is not None else False
+        key = (tuple(x.shape), str(x.device), ops.get_gemm_precision(), ops.PAIRS_MIN_ROWS, hp["n_last_frames"], hp["radius"], hp["topk"],
+               float(hp["epsilon"]), hp["iters"], hp["mask_features"], self.teacher is not None, None if self.queue is None else self.queue.shape[0],
+               full, tuple(id(p) for p in params), self.teacher_shares_frozen_blocks() if self.teacher is not None else None)
+        rec = self._step_graphs.get(key)
+        if rec is None:
+            if key not in self._step_graph_seen:   # the first step of a shape: eager (it creates what a capture may not create)
+                self._step_graph_seen.add(key)
+                return None
+            if len(self._step_graphs) >= 4:
+                self._step_graphs.clear()
+            # capture.  The host work of the step runs here, once, as it would in an eager step (queue bookkeeping, the permutation);
+            # the kernels are only recorded - the replay below executes them.
+            xs = x.clone()
+            g = torch.cuda.CUDAGraph()
+            ops.ksplit_workspace(x.device)
+            torch.cuda.synchronize(x.device)
+            with torch.cuda.graph(g):
+                loss, grads = self._run_step(xs, hp, True)
+            rec = self._step_graphs[key] = dict(graph=g, x=xs, loss=loss, grads=grads, aux=self.last_aux, m=min(bs * 10, self.queue.shape[0]) if self.queue is not None else 0)
+        else:
+            rec["x"].copy_(x)
+            # the host's share of the step (what _run_step does outside its launches): a fresh permutation in the pinned buffer the graph's
+            # copy node reads, the queue's bookkeeping
+            if self.queue is not None:
+                torch.randperm(bs * n, out=self._queue_perm_pinned)
+                self._queue_pushed(rec["m"])
+            self.last_aux = rec["aux"]
+        return _GraphLoss.apply(self, rec, *params)
 
     def _frame_map(self, bs, fs, device, only_t: Optional[int] = None):
         key = (bs, fs, only_t, str(device))
