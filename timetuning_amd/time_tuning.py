@@ -385,7 +385,11 @@ class TimeT(nn.Module):
     def _graph_step(self, x, hp, params):
         bs, fs = x.shape[0], x.shape[1]
         n = self.feature_extractor.spatial_resolution ** 2
-        full = self.queue_is_full() if self.queue is not None else False
+        # the queue's state as the step will see it AFTER its push (time_tuning.py:207: the scores take the queue rows once it is full)
+        full = False
+        if self.queue is not None:
+            full = self.queue_is_full() or (self._queue_rows_pushed is not None and
+                                            self._queue_rows_pushed + min(bs * 10, self.queue.shape[0]) >= self.queue.shape[0])
         key = (tuple(x.shape), str(x.device), ops.get_gemm_precision(), ops.PAIRS_MIN_ROWS, hp["n_last_frames"], hp["radius"], hp["topk"],
                float(hp["epsilon"]), hp["iters"], hp["mask_features"], self.teacher is not None, None if self.queue is None else self.queue.shape[0],
                full, tuple(id(p) for p in params), self.teacher_shares_frozen_blocks() if self.teacher is not None else None)
