@@ -327,8 +327,8 @@ def test_step_graph_replays_the_eager_step(accurate_precision, teacher_queue):
         if teacher_queue:
             m.init_momentum_teacher()
             m.set_momentum_teacher_schedular_params(0.995, 1.0, 1, 8)
-            m.init_queue(bs * 10 * 3)    # bs * 10 rows are pushed per step (time_tuning.py:250-261): full after three - the graph is captured
-                                         # in the filling state (step 2) and again in the full one (step 4; step 3's push fills it: eager)
+            m.init_queue(bs * 10 * 4)    # bs * 10 rows are pushed per step (time_tuning.py:250-261): steps 1 - 3 see a filling queue (eager,
+                                         # captured, replayed), step 4's push fills it (a new state: eager), 5 is captured, 6 replayed
         return m, o
 
     clips = [torch.from_numpy(synth.make_clips(bs, fs, 224, seed=40 + i)).cuda() for i in range(6)]
