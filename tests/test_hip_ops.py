@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_err
+from conftest import rel_err, rel_l2
 from oracle import timet_oracle as O
 from timetuning_amd import synth
 
@@ -280,6 +280,33 @@ def test_sinkhorn_c2_size_vs_oracle(ops):
         assert rel_err(q.sum(1), torch.ones(B)) < 1e-5          # rows of q sum to 1
         col = q.double().sum(0)                                   # prototypes are used (nearly) equally
         assert (col.max() / col.min()) < 1.05
+
+
+@pytest.mark.parametrize("B,K,iters", [(6272, 200, 10), (8320, 200, 10), (50176, 200, 10), (392, 50, 3), (1000, 333, 1), (6272, 200, 0), (777, 512, 5)])
+def test_sinkhorn_one_launch_equals_the_launch_per_iteration_path(ops, B, K, iters):
+    """sk_persistent_kernel (round 5: the whole solve in ONE launch - E resident in LDS, or in the workspace for problems beyond the chip's LDS
+    [50176 rows: the 8-rank global problem]; only the K row sums cross workgroups, through write-through partials + an arrival counter)
+    against the launch-per-iteration kernels (knob TT_SK_PERSIST = 0) and the fp64 oracle; run-to-run bit equality (the partials are folded in
+    workgroup order whoever arrives first); requested row windows."""
+    x = F.normalize(rnd(f"sk1.x{B}.{K}", B, 48), dim=1)
+    p = F.normalize(rnd(f"sk1.p{K}", K, 48), dim=1)
+    scores = dev((x @ p.t()).contiguous())
+    from timetuning_amd import hip_ops
+    q0 = ops.sinkhorn(scores, iters)                     # the product path: one launch per iteration
+    try:
+        hip_ops.set_tuning_knob("TT_SK_PERSIST", 1)      # (measured slower than it: kept behind the knob, see sinkhorn.hip)
+        q1 = ops.sinkhorn(scores, iters)
+        for _ in range(3):
+            assert torch.equal(ops.sinkhorn(scores, iters), q1)
+        r0, n = B // 3, B // 4
+        qw = ops.sinkhorn(scores, iters, row0=r0, rows_out=n)
+        assert torch.equal(qw, q1[r0:r0 + n])
+    finally:
+        hip_ops.set_tuning_knob("TT_SK_PERSIST", 0)
+    assert rel_err(q1.cpu(), q0.cpu()) < 2e-6 and rel_l2(q1.cpu(), q0.cpu()) < 1e-6
+    if B <= 8320:
+        ref = O.sinkhorn(torch.exp((x @ p.t()).double() / 0.05).t(), iters)
+        assert rel_err(q1.cpu(), ref) < 5e-5
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])

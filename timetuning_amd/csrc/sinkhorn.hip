@@ -186,6 +186,180 @@ __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __rest
   fold_waves(acc, red, partial_out + (long long)blockIdx.x * K, K);
 }
 
+// ---- the whole solve in ONE launch (round 5) ------------------------------------------------------------------------------
+// SURVEY 2.4 k12's persistent form.  G workgroups (one per CU: 1024 threads and most of the LDS), each owning a run of rows whose E it keeps
+// in LDS for the whole solve (LDS_E; 6272 x 200 at C2: 38 - 56 workgroups) or, for problems beyond the chip's LDS (the 8-rank global problem,
+// 40 MB), re-reads from its own slice of the workspace (L2 / Infinity Cache).  Per iteration the only thing that crosses workgroups is the
+// K-vector of row sums: every workgroup publishes its partial sums (write-through sc1 stores), one lane adds to an arrival counter behind the
+// workgroup's `s_waitcnt vmcnt(0)` + barrier, everybody polls the counter (one lane, sc1 loads, s_sleep) and then folds ALL partials in
+// workgroup order with sc1 loads - the hand-off form of MI355X_MICROARCH.md "Valid forms", first table row: no agent-scope fence (the
+// 287 us of the round-3 attempt were its L2 write-back + invalidate around the 5 MB of E, which now never leaves the CU).
+// MEASURED (tools/run_r05k.sh, one box, 10 iterations at K = 200): B = 6272: 105 us against 77.7 us for the launch-per-iteration path
+// (B = 50176: 270 against 188) - correct (bit-equal from run to run, equal to the other path to fp32 rounding: tests/test_hip_ops.py), and
+// SLOWER: an iteration costs ~ 9.5 us, of which the cross-workgroup exchange is ~ 8 - write-through stores complete (`vmcnt(0)`, ~ 2 us),
+// the arrival atomics land (~ 1), a poll sees them (~ 1.5 per round trip), the partials come back from beyond the XCD's L2 (~ 1.5; all
+// in flight at once or eight at a time made no difference) - against ~ 2 us for a kernel boundary plus an L2-served fold.  The price
+// list of the guide says the same: a chip-wide hand-off is 3 - 5 us, a boundary 1.5 - 2.  It stays in the library behind the knob
+// TT_SK_PERSIST (default 0) with its tests; the product path is the launch-per-iteration one.  Two partial
+// buffers alternate: a workgroup can publish iteration i + 1 only after it has read every partial of iteration i, i.e. after every other
+// workgroup has finished reading iteration i - 1.  The fold order is fixed (run-to-run bit equality); every spin is bounded (status word).
+struct SkpArgs {
+  const float* scores;   // [B][K]
+  float* Eg;             // [B][K] workspace (LDS_E = false) or unused
+  float* part;           // [2][SK_MAXWG][K]
+  unsigned* counter;     // [0]: arrivals (zeroed by the launch function), [1]: status (1 = a spin gave up)
+  float* q_out;          // [rows_out][K]
+  int B, K, G, rows_per_wg, row0, rows_out, iters;
+  float eps;
+  int b_norm;
+};
+constexpr int SKP_LDS_FLOATS = 38400;   // 150 KB
+__host__ __device__ inline int skp_kpad(int K) { return (K + 63) / 64 * 64; }
+__host__ __device__ inline int skp_lds_rows(int K) { return (SKP_LDS_FLOATS - 64 * SK_KPL - SK_WAVES * skp_kpad(K)) / K; }
+
+template <bool LDS_E>
+__global__ __launch_bounds__(SK_THREADS) void sk_persistent_kernel(SkpArgs g) {
+  __shared__ float sm[SKP_LDS_FLOATS];
+  const int K = g.K, KP = skp_kpad(K);
+  float* a_s = sm;                              // [64 SK_KPL]
+  float* red = sm + 64 * SK_KPL;                // [SK_WAVES][KP]
+  float* El = red + SK_WAVES * KP;              // [rows_per_wg][K] (LDS_E)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wg = blockIdx.x;
+  const int r0 = wg * g.rows_per_wg, r1 = min(g.B, r0 + g.rows_per_wg);
+  auto e_ptr = [&](int b) -> float* { return LDS_E ? El + (size_t)(b - r0) * K : g.Eg + (size_t)b * K; };
+  float acc[SK_KPL], a[SK_KPL];
+
+  // fold the 16 waves' register partials and publish them (sc1), then signal
+  auto publish = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < SK_KPL; ++i)
+      if (lane + 64 * i < K) red[wave * KP + lane + 64 * i] = acc[i];
+    __syncthreads();
+    float* out = g.part + ((size_t)buf * SK_MAXWG + wg) * K;
+    for (int k = threadIdx.x; k < K; k += SK_THREADS) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < SK_WAVES; ++w) s += red[w * KP + k];
+      __hip_atomic_store(out + k, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(g.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // wait for all G partials of phase `ph`, then a_k = (1 / K) / sum over workgroups (fixed order)
+  auto gather = [&](int ph) {
+    if (threadIdx.x == 0) {
+      const unsigned target = (unsigned)g.G * (unsigned)(ph + 1);
+      unsigned spins = 0;
+      while (__hip_atomic_load(g.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 24)) { __hip_atomic_store(g.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    __syncthreads();
+    // every partial is a round trip beyond this XCD's L2 (~ 1.5 us): all of them in flight at once - thread (k, j) takes the workgroups
+    // w = j, j + NJ, ... (NJ = 1024 / KP threads per k), their NJ sums meet in LDS and are added in the order of j: a fixed order
+    const float* in = g.part + (size_t)(ph & 1) * SK_MAXWG * K;
+    const int NJ = SK_THREADS / KP;
+    {
+      const int k = threadIdx.x % KP, j = threadIdx.x / KP;
+      float u = 0.f;
+      if (k < K && j < NJ) {
+        float v[16];
+        for (int w0 = j; w0 < g.G; w0 += 16 * NJ) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int w = w0 + q * NJ;
+            v[q] = w < g.G ? __hip_atomic_load(in + (size_t)w * K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+          }
+#pragma unroll
+          for (int q = 0; q < 16; ++q) u += v[q];
+        }
+      }
+      if (j < NJ) red[j * KP + k] = u;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += SK_THREADS) {
+      float u = 0.f;
+      for (int j = 0; j < NJ; ++j) u += red[j * KP + k];
+      a_s[k] = (1.0f / (float)K) / u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SK_KPL; ++i) a[i] = (lane + 64 * i < K) ? a_s[lane + 64 * i] : 0.f;
+  };
+
+  // ---- phase 0: E = exp(scores / eps) for this workgroup's rows (kept), their column sums
+#pragma unroll
+  for (int i = 0; i < SK_KPL; ++i) acc[i] = 0.f;
+  for (int b = r0 + wave; b < r1; b += SK_WAVES) {
+    float* er = e_ptr(b);
+#pragma unroll
+    for (int i = 0; i < SK_KPL; ++i) {
+      const int k = lane + 64 * i;
+      if (k < K) {
+        const float e = expf(g.scores[(long long)b * K + k] / g.eps);
+        er[k] = e;
+        acc[i] += e;
+      }
+    }
+  }
+  if (g.iters > 0) publish(0);
+  else __syncthreads();
+  const float c = 1.0f / (float)g.b_norm;
+  for (int it = 0; it < g.iters || it == 0; ++it) {
+    if (g.iters > 0) gather(it);
+    else {
+#pragma unroll
+      for (int i = 0; i < SK_KPL; ++i) a[i] = (lane + 64 * i < K) ? 1.0f : 0.f;
+    }
+    const bool last = it + 1 >= g.iters;
+    if (last) {
+      // the last row step's a, the final column normalisation, written for the requested rows this workgroup owns
+      const int o0 = max(r0, g.row0), o1 = min(r1, g.row0 + g.rows_out);
+      for (int b = o0 + wave; b < o1; b += SK_WAVES) {
+        const float* er = e_ptr(b);
+        float e[SK_KPL], t = 0.f;
+#pragma unroll
+        for (int i = 0; i < SK_KPL; ++i) {
+          e[i] = (lane + 64 * i < K) ? er[lane + 64 * i] : 0.f;
+          t += a[i] * e[i];
+        }
+        t = wave_sum(t);
+#pragma unroll
+        for (int i = 0; i < SK_KPL; ++i)
+          if (lane + 64 * i < K) g.q_out[(long long)(b - g.row0) * K + lane + 64 * i] = a[i] * e[i] / t;
+      }
+      break;
+    }
+    // column step over this workgroup's rows, two rows per wave in flight; the row sums that follow
+#pragma unroll
+    for (int i = 0; i < SK_KPL; ++i) acc[i] = 0.f;
+    for (int b = r0 + wave; b < r1; b += 2 * SK_WAVES) {
+      const int b2 = b + SK_WAVES;
+      const bool has2 = b2 < r1;
+      const float* er = e_ptr(b);
+      const float* fr = e_ptr(has2 ? b2 : b);
+      float e[SK_KPL], f[SK_KPL], t = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < SK_KPL; ++i) {
+        const int k = lane + 64 * i;
+        e[i] = (k < K) ? er[k] : 0.f;
+        f[i] = (k < K && has2) ? fr[k] : 0.f;
+        t += a[i] * e[i];
+        t2 += a[i] * f[i];
+      }
+      t = wave_sum(t);
+      t2 = wave_sum(t2);
+      const float bb = c / t, bb2 = has2 ? c / t2 : 0.f;
+#pragma unroll
+      for (int i = 0; i < SK_KPL; ++i) acc[i] += e[i] * bb + f[i] * bb2;
+    }
+    __syncthreads();   // (red is reused: the previous publish's readers are done - they passed gather's barriers)
+    publish((it + 1) & 1);
+  }
+}
+
 // ---- cross entropy -----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ scores, const int64_t* __restrict__ labels,
                                                  const float* __restrict__ row_weight, float* __restrict__ row_loss,
@@ -239,7 +413,7 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, 
 using namespace tt;
 
 extern "C" size_t tt_sinkhorn_workspace_bytes(int B_total, int K) {
-  return ((size_t)B_total * K + 2ull * SK_MAXWG * K) * sizeof(float);
+  return ((size_t)B_total * K + 2ull * SK_MAXWG * K) * sizeof(float) + 256;   // E | two partial buffers | the persistent kernel's counter block
 }
 
 static int sinkhorn_impl(const float* scores, const float* Q, int q_rows_are_columns, float* q_out, int B_total, int K, int row0,
@@ -270,6 +444,28 @@ static int sinkhorn_impl(const float* scores, const float* Q, int q_rows_are_col
   float* part[2] = {Ews + (size_t)B_total * K, Ews + (size_t)B_total * K + (size_t)SK_MAXWG * K};
   // E [B][K]: built in the workspace, or - when the caller already holds the positive matrix in that layout - read in place
   const float* E = (Q && q_rows_are_columns) ? Q : Ews;
+  // ---- one persistent launch (sk_persistent_kernel) where every workgroup can be resident at once: from scores only
+  if (!Q && tuning_knob(KNOB_SK_PERSIST) != 0) {   // (default off: measured slower, see sk_persistent_kernel)
+    const int ncu = device_cu_count();
+    const int cap = skp_lds_rows(K);
+    static const int rows_env = [] { const char* e = getenv("TT_SKP_ROWS"); return e ? atoi(e) : 0; }();   // tuning aid
+    int rows = rows_env > 0 ? rows_env : 112;
+    if (rows > cap) rows = cap;
+    int G = rows > 0 ? (B_total + rows - 1) / rows : ncu + 1;
+    bool lds_e = G <= ncu && G <= SK_MAXWG;
+    if (!lds_e) {                      // beyond the chip's LDS: E stays in the workspace, one workgroup per CU
+      G = ncu < SK_MAXWG ? ncu : SK_MAXWG;
+      rows = (B_total + G - 1) / G;
+      G = (B_total + rows - 1) / rows;
+    }
+    unsigned* counter = reinterpret_cast<unsigned*>(Ews + (size_t)B_total * K + 2ull * SK_MAXWG * K);
+    if (hipMemsetAsync(counter, 0, 16, s) != hipSuccess) { set_error("sinkhorn: hipMemsetAsync failed"); return TT_ELAUNCH; }
+    SkpArgs a{scores, Ews, part[0], counter, q_out, B_total, K, G, rows, row0, rows_out, iters, eps, B_total};
+    if (lds_e) hipLaunchKernelGGL((sk_persistent_kernel<true>), dim3(G), dim3(SK_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((sk_persistent_kernel<false>), dim3(G), dim3(SK_THREADS), 0, s, a);
+    TT_CHECK_LAUNCH("sinkhorn (persistent)");
+    return TT_OK;
+  }
   const int wgs = sk_wgs(B_total);
   const int rpw = (B_total + wgs - 1) / wgs;
   if (Q) {
