@@ -8,7 +8,8 @@
 // accumulator and kh ql + kl qh into a second one, folded with the exact 2^-11 per key tile; the probabilities p = 2^(s c - m c) in (0, 1] are
 // split into (hi, lo) on their way into O^T = V^T P^T, which runs the same way.  fp32 scores, softmax statistics and accumulation.
 //
-// Structure: that of attention_bf16.hip - ONE 8-wave workgroup per (frame, head); K and V of that head go HBM -> LDS once, by LDS-DMA, and stay:
+// Structure: that of attention_bf16.hip - an 8-wave workgroup works on one (frame, head) at a time (one workgroup per CU, looping over its
+// items: round 5, below); K and V of that head go HBM -> LDS once, by LDS-DMA, and stay:
 //   K image  [key][256 B]: 16-byte chunks XOR-swizzled by key & 15 -> conflict-free ds_read_b128 A fragments (rows of 256 B are whole bank rows)
 //   V image  [key][256 B]: the four 64-byte quarters (hi / lo of dims 0-31, 32-63) XOR-swizzled by key & 3 -> conflict-free
 //            ds_read_b64_tr_b16: V stays row-major (coalesced DMA) and is consumed transposed, as V^T fragments.
@@ -31,52 +32,99 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #ifndef TT_AP_DBG
 #define TT_AP_DBG 0
 #endif
+#ifndef TT_AP_VPOS
+#define TT_AP_VPOS 2   // the V image goes out behind this key tile of the score product (0: at the top of the item, in front of the Q loads)
+#endif
 template <int NKT>
 __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out_pairs,
-                                                                  float* __restrict__ out_f32, float* __restrict__ lse, int N, int H, float scale) {
+                                                                  float* __restrict__ out_f32, float* __restrict__ lse, int N, int H, float scale,
+                                                                  int FH) {
   constexpr int KROWS = NKT * 32;
+  constexpr int NPC = KROWS / 32;   // DMA pieces (4 keys x 256 B) per wave and image
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KROWS * 256 + 8 * 4096];
   unsigned char* Ks = smem;
   unsigned char* Vs = smem + KROWS * 256;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned char* Os = smem + 2 * KROWS * 256 + wave * 4096;   // this wave's output staging: 32 queries x 128 B
-  const int r = lane & 31, h = lane >> 5;
-  const int fh = blockIdx.x, f = fh / H, hd = fh - f * H;
   const int Dm = H * 64;
   const long long RS = 6ll * Dm;                                // fp16 elements per qkv row (2 x 3 D)
-  const _Float16* base = qkv + (long long)f * N * RS + hd * 128;   // q of this head; k: + 2 Dm, v: + 4 Dm
-
-  // ---- K and V: 4 keys x 256 B per DMA piece; lane -> (key, slot of 16), source chunk = slot ^ swizzle(key)
-  if (!(TT_AP_DBG & 32)) {
-    const int l_row = lane >> 4, l_slot = lane & 15;
-    for (int piece = wave; piece < KROWS / 4; piece += 8) {
-      const int key = piece * 4 + l_row;
-      const int krow = key < N ? key : N - 1;
-      const _Float16* src = base + (long long)krow * RS;
-      const int kc = l_slot ^ (key & 15);
-      const int vc = l_slot ^ ((key & 3) << 2);
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + 2 * Dm + kc * 8),
-                                       (void __attribute__((address_space(3)))*)(Ks + piece * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + 4 * Dm + vc * 8),
-                                       (void __attribute__((address_space(3)))*)(Vs + piece * 1024), 16, 0, 0);
-    }
-  }
-  __syncthreads();
-
-  const int nqt = (N + 31) / 32;   // <= 8: one query tile per wave, no loop (a loop lets the compiler hoist - and spill - a hundred loop invariants)
+  const int nqt = (N + 31) / 32;   // <= 8: one query tile per wave
   const int qt = wave;
-  if (qt < nqt) {
-    // Q fragments (B operand): lane (query r, half h) holds Q[query][16 ks + 8 h + j], hi and lo
-    const int query = qt * 32 + r;
+  int lane_o = tid & 63;
+#ifdef TT_AP_STAMP   // diagnostic build only (tools/ap_stamp.py): s_memtime stamps at the phase boundaries of every item, written over out_f32
+  long long stamp[7];
+  long long* stamp_out = reinterpret_cast<long long*>(out_f32);
+  out_f32 = nullptr;
+  int stamp_it = 0;
+#define AP_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i])::"memory")
+#else
+#define AP_STAMP(i)
+#endif
+
+  // K or V image of one (frame, head): 4 keys x 256 B per DMA piece (56 or 64 pieces); lane -> (key, slot of 16), source chunk = slot ^
+  // swizzle(key), one (clamped: no lane is out of range) offset register per piece under a buffer descriptor of the image.  The pieces
+  // w, w + 8, ... are "wave w's"; the swizzle terms are those of the first of them (a piece step is 32 keys).
+  auto issue_pieces = [&](int fh, int lane, bool v_image, int w) {
+    if (TT_AP_DBG & 32) return;
+    const int f = fh / H, hd = fh - f * H;
+    const char* src0 = reinterpret_cast<const char*>(qkv + (long long)f * N * RS + hd * 128 + (v_image ? 4 : 2) * Dm);   // (uniform)
+    const int l_row = lane >> 4, l_slot = lane & 15;
+    const int key0 = w * 4 + l_row;
+    const int ch = v_image ? (l_slot ^ ((key0 & 3) << 2)) : (l_slot ^ (key0 & 15));
+    unsigned char* dst = (v_image ? Vs : Ks) + w * 1024;
+    const unsigned rs2 = (unsigned)RS * 2u;   // bytes per qkv row (an image spans < 2^31 bytes: N <= 256 rows)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src0), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int key = key0 + 32 * j;
+      const unsigned off = (unsigned)(key < N ? key : N - 1) * rs2 + (unsigned)ch * 16u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (void __attribute__((address_space(3)))*)(dst + j * 8192), 16, off, 0, 0, 0);
+    }
+  };
+  auto issue_image = [&](int fh, int lane, bool v_image) { issue_pieces(fh, lane, v_image, wave); };
+
+  // Persistent over the (frame, head) items of this workgroup (round 5: 768 items on 256 CUs at ViT-S/16).  The K image is only read by the
+  // score product and the V image only by P V, so the loads of one item run under the other product of its neighbour with no LDS beyond the
+  // two images: V (item) is issued behind the second key tile of the scores (behind the Q loads in the memory queue - in front of them the
+  // score product waited ~5 k cycles for Q) and lands under the rest of them, K (next item) is issued behind the scores and lands under
+  // softmax + P V.  Two workgroup barriers per item.  With the probabilities made per key tile inside P V and the K fragments read one tile
+  // ahead: 58.3 -> 49.0 us per ViT-S/16 layer of 128 frames, bits equal (profiles/r05_attention_pairs_persistent.txt).  Measured and
+  // dropped there: the next item's Q loads under the end of P V (the 32 registers spill), a touch of the next Q tile's lines instead (no
+  // change), the pieces spread over the key tiles of both products (slower: 53 us), the idle eighth wave issuing every piece (51 us).
+  auto load_q = [&](int fh, int lane, f16x8* qh, f16x8* ql) {
+    const int f = fh / H, hd = fh - f * H;
+    const int query = qt * 32 + (lane & 31);
     const int qrow = query < N ? query : N - 1;
-    f16x8 qh[4], ql[4];
+    const _Float16* p0 = qkv + ((long long)f * N + qrow) * RS + hd * 128 + 8 * (lane >> 5);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const _Float16* p = base + (long long)qrow * RS + (ks >> 1) * 64 + (ks & 1) * 16 + 8 * h;
+      const _Float16* p = p0 + (ks >> 1) * 64 + (ks & 1) * 16;
       qh[ks] = *reinterpret_cast<const f16x8*>(p);
       ql[ks] = *reinterpret_cast<const f16x8*>(p + 32);
     }
+  };
+  int fh = blockIdx.x;
+  issue_image(fh, lane_o, false);
+  for (; fh < FH; fh += gridDim.x) {
+    asm volatile("" : "+v"(lane_o));   // the per-lane addresses below are recomputed per item: hoisted out of the loop they spill
+    const int lane = lane_o;
+    const int r = lane & 31, h = lane >> 5;
+    const int f = fh / H, hd = fh - f * H;
+    const _Float16* base = qkv + (long long)f * N * RS + hd * 128;   // q of this head; k: + 2 Dm, v: + 4 Dm
+    AP_STAMP(0);
+    // K (item) has landed (issued one product ago) and every wave is past the V reads of the previous item
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    AP_STAMP(1);
+    if (TT_AP_VPOS == 0 || qt >= nqt) issue_image(fh, lane, true);
+
+    const int query = qt * 32 + r;
+    f32x16 sacc[NKT];
+    if (qt < nqt) {
+    // Q fragments (B operand): lane (query r, half h) holds Q[query][16 ks + 8 h + j], hi and lo
+    f16x8 qh[4], ql[4];
+    load_q(fh, lane, qh, ql);
 
     // K fragment addresses: row kt * 32 + r -> a per-lane base (r) + an immediate (kt); the swizzle term depends on r & 15 only
     int kofs[8];   // [ks] hi, [4 + ks] lo
@@ -86,20 +134,25 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
       kofs[ks] = r * 256 + ((ch ^ (r & 15)) << 4);
       kofs[4 + ks] = r * 256 + (((ch + 4) ^ (r & 15)) << 4);
     }
-    f32x16 sacc[NKT];
+    // the K fragments of key tile kt + 1 are read in front of the products of tile kt (two sets of eight)
+    f16x8 kf[2][8];
+    auto read_k = [&](int kt, f16x8* dst) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if constexpr (TT_AP_DBG & 16) dst[i] = (i < 4 ? qh : ql)[(i + kt) & 3];
+        else dst[i] = *reinterpret_cast<const f16x8*>(Ks + kt * 8192 + kofs[i]);
+      }
+    };
+    read_k(0, kf[0]);
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
+      if (kt + 1 < NKT) read_k(kt + 1, kf[(kt + 1) & 1]);
       f32x16 s1, s2;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        f16x8 kfh, kfl;
-        if constexpr (TT_AP_DBG & 16) { kfh = qh[(ks + kt) & 3]; kfl = ql[(ks + kt) & 3]; }
-        else {
-          kfh = *reinterpret_cast<const f16x8*>(Ks + kt * 8192 + kofs[ks]);
-          kfl = *reinterpret_cast<const f16x8*>(Ks + kt * 8192 + kofs[4 + ks]);
-        }
+        const f16x8 kfh = kf[kt & 1][ks], kfl = kf[kt & 1][4 + ks];
         if constexpr (TT_AP_DBG & 1) { s1[ks] += (float)kfh[0]; s2[ks] += (float)kfl[0]; }
         else {
           s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, qh[ks], s1, 0, 0, 0);
@@ -109,8 +162,21 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) sacc[kt][e] = fmaf(s2[e], kPairInvScale, s1[e]);
-      __builtin_amdgcn_sched_barrier(0);   // one key tile at a time: the compiler otherwise hoists the next tiles' reads and spills
+      __builtin_amdgcn_sched_barrier(0);   // one key tile at a time: the compiler otherwise hoists the later tiles' reads and spills
+      if (TT_AP_VPOS != 0 && kt == TT_AP_VPOS - 1) {
+        issue_image(fh, lane, true);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    }
+    AP_STAMP(2);
+    // V (item) has landed; every wave is past its K reads: the next item's K goes out
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    AP_STAMP(3);
+    const bool more = fh + (int)gridDim.x < FH;
+    if (more) issue_image(fh + gridDim.x, lane, false);
+    if (qt < nqt) {
     // softmax over the keys of this lane column (attention_bf16.hip): p = 2^(s c - m c), c = scale log2(e)
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
@@ -127,36 +193,9 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    AP_STAMP(4);
     const float c = scale * 1.44269504088896340736f;
     const float mc = mx * c;
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float p = (TT_AP_DBG & 2) ? sacc[kt][e] : __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], c, -mc));
-        sacc[kt][e] = p;
-        sum += p;
-      }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = __builtin_amdgcn_rcpf(sum);
-    if (lse && h == 0 && query < N) lse[((long long)f * H + hd) * N + query] = (mc + __log2f(sum)) * 0.69314718055994530942f;   // natural-log units
-
-    // the probabilities as MFMA operands: P^T is the B operand of O^T = V^T P^T as it stands (k-step s of key tile kt = registers 8 s .. 8 s + 7),
-    // split into (hi, lo) once - the scores' registers are dead from here on
-    f16x8 ph[NKT][2], pl[NKT][2];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          _Float16 hi_, lo_;
-          if constexpr (TT_AP_DBG & 2) { hi_ = (_Float16)sacc[kt][8 * s + j]; lo_ = hi_; }
-          else split_pair(sacc[kt][8 * s + j], hi_, lo_);
-          ph[kt][s][j] = hi_;
-          pl[kt][s][j] = lo_;
-        }
     const int g16 = (lane >> 4) & 1, q4 = (lane >> 2) & 3, p4 = lane & 3;   // position inside the 16-lane transpose group
     // V^T gather addresses: block rows = keys key0 .. key0 + 3 (this lane supplies row q4), block columns = 16 dims of one 64-byte quarter
     // (hi or lo of a 32-dim group).  key0 = kt * 32 + 16 s + 4 h (+ 8) is a multiple of 4, so the quarter swizzle is q4 for every block:
@@ -165,38 +204,62 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
 #pragma unroll
     for (int qn = 0; qn < 4; ++qn) vofs[qn] = (4 * h + q4) * 256 + ((qn ^ q4) << 6) + (16 * g16 + 4 * p4) * 2;
     const int c8 = lane & 7;
-    // O^T [64 d x 32 queries] = V^T P^T, three products per term; one 32-dim group (dt) at a time
+    // O^T [64 d x 32 queries] = V^T P^T, three products per term, both 32-dim groups per key tile (four independent accumulator chains).
+    // The probabilities of a key tile are made where they are consumed (round 5): exp, row sum and the split into (hi, lo) of tile kt + 1
+    // are VALU work the scheduler places under the matrix products of tile kt, and at most one tile of P fragments is live.  P^T is the B
+    // operand as it stands (k-step s of key tile kt = registers 8 s .. 8 s + 7).
+    f32x16 o1[2], o2[2];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      f32x16 o1, o2;
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { o1[e] = 0.f; o2[e] = 0.f; }
+      for (int e = 0; e < 16; ++e) { o1[dt][e] = 0.f; o2[dt][e] = 0.f; }
+    float sum = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
+      f16x8 ph[2], pl[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const unsigned char* vrow = Vs + (kt * 32 + 16 * s) * 256;
+      for (int e = 0; e < 16; ++e) {   // exp, row sum and split of this key tile
+        const float p = (TT_AP_DBG & 2) ? sacc[kt][e] : __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], c, -mc));
+        sum += p;
+        _Float16 hi_, lo_;
+        if constexpr (TT_AP_DBG & 2) { hi_ = (_Float16)p; lo_ = hi_; }
+        else split_pair(p, hi_, lo_);
+        ph[e >> 3][e & 7] = hi_;
+        pl[e >> 3][e & 7] = lo_;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const unsigned char* vrow = Vs + (kt * 32 + 16 * s) * 256;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
           union { s16x4 s2[2]; f16x8 v; } vh, vl;
-          if constexpr (TT_AP_DBG & 8) { vh.v = ph[kt][s ^ 1]; vl.v = pl[kt][s ^ 1]; }
+          if constexpr (TT_AP_DBG & 8) { vh.v = ph[s ^ 1]; vl.v = pl[s ^ 1]; }
           else {
             vh.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + vofs[2 * dt]));
             vh.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + 2048 + vofs[2 * dt]));
             vl.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + vofs[2 * dt + 1]));
             vl.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + 2048 + vofs[2 * dt + 1]));
           }
-          if constexpr (TT_AP_DBG & 4) { o1[s] += (float)vh.v[0] * (float)ph[kt][s][0]; o2[s] += (float)vl.v[0] * (float)pl[kt][s][0]; }
+          if constexpr (TT_AP_DBG & 4) { o1[dt][s] += (float)vh.v[0] * (float)ph[s][0]; o2[dt][s] += (float)vl.v[0] * (float)pl[s][0]; }
           else {
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[kt][s], o1, 0, 0, 0);
-            o2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[kt][s], o2, 0, 0, 0);
-            o2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[kt][s], o2, 0, 0, 0);
+            o1[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[s], o1[dt], 0, 0, 0);
+            o2[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[s], o2[dt], 0, 0, 0);
+            o2[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[s], o2[dt], 0, 0, 0);
           }
         }
       }
+    }
+    AP_STAMP(5);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    if (lse && h == 0 && query < N) lse[((long long)f * H + hd) * N + query] = (mc + __log2f(sum)) * 0.69314718055994530942f;   // natural-log units
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
       // The output tile leaves through the wave's private LDS scratch so that a store instruction writes eight whole 128-byte rows (16 B
       // per lane): this 32-dim group as pairs [hi x 32][lo x 32] and / or as 32 floats.  Chunk c of row q sits at c ^ (q & 7).
       float o[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) o[e] = fmaf(o2[e], kPairInvScale, o1[e]) * inv;   // d = (e & 3) + 8 (e >> 2) + 4 h of this group
+      for (int e = 0; e < 16; ++e) o[e] = fmaf(o2[dt][e], kPairInvScale, o1[dt][e]) * inv;   // d = (e & 3) + 8 (e >> 2) + 4 h of this group
       if (out_pairs) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -236,6 +299,14 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
         }
       }
     }
+    }
+#ifdef TT_AP_STAMP
+    AP_STAMP(6);
+    if (qt >= nqt) { stamp[4] = stamp[3]; stamp[5] = stamp[3]; }
+    if (lane == 0 && stamp_it < 4)
+      for (int i = 0; i < 7; ++i) stamp_out[((long long)(blockIdx.x * 8 + wave) * 4 + stamp_it) * 8 + i] = stamp[i];
+    ++stamp_it;
+#endif
   }
 }
 
@@ -486,10 +557,11 @@ extern "C" int tt_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, fl
   const _Float16* q = static_cast<const _Float16*>(qkv_pairs);
   _Float16* o = static_cast<_Float16*>(out_pairs);
   const bool resident = tuning_knob(KNOB_ATTN_PAIRS_FLASH) == 0;   // (knob 1: the KV-tiled kernel at every N - tests and A/B)
+  const int grid = tuning_knob(KNOB_ATTN_PAIRS_PERSIST) ? (F * H < device_cu_count() ? F * H : device_cu_count()) : F * H;
   if (N <= 224 && resident) {
-    hipLaunchKernelGGL((attention_fwd_pairs_kernel<7>), dim3(F * H), dim3(512), 0, s, q, o, out_f32, lse, N, H, scale);
+    hipLaunchKernelGGL((attention_fwd_pairs_kernel<7>), dim3(grid), dim3(512), 0, s, q, o, out_f32, lse, N, H, scale, F * H);
   } else if (N <= 256 && resident) {
-    hipLaunchKernelGGL((attention_fwd_pairs_kernel<8>), dim3(F * H), dim3(512), 0, s, q, o, out_f32, lse, N, H, scale);
+    hipLaunchKernelGGL((attention_fwd_pairs_kernel<8>), dim3(grid), dim3(512), 0, s, q, o, out_f32, lse, N, H, scale, F * H);
   } else {
     const int nqt = (N + 31) / 32, nb = (nqt + 7) / 8;
     TT_REQUIRE((long long)F * H * nb < 0x7fffffffLL, "attention_fwd_pairs: grid too large");

@@ -5,7 +5,18 @@ vp, i32 = C.c_void_p, C.c_int
 def load(p):
     lib = C.CDLL(os.path.abspath(p)); lib.tt_attention_fwd_pairs.restype = C.c_int
     lib.tt_attention_fwd_pairs.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp]; return lib
-libs = [(os.path.basename(p), load(p)) for p in sys.argv[1:]]
+def parse(arg):   # `label=path.so:KNOB=v,...`: the knobs are set before each launch of that entry (the same path may appear twice)
+    label, rest = arg.split("=", 1) if ("=" in arg.split(":")[0]) else (None, arg)
+    path, _, kn = rest.partition(":")
+    knobs = [(k.split("=")[0].encode(), int(k.split("=")[1])) for k in kn.split(",") if k]
+    lib = load(path)
+    lib.tt_set_tuning_knob.restype = C.c_int; lib.tt_set_tuning_knob.argtypes = [C.c_char_p, C.c_int]
+    class L:
+        def tt_attention_fwd_pairs(self, *a):
+            for k, v in knobs: assert lib.tt_set_tuning_knob(k, v) == 0, k
+            return lib.tt_attention_fwd_pairs(*a)
+    return (label or os.path.basename(path)), (L() if knobs else lib)
+libs = [parse(p) for p in sys.argv[1:]]
 st = torch.cuda.current_stream().cuda_stream
 for F, N, H, allout in [(128, 197, 6, 0), (128, 197, 6, 1), (128, 197, 12, 0), (32, 197, 6, 1), (64, 256, 6, 0), (3, 50, 2, 1),
                         (64, 785, 6, 0), (16, 785, 6, 1), (128, 785, 6, 0), (5, 300, 3, 1), (64, 785, 12, 0)]:   # (> 256 tokens: the KV-tiled kernel)
