@@ -90,6 +90,26 @@ __device__ __forceinline__ float erf_fast_f(float x, float* exp_neg_half_x2_out 
   return copysignf(1.0f - poly * e, x);
 }
 __device__ __forceinline__ float gelu_fast_f(float x) { return 0.5f * x * (1.0f + erf_fast_f(x)); }
+// Two at a time, for the VALU-bound GELU epilogue of the pair GEMMs (gemm_pairs8.hip; ~100 issue cycles per element as the scalar form
+// compiles): the same erf, written so that everything but the two transcendentals and the two |x| products is a packed fp32 instruction -
+// gelu(x) = x / 2 + |x| erf(|x| / sqrt 2) / 2 with erf = 1 - poly(t) exp(-x^2 / 2): no copysign, no 1 + erf.
+typedef float tt_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ tt_f32x2 gelu_fast_f2(tt_f32x2 x) {
+  tt_f32x2 t, e, m;
+  t[0] = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x[0]), 1.0f));
+  t[1] = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x[1]), 1.0f));
+  const tt_f32x2 x2 = x * x * -0.72134752044448170368f;   // -x^2 / 2 in log2 units
+  e[0] = __builtin_amdgcn_exp2f(x2[0]);
+  e[1] = __builtin_amdgcn_exp2f(x2[1]);
+  tt_f32x2 poly = t * 1.061405429f + -1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t + -0.284496736f;
+  poly = poly * t + 0.254829592f;
+  const tt_f32x2 erf_abs = 1.0f - poly * t * e;
+  m[0] = fabsf(x[0]) * erf_abs[0];
+  m[1] = fabsf(x[1]) * erf_abs[1];
+  return m * 0.5f + x * 0.5f;
+}
 // gelu'(x) = Phi(x) + x phi(x) with the same erf and its exp(-x^2 / 2) reused for phi
 __device__ __forceinline__ float gelu_grad_fast_f(float x) {
   float g;

@@ -581,7 +581,16 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
               }
               if constexpr (ACT) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
+                for (int e = 0; e < 8; e += 2) {
+#ifdef TT_Q8_GELU_SCALAR   // (A/B: the round-4 form)
+                  v[e] = gelu_fast_f(v[e]);
+                  v[e + 1] = gelu_fast_f(v[e + 1]);
+#else
+                  const tt_f32x2 gq = gelu_fast_f2(tt_f32x2{v[e], v[e + 1]});
+                  v[e] = gq[0];
+                  v[e + 1] = gq[1];
+#endif
+                }
               }
               f16x8 qh, ql;
 #pragma unroll
@@ -1134,7 +1143,16 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
               }
               if constexpr (ACT) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
+                for (int e = 0; e < 8; e += 2) {
+#ifdef TT_Q8_GELU_SCALAR   // (A/B: the round-4 form)
+                  v[e] = gelu_fast_f(v[e]);
+                  v[e + 1] = gelu_fast_f(v[e + 1]);
+#else
+                  const tt_f32x2 gq = gelu_fast_f2(tt_f32x2{v[e], v[e + 1]});
+                  v[e] = gq[0];
+                  v[e + 1] = gq[1];
+#endif
+                }
               }
               f16x8 qh, ql;
 #pragma unroll
