@@ -50,13 +50,25 @@ ALT_NOTES = {
 }
 
 
+def kernel_source_sha16(files):
+    """sha256 (first 16 hex digits) over the named source files under the repo root, in order; None when one is missing."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        path = os.path.join(REPO, f)
+        if not os.path.isfile(path):
+            return None
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16] if files else None
+
+
 def kernel_label(name, tile):
     if name == "NT":
         return f"gemm_nt_fast_kernel<{TILE_NAMES[tile]}> (forward nn.Linear, whole tiles)"
     if name == "NTbf16":
         return f"gemm_nt_bf16_kernel<{TILE_NAMES[tile]}> (forward nn.Linear, fp32 operands converted while staged)"
     if name == "PAIRS8":
-        return "gemm_pairs8_kernel (nn.Linear on fp16-pair operands, persistent kernel, 3 MFMAs per term)"
+        return "gemm_pairs8s_kernel (nn.Linear on fp16-pair operands, persistent kernel, 3 MFMAs per term)"
     if name == "PAIRS_TN":
         return "gemm_pairs_tn_kernel (weight gradient from row pairs, transposing LDS reads) + fold"
     if name == "PAIRS":
@@ -238,7 +250,9 @@ def roofline_block(prof, step_seconds, precision):
     tpath = os.path.join(REPO, "profiles", "dominant_kernel_traffic.json")
     if os.path.isfile(tpath):
         tj = json.load(open(tpath))
-        if tj.get("kernel_label", "gemm_nt_fast_kernel<64x128>") in dom_label:
+        # ... and only while the kernel's source is the one that pass ran (the snapshot on the GPU box has no .git: the tie is a hash of
+        # the source files, written by tools/pmc_traffic.py next to the commit it was taken at)
+        if tj.get("kernel_label", "gemm_nt_fast_kernel<64x128>") in dom_label and tj.get("kernel_source_sha16") == kernel_source_sha16(tj.get("kernel_sources", [])):
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_git_head = tj.get("git_head")
     return {"bound": "mfma", "precision": DTYPE_NAMES.get(precision, precision),

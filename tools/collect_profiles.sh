@@ -1,9 +1,9 @@
 #!/bin/bash
 # Copies the judged summaries of a tools/final_run.sh run (gpurun_out/final_<tag>/) into profiles/ under per-round names.
-#   usage: bash tools/collect_profiles.sh <tag> [round-prefix, default r04]
+#   usage: bash tools/collect_profiles.sh <tag> [round-prefix, default r05]
 set -euo pipefail
 cd "$(dirname "$0")/.."
-T=$1; R=${2:-r04}; O=gpurun_out/final_$T
+T=$1; R=${2:-r05}; O=gpurun_out/final_$T
 for f in c2 c1 c3 c4 c4_bf16 c5; do cp "$O/$f.json" "profiles/${R}_bench_${f}_line.json"; done
 sum() { python3 tools/summarize_prof.py "$1" "$2" 45 | sed "1s|\$|   ($3)|"; }
 sum "$O/prof_c2/c2_kernel_stats.csv" 26 "steps incl. warm-up and the profiled-GEMM pass; default precision f32-split(f16x3)" > "profiles/${R}_bench_c2_kernel_stats.txt"

@@ -1,10 +1,10 @@
 #!/bin/bash
 # The round's evidence in ONE gpurun call: GPU tests, the bench lines of C1..C5, rocprofv3 kernel tables and the PMC passes.
-#   usage (from the repo root on the GPU box):  bash tools/final_run.sh [tag]      (tag names the outputs, default r04)
+#   usage (from the repo root on the GPU box):  bash tools/final_run.sh [tag]      (tag names the outputs, default r05)
 # Every profiled program follows `--` directly as python3 (no env / bash hop: the profiler initialises the GPU before the program starts).
 set -uo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-T=${1:-r04}
+T=${1:-r05}
 O=$R/gpurun_out/final_$T
 mkdir -p "$O"
 cd "$R"

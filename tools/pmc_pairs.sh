@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes over the kernels of the "f16x3" mode (one counter group per rocprofv3 run, no trace domains): the persistent pair GEMM on the
 # four ViT-S/16 block shapes and the pair attention kernel.  usage (GPU box, repo root): bash tools/pmc_pairs.sh ; then
-# python3 tools/pmc_pairs_summary.py gpurun_out/pmc_pairs profiles/r04_gemm_pairs_pmc.json profiles/r04_attention_pmc.json
+# python3 tools/pmc_pairs_summary.py gpurun_out/pmc_pairs profiles/r05_gemm_pairs_pmc.json profiles/r05_attention_pmc.json
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_pairs
 mkdir -p $OUT

@@ -50,10 +50,10 @@ def case(name, match):
 
 note = ("rocprofv3 --pmc passes (tools/pmc_pairs.sh: one counter group per run, no trace domains) over tools/pairs_one.py; averages per launch of the "
         "SHIPPED kernel on random operands.  Profiled passes clock lower than un-profiled ones (MI355X_MICROARCH.md 'DVFS give-back' item 2): fractions, not times.")
-g = {"note": note + "  gemm_pairs8_kernel on the four ViT-S/16 block shapes (25216 rows): qkv 1152 x 384 pairs out, proj 384 x 384 fp32 + residual, "
+g = {"note": note + "  gemm_pairs8s_kernel on the four ViT-S/16 block shapes (25216 rows): qkv 1152 x 384 pairs out, proj 384 x 384 fp32 + residual, "
              "fc1 1536 x 384 GELU -> pairs, fc2 384 x 1536 fp32 + residual."}
 for name in ("qkv", "proj", "fc1", "fc2"):
-    g[name] = case(name, "gemm_pairs8_kernel")
+    g[name] = case(name, "gemm_pairs8")
 json.dump(g, open(gemm_out, "w"), indent=1)
 a = {"note": note + "  attention_fwd_pairs_kernel, 128 frames x 197 tokens x 6 heads (one ViT-S/16 layer of the C2 step), pairs in / pairs out.",
      "attn_pairs": case("attn", "attention_fwd_pairs_kernel")}

@@ -26,18 +26,25 @@ for tot, k, n, fb, wb in rows[:14]:
 if len(sys.argv) > 3:
     # the dominant kernel of the step (bench.py's roofline kernel, keyed by label): round 4 - gemm_pairs8_kernel (all epilogue instantiations
     # together, as the bench line books them); earlier rounds - the gemm_nt_fast instantiation with the most launches
-    pairs = [r for r in rows if "gemm_pairs8_kernel" in r[1]]
+    pairs = [r for r in rows if "gemm_pairs8" in r[1]]   # gemm_pairs8s_kernel (round 5) / gemm_pairs8_kernel
     head = sys.argv[4] if len(sys.argv) > 4 else "unknown"
     if pairs:
         n = sum(r[2] for r in pairs)
         fb = sum(r[3] * r[2] for r in pairs) / n
         wb = sum(r[4] * r[2] for r in pairs) / n
-        k, label = "gemm_pairs8_kernel<*> (every epilogue instantiation, launch-weighted)", "gemm_pairs8_kernel"
+        k, label = "gemm_pairs8s_kernel<*> (every epilogue instantiation, launch-weighted)", "gemm_pairs8s_kernel"
+        sources = ["timetuning_amd/csrc/gemm_pairs8.hip", "timetuning_amd/csrc/common.hpp"]
     else:
         dom = sorted([r for r in rows if "gemm_nt_fast_kernel" in r[1]], key=lambda r: -r[2]) or rows[:1]
         tot, k, n, fb, wb = dom[0]
         names = {"<2, 2": "128x128", "<1, 2": "64x128", "<2, 1": "128x64", "<1, 1": "64x64"}   # <WM, WN[, BK]>
         label = next((f"gemm_nt_fast_kernel<{v}>" for t, v in names.items() if ("gemm_nt_fast_kernel" + t) in k), k)
-    json.dump({"kernel": k, "kernel_label": label, "git_head": head, "launches_profiled": n, "hbm_read_bytes_per_launch": round(fb), "hbm_write_bytes_per_launch": round(wb),
+        sources = ["timetuning_amd/csrc/gemm_nt_fast.hip", "timetuning_amd/csrc/common.hpp"]
+    import hashlib, os
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    hs = hashlib.sha256()
+    for sf in sources:
+        hs.update(open(os.path.join(root, sf), "rb").read())
+    json.dump({"kernel": k, "kernel_label": label, "git_head": head, "kernel_sources": sources, "kernel_source_sha16": hs.hexdigest()[:16], "launches_profiled": n, "hbm_read_bytes_per_launch": round(fb), "hbm_write_bytes_per_launch": round(wb),
                "hbm_bytes_per_launch": round(fb + wb), "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 per the gfx950 correction; average over the launches of one bench.py run (mixed shapes of this kernel)"},
               open(sys.argv[3], "w"), indent=1)
