@@ -247,8 +247,8 @@ int tt_attention_fwd_bf16(const void* qkv, void* out, int F, int N, int H, int h
  *   tt_layernorm_fwd_pairs  tt_layernorm_fwd with the result in pairs [rows][2 D] (D % 32 == 0; optional mean / rstd as there).
  *   tt_linear_fwd_pairs     y = act(x @ w^T + bias) (+ residual): x [M,K], w [N,K] in pairs.  Outputs, any of: y fp32 [M,N], pre_out
  *                           fp32 (pre-activation), y_pairs [M][2 N].  residual fp32 may alias y.  N % 64 == 0, K % 32 == 0; any M.
- *   tt_linear_fwd_pairs_route  which kernel such a call runs: 8 = the persistent gemm_pairs8_kernel (N % 128 == 0, K % 96 == 0,
- *                           M >= 256, a grid of at least half the CUs; every epilogue incl. pre_out + GELU pairs), 0 = the general
+ *   tt_linear_fwd_pairs_route  which kernel such a call runs: 8 = the persistent gemm_pairs8s_kernel (N % 128 == 0, K % 32 == 0,
+ *                           M >= 256, at least 96 tiles of 256 x 128; every epilogue incl. pre_out + GELU pairs), 0 = the general
  *                           kernel.  Profilers' labels only. */
 int tt_split_pairs(const float* src, void* dst_pairs, long long n, int* range_flag, tt_stream_t stream);
 int tt_join_pairs(const void* src_pairs, float* dst, long long n, tt_stream_t stream);
