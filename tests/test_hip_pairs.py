@@ -113,6 +113,9 @@ def test_linear_pairs_epilogues(M, N, K):
 
 
 @pytest.mark.parametrize("Fr,N,H,flash", [(3, 197, 6, 0), (2, 50, 2, 0), (1, 256, 12, 0), (2, 225, 3, 0), (5, 17, 1, 0),
+                                          # the persistent loop of the resident kernel (round 5): more (frame, head) items than CUs, unevenly
+                                          # (300 and 258 items on 256 workgroups: one or two items each; 768: three each)
+                                          (50, 197, 6, 0), (43, 256, 6, 0), (128, 197, 6, 0),
                                           # the KV-tiled kernel: beyond 256 tokens (785 = C5's 448 x 448 frames: 7 + 6 + 6 + 6 query tiles; ragged
                                           # last stages; one stage + one key), and forced at the sizes of the resident kernel
                                           (2, 785, 6, 0), (2, 300, 2, 0), (1, 257, 1, 0), (1, 1030, 2, 0), (1, 513, 3, 0),
@@ -143,6 +146,12 @@ def _attention_pairs_case(ops, Fr, N, H):
     assert rel_l2(of.cpu(), ref) <= rel_l2(o32.cpu(), ref)          # not worse than the f32-MFMA attention kernel
     only_pairs = ops.attention_fwd_pairs(qkvp, H)[0]
     assert torch.equal(only_pairs, op)
+    if N <= 256:   # one workgroup per item (the round-4 launch shape of the same kernel): the same bits
+        ops.set_tuning_knob("TT_ATTN_PAIRS_PERSIST", 0)
+        try:
+            assert torch.equal(ops.attention_fwd_pairs(qkvp, H)[0], op)
+        finally:
+            ops.set_tuning_knob("TT_ATTN_PAIRS_PERSIST", 1)
 
 
 @pytest.mark.parametrize("tn", [True, False])

@@ -111,7 +111,6 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
     const int lane = lane_o;
     const int r = lane & 31, h = lane >> 5;
     const int f = fh / H, hd = fh - f * H;
-    const _Float16* base = qkv + (long long)f * N * RS + hd * 128;   // q of this head; k: + 2 Dm, v: + 4 Dm
     AP_STAMP(0);
     // K (item) has landed (issued one product ago) and every wave is past the V reads of the previous item
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

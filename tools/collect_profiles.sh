@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies the judged summaries of a tools/final_run.sh run (gpurun_out/final_<tag>/) into profiles/ under per-round names.
-#   usage: bash tools/collect_profiles.sh <tag> [round-prefix, default r05]
+#   usage: bash tools/collect_profiles.sh <tag> [round-prefix, default r05] [git head the run was launched at]
 set -euo pipefail
 cd "$(dirname "$0")/.."
 T=$1; R=${2:-r05}; O=gpurun_out/final_$T
@@ -14,7 +14,7 @@ sum "$O/prof_c5/c5_kernel_stats.csv" 9 "steps incl. warm-up and the profiled-GEM
 sum "$O/prof_c4bf16/c4bf16_kernel_stats.csv" 14 "steps incl. warm-up and the profiled-GEMM pass; --precision bf16" > "profiles/${R}_bench_c4_bf16_kernel_stats.txt"
 sum "$O/prof_c1/c1_kernel_stats.csv" 61 "steps incl. warm-up and the profiled-GEMM pass" > "profiles/${R}_bench_c1_kernel_stats.txt"
 F=$(find "$O/pmc_fetch" -name "*counter_collection.csv" | head -1); W=$(find "$O/pmc_write" -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_traffic.py "$F" "$W" profiles/dominant_kernel_traffic.json "$(git rev-parse --short HEAD)" | head -12
+python3 tools/pmc_traffic.py "$F" "$W" profiles/dominant_kernel_traffic.json "${3:-$(git rev-parse --short HEAD)}" | head -12   # 3rd argument: the commit the run was LAUNCHED at, when HEAD has moved since
 python3 tools/pmc_pairs_summary.py gpurun_out/pmc_pairs "profiles/${R}_gemm_pairs_pmc.json" "profiles/${R}_attention_pmc.json"
 cp "$O/tests.log" "profiles/${R}_gpu_tests.log"
 ls profiles | grep -c "$R"
