@@ -948,8 +948,20 @@ static int linear_pairs_impl(const void* x_pairs, const void* w_pairs, const flo
   const long long t128 = (long long)((M + 127) / 128) * (N / 128);
   const bool big = (N % 128 == 0) && t128 * splits >= 3 * 256;
   const bool wide = (N % 128 == 0) && (long long)((M + 63) / 64) * (N / 128) * splits >= 2 * 256;
-  if (big) return launch_planes<1, 64, 2, 2, 2, 2, 2, 0, true>(g, s);
-  if (wide) return launch_planes<1, 64, 1, 2, 2, 2, 2, 0, true>(g, s);
+  // Ring depth (round 5; knob TT_PAIRS_NBUF: 0 = this rule, 2 .. 6 = forced).  These are the launches that do not fill the chip, and in a
+  // step their operands are cold (HBM / MALL, not L2): a workgroup's K loop is a chain of LDS-DMA latencies - one per 32-deep K-tile with a
+  // double buffer, a half / a third of one with two / three K-tiles in flight.  Three slabs everywhere (C2 -0.8 %); four on the 64 x 64
+  // tile while the grid is under two workgroups per CU, where the 64 KB cost no residency (C1 2.39 -> 2.09 ms; at 594 tiles - the
+  // 6304-row launches of C2 - four measured slower than two).  With hot operands (tools/ab_pairs.py) the depth changes nothing.
+  const int knob = tuning_knob(KNOB_PAIRS_NBUF);
+  const long long t64 = (long long)((M + 63) / 64) * (N / 64) * splits;
+  const int nbuf = knob ? knob : (!big && !wide && t64 <= 2LL * device_cu_count() ? 4 : 3);
+  if (big) return nbuf >= 3 ? launch_planes<1, 64, 2, 2, 3, 2, 2, 0, true>(g, s) : launch_planes<1, 64, 2, 2, 2, 2, 2, 0, true>(g, s);
+  if (wide) return nbuf >= 3 ? launch_planes<1, 64, 1, 2, 3, 2, 2, 0, true>(g, s) : launch_planes<1, 64, 1, 2, 2, 2, 2, 0, true>(g, s);
+  if (nbuf >= 6) return launch_planes<1, 64, 1, 1, 6, 2, 2, 0, true>(g, s);
+  if (nbuf == 5) return launch_planes<1, 64, 1, 1, 5, 2, 2, 0, true>(g, s);
+  if (nbuf == 4) return launch_planes<1, 64, 1, 1, 4, 2, 2, 0, true>(g, s);
+  if (nbuf == 3) return launch_planes<1, 64, 1, 1, 3, 2, 2, 0, true>(g, s);
   return launch_planes<1, 64, 1, 1, 2, 2, 2, 0, true>(g, s);
 }
 

@@ -48,7 +48,9 @@ cases = [(25216, 1152, 384, 0, 0, 0, "qkv"), (25216, 384, 384, 0, 0, 1, "proj"),
          (6272, 1024, 384, 1, 1, 0, "head 1"), (6272, 1024, 1024, 1, 1, 0, "head 2"), (6272, 512, 1024, 1, 1, 0, "head 3"), (6272, 256, 512, 0, 0, 0, "head 4"),
          # kept-frame launches of the trainable blocks (6304 rows: 75 tiles at N = 384)
          (6304, 384, 384, 0, 0, 1, "kept proj"), (6304, 384, 1536, 0, 0, 1, "kept fc2"), (6304, 1152, 384, 0, 1, 0, "kept qkv"),
-         (18912, 384, 384, 0, 0, 1, "rest proj"), (18912, 1536, 384, 1, 1, 0, "rest fc1")]
+         (18912, 384, 384, 0, 0, 1, "rest proj"), (18912, 1536, 384, 1, 1, 0, "rest fc1"),
+         # C1 (2 clips x 2 frames = 788 rows): launch-latency regime of the general kernel
+         (788, 1152, 384, 0, 1, 0, "C1 qkv"), (788, 384, 384, 0, 0, 1, "C1 proj"), (788, 1536, 384, 1, 1, 0, "C1 fc1"), (788, 384, 1536, 0, 0, 1, "C1 fc2")]
 tot = {n: 0.0 for n, _ in libs}
 for M, N, K, act, po, res, name in cases:
     x = split(torch.randn(M, K, device="cuda")); w = split(torch.randn(N, K, device="cuda") * 0.05)
