@@ -142,11 +142,12 @@ def pairs() -> bool:
 
 # The "f16x3" mode is a DISPATCH decision between two fp32-class arithmetics: below this many token rows per launch the pair kernels'
 # extra passes (operand splits, the gradient's max pass) cost more than three-MFMA products save, so small launches keep the exact-f32
-# kernels.  Measured on BASELINE C1 (4 frames: 788-row block launches, 394 / 392-row kept-frame and head launches), one box, ms per
-# step by threshold: 1536 -> 3.10 (everything on f32), 700 -> 2.68, 512 -> 2.79 (the 788-row launches on pairs), 393 -> 3.47,
-# 300 -> 2.89, 200 -> 3.23 (the 39x-row ones too); an 8-clip step: 4.21 -> 3.60.  (It was 1536 until the transposes left the backward:
-# round 4.)  Tests set it to 0 to drive the pair kernels with tiny models.
-PAIRS_MIN_ROWS = 640
+# kernels.  Measured on BASELINE C1 (4 frames: 788-row block launches, 394 / 392-row kept-frame and head launches), ms per step by
+# threshold.  Round 4 (launch by launch): 1536 -> 3.10 (everything on f32), 700 -> 2.68, 512 -> 2.79, 393 -> 3.47, 300 -> 2.89, 200 -> 3.23:
+# 640.  Round 5 (the step replayed as a HIP graph - launch counts no longer cost host time - and the general pair kernel on a ring of
+# three / four K-tiles): 640 -> 2.07-2.11, 400 -> 2.08, 393 -> 2.18 (the kept frames' 394 rows on pairs, the head's 392 not: conversions),
+# 300 -> 1.98-2.02, 200 -> 1.97-2.02, 0 -> 1.99-2.07: 256.  Tests set it to 0 to drive the pair kernels with tiny models.
+PAIRS_MIN_ROWS = int(os.environ.get("TT_PAIRS_MIN_ROWS", "256"))   # (the environment variable: sweeps only)
 GRAD_SCALE = os.environ.get("TT_NO_GRAD_SCALE") != "1"   # gradients are scaled by a power of two before their pair split (A/B aid: off)
 TN_WGRAD = True   # weight gradients of the "f16x3" mode from row pairs (gemm_pairs_tn.hip); False: the transposed-operand route (A/B, tests)
 
