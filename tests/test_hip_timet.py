@@ -357,6 +357,40 @@ def test_step_graph_replays_the_eager_step(accurate_precision, teacher_queue):
         assert len(mg._step_graphs) == 2   # filling, then full
 
 
+def test_step_graph_sees_rewritten_frozen_weights(accurate_precision):
+    """A captured step refreshes the pair operands of the tensors that were stale at capture time - the trainable ones.  A FROZEN weight
+    rewritten in place afterwards (``load_state_dict``, a hand edit) must not be served from the graph's stale operands: the frozen
+    tensors' version counters are part of the graph's signature, the step falls back to the eager path (which refreshes) and captures anew."""
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.my_utils import cosine_scheduler
+    from timetuning_amd.time_tuning import SwavOptimizer, TimeT
+
+    bs, fs, K = 2, 2, 50
+    clips = [torch.from_numpy(synth.make_clips(bs, fs, 224, seed=60 + i)).cuda() for i in range(6)]
+    runs = []
+    for graph in (False, True):
+        fe = FeatureExtractor("dino-s16", "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="stress", return_attention=False)
+        m = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, 256))).cuda()
+        o = SwavOptimizer(m, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, 1, 8), 8, 1)
+        if graph:
+            m.enable_step_graph()
+        losses = []
+        for i, x in enumerate(clips):
+            if i == 3:   # steps 0 - 2: eager, captured, replayed; now a frozen block's weight changes under the graph
+                with torch.no_grad():
+                    m.feature_extractor.backbone.blocks[3].mlp.fc1.weight.mul_(1.25)
+            loss = m.get_loss(x)
+            m.train_update(o, loss, min(i + 1, 7))
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        runs.append((m, losses))
+    (me, le), (mg, lg) = runs
+    assert le == lg, (le, lg)
+    pe, pg = dict(me.named_parameters()), dict(mg.named_parameters())
+    assert all(torch.equal(pe[n], pg[n]) for n in pe)
+    assert len(mg._step_graphs) == 2   # before and after the rewrite
+
+
 def test_c2_size_properties():
     """BASELINE C2 (bs 32 x 4 frames, K=200): too big for golden tensors; checked through invariants and against
     the CPU oracle on a sub-batch (per-clip computations are independent except for the Sinkhorn coupling)."""

@@ -392,7 +392,10 @@ class TimeT(nn.Module):
                                             self._queue_rows_pushed + min(bs * 10, self.queue.shape[0]) >= self.queue.shape[0])
         key = (tuple(x.shape), str(x.device), ops.get_gemm_precision(), ops.PAIRS_MIN_ROWS, hp["n_last_frames"], hp["radius"], hp["topk"],
                float(hp["epsilon"]), hp["iters"], hp["mask_features"], self.teacher is not None, None if self.queue is None else self.queue.shape[0],
-               full, tuple(id(p) for p in params), self.teacher_shares_frozen_blocks() if self.teacher is not None else None)
+               full, tuple(id(p) for p in params), self.teacher_shares_frozen_blocks() if self.teacher is not None else None,
+               # the frozen tensors' contents: their pair operands are refreshed by the EAGER path only (the captured step refreshes what
+               # was stale when it was captured - the trainable ones); an in-place rewrite (load_state_dict) bumps torch's version counter
+               sum(p_._version for p_ in self.parameters() if not p_.requires_grad))
         rec = self._step_graphs.get(key)
         if rec is None:
             if key not in self._step_graph_seen:   # the first step of a shape: eager (it creates what a capture may not create)
