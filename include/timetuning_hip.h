@@ -292,6 +292,11 @@ int tt_attention_fwd_pairs(const void* qkv_pairs, void* out_pairs, float* out_f3
 size_t tt_split_pairs_dual_workspace_bytes(int R, int C, int Rpad);
 int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, float* scale_out, int R, int C, int Rpad,
                         void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream);
+/* tt_split_pairs_dual that LEAVES the column partial sums - colsum_parts [ceil(Rpad / 64)][C] fp32, caller-owned - unfolded, for
+ * tt_linear_bwd_weight_pairs_tn_bias to fold in the launch that folds the weight gradient's split partials (one launch less per dy;
+ * the bias gradient has the same bits either way).  workspace: as tt_split_pairs_dual (needed for a scale only). */
+int tt_split_pairs_dual_parts(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum_parts, float* scale_out, int R, int C, int Rpad,
+                              void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream);
 int tt_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int R, int C, int Rpad, tt_stream_t stream);
 /* tt_split_pairs_dual (without column sums) for n matrices in ONE launch per 32 of them: host arrays of n pointers / sizes; dst_t_pairs[i] or
  * dst_row_pairs[i] may be null.  What a training step needs of every weight the optimizer rewrote (row pairs: forward and weight-gradient
@@ -307,6 +312,10 @@ int tt_linear_bwd_weight_pairs_tn_ok(int N, int K, int M);
 size_t tt_linear_bwd_weight_pairs_tn_workspace_bytes(int N, int K, int M);
 int tt_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, float* dw, const float* dy_scale, int N, int K, int M, void* workspace,
                                   size_t workspace_bytes, tt_stream_t stream);
+/* ... and the bias gradient db [N] = the column sums of dy from their partials (colsum_parts [colsum_count][N] of
+ * tt_split_pairs_dual_parts) in the same fold launch. */
+int tt_linear_bwd_weight_pairs_tn_bias(const void* dy_pairs, const void* x_pairs, float* dw, const float* dy_scale, int N, int K, int M, void* workspace,
+                                       size_t workspace_bytes, const float* colsum_parts, int colsum_count, float* db, tt_stream_t stream);
 /*   prepare_tokens (dino_vision_transformer.py:166-171,236-247) on pair operands: tt_patch_embed_fwd with the conv weight in pairs
  *   [D][2 C P P] (tt_split_pairs of patch_w viewed [D, C P P]); the patches are split into pairs on their way into an im2col buffer
  *   (workspace: the rows, then the GEMM's K-split block, whose counters the call zeroes itself), ONE pair GEMM over all F (n + 1) rows

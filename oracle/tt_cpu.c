@@ -1062,6 +1062,20 @@ int tt_cpu_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_p
   }
   return 0;
 }
+/* the column sums left as partials of 64-row blocks [ceil(Rpad / 64)][C] (tt_split_pairs_dual_parts) */
+int tt_cpu_split_pairs_dual_parts(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum_parts, float* scale_out, int R, int C,
+                                  int Rpad, void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream) {
+  const int rc = tt_cpu_split_pairs_dual(src, dst_t_pairs, dst_row_pairs, NULL, scale_out, R, C, Rpad, workspace, workspace_bytes, range_flag, stream);
+  if (rc) return rc;
+  const int chunks = (Rpad + 63) / 64;
+  for (int b = 0; b < chunks; ++b)
+    for (int c = 0; c < C; ++c) {
+      double s = 0.0;
+      for (int r = b * 64; r < (b + 1) * 64 && r < R; ++r) s += src[(size_t)r * C + c];
+      colsum_parts[(size_t)b * C + c] = (float)s;
+    }
+  return 0;
+}
 int tt_cpu_split_pairs_dual_multi(const float* const* src, void* const* dst_t_pairs, void* const* dst_row_pairs, const int* R, const int* C,
                                   const int* Rpad, int n, int* range_flag, tt_stream_t stream) {
   for (int i = 0; i < n; ++i) {
@@ -1123,6 +1137,17 @@ int tt_cpu_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs,
       dw[(size_t)n * K + k] = (float)(s * inv_s);
     }
   return 0;
+}
+
+int tt_cpu_linear_bwd_weight_pairs_tn_bias(const void* dy_pairs, const void* x_pairs, float* dw, const float* dy_scale, int N, int K, int M,
+                                           void* workspace, size_t workspace_bytes, const float* colsum_parts, int colsum_count, float* db,
+                                           tt_stream_t stream) {
+  for (int n = 0; n < N; ++n) {
+    double s = 0.0;
+    for (int b = 0; b < colsum_count; ++b) s += colsum_parts[(size_t)b * N + n];
+    db[n] = (float)s;
+  }
+  return tt_cpu_linear_bwd_weight_pairs_tn(dy_pairs, x_pairs, dw, dy_scale, N, K, M, workspace, workspace_bytes, stream);
 }
 
 /* prepare_tokens on pair operands (tt_patch_embed_fwd_pairs): patches and weight as (hi, lo) pairs, three products per term */

@@ -758,6 +758,13 @@ def test_round4_pair_twins_against_numpy(twin):
     assert twin.tt_cpu_split_pairs_dual(ptr(tiny), None, ptr(tu), None, None, M, N, 64, None, 0, None, None) == 0
     assert twin.tt_cpu_linear_bwd_weight_pairs_tn(ptr(tu), ptr(xp), ptr(dwu), None, N, K, M, None, 0, None) == 0
     assert rel(dwu, ref_dw) > 20 * rel(dws, ref_dw)                        # (what the scale is for)
+    # the column sums left as partials of 64-row blocks, folded by the weight gradient's call (round 5: one fold launch per Linear)
+    parts, tr3, S3 = np.full((1, N), np.nan, np.float32), np.empty((M, 2 * N), np.uint16), np.zeros(1, np.float32)
+    assert twin.tt_cpu_split_pairs_dual_parts(ptr(tiny), None, ptr(tr3), ptr(parts), ptr(S3), M, N, 64, None, 0, None, None) == 0
+    assert np.array_equal(tr3, tr) and S3[0] == S[0] and np.allclose(parts[0], tiny.sum(0), rtol=1e-5, atol=0)
+    dw3, db3 = np.empty((N, K), np.float32), np.empty((N,), np.float32)
+    assert twin.tt_cpu_linear_bwd_weight_pairs_tn_bias(ptr(tr3), ptr(xp), ptr(dw3), ptr(S3), N, K, M, None, 0, ptr(parts), 1, ptr(db3), None) == 0
+    assert np.array_equal(dw3, dws) and np.allclose(db3, cs2, rtol=1e-6, atol=0)
     # attention on pairs against torch in fp64
     Fr, Nn, H = 2, 19, 2
     D = 64 * H

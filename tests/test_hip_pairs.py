@@ -205,6 +205,24 @@ def test_transposed_pairs():
     assert t2.shape == (96, 512) and torch.equal(t2[:, :448].cpu().view(96, 7, 64), t.cpu().view(96, 7, 64)) and not t2[:, 448:].any()
 
 
+@pytest.mark.parametrize("M,N,K", [(6304, 1536, 384), (6299, 384, 1152), (591, 256, 512), (45, 128, 256)])
+@pytest.mark.parametrize("scaled", [False, True])
+def test_bias_gradient_fold_rides_on_the_weight_gradient_fold(M, N, K, scaled):
+    """tt_split_pairs_dual_parts leaves the column partials of a dy unfolded and tt_linear_bwd_weight_pairs_tn_bias folds them in the launch
+    that folds the weight gradient's split partials (round 5: one launch less per Linear): dw and db bit for bit as the two-launch route."""
+    from timetuning_amd import hip_ops as ops
+
+    dy = (rnd(f"cf.dy.{M}.{N}", M, N) * (1e-5 if scaled else 1.0)).cuda()
+    xp = ops.split_pairs(rnd(f"cf.x.{M}.{K}", M, K).cuda())
+    a = ops.split_pairs_dual(dy, want_row=True, want_colsum=True, want_t=False, scaled=scaled)
+    dw_a = ops.linear_bwd_weight_pairs_tn(a[1], xp, dy_scale=a[3] if scaled else None)
+    b = ops.split_pairs_dual(dy, want_row=True, want_colsum=True, want_t=False, scaled=scaled, colsum_parts=True)
+    assert torch.equal(a[1], b[1]) and tuple(b[2].shape) == (((M + 31) // 32 * 32 + 63) // 64, N)
+    dw_b, db_b = ops.linear_bwd_weight_pairs_tn(b[1], xp, dy_scale=b[3] if scaled else None, colsum_parts=b[2])
+    assert torch.equal(dw_a, dw_b) and torch.equal(a[2], db_b)
+    assert rel_err(db_b.cpu(), dy.double().sum(0).cpu()) < 1e-6
+
+
 def test_hip_pair_ops_equal_their_cpu_twins():
     """The HIP library and the plain-C twins (oracle/tt_cpu.c) through one call site with identical prototypes."""
     from oracle import cpu_twin

@@ -84,6 +84,7 @@ SIGNATURES = {
     "tt_attention_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp]),
     "tt_split_pairs_dual_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_split_pairs_dual": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp, c_vp]),
+    "tt_split_pairs_dual_parts": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp, c_vp]),
     "tt_transpose_pairs": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp]),
     "tt_linear_bwd_data_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_linear_bwd_weight_pairs_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
@@ -94,6 +95,7 @@ SIGNATURES = {
     "tt_linear_bwd_weight_pairs_tn_ok": (c_i, [c_i, c_i, c_i]),
     "tt_linear_bwd_weight_pairs_tn_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_linear_bwd_weight_pairs_tn": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "tt_linear_bwd_weight_pairs_tn_bias": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp, c_i, c_vp, c_vp]),
     "tt_transpose_planes": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp]),
     "tt_transpose_planes_colsum_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_transpose_planes_colsum": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp, c_vp, c_sz, c_vp]),

@@ -386,6 +386,17 @@ int launch_splitk_reduce(const float* partial, float* out, long long n, int spli
   return TT_OK;
 }
 
+int launch_splitk_reduce_colfold(const float* partial, float* out, long long n, int splits, long long stride, const float* colpart, float* db,
+                                 int colparts, int N, hipStream_t s) {
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(splitk_reduce_colfold_kernel, dim3((unsigned)blocks + (N + 63) / 64), dim3(256), 0, s, partial, out, n, splits, stride, (int)blocks,
+                     colpart, db, colparts, N);
+  TT_CHECK_LAUNCH("splitk_reduce_colfold");
+  return TT_OK;
+}
+
 int gemm_tile_choice(int M, int N, int batch) {
   static const int forced = [] { const char* e = getenv("TT_FORCE_TILE"); return e ? atoi(e) : -1; }();  // tuning aid
   if (forced >= 0 && forced <= 3) return forced;

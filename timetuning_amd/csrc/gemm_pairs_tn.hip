@@ -146,6 +146,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs_tn_kernel(TnArgs g) {
 }
 
 int launch_splitk_reduce(const float* partial, float* out, long long n, int splits, long long stride, hipStream_t s);  // gemm_f32.hip
+int launch_splitk_reduce_colfold(const float* partial, float* out, long long n, int splits, long long stride, const float* colpart, float* db,
+                                 int colparts, int N, hipStream_t s);                                                   // gemm_f32.hip
+int launch_colsum_fold(const float* partial, float* out, int chunks, int N, hipStream_t s);                            // rowops.hip
 
 // splits of the m range: ~ 1.5 workgroups per CU (measured best of 0.25 .. 3, tools/tn_sweep.py: two per CU fit, but the partials'
 // traffic - workgroups x 64 KB, written and read once - grows with the count), at least 8 chunks each, at most 64 partials
@@ -173,8 +176,9 @@ extern "C" size_t tt_linear_bwd_weight_pairs_tn_workspace_bytes(int N, int K, in
   const int s = tn_splits(N, K, M);
   return s > 1 ? (size_t)s * N * K * sizeof(float) : 16;
 }
-extern "C" int tt_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, float* dw, const float* dy_scale, int N, int K, int M,
-                                             void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+static int linear_bwd_weight_pairs_tn_impl(const void* dy_pairs, const void* x_pairs, float* dw, const float* dy_scale, int N, int K, int M,
+                                           void* workspace, size_t workspace_bytes, const float* colsum_parts, int colsum_count, float* db,
+                                           tt_stream_t stream) {
   TT_REQUIRE(dy_pairs && x_pairs && dw && workspace, "linear_bwd_weight_pairs_tn: null pointer");
   TT_REQUIRE(tt_linear_bwd_weight_pairs_tn_ok(N, K, M), "linear_bwd_weight_pairs_tn: need N %% 128 == 0, K %% 128 == 0, operands under 2 GB (N %d K %d M %d)", N, K, M);
   TT_REQUIRE(workspace_bytes >= tt_linear_bwd_weight_pairs_tn_workspace_bytes(N, K, M), "linear_bwd_weight_pairs_tn: workspace too small");
@@ -184,6 +188,19 @@ extern "C" int tt_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x
            K / 128, (N / 128) * (K / 128), s, (M + 31) / 32, (s % 8 == 0 && tuning_knob(KNOB_TN_XCD) != 0) ? 1 : 0};
   hipLaunchKernelGGL(gemm_pairs_tn_kernel, dim3((unsigned)(g.ntiles * s)), dim3(256), 0, as_stream(stream), g);
   TT_CHECK_LAUNCH("gemm_pairs_tn");
-  if (s == 1) return TT_OK;
+  if (s == 1) return db ? launch_colsum_fold(colsum_parts, db, colsum_count, N, as_stream(stream)) : TT_OK;
+  if (db)   // ONE launch folds the split partials of dw and the column partials of db (in colsum_stage2's order: the same bits)
+    return launch_splitk_reduce_colfold(static_cast<const float*>(workspace), dw, (long long)N * K, s, (long long)N * K, colsum_parts, db, colsum_count, N,
+                                        as_stream(stream));
   return launch_splitk_reduce(static_cast<const float*>(workspace), dw, (long long)N * K, s, (long long)N * K, as_stream(stream));
+}
+extern "C" int tt_linear_bwd_weight_pairs_tn(const void* dy_pairs, const void* x_pairs, float* dw, const float* dy_scale, int N, int K, int M,
+                                             void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+  return linear_bwd_weight_pairs_tn_impl(dy_pairs, x_pairs, dw, dy_scale, N, K, M, workspace, workspace_bytes, nullptr, 0, nullptr, stream);
+}
+extern "C" int tt_linear_bwd_weight_pairs_tn_bias(const void* dy_pairs, const void* x_pairs, float* dw, const float* dy_scale, int N, int K, int M,
+                                                  void* workspace, size_t workspace_bytes, const float* colsum_parts, int colsum_count, float* db,
+                                                  tt_stream_t stream) {
+  TT_REQUIRE(colsum_parts && db && colsum_count > 0, "linear_bwd_weight_pairs_tn_bias: the column partials of dy (tt_split_pairs_dual_parts) and db are required");
+  return linear_bwd_weight_pairs_tn_impl(dy_pairs, x_pairs, dw, dy_scale, N, K, M, workspace, workspace_bytes, colsum_parts, colsum_count, db, stream);
 }

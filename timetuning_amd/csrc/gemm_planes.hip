@@ -987,24 +987,27 @@ extern "C" size_t tt_split_pairs_dual_workspace_bytes(int R, int C, int Rpad) {
   return ((size_t)((Rpad + 63) / 64) * C + kAmaxParts) * sizeof(float);
 }
 
-extern "C" int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, float* scale_out, int R, int C, int Rpad,
-                                   void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream) {
+// colsum_parts (tt_split_pairs_dual_parts): the column partial sums [ceil(Rpad / 64)][C] are LEFT there, unfolded, for the launch that
+// folds the weight gradient's split partials to fold them too (tt_linear_bwd_weight_pairs_tn_bias: one launch less per dy)
+static int split_pairs_dual_impl(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, float* colsum_parts, float* scale_out, int R,
+                                 int C, int Rpad, void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream) {
   TT_REQUIRE(src && (dst_t_pairs || dst_row_pairs) && R > 0 && C > 0 && Rpad >= R && Rpad % 32 == 0,
              "split_pairs_dual: bad arguments (an output, Rpad a multiple of 32)");
   TT_REQUIRE(!dst_row_pairs || C % 32 == 0, "split_pairs_dual: row-major pairs need C %% 32 == 0 (got %d)", C);
   TT_REQUIRE(!(colsum || scale_out) || (workspace && workspace_bytes >= tt_split_pairs_dual_workspace_bytes(R, C, Rpad)),
-             "split_pairs_dual: workspace too small");
+             "split_pairs_dual: workspace too small");   // (colsum_parts + scale: the max pass's partials still live behind the colsum region)
   TT_REQUIRE((reinterpret_cast<uintptr_t>(dst_t_pairs) & 7u) == 0, "split_pairs_dual: the transposed output must be 8-byte aligned");
   TT_REQUIRE(!scale_out || aligned16(src), "split_pairs_dual: a scaled split needs a 16-byte aligned source");
   const dim3 grid((Rpad + 63) / 64, (C + 63) / 64), block(256);
   hipStream_t s = as_stream(stream);
   _Float16* dt = static_cast<_Float16*>(dst_t_pairs);
   _Float16* dr = static_cast<_Float16*>(dst_row_pairs);
-  float* partial = static_cast<float*>(workspace);
+  float* partial = colsum_parts ? colsum_parts : static_cast<float*>(workspace);
+  if (colsum_parts) colsum = colsum_parts;   // (non-null: the SUM instantiations below; never folded here)
   float* amax_part = nullptr;
   int n_part = 0;
   if (scale_out) {
-    amax_part = partial + (size_t)((Rpad + 63) / 64) * C;
+    amax_part = static_cast<float*>(workspace) + (size_t)((Rpad + 63) / 64) * C;
     const long long n = (long long)R * C;
     n_part = (int)((n + 4095) / 4096 < kAmaxParts ? (n + 4095) / 4096 : kAmaxParts);
     hipLaunchKernelGGL(amax_partial_kernel, dim3(n_part), dim3(256), 0, s, src, n, amax_part);
@@ -1014,8 +1017,17 @@ extern "C" int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* ds
   else if (colsum) hipLaunchKernelGGL((transpose_pairs_kernel<false, false, true>), grid, block, 0, s, src, dt, dr, R, C, Rpad, partial, amax_part, n_part, scale_out, range_flag);
   else hipLaunchKernelGGL((transpose_pairs_kernel<false, false, false>), grid, block, 0, s, src, dt, dr, R, C, Rpad, nullptr, amax_part, n_part, scale_out, range_flag);
   TT_CHECK_LAUNCH("split_pairs_dual");
-  if (colsum) return launch_colsum_fold(partial, colsum, (Rpad + 63) / 64, C, s);
+  if (colsum && !colsum_parts) return launch_colsum_fold(partial, colsum, (Rpad + 63) / 64, C, s);
   return TT_OK;
+}
+extern "C" int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, float* scale_out, int R, int C, int Rpad,
+                                   void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream) {
+  return split_pairs_dual_impl(src, dst_t_pairs, dst_row_pairs, colsum, nullptr, scale_out, R, C, Rpad, workspace, workspace_bytes, range_flag, stream);
+}
+extern "C" int tt_split_pairs_dual_parts(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum_parts, float* scale_out, int R, int C,
+                                         int Rpad, void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream) {
+  TT_REQUIRE(colsum_parts && aligned16(colsum_parts), "split_pairs_dual_parts: colsum_parts [ceil(Rpad / 64)][C] is required (16-byte aligned)");
+  return split_pairs_dual_impl(src, dst_t_pairs, dst_row_pairs, nullptr, colsum_parts, scale_out, R, C, Rpad, workspace, workspace_bytes, range_flag, stream);
 }
 
 // n fp32 matrices [R_i][C_i] -> row pairs and / or transposed pairs [C_i][2 Rpad_i] each, ONE launch per 32 of them

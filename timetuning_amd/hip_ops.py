@@ -1068,16 +1068,29 @@ def attention_fwd_pairs(qkv_pairs, num_heads: int, out_pairs: bool = True, out_f
 
 
 def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad: Optional[int] = None, colsum_out=None, want_t: bool = True,
-                     scaled: bool = False):
+                     scaled: bool = False, colsum_parts: bool = False):
     """fp32 [R, C] -> (transposed pairs [C, 2 Rpad] or None, row-major pairs [R, 2 C] or None, column sums [C] or None) in ONE pass
     (tt_split_pairs_dual): what the backward of an nn.Linear needs of its dy.  ``scaled`` (a GRADIENT, whose whole magnitude may sit
     below fp16's normal range): the pairs hold x * S with S the power of two that brings max |x| into [2^13, 2^14); a fourth value is
-    returned, the DEVICE scalar S, which the products take as ``dy_scale`` and divide by (no host round trip)."""
+    returned, the DEVICE scalar S, which the products take as ``dy_scale`` and divide by (no host round trip).
+    ``colsum_parts`` (tt_split_pairs_dual_parts): the column sums come back UNFOLDED, as the partials of 64-row blocks [ceil(Rpad / 64), C],
+    for ``linear_bwd_weight_pairs_tn(..., colsum_parts=, db_out=)`` to fold in the launch that folds the weight gradient."""
     lib = _lib.load()
     _chk(x, "x")
     R, Cc = x.shape
     rpad = (R + 31) // 32 * 32 if rpad is None else rpad
     assert want_t or want_row
+    if colsum_parts:
+        assert want_colsum and colsum_out is None
+        t = torch.empty((Cc, 2 * rpad), dtype=f16, device=x.device) if want_t else None
+        row = torch.empty((R, 2 * Cc), dtype=f16, device=x.device) if want_row else None
+        parts = torch.empty(((rpad + 63) // 64, Cc), dtype=f32, device=x.device)
+        nb = lib.tt_split_pairs_dual_workspace_bytes(R, Cc, rpad) if scaled else 0
+        ws = _ws(nb, x.device) if scaled else None
+        scale = torch.empty((1,), dtype=f32, device=x.device) if scaled else None
+        _lib.check(lib.tt_split_pairs_dual_parts(_p(x), _p(t), _p(row), _p(parts), _p(scale), R, Cc, rpad, _p(ws), nb, _p(range_flag(x.device)), _stream()),
+                   "tt_split_pairs_dual_parts")
+        return (t, row, parts, scale) if scaled else (t, row, parts)
     t = torch.empty((Cc, 2 * rpad), dtype=f16, device=x.device) if want_t else None
     row = torch.empty((R, 2 * Cc), dtype=f16, device=x.device) if want_row else None
     sums = (_chk(colsum_out, "colsum_out") if colsum_out is not None else torch.empty((Cc,), dtype=f32, device=x.device)) if want_colsum else None
@@ -1134,9 +1147,10 @@ def bwd_weight_pairs_tn_ok(M: int, N: int, K: int) -> bool:
     return bool(TN_WGRAD) and bool(_lib.load().tt_linear_bwd_weight_pairs_tn_ok(N, K, M))
 
 
-def linear_bwd_weight_pairs_tn(dy_pairs, x_pairs, dw_out=None, dy_scale=None):
+def linear_bwd_weight_pairs_tn(dy_pairs, x_pairs, dw_out=None, dy_scale=None, colsum_parts=None, db_out=None):
     """dw [N,K] = dy^T @ x from ROW pairs dy [M, 2 N], x [M, 2 K] (gemm_pairs_tn.hip: no transposed copies); ``dy_scale``: the device
-    scalar a scaled split of dy returned."""
+    scalar a scaled split of dy returned.  ``colsum_parts`` (``split_pairs_dual(..., colsum_parts=True)``): the bias gradient is folded
+    from them in the same launch as dw's split partials and returned too: (dw, db)."""
     lib = _lib.load()
     _chk(dy_pairs, "dy_pairs", f16); _chk(x_pairs, "x_pairs", f16)
     M, N, K = dy_pairs.shape[0], dy_pairs.shape[1] // 2, x_pairs.shape[1] // 2
@@ -1145,6 +1159,14 @@ def linear_bwd_weight_pairs_tn(dy_pairs, x_pairs, dw_out=None, dy_scale=None):
     nb = lib.tt_linear_bwd_weight_pairs_tn_workspace_bytes(N, K, M)
     ws = _ws(nb, dy_pairs.device)
     e0 = _prof_begin()
+    if colsum_parts is not None:
+        _chk(colsum_parts, "colsum_parts")
+        assert colsum_parts.shape[1] == N, (colsum_parts.shape, N)
+        db = _chk(db_out, "db_out") if db_out is not None else torch.empty((N,), dtype=f32, device=dy_pairs.device)
+        _lib.check(lib.tt_linear_bwd_weight_pairs_tn_bias(_p(dy_pairs), _p(x_pairs), _p(dw), _p(dy_scale), N, K, M, _p(ws), nb, _p(colsum_parts),
+                                                          colsum_parts.shape[0], _p(db), _stream()), "tt_linear_bwd_weight_pairs_tn_bias")
+        _prof_end(e0, "PAIRS_TN", N, K, M)
+        return dw, db
     _lib.check(lib.tt_linear_bwd_weight_pairs_tn(_p(dy_pairs), _p(x_pairs), _p(dw), _p(dy_scale), N, K, M, _p(ws), nb, _stream()), "tt_linear_bwd_weight_pairs_tn")
     _prof_end(e0, "PAIRS_TN", N, K, M)
     return dw
@@ -1162,9 +1184,13 @@ def linear_bwd_pairs(dy, wT_pairs, xT_pairs=None, gelu_pre=None, need_bias: bool
     if x_pairs is not None and bwd_weight_pairs_tn_ok(M, N, K):
         _chk(x_pairs, "x_pairs", f16)
         assert wT_pairs.shape == (K, 2 * N) and x_pairs.shape == (M, 2 * K), (dy.shape, wT_pairs.shape, x_pairs.shape)
-        r4 = split_pairs_dual(dy, want_row=True, want_colsum=need_bias, colsum_out=db_out, want_t=False, scaled=GRAD_SCALE)
-        dy_row, db, dy_scale = r4[1], r4[2], (r4[3] if GRAD_SCALE else None)
-        dw = linear_bwd_weight_pairs_tn(dy_row, x_pairs, dw_out, dy_scale)
+        # the bias gradient's fold rides on the weight gradient's (one launch less per Linear): the column partials stay unfolded here
+        r4 = split_pairs_dual(dy, want_row=True, want_colsum=need_bias, want_t=False, scaled=GRAD_SCALE, colsum_parts=need_bias)
+        dy_row, parts, dy_scale = r4[1], r4[2], (r4[3] if GRAD_SCALE else None)
+        if need_bias:
+            dw, db = linear_bwd_weight_pairs_tn(dy_row, x_pairs, dw_out, dy_scale, colsum_parts=parts, db_out=db_out)
+        else:
+            dw, db = linear_bwd_weight_pairs_tn(dy_row, x_pairs, dw_out, dy_scale), None
     else:
         if xT_pairs is None:
             xT_pairs = transpose_pairs(x_pairs)
