@@ -33,6 +33,11 @@ struct TnArgs {
   int M, N, K;
   int ntk, ntiles, splits, nchunks;   // tiles along K, tiles, splits of the m range, 32-row chunks
   int xcd_groups;                     // splits % 8 == 0: the workgroups of a split share an XCD
+  // splits == 1 with a bias gradient (tt_linear_bwd_weight_pairs_tn_bias: small row counts, BASELINE C1): there is no fold launch for the
+  // column sums to ride on - the workgroups behind the last tile fold them, 64 columns each (colsum_stage2's order: the same bits)
+  const float* colpart;
+  float* db;
+  int colparts;
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_pairs_tn_kernel(TnArgs g) {
@@ -40,6 +45,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs_tn_kernel(TnArgs g) {
   constexpr int STAGE_B = 2 * CH_B;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
   const int tid = threadIdx.x, lane = tid & 63;
+  if ((int)blockIdx.x >= g.ntiles * g.splits) {   // (uniform) a column-sum workgroup
+    colsum_fold_block(g.colpart, g.db, g.colparts, g.N, g.N, 0, (int)blockIdx.x - g.ntiles * g.splits, reinterpret_cast<float (*)[64]>(smem));
+    return;
+  }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
   // workgroup -> (tile, split).  The tiles of one split read the SAME 32-row chunks of dy and x: they are placed on ONE XCD (workgroup
@@ -185,10 +194,12 @@ static int linear_bwd_weight_pairs_tn_impl(const void* dy_pairs, const void* x_p
   TT_REQUIRE(aligned16(dy_pairs) && aligned16(x_pairs) && aligned16(dw) && aligned16(workspace), "linear_bwd_weight_pairs_tn: buffers must be 16-byte aligned");
   const int s = tn_splits(N, K, M);
   TnArgs g{static_cast<const _Float16*>(dy_pairs), static_cast<const _Float16*>(x_pairs), s > 1 ? static_cast<float*>(workspace) : dw, dy_scale, M, N, K,
-           K / 128, (N / 128) * (K / 128), s, (M + 31) / 32, (s % 8 == 0 && tuning_knob(KNOB_TN_XCD) != 0) ? 1 : 0};
-  hipLaunchKernelGGL(gemm_pairs_tn_kernel, dim3((unsigned)(g.ntiles * s)), dim3(256), 0, as_stream(stream), g);
+           K / 128, (N / 128) * (K / 128), s, (M + 31) / 32, (s % 8 == 0 && tuning_knob(KNOB_TN_XCD) != 0) ? 1 : 0,
+           colsum_parts, db, colsum_count};
+  const int extra = (s == 1 && db) ? (N + 63) / 64 : 0;
+  hipLaunchKernelGGL(gemm_pairs_tn_kernel, dim3((unsigned)(g.ntiles * s + extra)), dim3(256), 0, as_stream(stream), g);
   TT_CHECK_LAUNCH("gemm_pairs_tn");
-  if (s == 1) return db ? launch_colsum_fold(colsum_parts, db, colsum_count, N, as_stream(stream)) : TT_OK;
+  if (s == 1) return TT_OK;
   if (db)   // ONE launch folds the split partials of dw and the column partials of db (in colsum_stage2's order: the same bits)
     return launch_splitk_reduce_colfold(static_cast<const float*>(workspace), dw, (long long)N * K, s, (long long)N * K, colsum_parts, db, colsum_count, N,
                                         as_stream(stream));
