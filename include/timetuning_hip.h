@@ -148,9 +148,15 @@ int tt_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
 /*   dx has x's layout; dgamma/dbeta [D] optional (NULL for frozen norms).  add_to_dx != 0 accumulates
  *   into dx (residual branch).  With skip_group the rows of dx that belong to token 0 are not touched.
  *   workspace: tt_layernorm_bwd_workspace_bytes(rows, D). */
+/* amax_out (ABI 7, here and on tt_attention_bwd / tt_l2norm_bwd / tt_linear_bwd_data_pairs): an "amax slot" - tt_amax_slot_bytes()
+ * bytes of device memory (16 floats 256 bytes apart: the waves of a kernel spread their atomics over them, thousands on one address
+ * serialise) that the caller ZEROED - or NULL.  The kernel raises the slot to max |.| of the gradient it writes (relaxed atomic max on
+ * the non-negative floats' bits: deterministic).  That gradient is the dy of the next Linear's backward: tt_split_pairs_dual_parts takes
+ * the slot as amax_in and needs no max pass of its own for the power-of-two scale of the split (measured: C2 -0.8 %, C1 -1 %). */
+size_t tt_amax_slot_bytes(void);
 int tt_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                      float* dx, float* dgamma, float* dbeta, int rows, int D, int add_to_dx, int skip_group,
-                     void* workspace, size_t workspace_bytes, tt_stream_t stream);
+                     void* workspace, size_t workspace_bytes, float* amax_out, tt_stream_t stream);
 size_t tt_layernorm_bwd_workspace_bytes(int rows, int D);
 
 /* ---- k5 (+k10): multi-head self-attention core (dino_vision_transformer.py:122-129)
@@ -161,7 +167,7 @@ int tt_attention_fwd(const float* qkv, float* out, float* lse, float* probs, int
                      float scale, tt_stream_t stream);
 /*   dqkv [F,N,3*H*hd] from dout [F,N,H*hd]; workspace: tt_attention_bwd_workspace_bytes. */
 int tt_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F,
-                     int N, int H, int hd, float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream);
+                     int N, int H, int hd, float scale, void* workspace, size_t workspace_bytes, float* amax_out, tt_stream_t stream);
 size_t tt_attention_bwd_workspace_bytes(int F, int N, int H, int hd);
 /* The same backward on bf16 MATRIX operands (BASELINE C4's bf16 path; what torch.autocast makes of the backward of q k^T and attn v,
  * dino_vision_transformer.py:125-129): q, k, v, dout, P and dS are rounded to bf16 where they enter a product, products on
@@ -174,7 +180,7 @@ int tt_attention_bwd_bf16(const float* qkv, const float* out, const float* dout,
  *   xn[rows,D] = x / max(||x||, 1e-12); inv_norm[rows] optional.  x rows may be strided (ldx). */
 int tt_l2norm_fwd(const float* x, int ldx, float* xn, float* inv_norm, int rows, int D, tt_stream_t stream);
 /*   dx = (dxn - xn * <xn, dxn>) * inv_norm */
-int tt_l2norm_bwd(const float* dxn, const float* xn, const float* inv_norm, float* dx, int rows, int D,
+int tt_l2norm_bwd(const float* dxn, const float* xn, const float* inv_norm, float* dx, int rows, int D, float* amax_out,
                   tt_stream_t stream);
 /* ---- k18: in-place row L2 normalisation of the prototypes (time_tuning.py:124-128). */
 int tt_normalize_rows_inplace(float* w, int rows, int D, tt_stream_t stream);
@@ -295,8 +301,10 @@ int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_pairs
 /* tt_split_pairs_dual that LEAVES the column partial sums - colsum_parts [ceil(Rpad / 64)][C] fp32, caller-owned - unfolded, for
  * tt_linear_bwd_weight_pairs_tn_bias to fold in the launch that folds the weight gradient's split partials (one launch less per dy;
  * the bias gradient has the same bits either way).  workspace: as tt_split_pairs_dual (needed for a scale only). */
-int tt_split_pairs_dual_parts(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum_parts, float* scale_out, int R, int C, int Rpad,
-                              void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream);
+int tt_split_pairs_dual_parts(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum_parts, float* scale_out, const float* amax_in,
+                              int R, int C, int Rpad, void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream);
+/* amax_in (with scale_out): the amax slot the kernel that wrote src raised (amax_out above) - the split then needs no max pass and no
+ * workspace; NULL: it makes its own. */
 int tt_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int R, int C, int Rpad, tt_stream_t stream);
 /* tt_split_pairs_dual (without column sums) for n matrices in ONE launch per 32 of them: host arrays of n pointers / sizes; dst_t_pairs[i] or
  * dst_row_pairs[i] may be null.  What a training step needs of every weight the optimizer rewrote (row pairs: forward and weight-gradient
@@ -304,7 +312,7 @@ int tt_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int R, int C, i
 int tt_split_pairs_dual_multi(const float* const* src, void* const* dst_t_pairs, void* const* dst_row_pairs, const int* R, const int* C,
                               const int* Rpad, int n, int* range_flag, tt_stream_t stream);
 int tt_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, const float* dy_scale, int M, int N, int K,
-                             void* workspace, size_t workspace_bytes, tt_stream_t stream);   /* workspace: the K-split block or NULL (ABI 7) */
+                             void* workspace, size_t workspace_bytes, float* amax_out, tt_stream_t stream);   /* workspace: the K-split block or NULL (ABI 7) */
 size_t tt_linear_bwd_weight_pairs_workspace_bytes(int N, int K, int Mpad);
 int tt_linear_bwd_weight_pairs(const void* dyT_pairs, const void* xT_pairs, float* dw, const float* dy_scale, int N, int K, int Mpad, void* workspace,
                                size_t workspace_bytes, tt_stream_t stream);

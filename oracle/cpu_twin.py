@@ -32,7 +32,7 @@ TWINS = ["sinkhorn", "ce_loss_fwd_bwd", "img_resample_h", "img_resample_v", "img
          "split_pairs_dual_workspace_bytes", "transpose_pairs", "linear_bwd_data_pairs", "linear_bwd_weight_pairs",
          "linear_bwd_weight_pairs_workspace_bytes", "linear_bwd_weight_pairs_tn", "linear_bwd_weight_pairs_tn_ok",
          "linear_bwd_weight_pairs_tn_workspace_bytes", "split_pairs_dual_multi",
-         "split_pairs_dual_parts", "linear_bwd_weight_pairs_tn_bias",
+         "split_pairs_dual_parts", "linear_bwd_weight_pairs_tn_bias", "amax_slot_bytes",
          "patch_embed_fwd_pairs", "patch_embed_pairs_workspace_bytes",
          "sinkhorn_local_workspace_bytes", "sinkhorn_local_begin", "sinkhorn_local_step", "sinkhorn_local_end"]
 _lib = None

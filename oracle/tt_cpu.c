@@ -595,9 +595,14 @@ int tt_cpu_add_inplace(float* dst, const float* src, long long n, tt_stream_t st
 
 /* ---- autograd of nn.LayerNorm: dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma; dgamma = sum dy xhat; dbeta = sum dy.
  *      skip_group = N: dy has no rows for token 0 of each group; those rows of dx are left untouched.  add_to_dx accumulates. */
+/* amax_out of the gradient producers (include/timetuning_hip.h): the caller's float is raised to max |.| of what was written */
+size_t tt_cpu_amax_slot_bytes(void) { return (size_t)16 * 64 * sizeof(float); }   /* (the twin raises way 0 only) */
+static void cpu_amax_raise(float* slot, float v) {
+  if (slot && fabsf(v) > *slot) *slot = fabsf(v);
+}
 int tt_cpu_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
                          float* dgamma, float* dbeta, int rows, int D, int add_to_dx, int skip_group, void* workspace,
-                         size_t workspace_bytes, tt_stream_t stream) {
+                         size_t workspace_bytes, float* amax_out, tt_stream_t stream) {
   (void)workspace; (void)workspace_bytes; (void)stream;
   double* dg = (double*)calloc((size_t)2 * D, sizeof(double));
   if (!dg) return -3;
@@ -617,6 +622,7 @@ int tt_cpu_layernorm_bwd(const float* dy, const float* x, const float* gamma, co
       const double xh = ((double)xv[c] - mean[r]) * rstd[r], gg = (double)dv[c] * gamma[c];
       const float v = (float)(rstd[r] * (gg - m1 - xh * m2));
       if (add_to_dx) dx[xr * D + c] += v; else dx[xr * D + c] = v;
+      cpu_amax_raise(amax_out, dx[xr * D + c]);
     }
   }
   if (dgamma) for (int c = 0; c < D; ++c) { dgamma[c] = (float)dg[c]; dbeta[c] = (float)db[c]; }
@@ -625,12 +631,15 @@ int tt_cpu_layernorm_bwd(const float* dy, const float* x, const float* gamma, co
 }
 
 /* ---- autograd of F.normalize: dx = (dxn - xn <xn, dxn>) inv_norm */
-int tt_cpu_l2norm_bwd(const float* dxn, const float* xn, const float* inv_norm, float* dx, int rows, int D, tt_stream_t stream) {
+int tt_cpu_l2norm_bwd(const float* dxn, const float* xn, const float* inv_norm, float* dx, int rows, int D, float* amax_out, tt_stream_t stream) {
   (void)stream;
   for (int r = 0; r < rows; ++r) {
     double dot = 0.0;
     for (int c = 0; c < D; ++c) dot += (double)xn[(size_t)r * D + c] * dxn[(size_t)r * D + c];
-    for (int c = 0; c < D; ++c) dx[(size_t)r * D + c] = (float)(((double)dxn[(size_t)r * D + c] - xn[(size_t)r * D + c] * dot) * inv_norm[r]);
+    for (int c = 0; c < D; ++c) {
+      dx[(size_t)r * D + c] = (float)(((double)dxn[(size_t)r * D + c] - xn[(size_t)r * D + c] * dot) * inv_norm[r]);
+      cpu_amax_raise(amax_out, dx[(size_t)r * D + c]);
+    }
   }
   return 0;
 }
@@ -638,7 +647,7 @@ int tt_cpu_l2norm_bwd(const float* dxn, const float* xn, const float* inv_norm, 
 /* ---- autograd of Attention.forward's softmax(q k^T scale) v (dino_vision_transformer.py:122-129) from the saved lse:
  *      P = exp(s - lse); dV = P^T dO; dP = dO V^T; dS = P (dP - rowsum(dO O)); dQ = dS K scale; dK = dS^T Q scale */
 int tt_cpu_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N, int H, int hd,
-                         float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+                         float scale, void* workspace, size_t workspace_bytes, float* amax_out, tt_stream_t stream) {
   (void)workspace; (void)workspace_bytes; (void)stream;
   const int D = H * hd, D3 = 3 * D;
   memset(dqkv, 0, (size_t)F * N * D3 * sizeof(float));
@@ -667,7 +676,10 @@ int tt_cpu_attention_bwd(const float* qkv, const float* out, const float* dout, 
           }
         }
       }
-    for (size_t t = 0; t < (size_t)N * D3; ++t) dqkv[(size_t)f * N * D3 + t] = (float)acc[t];
+    for (size_t t = 0; t < (size_t)N * D3; ++t) {
+      dqkv[(size_t)f * N * D3 + t] = (float)acc[t];
+      cpu_amax_raise(amax_out, dqkv[(size_t)f * N * D3 + t]);
+    }
   }
   free(acc);
   return 0;
@@ -1063,8 +1075,11 @@ int tt_cpu_split_pairs_dual(const float* src, void* dst_t_pairs, void* dst_row_p
   return 0;
 }
 /* the column sums left as partials of 64-row blocks [ceil(Rpad / 64)][C] (tt_split_pairs_dual_parts) */
-int tt_cpu_split_pairs_dual_parts(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum_parts, float* scale_out, int R, int C,
-                                  int Rpad, void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream) {
+int tt_cpu_split_pairs_dual_parts(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum_parts, float* scale_out,
+                                  const float* amax_in, int R, int C, int Rpad, void* workspace, size_t workspace_bytes, int* range_flag,
+                                  tt_stream_t stream) {
+  /* (amax_in: max |src| as its producer left it - equal to the maximum this twin finds itself, which is what it uses) */
+  (void)amax_in;
   const int rc = tt_cpu_split_pairs_dual(src, dst_t_pairs, dst_row_pairs, NULL, scale_out, R, C, Rpad, workspace, workspace_bytes, range_flag, stream);
   if (rc) return rc;
   const int chunks = (Rpad + 63) / 64;
@@ -1096,7 +1111,7 @@ int tt_cpu_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int R, int 
   return 0;
 }
 int tt_cpu_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, const float* dy_scale, int M, int N,
-                                 int K, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+                                 int K, void* workspace, size_t workspace_bytes, float* amax_out, tt_stream_t stream) {
   (void)stream; (void)workspace; (void)workspace_bytes;
   const uint16_t *dy = (const uint16_t*)dy_pairs, *wT = (const uint16_t*)wT_pairs;   /* dy [M][2 N], wT [K][2 N] */
   const double inv_s = dy_scale ? 1.0 / (double)*dy_scale : 1.0;
@@ -1105,6 +1120,7 @@ int tt_cpu_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, con
       float v = (float)(pair_dot(dy + (size_t)m * 2 * N, wT + (size_t)k * 2 * N, N) * inv_s);
       if (gelu_pre) v *= tt_cpu_gelu_grad(gelu_pre[(size_t)m * K + k]);
       dx[(size_t)m * K + k] = v;
+      cpu_amax_raise(amax_out, v);
     }
   return 0;
 }

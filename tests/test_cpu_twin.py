@@ -361,19 +361,25 @@ def _round2b_cases(side):
     rs = (1.0 / np.sqrt(x.astype(np.float64).var(-1) + 1e-6)).reshape(-1).astype(np.float32)
     dy = f32(Fr * Nt, D)
     dx, dg, db = np.empty((Fr * Nt, D), np.float32), np.empty(D, np.float32), np.empty(D, np.float32)
-    side.run("layernorm_bwd", dy, x, g, mu, rs, dx, dg, db, Fr * Nt, D, 0, 0, ws, 1 << 20, st, outs=(dx, dg, db))
+    # amax_out: a zeroed slot of 16 ways x 64 floats (csrc/common.hpp amax_publish spreads its atomics; the twin uses way 0) that the kernel
+    # raises to max |dx| - the maximum the next Linear's pair split scales by
+    am_ln = np.zeros(16 * 64, np.float32)
+    side.run("layernorm_bwd", dy, x, g, mu, rs, dx, dg, db, Fr * Nt, D, 0, 0, ws, 1 << 20, am_ln, st, outs=(dx, dg, db, am_ln))
+    assert am_ln.max() == np.abs(dx).max()
     # dropped-cls form: statistics / dy only for the patch rows, dx has x's layout and its cls rows are not written
     keep = np.array([r for r in range(Fr * Nt) if r % Nt != 0])
     dyd = np.ascontiguousarray(dy[keep])
     dxd = np.zeros((Fr * Nt, D), np.float32)
     side.run("layernorm_bwd", dyd, x, g, np.ascontiguousarray(mu[keep]), np.ascontiguousarray(rs[keep]), dxd, None, None, Fr * (Nt - 1), D, 1, Nt, ws, 1 << 20,
-             st, outs=(dxd,))
-    R["ln_bwd"] = (x, g, dy, dx.copy(), dg.copy(), db.copy(), keep, dxd.copy())
+             None, st, outs=(dxd,))
+    R["ln_bwd"] = (x, g, dy, dx.copy(), dg.copy(), db.copy(), keep, dxd.copy(), am_ln.max(keepdims=True))
     xn = x.reshape(-1, D) / np.linalg.norm(x.reshape(-1, D), axis=1, keepdims=True)
     inv = (1.0 / np.linalg.norm(x.reshape(-1, D), axis=1)).astype(np.float32)
     dxn, dxl = f32(Fr * Nt, D), np.empty((Fr * Nt, D), np.float32)
-    side.run("l2norm_bwd", dxn, xn.astype(np.float32), inv, dxl, Fr * Nt, D, st, outs=(dxl,))
-    R["l2_bwd"] = (x.reshape(-1, D), dxn, dxl.copy())
+    am_l2 = np.zeros(16 * 64, np.float32)
+    side.run("l2norm_bwd", dxn, xn.astype(np.float32), inv, dxl, Fr * Nt, D, am_l2, st, outs=(dxl, am_l2))
+    assert am_l2.max() == np.abs(dxl).max()
+    R["l2_bwd"] = (x.reshape(-1, D), dxn, dxl.copy(), am_l2.max(keepdims=True))
     # attention backward from the forward's saved out / lse
     Fa, Na, H = 2, 21, 2
     qkv = f32(Fa, Na, 3 * H * 64, scale=0.5)
@@ -382,8 +388,10 @@ def _round2b_cases(side):
     dout, dqkv = f32(Fa, Na, H * 64), np.empty_like(qkv)
     nbw = 1 << 24
     wsa = np.empty(nbw, np.uint8)
-    side.run("attention_bwd", qkv, out, dout, lse, dqkv, Fa, Na, H, 64, 0.125, wsa, nbw, st, outs=(dqkv,))
-    R["att_bwd"] = (qkv, dout, dqkv.copy())
+    am_at = np.zeros(16 * 64, np.float32)
+    side.run("attention_bwd", qkv, out, dout, lse, dqkv, Fa, Na, H, 64, 0.125, wsa, nbw, am_at, st, outs=(dqkv, am_at))
+    assert am_at.max() == np.abs(dqkv).max()
+    R["att_bwd"] = (qkv, dout, dqkv.copy(), am_at.max(keepdims=True))
     dqkv_b = np.empty_like(qkv)
     side.run("attention_bwd_bf16", qkv, out, dout, lse, dqkv_b, Fa, Na, H, 64, 0.125, wsa, nbw, st, outs=(dqkv_b,))
     R["att_bwd_bf16"] = (qkv, dout, dqkv_b.copy())
@@ -457,7 +465,7 @@ def test_round2b_twins_against_torch(twin):
     R = _round2b_cases(_Side(twin, "tt_cpu_"))
     a, cs, b_, a2 = R["colsum_add"]
     assert _re(cs, a.astype(np.float64).sum(0)) < 1e-6 and np.array_equal(a2, a.reshape(-1) + b_)
-    x, g, dy, dx, dg, db, keep, dxd = R["ln_bwd"]
+    x, g, dy, dx, dg, db, keep, dxd, _ = R["ln_bwd"]
     xt = torch.from_numpy(x).double().requires_grad_(True)
     gt = torch.from_numpy(g).double().requires_grad_(True)
     bt = torch.zeros(x.shape[-1], dtype=torch.float64, requires_grad=True)
@@ -467,11 +475,11 @@ def test_round2b_twins_against_torch(twin):
     y2 = F.layer_norm(xt, (x.shape[-1],), gt.detach(), bt.detach(), 1e-6).reshape(-1, x.shape[-1])[torch.from_numpy(keep)]
     (y2 * torch.from_numpy(dy[keep]).double()).sum().backward()
     assert _re(dxd, xt.grad.reshape(dxd.shape).numpy()) < 1e-5 and (dxd[::5] == 0).all()
-    xx, dxn, dxl = R["l2_bwd"]
+    xx, dxn, dxl, _ = R["l2_bwd"]
     xt = torch.from_numpy(xx).double().requires_grad_(True)
     (F.normalize(xt, dim=1) * torch.from_numpy(dxn).double()).sum().backward()
     assert _re(dxl, xt.grad.numpy()) < 1e-5
-    qkv, dout, dqkv = R["att_bwd"]
+    qkv, dout, dqkv, _ = R["att_bwd"]
     qt = torch.from_numpy(qkv).double().requires_grad_(True)
     q, k, v = qt.view(2, 21, 3, 2, 64).permute(2, 0, 3, 1, 4)
     o = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(2, 21, 128)
@@ -721,7 +729,9 @@ def test_round4_pair_twins_against_numpy(twin):
     wT = np.empty((K, 2 * N), np.uint16)
     assert twin.tt_cpu_split_pairs_dual(ptr(w), ptr(wT), None, None, None, N, K, N, None, 0, None, None) == 0
     dx, dw = np.empty((M, K), np.float32), np.empty((N, K), np.float32)
-    assert twin.tt_cpu_linear_bwd_data_pairs(ptr(dyr), ptr(wT), None, ptr(dx), None, M, N, K, None, 0, None) == 0
+    am = np.zeros(16 * 64, np.float32)
+    assert twin.tt_cpu_linear_bwd_data_pairs(ptr(dyr), ptr(wT), None, ptr(dx), None, M, N, K, None, 0, ptr(am), None) == 0
+    assert am.max() == np.abs(dx).max()
     assert twin.tt_cpu_linear_bwd_weight_pairs(ptr(dyT), ptr(t), ptr(dw), None, N, K, 64, None, 0, None) == 0
     dx_ref, dw_ref = dy.astype(np.float64) @ w, dy.astype(np.float64).T @ x
     assert np.abs(dx - dx_ref).max() / np.abs(dx_ref).max() < 5e-7 and np.abs(dw - dw_ref).max() / np.abs(dw_ref).max() < 5e-7
@@ -751,7 +761,7 @@ def test_round4_pair_twins_against_numpy(twin):
     assert S[0] == 2.0 ** (13 - np.floor(np.log2(amax))) and 2 ** 13 <= amax * S[0] < 2 ** 14 and np.allclose(cs2, tiny.sum(0), rtol=1e-5, atol=0)
     dws, dxs = np.empty((N, K), np.float32), np.empty((M, K), np.float32)
     assert twin.tt_cpu_linear_bwd_weight_pairs_tn(ptr(tr), ptr(xp), ptr(dws), ptr(S), N, K, M, None, 0, None) == 0
-    assert twin.tt_cpu_linear_bwd_data_pairs(ptr(tr), ptr(wT), None, ptr(dxs), ptr(S), M, N, K, None, 0, None) == 0
+    assert twin.tt_cpu_linear_bwd_data_pairs(ptr(tr), ptr(wT), None, ptr(dxs), ptr(S), M, N, K, None, 0, None, None) == 0
     rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
     assert rel(dws, ref_dw) < 5e-7 and rel(dxs, ref_dx) < 5e-7
     tu, dwu = np.empty((M, 2 * N), np.uint16), np.empty((N, K), np.float32)
@@ -760,7 +770,8 @@ def test_round4_pair_twins_against_numpy(twin):
     assert rel(dwu, ref_dw) > 20 * rel(dws, ref_dw)                        # (what the scale is for)
     # the column sums left as partials of 64-row blocks, folded by the weight gradient's call (round 5: one fold launch per Linear)
     parts, tr3, S3 = np.full((1, N), np.nan, np.float32), np.empty((M, 2 * N), np.uint16), np.zeros(1, np.float32)
-    assert twin.tt_cpu_split_pairs_dual_parts(ptr(tiny), None, ptr(tr3), ptr(parts), ptr(S3), M, N, 64, None, 0, None, None) == 0
+    amx = np.zeros(16 * 64, np.float32); amx[0] = np.abs(tiny).max()   # (what the kernel that produced `tiny` would have published)
+    assert twin.tt_cpu_split_pairs_dual_parts(ptr(tiny), None, ptr(tr3), ptr(parts), ptr(S3), ptr(amx), M, N, 64, None, 0, None, None) == 0
     assert np.array_equal(tr3, tr) and S3[0] == S[0] and np.allclose(parts[0], tiny.sum(0), rtol=1e-5, atol=0)
     dw3, db3 = np.empty((N, K), np.float32), np.empty((N,), np.float32)
     assert twin.tt_cpu_linear_bwd_weight_pairs_tn_bias(ptr(tr3), ptr(xp), ptr(dw3), ptr(S3), N, K, M, None, 0, ptr(parts), 1, ptr(db3), None) == 0

@@ -223,6 +223,37 @@ def test_bias_gradient_fold_rides_on_the_weight_gradient_fold(M, N, K, scaled):
     assert rel_err(db_b.cpu(), dy.double().sum(0).cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("M,N,K,gelu", [(6304, 1536, 384, True), (6304, 384, 1536, False), (788, 384, 384, True), (6272, 1024, 512, True)])
+def test_gradient_scale_from_the_producers_maximum(M, N, K, gelu):
+    """Round 5: the kernel that PRODUCES a dy publishes max |dy| (``amax_out``) and the scaled pair split of that dy takes it (``dy_amax``)
+    instead of making a max pass of its own.  The published maximum is exact, so the power-of-two scale - and with it every bit of dx, dw
+    and db - is the one the max pass finds; the data-gradient kernels (persistent x gelu' epilogue, general kernel) publish max |dx|."""
+    from timetuning_amd import engine, hip_ops as ops
+
+    dy = (rnd(f"am.dy.{M}.{N}", M, N) * 3e-6).cuda()
+    w = (rnd(f"am.w.{N}.{K}", N, K) * 0.05).cuda()
+    xp = ops.split_pairs(rnd(f"am.x.{M}.{K}", M, K).cuda())
+    pre = rnd(f"am.pre.{M}.{K}", M, K).cuda() if gelu else None
+    ref = engine._bwd_both_pairs(dy, w, xp, pre)
+    pool = ops.AmaxPool.get(dy.device)
+    pool.reset()
+    a_dy, a_dx = pool.take(), pool.take()
+    a_dy[0] = dy.abs().max()                     # (what layernorm_bwd / attention_bwd / ... leave in one of the slot's 16 ways: test_cpu_twin)
+    # (max |dx| is asked of the x gelu' data gradients only - the dx that are a next Linear's dy; without it the request would route
+    # the product to the general kernel)
+    got = engine._bwd_both_pairs(dy, w, xp, pre, dy_amax=a_dy, dx_amax_out=a_dx if gelu else None)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    if gelu:
+        assert a_dx.max().item() == got[0].abs().max().item()
+    # a stale (too small) maximum would overflow the split: the range flag says so
+    ops.range_flag(dy.device).zero_()
+    a_dy.fill_(float(dy.abs().max()) * 2.0 ** -6)
+    engine._bwd_both_pairs(dy, w, xp, pre, dy_amax=a_dy)
+    assert int(ops.range_flag(dy.device)[0].item()) == 1
+    ops.range_flag(dy.device).zero_()
+
+
 def test_hip_pair_ops_equal_their_cpu_twins():
     """The HIP library and the plain-C twins (oracle/tt_cpu.c) through one call site with identical prototypes."""
     from oracle import cpu_twin

@@ -69,7 +69,7 @@ SIGNATURES = {
     "tt_patch_embed_planes_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "tt_patch_embed_fwd_planes": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_layernorm_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_i, c_vp]),
-    "tt_layernorm_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "tt_layernorm_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp, c_vp]),
     "tt_layernorm_bwd_workspace_bytes": (c_sz, [c_i, c_i]),
     "tt_attention_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp]),
     "tt_split_planes": (c_i, [c_vp, c_vp, c_ll, c_i, c_ll, c_vp]),
@@ -84,9 +84,10 @@ SIGNATURES = {
     "tt_attention_fwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp]),
     "tt_split_pairs_dual_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_split_pairs_dual": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp, c_vp]),
-    "tt_split_pairs_dual_parts": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp, c_vp]),
+    "tt_amax_slot_bytes": (c_sz, []),
+    "tt_split_pairs_dual_parts": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp, c_vp]),
     "tt_transpose_pairs": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp]),
-    "tt_linear_bwd_data_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "tt_linear_bwd_data_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp, c_vp]),
     "tt_linear_bwd_weight_pairs_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "tt_linear_bwd_weight_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_split_pairs_dual_multi": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_vp]),
@@ -102,11 +103,11 @@ SIGNATURES = {
     "tt_linear_bwd_data_planes": (c_i, [c_vp, c_ll, c_vp, c_ll, c_i, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_linear_bwd_weight_planes": (c_i, [c_vp, c_ll, c_vp, c_ll, c_i, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_linear_bwd_weight_planes_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
-    "tt_attention_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
+    "tt_attention_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp, c_vp]),
     "tt_attention_bwd_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "tt_attention_bwd_bf16": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
     "tt_l2norm_fwd": (c_i, [c_vp, c_i, c_vp, c_vp, c_i, c_i, c_vp]),
-    "tt_l2norm_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp]),
+    "tt_l2norm_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp]),
     "tt_normalize_rows_inplace": (c_i, [c_vp, c_i, c_i, c_vp]),
     "tt_sinkhorn": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_i, c_vp, c_sz, c_vp]),
     "tt_sinkhorn_workspace_bytes": (c_sz, [c_i, c_i]),

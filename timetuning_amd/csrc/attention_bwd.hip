@@ -51,7 +51,7 @@ __device__ __forceinline__ void tile_to_regs(const float* __restrict__ src, long
 template <bool BF16>
 __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                                const float* __restrict__ dout, const float* __restrict__ lse,
-                                                               float* __restrict__ dqkv, float* __restrict__ delta, int N, int H,
+                                                               float* __restrict__ dqkv, float* __restrict__ delta, float* __restrict__ amax_out, int N, int H,
                                                                int FH, float scale) {
   __shared__ __attribute__((aligned(16))) float smem[4 * BCH * BSTR + 64 * BSTR];
   float* Ks = smem;                   // [2][32][68]
@@ -163,18 +163,23 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
     if (c + 1 < nchunks) swrite(buf ^ 1);
     __syncthreads();
   }
+  float am = 0.f;
   if (wave_active && q < N) {
     float* o = dqkv + ((long long)f * N + q) * D3 + h * BHD + 4 * g;
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
-      *reinterpret_cast<float4*>(o + 16 * d) = make_float4(dq[d][0] * scale, dq[d][1] * scale, dq[d][2] * scale, dq[d][3] * scale);
+    for (int d = 0; d < 4; ++d) {
+      const float4 w = make_float4(dq[d][0] * scale, dq[d][1] * scale, dq[d][2] * scale, dq[d][3] * scale);
+      *reinterpret_cast<float4*>(o + 16 * d) = w;
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(w.x), fabsf(w.y))), fmaxf(fabsf(w.z), fabsf(w.w)));
+    }
   }
+  if (amax_out) amax_publish(amax_out, am);   // (every lane of the wave is here: the max of what dqkv received, for the pair split of it)
 }
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                float* __restrict__ dqkv, int N, int H, int FH, float scale) {
+                                                                float* __restrict__ dqkv, float* __restrict__ amax_out, int N, int H, int FH, float scale) {
   __shared__ __attribute__((aligned(16))) float smem[4 * BCH * BSTR + 64 * BSTR + 4 * BCH];
   float* Qs = smem;                    // [2][32][68]
   float* Os = smem + 2 * BCH * BSTR;   // dO chunks [2][32][68]
@@ -300,15 +305,21 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
     if (c + 1 < nchunks) swrite(buf ^ 1);
     __syncthreads();
   }
+  float am = 0.f;
   if (wave_active && key < N) {
     float* ok_ = dqkv + ((long long)f * N + key) * D3 + D + h * BHD + 4 * g;
     float* ov = ok_ + D;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      *reinterpret_cast<float4*>(ok_ + 16 * d) = make_float4(dk[d][0] * scale, dk[d][1] * scale, dk[d][2] * scale, dk[d][3] * scale);
-      *reinterpret_cast<float4*>(ov + 16 * d) = make_float4(dv[d][0], dv[d][1], dv[d][2], dv[d][3]);
+      const float4 wk_ = make_float4(dk[d][0] * scale, dk[d][1] * scale, dk[d][2] * scale, dk[d][3] * scale);
+      const float4 wv_ = make_float4(dv[d][0], dv[d][1], dv[d][2], dv[d][3]);
+      *reinterpret_cast<float4*>(ok_ + 16 * d) = wk_;
+      *reinterpret_cast<float4*>(ov + 16 * d) = wv_;
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(wk_.x), fabsf(wk_.y))), fmaxf(fabsf(wk_.z), fabsf(wk_.w)));
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(wv_.x), fabsf(wv_.y))), fmaxf(fabsf(wv_.z), fabsf(wv_.w)));
     }
   }
+  if (amax_out) amax_publish(amax_out, am);
 }
 
 }  // namespace tt
@@ -322,7 +333,7 @@ extern "C" size_t tt_attention_bwd_workspace_bytes(int F, int N, int H, int hd) 
 
 template <bool BF16>
 static int attention_bwd_impl(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N,
-                              int H, int hd, float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+                              int H, int hd, float scale, void* workspace, size_t workspace_bytes, float* amax_out, tt_stream_t stream) {
   TT_REQUIRE(qkv && out && dout && lse && dqkv && workspace, "attention_bwd: null pointer");
   TT_REQUIRE(hd == 64, "attention_bwd: head_dim must be 64 (got %d)", hd);
   TT_REQUIRE(F > 0 && H > 0 && N > 0, "attention_bwd: bad shape");
@@ -331,18 +342,18 @@ static int attention_bwd_impl(const float* qkv, const float* out, const float* d
   hipStream_t s = as_stream(stream);
   float* delta = static_cast<float*>(workspace);
   dim3 grid(xcd_group_grid(F * H, (N + 63) / 64));
-  hipLaunchKernelGGL(attention_bwd_dq_kernel<BF16>, grid, dim3(256), 0, s, qkv, out, dout, lse, dqkv, delta, N, H, F * H, scale);
-  hipLaunchKernelGGL(attention_bwd_dkv_kernel<BF16>, grid, dim3(256), 0, s, qkv, dout, lse, delta, dqkv, N, H, F * H, scale);
+  hipLaunchKernelGGL(attention_bwd_dq_kernel<BF16>, grid, dim3(256), 0, s, qkv, out, dout, lse, dqkv, delta, amax_out, N, H, F * H, scale);
+  hipLaunchKernelGGL(attention_bwd_dkv_kernel<BF16>, grid, dim3(256), 0, s, qkv, dout, lse, delta, dqkv, amax_out, N, H, F * H, scale);
   TT_CHECK_LAUNCH("attention_bwd");
   return TT_OK;
 }
 
 extern "C" int tt_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N,
-                                int H, int hd, float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
-  return attention_bwd_impl<false>(qkv, out, dout, lse, dqkv, F, N, H, hd, scale, workspace, workspace_bytes, stream);
+                                int H, int hd, float scale, void* workspace, size_t workspace_bytes, float* amax_out, tt_stream_t stream) {
+  return attention_bwd_impl<false>(qkv, out, dout, lse, dqkv, F, N, H, hd, scale, workspace, workspace_bytes, amax_out, stream);
 }
 
 extern "C" int tt_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N,
                                      int H, int hd, float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
-  return attention_bwd_impl<true>(qkv, out, dout, lse, dqkv, F, N, H, hd, scale, workspace, workspace_bytes, stream);
+  return attention_bwd_impl<true>(qkv, out, dout, lse, dqkv, F, N, H, hd, scale, workspace, workspace_bytes, nullptr, stream);
 }

@@ -64,6 +64,22 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// max |.| of what a kernel wrote, published into a caller-owned device float (zeroed by the caller; non-negative floats order as unsigned
+// integers: one relaxed atomic max per wave, order-independent = deterministic).  The PRODUCERS of a gradient leave it for the pair split
+// of that gradient (tt_split_pairs_dual_parts amax_in: the power-of-two scale without a max pass of its own); NaNs are ignored as fmaxf
+// ignores them - the split's range flag reports them.
+// The "float" is kAmaxWays floats, kAmaxStride apart (different memory channels), and a workgroup uses way blockIdx.x % kAmaxWays: thousands
+// of waves on ONE address serialise (measured: +0.2 ms on a C2 step with an atomic per wave on one address, +0.05 ms with a read in front
+// of it - against the 0.11 ms of max passes this replaces).  A wave READS its way first and skips the atomic unless it would raise it.
+constexpr int kAmaxWays = 16, kAmaxStride = 64;   // floats: a slot is kAmaxWays * kAmaxStride floats (4 KB), zeroed by the caller
+__device__ __forceinline__ void amax_publish(float* slot, float m) {
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) {
+    float* way = slot + (blockIdx.x % kAmaxWays) * kAmaxStride;
+    const float cur = __hip_atomic_load(way, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (m > cur) __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(way), __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 
 // exp for softmax probabilities: v_exp_f32 on x * log2(e) (a handful of instructions; ocml's expf is ~10x that and the
 // softmax phase of the attention kernels is pure VALU time during which the matrix pipe idles).  Arguments are <= 0 and

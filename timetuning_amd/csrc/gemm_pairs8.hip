@@ -59,6 +59,7 @@ struct Q8Args {
   float* ks_ws;           // [ks_R][ks_S][8 waves][4096]
   int* ks_cnt;            // [ks_R][8], zero between launches (the finishing wave resets its counter)
   int* range_flag;        // device word or null: set to 1 when a pair output's hi leaves fp16's range (common.hpp: pair_hi_bad)
+  float* amax_out;        // device float or null (Q8_F32_GELUGRAD, the symmetric kernel): max |C| is published into it (common.hpp: amax_publish)
 };
 
 __device__ __forceinline__ void q8_dma16(const void* base, unsigned char* lds_dst, int voffset, int soffset) {
@@ -1044,6 +1045,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
   constexpr int NLD = NPASS * NRB;
   auto esw = [](int row) { return (row >> 2) & (CPRW - 1); };
   const unsigned out_bytes = (unsigned)g.M * (unsigned)g.N * 4u;
+  float amax_run = 0.f;   // (Q8_F32_GELUGRAD with g.amax_out: max |.| of what this wave stored - a dy for the next Linear's backward)
   auto epilogue = [&](int row0, int n0, bool half) {
     if constexpr (DBG & 8) {
       float sres = 0.f;
@@ -1125,6 +1127,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
               if constexpr (GG) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast_f(rres[j % 3][q * NRB + i][e]);
+                if (m < g.M) amax_run = fmaxf(fmaxf(amax_run, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
               } else if constexpr (RES) {
                 v += rres[j % 3][q * NRB + i];
               }
@@ -1304,6 +1307,9 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
            (double)st_body / st_n, st_nepi, st_nepi ? (double)st_epi / st_nepi : 0.0, dt, (double)dt / (double)dr * 0.1);
   }
 #endif
+  if constexpr (GG) {
+    if (g.amax_out) amax_publish(g.amax_out, amax_run);   // (uniform; every lane of the wave is here)
+  }
 #undef Q8S_FENCE
 }
 
@@ -1407,7 +1413,9 @@ int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, 
 // gelu_pre: the pre-activation whose gelu' multiplies a data-gradient product.
 int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out, void* y_pairs,
                const float* gelu_pre, const float* out_scale, int M, int N, int K, int act, void* ksplit_ws, size_t ksplit_ws_bytes_, int* range_flag,
-               hipStream_t s) {
+               float* amax_out, hipStream_t s) {
+  // (max |y| for the caller: the symmetric kernel's x gelu' epilogue publishes it; every other route leaves the call to the general kernel)
+  if (amax_out && (!gelu_pre || q8_kgroup(K) != 1)) return 1;
   Q8Plan pl;
   // the K-split needs the caller's workspace (tt_linear_ksplit_workspace_bytes, counters zeroed by tt_linear_ksplit_workspace_init);
   // without one the left-over tiles are cut into halves / dealt round-robin
@@ -1420,7 +1428,7 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
   int* ks_cnt = pl.ks_S >= 2 ? kw.counters : nullptr;
   Q8Args g{static_cast<const _Float16*>(x_pairs), static_cast<const _Float16*>(w_pairs), M, N, K, bias, gelu_pre ? gelu_pre : residual,
            pre_out ? pre_out : y, static_cast<_Float16*>(y_pairs), pl.ntn, (int)pl.ntiles, pl.ncu, pl.n_full, pl.n_half, q8_order_mode(),
-           pl.ks_S, pl.ks_R, out_scale, ks_ws, ks_cnt, range_flag};
+           pl.ks_S, pl.ks_R, out_scale, ks_ws, ks_cnt, range_flag, amax_out};
 #ifdef TT_Q8_ABLATE   // timing-study build only: TT_Q8_DBG selects a crippled instantiation
   if (kgroup == 3) {
     const char* e = getenv("TT_Q8_DBG");

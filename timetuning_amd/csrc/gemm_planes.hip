@@ -64,6 +64,8 @@ struct PlaneArgs {
   const float* out_scale; // PAIR: device scalar S (a power of two) by which an operand was scaled before its split (a gradient: see
                           // transpose_pairs_tile) - the product is divided by it; null: none
   int* range_flag;        // PAIR outputs: device word set to 1 when an output's hi leaves fp16's range (common.hpp pair_hi_bad); null: none
+  float* amax_out;        // device float or null: max |C| is published into it (common.hpp amax_publish: a data gradient that is the next
+                          // Linear's dy leaves its maximum for that dy's pair split)
 };
 
 // x -> up to three bf16 planes with x = p0 + p1 + p2 (exact when 3 planes are taken and no exponent underflow)
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(Pl
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = g.bias ? g.bias[n + e] : 0.f;
   const float inv_s = (PAIR && g.out_scale) ? 1.0f / *g.out_scale : 1.0f;   // exact: S is a power of two
+  float am = 0.f;
 #pragma unroll
   for (int wmi = 0; wmi < GM; ++wmi) {
     if (computes && wm == wmi) {
@@ -354,6 +357,10 @@ __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(Pl
           float* c = g.C + (size_t)blockIdx.y * g.split_stride + off;
           *reinterpret_cast<float4*>(c) = *reinterpret_cast<const float4*>(v);
           *reinterpret_cast<float4*>(c + 4) = *reinterpret_cast<const float4*>(v + 4);
+          if (g.amax_out) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(v[e]));
+          }
         }
         if constexpr (PAIR) {
           if (g.po > 0) {   // pairs [M][2 N]: this thread's 8 columns lie in one group of 32
@@ -389,6 +396,7 @@ __global__ __launch_bounds__(64 * GM * GN * (1 + LD)) void gemm_planes_kernel(Pl
     }
     __syncthreads();
   }
+  if (g.amax_out) amax_publish(g.amax_out, am);   // (uniform; every lane is here)
 }
 
 template <int P, int BK, int WM, int WN, int NBUF = 2, int GM = 2, int GN = 2, int LD = 0, bool PAIR = false>
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(256) void join_pairs_kernel(const _Float16* __restr
 
 int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out, void* y_pairs,
                const float* gelu_pre, const float* out_scale, int M, int N, int K, int act, void* ksplit_ws, size_t ksplit_ws_bytes_, int* range_flag,
-               hipStream_t s);                                                                                        // gemm_pairs8.hip
+               float* amax_out, hipStream_t s);                                                                       // gemm_pairs8.hip
 int pairs8_would_run(int M, int N, int K, int act, int has_residual, int has_y, int has_pairs, int has_pre, int has_gelu_pre);
 
 // ---- transposed pairs: the operands of the backward products in the "f16x3" mode (reduction index contiguous, in pair groups).
@@ -565,7 +573,9 @@ __device__ __forceinline__ void transpose_pairs_tile(const void* __restrict__ sr
     float S = 1.0f;
     if (amax_part) {   // (uniform) fold of the <= 256 partial maxima: one per thread, then across the four waves
       __shared__ float sred[4];
-      float m = (int)threadIdx.x < n_part ? amax_part[threadIdx.x] : 0.f;
+      // (n_part < 0: the -n_part ways of a producer's amax slot, kAmaxStride floats apart - common.hpp amax_publish)
+      float m = n_part < 0 ? ((int)threadIdx.x < -n_part ? amax_part[threadIdx.x * kAmaxStride] : 0.f)
+                           : ((int)threadIdx.x < n_part ? amax_part[threadIdx.x] : 0.f);
       m = wave_max(m);
       if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = m;
       __syncthreads();
@@ -927,7 +937,7 @@ extern "C" int tt_join_pairs(const void* src_pairs, float* dst, long long n, tt_
 static int linear_pairs_impl(const void* x_pairs, const void* w_pairs, const float* bias, const float* residual, float* y, float* pre_out,
                              void* y_pairs, int M, int N, int K, int act, const float* gelu_pre, int splits, long long split_stride,
                              tt_stream_t stream, const float* out_scale = nullptr, void* ksplit_ws = nullptr, size_t ksplit_ws_bytes_ = 0,
-                             int* range_flag = nullptr) {
+                             int* range_flag = nullptr, float* amax_out = nullptr) {
   TT_REQUIRE(x_pairs && w_pairs && (y || y_pairs), "linear_fwd_pairs: null operand / no output");
   TT_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 32 == 0, "linear_fwd_pairs: need N %% 64 == 0 and K %% 32 == 0 (got N=%d K=%d)", N, K);
   auto ok16 = [](const void* p) { return p == nullptr || aligned16(p); };
@@ -939,12 +949,12 @@ static int linear_pairs_impl(const void* x_pairs, const void* w_pairs, const flo
   const bool no8 = tuning_knob(KNOB_PAIRS_NO8) != 0;   // tuning aid: the general kernel everywhere
   if (!no8 && splits == 1) {
     const int rc = pairs8_try(x_pairs, w_pairs, bias, residual, y, pre_out, y_pairs, gelu_pre, out_scale, M, N, K, act, ksplit_ws, ksplit_ws_bytes_,
-                              range_flag, s);
+                              range_flag, amax_out, s);
     if (rc <= 0) return rc;
   }
   // the general kernel sees rows of 2 K 16-bit elements in K-tiles of 64 (= one pair group)
   PlaneArgs g{static_cast<const __bf16*>(x_pairs), static_cast<const __bf16*>(w_pairs), 0, 0, M, N, 2 * K, bias, residual, y,
-              pre_out, static_cast<__bf16*>(y_pairs), 0, y_pairs ? 1 : 0, act, gelu_pre, splits, split_stride, out_scale, range_flag};
+              pre_out, static_cast<__bf16*>(y_pairs), 0, y_pairs ? 1 : 0, act, gelu_pre, splits, split_stride, out_scale, range_flag, amax_out};
   const long long t128 = (long long)((M + 127) / 128) * (N / 128);
   const bool big = (N % 128 == 0) && t128 * splits >= 3 * 256;
   const bool wide = (N % 128 == 0) && (long long)((M + 63) / 64) * (N / 128) * splits >= 2 * 256;
@@ -990,11 +1000,12 @@ extern "C" size_t tt_split_pairs_dual_workspace_bytes(int R, int C, int Rpad) {
 // colsum_parts (tt_split_pairs_dual_parts): the column partial sums [ceil(Rpad / 64)][C] are LEFT there, unfolded, for the launch that
 // folds the weight gradient's split partials to fold them too (tt_linear_bwd_weight_pairs_tn_bias: one launch less per dy)
 static int split_pairs_dual_impl(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum, float* colsum_parts, float* scale_out, int R,
-                                 int C, int Rpad, void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream) {
+                                 int C, int Rpad, void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream,
+                                 const float* amax_in = nullptr) {
   TT_REQUIRE(src && (dst_t_pairs || dst_row_pairs) && R > 0 && C > 0 && Rpad >= R && Rpad % 32 == 0,
              "split_pairs_dual: bad arguments (an output, Rpad a multiple of 32)");
   TT_REQUIRE(!dst_row_pairs || C % 32 == 0, "split_pairs_dual: row-major pairs need C %% 32 == 0 (got %d)", C);
-  TT_REQUIRE(!(colsum || scale_out) || (workspace && workspace_bytes >= tt_split_pairs_dual_workspace_bytes(R, C, Rpad)),
+  TT_REQUIRE(!((colsum && !colsum_parts) || (scale_out && !amax_in)) || (workspace && workspace_bytes >= tt_split_pairs_dual_workspace_bytes(R, C, Rpad)),
              "split_pairs_dual: workspace too small");   // (colsum_parts + scale: the max pass's partials still live behind the colsum region)
   TT_REQUIRE((reinterpret_cast<uintptr_t>(dst_t_pairs) & 7u) == 0, "split_pairs_dual: the transposed output must be 8-byte aligned");
   TT_REQUIRE(!scale_out || aligned16(src), "split_pairs_dual: a scaled split needs a 16-byte aligned source");
@@ -1006,7 +1017,10 @@ static int split_pairs_dual_impl(const float* src, void* dst_t_pairs, void* dst_
   if (colsum_parts) colsum = colsum_parts;   // (non-null: the SUM instantiations below; never folded here)
   float* amax_part = nullptr;
   int n_part = 0;
-  if (scale_out) {
+  if (scale_out && amax_in) {   // the producer of src left max |src| there (amax_publish): no max pass
+    amax_part = const_cast<float*>(amax_in);
+    n_part = -kAmaxWays;
+  } else if (scale_out) {
     amax_part = static_cast<float*>(workspace) + (size_t)((Rpad + 63) / 64) * C;
     const long long n = (long long)R * C;
     n_part = (int)((n + 4095) / 4096 < kAmaxParts ? (n + 4095) / 4096 : kAmaxParts);
@@ -1024,10 +1038,13 @@ extern "C" int tt_split_pairs_dual(const float* src, void* dst_t_pairs, void* ds
                                    void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream) {
   return split_pairs_dual_impl(src, dst_t_pairs, dst_row_pairs, colsum, nullptr, scale_out, R, C, Rpad, workspace, workspace_bytes, range_flag, stream);
 }
-extern "C" int tt_split_pairs_dual_parts(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum_parts, float* scale_out, int R, int C,
-                                         int Rpad, void* workspace, size_t workspace_bytes, int* range_flag, tt_stream_t stream) {
+extern "C" int tt_split_pairs_dual_parts(const float* src, void* dst_t_pairs, void* dst_row_pairs, float* colsum_parts, float* scale_out,
+                                         const float* amax_in, int R, int C, int Rpad, void* workspace, size_t workspace_bytes, int* range_flag,
+                                         tt_stream_t stream) {
   TT_REQUIRE(colsum_parts && aligned16(colsum_parts), "split_pairs_dual_parts: colsum_parts [ceil(Rpad / 64)][C] is required (16-byte aligned)");
-  return split_pairs_dual_impl(src, dst_t_pairs, dst_row_pairs, nullptr, colsum_parts, scale_out, R, C, Rpad, workspace, workspace_bytes, range_flag, stream);
+  TT_REQUIRE(!amax_in || scale_out, "split_pairs_dual_parts: amax_in is the scaled split's maximum (scale_out required)");
+  return split_pairs_dual_impl(src, dst_t_pairs, dst_row_pairs, nullptr, colsum_parts, scale_out, R, C, Rpad, workspace, workspace_bytes, range_flag, stream,
+                               amax_in);
 }
 
 // n fp32 matrices [R_i][C_i] -> row pairs and / or transposed pairs [C_i][2 Rpad_i] each, ONE launch per 32 of them
@@ -1075,9 +1092,10 @@ extern "C" int tt_transpose_pairs(const void* src_pairs, void* dst_t_pairs, int 
 // dx[M,K] = dy[M,N] @ w[N,K] (* gelu'(gelu_pre)): dy in pairs [M][2 N], the weight TRANSPOSED in pairs wT [K][2 N].
 // dy_scale (device scalar or null): the pairs hold dy * S (tt_split_pairs_dual's scale_out) - the product is divided by S.
 extern "C" int tt_linear_bwd_data_pairs(const void* dy_pairs, const void* wT_pairs, const float* gelu_pre, float* dx, const float* dy_scale, int M,
-                                        int N, int K, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+                                        int N, int K, void* workspace, size_t workspace_bytes, float* amax_out, tt_stream_t stream) {
   TT_REQUIRE(dx, "linear_bwd_data_pairs: null output");
-  return linear_pairs_impl(dy_pairs, wT_pairs, nullptr, nullptr, dx, nullptr, nullptr, M, K, N, 0, gelu_pre, 1, 0, stream, dy_scale, workspace, workspace_bytes);
+  return linear_pairs_impl(dy_pairs, wT_pairs, nullptr, nullptr, dx, nullptr, nullptr, M, K, N, 0, gelu_pre, 1, 0, stream, dy_scale, workspace, workspace_bytes,
+                           nullptr, amax_out);
 }
 
 // dw[N,K] = dy[M,N]^T @ x[M,K]: both operands transposed in pairs, dyT [N][2 Mpad], xT [K][2 Mpad] (zero beyond M).  Split-K over Mpad

@@ -338,8 +338,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
                                                             float* __restrict__ partial, int rows, int D, int rows_per_wg,
-                                                            int add_to_dx, int skip_group) {
+                                                            int add_to_dx, int skip_group, float* __restrict__ amax_out) {
   __shared__ float red[4][2][64 * kMaxPerLane];
+  float am = 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_wg;
   const int r1 = min(rows, r0 + rows_per_wg);
@@ -377,10 +378,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       const int c = lane + 64 * i;
       if (c < D) {
         const float o = rs * (gy[i] - c2 - xh[i] * c1);
-        dxr[c] = add_to_dx ? dxr[c] + o : o;
+        const float w = add_to_dx ? dxr[c] + o : o;
+        dxr[c] = w;
+        am = fmaxf(am, fabsf(w));
       }
     }
   }
+  if (amax_out) amax_publish(amax_out, am);
   if (!partial) return;
 #pragma unroll
   for (int i = 0; i < kMaxPerLane; ++i) {
@@ -406,8 +410,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, float* __restrict__ dx,
                                                                 float* __restrict__ partial, int rows, int rows_per_wg, int add_to_dx,
-                                                                int skip_group) {
+                                                                int skip_group, float* __restrict__ amax_out) {
   constexpr int D = 128 * NV;
+  float am = 0.f;
   __shared__ float2 red[4][2][64 * NV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_wg;
@@ -460,9 +465,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
           o.x += old.x; o.y += old.y;
         }
         dxr[lane + 64 * i] = o;
+        am = fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y)));
       }
     }
   }
+  if (amax_out) amax_publish(amax_out, am);
   if (!partial) return;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -554,10 +561,11 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* x, int ldx
 
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ xn,
                                                          const float* __restrict__ inv_norm, float* __restrict__ dx,
-                                                         int rows, int D) {
+                                                         int rows, int D, float* __restrict__ amax_out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  float am = 0.f;
   float a[kMaxPerLane], b[kMaxPerLane];
   float s = 0.f;
 #pragma unroll
@@ -571,8 +579,13 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < kMaxPerLane; ++i) {
     const int c = lane + 64 * i;
-    if (c < D) dx[(long long)row * D + c] = (a[i] - b[i] * dot) * inv;
+    if (c < D) {
+      const float w = (a[i] - b[i] * dot) * inv;
+      dx[(long long)row * D + c] = w;
+      am = fmaxf(am, fabsf(w));
+    }
   }
+  if (amax_out) amax_publish(amax_out, am);
 }
 
 // cls rows of the token tensor: tokens[f][0][:] = cls + pos[0] (dino_vision_transformer.py:241-245)
@@ -755,7 +768,7 @@ extern "C" size_t tt_layernorm_bwd_workspace_bytes(int rows, int D) { return (si
 
 extern "C" int tt_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                 float* dx, float* dgamma, float* dbeta, int rows, int D, int add_to_dx, int skip_group,
-                                void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+                                void* workspace, size_t workspace_bytes, float* amax_out, tt_stream_t stream) {
   TT_REQUIRE(skip_group == 0 || (skip_group >= 2 && rows % (skip_group - 1) == 0), "layernorm_bwd: rows must be a multiple of skip_group - 1");
   TT_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
   TT_REQUIRE(rows > 0 && D > 0 && D <= 64 * kMaxPerLane, "layernorm_bwd: need 0 < D <= %d", 64 * kMaxPerLane);
@@ -769,11 +782,11 @@ extern "C" int tt_layernorm_bwd(const float* dy, const float* x, const float* ga
                      reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(partial)) & 7u) == 0;
   hipStream_t s = as_stream(stream);
   const dim3 grid(wgs), block(256);
-  if (al8 && D == 384) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<3>), grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, rpw, add_to_dx, skip_group);
-  else if (al8 && D == 768) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<6>), grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, rpw, add_to_dx, skip_group);
-  else if (al8 && D == 128) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<1>), grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, rpw, add_to_dx, skip_group);
+  if (al8 && D == 384) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<3>), grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, rpw, add_to_dx, skip_group, amax_out);
+  else if (al8 && D == 768) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<6>), grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, rpw, add_to_dx, skip_group, amax_out);
+  else if (al8 && D == 128) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<1>), grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, rpw, add_to_dx, skip_group, amax_out);
   else
-    hipLaunchKernelGGL(layernorm_bwd_kernel, grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, D, rpw, add_to_dx, skip_group);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, D, rpw, add_to_dx, skip_group, amax_out);
   TT_CHECK_LAUNCH("layernorm_bwd");
   if (want) {
     hipLaunchKernelGGL(colsum_stage2_pair, dim3((D + 63) / 64, 2), dim3(256), 0, as_stream(stream), partial, dgamma, dbeta, wgs, D);
@@ -803,10 +816,10 @@ extern "C" int tt_l2norm_fwd(const float* x, int ldx, float* xn, float* inv_norm
   return TT_OK;
 }
 
-extern "C" int tt_l2norm_bwd(const float* dxn, const float* xn, const float* inv_norm, float* dx, int rows, int D,
+extern "C" int tt_l2norm_bwd(const float* dxn, const float* xn, const float* inv_norm, float* dx, int rows, int D, float* amax_out,
                              tt_stream_t stream) {
   TT_REQUIRE(dxn && xn && inv_norm && dx && rows > 0 && D > 0 && D <= 64 * kMaxPerLane, "l2norm_bwd: bad arguments");
-  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), dxn, xn, inv_norm, dx, rows, D);
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), dxn, xn, inv_norm, dx, rows, D, amax_out);
   TT_CHECK_LAUNCH("l2norm_bwd");
   return TT_OK;
 }

@@ -214,9 +214,11 @@ def weight_pairs_t(w: torch.Tensor) -> torch.Tensor:
 
 
 def _bwd_both_pairs(dy: torch.Tensor, w: torch.Tensor, xp: torch.Tensor, gelu_pre: Optional[torch.Tensor] = None, need_dx: bool = True,
-                    dw_out=None, db_out=None):
-    """(dx, dw, db) of an nn.Linear on pair operands: xp = the layer's input as kept by the forward (row-major pairs [M, 2 K])."""
-    return ops.linear_bwd_pairs(dy, weight_pairs_t(w), gelu_pre=gelu_pre, need_dx=need_dx, dw_out=dw_out, db_out=db_out, x_pairs=xp)
+                    dw_out=None, db_out=None, dy_amax=None, dx_amax_out=None):
+    """(dx, dw, db) of an nn.Linear on pair operands: xp = the layer's input as kept by the forward (row-major pairs [M, 2 K]).
+    ``dy_amax`` / ``dx_amax_out``: the maxima the gradient producers publish for the pair splits (``ops.AmaxPool``)."""
+    return ops.linear_bwd_pairs(dy, weight_pairs_t(w), gelu_pre=gelu_pre, need_dx=need_dx, dw_out=dw_out, db_out=db_out, x_pairs=xp,
+                                dy_amax=dy_amax, dx_amax_out=dx_amax_out if need_dx else None)
 
 
 def _bwd_weight(dy: torch.Tensor, x: torch.Tensor, need_bias: bool = True):
@@ -242,32 +244,41 @@ def _bwd_both(dy: torch.Tensor, w: torch.Tensor, x: torch.Tensor, gelu_pre: Opti
 
 
 def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int, f1: int, grads: Dict[torch.nn.Parameter, torch.Tensor],
-                   need_dx: bool = True, after_mlp=None, out=None) -> Optional[torch.Tensor]:
+                   need_dx: bool = True, after_mlp=None, out=None, dx_out_amax=None, amax_pool=None):
     """Backward of one block restricted to frames [f0, f1) of the saved activations.  dx_out [(f1-f0)*N, D]
     is consumed (overwritten).  Writes parameter gradients into ``grads``.  ``after_mlp()`` is called once the MLP's
     gradients (two thirds of a block's parameters) exist - the data-parallel exchange sends them while the attention half runs.
     ``out(param)`` -> a caller-owned destination for that parameter's gradient or None (``GradExchange.out``: the kernels then write the
-    exchange's flat buckets directly)."""
+    exchange's flat buckets directly).  "f16x3" mode: ``amax_pool`` (``ops.AmaxPool``) hands out the slots in which the kernel that
+    PRODUCES a dy leaves max |dy| for that dy's scaled pair split (no max pass per dy); ``dx_out_amax`` = that slot for ``dx_out``.
+    Returns dx_in - with ``amax_pool``: (dx_in, its slot)."""
+    take = amax_pool.take if amax_pool is not None else (lambda: None)
     Fr, N, D = sv["x_in"].shape
     r0, r1 = f0 * N, f1 * N
     out = out or (lambda p: None)
     o = lambda lin: dict(dw_out=out(lin.weight), db_out=out(lin.bias))
     oln = lambda ln: dict(dg_out=out(ln.weight), db_out=out(ln.bias))
     if sv.get("pairs"):   # the "f16x3" mode: the four Linears' backward products on pair operands
+        a_fc1, a_proj, a_qkv, a_in = take(), take(), take(), take()
         d_pre, grads[blk.mlp.fc2.weight], grads[blk.mlp.fc2.bias] = _bwd_both_pairs(dx_out, blk.mlp.fc2.weight, sv["ap"][r0:r1], sv["pre"][r0:r1],
-                                                                                     **o(blk.mlp.fc2))
-        d_h2, grads[blk.mlp.fc1.weight], grads[blk.mlp.fc1.bias] = _bwd_both_pairs(d_pre, blk.mlp.fc1.weight, sv["h2p"][r0:r1], **o(blk.mlp.fc1))
+                                                                                     dy_amax=dx_out_amax, dx_amax_out=a_fc1, **o(blk.mlp.fc2))
+        d_h2, grads[blk.mlp.fc1.weight], grads[blk.mlp.fc1.bias] = _bwd_both_pairs(d_pre, blk.mlp.fc1.weight, sv["h2p"][r0:r1], dy_amax=a_fc1,
+                                                                                    **o(blk.mlp.fc1))
         dx_mid, grads[blk.norm2.weight], grads[blk.norm2.bias] = ops.layernorm_bwd(
-            d_h2, sv["x_mid"][r0:r1], blk.norm2.weight, sv["mean2"][r0:r1], sv["rstd2"][r0:r1], dx_accum=dx_out, **oln(blk.norm2))
+            d_h2, sv["x_mid"][r0:r1], blk.norm2.weight, sv["mean2"][r0:r1], sv["rstd2"][r0:r1], dx_accum=dx_out, amax_out=a_proj, **oln(blk.norm2))
         if after_mlp is not None:
             after_mlp()
         d_att, grads[blk.attn.proj.weight], grads[blk.attn.proj.bias] = _bwd_both_pairs(dx_mid, blk.attn.proj.weight, sv["attp"][r0:r1],
-                                                                                        **o(blk.attn.proj))
-        dqkv = ops.attention_bwd(sv["qkv"].view(Fr, N, 3 * D)[f0:f1], sv["att"][f0:f1], d_att.view(f1 - f0, N, D), sv["lse"][f0:f1], num_heads)
+                                                                                        dy_amax=a_proj, **o(blk.attn.proj))
+        dqkv = ops.attention_bwd(sv["qkv"].view(Fr, N, 3 * D)[f0:f1], sv["att"][f0:f1], d_att.view(f1 - f0, N, D), sv["lse"][f0:f1], num_heads,
+                                 amax_out=a_qkv)
         d_h1, grads[blk.attn.qkv.weight], grads[blk.attn.qkv.bias] = _bwd_both_pairs(dqkv.view((f1 - f0) * N, 3 * D), blk.attn.qkv.weight,
-                                                                                       sv["h1p"][r0:r1], **o(blk.attn.qkv))
+                                                                                       sv["h1p"][r0:r1], dy_amax=a_qkv, **o(blk.attn.qkv))
         dx_in, grads[blk.norm1.weight], grads[blk.norm1.bias] = ops.layernorm_bwd(
-            d_h1, sv["x_in"].view(Fr * N, D)[r0:r1], blk.norm1.weight, sv["mean1"][r0:r1], sv["rstd1"][r0:r1], dx_accum=dx_mid, **oln(blk.norm1))
+            d_h1, sv["x_in"].view(Fr * N, D)[r0:r1], blk.norm1.weight, sv["mean1"][r0:r1], sv["rstd1"][r0:r1], dx_accum=dx_mid,
+            amax_out=a_in if need_dx else None, **oln(blk.norm1))
+        if amax_pool is not None:
+            return (dx_in, a_in) if need_dx else (None, None)
         return dx_in if need_dx else None
     a, pre, h2 = sv["a"][r0:r1], sv["pre"][r0:r1], sv["h2"][r0:r1]
     # x_out = x_mid + fc2(gelu(fc1(ln2(x_mid))))
@@ -290,6 +301,8 @@ def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int,
     x_in = sv["x_in"].view(Fr * N, D)[r0:r1]
     dx_in, grads[blk.norm1.weight], grads[blk.norm1.bias] = ops.layernorm_bwd(
         d_h1, x_in, blk.norm1.weight, sv["mean1"][r0:r1], sv["rstd1"][r0:r1], dx_accum=dx_mid, **oln(blk.norm1))
+    if amax_pool is not None:   # (a block whose launches are under the pair threshold: no slot for its dx)
+        return (dx_in if need_dx else None), None
     return dx_in if need_dx else None
 
 
@@ -510,15 +523,22 @@ def head_forward(x: torch.Tensor, head, save: Optional[dict] = None) -> torch.Te
     return x
 
 
-def head_backward(dz: torch.Tensor, head, sv: dict, grads, out=None) -> torch.Tensor:
+def head_backward(dz: torch.Tensor, head, sv: dict, grads, out=None, dz_amax=None, amax_pool=None) -> torch.Tensor:
+    """``dz_amax`` / ``amax_pool`` ("f16x3" mode): as ``block_backward`` - max |dz| from the kernel that wrote dz, and the slots in which
+    each Linear's gelu' data gradient leaves the maximum of the next dy."""
     lins = head_linears(head)
     out = out or (lambda p: None)
-    d = dz
+    d, d_amax = dz, dz_amax
     for i in range(len(lins) - 1, -1, -1):
         lin = lins[i]
-        both = _bwd_both_pairs if sv.get("pairs") else _bwd_both
-        d, grads[lin.weight], grads[lin.bias] = both(d, lin.weight, sv["acts"][i], sv["pres"][i - 1] if i > 0 else None,
-                                                     dw_out=out(lin.weight), db_out=out(lin.bias))
+        if sv.get("pairs"):
+            nxt = amax_pool.take() if (amax_pool is not None and i > 0) else None   # (i == 0: its dx feeds the final norm, not a Linear)
+            d, grads[lin.weight], grads[lin.bias] = _bwd_both_pairs(d, lin.weight, sv["acts"][i], sv["pres"][i - 1] if i > 0 else None,
+                                                                    dw_out=out(lin.weight), db_out=out(lin.bias), dy_amax=d_amax, dx_amax_out=nxt)
+            d_amax = nxt
+        else:
+            d, grads[lin.weight], grads[lin.bias] = _bwd_both(d, lin.weight, sv["acts"][i], sv["pres"][i - 1] if i > 0 else None,
+                                                              dw_out=out(lin.weight), db_out=out(lin.bias))
     return d
 
 

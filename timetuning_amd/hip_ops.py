@@ -149,6 +149,7 @@ def pairs() -> bool:
 # 300 -> 1.98-2.02, 200 -> 1.97-2.02, 0 -> 1.99-2.07: 256.  Tests set it to 0 to drive the pair kernels with tiny models.
 PAIRS_MIN_ROWS = int(os.environ.get("TT_PAIRS_MIN_ROWS", "256"))   # (the environment variable: sweeps only)
 GRAD_SCALE = os.environ.get("TT_NO_GRAD_SCALE") != "1"   # gradients are scaled by a power of two before their pair split (A/B aid: off)
+AMAX_FROM_PRODUCERS = os.environ.get("TT_NO_AMAX_POOL") != "1"   # the gradient scale's maximum from the kernel that produced the dy (A/B aid: off = a max pass per dy)
 TN_WGRAD = True   # weight gradients of the "f16x3" mode from row pairs (gemm_pairs_tn.hip); False: the transposed-operand route (A/B, tests)
 
 
@@ -431,9 +432,11 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6, save_stats=False, out=None, drop_fir
     return (y, mean, rstd) if save_stats else y
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, dx_accum=None, drop_first_token=False, dg_out=None, db_out=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, dx_accum=None, drop_first_token=False, dg_out=None, db_out=None, amax_out=None):
     """Returns (dx, dgamma, dbeta).  dx_accum: tensor to accumulate dx into (residual branch).
-    drop_first_token: dy is [F*(N-1), D] against x [F,N,D]; dx is [F,N,D] with zero cls rows."""
+    drop_first_token: dy is [F*(N-1), D] against x [F,N,D]; dx is [F,N,D] with zero cls rows.
+    ``amax_out``: a zeroed 1-float device tensor (``AmaxPool.take``) the kernel raises to max |dx| - dx is the next Linear's dy, whose pair
+    split then needs no max pass (``linear_bwd_pairs(dy_amax=)``)."""
     lib = _lib.load()
     _chk(dy, "dy"); _chk(x, "x")
     D = x.shape[-1]
@@ -450,7 +453,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, dx_accum=None, drop
     nb = lib.tt_layernorm_bwd_workspace_bytes(rows, D)
     ws = _ws(nb, x.device)
     _lib.check(lib.tt_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), rows, D,
-                                    1 if dx_accum is not None else 0, skip, _p(ws), nb, _stream()), "tt_layernorm_bwd")
+                                    1 if dx_accum is not None else 0, skip, _p(ws), nb, _p(amax_out), _stream()), "tt_layernorm_bwd")
     return dx, dg, db
 
 
@@ -469,7 +472,7 @@ def attention_fwd(qkv, num_heads: int, save_lse=False, return_probs=False):
     return out, lse, probs
 
 
-def attention_bwd(qkv, out, dout, lse, num_heads: int, bf16_products: bool = False):
+def attention_bwd(qkv, out, dout, lse, num_heads: int, bf16_products: bool = False, amax_out=None):
     """dqkv of the fused attention core from the forward's out / lse.  ``bf16_products``: the matrix products on bf16 MFMA
     (tt_attention_bwd_bf16 - the "bf16" precision mode's backward; statistics, P and dS stay fp32)."""
     lib = _lib.load()
@@ -479,9 +482,12 @@ def attention_bwd(qkv, out, dout, lse, num_heads: int, bf16_products: bool = Fal
     dqkv = torch.empty_like(qkv)
     nb = lib.tt_attention_bwd_workspace_bytes(F, N, num_heads, hd)
     ws = _ws(nb, qkv.device)
-    fn = lib.tt_attention_bwd_bf16 if bf16_products else lib.tt_attention_bwd
-    _lib.check(fn(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), F, N, num_heads, hd, float(hd ** -0.5), _p(ws), nb, _stream()),
-               "tt_attention_bwd_bf16" if bf16_products else "tt_attention_bwd")
+    if bf16_products:
+        _lib.check(lib.tt_attention_bwd_bf16(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), F, N, num_heads, hd, float(hd ** -0.5), _p(ws), nb, _stream()),
+                   "tt_attention_bwd_bf16")
+    else:   # (amax_out: max |dqkv| for the pair split of the qkv Linear's dy, as layernorm_bwd)
+        _lib.check(lib.tt_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), F, N, num_heads, hd, float(hd ** -0.5), _p(ws), nb, _p(amax_out),
+                                        _stream()), "tt_attention_bwd")
     return dqkv
 
 
@@ -499,13 +505,44 @@ def l2norm_fwd(x, save_inv=False, out=None):
     return (xn, inv) if save_inv else xn
 
 
-def l2norm_bwd(dxn, xn, inv):
+def l2norm_bwd(dxn, xn, inv, amax_out=None):
     lib = _lib.load()
     _chk(dxn, "dxn"); _chk(xn, "xn"); _chk(inv, "inv")
     rows, D = xn.shape
     dx = torch.empty_like(xn)
-    _lib.check(lib.tt_l2norm_bwd(_p(dxn), _p(xn), _p(inv), _p(dx), rows, D, _stream()), "tt_l2norm_bwd")
+    _lib.check(lib.tt_l2norm_bwd(_p(dxn), _p(xn), _p(inv), _p(dx), rows, D, _p(amax_out), _stream()), "tt_l2norm_bwd")
     return dx
+
+
+class AmaxPool:
+    """Zeroed 1-float device slots for the maxima the gradient PRODUCERS publish (``amax_out`` of layernorm_bwd / attention_bwd /
+    l2norm_bwd / the gelu' data gradient) and the pair split of that gradient consumes (``linear_bwd_pairs(dy_amax=)``): one ``reset()`` (a
+    64-float fill) at the top of a backward instead of a max pass over every dy (12 per C2 step, 0.11 ms)."""
+    _pools: dict = {}
+
+    def __init__(self, device):
+        self.SLOT = _lib.load().tt_amax_slot_bytes() // 4   # floats per slot: 16 ways, 64 floats apart (the producers spread their atomics)
+        self.buf = torch.zeros(24 * self.SLOT, dtype=f32, device=device)
+        self.n = 0
+
+    @classmethod
+    def get(cls, device) -> "AmaxPool":
+        dev = torch.device(device)
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
+        p = cls._pools.get(key)
+        if p is None:
+            p = cls._pools[key] = cls(dev)
+        return p
+
+    def reset(self) -> None:
+        self.buf.zero_()
+        self.n = 0
+
+    def take(self):
+        if (self.n + 1) * self.SLOT > self.buf.numel():
+            return None            # (more gradients than slots: those splits make their own max pass)
+        self.n += 1
+        return self.buf[(self.n - 1) * self.SLOT:self.n * self.SLOT]
 
 
 def normalize_rows_(w):
@@ -1068,7 +1105,7 @@ def attention_fwd_pairs(qkv_pairs, num_heads: int, out_pairs: bool = True, out_f
 
 
 def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad: Optional[int] = None, colsum_out=None, want_t: bool = True,
-                     scaled: bool = False, colsum_parts: bool = False):
+                     scaled: bool = False, colsum_parts: bool = False, amax_in=None):
     """fp32 [R, C] -> (transposed pairs [C, 2 Rpad] or None, row-major pairs [R, 2 C] or None, column sums [C] or None) in ONE pass
     (tt_split_pairs_dual): what the backward of an nn.Linear needs of its dy.  ``scaled`` (a GRADIENT, whose whole magnitude may sit
     below fp16's normal range): the pairs hold x * S with S the power of two that brings max |x| into [2^13, 2^14); a fourth value is
@@ -1085,11 +1122,12 @@ def split_pairs_dual(x, want_row: bool = False, want_colsum: bool = False, rpad:
         t = torch.empty((Cc, 2 * rpad), dtype=f16, device=x.device) if want_t else None
         row = torch.empty((R, 2 * Cc), dtype=f16, device=x.device) if want_row else None
         parts = torch.empty(((rpad + 63) // 64, Cc), dtype=f32, device=x.device)
-        nb = lib.tt_split_pairs_dual_workspace_bytes(R, Cc, rpad) if scaled else 0
-        ws = _ws(nb, x.device) if scaled else None
+        own_max = scaled and amax_in is None
+        nb = lib.tt_split_pairs_dual_workspace_bytes(R, Cc, rpad) if own_max else 0
+        ws = _ws(nb, x.device) if own_max else None
         scale = torch.empty((1,), dtype=f32, device=x.device) if scaled else None
-        _lib.check(lib.tt_split_pairs_dual_parts(_p(x), _p(t), _p(row), _p(parts), _p(scale), R, Cc, rpad, _p(ws), nb, _p(range_flag(x.device)), _stream()),
-                   "tt_split_pairs_dual_parts")
+        _lib.check(lib.tt_split_pairs_dual_parts(_p(x), _p(t), _p(row), _p(parts), _p(scale), _p(amax_in) if scaled else None, R, Cc, rpad, _p(ws), nb,
+                                                 _p(range_flag(x.device)), _stream()), "tt_split_pairs_dual_parts")
         return (t, row, parts, scale) if scaled else (t, row, parts)
     t = torch.empty((Cc, 2 * rpad), dtype=f16, device=x.device) if want_t else None
     row = torch.empty((R, 2 * Cc), dtype=f16, device=x.device) if want_row else None
@@ -1172,11 +1210,14 @@ def linear_bwd_weight_pairs_tn(dy_pairs, x_pairs, dw_out=None, dy_scale=None, co
     return dw
 
 
-def linear_bwd_pairs(dy, wT_pairs, xT_pairs=None, gelu_pre=None, need_bias: bool = True, need_dx: bool = True, dw_out=None, db_out=None, x_pairs=None):
+def linear_bwd_pairs(dy, wT_pairs, xT_pairs=None, gelu_pre=None, need_bias: bool = True, need_dx: bool = True, dw_out=None, db_out=None, x_pairs=None,
+                     dy_amax=None, dx_amax_out=None):
     """(dx, dw, db) of an nn.Linear on pair operands: dy fp32 [M,N] is split here in ONE pass (row pairs for both gradient products, column
     sums = the bias gradient); wT_pairs [K, 2 N] = the weight transposed in pairs.  The layer's input comes as ``x_pairs`` [M, 2 K] (row
     pairs as the forward kept them: the transpose-free weight-gradient kernel) or, for the shapes that kernel does not take, as
-    ``xT_pairs`` [K, 2 Mpad] (``transpose_pairs``; dy's transposed pairs are then made in the same pass)."""
+    ``xT_pairs`` [K, 2 Mpad] (``transpose_pairs``; dy's transposed pairs are then made in the same pass).
+    ``dy_amax``: max |dy| as the kernel that produced dy published it (``AmaxPool``; the scaled split then skips its max pass);
+    ``dx_amax_out``: a zeroed slot the data-gradient kernel raises to max |dx| (dx = the next Linear's dy: the gelu' route)."""
     lib = _lib.load()
     _chk(dy, "dy"); _chk(wT_pairs, "wT_pairs", f16)
     M, N = dy.shape
@@ -1185,7 +1226,8 @@ def linear_bwd_pairs(dy, wT_pairs, xT_pairs=None, gelu_pre=None, need_bias: bool
         _chk(x_pairs, "x_pairs", f16)
         assert wT_pairs.shape == (K, 2 * N) and x_pairs.shape == (M, 2 * K), (dy.shape, wT_pairs.shape, x_pairs.shape)
         # the bias gradient's fold rides on the weight gradient's (one launch less per Linear): the column partials stay unfolded here
-        r4 = split_pairs_dual(dy, want_row=True, want_colsum=need_bias, want_t=False, scaled=GRAD_SCALE, colsum_parts=need_bias)
+        r4 = split_pairs_dual(dy, want_row=True, want_colsum=need_bias, want_t=False, scaled=GRAD_SCALE, colsum_parts=need_bias,
+                              amax_in=dy_amax if (need_bias and GRAD_SCALE) else None)
         dy_row, parts, dy_scale = r4[1], r4[2], (r4[3] if GRAD_SCALE else None)
         if need_bias:
             dw, db = linear_bwd_weight_pairs_tn(dy_row, x_pairs, dw_out, dy_scale, colsum_parts=parts, db_out=db_out)
@@ -1213,8 +1255,8 @@ def linear_bwd_pairs(dy, wT_pairs, xT_pairs=None, gelu_pre=None, need_bias: bool
         p8 = PROFILE is not None and lib.tt_linear_fwd_pairs_route(M, K, N, 0, 0, int(gelu_pre is not None), 1, 0, 0) == 8
         e0 = _prof_begin()
         kws = ksplit_workspace(dx.device)
-        _lib.check(lib.tt_linear_bwd_data_pairs(_p(dy_row), _p(wT_pairs), _p(gelu_pre), _p(dx), _p(dy_scale), M, N, K, _p(kws), kws.numel(), _stream()),
-                   "tt_linear_bwd_data_pairs")
+        _lib.check(lib.tt_linear_bwd_data_pairs(_p(dy_row), _p(wT_pairs), _p(gelu_pre), _p(dx), _p(dy_scale), M, N, K, _p(kws), kws.numel(),
+                                                _p(dx_amax_out), _stream()), "tt_linear_bwd_data_pairs")
         _prof_end(e0, "PAIRS8" if p8 else "PAIRS", M, K, N)
     return dx, dw, db
 

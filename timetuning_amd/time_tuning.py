@@ -574,17 +574,25 @@ class TimeT(nn.Module):
         out = exchange.out
         prescaled = exchange.prescale_(dscores)   # 1 / W once, on the 5 MB loss gradient, instead of on every bucket
         grads[self.prototypes], _ = ops.linear_bwd_weight(dscores, sv_sc["zn"], need_bias=False, dw_out=out(self.prototypes))
-        dz = ops.l2norm_bwd(ops.linear_bwd_data(dscores, self.prototypes.data), sv_sc["zn"], sv_sc["inv"])
+        # "f16x3": every dy of a Linear is scaled by a power of two before its pair split; the kernel that PRODUCES the dy publishes its
+        # max |.| into a slot of this pool (one 64-float fill per step instead of a max pass per dy: 12 launches)
+        pool = ops.AmaxPool.get(dev) if (ops.pairs() and ops.GRAD_SCALE and ops.AMAX_FROM_PRODUCERS) else None
+        if pool is not None:
+            pool.reset()
+        take = pool.take if pool is not None else (lambda: None)
+        a_dz = take()
+        dz = ops.l2norm_bwd(ops.linear_bwd_data(dscores, self.prototypes.data), sv_sc["zn"], sv_sc["inv"], amax_out=a_dz)
         if use_mask:
-            ops.scale_rows_(dz, mask_tgt)  # backward of features * mask
-        d_feats = engine.head_backward(dz, fe.head, sv_head, grads, out=out) if fe.head is not None else dz
+            ops.scale_rows_(dz, mask_tgt)  # backward of features * mask (rows times a number in [0, 1]: a_dz stays an upper bound)
+        d_feats = engine.head_backward(dz, fe.head, sv_head, grads, out=out, dz_amax=a_dz, amax_pool=pool) if fe.head is not None else dz
         exchange.push(grads)  # prototypes + head
         #  the final norm's backward also runs when ONLY that norm is trainable, and its parameter gradients are built when
         # either of them asks for one
         wg = vit.norm.weight.requires_grad or vit.norm.bias.requires_grad
         if train_ids or wg:
+            a_tok = take()
             dx, dg, db = ops.layernorm_bwd(d_feats, tok_hi, vit.norm.weight, mean_f, rstd_f, need_wgrad=wg, drop_first_token=True,
-                                           dg_out=out(vit.norm.weight) if wg else None, db_out=out(vit.norm.bias) if wg else None)
+                                           dg_out=out(vit.norm.weight) if wg else None, db_out=out(vit.norm.bias) if wg else None, amax_out=a_tok)
             if wg:
                 grads[vit.norm.weight], grads[vit.norm.bias] = dg, db
         if train_ids:
@@ -596,7 +604,10 @@ class TimeT(nn.Module):
                 # the LAST block of the backward has nothing after it to hide its bucket behind: its MLP gradients (two thirds of
                 # the block) leave as soon as they exist, so only the attention third is exposed
                 dx = engine.block_backward(dx, vit.blocks[i], vit.num_heads, save[i], b0, b1, grads, need_dx=i > first,
-                                           after_mlp=(lambda: exchange.push(grads)) if i == first else None, out=out)
+                                           after_mlp=(lambda: exchange.push(grads)) if i == first else None, out=out,
+                                           dx_out_amax=a_tok, amax_pool=pool)
+                if pool is not None:
+                    dx, a_tok = dx
                 if i > first:
                     exchange.push(grads)  # this block's gradients travel while the next block's backward runs
         grads = {p: g for p, g in grads.items() if p.requires_grad}
