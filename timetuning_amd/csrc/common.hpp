@@ -80,6 +80,20 @@ __device__ __forceinline__ void amax_publish(float* slot, float m) {
     if (m > cur) __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(way), __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+// ... one access per WORKGROUP of up to 16 waves (every thread must call it; one barrier): for kernels whose waves finish together
+__device__ __forceinline__ void amax_publish_block(float* slot, float m) {
+  __shared__ float wg_max[16];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) wg_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (int)(blockDim.x + 63) >> 6;
+    for (int w = 1; w < nw; ++w) m = fmaxf(m, wg_max[w]);
+    float* way = slot + (blockIdx.x % kAmaxWays) * kAmaxStride;
+    const float cur = __hip_atomic_load(way, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (m > cur) __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(way), __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 
 // exp for softmax probabilities: v_exp_f32 on x * log2(e) (a handful of instructions; ocml's expf is ~10x that and the
 // softmax phase of the attention kernels is pure VALU time during which the matrix pipe idles).  Arguments are <= 0 and

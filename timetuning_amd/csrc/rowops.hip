@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       }
     }
   }
-  if (amax_out) amax_publish(amax_out, am);
+  if (amax_out) amax_publish_block(amax_out, am);   // (uniform: every thread of the workgroup is here)
   if (!partial) return;
 #pragma unroll
   for (int i = 0; i < kMaxPerLane; ++i) {
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
       }
     }
   }
-  if (amax_out) amax_publish(amax_out, am);
+  if (amax_out) amax_publish_block(amax_out, am);   // (uniform: every thread of the workgroup is here)
   if (!partial) return;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
