@@ -33,6 +33,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+import timetuning_amd  # noqa: E402,F401  (first: it switches ROCm's hipGraph packet capture off before the runtime initialises)
 import torch  # noqa: E402
 
 F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
@@ -104,6 +105,63 @@ def train_step(model, opt, x, use_teacher):
     # optimizer.step(loss) + normalize_prototypes() + update_momentum_teacher(step) (time_tuning.py:659-663), one C call
     model.train_update(opt, loss, min(opt.global_step + 1, len(model.momentum_schedule) - 1) if use_teacher else 0)
     return loss
+
+
+def _core(model):
+    return model.get_non_ddp_model() if hasattr(model, "get_non_ddp_model") else model
+
+
+def _snapshot(model, opt):
+    """Everything a training step changes: trainable + teacher tensors, optimizer / scheduler state, the queue, the host generator."""
+    import copy
+
+    core = _core(model)
+    tensors = [p for p in core.parameters() if p.requires_grad]
+    if core.teacher is not None:
+        tensors += list(core.teacher.parameters()) + [core.teacher_prototypes]
+    return dict(tensors=[(t, t.detach().clone()) for t in tensors], opt=copy.deepcopy(opt.optimizer.state_dict()),
+                sched=copy.deepcopy(opt.lr_scheduler.state_dict()) if opt.lr_scheduler is not None else None, global_step=opt.global_step,
+                probe=core.probe_state())
+
+
+def _restore(model, opt, st):
+    from timetuning_amd import hip_ops
+
+    for t, saved in st["tensors"]:
+        # through a raw-pointer kernel (t <- t * 0 + saved): an ATen copy_ would advance the version counters that are part of the step
+        # graph's signature and send the next step down the eager path
+        hip_ops.ema_update_(t.data.view(-1), saved.view(-1), 1.0)
+    import copy
+
+    opt.optimizer.load_state_dict(copy.deepcopy(st["opt"]))
+    if st["sched"] is not None:
+        opt.lr_scheduler.load_state_dict(copy.deepcopy(st["sched"]))
+    opt.global_step = st["global_step"]
+    _core(model).restore_probe_state(st["probe"])
+
+
+def graph_check(model, opt, x, use_teacher):
+    """is the REPLAYED step the eager step, here, on the state the timed region left behind?  One more replayed step
+    and - from the same state - one eager step: loss, every gradient and every updated parameter must be equal bit for bit."""
+    core = _core(model)
+    st = _snapshot(model, opt)
+    n_graphs = len(core._step_graphs)
+    lg = train_step(model, opt, x, use_teacher)
+    gg = [p.grad.clone() for p in core.parameters() if p.grad is not None]
+    pg = [t.detach().clone() for t, _ in st["tensors"]]
+    replayed = len(core._step_graphs) == n_graphs and n_graphs > 0   # (no new capture, no fall-back to the eager path: it WAS a replay)
+    _restore(model, opt, st)
+    core._step_graph_on = False
+    try:
+        le = train_step(model, opt, x, use_teacher)
+    finally:
+        core._step_graph_on = True
+    ge = [p.grad.clone() for p in core.parameters() if p.grad is not None]
+    torch.cuda.synchronize()
+    ok = (replayed and float(lg.item()) == float(le.item()) and len(gg) == len(ge) and all(torch.equal(a, b) for a, b in zip(gg, ge))
+          and all(torch.equal(a, t.detach()) for a, (t, _) in zip(pg, st["tensors"])))
+    return {"replay_equals_eager": bool(ok), "was_replay": bool(replayed), "loss_replay": float(lg.item()), "loss_eager_ref": float(le.item()),
+            "compared": f"loss, {len(ge)} gradients, {len(pg)} updated tensors, bit for bit, from the state the timed region left"}
 
 
 DTYPE_NAMES = {"f16x3": "f32-split(f16x3)", "bf16x6": "f32-split(bf16x6)"}   # (the other modes are named by their mode string)
@@ -516,16 +574,14 @@ def main():
     if world > 1 and not a.no_exchange_autotune:
         # which Sinkhorn exchange / gradient bucketing is faster on THIS node's links is measured, once, before the warm-up (outside the
         # timed region): forward + backward of the real step, no update (engine.autotune_exchange; the choice is printed under `rccl`)
-        q_keep = model.queue.clone() if getattr(model, "queue", None) is not None else None
-
         def _probe_step():
             model.zero_grad(set_to_none=True)
             model(x, None, True, USE_MASK).backward()
 
-        engine.autotune_exchange(_probe_step, device, log=(lambda m: print(m, file=sys.stderr, flush=True)))
+        core_ = model.get_non_ddp_model() if hasattr(model, "get_non_ddp_model") else model
+        engine.autotune_exchange(_probe_step, device, log=(lambda m: print(m, file=sys.stderr, flush=True)),
+                                 state=(core_.probe_state, core_.restore_probe_state))   # queue + host generator put back: same workload for every variant
         model.zero_grad(set_to_none=True)
-        if q_keep is not None:
-            model.set_queue(q_keep)
     if step_graph:
         # the graph of a step is captured at the SECOND occurrence of its signature (the first runs eagerly); with a queue the signature
         # changes once, when the queue fills: run until the replay is steady, so that no capture lands in the W warm-up or the K timed steps
@@ -555,6 +611,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())
+
+    # the replayed step against the eager one (same state), and the eager step's own time beside the replayed one's
+    check = None
+    eager_ms = None
+    if step_graph:
+        check = graph_check(model, opt, x, a.use_teacher)
+        if not check["replay_equals_eager"]:
+            raise SystemExit(f"bench.py: the replayed step is NOT the eager step: {check}")
+        model._step_graph_on = False
+        for _ in range(2):
+            train_step(model, opt, x, a.use_teacher)
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for _ in range(a.steps):
+            train_step(model, opt, x, a.use_teacher)
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - te) / a.steps * 1e3
+        model._step_graph_on = True
 
     out = None
     # the instrumented step contains the step's collectives (score all-gather, gradient all-reduce): EVERY rank runs it
@@ -606,6 +680,8 @@ def main():
                        "global_batch": bs * world, "parallelism": f"dp{world}"},
             "loss": round(final_loss, 5),
             "step_graph": bool(step_graph),   # True: the timed steps replay ONE captured hipGraph of the step's launch sequence (+ the eager optimizer call)
+            "ms_per_step_eager": None if eager_ms is None else round(eager_ms, 3),   # the same step launch by launch (what an N > 1 rank runs), same process
+            "graph_check": check,             # the replayed step == the eager step from the same state, bit for bit (asserted)
             # proof of what carried the exchange: RCCL ("nccl") saw this many ranks (None for the single-process run)
             # with the compute stream's exposed wait per collective in the instrumented step
             "rccl": dict(rccl_report(dist, headline_waits), exchange_autotune=engine.EXCHANGE_CHOICE) if world > 1 else None,

@@ -8,6 +8,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, "tests", "golden")
+import timetuning_amd  # noqa: E402,F401  (before the first HIP call - torch.cuda.is_available() below: it switches ROCm's hipGraph packet capture off)
 
 
 def pytest_configure(config):

@@ -391,6 +391,179 @@ def test_step_graph_sees_rewritten_frozen_weights(accurate_precision):
     assert len(mg._step_graphs) == 2   # before and after the rewrite
 
 
+GRAPH_CASES = [("c2", "f16x3", 12), ("c3", "f16x3", 10), ("c5", "f16x3", 6), ("c4", "bf16", 6), ("c4", "f16x3", 5)]
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("cfg,mode,steps", GRAPH_CASES)
+def test_step_graph_equals_eager_at_baseline_shapes(cfg, mode, steps):
+    """the captured step IS the eager step at every BASELINE shape - C2 (32 x 4, K 200), C3 (EMA teacher + full 2048-row
+    queue, 32 clips), C5 (16 x 4, ViT-S/8), C4 (16 x 8, ViT-B/16, K 400) in the "bf16" mode and in the default one - with the bench's own
+    dispatch thresholds (PAIRS_MIN_ROWS as shipped: the persistent pair GEMM, its K-split workspace, the row-pair weight gradients, the
+    amax slots, the persistent / KV-tiled attention) and in the bench's REGIME: no host synchronisation between steps, so the host runs
+    ahead of the device by as many replays as the runtime lets it.  Two models from the same weights, the same clip every step (as
+    bench.py), one eager, one through the graph: every step's loss, the last step's 33 gradients, every parameter (and C3's queue and
+    teacher) bit for bit.  (Round 5's headline was timed on replays that failed exactly this: an unbounded run-ahead of graph launches
+    corrupts them on ROCm 7.2 - time_tuning.STEP_GRAPHS_IN_FLIGHT.)"""
+    from timetuning_amd import hip_ops
+    from tools.graph_vs_eager import CONFIGS, make
+
+    arch, bs, fs, K, queue = CONFIGS[cfg]
+    hip_ops.set_gemm_precision(mode)
+    try:
+        x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=11)).cuda()
+        runs = []
+        for graph in (False, True):
+            m, o = make(cfg, steps + 203)
+            if graph:
+                m.enable_step_graph()
+            torch.manual_seed(321)   # the queue's permutations
+            losses = []
+            for i in range(steps):
+                loss = m.get_loss(x)
+                m.train_update(o, loss, i + 1 if queue else 0)
+                losses.append(loss.detach().clone())          # (no .item(): nothing here waits for the device)
+            grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+            torch.cuda.synchronize()
+            runs.append((m, [l.item() for l in losses], grads))
+            del o
+        (me, le, ge), (mg, lg, gg) = runs
+        assert len(mg._step_graphs) == 1 and not mg._step_graph_failed, (len(mg._step_graphs), mg._step_graph_failed)
+        assert le == lg, (cfg, mode, le, lg)
+        assert len(ge) == 33 and ge.keys() == gg.keys() and all(torch.equal(ge[n], gg[n]) for n in ge)
+        pe, pg = dict(me.named_parameters()), dict(mg.named_parameters())
+        assert all(torch.equal(pe[n], pg[n]) for n in pe)
+        if queue:
+            assert torch.equal(me.queue, mg.queue) and torch.equal(me.teacher_prototypes, mg.teacher_prototypes)
+            te, tg = dict(me.teacher.named_parameters()), dict(mg.teacher.named_parameters())
+            assert all(torch.equal(te[n], tg[n]) for n in te)
+    finally:
+        hip_ops.set_gemm_precision("f32")
+
+
+@pytest.mark.timeout(900)
+def test_step_graph_replay_vs_oracle_c2():
+    """A REPLAYED step against the oracle at C2's full size: ``target_labels`` ride into the captured step through a device buffer (they no
+    longer bypass it), so the very assertions of ``test_c2_full_step_vs_oracle`` apply to the graph - the first call runs eagerly, the
+    second is captured and replayed, the third replayed; all three are the same step (no update in between: the capture converts the pair
+    operands although nothing made them stale)."""
+    from timetuning_amd import hip_ops
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+
+    hip_ops.set_gemm_precision("f16x3")
+    try:
+        bs, fs, K = 32, 4, 200
+        fe = FeatureExtractor("dino-s16", "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="stress", return_attention=False)
+        model = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, 256))).cuda()
+        model.enable_step_graph()
+        o = _c2_oracle_step()
+        x = o["x"].cuda()
+        for call in range(3):
+            model.zero_grad(set_to_none=True)
+            loss = model.get_loss(x, target_labels=o["labels"])
+            assert len(model._step_graphs) == (1 if call else 0)
+            assert rel_err(model.last_aux["q"].cpu(), o["batch_q"]) < TOL and rel_l2(model.last_aux["q"].cpu(), o["batch_q"]) < TOL, call
+            assert_close(model.last_aux["target_scores"].cpu(), o["target_scores"], TOL, f"C2 assignment logits, call {call}")
+            assert (model.last_aux["labels"].cpu() != o["labels"]).float().mean().item() <= 0.01
+            assert abs(loss.item() - o["loss"]) < 2e-4, (call, loss.item(), o["loss"])
+            loss.backward()
+            assert assert_all_grads(dict(model.named_parameters()), o["grads"], f"C2 replayed step, call {call}") == 33
+    finally:
+        hip_ops.set_gemm_precision("f32")
+
+
+def _small_graph_pair(make_queue=None, teacher=False, K=50):
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.my_utils import cosine_scheduler
+    from timetuning_amd.time_tuning import SwavOptimizer, TimeT
+
+    out = []
+    for graph in (False, True):
+        fe = FeatureExtractor("dino-s16", "", [1024, 1024, 512, 256], unfreeze_layers=["blocks.11", "blocks.10"], init="stress", return_attention=False)
+        m = TimeT(fe, K, prototype_init=torch.from_numpy(synth.make_prototypes(K, 256))).cuda()
+        o = SwavOptimizer(m, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, 1, 12), 12, 1)
+        if teacher:
+            m.init_momentum_teacher()
+            m.set_momentum_teacher_schedular_params(0.995, 1.0, 1, 12)
+        if make_queue is not None:
+            make_queue(m)
+        if graph:
+            m.enable_step_graph()
+        out.append((m, o))
+    return out
+
+
+def test_step_graph_with_a_restored_half_filled_queue(accurate_precision):
+    """after ``set_queue`` with a NOT yet full queue (a restored checkpoint) the queue's fullness is unknown to the host; the
+    step must ask the device - a synchronisation no capture can hold - so those steps stay eager until the FIFO is full, and the run equals
+    the eager one bit for bit (it used to die in the capture at its second step)."""
+    bs, fs = 2, 2
+    Q = bs * 10 * 5
+    half = torch.zeros(Q, 256)
+    half[: Q // 2] = torch.nn.functional.normalize(torch.randn(Q // 2, 256, generator=torch.Generator().manual_seed(3)), dim=1)
+
+    def mq(m):
+        m.init_queue(Q)
+        m.set_queue(half.cuda())
+
+    clips = [torch.from_numpy(synth.make_clips(bs, fs, 224, seed=80 + i)).cuda() for i in range(7)]
+    res = []
+    for m, o in _small_graph_pair(mq, teacher=True):
+        torch.manual_seed(7)
+        losses = []
+        for i, x in enumerate(clips):
+            loss = m.get_loss(x)
+            m.train_update(o, loss, i + 1)
+            losses.append(loss.item())
+        res.append((m, losses))
+    (me, le), (mg, lg) = res
+    assert le == lg, (le, lg)
+    assert torch.equal(me.queue, mg.queue)
+    assert len(mg._step_graphs) == 1 and not mg._step_graph_failed   # the full-queue signature, captured once the device said "full"
+
+
+def test_step_graph_two_losses_per_update(accurate_precision):
+    """the capture must not freeze the host's staleness decision.  Two ``get_loss`` calls per update (a probe forward, gradient
+    statistics): the second call is the one that gets captured, at a moment when no weight is stale - the captured step converts the
+    trainable weights' pair operands all the same, so the replays after the following updates see the updated weights."""
+    bs, fs = 2, 2
+    clips = [torch.from_numpy(synth.make_clips(bs, fs, 224, seed=90 + i)).cuda() for i in range(5)]
+    res = []
+    for m, o in _small_graph_pair():
+        losses = []
+        for i, x in enumerate(clips):
+            probe = m.get_loss(x).item()          # no backward, no update
+            loss = m.get_loss(x)
+            m.train_update(o, loss, 0)
+            losses.append((probe, loss.item()))
+        res.append((m, losses))
+    (me, le), (mg, lg) = res
+    assert le == lg, (le, lg)
+    assert all(a == b for a, b in le), le       # (the probe IS the step's loss: same weights, same clip)
+    pe, pg = dict(me.named_parameters()), dict(mg.named_parameters())
+    assert all(torch.equal(pe[n], pg[n]) for n in pe)
+    assert len(mg._step_graphs) == 1
+
+
+def test_step_graph_refuses_silent_gradient_accumulation():
+    """a captured step's gradients are the graph's static buffers.  Accumulating over two steps without ``zero_grad`` would add
+    the second gradient to a buffer the second replay has already overwritten (2 x g2 instead of g1 + g2): the backward raises instead."""
+    from timetuning_amd import hip_ops
+
+    hip_ops.set_gemm_precision("f16x3")
+    try:
+        (_, _), (m, o) = _small_graph_pair()
+        x = torch.from_numpy(synth.make_clips(2, 2, 224, seed=5)).cuda()
+        for i in range(3):                         # eager, captured, replayed - with zero_grad in between: fine
+            m.zero_grad(set_to_none=True)
+            m.get_loss(x).backward()
+        with pytest.raises(RuntimeError, match="accumulation"):
+            m.get_loss(x).backward()
+    finally:
+        hip_ops.set_gemm_precision("f32")
+
+
 def test_c2_size_properties():
     """BASELINE C2 (bs 32 x 4 frames, K=200): too big for golden tensors; checked through invariants and against
     the CPU oracle on a sub-batch (per-clip computations are independent except for the Sinkhorn coupling)."""

@@ -1,0 +1,19 @@
+"""TimeTuning's training hot path on MI355X (gfx950): hand-written HIP kernels behind a C ABI (include/timetuning_hip.h) and the Python
+mirror of the reference's modules."""
+import os as _os
+
+# ROCm 7.2 replays a hipGraph from AQL packets it captured when the graph was instantiated (DEBUG_CLR_GRAPH_PACKET_CAPTURE, on by default).
+# TimeT's captured training step (TimeT.enable_step_graph: ~600 kernel nodes at BASELINE C2, a few memset nodes) does NOT execute
+# reliably on that path: with the host more than three replays ahead of the device, or after large synchronous device-to-host copies
+# between replays, a later replay computes a different step (round 6: bench.py's loss 3.56 - 3.79 by build against the eager step's
+# 4.27454; tools/graph_vs_eager.py, tools/probes/graph_repeat2.py).  With the packet capture off the same graph is, bit for
+# bit, the eager step in every regime measured - at the same speed (C2 7.48 ms either way).  The runtime reads the flag once, when it
+# initialises (the first HIP call of the process - torch.cuda.is_available() is one): this package therefore switches it off on import,
+# and TimeT.enable_step_graph() refuses to capture when somebody asked for it to stay on.
+GRAPH_FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+_os.environ.setdefault(GRAPH_FLAG, "0")
+
+
+def step_graph_safe() -> bool:
+    """True when the process runs hipGraphs without the AQL packet capture (the only mode TimeT's step graph is verified in)."""
+    return _os.environ.get(GRAPH_FLAG) == "0"

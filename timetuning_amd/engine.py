@@ -618,7 +618,7 @@ GRAD_BUCKETS = 0
 EXCHANGE_CHOICE: Optional[dict] = None
 
 
-def autotune_exchange(run_step, device, reps: int = 3, margin: float = 0.97, log=None) -> Optional[dict]:
+def autotune_exchange(run_step, device, reps: int = 3, margin: float = 0.97, log=None, state=None) -> Optional[dict]:
     """Which of the two Sinkhorn exchanges ("allgather": one 6.7 MB all-gather + a W-times-larger redundant solve; "allreduce": the
     reference's ``iters`` K-float all-reduces, my_utils.py:250-272) and which gradient exchange (four buckets behind the backward, or one
     at its end) is faster over THIS node's links is a property of the machine (xGMI ring latency against the solve's size) that no
@@ -627,7 +627,12 @@ def autotune_exchange(run_step, device, reps: int = 3, margin: float = 0.97, log
     steps each behind one warm-up step, barrier + synchronise on both sides, MAX over ranks so that every rank sees the same numbers and
     takes the same decision - and a variant replaces the default only when it is faster by more than ``1 - margin`` (3 %).
     Sets ``SINKHORN_EXCHANGE`` / ``GRAD_BUCKETS``, records the measurements in ``EXCHANGE_CHOICE`` and returns it; a no-op (None) without
-    a process group of more than one rank."""
+    a process group of more than one rank.
+
+    ``state = (snapshot, restore)`` (``TimeT.probe_state`` / ``restore_probe_state``): what a forward + backward of the workload changes
+    besides gradients - the queue and its bookkeeping, the host generator the queue permutations are drawn from.  It is put back before
+    EVERY timed configuration and at the end, so that all three are timed on the same workload (the queue fills while probing, and a full
+    queue adds its rows to the Sinkhorn problem) and the run after the probe is seed for seed the run without one."""
     import time
 
     global SINKHORN_EXCHANGE, GRAD_BUCKETS, EXCHANGE_CHOICE
@@ -637,9 +642,13 @@ def autotune_exchange(run_step, device, reps: int = 3, margin: float = 0.97, log
     dev = torch.device(device)
     cuda = dev.type == "cuda"
 
+    snap = state[0]() if state is not None else None
+
     def timed(sk: str, buckets: int) -> float:
         global SINKHORN_EXCHANGE, GRAD_BUCKETS
         SINKHORN_EXCHANGE, GRAD_BUCKETS = sk, buckets
+        if state is not None:
+            state[1](snap)
         run_step()                                   # warm-up: buffers, communicator channels, the arena's layout for this bucket count
         if cuda:
             torch.cuda.synchronize(dev)
@@ -664,6 +673,9 @@ def autotune_exchange(run_step, device, reps: int = 3, margin: float = 0.97, log
     except Exception:
         SINKHORN_EXCHANGE, GRAD_BUCKETS = keep
         raise
+    finally:
+        if state is not None:
+            state[1](snap)
     SINKHORN_EXCHANGE, GRAD_BUCKETS = sk, buckets
     EXCHANGE_CHOICE = dict(sinkhorn_exchange=sk, grad_buckets=4 if buckets == 0 else 1, ms_per_step=ms, reps=reps, world_size=dist.get_world_size(),
                            rule=f"a variant replaces the default (allgather, 4 buckets) when faster by > {100 * (1 - margin):.0f} %")

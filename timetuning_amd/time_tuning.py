@@ -115,6 +115,14 @@ class _FusedLoss(torch.autograd.Function):
         return (None, None, None, None, *out)
 
 
+# Launches of ONE captured step graph allowed in flight (0 = unbounded).  Defensive: the cause of round 5's diverging replays is ROCm 7.2's
+# replay of AQL packets captured at instantiation, which this package switches off (timetuning_amd/__init__.py) - with the capture ON the
+# replays went wrong once the host was more than three launches ahead (bound 1, 2, 3: exact; unbounded: loss 3.69 instead of 4.27454,
+# gpurun_out/r06a/bis4_*).  The bound costs nothing (the eager tail of a step - loss copy, AdamW, EMA - is queued behind its replay and
+# runs while the host issues the next one) and keeps the host from running an epoch ahead of the device.
+STEP_GRAPHS_IN_FLIGHT = int(os.environ.get("TT_STEP_GRAPHS_IN_FLIGHT", "2"))   # (the environment variable: sweeps only)
+
+
 class _GraphLoss(torch.autograd.Function):
     """``_FusedLoss`` for a step that lives in a captured hipGraph (``TimeT.enable_step_graph``): forward replays the graph - the whole
     launch sequence of forward AND backward in one host call - and hands out the loss; backward hands out the graph's static gradient
@@ -122,12 +130,33 @@ class _GraphLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, rec, *params):
+        # a bounded number of launches in flight (STEP_GRAPHS_IN_FLIGHT).  The wait costs nothing: the eager tail of the previous step (loss
+        # copy, AdamW, EMA) is queued behind its replay and runs while the host issues this one.
+        evs = rec.setdefault("_events", [])
+        if STEP_GRAPHS_IN_FLIGHT > 0 and len(evs) >= STEP_GRAPHS_IN_FLIGHT:
+            evs.pop(0).synchronize()
         rec["graph"].replay()
+        if STEP_GRAPHS_IN_FLIGHT > 0:
+            ev = torch.cuda.Event()
+            ev.record()
+            evs.append(ev)
         ctx.grads = [rec["grads"].get(p) for p in params]
+        ctx.params = params
         return rec["loss"].clone().view(())
 
     @staticmethod
     def backward(ctx, gout):
+        if ctx.grads is None:
+            raise RuntimeError("the captured TimeT step hands its gradient buffers out once per forward (no second backward / retain_graph)")
+        # The gradients ARE the graph's static buffers (autograd adopts the views; the next replay overwrites them).  With the usual
+        # zero_grad() -> backward() -> step() that is what one wants; a .grad that still aliases a buffer HERE was adopted from an earlier
+        # step and never reset - gradient accumulation across steps - and this step's replay has already overwritten what it held
+        # (ADVICE r5): fail loudly instead of handing the optimizer 2 x the newest gradient.
+        for p, g in zip(ctx.params, ctx.grads):
+            if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+                raise RuntimeError("gradient accumulation across captured TimeT steps: .grad still holds the previous step's graph buffer, which "
+                                   "this step's replay overwrote.  Call zero_grad() between steps (SwavOptimizer.step does), or "
+                                   "enable_step_graph(False) to accumulate.")
         out, ctx.grads = [None if g is None else g.view(g.shape) for g in ctx.grads], None
         live = [g for g in out if g is not None]
         ops.scale_tensors_(live, gout.reshape(1).to(torch.float32).contiguous())
@@ -216,6 +245,20 @@ class TimeT(nn.Module):
             self._queue_seen = self._queue_signature() if full else None
             return full
         return self._queue_rows_pushed >= self.queue.shape[0]
+
+    def probe_state(self) -> dict:
+        """What a forward + backward of the training step changes besides ``.grad``: the queue (contents and host bookkeeping) and torch's CPU
+        generator (the queue permutation, time_tuning.py:259).  ``restore_probe_state`` puts it back - a start-up probe
+        (``engine.autotune_exchange``) then leaves the run seed for seed what it would have been."""
+        return dict(queue=None if self.queue is None else self.queue.clone(), pushed=self._queue_rows_pushed, known=self._queue_seen is not None,
+                    rng=torch.get_rng_state())
+
+    def restore_probe_state(self, st: dict) -> None:
+        if st["queue"] is not None:
+            self.queue.copy_(st["queue"])
+            self._queue_rows_pushed = st["pushed"]
+            self._queue_seen = self._queue_signature() if st["known"] else None   # (the copy bumped the version: re-sign what this module knows)
+        torch.set_rng_state(st["rng"])
 
     def set_momentum_teacher_schedular_params(self, momentum_teacher, momentum_teacher_end, max_epochs, train_iter_per_epoch):
         self.momentum_schedule = cosine_scheduler(momentum_teacher, momentum_teacher_end, max_epochs, train_iter_per_epoch)
@@ -361,8 +404,7 @@ class TimeT(nn.Module):
                   target_labels=target_labels)
         params = [p for p in self.parameters() if p.requires_grad]
         need_grad = torch.is_grad_enabled() and len(params) > 0
-        if getattr(self, "_step_graph_on", False) and need_grad and x.is_cuda and queue_perm is None and target_labels is None \
-                and engine.exchange_group() is None:
+        if getattr(self, "_step_graph_on", False) and need_grad and x.is_cuda and engine.exchange_group() is None:
             out = self._graph_step(x, hp, params)
             if out is not None:
                 return out
@@ -378,49 +420,114 @@ class TimeT(nn.Module):
         optimizer (its learning rate / weight decay / step count are kernel ARGUMENTS that change every step) and the host's own
         bookkeeping - the queue permutation is drawn on the host into the pinned buffer the graph's copy node reads.  Needs ABI 7 (no
         allocation on a launch path).  One process per GPU without an exchange (W = 1); memory: the graph keeps the step's activations."""
+        if on:
+            from . import GRAPH_FLAG, step_graph_safe
+            if not step_graph_safe():
+                raise RuntimeError(f"TimeT.enable_step_graph: {GRAPH_FLAG}={os.environ.get(GRAPH_FLAG)!r} - ROCm 7.2 does not replay the captured step reliably "
+                                   f"with its AQL packet capture on (timetuning_amd/__init__.py); run with {GRAPH_FLAG}=0 or without the step graph")
         self._step_graph_on = bool(on)
         self._step_graphs = {}
         self._step_graph_seen = set()
+        self._step_graph_failed = set()
 
     def _graph_step(self, x, hp, params):
         bs, fs = x.shape[0], x.shape[1]
         n = self.feature_extractor.spatial_resolution ** 2
         # the queue's state as the step will see it AFTER its push (time_tuning.py:207: the scores take the queue rows once it is full)
-        full = False
+        full, m = False, 0
         if self.queue is not None:
-            full = self.queue_is_full() or (self._queue_rows_pushed is not None and
-                                            self._queue_rows_pushed + min(bs * 10, self.queue.shape[0]) >= self.queue.shape[0])
+            if self._queue_rows_pushed is None or self._queue_seen is None or self._queue_seen != self._queue_signature():
+                # somebody else wrote the queue (set_queue / queue.copy_ / a checkpoint) and it is not known to be full: the eager step asks
+                # the device (a synchronisation no capture can hold, ADVICE r5) - and keeps asking until the FIFO is full
+                if not self.queue_is_full():
+                    return None
+            m = min(bs * 10, self.queue.shape[0])
+            full = self._queue_rows_pushed + m >= self.queue.shape[0]
+        labels_in = hp["target_labels"] is not None
         key = (tuple(x.shape), str(x.device), ops.get_gemm_precision(), ops.PAIRS_MIN_ROWS, hp["n_last_frames"], hp["radius"], hp["topk"],
                float(hp["epsilon"]), hp["iters"], hp["mask_features"], self.teacher is not None, None if self.queue is None else self.queue.shape[0],
-               full, tuple(id(p) for p in params), self.teacher_shares_frozen_blocks() if self.teacher is not None else None,
-               # the frozen tensors' contents: their pair operands are refreshed by the EAGER path only (the captured step refreshes what
-               # was stale when it was captured - the trainable ones); an in-place rewrite (load_state_dict) bumps torch's version counter
+               full, labels_in, tuple(id(p) for p in params), self.teacher_shares_frozen_blocks() if self.teacher is not None else None,
+               # the STATIC frozen tensors' contents: their pair operands are made once and never refreshed by a replay (everything else is
+               # converted inside the captured step); an in-place rewrite (load_state_dict, a hand edit) bumps torch's version counter
                sum(p_._version for p_ in self.parameters() if not p_.requires_grad))
+        if key in self._step_graph_failed:
+            return None
         rec = self._step_graphs.get(key)
+        if rec is None and key not in self._step_graph_seen:   # the first step of a shape: eager (it creates what a capture may not create)
+            self._step_graph_seen.add(key)
+            return None
+        # the host's share of the step (what _run_step does outside its launches): the queue permutation travels to the device buffer the
+        # captured push reads, target labels (a test's pinned decision) to theirs
+        rng = torch.get_rng_state() if rec is None else None
+        hp = dict(hp)
+        if self.queue is not None:
+            hp["_perm_dev"] = self._stage_queue_perm(bs * n, m, hp["queue_perm"], x.device)
         if rec is None:
-            if key not in self._step_graph_seen:   # the first step of a shape: eager (it creates what a capture may not create)
-                self._step_graph_seen.add(key)
-                return None
             if len(self._step_graphs) >= 4:
                 self._step_graphs.clear()
-            # capture.  The host work of the step runs here, once, as it would in an eager step (queue bookkeeping, the permutation);
-            # the kernels are only recorded - the replay below executes them.
+            # capture.  The host work of the step runs here, once, as it would in an eager step (queue bookkeeping); the kernels are only
+            # recorded - the replay below executes them.  A replay cannot retake a host decision, so: every cached operand derived from a
+            # tensor the optimizer / EMA may rewrite is made stale first (the captured step then converts them all, whether or not an
+            # update happened since the last step - ADVICE r5: two get_loss calls per update), and a capture that fails (a host
+            # synchronisation inside it) puts the host state back and leaves this signature to the eager path for good.
             xs = x.clone()
+            lab = torch.as_tensor(hp["target_labels"]).to(device=x.device, dtype=torch.int64).reshape(bs, n).contiguous().clone() if labels_in else None
+            hp["target_labels"] = lab
             g = torch.cuda.CUDAGraph()
-            ops.ksplit_workspace(x.device)
+            keep = (self._queue_rows_pushed, self._queue_seen, self.last_aux)
+            ops._bump_param_epoch()
             torch.cuda.synchronize(x.device)
-            with torch.cuda.graph(g):
-                loss, grads = self._run_step(xs, hp, True)
-            rec = self._step_graphs[key] = dict(graph=g, x=xs, loss=loss, grads=grads, aux=self.last_aux, m=min(bs * 10, self.queue.shape[0]) if self.queue is not None else 0)
+            try:
+                with torch.cuda.graph(g):
+                    loss, grads = self._run_step(xs, hp, True)
+            except Exception as e:   # noqa: BLE001 - whatever broke the capture, the eager path is the answer
+                import warnings
+                warnings.warn(f"TimeT step graph: capture failed ({type(e).__name__}: {e}); this step signature stays on the eager path")
+                self._step_graph_failed.add(key)
+                self._queue_rows_pushed, self._queue_seen, self.last_aux = keep
+                ops._bump_param_epoch()   # operands 'converted' by launches that never ran are stale
+                torch.set_rng_state(rng)
+                return None
+            rec = self._step_graphs[key] = dict(graph=g, x=xs, loss=loss, grads=grads, aux=self.last_aux, m=m, labels=lab)
         else:
             rec["x"].copy_(x)
-            # the host's share of the step (what _run_step does outside its launches): a fresh permutation in the pinned buffer the graph's
-            # copy node reads, the queue's bookkeeping
+            if labels_in:
+                rec["labels"].copy_(torch.as_tensor(hp["target_labels"]).reshape(bs, n))
             if self.queue is not None:
-                torch.randperm(bs * n, out=self._queue_perm_pinned)
                 self._queue_pushed(rec["m"])
             self.last_aux = rec["aux"]
         return _GraphLoss.apply(self, rec, *params)
+
+    _PERM_RING = 8
+
+    def _stage_queue_perm(self, total: int, m: int, perm, dev) -> torch.Tensor:
+        """The queue's permutation (time_tuning.py:259: ``torch.randperm`` from torch's CPU generator - kept, for seed-for-seed
+        reproducibility) on its way to the device: drawn into a slot of a small ring of PINNED buffers, its first ``m`` entries copied
+        asynchronously into the one persistent device buffer the push kernel reads (the same address every step: a captured step reads it
+        too).  A slot is rewritten only after the copy that last read it has run (its event) - the host may be several steps ahead of the
+        device, with graph replays by the whole step."""
+        ring = getattr(self, "_queue_perm_ring", None)
+        if ring is None or ring["total"] != total or ring["dev"].device != torch.device(dev):
+            cuda = torch.device(dev).type == "cuda"
+            ring = self._queue_perm_ring = dict(
+                total=total, i=0, events=[None] * self._PERM_RING,
+                pins=[torch.empty(total, dtype=torch.int64).pin_memory() if cuda else torch.empty(total, dtype=torch.int64) for _ in range(self._PERM_RING)],
+                dev=torch.empty(total, dtype=torch.int64, device=dev))
+        i = ring["i"]
+        ring["i"] = (i + 1) % self._PERM_RING
+        if ring["events"][i] is not None:
+            ring["events"][i].synchronize()
+        pin = ring["pins"][i]
+        if perm is None:
+            torch.randperm(total, out=pin)
+        else:
+            pin.copy_(torch.as_tensor(perm).to(torch.int64).reshape(-1)[:total])
+        idx = ring["dev"][:m]
+        idx.copy_(pin[:m], non_blocking=True)
+        if idx.is_cuda:
+            ring["events"][i] = torch.cuda.Event()
+            ring["events"][i].record()
+        return idx
 
     def _frame_map(self, bs, fs, device, only_t: Optional[int] = None):
         key = (bs, fs, only_t, str(device))
@@ -436,6 +543,8 @@ class TimeT(nn.Module):
         bs, fs, c, h, w = x.shape
         if fs < 2:
             raise ValueError("TimeT needs clips of at least 2 frames")
+        keep = getattr(self, "_debug_tensors", None)   # tools/graph_vs_eager.py: {name: tensor} of the step's intermediates, or None
+        dbg = (lambda name, t: keep.__setitem__(name, t)) if keep is not None else (lambda name, t: None)
         Fr = bs * fs
         xf = vit._check(x.reshape(Fr, c, h, w))
         dev = xf.device
@@ -472,6 +581,12 @@ class TimeT(nn.Module):
         tok, _ = engine.vit_tokens(vit, xf, self._frame_map(bs, fs, dev), save, last_block_aux=s_aux, tap=tap,
                                    save_from_frame=f0 if ops.plane_count_for(f0 * (1 + fe.spatial_resolution ** 2)) else 0)
         tok_lo, tok_hi = tok if isinstance(tok, tuple) else (tok[:f0], tok[f0:])
+        dbg("tok_lo", tok_lo); dbg("tok_hi", tok_hi)
+        if keep is not None and save:
+            for i_, sv_ in save.items():
+                for k_, v_ in sv_.items():
+                    if isinstance(v_, torch.Tensor):
+                        dbg(f"save{i_}.{k_}", v_)
         N, D = tok_hi.shape[1], tok_hi.shape[2]
         n = N - 1
         # --use_mask (time_tuning.py:244-246 -> models.py:93-144): foreground masks from the last block's cls attention.
@@ -491,6 +606,7 @@ class TimeT(nn.Module):
             ops.layernorm_fwd(tok_hi, vit.norm.weight, vit.norm.bias, drop_first_token=True, out=feats[f0 * n:])
         xn_bb = ops.l2norm_fwd(feats).view(fs, bs, n, D)           # label-propagation features (pre-head tokens)
         src_rows, tgt_rows = feats[: bs * n], feats[(fs - 1) * bs * n:]
+        dbg("feats", feats); dbg("xn_bb", xn_bb)
 
         # ---- assignment source: teacher on frame 0 if present, else the student's frame 0 (no grad either way)
         if self.teacher is not None:
@@ -517,19 +633,10 @@ class TimeT(nn.Module):
 
         if self.queue is not None:  # time_tuning.py:250-261 (before scoring, so the batch is also in the queue)
             m = min(bs * 10, self.queue.shape[0])
-            perm = hp["queue_perm"]
-            # the reference draws the permutation from torch's CPU generator (time_tuning.py:259) - kept, for seed-for-seed reproducibility -
-            # into a persistent PINNED buffer, and its first m entries travel to the device asynchronously (no pageable staging copy)
-            pin = getattr(self, "_queue_perm_pinned", None)
-            if pin is None or pin.numel() != bs * n:
-                pin = self._queue_perm_pinned = torch.empty(bs * n, dtype=torch.int64).pin_memory() if dev.type == "cuda" else torch.empty(bs * n, dtype=torch.int64)
-                self._queue_perm_dev = torch.empty(bs * n, dtype=torch.int64, device=dev)
-            if perm is None:
-                torch.randperm(bs * n, out=pin)
-            else:
-                pin.copy_(torch.as_tensor(perm).to(torch.int64).reshape(-1)[: bs * n])
-            idx = self._queue_perm_dev[:m]
-            idx.copy_(pin[:m], non_blocking=True)
+            # (a captured step: the host staged the permutation before the capture / each replay, _graph_step)
+            idx = hp.get("_perm_dev")
+            if idx is None:
+                idx = self._stage_queue_perm(bs * n, m, hp["queue_perm"], dev)
             foreign = self._queue_seen is None or self._queue_seen != self._queue_signature()
             if foreign:
                 self.queue_is_full()   # somebody else wrote the queue: read its state from the device before this push hides it
@@ -542,6 +649,7 @@ class TimeT(nn.Module):
             engine.prototype_scores(self.queue, protos_q, out=scores_q[z_q.shape[0]:])
         else:
             scores_q = engine.prototype_scores(z_q, protos_q)
+        dbg("z_q", z_q); dbg("scores_q", scores_q)
         gather = engine.global_sinkhorn_begin(scores_q)  # W > 1: the score rows travel while the target head runs
 
         # ---- target frames: head + scores (with grad)
@@ -558,6 +666,7 @@ class TimeT(nn.Module):
         if hp.get("target_labels") is not None:
             ce_labels = torch.as_tensor(hp["target_labels"]).to(device=dev, dtype=torch.int64).reshape(bs, n).contiguous()
         loss, dscores = ops.ce_loss_fwd_bwd(scores_t, ce_labels.view(-1), 0.1, need_grad, row_weight=mask_tgt)  # :296-300
+        dbg("z_tgt", z_tgt); dbg("scores_t", scores_t); dbg("q", q); dbg("labels", labels); dbg("loss", loss); dbg("dscores", dscores)
         self.last_aux = dict(q=q.view(bs, n, K), target_scores=scores_t.view(bs, n, K), labels=labels)
         if use_mask:
             self.last_aux.update(target_mask=mask_tgt.view(bs, n), source_mask=mask_q.view(bs, n))
@@ -585,6 +694,7 @@ class TimeT(nn.Module):
         if use_mask:
             ops.scale_rows_(dz, mask_tgt)  # backward of features * mask (rows times a number in [0, 1]: a_dz stays an upper bound)
         d_feats = engine.head_backward(dz, fe.head, sv_head, grads, out=out, dz_amax=a_dz, amax_pool=pool) if fe.head is not None else dz
+        dbg("dz", dz); dbg("d_feats", d_feats)
         exchange.push(grads)  # prototypes + head
         #  the final norm's backward also runs when ONLY that norm is trainable, and its parameter gradients are built when
         # either of them asks for one
@@ -608,6 +718,8 @@ class TimeT(nn.Module):
                                            dx_out_amax=a_tok, amax_pool=pool)
                 if pool is not None:
                     dx, a_tok = dx
+                if dx is not None:
+                    dbg(f"dx_in{i}", dx)
                 if i > first:
                     exchange.push(grads)  # this block's gradients travel while the next block's backward runs
         grads = {p: g for p, g in grads.items() if p.requires_grad}
@@ -962,18 +1074,14 @@ def time_tuning(gpu=0, args=None):
         for i, (data, annotations, label) in enumerate(loader):
             data = data.squeeze(1)
             if world_size > 1 and sk_exchange == "auto" and engine.EXCHANGE_CHOICE is None:
-                # the first batch decides how this communicator exchanges (forward + backward only: no parameter, queue or teacher update
-                # is kept - the queue is restored below)
-                q_keep = model.queue.clone() if getattr(model, "queue", None) is not None else None
-
+                # the first batch decides how this communicator exchanges (forward + backward only: no parameter or teacher update; the queue,
+                # its bookkeeping and the host generator are put back before every timed variant and afterwards - TimeT.probe_state)
                 def _probe_step():
                     model.zero_grad(set_to_none=True)
                     model(data, annotations, True, args.use_mask).backward()
 
-                engine.autotune_exchange(_probe_step, device, log=print)
+                engine.autotune_exchange(_probe_step, device, log=print, state=(eval_model.probe_state, eval_model.restore_probe_state))
                 model.zero_grad(set_to_none=True)
-                if q_keep is not None:
-                    model.set_queue(q_keep)
             loss = model(data, annotations, True, args.use_mask)
             # optimizer.step(loss); model.normalize_prototypes(); model.update_momentum_teacher(global_step) (:659-663) as one call
             model.train_update(opt, loss, min(opt.global_step + 1, last))
