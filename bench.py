@@ -506,7 +506,8 @@ def main():
     ap.add_argument("--no_exchange_probe", action="store_true", help="skip the one-rank RCCL probe of the exchange path (1-GPU runs)")
     ap.add_argument("--step_graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step's launch sequence as ONE captured hipGraph (TimeT.enable_step_graph, the driver's default too): "
-                         "auto = on with one GPU (no exchange inside the step: C1 -22 %, C2 -2.4 % against launch by launch), off with N > 1")
+                         "auto = one GPU AND a launch-bound step (at most 10 k token rows: C1 2.0 against 3.5 ms; C2 - C5 are equal either way "
+                         "and stay launch by launch), off with N > 1")
     ap.add_argument("--no_exchange_autotune", action="store_true",
                     help="N > 1: keep the default exchange (all-gather Sinkhorn, 4 gradient buckets) instead of timing the variants first")
     ap.add_argument("--exchange_probe_child", action="store_true", help=argparse.SUPPRESS)
@@ -564,7 +565,12 @@ def main():
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1 + rank)).to(device)  # resident in HBM before timing
     step_graph = world == 1 and a.step_graph in ("on", "auto")
     if step_graph:
-        model.enable_step_graph()
+        from timetuning_amd.time_tuning import TimeT
+
+        # auto: replay launch-bound steps only (TimeT.STEP_GRAPH_AUTO_MAX_ROWS: C1-sized steps; C2 - C5 run launch by launch, as an N > 1 rank does)
+        model.enable_step_graph(max_token_rows=TimeT.STEP_GRAPH_AUTO_MAX_ROWS if a.step_graph == "auto" else None)
+        rows = bs * fs * (1 + model.feature_extractor.spatial_resolution ** 2)
+        step_graph = a.step_graph == "on" or rows <= TimeT.STEP_GRAPH_AUTO_MAX_ROWS
 
     from timetuning_amd import hip_ops
 

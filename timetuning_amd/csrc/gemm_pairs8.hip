@@ -788,7 +788,8 @@ __global__ __launch_bounds__(512) void gemm_pairs8_kernel(Q8Args g) {
 #ifndef TT_Q8S_LOADER
 #define TT_Q8S_LOADER 2
 #endif
-// DBG (timing studies only, tools/q8_ablate.py; the shipped instantiations are DBG = 0), a bit mask: 1 no MFMAs, 2 no LDS-DMA, 8 no epilogue
+// DBG (timing studies only, tools/q8_ablate.py; the shipped instantiations are DBG = 0), a bit mask: 1 no MFMAs, 2 no LDS-DMA, 8 no epilogue,
+// 4 hot operands (every item streams operand tile (0, 0): what the traffic from beyond the L2 costs)
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
   constexpr int ROWB = 128, CPR = 8, WIN = 2, RPI = 8;
@@ -890,6 +891,7 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
   auto cursor_item = [&]() {
     int row0, n0;
     item(d_item, row0, n0, d_half, d_kt, d_kend);
+    if constexpr (DBG & 4) { row0 = 0; n0 = 0; }   // (timing study: every item streams the SAME operand tiles - hot in every XCD's L2)
     cur_w = (unsigned)n0 * (unsigned)K4 + (unsigned)d_kt * ROWB;
     cur_x = (unsigned)row0 * (unsigned)K4 + (unsigned)d_kt * ROWB;
   };
@@ -1461,6 +1463,9 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
     if (dbg == 10) return launch_pairs8s<EV, 10>(g, s);    \
     if (dbg == 3) return launch_pairs8s<EV, 3>(g, s);      \
     if (dbg == 11) return launch_pairs8s<EV, 11>(g, s);    \
+    if (dbg == 4) return launch_pairs8s<EV, 4>(g, s);      \
+    if (dbg == 12) return launch_pairs8s<EV, 12>(g, s);    \
+    if (dbg == 13) return launch_pairs8s<EV, 13>(g, s);    \
   }
     Q8S_DBG_CASE(Q8_F32) Q8S_DBG_CASE(Q8_F32_RES) Q8S_DBG_CASE(Q8_PAIR_GELU)
 #undef Q8S_DBG_CASE

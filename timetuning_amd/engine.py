@@ -389,6 +389,36 @@ def vit_params(vit, first: int, last: int, pos: Optional[torch.Tensor] = None):
     return vp, keep
 
 
+# Two HIP streams inside a step (round 6; measured in round 5, tools/two_stream_probe.py: -3.7 % on the frozen blocks, -6.2 % on the trainable
+# blocks' forward): the persistent GEMMs run one 8-wave workgroup per CU over whole rounds of tiles + a remainder round, and a launch's last
+# round leaves CUs idle that the NEXT kernel of the same stream cannot use; an INDEPENDENT chain on a second stream can.  Two places have one:
+#   * the frozen blocks (tt_vit_forward over blocks [0, first trainable)): the batch as two halves of frames, one per stream;
+#   * the trainable blocks' forward: the frames that keep nothing (all but the target frames) and the kept target frames are separate chains
+#     already (vit_tokens' lo / hi); lo goes to the side stream.
+# Fork / join by stream waits on both sides of the section (every side-stream launch is bracketed by them: buffers allocated on one stream
+# and used on the other need no record_stream, and a captured step - TimeT.enable_step_graph - records the fork and the join as graph edges).
+# Off: TT_SINGLE_STREAM=1, and whenever launches are being timed one by one (``ops.fine_grained()``: bench.py's roofline pass - a kernel that
+# shares the chip with another stream's kernel has no launch duration of its own).  Results: the frames of a batch are independent, so the two
+# halves compute what the whole batch computes - bit for bit wherever a launch's grid decomposition does not change an accumulation order
+# (the K-split of a K = 1536 launch's left-over tiles does: those rows agree to fp32 rounding; tests/test_hip_timet.py).
+TWO_STREAMS = __import__("os").environ.get("TT_SINGLE_STREAM") != "1"
+TWO_STREAMS_MIN_FRAMES = 32     # halves below 16 frames (3 152 token rows) no longer fill the chip: one stream
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    s = _SIDE_STREAMS.get(idx)
+    if s is None:
+        s = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return s
+
+
+def two_streams(device, frames: int) -> bool:
+    return TWO_STREAMS and torch.device(device).type == "cuda" and not ops.fine_grained() and frames >= TWO_STREAMS_MIN_FRAMES
+
+
 def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None, save_blocks: Optional[Dict[int, dict]] = None,
                last_block_probs: bool = False, last_block_aux: Optional[dict] = None, tap: Optional[dict] = None,
                save_from_frame: int = 0):
@@ -425,9 +455,21 @@ def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None,
         P_ = vit.patch_embed.patch_size
         x = torch.empty((Fr, 1 + (img.shape[-2] // P_) * (img.shape[-1] // P_), D), dtype=f32, device=img.device)
         want_qkv = last_block_aux is not None and done == depth
-        _, qkv_last, _ = ops.vit_forward(vit_params(vit, 0, done, pos), done, x, img=img, frame_map=frame_map, last_qkv=want_qkv)
-        if want_qkv:
-            last_block_aux["qkv"] = qkv_last
+        if not want_qkv and two_streams(img.device, Fr):
+            # the batch as two halves of frames on two streams (see TWO_STREAMS): the first half on the side stream, the second on this one
+            h = Fr // 2
+            cur, side = torch.cuda.current_stream(), side_stream(img.device)
+            fm = frame_map if frame_map is not None else None
+            params = vit_params(vit, 0, done, pos)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                ops.vit_forward(params, done, x[:h], img=img if fm is not None else img[:h], frame_map=None if fm is None else fm[:h])
+            ops.vit_forward(params, done, x[h:], img=img if fm is not None else img[h:], frame_map=None if fm is None else fm[h:])
+            cur.wait_stream(side)
+        else:
+            _, qkv_last, _ = ops.vit_forward(vit_params(vit, 0, done, pos), done, x, img=img, frame_map=frame_map, last_qkv=want_qkv)
+            if want_qkv:
+                last_block_aux["qkv"] = qkv_last
     for i, blk in enumerate(vit.blocks):
         if i < done:
             continue
@@ -435,6 +477,31 @@ def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None,
             tap["x"] = (x if lo is None else lo)[: tap["rows"]].clone()
         sv = save_blocks.get(i) if save_blocks is not None else None
         aux = last_block_aux if i == depth - 1 else None
+        if split and i >= first_saved and lo is None and two_streams(img.device, x.shape[0]) and (tap is None or tap["block"] <= i or tap["block"] == depth):
+            # blocks [i, depth) as two concurrent chains (see TWO_STREAMS): the frames that keep nothing on the side stream, the kept ones here
+            lo, hi = x[:save_from_frame], x[save_from_frame:]
+            want_aux = last_block_aux is not None
+            aux_lo, aux_hi = ({} if want_aux else None), ({} if want_aux else None)
+            cur, side = torch.cuda.current_stream(), side_stream(img.device)
+            # operands that are made lazily and cached (the pair / plane form of a weight at its first use) are made HERE, on this stream,
+            # before the fork: made inside one chain they would be a cache hit for the other chain, on another stream, before they are written
+            for rows in (lo.shape[0] * lo.shape[1], hi.shape[0] * hi.shape[1]):
+                planes = ops.plane_count_for(rows)
+                if planes and D % 64 == 0 and vit.blocks[i].mlp.fc1.weight.shape[0] % 64 == 0:
+                    for j in range(i, depth):
+                        b_ = vit.blocks[j]
+                        for w_ in (b_.attn.qkv.weight, b_.attn.proj.weight, b_.mlp.fc1.weight, b_.mlp.fc2.weight):
+                            weight_planes(w_, planes)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for j in range(i, depth):
+                    lo = block_forward(lo, vit.blocks[j], vit.num_heads, None, aux_lo if j == depth - 1 else None)
+            for j in range(i, depth):
+                hi = block_forward(hi, vit.blocks[j], vit.num_heads, save_blocks.get(j), aux_hi if j == depth - 1 else None)
+            cur.wait_stream(side)
+            if want_aux:
+                last_block_aux["qkv_lo"], last_block_aux["qkv_hi"] = aux_lo["qkv"], aux_hi["qkv"]
+            break
         if split and i >= first_saved:
             if lo is None:
                 lo, hi = x[:save_from_frame], x[save_from_frame:]

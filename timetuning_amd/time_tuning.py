@@ -404,14 +404,23 @@ class TimeT(nn.Module):
                   target_labels=target_labels)
         params = [p for p in self.parameters() if p.requires_grad]
         need_grad = torch.is_grad_enabled() and len(params) > 0
-        if getattr(self, "_step_graph_on", False) and need_grad and x.is_cuda and engine.exchange_group() is None:
+        if getattr(self, "_step_graph_on", False) and need_grad and x.is_cuda and engine.exchange_group() is None and (
+                self._step_graph_max_rows is None
+                or x.shape[0] * x.shape[1] * (1 + self.feature_extractor.spatial_resolution ** 2) <= self._step_graph_max_rows):
             out = self._graph_step(x, hp, params)
             if out is not None:
                 return out
         return _FusedLoss.apply(self, x, hp, need_grad, *params)
 
     # -- the step as ONE captured hipGraph (launch-bound regimes: BASELINE C1's 4 frames are ~230 launches of 5 - 15 us each) ---------
-    def enable_step_graph(self, on: bool = True) -> None:
+    # ``--step_graph auto``: a step is replayed from its captured graph while it is LAUNCH-bound - the host needs ~3.5 ms to issue a step's
+    # ~600 launches whatever their size, so below ~10 k token rows (12 clips x 4 frames of ViT-S/16) the replay wins (C1: 2.0 against 3.5 ms)
+    # and above it the two are equal to +- 1 % (round 6, one box, ms graph / eager: 8 clips 3.14 / 3.72, 12: 3.93 / 3.96, 16: 4.69 / 4.68,
+    # 32 = C2: 7.40 / 7.34, C4 18.24 / 18.22, C5 16.89 / 16.94): large steps stay on the launch-by-launch path, which is also what a
+    # multi-GPU rank runs.
+    STEP_GRAPH_AUTO_MAX_ROWS = 10000
+
+    def enable_step_graph(self, on: bool = True, max_token_rows: Optional[int] = None) -> None:
         """From the second training step of a given shape on, ``get_loss`` replays a captured hipGraph of the step's whole launch
         sequence (forward + backward, ~230 launches at C1) instead of issuing it launch by launch: the host then costs one replay
         (~15 us) instead of ~10 us per launch.  The first step of a shape runs eagerly (lazily made operands, pinned buffers and the
@@ -426,6 +435,7 @@ class TimeT(nn.Module):
                 raise RuntimeError(f"TimeT.enable_step_graph: {GRAPH_FLAG}={os.environ.get(GRAPH_FLAG)!r} - ROCm 7.2 does not replay the captured step reliably "
                                    f"with its AQL packet capture on (timetuning_amd/__init__.py); run with {GRAPH_FLAG}=0 or without the step graph")
         self._step_graph_on = bool(on)
+        self._step_graph_max_rows = max_token_rows   # None: every step; else only steps of at most this many token rows (``auto``)
         self._step_graphs = {}
         self._step_graph_seen = set()
         self._step_graph_failed = set()
@@ -1025,7 +1035,7 @@ def time_tuning(gpu=0, args=None):
     if world_size > 1:
         model = DistributedDataParallelModel(model, gpu)
     elif getattr(args, "step_graph", "auto") in ("auto", "on"):
-        model.enable_step_graph()
+        model.enable_step_graph(max_token_rows=TimeT.STEP_GRAPH_AUTO_MAX_ROWS if args.step_graph == "auto" else None)
     if args.dataset == "synthetic":
         loader = SyntheticClips(args.batch_size, args.num_frames, args.input_resolution, args.steps_per_epoch, device, rank)
     elif args.dataset == "synthetic_frames":  # raw uint8 frames through the GPU input pipeline

@@ -17,6 +17,9 @@ lib.tt_split_pairs.restype = C.c_int
 lib.tt_split_pairs.argtypes = [vp, vp, ll, vp, vp]
 st = torch.cuda.current_stream().cuda_stream
 NAMES = {0: "full", 1: "noMFMA", 2: "noDMA", 8: "noEpi", 9: "noEpi+noMFMA", 10: "noEpi+noDMA", 3: "noMFMA+noDMA", 11: "reads+barriers only"}
+if "hot" in sys.argv:   # round 6: + the hot-operand instantiations of gemm_pairs8s_kernel (every item streams operand tile (0, 0))
+    sys.argv.remove("hot")
+    NAMES.update({4: "hot", 12: "hot+noEpi", 13: "hot+noEpi+noMFMA"})
 def split(x):
     out = torch.empty((x.shape[0], 2 * x.shape[1]), device="cuda", dtype=torch.float16)
     assert lib.tt_split_pairs(x.data_ptr(), out.data_ptr(), x.numel(), None, st) == 0
