@@ -114,6 +114,11 @@ __global__ __launch_bounds__(SK_THREADS) void sk_init_from_e_kernel(const float*
   fold_waves(acc, red, partial + (long long)blockIdx.x * K, K);
 }
 
+// (Round 6 tried to cut this kernel's two latency chains - the fold of the nwg_in x K partials spread over all 1024 threads in four slices
+// of the workgroup list, and four rows of a wave in flight instead of two: 88.9 us per solve against 79.8 for this form (one box,
+// tools/sk_time.py: graph replays of the 12 launches, device time); each variant alone was slower too (profiles/r06_sinkhorn.txt).  An
+// iteration is ~ 6.7 us of which the fold of 64 partials is ~ 0.8; the rest is the launch of 64 - 96 sixteen-wave workgroups, two passes
+// over L2-resident rows and the drain.)
 // One Sinkhorn iteration (row step + column step) or, with LAST, the final column normalisation + output.
 template <bool LAST>
 __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __restrict__ E, const float* __restrict__ partial_in,
@@ -186,29 +191,27 @@ __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __rest
   fold_waves(acc, red, partial_out + (long long)blockIdx.x * K, K);
 }
 
-// ---- the whole solve in ONE launch (round 5) ------------------------------------------------------------------------------
-// SURVEY 2.4 k12's persistent form.  G workgroups (one per CU: 1024 threads and most of the LDS), each owning a run of rows whose E it keeps
-// in LDS for the whole solve (LDS_E; 6272 x 200 at C2: 38 - 56 workgroups) or, for problems beyond the chip's LDS (the 8-rank global problem,
-// 40 MB), re-reads from its own slice of the workspace (L2 / Infinity Cache).  Per iteration the only thing that crosses workgroups is the
-// K-vector of row sums: every workgroup publishes its partial sums (write-through sc1 stores), one lane adds to an arrival counter behind the
-// workgroup's `s_waitcnt vmcnt(0)` + barrier, everybody polls the counter (one lane, sc1 loads, s_sleep) and then folds ALL partials in
-// workgroup order with sc1 loads - the hand-off form of MI355X_MICROARCH.md "Valid forms", first table row: no agent-scope fence (the
-// 287 us of the round-3 attempt were its L2 write-back + invalidate around the 5 MB of E, which now never leaves the CU).
-// MEASURED (tools/run_r05k.sh, one box, 10 iterations at K = 200): B = 6272: 105 us against 77.7 us for the launch-per-iteration path
-// (B = 50176: 270 against 188) - correct (bit-equal from run to run, equal to the other path to fp32 rounding: tests/test_hip_ops.py), and
-// SLOWER: an iteration costs ~ 9.5 us, of which the cross-workgroup exchange is ~ 8 - write-through stores complete (`vmcnt(0)`, ~ 2 us),
-// the arrival atomics land (~ 1), a poll sees them (~ 1.5 per round trip), the partials come back from beyond the XCD's L2 (~ 1.5; all
-// in flight at once or eight at a time made no difference) - against ~ 2 us for a kernel boundary plus an L2-served fold.  The price
-// list of the guide says the same: a chip-wide hand-off is 3 - 5 us, a boundary 1.5 - 2.  It stays in the library behind the knob
-// TT_SK_PERSIST (default 0) with its tests; the product path is the launch-per-iteration one.  Two partial
-// buffers alternate: a workgroup can publish iteration i + 1 only after it has read every partial of iteration i, i.e. after every other
-// workgroup has finished reading iteration i - 1.  The fold order is fixed (run-to-run bit equality); every spin is bounded (status word).
+// ---- the whole solve in ONE launch ----------------------------------------------------------------------------------------------
+// SURVEY 2.4 k12's persistent form.  G workgroups (one per CU: 1024 threads and most of the LDS), each owning a run of rows whose
+// E = exp(scores / eps) it keeps in LDS for the whole solve (6272 x 200 at C2: 37 workgroups); per iteration the only thing that crosses
+// workgroups is the K-vector of row sums.
+// Round 5 built the exchange from the expensive primitives (4-byte write-through stores, `s_waitcnt vmcnt(0)` + barrier, ONE arrival
+// counter everybody polls, then the partials): ~ 8 us per iteration, 105 us per solve against 78 for a launch per iteration.  Round 6: the
+// exchange is a TAGGED GRANULE all-gather (MI355X_MICROARCH.md "Valid forms": an aligned 8-byte {data, tag} written by ONE store is seen
+// whole or not at all) - a workgroup's partial sum of column k travels as {float bits, iteration tag} in one 8-byte agent-scope store, a
+// reader polls the granules it needs (all of its loads in flight, re-issuing only those whose tag is not this iteration's yet) and sums
+// them in workgroup order once they are all there.  No counter, no fence, no wait for the stores, no barrier between publishing and
+// gathering: one fabric write + one fabric read per iteration.  Tags are iteration + 1 and the granule buffers are zeroed by the launch
+// function (a tag never matches memory that was not written by this solve); two granule buffers alternate - a workgroup publishes iteration
+// i + 1 only after it has gathered iteration i, i.e. after EVERY workgroup has published i, i.e. after every workgroup has finished
+// gathering i - 1 from the buffer that i + 1 overwrites.  The fold order is fixed (run-to-run bit equality); every spin is bounded (status
+// word).  Needs every workgroup resident at once (G <= CUs: they wait for each other) and 2 G K granules in the workspace's partial region
+// (G <= SK_MAXWG / 2); larger problems (the 8-rank global problem: 50176 rows) take the launch-per-iteration path.
 struct SkpArgs {
-  const float* scores;   // [B][K]
-  float* Eg;             // [B][K] workspace (LDS_E = false) or unused
-  float* part;           // [2][SK_MAXWG][K]
-  unsigned* counter;     // [0]: arrivals (zeroed by the launch function), [1]: status (1 = a spin gave up)
-  float* q_out;          // [rows_out][K]
+  const float* scores;          // [B][K]
+  unsigned long long* gran;     // [2][G][K] granules: float bits | (tag << 32)
+  unsigned* status;             // [0]: 1 = a spin gave up (zeroed by the launch function)
+  float* q_out;                 // [rows_out][K]
   int B, K, G, rows_per_wg, row0, rows_out, iters;
   float eps;
   int b_norm;
@@ -217,90 +220,112 @@ constexpr int SKP_LDS_FLOATS = 38400;   // 150 KB
 __host__ __device__ inline int skp_kpad(int K) { return (K + 63) / 64 * 64; }
 __host__ __device__ inline int skp_lds_rows(int K) { return (SKP_LDS_FLOATS - 64 * SK_KPL - SK_WAVES * skp_kpad(K)) / K; }
 
-template <bool LDS_E>
 __global__ __launch_bounds__(SK_THREADS) void sk_persistent_kernel(SkpArgs g) {
   __shared__ float sm[SKP_LDS_FLOATS];
   const int K = g.K, KP = skp_kpad(K);
   float* a_s = sm;                              // [64 SK_KPL]
   float* red = sm + 64 * SK_KPL;                // [SK_WAVES][KP]
-  float* El = red + SK_WAVES * KP;              // [rows_per_wg][K] (LDS_E)
+  float* El = red + SK_WAVES * KP;              // [rows_per_wg][K]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wg = blockIdx.x;
   const int r0 = wg * g.rows_per_wg, r1 = min(g.B, r0 + g.rows_per_wg);
-  auto e_ptr = [&](int b) -> float* { return LDS_E ? El + (size_t)(b - r0) * K : g.Eg + (size_t)b * K; };
+  auto e_ptr = [&](int b) -> float* { return El + (size_t)(b - r0) * K; };
   float acc[SK_KPL], a[SK_KPL];
 
-  // fold the 16 waves' register partials and publish them (sc1), then signal
-  auto publish = [&](int buf) {
+  // fold the 16 waves' register partials (LDS) and publish the K sums of phase `ph` as granules
+  auto publish = [&](int ph) {
 #pragma unroll
     for (int i = 0; i < SK_KPL; ++i)
       if (lane + 64 * i < K) red[wave * KP + lane + 64 * i] = acc[i];
     __syncthreads();
-    float* out = g.part + ((size_t)buf * SK_MAXWG + wg) * K;
+    unsigned long long* out = g.gran + ((size_t)(ph & 1) * g.G + wg) * K;
     for (int k = threadIdx.x; k < K; k += SK_THREADS) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < SK_WAVES; ++w) s += red[w * KP + k];
-      __hip_atomic_store(out + k, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long v = (unsigned long long)__float_as_uint(s) | ((unsigned long long)(unsigned)(ph + 1) << 32);
+      __hip_atomic_store(out + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(g.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  // wait for all G partials of phase `ph`, then a_k = (1 / K) / sum over workgroups (fixed order)
+  // a_k = (1 / K) / sum over the workgroups' phase-`ph` partials (fixed order), each taken when its granule carries this phase's tag
   auto gather = [&](int ph) {
-    if (threadIdx.x == 0) {
-      const unsigned target = (unsigned)g.G * (unsigned)(ph + 1);
-      unsigned spins = 0;
-      while (__hip_atomic_load(g.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 24)) { __hip_atomic_store(g.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      }
-    }
-    __syncthreads();
-    // every partial is a round trip beyond this XCD's L2 (~ 1.5 us): all of them in flight at once - thread (k, j) takes the workgroups
-    // w = j, j + NJ, ... (NJ = 1024 / KP threads per k), their NJ sums meet in LDS and are added in the order of j: a fixed order
-    const float* in = g.part + (size_t)(ph & 1) * SK_MAXWG * K;
+    const unsigned tag = (unsigned)(ph + 1);
+    const unsigned long long* in = g.gran + (size_t)(ph & 1) * g.G * K;
     const int NJ = SK_THREADS / KP;
-    {
-      const int k = threadIdx.x % KP, j = threadIdx.x / KP;
-      float u = 0.f;
-      if (k < K && j < NJ) {
+    const int k = threadIdx.x % KP, j = threadIdx.x / KP;
+    float u = 0.f;
+    if (k < K && j < NJ) {
+      // thread (k, j) takes the workgroups w = j, j + NJ, ... - sixteen granules in flight, re-polled until they are all this phase's
+      for (int w0 = j; w0 < g.G; w0 += 16 * NJ) {
         float v[16];
-        for (int w0 = j; w0 < g.G; w0 += 16 * NJ) {
+        unsigned need = 0;
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const int w = w0 + q * NJ;
-            v[q] = w < g.G ? __hip_atomic_load(in + (size_t)w * K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-          }
-#pragma unroll
-          for (int q = 0; q < 16; ++q) u += v[q];
+        for (int q = 0; q < 16; ++q) {
+          v[q] = 0.f;
+          if (w0 + q * NJ < g.G) need |= 1u << q;
         }
+        unsigned spins = 0;
+        while (need) {
+          unsigned long long raw[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (need >> q & 1u) raw[q] = __hip_atomic_load(in + (size_t)(w0 + q * NJ) * K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if ((need >> q & 1u) && (unsigned)(raw[q] >> 32) == tag) {
+              v[q] = __uint_as_float((unsigned)raw[q]);
+              need &= ~(1u << q);
+            }
+          if (need) {
+            if (++spins > (1u << 22)) { __hip_atomic_store(g.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) u += v[q];
       }
-      if (j < NJ) red[j * KP + k] = u;
     }
+    __syncthreads();   // (red: publish's readers are done)
+    if (j < NJ) red[j * KP + k] = u;
     __syncthreads();
-    for (int k = threadIdx.x; k < K; k += SK_THREADS) {
-      float u = 0.f;
-      for (int j = 0; j < NJ; ++j) u += red[j * KP + k];
-      a_s[k] = (1.0f / (float)K) / u;
+    for (int k2 = threadIdx.x; k2 < K; k2 += SK_THREADS) {
+      float t = 0.f;
+      for (int j2 = 0; j2 < NJ; ++j2) t += red[j2 * KP + k2];
+      a_s[k2] = (1.0f / (float)K) / t;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < SK_KPL; ++i) a[i] = (lane + 64 * i < K) ? a_s[lane + 64 * i] : 0.f;
   };
 
-  // ---- phase 0: E = exp(scores / eps) for this workgroup's rows (kept), their column sums
+  // ---- phase 0: E = exp(scores / eps) for this workgroup's rows (kept in LDS), their column sums; four rows of a wave in flight
 #pragma unroll
   for (int i = 0; i < SK_KPL; ++i) acc[i] = 0.f;
-  for (int b = r0 + wave; b < r1; b += SK_WAVES) {
-    float* er = e_ptr(b);
+  for (int b = r0 + wave; b < r1; b += 4 * SK_WAVES) {
+    float v[4][SK_KPL];
 #pragma unroll
-    for (int i = 0; i < SK_KPL; ++i) {
-      const int k = lane + 64 * i;
-      if (k < K) {
-        const float e = expf(g.scores[(long long)b * K + k] / g.eps);
-        er[k] = e;
-        acc[i] += e;
+    for (int jj = 0; jj < 4; ++jj) {
+      const int bj = b + jj * SK_WAVES;
+      const int bc = min(bj, r1 - 1);                   // (clamped, not predicated: the loads of a pass then issue back to back)
+#pragma unroll
+      for (int i = 0; i < SK_KPL; ++i) {
+        const int k = lane + 64 * i;
+        if (64 * i < K) v[jj][i] = g.scores[(long long)bc * K + min(k, K - 1)];
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int bj = b + jj * SK_WAVES;
+      if (bj < r1) {
+        float* er = e_ptr(bj);
+#pragma unroll
+        for (int i = 0; i < SK_KPL; ++i) {
+          const int k = lane + 64 * i;
+          if (64 * i < K && k < K) {
+            const float e = expf(v[jj][i] / g.eps);
+            er[k] = e;
+            acc[i] += e;
+          }
+        }
       }
     }
   }
@@ -332,7 +357,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_persistent_kernel(SkpArgs g) {
       }
       break;
     }
-    // column step over this workgroup's rows, two rows per wave in flight; the row sums that follow
+    // column step over this workgroup's rows (LDS), two rows per wave in flight; the row sums that follow
 #pragma unroll
     for (int i = 0; i < SK_KPL; ++i) acc[i] = 0.f;
     for (int b = r0 + wave; b < r1; b += 2 * SK_WAVES) {
@@ -355,8 +380,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_persistent_kernel(SkpArgs g) {
 #pragma unroll
       for (int i = 0; i < SK_KPL; ++i) acc[i] += e[i] * bb + f[i] * bb2;
     }
-    __syncthreads();   // (red is reused: the previous publish's readers are done - they passed gather's barriers)
-    publish((it + 1) & 1);
+    publish(it + 1);   // (red: the gather above ended with a barrier behind its last reader)
   }
 }
 
@@ -444,27 +468,26 @@ static int sinkhorn_impl(const float* scores, const float* Q, int q_rows_are_col
   float* part[2] = {Ews + (size_t)B_total * K, Ews + (size_t)B_total * K + (size_t)SK_MAXWG * K};
   // E [B][K]: built in the workspace, or - when the caller already holds the positive matrix in that layout - read in place
   const float* E = (Q && q_rows_are_columns) ? Q : Ews;
-  // ---- one persistent launch (sk_persistent_kernel) where every workgroup can be resident at once: from scores only
-  if (!Q && tuning_knob(KNOB_SK_PERSIST) != 0) {   // (default off: measured slower, see sk_persistent_kernel)
+  // ---- one persistent launch (sk_persistent_kernel): from scores, every workgroup resident at once with its rows of E in LDS, the
+  // granule buffers inside the workspace's partial region.  Knob TT_SK_PERSIST: 0 never, 1 whenever it applies.
+  if (!Q && tuning_knob(KNOB_SK_PERSIST) != 0) {
     const int ncu = device_cu_count();
     const int cap = skp_lds_rows(K);
     static const int rows_env = [] { const char* e = getenv("TT_SKP_ROWS"); return e ? atoi(e) : 0; }();   // tuning aid
-    int rows = rows_env > 0 ? rows_env : 112;
+    int rows = rows_env > 0 ? rows_env : cap;
     if (rows > cap) rows = cap;
-    int G = rows > 0 ? (B_total + rows - 1) / rows : ncu + 1;
-    bool lds_e = G <= ncu && G <= SK_MAXWG;
-    if (!lds_e) {                      // beyond the chip's LDS: E stays in the workspace, one workgroup per CU
-      G = ncu < SK_MAXWG ? ncu : SK_MAXWG;
-      rows = (B_total + G - 1) / G;
-      G = (B_total + rows - 1) / rows;
+    const int G = rows > 0 ? (B_total + rows - 1) / rows : ncu + 1;
+    if (G <= ncu && G <= SK_MAXWG / 2) {
+      rows = (B_total + G - 1) / G;             // even shares
+      unsigned long long* gran = reinterpret_cast<unsigned long long*>(part[0]);
+      unsigned* status = reinterpret_cast<unsigned*>(Ews + (size_t)B_total * K + 2ull * SK_MAXWG * K);
+      // tags start at 1: zeroed granules never match.  The status word sits right behind the partial region: one memset for both
+      if (hipMemsetAsync(gran, 0, 2ull * SK_MAXWG * K * sizeof(float) + 16, s) != hipSuccess) { set_error("sinkhorn: hipMemsetAsync failed"); return TT_ELAUNCH; }
+      SkpArgs a{scores, gran, status, q_out, B_total, K, G, rows, row0, rows_out, iters, eps, B_total};
+      hipLaunchKernelGGL(sk_persistent_kernel, dim3(G), dim3(SK_THREADS), 0, s, a);
+      TT_CHECK_LAUNCH("sinkhorn (persistent)");
+      return TT_OK;
     }
-    unsigned* counter = reinterpret_cast<unsigned*>(Ews + (size_t)B_total * K + 2ull * SK_MAXWG * K);
-    if (hipMemsetAsync(counter, 0, 16, s) != hipSuccess) { set_error("sinkhorn: hipMemsetAsync failed"); return TT_ELAUNCH; }
-    SkpArgs a{scores, Ews, part[0], counter, q_out, B_total, K, G, rows, row0, rows_out, iters, eps, B_total};
-    if (lds_e) hipLaunchKernelGGL((sk_persistent_kernel<true>), dim3(G), dim3(SK_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((sk_persistent_kernel<false>), dim3(G), dim3(SK_THREADS), 0, s, a);
-    TT_CHECK_LAUNCH("sinkhorn (persistent)");
-    return TT_OK;
   }
   const int wgs = sk_wgs(B_total);
   const int rpw = (B_total + wgs - 1) / wgs;
