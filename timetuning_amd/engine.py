@@ -403,15 +403,16 @@ def vit_params(vit, first: int, last: int, pos: Optional[torch.Tensor] = None):
 # (the K-split of a K = 1536 launch's left-over tiles does: those rows agree to fp32 rounding; tests/test_hip_timet.py).
 TWO_STREAMS = __import__("os").environ.get("TT_SINGLE_STREAM") != "1"
 TWO_STREAMS_MIN_FRAMES = 32     # halves below 16 frames (3 152 token rows) no longer fill the chip: one stream
-_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+_SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
 
 
-def side_stream(device) -> "torch.cuda.Stream":
+def side_stream(device, which: int = 0) -> "torch.cuda.Stream":
+    """The side stream(s) of a device: 0 = the second chain of a section (see TWO_STREAMS), 1 = the EMA teacher's blocks and head."""
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
-    s = _SIDE_STREAMS.get(idx)
+    s = _SIDE_STREAMS.get((idx, which))
     if s is None:
-        s = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+        s = _SIDE_STREAMS[(idx, which)] = torch.cuda.Stream(device=idx)
     return s
 
 
@@ -421,11 +422,12 @@ def two_streams(device, frames: int) -> bool:
 
 def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None, save_blocks: Optional[Dict[int, dict]] = None,
                last_block_probs: bool = False, last_block_aux: Optional[dict] = None, tap: Optional[dict] = None,
-               save_from_frame: int = 0):
+               save_from_frame: int = 0, on_tap=None):
     """prepare_tokens + all blocks (dino_vision_transformer.py:236-252).  Returns (tokens before the final norm, attention
     probabilities of the last block or None).  ``last_block_aux`` receives the last block's qkv.
     ``tap = {"block": i, "rows": r}`` receives under ``"x"`` a private copy of the first ``r`` frames' residual stream as it
-    ENTERS block ``i`` (``i == depth``: as it leaves the last block) - what an EMA teacher sharing blocks [0, i) continues from.
+    ENTERS block ``i`` (``i == depth``: as it leaves the last block) - what an EMA teacher sharing blocks [0, i) continues from;
+    ``on_tap(tap)`` is called as soon as it exists (the teacher's own blocks can then start on another stream, beside the student's).
 
     ``save_blocks`` = {block id: dict} keeps the activations of those blocks for a later ``block_backward`` - of the frames
     [save_from_frame, F) only: a gradient reaches only the target frames (time_tuning.py:296-302), so from the first kept block
@@ -475,6 +477,8 @@ def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None,
             continue
         if tap is not None and tap["block"] == i:
             tap["x"] = (x if lo is None else lo)[: tap["rows"]].clone()
+            if on_tap is not None:
+                on_tap(tap)
         sv = save_blocks.get(i) if save_blocks is not None else None
         aux = last_block_aux if i == depth - 1 else None
         if split and i >= first_saved and lo is None and two_streams(img.device, x.shape[0]) and (tap is None or tap["block"] <= i or tap["block"] == depth):
@@ -517,6 +521,8 @@ def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None,
         x = block_forward(x, blk, vit.num_heads, sv, aux)
     if tap is not None and tap["block"] == depth:
         tap["x"] = (x if lo is None else lo)[: tap["rows"]].clone()
+        if on_tap is not None:
+            on_tap(tap)
     return (x if lo is None else (lo, hi)), probs
 
 
@@ -893,6 +899,7 @@ class GradExchange:
     def push(self, grads: Dict[torch.nn.Parameter, torch.Tensor], final: bool = False) -> None:
         if self.dist is None:
             return
+        ops.wgrad_join(final=False)   # (weight gradients launched on the side stream: the bucket's all-reduce reads them)
         if GRAD_BUCKETS == 1 and not final:
             return                                   # one all-reduce of everything, issued by ``finish``
         keys = [k for k in grads if k not in self.sent and k.requires_grad]

@@ -1210,6 +1210,37 @@ def linear_bwd_weight_pairs_tn(dy_pairs, x_pairs, dw_out=None, dy_scale=None, co
     return dw
 
 
+# Weight gradients on a side stream (round 6): ``wgrad_fork(stream)`` at the top of a backward, ``wgrad_join()`` before anything reads a
+# gradient (the optimizer, a gradient bucket's all-reduce).  Between them ``linear_bwd_pairs`` launches its transpose-free weight-gradient
+# product on ``stream`` behind the dy's split and carries on with the data gradient on the current stream.
+_WGRAD = {"side": None, "keep": []}
+
+
+def wgrad_fork(stream) -> None:
+    _WGRAD["side"] = stream
+
+
+def wgrad_join(final: bool = True) -> None:
+    side = _WGRAD["side"]
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
+        _WGRAD["keep"].clear()
+        if final:
+            _WGRAD["side"] = None
+
+
+def wgrad_call(fn, keep=()):
+    """``fn()`` on the weight-gradient side stream when one is armed (``wgrad_fork``), behind everything queued on the current stream so far;
+    ``keep``: the tensors ``fn`` reads that the caller is about to drop (held until the join)."""
+    side = _WGRAD["side"] if PROFILE is None else None
+    if side is None:
+        return fn()
+    side.wait_stream(torch.cuda.current_stream())
+    _WGRAD["keep"].append(keep)
+    with torch.cuda.stream(side):
+        return fn()
+
+
 def linear_bwd_pairs(dy, wT_pairs, xT_pairs=None, gelu_pre=None, need_bias: bool = True, need_dx: bool = True, dw_out=None, db_out=None, x_pairs=None,
                      dy_amax=None, dx_amax_out=None):
     """(dx, dw, db) of an nn.Linear on pair operands: dy fp32 [M,N] is split here in ONE pass (row pairs for both gradient products, column
@@ -1229,10 +1260,14 @@ def linear_bwd_pairs(dy, wT_pairs, xT_pairs=None, gelu_pre=None, need_bias: bool
         r4 = split_pairs_dual(dy, want_row=True, want_colsum=need_bias, want_t=False, scaled=GRAD_SCALE, colsum_parts=need_bias,
                               amax_in=dy_amax if (need_bias and GRAD_SCALE) else None)
         dy_row, parts, dy_scale = r4[1], r4[2], (r4[3] if GRAD_SCALE else None)
+        # the weight gradient is a LEAF of the backward (nothing downstream reads it before the optimizer): with a side stream set
+        # (``wgrad_fork``: engine.TWO_STREAMS) it runs there, beside the data-gradient chain that continues on this stream
+        # (kept alive until the join: freed earlier, their blocks could be reused on THIS stream under the side stream's reads)
         if need_bias:
-            dw, db = linear_bwd_weight_pairs_tn(dy_row, x_pairs, dw_out, dy_scale, colsum_parts=parts, db_out=db_out)
+            dw, db = wgrad_call(lambda: linear_bwd_weight_pairs_tn(dy_row, x_pairs, dw_out, dy_scale, colsum_parts=parts, db_out=db_out),
+                                keep=(dy_row, parts, dy_scale, x_pairs))
         else:
-            dw, db = linear_bwd_weight_pairs_tn(dy_row, x_pairs, dw_out, dy_scale), None
+            dw, db = wgrad_call(lambda: linear_bwd_weight_pairs_tn(dy_row, x_pairs, dw_out, dy_scale), keep=(dy_row, dy_scale, x_pairs)), None
     else:
         if xT_pairs is None:
             xT_pairs = transpose_pairs(x_pairs)

@@ -548,6 +548,12 @@ class TimeT(nn.Module):
         return self._frame_maps[key]
 
     def _run_step(self, x: torch.Tensor, hp: dict, need_grad: bool):
+        try:
+            return self._run_step_impl(x, hp, need_grad)
+        finally:
+            ops.wgrad_join()   # (an exception inside the backward must not leave the side stream armed for the next caller)
+
+    def _run_step_impl(self, x: torch.Tensor, hp: dict, need_grad: bool):
         fe = self.feature_extractor
         vit = fe.backbone
         bs, fs, c, h, w = x.shape
@@ -588,8 +594,27 @@ class TimeT(nn.Module):
         f0 = (fs - 1) * bs
         # (in the default f32 mode the two streams would run the same kernels on smaller launches: split only when a bf16-plane
         # mode gives the stream that keeps nothing a faster path)
+        # The EMA teacher's own blocks + head on frame 0 continue from the tap (the student's frozen-block activations): an independent chain
+        # of 6 304-row launches - with two streams it starts on side stream 1 as soon as the tap exists, beside the student's trainable blocks
+        teach: dict = {}
+
+        def teacher_chain(tap_):
+            tvit_ = self.teacher.backbone
+            t_tok_ = engine.vit_blocks(tvit_, tap_["x"], t_first)
+            t_feats_ = ops.layernorm_fwd(t_tok_, tvit_.norm.weight, tvit_.norm.bias, drop_first_token=True)
+            teach["z_q"] = engine.head_forward(t_feats_, self.teacher.head) if self.teacher.head is not None else t_feats_
+
+        def on_tap(tap_):
+            s1 = engine.side_stream(dev, 1)
+            s1.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s1):
+                teacher_chain(tap_)
+            teach["stream"] = s1
+
+        early_teacher = tap is not None and not use_mask and t_first < depth and engine.two_streams(dev, Fr)
         tok, _ = engine.vit_tokens(vit, xf, self._frame_map(bs, fs, dev), save, last_block_aux=s_aux, tap=tap,
-                                   save_from_frame=f0 if ops.plane_count_for(f0 * (1 + fe.spatial_resolution ** 2)) else 0)
+                                   save_from_frame=f0 if ops.plane_count_for(f0 * (1 + fe.spatial_resolution ** 2)) else 0,
+                                   on_tap=on_tap if early_teacher else None)
         tok_lo, tok_hi = tok if isinstance(tok, tuple) else (tok[:f0], tok[f0:])
         dbg("tok_lo", tok_lo); dbg("tok_hi", tok_hi)
         if keep is not None and save:
@@ -618,18 +643,43 @@ class TimeT(nn.Module):
         src_rows, tgt_rows = feats[: bs * n], feats[(fs - 1) * bs * n:]
         dbg("feats", feats); dbg("xn_bb", xn_bb)
 
+        # ---- target frames: head + scores (with grad).  Independent of the assignment chain below (source head, queue, scores, Sinkhorn,
+        # label propagation) until the cross entropy: with two streams (engine.TWO_STREAMS) it runs on the side stream beside that chain -
+        # both are 6 272-row launch sequences that leave a quarter of the chip idle on their own
+        def target_chain():
+            sv_h: Optional[dict] = {} if need_grad else None
+            z_t = engine.head_forward(tgt_rows, fe.head, sv_h) if fe.head is not None else tgt_rows
+            if use_mask:
+                z_t = ops.scale_rows_(z_t if fe.head is not None else z_t.clone(), mask_tgt)  # features * mask (models.py:142)
+            sv_s: Optional[dict] = {} if need_grad else None
+            return z_t, engine.prototype_scores(z_t, self.prototypes.data, sv_s), sv_h, sv_s   # scores [bs*n, K]
+
+        tgt = None
+        side = engine.side_stream(dev) if engine.two_streams(dev, Fr) else None
+        if side is not None:
+            if fe.head is not None and engine._head_pairs_ok(engine.head_linears(fe.head), tgt_rows.shape[0]):
+                for lin_ in engine.head_linears(fe.head):     # lazily made, cached operands: made on THIS stream before the fork
+                    engine.weight_planes(lin_.weight, 2)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                tgt = target_chain()
+
         # ---- assignment source: teacher on frame 0 if present, else the student's frame 0 (no grad either way)
         if self.teacher is not None:
             tvit = self.teacher.backbone
             t_aux: Optional[dict] = {} if use_mask else None
-            if tap is not None:   # frame 0 = the first bs frames of the time-major pass
-                t_tok = engine.vit_blocks(tvit, tap["x"], t_first, last_block_aux=t_aux)
-                if use_mask and t_first == depth:
-                    t_aux["qkv"] = qkv_src
+            if "stream" in teach:   # (launched from inside the student's pass, on side stream 1: see teacher_chain)
+                torch.cuda.current_stream().wait_stream(teach["stream"])
+                z_q = teach["z_q"]
             else:
-                t_tok, _ = engine.vit_tokens(tvit, xf, self._frame_map(bs, fs, dev, only_t=0), last_block_aux=t_aux)
-            t_feats = ops.layernorm_fwd(t_tok, tvit.norm.weight, tvit.norm.bias, drop_first_token=True)
-            z_q = engine.head_forward(t_feats, self.teacher.head) if self.teacher.head is not None else t_feats
+                if tap is not None:   # frame 0 = the first bs frames of the time-major pass
+                    t_tok = engine.vit_blocks(tvit, tap["x"], t_first, last_block_aux=t_aux)
+                    if use_mask and t_first == depth:
+                        t_aux["qkv"] = qkv_src
+                else:
+                    t_tok, _ = engine.vit_tokens(tvit, xf, self._frame_map(bs, fs, dev, only_t=0), last_block_aux=t_aux)
+                t_feats = ops.layernorm_fwd(t_tok, tvit.norm.weight, tvit.norm.bias, drop_first_token=True)
+                z_q = engine.head_forward(t_feats, self.teacher.head) if self.teacher.head is not None else t_feats
             protos_q = self.teacher_prototypes.data
             mask_q = ops.foreground_mask(t_aux["qkv"], tvit.num_heads, g).view(-1) if use_mask else None  # time_tuning.py:235-236
         else:
@@ -662,16 +712,14 @@ class TimeT(nn.Module):
         dbg("z_q", z_q); dbg("scores_q", scores_q)
         gather = engine.global_sinkhorn_begin(scores_q)  # W > 1: the score rows travel while the target head runs
 
-        # ---- target frames: head + scores (with grad)
-        sv_head: Optional[dict] = {} if need_grad else None
-        z_tgt = engine.head_forward(tgt_rows, fe.head, sv_head) if fe.head is not None else tgt_rows
-        if use_mask:
-            z_tgt = ops.scale_rows_(z_tgt if fe.head is not None else z_tgt.clone(), mask_tgt)  # features * mask (models.py:142)
-        sv_sc: Optional[dict] = {} if need_grad else None
-        scores_t = engine.prototype_scores(z_tgt, self.prototypes.data, sv_sc)                 # [bs*n, K]
-        K = scores_t.shape[1]
+        if side is None:   # one stream: the target chain here, between the two halves of the exchange (W > 1: the score rows travel under it)
+            tgt = target_chain()
+        K = self.prototypes.shape[0]
         q = engine.global_sinkhorn_end(gather, bs * n, hp["epsilon"], hp["iters"])              # [bs*n, K]
         labels = ops.label_propagate(xn_bb, q.view(bs, n, K), hp["n_last_frames"], hp["radius"], hp["topk"], 0.1)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        z_tgt, scores_t, sv_head, sv_sc = tgt
         ce_labels = labels
         if hp.get("target_labels") is not None:
             ce_labels = torch.as_tensor(hp["target_labels"]).to(device=dev, dtype=torch.int64).reshape(bs, n).contiguous()
@@ -692,7 +740,11 @@ class TimeT(nn.Module):
         exchange = engine.GradExchange(self._grad_arena)
         out = exchange.out
         prescaled = exchange.prescale_(dscores)   # 1 / W once, on the 5 MB loss gradient, instead of on every bucket
-        grads[self.prototypes], _ = ops.linear_bwd_weight(dscores, sv_sc["zn"], need_bias=False, dw_out=out(self.prototypes))
+        if engine.two_streams(dev, bs * fs) and ops.pairs():
+            ops.wgrad_fork(engine.side_stream(dev))   # the weight-gradient products beside the data-gradient chain (joined below)
+        zn_t = sv_sc["zn"]
+        grads[self.prototypes], _ = ops.wgrad_call(lambda: ops.linear_bwd_weight(dscores, zn_t, need_bias=False, dw_out=out(self.prototypes)),
+                                                   keep=(dscores, zn_t))   # (a leaf too: beside the head's backward)
         # "f16x3": every dy of a Linear is scaled by a power of two before its pair split; the kernel that PRODUCES the dy publishes its
         # max |.| into a slot of this pool (one 64-float fill per step instead of a max pass per dy: 12 launches)
         pool = ops.AmaxPool.get(dev) if (ops.pairs() and ops.GRAD_SCALE and ops.AMAX_FROM_PRODUCERS) else None
@@ -733,6 +785,7 @@ class TimeT(nn.Module):
                 if i > first:
                     exchange.push(grads)  # this block's gradients travel while the next block's backward runs
         grads = {p: g for p, g in grads.items() if p.requires_grad}
+        ops.wgrad_join()
         return loss, exchange.finish(grads, scale=not prescaled)
 
 
