@@ -36,7 +36,7 @@ extern "C" {
 typedef void* tt_stream_t;
 
 const char* tt_last_error(void);
-int tt_abi_version(void);   /* 7 = this header (6: before the caller-owned K-split workspace and the range flag; 5: before the transpose-free weight gradient, the batched operand refresh and the distributed Sinkhorn steps; 4: before the fp16-pair entry points; 3: before tt_vit_params.patch_wp; 2: before the coarse entry points) */
+int tt_abi_version(void);   /* 8 = this header (7: before `precision` became an argument - tt_set_gemm_precision, a process-wide switch, is gone; 6: before the caller-owned K-split workspace and the range flag; 5: before the transpose-free weight gradient, the batched operand refresh and the distributed Sinkhorn steps; 4: before the fp16-pair entry points; 3: before tt_vit_params.patch_wp; 2: before the coarse entry points) */
 /* Tuning knobs of the dispatchers (TT_PLANES_VARIANT, TT_P8_ORDER, TT_P8_NO_HALF, TT_P8_CLOCK_PRINT, TT_Q8_ORDER, TT_PAIRS_NO8,
  * TT_PAIRS8_NO_KEPT) are read ONCE from the environment; this setter changes one afterwards - for the A/B tools and tests only. */
 int tt_set_tuning_knob(const char* name, int value);
@@ -63,7 +63,7 @@ int tt_linear_ksplit_workspace_init(void* workspace, size_t workspace_bytes, tt_
  *   activation (saved for backward).  residual (optional, [M,N]) is added after the activation;
  *   it may alias y. */
 int tt_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
-                  float* pre_act, int M, int N, int K, int act, tt_stream_t stream);
+                  float* pre_act, int M, int N, int K, int act, int precision, tt_stream_t stream);
 
 /* ---- k16: nn.Linear backward (autograd of the sites above)
  *   dx[M,K] = dy[M,N] @ w[N,K]            (* gelu'(gelu_pre[M,K]) if gelu_pre != NULL)
@@ -112,15 +112,20 @@ int tt_linear_fwd_planes_route(int planes, int M, int N, int K, int act, int has
 int tt_pos_embed_interpolate(const float* pos, float* out, int g, int gh, int gw, int D, float scale_h, float scale_w,
                              tt_stream_t stream);
 
-/* Arithmetic of the forward nn.Linear products (tt_linear_fwd), process-wide:
- *   0 = f32 MFMA (default; exact fmaf chain, the mode every parity claim and the headline benchmark refer to)
- *   1 = "bf16x3": operands split into bf16 hi + lo, three bf16 MFMAs per product term (~2^-16 relative per product)
- *   2 = "bf16":   operands rounded to bf16 (BASELINE config C4's "MFMA bf16 path"; does not meet the 1e-3 fp32 contract); in this mode
- *                 tt_label_propagate[_maps] computes its cosine similarities on bf16 MFMA too (what torch.autocast makes of them)
- * Inputs/outputs stay fp32 in memory in every mode.  tt_linear_bwd* always run in f32 (the bf16 path's backward products have their own
- * entry points: tt_linear_bwd_data_planes, tt_linear_bwd_weight_planes, tt_attention_bwd_bf16). */
-int tt_set_gemm_precision(int mode);
-int tt_get_gemm_precision(void);
+/* `precision`: the arithmetic of the fp32-OPERAND forward products - an ARGUMENT of every entry point that has one (ABI 8; until ABI 7 a
+ * process-wide switch, tt_set_gemm_precision: hidden state this interface promises not to have).  Taken by tt_linear_fwd,
+ * tt_label_propagate[_maps], tt_mlp_head_forward, tt_scores_sinkhorn and, as tt_vit_params.precision, tt_vit_forward (planes == 0):
+ *   TT_PRECISION_F32    0  f32 MFMA (exact fmaf chain)
+ *   TT_PRECISION_BF16X3 1  operands split into bf16 hi + lo while staged, three bf16 MFMAs per product term (~2^-16 relative per product)
+ *   TT_PRECISION_BF16   2  operands rounded to bf16 (BASELINE config C4's "MFMA bf16 path"; does not meet the 1e-3 fp32 contract);
+ *                          tt_label_propagate[_maps] then computes its cosine similarities on bf16 MFMA too (what torch.autocast makes of
+ *                          them); 0 and 1 leave them exact
+ * Inputs / outputs stay fp32 in memory in every case.  The fp32-accurate split modes are not a `precision` but an operand FORMAT with
+ * entry points of its own (fp16 pairs: tt_*_pairs*; three bf16 planes: tt_*_planes*).  tt_linear_bwd* always run in f32 (the bf16 path's
+ * backward products have their own entry points: tt_linear_bwd_data_planes, tt_linear_bwd_weight_planes, tt_attention_bwd_bf16). */
+#define TT_PRECISION_F32 0
+#define TT_PRECISION_BF16X3 1
+#define TT_PRECISION_BF16 2
 
 /* ---- k1,k2: PatchEmbed conv (kernel = stride = P) + cls token + pos-embed
  *      (dino_vision_transformer.py:166-171, 236-247)
@@ -360,7 +365,7 @@ size_t tt_linear_bwd_weight_planes_workspace_bytes(int N, int K, int Mpad);
  *   pmap_last [bs, n, K] fp64 optional (the map itself).
  *   workspace: tt_label_propagate_workspace_bytes(...). */
 int tt_label_propagate(const float* xn, const float* seg0, int64_t* labels, double* pmap_last, int bs, int fs, int g,
-                       int D, int K, int n_last_frames, int radius, int topk, float temperature, void* workspace,
+                       int D, int K, int n_last_frames, int radius, int topk, float temperature, int precision, void* workspace,
                        size_t workspace_bytes, tt_stream_t stream);
 size_t tt_label_propagate_workspace_bytes(int bs, int fs, int g, int D, int K, int n_last_frames);
 
@@ -375,7 +380,7 @@ size_t tt_label_propagate_workspace_bytes(int bs, int fs, int g, int D, int K, i
  *                            C <= 4096: the confusion matrix from which the Jaccard index (J) of the propagated masks and
  *                            the evaluator's matched mIoU (metrics.py:357-432) follow. */
 int tt_label_propagate_maps(const float* xn, const float* seg0, double* pmap_all, int bs, int fs, int g, int D, int K,
-                            int n_last_frames, int radius, int topk, float temperature, void* workspace,
+                            int n_last_frames, int radius, int topk, float temperature, int precision, void* workspace,
                             size_t workspace_bytes, tt_stream_t stream);
 int tt_upsample_argmax(const double* maps, int64_t* labels_out, int M, int g, int K, int R, tt_stream_t stream);
 int tt_confusion_counts(const int64_t* pred, const int64_t* gt, long long n, int C, unsigned long long* counts,
@@ -490,7 +495,7 @@ int tt_img_box_blur(const unsigned char* in, unsigned char* out, int F, int H, i
 
 /* ---- Coarse entry points: whole reference functions as ONE call each.  They sequence the op-level entry
  *      points above on `stream` (same kernels, same results bit for bit as calling those one by one; they honour
- *      tt_set_gemm_precision the way tt_linear_fwd does) and add nothing but the scratch layout.  Parameter tables are HOST
+ *      their `precision` argument / tt_vit_params.precision the way tt_linear_fwd does) and add nothing but the scratch layout.  Parameter tables are HOST
  *      arrays of DEVICE pointers, read during the call only.
  *
  *   tt_vit_forward       VisionTransformer.prepare_tokens + blocks + norm (dino_vision_transformer.py:236-252,265-273; Block
@@ -533,6 +538,7 @@ typedef struct {
                                                    pairs [D][2 C P P] - tt_patch_embed_fwd_pairs where ITS rules hold and C P P <= 3 D
                                                    (the rows then fit the scratch) (ABI 6) */
   int* range_flag;                              /* planes == 2: the pair producers' range flag (device int or NULL; ABI 7) */
+  int precision;                                /* planes == 0: the `precision` of the blocks' tt_linear_fwd products (TT_PRECISION_*; ABI 8) */
 } tt_vit_params;
 typedef struct {
   const float* w;   /* [out_features, in_features] */
@@ -544,12 +550,12 @@ int tt_vit_forward(const tt_vit_params* p, const float* img, const int32_t* fram
                    float* normed, int drop_cls, float* last_qkv, float* last_probs, void* workspace, size_t workspace_bytes,
                    tt_stream_t stream);
 size_t tt_mlp_head_forward_workspace_bytes(int M, const tt_linear_params* layers, int n_layers);
-int tt_mlp_head_forward(const float* x, int M, const tt_linear_params* layers, int n_layers, float* out, void* workspace,
+int tt_mlp_head_forward(const float* x, int M, const tt_linear_params* layers, int n_layers, float* out, int precision, void* workspace,
                         size_t workspace_bytes, tt_stream_t stream);
 size_t tt_scores_sinkhorn_workspace_bytes(int B, int queue_rows, int K, int dim);
 int tt_scores_sinkhorn(const float* z, int B, const float* queue, int queue_rows, const float* prototypes, int K, int dim,
-                       float* scores, float* q_out, int rows_out, float eps, int iters, void* workspace, size_t workspace_bytes,
-                       tt_stream_t stream);
+                       float* scores, float* q_out, int rows_out, float eps, int iters, int precision, void* workspace,
+                       size_t workspace_bytes, tt_stream_t stream);
 int tt_adamw_ema_step(const tt_adamw_tensor* tensors, int count, int step, float beta1, float beta2, float eps, float* prototypes,
                       int K, int dim, float* teacher_flat, const float* student_flat, long long n_flat, float* teacher_prototypes,
                       double momentum, tt_stream_t stream);

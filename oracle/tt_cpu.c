@@ -352,9 +352,10 @@ static float tt_cpu_gelu_grad(float x) {
 }
 
 /* ---- nn.Linear forward (dino_vision_transformer.py:94-103,115-130; models.py:915-926): y = act(x w^T + b) (+ residual) */
+/* (`precision`, ABI 8: which MFMA arithmetic the GPU entry point runs the product in; the twin is the exact product whatever it says) */
 int tt_cpu_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, float* pre_act, int M, int N,
-                      int K, int act, tt_stream_t stream) {
-  (void)stream;
+                      int K, int act, int precision, tt_stream_t stream) {
+  (void)stream; (void)precision;
   for (int m = 0; m < M; ++m)
     for (int n = 0; n < N; ++n) {
       double s = bias ? (double)bias[n] : 0.0;
@@ -907,6 +908,7 @@ typedef struct {
   int planes;
   const void* patch_wp;
   int* range_flag;
+  int precision;
 } tt_cpu_vit_params;
 typedef struct { const float* w; const float* b; int out_features, in_features; } tt_cpu_linear_params;
 
@@ -1231,12 +1233,12 @@ int tt_cpu_vit_forward(const tt_cpu_vit_params* p, const float* img, const int32
     float* qkv = (last && last_qkv) ? last_qkv : qkv_own;
     if (P == 0) {
       tt_cpu_layernorm_fwd(tokens, b->norm1_w, b->norm1_b, h, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
-      tt_cpu_linear_fwd(h, b->qkv_w, b->qkv_b, NULL, qkv, NULL, (int)M, 3 * D, D, 0, stream);
+      tt_cpu_linear_fwd(h, b->qkv_w, b->qkv_b, NULL, qkv, NULL, (int)M, 3 * D, D, 0, 0, stream);
       tt_cpu_attention_fwd(qkv, att, NULL, probs, F, N, p->heads, hd, scale, stream);
-      tt_cpu_linear_fwd(att, b->proj_w, b->proj_b, tokens, tokens, NULL, (int)M, D, D, 0, stream);
+      tt_cpu_linear_fwd(att, b->proj_w, b->proj_b, tokens, tokens, NULL, (int)M, D, D, 0, 0, stream);
       tt_cpu_layernorm_fwd(tokens, b->norm2_w, b->norm2_b, h, NULL, NULL, (int)M, D, 1e-6f, 0, stream);
-      tt_cpu_linear_fwd(h, b->fc1_w, b->fc1_b, NULL, act, NULL, (int)M, Hd, D, 1, stream);
-      tt_cpu_linear_fwd(act, b->fc2_w, b->fc2_b, tokens, tokens, NULL, (int)M, D, Hd, 0, stream);
+      tt_cpu_linear_fwd(h, b->fc1_w, b->fc1_b, NULL, act, NULL, (int)M, Hd, D, 1, 0, stream);
+      tt_cpu_linear_fwd(act, b->fc2_w, b->fc2_b, tokens, tokens, NULL, (int)M, D, Hd, 0, 0, stream);
       continue;
     }
     const long long MD = (long long)M * D;
@@ -1285,8 +1287,9 @@ int tt_cpu_vit_forward(const tt_cpu_vit_params* p, const float* img, const int32
 }
 
 /* models.py:915-926,1075-1077: Linear (GELU Linear)* */
-int tt_cpu_mlp_head_forward(const float* x, int M, const tt_cpu_linear_params* layers, int n_layers, float* out, void* workspace,
+int tt_cpu_mlp_head_forward(const float* x, int M, const tt_cpu_linear_params* layers, int n_layers, float* out, int precision, void* workspace,
                             size_t workspace_bytes, tt_stream_t stream) {
+  (void)precision;
   int width = 1;
   for (int i = 0; i < n_layers; ++i) width = layers[i].out_features > width ? layers[i].out_features : width;
   float* buf[2] = {(float*)malloc((size_t)M * width * 4), (float*)malloc((size_t)M * width * 4)};
@@ -1295,7 +1298,7 @@ int tt_cpu_mlp_head_forward(const float* x, int M, const tt_cpu_linear_params* l
   for (int i = 0; i < n_layers; ++i) {
     const int last = i == n_layers - 1;
     float* dst = last ? out : buf[i & 1];
-    tt_cpu_linear_fwd(cur, layers[i].w, layers[i].b, NULL, dst, NULL, M, layers[i].out_features, layers[i].in_features, last ? 0 : 1, stream);
+    tt_cpu_linear_fwd(cur, layers[i].w, layers[i].b, NULL, dst, NULL, M, layers[i].out_features, layers[i].in_features, last ? 0 : 1, 0, stream);
     cur = dst;
   }
   free(buf[0]); free(buf[1]);
@@ -1304,16 +1307,18 @@ int tt_cpu_mlp_head_forward(const float* x, int M, const tt_cpu_linear_params* l
 
 /* time_tuning.py:195-217 (get_scores) on one rank: normalised batch and queue rows against the prototypes, one assignment */
 int tt_cpu_scores_sinkhorn(const float* z, int B, const float* queue, int queue_rows, const float* prototypes, int K, int dim, float* scores,
-                           float* q_out, int rows_out, float eps, int iters, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+                           float* q_out, int rows_out, float eps, int iters, int precision, void* workspace, size_t workspace_bytes,
+                           tt_stream_t stream) {
+  (void)precision;
   if (!queue) queue_rows = 0;
   const int total = B + queue_rows;
   float* zn = (float*)malloc((size_t)total * dim * 4);
   if (!zn) return -3;
   tt_cpu_l2norm_fwd(z, dim, zn, NULL, B, dim, stream);
-  tt_cpu_linear_fwd(zn, prototypes, NULL, NULL, scores, NULL, B, K, dim, 0, stream);
+  tt_cpu_linear_fwd(zn, prototypes, NULL, NULL, scores, NULL, B, K, dim, 0, 0, stream);
   if (queue_rows) {
     tt_cpu_l2norm_fwd(queue, dim, zn + (size_t)B * dim, NULL, queue_rows, dim, stream);
-    tt_cpu_linear_fwd(zn + (size_t)B * dim, prototypes, NULL, NULL, scores + (size_t)B * K, NULL, queue_rows, K, dim, 0, stream);
+    tt_cpu_linear_fwd(zn + (size_t)B * dim, prototypes, NULL, NULL, scores + (size_t)B * K, NULL, queue_rows, K, dim, 0, 0, stream);
   }
   free(zn);
   return tt_cpu_sinkhorn(scores, q_out, total, K, 0, rows_out, eps, iters, NULL, 0, stream);
@@ -1663,10 +1668,14 @@ static int lp_cpu(const float* xn, const float* seg0, int64_t* labels, double* p
 }
 size_t tt_cpu_label_propagate_workspace_bytes(int bs, int fs, int g, int D, int K, int n_last_frames) { return 0; }
 int tt_cpu_label_propagate(const float* xn, const float* seg0, int64_t* labels, double* pmap_last, int bs, int fs, int g, int D, int K,
-                           int n_last_frames, int radius, int topk, float temperature, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+                           int n_last_frames, int radius, int topk, float temperature, int precision, void* workspace, size_t workspace_bytes,
+                           tt_stream_t stream) {
+  (void)precision;
   return lp_cpu(xn, seg0, labels, pmap_last, NULL, bs, fs, g, D, K, n_last_frames, radius, topk, temperature);
 }
 int tt_cpu_label_propagate_maps(const float* xn, const float* seg0, double* pmap_all, int bs, int fs, int g, int D, int K, int n_last_frames,
-                                int radius, int topk, float temperature, void* workspace, size_t workspace_bytes, tt_stream_t stream) {
+                                int radius, int topk, float temperature, int precision, void* workspace, size_t workspace_bytes,
+                                tt_stream_t stream) {
+  (void)precision;
   return lp_cpu(xn, seg0, NULL, NULL, pmap_all, bs, fs, g, D, K, n_last_frames, radius, topk, temperature);
 }

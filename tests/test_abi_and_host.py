@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} is declared in include/timetuning_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in timetuning_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(declared)
-    assert lib.tt_abi_version() == 7
+    assert lib.tt_abi_version() == 8
     # size queries are pure host functions and can be called without a GPU
     assert lib.tt_sinkhorn_workspace_bytes(6272, 200) >= 6272 * 200 * 4
     assert lib.tt_ce_workspace_bytes(100) == 400

@@ -145,7 +145,7 @@ def _small_cases(lib, prefix, mem):
     out = np.empty((M, dims[-1]), np.float32)
     nb = getattr(lib, prefix + "mlp_head_forward_workspace_bytes")(M, arr, 3)
     ws = np.empty(max(nb, 16), np.uint8)
-    assert getattr(lib, prefix + "mlp_head_forward")(mem(x), M, arr, 3, mem(out), mem(ws), nb, mem.stream) == 0
+    assert getattr(lib, prefix + "mlp_head_forward")(mem(x), M, arr, 3, mem(out), 0, mem(ws), nb, mem.stream) == 0
     mem.back(out)
     R["head"] = (x, lay, out)
     # scores + assignment, with queue rows
@@ -157,7 +157,7 @@ def _small_cases(lib, prefix, mem):
         nb = getattr(lib, prefix + "scores_sinkhorn_workspace_bytes")(B, qrows, K, dim)
         ws = np.empty(max(nb, 16), np.uint8)
         assert getattr(lib, prefix + "scores_sinkhorn")(mem(z), B, mem(queue) if qrows else None, qrows, mem(protos), K, dim, mem(scores), mem(q), B,
-                                                        0.05, 10, mem(ws), nb, mem.stream) == 0
+                                                        0.05, 10, 0, mem(ws), nb, mem.stream) == 0
         mem.back(scores, q)
         R[f"scores{qrows}"] = (z, queue[:qrows], protos, scores, q)
     # AdamW over 45 tensors (more than one table of TT_MAX_TENSORS) + prototype renormalisation + EMA
@@ -290,9 +290,9 @@ def test_coarse_entry_argument_checks():
     assert lib.tt_vit_forward(C.byref(vp), None, None, 1, 3, 30, 48, t.data_ptr(), None, 0, None, None, None, 0, None) == -1
     assert lib.tt_vit_forward(C.byref(vp), None, None, 1, 3, 32, 48, t.data_ptr(), None, 0, None, None, None, 0, None) == 0   # nothing to do
     arr = (L.LinearParams * 2)(L.LinearParams(t.data_ptr(), None, 8, 16), L.LinearParams(t.data_ptr(), None, 4, 9))
-    assert lib.tt_mlp_head_forward(t.data_ptr(), 4, arr, 2, t.data_ptr(), t.data_ptr(), 1 << 20, None) == -1
+    assert lib.tt_mlp_head_forward(t.data_ptr(), 4, arr, 2, t.data_ptr(), 0, t.data_ptr(), 1 << 20, None) == -1
     assert b"layer 1 takes 9" in lib.tt_last_error()
-    assert lib.tt_scores_sinkhorn(t.data_ptr(), 4, None, 0, t.data_ptr(), 4, 8, t.data_ptr(), t.data_ptr(), 9, 0.05, 3, t.data_ptr(), 1 << 20, None) == -1
+    assert lib.tt_scores_sinkhorn(t.data_ptr(), 4, None, 0, t.data_ptr(), 4, 8, t.data_ptr(), t.data_ptr(), 9, 0.05, 3, 0, t.data_ptr(), 1 << 20, None) == -1
     # the bf16 patch embedding: shape rules and the workspace size are checked, nothing is launched on a bad call
     big = torch.zeros(1 << 20, device="cuda")
     p_ = big.data_ptr()

@@ -193,7 +193,7 @@ def _round2_cases(side, tol):
     M, N, K = 70, 64, 48
     x, w, b, res = f32(M, K), f32(N, K, scale=0.1), f32(N), f32(M, N)
     y, pre = np.empty((M, N), np.float32), np.empty((M, N), np.float32)
-    side.run("linear_fwd", x, w, b, res, y, pre, M, N, K, 1, st, outs=(y, pre))
+    side.run("linear_fwd", x, w, b, res, y, pre, M, N, K, 1, 0, st, outs=(y, pre))
     R["linear_fwd"] = (x, w, b, res, y.copy(), pre.copy())
     dy, gp = f32(M, N), f32(M, K)
     dx = np.empty((M, K), np.float32)
@@ -618,8 +618,8 @@ def _round2c_cases(side):
     seg0 = np.exp(f32(bs, nl, Kl) * 2)
     seg0 = (seg0 / seg0.sum(-1, keepdims=True)).astype(np.float32)
     labels, last, allm = np.empty((bs, nl), np.int64), np.empty((bs, nl, Kl), np.float64), np.empty((fs - 1, bs, nl, Kl), np.float64)
-    side.run("label_propagate", xn, seg0, labels, last, bs, fs, gl, Dl, Kl, nlast, 2, 3, 0.1, ws, nb, st, outs=(labels, last))
-    side.run("label_propagate_maps", xn, seg0, allm, bs, fs, gl, Dl, Kl, nlast, 2, 3, 0.1, ws, nb, st, outs=(allm,))
+    side.run("label_propagate", xn, seg0, labels, last, bs, fs, gl, Dl, Kl, nlast, 2, 3, 0.1, 0, ws, nb, st, outs=(labels, last))
+    side.run("label_propagate_maps", xn, seg0, allm, bs, fs, gl, Dl, Kl, nlast, 2, 3, 0.1, 0, ws, nb, st, outs=(allm,))
     R["lp"] = (xn, seg0, labels.copy(), last.copy(), allm.copy(), (bs, fs, gl, Dl, Kl, nlast))
     return R
 

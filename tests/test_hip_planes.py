@@ -290,7 +290,7 @@ def test_attention_backward_on_bf16_products(Fr, N, H):
 
 
 def test_label_propagation_similarities_on_bf16_products():
-    """In the "bf16" mode (tt_set_gemm_precision 2, BASELINE C4's path) the label propagation's cosine similarities run on bf16 MFMA
+    """In the "bf16" mode (``precision`` = TT_PRECISION_BF16, BASELINE C4's path) the label propagation's cosine similarities run on bf16 MFMA
     (gemm_f32_kernel<BF16>): the propagated maps must equal the oracle's on the bf16-ROUNDED features (mask_propagation.py:448-496) as
     well as the f32 mode's equal the oracle's on the fp32 features, and the mode must actually change the similarities."""
     import torch.nn.functional as F_

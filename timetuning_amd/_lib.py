@@ -37,7 +37,8 @@ class VitBlockParams(C.Structure):
 class VitParams(C.Structure):
     _fields_ = [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
                 ("blocks", C.POINTER(VitBlockParams)), ("n_blocks", C.c_int), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
-                ("dim", C.c_int), ("heads", C.c_int), ("hidden", C.c_int), ("patch", C.c_int), ("planes", C.c_int), ("patch_wp", C.c_void_p), ("range_flag", C.c_void_p)]
+                ("dim", C.c_int), ("heads", C.c_int), ("hidden", C.c_int), ("patch", C.c_int), ("planes", C.c_int), ("patch_wp", C.c_void_p), ("range_flag", C.c_void_p),
+                ("precision", C.c_int)]
 
 
 class LinearParams(C.Structure):
@@ -52,7 +53,7 @@ SIGNATURES = {
     "tt_device_info": (c_i, [C.c_char_p, c_i]),
     "tt_linear_ksplit_workspace_bytes": (c_sz, []),
     "tt_linear_ksplit_workspace_init": (c_i, [c_vp, c_sz, c_vp]),
-    "tt_linear_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
+    "tt_linear_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp]),   # (..., act, precision, stream)
     "tt_linear_bwd_data": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp]),
     "tt_linear_bwd_weight": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_linear_bwd_weight_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
@@ -63,8 +64,6 @@ SIGNATURES = {
     "tt_gemm_tile_choice": (c_i, [c_i, c_i, c_i]),
     "tt_linear_fwd_route": (c_i, [c_i, c_i, c_i]),
     "tt_linear_fwd_planes_route": (c_i, [c_i] * 10),
-    "tt_set_gemm_precision": (c_i, [c_i]),
-    "tt_get_gemm_precision": (c_i, []),
     "tt_patch_embed_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "tt_patch_embed_planes_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "tt_patch_embed_fwd_planes": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
@@ -116,7 +115,7 @@ SIGNATURES = {
     "tt_sinkhorn_local_step": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_sinkhorn_local_end": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_sinkhorn_from_q": (c_i, [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
-    "tt_label_propagate": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
+    "tt_label_propagate": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_vp, c_sz, c_vp]),
     "tt_label_propagate_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "tt_ce_loss_fwd_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
     "tt_ce_workspace_bytes": (c_sz, [c_i]),
@@ -127,9 +126,9 @@ SIGNATURES = {
     "tt_vit_forward_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "tt_vit_forward": (c_i, [C.POINTER(VitParams), c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tt_mlp_head_forward_workspace_bytes": (c_sz, [c_i, C.POINTER(LinearParams), c_i]),
-    "tt_mlp_head_forward": (c_i, [c_vp, c_i, C.POINTER(LinearParams), c_i, c_vp, c_vp, c_sz, c_vp]),
+    "tt_mlp_head_forward": (c_i, [c_vp, c_i, C.POINTER(LinearParams), c_i, c_vp, c_i, c_vp, c_sz, c_vp]),
     "tt_scores_sinkhorn_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
-    "tt_scores_sinkhorn": (c_i, [c_vp, c_i, c_vp, c_i, c_vp, c_i, c_i, c_vp, c_vp, c_i, c_f, c_i, c_vp, c_sz, c_vp]),
+    "tt_scores_sinkhorn": (c_i, [c_vp, c_i, c_vp, c_i, c_vp, c_i, c_i, c_vp, c_vp, c_i, c_f, c_i, c_i, c_vp, c_sz, c_vp]),
     "tt_adamw_ema_step": (c_i, [C.POINTER(AdamwTensor), c_i, c_i, c_f, c_f, c_f, c_vp, c_i, c_i, c_vp, c_vp, c_ll, c_vp, c_d, c_vp]),
     "tt_add_inplace": (c_i, [c_vp, c_vp, c_ll, c_vp]),
     "tt_count_mismatch": (c_i, [c_vp, c_vp, c_ll, c_vp, c_vp]),
@@ -149,7 +148,7 @@ SIGNATURES = {
     "tt_kmeans_assign": (c_i, [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_vp]),
     "tt_kmeans_accumulate_workspace_bytes": (c_sz, [c_ll, c_i, c_i]),
     "tt_kmeans_accumulate": (c_i, [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_vp, c_sz, c_vp]),
-    "tt_label_propagate_maps": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
+    "tt_label_propagate_maps": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_vp, c_sz, c_vp]),
     "tt_upsample_argmax": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "tt_confusion_counts": (c_i, [c_vp, c_vp, c_ll, c_i, c_vp, c_vp]),
 }

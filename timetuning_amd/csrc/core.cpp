@@ -72,7 +72,7 @@ extern "C" int tt_set_tuning_knob(const char* name, int value) {
 }
 
 extern "C" const char* tt_last_error(void) { return tt::g_err; }
-extern "C" int tt_abi_version(void) { return 7; }   // 7: caller-owned K-split workspace (tt_linear_ksplit_workspace_*; workspace arguments of tt_linear_fwd_pairs / _planes / tt_linear_bwd_data_pairs / _planes), the pair producers' range flag; 6: tt_linear_bwd_weight_pairs_tn*, tt_split_pairs_dual_multi, tt_sinkhorn_local_*, pair attention at any N; 5: the fp16-pair entry points (tt_*_pairs*), tt_vit_params.planes == 2; 4: tt_vit_params.patch_wp; 3: the coarse entry points (tt_vit_forward, ...) and their parameter structs
+extern "C" int tt_abi_version(void) { return 8; }   // 8: `precision` is an argument (tt_linear_fwd, tt_label_propagate[_maps], tt_mlp_head_forward, tt_scores_sinkhorn, tt_vit_params.precision) - tt_set_gemm_precision is gone; 7: caller-owned K-split workspace (tt_linear_ksplit_workspace_*; workspace arguments of tt_linear_fwd_pairs / _planes / tt_linear_bwd_data_pairs / _planes), the pair producers' range flag; 6: tt_linear_bwd_weight_pairs_tn*, tt_split_pairs_dual_multi, tt_sinkhorn_local_*, pair attention at any N; 5: the fp16-pair entry points (tt_*_pairs*), tt_vit_params.planes == 2; 4: tt_vit_params.patch_wp; 3: the coarse entry points (tt_vit_forward, ...) and their parameter structs
 
 extern "C" size_t tt_amax_slot_bytes(void) { return (size_t)tt::kAmaxWays * tt::kAmaxStride * sizeof(float); }
 extern "C" size_t tt_linear_ksplit_workspace_bytes(void) { return tt::ksplit_ws_bytes(); }

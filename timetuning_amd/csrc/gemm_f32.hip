@@ -56,7 +56,6 @@ struct GemmArgs {
   int bf16;          // NT products on bf16 MFMA (operands rounded as they leave LDS); set by launch_gemm_plain2 in the "bf16" mode
 };
 
-extern int g_gemm_precision;
 
 // BF16 (the "bf16" precision mode's batched products - the label propagation's cosine similarities): every group of four k = 2 f32 MFMAs
 // becomes ONE v_mfma_f32_32x32x8_bf16 on operands rounded to bf16 as they leave LDS (element q of a lane's operand is the fp32 loop's
@@ -505,12 +504,13 @@ static GemmArgs base_args(const float* A, const float* B, float* C, int M, int N
 
 // plain NT product with a two-level batch, used by other translation units (label propagation): problem (i, o), i < batch_inner, o < batch_outer, at i * s?1 + o * s?2
 int launch_gemm_plain2(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int batch_inner,
-                       int batch_outer, long long sA, long long sB, long long sC, long long sA2, long long sB2, long long sC2, hipStream_t s) {
+                       int batch_outer, long long sA, long long sB, long long sC, long long sA2, long long sB2, long long sC2, int bf16,
+                       hipStream_t s) {
   GemmArgs g = base_args(A, B, C, M, N, K, lda, ldb, ldc);
   g.strideA = sA; g.strideB = sB; g.strideC = sC;
   g.batch_inner = batch_inner;
   g.strideA2 = sA2; g.strideB2 = sB2; g.strideC2 = sC2;
-  g.bf16 = g_gemm_precision == 2;   // the "bf16" mode (BASELINE C4's path): these products on bf16 MFMA too, as torch.autocast would run them
+  g.bf16 = bf16 != 0;   // precision 2, the "bf16" mode (BASELINE C4's path): these products on bf16 MFMA too, as torch.autocast would run them
   return launch_gemm(g, 0, 0, batch_inner * batch_outer, s);
 }
 
@@ -524,7 +524,6 @@ int try_launch_gemm_nt_fast(const float* A, const float* B, float* C, int M, int
                             const float* residual, float* pre_out, int act, hipStream_t s);
 int try_launch_gemm_nt_bf16(const float* A, const float* B, float* C, int M, int N, int K, const float* bias, const float* residual,
                             float* pre_out, int act, int npass, hipStream_t s);
-int g_gemm_precision = 0;  // 0 = f32 MFMA (default, exact), 1 = bf16x3 split, 2 = bf16; forward nn.Linear (+ label-propagation similarities at 2)
 int try_launch_dgrad_fast(const float* dy, const float* w, const float* gelu_pre, float* dx, int M, int N, int K, hipStream_t s);
 int try_launch_wgrad_fast(const float* dy, const float* x, float* out, int M, int N, int K, int splits, int kchunk, float* colpart,
                           int* colparts, hipStream_t s);
@@ -547,16 +546,6 @@ extern "C" int tt_linear_fwd_route(int M, int N, int K) {
   return tile;
 }
 
-extern "C" int tt_set_gemm_precision(int mode) {
-  if (mode < 0 || mode > 2) {
-    tt::set_error("set_gemm_precision: mode must be 0 (f32), 1 (bf16x3) or 2 (bf16), got %d", mode);
-    return TT_EINVAL;
-  }
-  tt::g_gemm_precision = mode;
-  return TT_OK;
-}
-extern "C" int tt_get_gemm_precision(void) { return tt::g_gemm_precision; }
-
 extern "C" int tt_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                            int a_mmajor, int b_nmajor, float alpha, int batch, long long strideA, long long strideB,
                            long long strideC, tt_stream_t stream) {
@@ -567,10 +556,14 @@ extern "C" int tt_gemm_f32(const float* A, const float* B, float* C, int M, int 
 }
 
 extern "C" int tt_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
-                             float* pre_act, int M, int N, int K, int act, tt_stream_t stream) {
+                             float* pre_act, int M, int N, int K, int act, int precision, tt_stream_t stream) {
+  if (precision < TT_PRECISION_F32 || precision > TT_PRECISION_BF16) {
+    tt::set_error("linear_fwd: precision must be 0 (f32), 1 (bf16x3) or 2 (bf16), got %d", precision);
+    return TT_EINVAL;
+  }
   if (x && w && y && M > 0 && N > 0 && K > 0) {
-    if (tt::g_gemm_precision != 0) {  // opt-in bf16 / split-bf16 MFMA instances (gemm_nt_bf16.hip)
-      const int rc = tt::try_launch_gemm_nt_bf16(x, w, y, M, N, K, bias, residual, pre_act, act, tt::g_gemm_precision == 1 ? 3 : 1,
+    if (precision != TT_PRECISION_F32) {  // opt-in bf16 / split-bf16 MFMA instances (gemm_nt_bf16.hip)
+      const int rc = tt::try_launch_gemm_nt_bf16(x, w, y, M, N, K, bias, residual, pre_act, act, precision == TT_PRECISION_BF16X3 ? 3 : 1,
                                                  tt::as_stream(stream));
       if (rc <= 0) return rc;
     }

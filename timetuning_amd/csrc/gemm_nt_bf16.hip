@@ -1,4 +1,4 @@
-// bf16-MFMA instances of the forward nn.Linear GEMM (y = act(x @ w^T + b) (+ residual)), opt-in via tt_set_gemm_precision:
+// bf16-MFMA instances of the forward nn.Linear GEMM (y = act(x @ w^T + b) (+ residual)), opt-in via tt_linear_fwd's `precision` argument (ABI 8):
 //
 //   mode 2  "bf16"    operands rounded to bf16 (RNE), f32 accumulate: the "MFMA bf16 path" of BASELINE config C4.  Does NOT
 //                     meet the 1e-3 fp32 contract of the default path (bf16 has 8 significant bits) and is reported as such.

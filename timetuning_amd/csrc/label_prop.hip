@@ -20,7 +20,8 @@
 namespace tt {
 
 int launch_gemm_plain2(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int batch_inner,
-                       int batch_outer, long long sA, long long sB, long long sC, long long sA2, long long sB2, long long sC2, hipStream_t s);
+                       int batch_outer, long long sA, long long sB, long long sC, long long sA2, long long sB2, long long sC2, int bf16,
+                       hipStream_t s);
 
 constexpr int LP_MAXC = 8;      // context frames (frame 0 + n_last_frames <= 7)
 // candidates per thread (template parameter of the kernel): 8 covers the training protocol (13x13 window x 8 context
@@ -372,9 +373,11 @@ extern "C" size_t tt_label_propagate_workspace_bytes(int bs, int fs, int g, int 
 }
 
 static int lp_run(const char* who, const float* xn, const float* seg0, int64_t* labels, double* pmap_last, double* pmap_all, int bs,
-                  int fs, int g, int D, int K, int n_last_frames, int radius, int topk, float temperature, void* workspace,
+                  int fs, int g, int D, int K, int n_last_frames, int radius, int topk, float temperature, int precision, void* workspace,
                   size_t workspace_bytes, tt_stream_t stream) {
   TT_REQUIRE(xn && seg0 && workspace, "%s: null pointer", who);
+  TT_REQUIRE(precision >= TT_PRECISION_F32 && precision <= TT_PRECISION_BF16, "%s: precision must be 0, 1 or 2 (got %d)", who, precision);
+  const int sims_bf16 = precision == TT_PRECISION_BF16;   // the "bf16" mode: the cosine similarities on bf16 MFMA (what torch.autocast makes of them)
   TT_REQUIRE(bs > 0 && fs >= 2 && g > 0 && D > 0 && K > 0, "%s: need fs >= 2 and positive sizes", who);
   TT_REQUIRE(n_last_frames >= 0 && n_last_frames + 1 <= LP_MAXC, "%s: n_last_frames must be <= %d", who, LP_MAXC - 1);
   TT_REQUIRE(radius > 0, "%s: size_mask_neighborhood must be > 0 (the unrestricted variant is not built)", who);
@@ -404,7 +407,7 @@ static int lp_run(const char* who, const float* xn, const float* seg0, int64_t* 
     //      lo_t = max(1, t - n_last)  (mask_propagation.py:480-487: the first frame and the queue of the last n_last frames)
     // slot 0, the pairs (t, 0) of every t in the chunk: inner batch = clip, outer = t
     int rc = launch_gemm_plain2(xn + t0 * frame, xn, sims, n, n, D, D, D, n, bs, t1 - t0, (long long)n * D, (long long)n * D,
-                                (long long)cmax * nn, frame, 0, per_t, s);
+                                (long long)cmax * nn, frame, 0, per_t, sims_bf16, s);
     if (rc != TT_OK) return rc;
     for (int d = 1; d <= n_last_frames; ++d) {
       // pairs (t, t - d), t - d >= 1.  While the queue is still filling (t <= n_last + 1: lo_t = 1) the slot is j = t - d and
@@ -413,13 +416,13 @@ static int lp_run(const char* who, const float* xn, const float* seg0, int64_t* 
       const int a1 = t1 < n_last_frames + 2 ? t1 : n_last_frames + 2;
       if (a1 > a0) {
         rc = launch_gemm_plain2(xn + a0 * frame, xn + (a0 - d) * frame, sims + (a0 - t0) * per_t + (a0 - d) * nn, n, n, D, D, D, n, bs,
-                                a1 - a0, (long long)n * D, (long long)n * D, (long long)cmax * nn, frame, frame, per_t + nn, s);
+                                a1 - a0, (long long)n * D, (long long)n * D, (long long)cmax * nn, frame, frame, per_t + nn, sims_bf16, s);
         if (rc != TT_OK) return rc;
       }
       const int b0 = a0 > n_last_frames + 2 ? a0 : n_last_frames + 2;
       if (t1 > b0) {
         rc = launch_gemm_plain2(xn + b0 * frame, xn + (b0 - d) * frame, sims + (b0 - t0) * per_t + (1 + n_last_frames - d) * nn, n, n, D, D,
-                                D, n, bs, t1 - b0, (long long)n * D, (long long)n * D, (long long)cmax * nn, frame, frame, per_t, s);
+                                D, n, bs, t1 - b0, (long long)n * D, (long long)n * D, (long long)cmax * nn, frame, frame, per_t, sims_bf16, s);
         if (rc != TT_OK) return rc;
       }
     }
@@ -463,19 +466,19 @@ static int lp_run(const char* who, const float* xn, const float* seg0, int64_t* 
 }
 
 extern "C" int tt_label_propagate(const float* xn, const float* seg0, int64_t* labels, double* pmap_last, int bs, int fs, int g,
-                                  int D, int K, int n_last_frames, int radius, int topk, float temperature, void* workspace,
+                                  int D, int K, int n_last_frames, int radius, int topk, float temperature, int precision, void* workspace,
                                   size_t workspace_bytes, tt_stream_t stream) {
   TT_REQUIRE(labels, "label_propagate: null pointer");
   return lp_run("label_propagate", xn, seg0, labels, pmap_last, nullptr, bs, fs, g, D, K, n_last_frames, radius, topk, temperature,
-                workspace, workspace_bytes, stream);
+                precision, workspace, workspace_bytes, stream);
 }
 
 extern "C" int tt_label_propagate_maps(const float* xn, const float* seg0, double* pmap_all, int bs, int fs, int g, int D, int K,
-                                       int n_last_frames, int radius, int topk, float temperature, void* workspace,
+                                       int n_last_frames, int radius, int topk, float temperature, int precision, void* workspace,
                                        size_t workspace_bytes, tt_stream_t stream) {
   TT_REQUIRE(pmap_all, "label_propagate_maps: null pointer");
   return lp_run("label_propagate_maps", xn, seg0, nullptr, nullptr, pmap_all, bs, fs, g, D, K, n_last_frames, radius, topk, temperature,
-                workspace, workspace_bytes, stream);
+                precision, workspace, workspace_bytes, stream);
 }
 
 // ---- evaluation tail of mask_propagation.py:826-829: bilinear upsample (align_corners=False) of the fp64 maps to the

@@ -67,6 +67,7 @@ extern "C" int tt_vit_forward(const tt_vit_params* p, const float* img, const in
   TT_REQUIRE(p->dim % p->heads == 0, "vit_forward: dim %d not divisible by %d heads", p->dim, p->heads);
   TT_REQUIRE(p->n_blocks == 0 || p->blocks, "vit_forward: null block table");
   TT_REQUIRE(p->planes >= 0 && p->planes <= 3, "vit_forward: planes must be 0, 1, 3 (bf16 planes) or 2 (fp16 pairs) (got %d)", p->planes);
+  TT_REQUIRE(p->precision >= TT_PRECISION_F32 && p->precision <= TT_PRECISION_BF16, "vit_forward: precision must be 0, 1 or 2 (got %d)", p->precision);
   TT_REQUIRE(p->planes == 0 || p->dim % 64 == 0, "vit_forward: the plane path needs dim %% 64 == 0 (got %d)", p->dim);
   TT_REQUIRE(p->planes != 2 || p->hidden % 64 == 0, "vit_forward: the pair path needs hidden %% 64 == 0 (got %d)", p->hidden);
   const int D = p->dim, hd = D / p->heads, P = p->planes;
@@ -117,12 +118,12 @@ extern "C" int tt_vit_forward(const tt_vit_params* p, const float* img, const in
       float* att = reinterpret_cast<float*>(big + s.qkv_bytes);
       float* act = reinterpret_cast<float*>(big);
       TT_FORWARD(tt_layernorm_fwd(tokens, b.norm1_w, b.norm1_b, h, nullptr, nullptr, (int)M, D, 1e-6f, 0, stream));
-      TT_FORWARD(tt_linear_fwd(h, b.qkv_w, b.qkv_b, nullptr, qkv, nullptr, (int)M, 3 * D, D, 0, stream));
+      TT_FORWARD(tt_linear_fwd(h, b.qkv_w, b.qkv_b, nullptr, qkv, nullptr, (int)M, 3 * D, D, 0, p->precision, stream));
       TT_FORWARD(tt_attention_fwd(qkv, att, nullptr, probs, F, N, p->heads, hd, scale, stream));
-      TT_FORWARD(tt_linear_fwd(att, b.proj_w, b.proj_b, tokens, tokens, nullptr, (int)M, D, D, 0, stream));
+      TT_FORWARD(tt_linear_fwd(att, b.proj_w, b.proj_b, tokens, tokens, nullptr, (int)M, D, D, 0, p->precision, stream));
       TT_FORWARD(tt_layernorm_fwd(tokens, b.norm2_w, b.norm2_b, h, nullptr, nullptr, (int)M, D, 1e-6f, 0, stream));
-      TT_FORWARD(tt_linear_fwd(h, b.fc1_w, b.fc1_b, nullptr, act, nullptr, (int)M, p->hidden, D, 1, stream));
-      TT_FORWARD(tt_linear_fwd(act, b.fc2_w, b.fc2_b, tokens, tokens, nullptr, (int)M, D, p->hidden, 0, stream));
+      TT_FORWARD(tt_linear_fwd(h, b.fc1_w, b.fc1_b, nullptr, act, nullptr, (int)M, p->hidden, D, 1, p->precision, stream));
+      TT_FORWARD(tt_linear_fwd(act, b.fc2_w, b.fc2_b, tokens, tokens, nullptr, (int)M, D, p->hidden, 0, p->precision, stream));
       continue;
     }
     // bf16-plane / fp16-pair operands: every Linear reads what its producer wrote; the residual stream stays fp32, in place
@@ -198,8 +199,8 @@ extern "C" size_t tt_mlp_head_forward_workspace_bytes(int M, const tt_linear_par
   return n_layers > 2 ? 2 * one : one;
 }
 
-extern "C" int tt_mlp_head_forward(const float* x, int M, const tt_linear_params* layers, int n_layers, float* out, void* workspace,
-                                   size_t workspace_bytes, tt_stream_t stream) {
+extern "C" int tt_mlp_head_forward(const float* x, int M, const tt_linear_params* layers, int n_layers, float* out, int precision,
+                                   void* workspace, size_t workspace_bytes, tt_stream_t stream) {
   TT_REQUIRE(x && layers && out, "mlp_head_forward: null pointer");
   TT_REQUIRE(M > 0 && n_layers > 0, "mlp_head_forward: bad shape");
   for (int i = 0; i < n_layers; ++i) {
@@ -216,7 +217,7 @@ extern "C" int tt_mlp_head_forward(const float* x, int M, const tt_linear_params
     const bool last = i == n_layers - 1;
     float* dst = last ? out : buf[i & 1];
     TT_FORWARD(tt_linear_fwd(cur, layers[i].w, layers[i].b, nullptr, dst, nullptr, M, layers[i].out_features, layers[i].in_features, last ? 0 : 1,
-                             stream));
+                             precision, stream));
     cur = dst;
   }
   return TT_OK;
@@ -230,8 +231,8 @@ extern "C" size_t tt_scores_sinkhorn_workspace_bytes(int B, int queue_rows, int 
 }
 
 extern "C" int tt_scores_sinkhorn(const float* z, int B, const float* queue, int queue_rows, const float* prototypes, int K, int dim,
-                                  float* scores, float* q_out, int rows_out, float eps, int iters, void* workspace, size_t workspace_bytes,
-                                  tt_stream_t stream) {
+                                  float* scores, float* q_out, int rows_out, float eps, int iters, int precision, void* workspace,
+                                  size_t workspace_bytes, tt_stream_t stream) {
   TT_REQUIRE(z && prototypes && scores && q_out && workspace, "scores_sinkhorn: null pointer");
   TT_REQUIRE(B > 0 && K > 0 && dim > 0 && queue_rows >= 0, "scores_sinkhorn: bad shape");
   if (!queue) queue_rows = 0;
@@ -243,11 +244,11 @@ extern "C" int tt_scores_sinkhorn(const float* z, int B, const float* queue, int
   const size_t zn_bytes = ((size_t)total * dim * 4 + 255) / 256 * 256;
   void* sk_ws = static_cast<unsigned char*>(workspace) + zn_bytes;
   TT_FORWARD(tt_l2norm_fwd(z, dim, zn, nullptr, B, dim, stream));
-  TT_FORWARD(tt_linear_fwd(zn, prototypes, nullptr, nullptr, scores, nullptr, B, K, dim, 0, stream));
+  TT_FORWARD(tt_linear_fwd(zn, prototypes, nullptr, nullptr, scores, nullptr, B, K, dim, 0, precision, stream));
   if (queue_rows) {   // time_tuning.py:207-211: the queue rows are scored the same way and take part in the assignment
     float* qn = zn + (size_t)B * dim;
     TT_FORWARD(tt_l2norm_fwd(queue, dim, qn, nullptr, queue_rows, dim, stream));
-    TT_FORWARD(tt_linear_fwd(qn, prototypes, nullptr, nullptr, scores + (size_t)B * K, nullptr, queue_rows, K, dim, 0, stream));
+    TT_FORWARD(tt_linear_fwd(qn, prototypes, nullptr, nullptr, scores + (size_t)B * K, nullptr, queue_rows, K, dim, 0, precision, stream));
   }
   return tt_sinkhorn(scores, q_out, total, K, 0, rows_out, eps, iters, sk_ws, workspace_bytes - zn_bytes, stream);
 }

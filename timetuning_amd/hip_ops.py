@@ -103,7 +103,8 @@ _precision = "f32"
 
 
 def set_gemm_precision(mode: str) -> None:
-    """Arithmetic of the forward nn.Linear products.  Process-wide.
+    """Arithmetic of the forward nn.Linear products: a setting of THIS front end (which launch sequences it strings together, and the
+    ``precision`` argument it hands to the entry points that take one - ABI 8: the library itself keeps no such state).
     "f32"     (default) exact fp32 MFMA - every headline / parity number.
     "f16x3"   fp32-ACCURATE split mode (round 4): operands pre-split by their producers into fp16 PAIRS (hi = fp16(x), lo = fp16((x - hi)
               2^11): 23 significant bits), three fp16 MFMAs per product term into two fp32 accumulators (gemm_pairs8.hip).  Same blocks
@@ -117,7 +118,7 @@ def set_gemm_precision(mode: str) -> None:
     global _precision
     if mode not in _PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
-    _lib.check(_lib.load().tt_set_gemm_precision(_PRECISIONS[mode][0]), "tt_set_gemm_precision")
+    _lib.load()            # (a missing library fails here, loudly, as it always has)
     _precision = mode
 
 
@@ -128,6 +129,12 @@ def set_tuning_knob(name: str, value: int) -> None:
 
 def get_gemm_precision() -> str:
     return _precision
+
+
+def precision_code() -> int:
+    """The ``precision`` argument (TT_PRECISION_F32 / _BF16X3 / _BF16) of tt_linear_fwd, tt_label_propagate[_maps], tt_mlp_head_forward,
+    tt_scores_sinkhorn and tt_vit_params.precision in the current mode."""
+    return _PRECISIONS[_precision][0]
 
 
 def plane_count() -> int:
@@ -215,7 +222,7 @@ def linear_fwd(x, w, bias=None, residual=None, act: int = 0, save_pre: bool = Fa
     if bias is not None: _chk(bias, "bias")
     if residual is not None: _chk(residual, "residual")
     e0 = _prof_begin()
-    _lib.check(lib.tt_linear_fwd(_p(x), _p(w), _p(bias), _p(residual), _p(y), _p(pre), M, N, K, act, _stream()), "tt_linear_fwd")
+    _lib.check(lib.tt_linear_fwd(_p(x), _p(w), _p(bias), _p(residual), _p(y), _p(pre), M, N, K, act, precision_code(), _stream()), "tt_linear_fwd")
     _prof_end(e0, "NT", M, N, K)
     return (y, pre) if save_pre else y
 
@@ -637,7 +644,7 @@ def label_propagate(xn, seg0, n_last_frames=7, radius=6, topk=5, temperature=0.1
     nb = lib.tt_label_propagate_workspace_bytes(bs, fs, g, D, K, n_last_frames)
     ws = _ws(nb, xn.device)
     _lib.check(lib.tt_label_propagate(_p(xn), _p(seg0), _p(labels), _p(pmap), bs, fs, g, D, K, n_last_frames, radius, topk,
-                                      float(temperature), _p(ws), nb, _stream()), "tt_label_propagate")
+                                      float(temperature), precision_code(), _p(ws), nb, _stream()), "tt_label_propagate")
     return (labels, pmap) if return_pmap else labels
 
 
@@ -653,7 +660,7 @@ def label_propagate_maps(xn, seg0, n_last_frames=7, radius=6, topk=5, temperatur
     nb = lib.tt_label_propagate_workspace_bytes(bs, fs, g, D, K, n_last_frames)
     ws = _ws(nb, xn.device)
     _lib.check(lib.tt_label_propagate_maps(_p(xn), _p(seg0), _p(maps), bs, fs, g, D, K, n_last_frames, radius, topk, float(temperature),
-                                           _p(ws), nb, _stream()), "tt_label_propagate_maps")
+                                           precision_code(), _p(ws), nb, _stream()), "tt_label_propagate_maps")
     return maps
 
 
@@ -1395,6 +1402,7 @@ def vit_forward(params, n_blocks: int, tokens, img=None, frame_map=None, normed_
     dev = tokens.device
     rf = range_flag(dev) if vp.planes == 2 else None
     vp.range_flag = _p(rf)
+    vp.precision = precision_code()
     if img is not None:
         _chk(img, "img")
         C_, H, W = img.shape[1], img.shape[2], img.shape[3]
@@ -1430,7 +1438,7 @@ def mlp_head_forward(x, layers: Sequence[tuple]):
     out = torch.empty((M, layers[-1][0].shape[0]), dtype=f32, device=x.device)
     nb = lib.tt_mlp_head_forward_workspace_bytes(M, arr, len(layers))
     ws = _ws(nb, x.device)
-    _lib.check(lib.tt_mlp_head_forward(_p(x), M, arr, len(layers), _p(out), _p(ws), nb, _stream()), "tt_mlp_head_forward")
+    _lib.check(lib.tt_mlp_head_forward(_p(x), M, arr, len(layers), _p(out), precision_code(), _p(ws), nb, _stream()), "tt_mlp_head_forward")
     return out
 
 
@@ -1450,7 +1458,7 @@ def scores_sinkhorn(z, prototypes, queue=None, iters: int = 10, eps: float = 0.0
     nb = lib.tt_scores_sinkhorn_workspace_bytes(B, Qr, K, dim)
     ws = _ws(nb, z.device)
     _lib.check(lib.tt_scores_sinkhorn(_p(z), B, _p(queue), Qr, _p(prototypes), K, dim, _p(scores), _p(q), rows_out, float(eps), int(iters),
-                                      _p(ws), nb, _stream()), "tt_scores_sinkhorn")
+                                      precision_code(), _p(ws), nb, _stream()), "tt_scores_sinkhorn")
     return q, scores
 
 

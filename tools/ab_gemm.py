@@ -15,7 +15,7 @@ SHAPES = [("qkv", 25216, 1152, 384, 0), ("proj", 25216, 384, 384, 0), ("fc1", 25
 def load(path):
     lib = C.CDLL(os.path.abspath(path))
     lib.tt_linear_fwd.restype = C.c_int
-    lib.tt_linear_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]
+    lib.tt_linear_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]   # ABI 8: + precision
     return lib
 
 
@@ -34,7 +34,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(5):
-                    rc = lib.tt_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), None, M, N, K, act, st)
+                    rc = lib.tt_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), None, M, N, K, act, 0, st)
                     assert rc == 0
                 e1.record()
                 torch.cuda.synchronize()
@@ -43,7 +43,7 @@ def main():
         outs = []
         for p, lib in libs:  # the builds must agree bit for bit unless the summation order changed
             yo = torch.empty(M, N, device="cuda")
-            lib.tt_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, yo.data_ptr(), None, M, N, K, act, st)
+            lib.tt_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, yo.data_ptr(), None, M, N, K, act, 0, st)
             outs.append(yo)
         torch.cuda.synchronize()
         diff = max((o - outs[0]).abs().max().item() for o in outs)

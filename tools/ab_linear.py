@@ -4,7 +4,7 @@ import ctypes as C, os, statistics, sys, torch
 vp, i32 = C.c_void_p, C.c_int
 def load(p):
     lib = C.CDLL(os.path.abspath(p)); lib.tt_linear_fwd.restype = C.c_int
-    lib.tt_linear_fwd.argtypes = [vp] * 6 + [i32] * 4 + [vp]; return lib
+    lib.tt_linear_fwd.argtypes = [vp] * 6 + [i32] * 5 + [vp]; return lib
 libs = [(p, load(p)) for p in sys.argv[1:]]
 M = 25216; st = torch.cuda.current_stream().cuda_stream
 for N, K, name, act, res in ((1152, 384, "qkv", 0, 0), (384, 384, "proj", 0, 1), (1536, 384, "fc1", 1, 0), (384, 1536, "fc2", 0, 1)):
@@ -19,7 +19,7 @@ for N, K, name, act, res in ((1152, 384, "qkv", 0, 0), (384, 384, "proj", 0, 1),
         for p_, lib in libs:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(10): assert lib.tt_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, y.data_ptr(), None, M, N, K, act, st) == 0
+            for _ in range(10): assert lib.tt_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, y.data_ptr(), None, M, N, K, act, 0, st) == 0
             e1.record(); torch.cuda.synchronize()
             if rd >= 3: ts[p_].append(e0.elapsed_time(e1) * 1e2)
             errs[p_] = ((y[:256].double() - ref).abs().max() / ref.abs().max()).item()

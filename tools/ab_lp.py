@@ -5,7 +5,7 @@ vp, i32 = C.c_void_p, C.c_int
 def load(p):
     lib = C.CDLL(os.path.abspath(p))
     lib.tt_label_propagate.restype = C.c_int
-    lib.tt_label_propagate.argtypes = [vp] * 4 + [i32] * 8 + [C.c_float, vp, C.c_size_t, vp]
+    lib.tt_label_propagate.argtypes = [vp] * 4 + [i32] * 8 + [C.c_float, i32, vp, C.c_size_t, vp]
     lib.tt_label_propagate_workspace_bytes.restype = C.c_size_t
     lib.tt_label_propagate_workspace_bytes.argtypes = [i32] * 6
     return lib
@@ -24,7 +24,7 @@ for bs, fs, g, D, K in ((32, 4, 14, 384, 200), (16, 8, 14, 768, 400)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                assert lib.tt_label_propagate(xn.data_ptr(), seg0.data_ptr(), labels.data_ptr(), None, bs, fs, g, D, K, 7, 6, 5, 0.1, ws.data_ptr(), nb, st) == 0
+                assert lib.tt_label_propagate(xn.data_ptr(), seg0.data_ptr(), labels.data_ptr(), None, bs, fs, g, D, K, 7, 6, 5, 0.1, 0, ws.data_ptr(), nb, st) == 0
             e1.record(); torch.cuda.synchronize()
             if rd >= 2: ts[p].append(e0.elapsed_time(e1) * 1e3 / 5)
             outs[p] = labels.clone()

@@ -20,7 +20,7 @@ def main():
     lib = C.CDLL(os.path.abspath(sys.argv[1]))
     secs = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
     lib.tt_linear_fwd.restype = C.c_int
-    lib.tt_linear_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]
+    lib.tt_linear_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]
     lib.tt_debug_read_clock_stamps.argtypes = [C.c_void_p, C.c_int]
     st = torch.cuda.current_stream().cuda_stream
     torch.manual_seed(0)
@@ -36,7 +36,7 @@ def main():
             while time.time() - t0 < secs:
                 e0.record()
                 for _ in range(50):
-                    lib.tt_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), None, M, N, K, act, st)
+                    lib.tt_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), None, M, N, K, act, 0, st)
                 e1.record()
                 torch.cuda.synchronize()
                 n += 50
