@@ -10,6 +10,11 @@ from timetuning_amd.time_tuning import SwavOptimizer
 
 ops.set_gemm_precision("f16x3")
 dev = torch.device("cuda", 0)
+if os.environ.get("TT_EXCHANGE_SINGLE_RANK") == "1":   # the exchange path on a one-rank RCCL communicator (bench.py's probe child)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", init_method="env://", world_size=1, rank=0, device_id=dev)
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 model = bench.build_model("dino-s16", 200, dev)
 opt = SwavOptimizer(model, "AdamW", True, 1e-5, 1e-4, "CosineAnnealingLR", cosine_scheduler(0.04, 0.4, 1, 300), 300, 1)
