@@ -3,8 +3,11 @@
 #   usage (from the repo root on the GPU box):  bash tools/final_run.sh [tag]      (tag names the outputs, default r05)
 # Every profiled program follows `--` directly as python3 (no env / bash hop: the profiler initialises the GPU before the program starts).
 set -uo pipefail
+# what `import timetuning_amd` sets before the first HIP call - exported here because under rocprofv3 the profiler's library may initialise the
+# runtime before the program starts (timetuning_amd/__init__.py says why each is needed)
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 GPU_MAX_HW_QUEUES=8
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-T=${1:-r05}
+T=${1:-r06}
 O=$R/gpurun_out/final_$T
 mkdir -p "$O"
 cd "$R"
@@ -26,7 +29,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c4bf16" -o c4bf
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c1" -o c1 -- python3 "$R/bench.py" --steps 50 --warmup 10 --batch_size 2 --num_frames 2 --num_clusters 50 $P > "$O/prof_c1.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch" -o f -- python3 "$R/bench.py" --steps 3 --warmup 1 $P > "$O/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write" -o w -- python3 "$R/bench.py" --steps 3 --warmup 1 $P > "$O/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$O/trace_c2" -o t -- python3 "$R/bench.py" --steps 6 --warmup 2 $P > "$O/trace_c2.log" 2>&1
 cd "$R"
+python3 tools/stream_timeline.py "$O/trace_c2/t_kernel_trace.csv" > "$O/stream_timeline_c2.txt" 2>&1; rm -f "$O/trace_c2/t_kernel_trace.csv"
+python3 tools/sk_time.py 6272 200 10 > "$O/sinkhorn_device_time.txt" 2>&1
+for v in 0 1; do TT_SINGLE_STREAM=$v $B --steps 20 --warmup 5 $P > "$O/c2_single_stream_$v.json" 2>> "$O/c2.err"; done   # the streams' A/B on this box
 bash tools/pmc_pairs.sh > "$O/pmc_pairs.log" 2>&1
 find "$O" "$R/gpurun_out/pmc_pairs" -name "*kernel_trace.csv" -size +8M -delete
 find "$R/gpurun_out/pmc_pairs" -name "*.db" -delete 2>/dev/null
