@@ -152,8 +152,35 @@ def _worker(rank, W, port, ret):
         dist.all_reduce = real_all_reduce
     # (ii) the variants are the slow ones -> the default stays
     engine.SINKHORN_EXCHANGE, engine.GRAD_BUCKETS, engine.EXCHANGE_CHOICE = "allgather", 0, None
-    c2 = engine.autotune_exchange(make_step(lambda sk, nb: sk == "allreduce" or nb == 1), "cpu", reps=2)
+    # (round 6, ADVICE r5: the probe is side-effect free) a step that consumes the host generator and pushes "queue rows": with
+    # ``state = (snapshot, restore)`` every timed variant starts from the same state and the state after the probe is the state before it
+    probe = {"pushed": 0, "seen": []}
+
+    def snap():
+        return (probe["pushed"], torch.get_rng_state())
+
+    def restore(st):
+        probe["pushed"] = st[0]
+        torch.set_rng_state(st[1])
+
+    inner = make_step(lambda sk, nb: sk == "allreduce" or nb == 1)
+
+    def stateful_step():
+        probe["seen"].append((engine.SINKHORN_EXCHANGE, engine.GRAD_BUCKETS, probe["pushed"]))
+        torch.randperm(64)          # (the queue permutation: torch's CPU generator)
+        probe["pushed"] += 1
+        inner()
+
+    torch.manual_seed(77)
+    before = torch.get_rng_state().clone()
+    c2 = engine.autotune_exchange(stateful_step, "cpu", reps=2, state=(snap, restore))
     out["auto_2"] = (c2["sinkhorn_exchange"], c2["grad_buckets"], engine.SINKHORN_EXCHANGE, engine.GRAD_BUCKETS)
+    # every variant saw the queue as it was (its warm-up step starts at 0 pushes), and nothing of the probe is left behind
+    firsts = {}
+    for sk_, nb_, pushed_ in probe["seen"]:
+        firsts.setdefault((sk_, nb_), pushed_)
+    out["auto_state_ok"] = bool(all(v == 0 for v in firsts.values()) and len(firsts) == 3 and probe["pushed"] == 0
+                                and torch.equal(torch.get_rng_state(), before))
     out["auto_err"] = out["last_step_bucket_err"]
     engine.SINKHORN_EXCHANGE, engine.GRAD_BUCKETS, engine.EXCHANGE_CHOICE = "allgather", 0, None
 
@@ -196,6 +223,7 @@ def test_world_size_2_gloo():
         # the self-deciding exchange: same decision on every rank, recorded with its measurements; one bucket = one all-reduce at the end
         assert o["auto_1"] == ("allreduce", 1, "allreduce", 1, ["allgather/4", "allreduce/1", "allreduce/4"]), o["auto_1"]
         assert o["auto_2"] == ("allgather", 4, "allgather", 0), o["auto_2"]
+        assert o["auto_state_ok"], "the exchange probe left state behind (queue rows / host generator)"
         assert o["one_bucket"][0] == 0 and o["one_bucket"][1] == 1 and o["one_bucket"][2] < 1e-6, o["one_bucket"]
         assert o["auto_err"] < 1e-6, o
         assert o["bcast_err"] == 0.0 and o["bcast_err_w"] == 0.0, o
