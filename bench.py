@@ -568,6 +568,8 @@ def main():
         model.set_queue(torch.nn.functional.normalize(torch.randn_like(model.queue), dim=1))
     x = torch.from_numpy(synth.make_clips(bs, fs, 224, seed=1 + rank)).to(device)  # resident in HBM before timing
     step_graph = world == 1 and a.step_graph in ("on", "auto")
+    if step_graph and a.step_graph == "auto" and not timetuning_amd.step_graph_safe():
+        step_graph = False   # (the runtime's hipGraph packet capture could not be switched off in this process: launches only; "on" raises)
     if step_graph:
         from timetuning_amd.time_tuning import TimeT
 

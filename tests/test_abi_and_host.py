@@ -308,3 +308,29 @@ def test_kmeans_empty_cluster_split_terminates():
     assert km._split_empty(cent, counts, 9) == 0                                        # all singletons
     counts = np.array([5, 0, 1, 1])
     assert km._split_empty(cent, counts, 7) == 1 and counts.tolist() == [3, 2, 1, 1]    # the populated donor is split
+
+
+def test_step_graph_refuses_the_runtimes_packet_capture(monkeypatch):
+    """Round 6: ROCm 7.2's packet-captured hipGraph replay corrupts TimeT's captured step.  The package switches it off
+    on import; where somebody asked for it to stay on - or the package was imported after the GPU had been initialised -
+    ``TimeT.enable_step_graph`` refuses instead of replaying a graph nobody can trust.  Host logic only: no GPU call."""
+    import timetuning_amd
+    from timetuning_amd.models import FeatureExtractor
+    from timetuning_amd.time_tuning import TimeT
+    from timetuning_amd import synth
+
+    assert os.environ.get(timetuning_amd.GRAPH_FLAG) == "0" and timetuning_amd.step_graph_safe()
+    assert os.environ.get("GPU_MAX_HW_QUEUES") is not None
+    cfg = synth.ARCHS["tiny-s16"]
+    fe = FeatureExtractor("dino-s16", "", [32, 32, 16, 8], unfreeze_layers=["blocks.11"], vit_cfg=cfg, init="stress")
+    m = TimeT(fe, 5)
+    m.enable_step_graph()                       # fine
+    m.enable_step_graph(False)
+    monkeypatch.setenv(timetuning_amd.GRAPH_FLAG, "1")
+    assert not timetuning_amd.step_graph_safe()
+    with pytest.raises(RuntimeError, match="packet capture"):
+        m.enable_step_graph()
+    monkeypatch.setenv(timetuning_amd.GRAPH_FLAG, "0")
+    monkeypatch.setattr(timetuning_amd, "_LATE", True)   # imported after the runtime came up
+    with pytest.raises(RuntimeError, match="packet capture"):
+        m.enable_step_graph()

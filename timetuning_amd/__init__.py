@@ -11,6 +11,22 @@ import os as _os
 # initialises (the first HIP call of the process - torch.cuda.is_available() is one): this package therefore switches it off on import,
 # and TimeT.enable_step_graph() refuses to capture when somebody asked for it to stay on.
 GRAPH_FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+
+
+def _runtime_already_up() -> bool:
+    """True when this process has visibly initialised the HIP runtime before this import (torch's lazy CUDA init has run): what is set
+    below then comes too late for the runtime to read.  (A bare ``torch.cuda.is_available()`` initialises the runtime too and cannot be
+    seen from here: import this package first - bench.py, tests/conftest.py, __graft_entry__.py and the driver do.)"""
+    import sys
+
+    t = sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:   # noqa: BLE001
+        return False
+
+
+_LATE = _os.environ.get(GRAPH_FLAG) != "0" and _runtime_already_up()
 _os.environ.setdefault(GRAPH_FLAG, "0")
 
 
@@ -24,4 +40,4 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 def step_graph_safe() -> bool:
     """True when the process runs hipGraphs without the AQL packet capture (the only mode TimeT's step graph is verified in)."""
-    return _os.environ.get(GRAPH_FLAG) == "0"
+    return _os.environ.get(GRAPH_FLAG) == "0" and not _LATE

@@ -433,7 +433,8 @@ class TimeT(nn.Module):
             from . import GRAPH_FLAG, step_graph_safe
             if not step_graph_safe():
                 raise RuntimeError(f"TimeT.enable_step_graph: {GRAPH_FLAG}={os.environ.get(GRAPH_FLAG)!r} - ROCm 7.2 does not replay the captured step reliably "
-                                   f"with its AQL packet capture on (timetuning_amd/__init__.py); run with {GRAPH_FLAG}=0 or without the step graph")
+                                   f"with its AQL packet capture on (timetuning_amd/__init__.py); export {GRAPH_FLAG}=0, or import timetuning_amd before the "
+                                   "process's first HIP call (it was imported after torch had initialised the GPU), or run without the step graph")
         self._step_graph_on = bool(on)
         self._step_graph_max_rows = max_token_rows   # None: every step; else only steps of at most this many token rows (``auto``)
         self._step_graphs = {}
@@ -1088,7 +1089,11 @@ def time_tuning(gpu=0, args=None):
     if world_size > 1:
         model = DistributedDataParallelModel(model, gpu)
     elif getattr(args, "step_graph", "auto") in ("auto", "on"):
-        model.enable_step_graph(max_token_rows=TimeT.STEP_GRAPH_AUTO_MAX_ROWS if args.step_graph == "auto" else None)
+        from . import step_graph_safe
+        if args.step_graph == "on" or step_graph_safe():     # ("on" raises where the runtime's packet capture could not be switched off)
+            model.enable_step_graph(max_token_rows=TimeT.STEP_GRAPH_AUTO_MAX_ROWS if args.step_graph == "auto" else None)
+        elif rank == 0:
+            print("step graph: off (the runtime's hipGraph packet capture could not be switched off in this process: timetuning_amd/__init__.py)")
     if args.dataset == "synthetic":
         loader = SyntheticClips(args.batch_size, args.num_frames, args.input_resolution, args.steps_per_epoch, device, rank)
     elif args.dataset == "synthetic_frames":  # raw uint8 frames through the GPU input pipeline
