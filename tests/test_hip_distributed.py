@@ -322,3 +322,25 @@ def test_training_cli_spawns_two_ranks(tmp_path):
     assert "Scores/localization" in r.stdout and r.stdout.count("Iteration:") == 2           # rank 0 only prints
     ck = torch.load(str(tmp_path / "checkpoint.pth"), map_location="cpu", weights_only=False)
     assert all(k.startswith("model.module.") for k in ck["model"]) and "model.module.teacher_prototypes" in ck["model"]
+
+
+@pytest.mark.timeout(900)
+def test_one_rank_exchange_path_equals_no_exchange():
+    """Round 6: the exchange path as an N-GPU rank runs it - a one-rank RCCL communicator (TT_EXCHANGE_SINGLE_RANK=1), the side streams
+    of engine.TWO_STREAMS with each bucket's all-reduce issued from the weight-gradient stream, the double-buffered gradient arena -
+    trains exactly what the plain one-process step trains (W = 1: the mean over ranks is the identity): four steps' losses and every
+    parameter bit for bit; the gradients are views of the arena's current buffer (no clone per step); and accumulating over backward
+    calls WITHOUT zero_grad stays correct across the buffer swap (g0 + g1, then + g1 again when the first buffer comes round).  In a
+    child process: the communicator is process-global."""
+    import json
+    import subprocess
+    import sys
+
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_exchange_single_rank_child.py")
+    r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=800)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    o = json.loads(lines[-1][7:])
+    assert o["losses_equal"] and o["params_equal"], o
+    assert o["two_buffers"] and o["grads_in_current_buffer"], o
+    assert o["accumulate_err"] < 1e-6 and o["accumulate3_err"] < 1e-6, o

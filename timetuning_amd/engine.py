@@ -828,39 +828,63 @@ def global_sinkhorn(scores_local: torch.Tensor, rows_out: int, eps: float, iters
 
 
 class GradArena:
-    """Persistent flat fp32 buffer that holds every gradient the exchange sends, laid out in the order the fused backward produces them,
+    """Persistent flat fp32 buffers that hold every gradient the exchange sends, laid out in the order the fused backward produces them,
     one contiguous range per bucket: the backward kernels write their dw / db straight into it (``GradExchange.out``), a bucket's
     all-reduce runs on a slice of it, and the averaged gradients are handed out as views - no ``torch.cat``, no allocation per step
     (what DDP's ``gradient_as_bucket_view`` does for the reference's wrapper, models.py:1295).  Built from the first step's buckets;
-    rebuilt if a later step produces a different set or order of gradients (a changed ``requires_grad``)."""
+    rebuilt if a later step produces a different set or order of gradients (a changed ``requires_grad``).
+
+    TWO buffers alternate from step to step (round 6): autograd adopts the views it is handed, so after a step ``.grad`` aliases that
+    step's buffer - and in the reference's loop (``zero_grad()`` inside ``optimizer.step(loss)``, AFTER the next forward + backward has
+    been launched, time_tuning.py:379-429) it still does while the next backward runs.  With one buffer every such gradient had to be
+    given storage of its own before the buffer was overwritten (33 clone launches per step, 0.13 ms at C2); with two the next backward
+    writes the OTHER buffer and nothing is copied.  Only a gradient that still aliases the buffer about to be written - a caller that
+    accumulates over several backward calls without ``zero_grad()`` - is detached first (``detach_stale_grads``)."""
 
     def __init__(self):
-        self.flat: Optional[torch.Tensor] = None
-        self.slots: Dict[torch.nn.Parameter, torch.Tensor] = {}     # param -> its view of ``flat``
+        self.flats: List[torch.Tensor] = []                           # the two buffers
+        self.cur = 0                                                  # the one the running / last backward writes
+        self.all_slots: List[Dict[torch.nn.Parameter, torch.Tensor]] = []
         self.buckets: List[tuple] = []                                # (start, end, [params])
 
     ALIGN = 4   # floats: the backward kernels write dw / db through 16-byte stores (tt_linear_bwd_weight_pairs_tn rejects anything else)
+
+    @property
+    def flat(self) -> Optional[torch.Tensor]:
+        return self.flats[self.cur] if self.flats else None
+
+    @property
+    def slots(self) -> Dict[torch.nn.Parameter, torch.Tensor]:       # param -> its view of the current buffer
+        return self.all_slots[self.cur] if self.all_slots else {}
 
     def build(self, buckets: List[List[torch.nn.Parameter]], device) -> None:
         # every slot starts on a 16-byte boundary (ADVICE r4: a tensor whose numel is not a multiple of 4 - an odd bias, a custom head
         # width - misaligned every slot behind it); the padding floats stay zero and travel with their bucket, which is harmless
         pad = lambda n: (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         total = sum(pad(p.numel()) for keys in buckets for p in keys)
-        self.flat = torch.zeros((total,), dtype=f32, device=device)
-        self.slots, self.buckets, off = {}, [], 0
+        self.flats = [torch.zeros((total,), dtype=f32, device=device) for _ in range(2)]
+        self.all_slots, self.buckets, self.cur = [{}, {}], [], 0
+        off = 0
         for keys in buckets:
             start = off
             for p in keys:
-                self.slots[p] = self.flat[off:off + p.numel()].view(p.shape)
+                for i in range(2):
+                    self.all_slots[i][p] = self.flats[i][off:off + p.numel()].view(p.shape)
                 off += pad(p.numel())
             self.buckets.append((start, off, list(keys)))
 
     def reset(self) -> None:
-        self.flat, self.slots, self.buckets = None, {}, []
+        self.flats, self.all_slots, self.buckets, self.cur = [], [], [], 0
+
+    def next_step(self) -> None:
+        """A new backward is about to write gradients: it takes the buffer the previous one did not use."""
+        if self.flats:
+            self.cur ^= 1
+            self.detach_stale_grads()
 
     def detach_stale_grads(self) -> None:
-        """A ``.grad`` that still aliases the arena (autograd adopts the views it is handed) would be overwritten by the next backward
-        before a caller that accumulates over several backward calls has used it: give such a gradient its own storage first."""
+        """A ``.grad`` that still aliases the buffer about to be written (it was adopted two backward calls ago and never reset: a caller
+        that accumulates across steps) would be overwritten under the caller: give such a gradient its own storage first."""
         for p, view in self.slots.items():
             if p.grad is not None and p.grad.data_ptr() == view.data_ptr():
                 p.grad = p.grad.clone()
@@ -887,7 +911,7 @@ class GradExchange:
         self.arena = arena if self.dist is not None else None
         self.use_arena = self.arena is not None and self.arena.flat is not None
         if self.use_arena:
-            self.arena.detach_stale_grads()
+            self.arena.next_step()
         self.recorded: List[List[torch.nn.Parameter]] = []
 
     def out(self, p) -> Optional[torch.Tensor]:
@@ -899,7 +923,6 @@ class GradExchange:
     def push(self, grads: Dict[torch.nn.Parameter, torch.Tensor], final: bool = False) -> None:
         if self.dist is None:
             return
-        ops.wgrad_join(final=False)   # (weight gradients launched on the side stream: the bucket's all-reduce reads them)
         if GRAD_BUCKETS == 1 and not final:
             return                                   # one all-reduce of everything, issued by ``finish``
         keys = [k for k in grads if k not in self.sent and k.requires_grad]
@@ -920,9 +943,21 @@ class GradExchange:
             else:
                 self.use_arena = False   # a different set / order of gradients: this step flattens by hand, the layout is rebuilt at finish
         in_arena = flat is not None
+        # Weight gradients may have been launched on the side stream (``ops.wgrad_fork``): the bucket's all-reduce has to follow BOTH
+        # streams.  Issued from the side stream behind a wait for this one, it does (the collective's stream waits for the stream it is
+        # issued from) WITHOUT joining the compute stream at every bucket boundary: the data-gradient chain runs on.
+        side = ops.wgrad_side()
         if flat is None:
+            if side is not None:
+                ops.wgrad_join(final=False)          # (the hand-flattened first step reads the gradients on this stream)
+                side = None
             flat = torch.cat([grads[k].reshape(-1) for k in keys])
-        work = self.dist.all_reduce(flat, async_op=True)
+        if side is not None and flat.is_cuda:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                work = self.dist.all_reduce(flat, async_op=True)
+        else:
+            work = self.dist.all_reduce(flat, async_op=True)
         self.sent.update(keys)
         self.buckets.append((keys, flat, work, in_arena))
 

@@ -1227,6 +1227,11 @@ def wgrad_fork(stream) -> None:
     _WGRAD["side"] = stream
 
 
+def wgrad_side():
+    """The armed weight-gradient side stream, or None."""
+    return _WGRAD["side"] if PROFILE is None else None
+
+
 def wgrad_join(final: bool = True) -> None:
     side = _WGRAD["side"]
     if side is not None:
