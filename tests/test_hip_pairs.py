@@ -112,6 +112,49 @@ def test_linear_pairs_epilogues(M, N, K):
     assert rel_err(o6["y"].cpu(), pre_ref) < TOL_F32 and rel_err(join(o6["pairs"].cpu()), o6["y"].cpu().double()) <= 2.0 ** -22
 
 
+@pytest.mark.parametrize("M,N,K", [(25216, 384, 384), (12608, 1152, 384), (25216, 1536, 384), (8100, 1024, 768), (70000, 128, 64)])
+def test_four_wave_pair_gemm_experiment(M, N, K):
+    """gemm_pairs4_kernel (round 6, knob TT_Q4, default OFF: DESIGN 5.1) - 128 x 128 tiles in four-wave workgroups, two per CU, the left-over
+    tiles as half items in a second launch: every epilogue against fp64 at the pair kernels' bounds, bit for bit equal to the 8-wave kernel
+    wherever that one does not K-split (same products in the same order per output element), run-to-run bit equality; ragged last tiles."""
+    from timetuning_amd import hip_ops as ops
+
+    x, w, b, res = rnd(f"q4.x{M}.{K}", M, K), rnd(f"q4.w{N}.{K}", N, K, scale=0.1), rnd(f"q4.b{N}", N, scale=0.1), rnd(f"q4.r{M}.{N}", M, N)
+    xp, wp = ops.split_pairs(x.cuda()), ops.split_pairs(w.cuda())
+    pre_ref = x.double() @ w.double().t() + b.double()
+
+    def run_all():
+        out = {}
+        out["f32"] = ops.linear_fwd_pairs(xp, wp, b.cuda())["y"]
+        rc = res.clone().cuda()
+        ops.linear_fwd_pairs(xp, wp, b.cuda(), residual=rc, out=rc)
+        out["res"] = rc
+        out["pair"] = ops.linear_fwd_pairs(xp, wp, b.cuda(), out_f32=False, out_pairs=True)["pairs"]
+        out["gelu"] = ops.linear_fwd_pairs(xp, wp, b.cuda(), act=1, out_f32=False, out_pairs=True)["pairs"]
+        o = ops.linear_fwd_pairs(xp, wp, b.cuda(), out_pairs=True)
+        out["both_y"], out["both_p"] = o["y"], o["pairs"]
+        o = ops.linear_fwd_pairs(xp, wp, b.cuda(), act=1, out_f32=False, out_pairs=True, save_pre=True)
+        out["bg_pre"], out["bg_p"] = o["pre"], o["pairs"]
+        return out
+
+    ops.set_tuning_knob("TT_Q8_KSPLIT", 0)          # (the 8-wave kernel's K-split changes an accumulation order: off for the bit comparison)
+    try:
+        base = run_all()
+        ops.set_tuning_knob("TT_Q4", 1)
+        q4 = run_all()
+        again = run_all()
+    finally:
+        ops.set_tuning_knob("TT_Q4", 0)
+        ops.set_tuning_knob("TT_Q8_KSPLIT", 1)
+    for k_ in q4:
+        assert torch.equal(q4[k_], again[k_]), k_
+        assert torch.equal(q4[k_], base[k_]), k_
+    assert rel_err(q4["f32"].cpu(), pre_ref) < TOL_F32 and rel_l2(q4["f32"].cpu(), pre_ref) < TOL_L2
+    assert rel_err(q4["res"].cpu(), pre_ref + res.double()) < TOL_F32
+    assert rel_err(join(q4["gelu"].cpu()), F.gelu(pre_ref)) < TOL_F32
+    assert rel_err(join(q4["bg_p"].cpu()), F.gelu(q4["bg_pre"].cpu().double())) < 2e-6
+
+
 @pytest.mark.parametrize("Fr,N,H,flash", [(3, 197, 6, 0), (2, 50, 2, 0), (1, 256, 12, 0), (2, 225, 3, 0), (5, 17, 1, 0),
                                           # the persistent loop of the resident kernel (round 5): more (frame, head) items than CUs, unevenly
                                           # (300 and 258 items on 256 workgroups: one or two items each; 768: three each)

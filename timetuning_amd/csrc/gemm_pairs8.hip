@@ -1315,6 +1315,353 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
 #undef Q8S_FENCE
 }
 
+// =====================================================================================================================================
+// gemm_pairs4_kernel (round 6, EXPERIMENT behind the knob TT_Q4): the same product, operands, lane maps and epilogues as gemm_pairs8s_kernel
+// in FOUR-wave workgroups on 128 x 128 tiles, TWO workgroups per CU.  Why: an item of the 8-wave kernel ends with an epilogue in which no
+// wave issues an MFMA (10 - 29 % of a launch: profiles/r05_q8s_ablation.txt), and its eight waves share one barrier per K-tile; two
+// independent workgroups per CU interleave - one's epilogue, barrier waits and DMA-issue stalls run under the other's MFMAs.  Price: the W
+// tile is re-read per 128 (not 256) x rows (+ 33 % LDS-DMA bytes per flop) and each workgroup's ring is TWO K-tiles (2 x 32 KB + 8 KB of
+// scratch = 72 KB; two workgroups = 144 of the 160 KB) with the fragments of K-tile t + 1 prefetched into registers during K-tile t:
+//   iteration t:  [lgkmcnt(0) | vmcnt: the pieces of K-tile t + 1, issued in iteration t - 1 | barrier]
+//                 24 MFMAs on the registers of K-tile t; between them the 8 LDS-DMA pieces of K-tile t + 2 into the slot of K-tile t
+//                 (its fragments went to registers in iteration t - 1: every wave's reads completed before this barrier), and the 16
+//                 fragment reads of K-tile t + 1, each into the register its last reader of K-tile t has just been issued from.
+// No half tiles (the tile IS the half), no K-split; items dealt round-robin to the 2 x CUs workgroups, consecutive tiles to one XCD.
+#ifndef TT_Q4_SITES
+#define TT_Q4_SITES 2
+#endif
+// HALFK: the launch of the left-over tiles as HALVES (one half item per workgroup; a separate instantiation - both item kinds in one kernel
+// spilled 15 - 45 registers)
+template <int EPI, bool HALFK>
+__global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
+  constexpr int ROWB = 128, CPR = 8, WIN = 2, RPI = 8;
+  constexpr int CHUNK_B = 128 * ROWB;       // 16 KB: 128 rows of one operand
+  constexpr int SLOT_B = 2 * CHUNK_B;       // W, X
+  constexpr int RING_B = 2 * SLOT_B;
+  constexpr int SCR_B = 2048;
+  constexpr int CW = SCR_B / 128;
+  constexpr int NPASS = 32 / CW;
+  constexpr int BN = 128;
+  constexpr bool F32OUT = EPI == Q8_F32 || EPI == Q8_F32_RES || EPI == Q8_F32_GELUGRAD;
+  constexpr bool RES = EPI == Q8_F32_RES || EPI == Q8_F32_GELUGRAD;
+  constexpr bool GG = EPI == Q8_F32_GELUGRAD;
+  constexpr bool BOTH = EPI == Q8_BOTH || EPI == Q8_BOTH_GELU;
+  constexpr bool ACT = EPI == Q8_PAIR_GELU || EPI == Q8_BOTH_GELU;
+  constexpr int ST_TILE = BOTH ? 8 : 4;               // stores a wave issues per 32 x 32 MFMA tile
+  constexpr int ST_FULL = 4 * ST_TILE;
+  static_assert(CW == 16 && ST_FULL < 56, "scratch / counted waits");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_B + 4 * SCR_B];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave & 1, wc = wave >> 1;          // 2 x 2 waves of 64 x 64
+  const int r = lane & 31, h = lane >> 5;
+  const int K4 = g.K * 4, nk = g.K / 32;
+
+  // ---- work items: tile = it * nwg + wg; consecutive wg on one XCD (they share the x rows of a row block / the W column tile)
+  const int nwg = g.ncu;
+  int wg = blockIdx.x;
+  if ((nwg & 7) == 0) wg = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  // n_half > 0: g.n_full whole tiles per workgroup, then the left-over tiles cut into HALVES (64 x rows: x block 0 of every wave only),
+  // workgroup h < n_half takes half h & 1 of tile n_full * nwg + h / 2 - a left-over round costs ~ 0.55 of a tile instead of a whole one
+  // (whole-tile launch: tiles [0, g.ntiles) round-robin; half launch: g.ntiles = the first left-over tile, workgroup h takes half h & 1 of
+  // tile g.ntiles + h / 2)
+  const int n_items = HALFK ? 1 : (wg < g.ntiles ? (g.ntiles - wg + nwg - 1) / nwg : 0);
+  if (n_items == 0) return;
+  auto item = [&](int it, int& row0, int& n0) {
+    const int tile = HALFK ? g.ntiles + (wg >> 1) : it * nwg + wg;
+    const int mb = tile / g.ntn, ns = tile - mb * g.ntn;
+    row0 = mb * 128 + (HALFK ? (wg & 1) * 64 : 0);
+    n0 = ns * BN;
+  };
+
+  // ---- LDS-DMA lane map (as gemm_pairs8s_kernel): lane -> (row, 16-byte slot) of a 1 KB piece (8 rows); four waves cover 32 rows per
+  // site, four sites per 128-row chunk.  Rows beyond the operand and K-tiles that do not exist are out of the descriptor's range: zeros.
+  const int l_row = lane / CPR, l_slot = lane % CPR;
+  const int d_row0 = wave * RPI + l_row;
+  const int d_chunk = l_slot ^ ((d_row0 / WIN) & (CPR - 1));
+  const unsigned lane_voff = (unsigned)(d_row0 * K4 + d_chunk * 16);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(g.X), 0, (unsigned)g.M * (unsigned)K4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(g.W), 0, (unsigned)g.N * (unsigned)K4, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  const unsigned site_step = 4u * RPI * (unsigned)K4;   // 32 rows
+
+  // ---- DMA cursor: the K-tile whose pieces are issued next (two K-tiles ahead of the MFMAs)
+  int d_item = 0, d_kt = 0;
+  bool d_done = false;
+  unsigned cur_w = OOB, cur_x = OOB;
+  auto cursor_item = [&]() {
+    int row0, n0;
+    item(d_item, row0, n0);
+    d_kt = 0;
+    cur_w = (unsigned)n0 * (unsigned)K4;
+    cur_x = (unsigned)row0 * (unsigned)K4;
+  };
+  cursor_item();
+  auto cursor_advance = [&]() {
+    if (d_done) return;
+    ++d_kt;
+    cur_w += ROWB;
+    cur_x += ROWB;
+    if (d_kt == nk) {
+      ++d_item;
+      if (d_item >= n_items) { d_done = true; cur_w = OOB; cur_x = OOB; }
+      else cursor_item();
+    }
+  };
+  // site k of the cursor's K-tile into ring slot `slot`: k = 0 .. 3 W rows [32 k, 32 k + 32), 4 .. 7 X rows
+  auto site = [&](int k, int slot) {
+    if (k < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (q8_lds_ptr_t)(smem + slot + k * 4096 + wave * 1024), 16, lane_voff + cur_w + (unsigned)k * site_step, 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (q8_lds_ptr_t)(smem + slot + CHUNK_B + (k - 4) * 4096 + wave * 1024), 16,
+                                                  (k >= 6 && HALFK) ? OOB : lane_voff + cur_x + (unsigned)(k - 4) * site_step, 0, 0, 0);   // (a half item has 64 x rows)
+  };
+
+  // ---- fragment addressing (as gemm_pairs8s_kernel)
+  const int f_sw = (r / WIN) & (CPR - 1);
+  int fo[4];
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) fo[c4] = r * ROWB + (((2 * c4 + h) ^ f_sw) << 4);
+  const int x_slice = CHUNK_B + wr * (HALFK ? 32 : 64) * ROWB;
+  const int w_slice = wc * 64 * ROWB;
+
+  f32x16 a1[2][2], a2[2][2];   // [x block][w block]
+  f16x8 Wf[2][4];              // [w block][hi k-step 0, 1, lo k-step 0, 1]
+  f16x8 Xf[2][4];              // [x block][...]
+  auto rd_w = [&](int slot, int mt, int c4) { Wf[mt][c4] = *reinterpret_cast<const f16x8*>(smem + slot + w_slice + mt * 32 * ROWB + fo[c4]); };
+  auto rd_x = [&](int slot, int xt, int c4) { Xf[xt][c4] = *reinterpret_cast<const f16x8*>(smem + slot + x_slice + xt * 32 * ROWB + fo[c4]); };
+
+  int s_cur = 0, s_nxt = SLOT_B;   // ring slots of K-tile t (refilled with t + 2 during iteration t) and t + 1 (read during iteration t)
+  bool post_epi = false, post_half = false;
+#define Q4_FENCE() __builtin_amdgcn_sched_barrier(0)
+  auto ktile = [&](auto last_c) {
+    constexpr bool LAST = decltype(last_c)::value;   // the item's last K-tile: no refresh (the fragments would be live across the epilogue)
+    constexpr bool HALF = HALFK;                     // a half item: x block 0 only, 12 MFMAs, all eight DMA sites and the W refresh in its one phase
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (post_epi) {                                   // (the epilogue's stores are younger than the pieces waited for)
+      if (post_half) q8_wait_vmcnt<ST_FULL / 2>(); else q8_wait_vmcnt<ST_FULL>();
+      post_epi = false;
+    } else q8_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    Q4_FENCE();
+    auto slot = [&](auto ph_c, int q) {
+      constexpr int PH = decltype(ph_c)::value;
+      const int ks = q >> 1, mt = q & 1;
+      a2[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][ks], Xf[PH][2 + ks], a2[PH][mt], 0, 0, 0);
+      Q4_FENCE();
+      // the eight pieces of K-tile t + 2, all in the FIRST phase (TT_Q4_SITES = 2: two per slot; 1: one per slot over both phases): a piece
+      // issued in the last slot had the whole memory latency exposed at the next iteration's wait
+      if constexpr (TT_Q4_SITES == 2 || HALF) { if constexpr (PH == 0) site(2 * q, s_cur); }
+      else site(4 * PH + q, s_cur);
+      Q4_FENCE();
+      a1[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][ks], Xf[PH][ks], a1[PH][mt], 0, 0, 0);
+      Q4_FENCE();
+      if constexpr ((TT_Q4_SITES == 2 || HALF) && PH == 0) site(2 * q + 1, s_cur);
+      Q4_FENCE();
+      a2[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][2 + ks], Xf[PH][ks], a2[PH][mt], 0, 0, 0);
+      Q4_FENCE();
+      if constexpr (!LAST) {
+        // in-place refresh from K-tile t + 1: X block PH's k-step ks is done once its second w block (mt = 1) is; in the last phase every
+        // slot's own two W fragments are done behind its last MFMA
+        if (mt == 1) { rd_x(s_nxt, PH, ks); rd_x(s_nxt, PH, 2 + ks); }
+        if constexpr (PH == 1 || HALF) { rd_w(s_nxt, mt, ks); rd_w(s_nxt, mt, 2 + ks); }
+      }
+      Q4_FENCE();
+    };
+    using PH0 = std::integral_constant<int, 0>; using PH1 = std::integral_constant<int, 1>;
+    slot(PH0{}, 0); slot(PH0{}, 1); slot(PH0{}, 2); slot(PH0{}, 3);
+    if constexpr (!HALF) { slot(PH1{}, 0); slot(PH1{}, 1); slot(PH1{}, 2); slot(PH1{}, 3); }
+    cursor_advance();
+    const int t_ = s_cur; s_cur = s_nxt; s_nxt = t_;
+  };
+
+  // ---- epilogue of one item (gemm_pairs8s_kernel's, through the wave's private scratch)
+  unsigned char* scr = smem + RING_B + wave * SCR_B;
+  constexpr int CPRW = CW / 4;
+  constexpr int LPR = F32OUT ? CPRW : CPRW / 2;
+  constexpr int RPW = 64 / LPR;
+  constexpr int NRB = 32 / RPW;
+  constexpr int NLD = NPASS * NRB;
+  auto esw = [](int row) { return (row >> 2) & (CPRW - 1); };
+  const unsigned out_bytes = (unsigned)g.M * (unsigned)g.N * 4u;
+  float amax_run = 0.f;
+  auto epilogue = [&](int row0, int n0) {
+    constexpr bool half = HALFK;
+    constexpr int NT = half ? 2 : 4;
+    constexpr int nt = NT;
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int r = lane_e & 31, h = lane_e >> 5;
+    const int rr = lane_e / LPR, cc = lane_e % LPR;
+    unsigned hi_max = 0;
+    const float inv_s = g.out_scale ? 1.0f / *g.out_scale : 1.0f;
+    auto mrow = [&](int j) { return half ? row0 + wr * 32 : row0 + wr * 64 + (j >> 1) * 32; };
+    auto ncol = [&](int j) { return n0 + wc * 64 + (j & 1) * 32; };
+    f32x4 bias_lo[2][NPASS], bias_hi[2][NPASS];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q) {
+        const int n = ncol(b) + q * CW + (F32OUT ? 4 : 8) * cc;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        bias_lo[b][q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n) : zero;
+        if constexpr (!F32OUT) bias_hi[b][q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + n + 4) : zero;
+      }
+    f32x4 rres[3][RES ? NLD : 1];
+    auto prefetch = [&](int j, int slot) {
+      if constexpr (RES) {
+        const int mbase = mrow(j), nbase = ncol(j);
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q)
+#pragma unroll
+          for (int i = 0; i < NRB; ++i) {
+            const unsigned off = ((unsigned)(mbase + i * RPW + rr) * (unsigned)g.N + (unsigned)(nbase + q * CW + 4 * cc)) * 4u;
+            rres[slot][q * NRB + i] = q8_ld128(g.residual, out_bytes, off);
+          }
+      }
+    };
+    if constexpr (RES) {
+      prefetch(0, 0);
+      prefetch(1, 1);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+     {
+      const int ha = j >> 1, mt = j & 1;
+      const int mbase = mrow(j), nbase = ncol(j);
+      if constexpr (RES) {
+        if (j + 2 < nt) prefetch(j + 2, (j + 2) % 3);
+      }
+#pragma unroll
+      for (int q = 0; q < NPASS; ++q) {
+#pragma unroll
+        for (int gg = 0; gg < CW / 8; ++gg) {
+          const int gi = q * (CW / 8) + gg;
+          const int phys = (2 * gg + h) ^ esw(r);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(a2[ha][mt][4 * gi + e], 0.00048828125f, a1[ha][mt][4 * gi + e]) * inv_s;
+          *reinterpret_cast<f32x4*>(scr + r * (CW * 4) + phys * 16) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) {
+          const int row = i * RPW + rr;
+          const int m = mbase + row;
+          if constexpr (F32OUT) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + ((cc ^ esw(row)) << 4));
+            v += bias_lo[mt][q];
+            if constexpr (GG) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast_f(rres[j % 3][q * NRB + i][e]);
+              if (m < g.M) amax_run = fmaxf(fmaxf(amax_run, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            } else if constexpr (RES) {
+              v += rres[j % 3][q * NRB + i];
+            }
+            const unsigned off = ((unsigned)m * (unsigned)g.N + (unsigned)(nbase + q * CW + 4 * cc)) * 4u;
+            q8_st128(g.C, out_bytes, off, __builtin_bit_cast(u32x4, v));
+          } else {
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + (((2 * cc) ^ esw(row)) << 4));
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(scr + row * (CW * 4) + (((2 * cc + 1) ^ esw(row)) << 4));
+            v0 += bias_lo[mt][q];
+            v1 += bias_hi[mt][q];
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if constexpr (BOTH) {
+              const unsigned offc = ((unsigned)m * (unsigned)g.N + (unsigned)(nbase + q * CW + 8 * cc)) * 4u;
+              q8_st128(g.C, out_bytes, offc, __builtin_bit_cast(u32x4, v0));
+              q8_st128(g.C, out_bytes, offc + 16u, __builtin_bit_cast(u32x4, v1));
+            }
+            if constexpr (ACT) {
+#pragma unroll
+              for (int e = 0; e < 8; e += 2) {
+                const tt_f32x2 gq = gelu_fast_f2(tt_f32x2{v[e], v[e + 1]});
+                v[e] = gq[0];
+                v[e + 1] = gq[1];
+              }
+            }
+            f16x8 qh, ql;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              _Float16 hi_, lo_;
+              split_pair(v[e], hi_, lo_);
+              qh[e] = hi_;
+              ql[e] = lo_;
+            }
+            {
+              typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+              const u32x4 hb = __builtin_bit_cast(u32x4, qh);
+              unsigned mx = 0;
+#pragma unroll
+              for (int w4 = 0; w4 < 4; ++w4)
+                mx = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, mx), __builtin_bit_cast(u16x2, hb[w4] & 0x7fff7fffu)));
+              if (m < g.M) hi_max = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, hi_max), __builtin_bit_cast(u16x2, mx)));
+            }
+            const unsigned off = ((unsigned)m * (unsigned)g.N + (unsigned)nbase) * 4u + (unsigned)(q * CW + 8 * cc) * 2u;
+            q8_st128(g.Cp, out_bytes, off, __builtin_bit_cast(u32x4, qh));
+            q8_st128(g.Cp, out_bytes, off + 64u, __builtin_bit_cast(u32x4, ql));
+          }
+        }
+      }
+     }
+    }
+    post_epi = true;
+    post_half = half;
+    if constexpr (!F32OUT) range_flag_raise(g.range_flag, (hi_max & 0xffffu) >= 0x7c00u || (hi_max >> 16) >= 0x7c00u);
+  };
+
+  // ---- prologue: K-tile 0 -> slot 0, K-tile 1 -> slot 1 (K-tiles that do not exist: zero-filled)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) site(k, 0);
+  cursor_advance();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) site(k, SLOT_B);
+  cursor_advance();
+  q8_wait_vmcnt<8>();            // K-tile 0's eight pieces (K-tile 1's may still be in flight)
+  __builtin_amdgcn_s_barrier();
+
+  using NO = std::false_type; using YES = std::true_type;
+  for (int it = 0; it < n_items; ++it) {
+    int row0, n0;
+    item(it, row0, n0);
+    // the item's first fragments, exposed: its first K-tile is in s_cur (waited for by every wave before the barrier at the top of the
+    // previous iteration - the first item: by the prologue)
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      rd_w(s_cur, 0, c4);
+      rd_w(s_cur, 1, c4);
+      rd_x(s_cur, 0, c4);
+      if constexpr (!HALFK) rd_x(s_cur, 1, c4);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { a1[a][m][e] = 0.f; a2[a][m][e] = 0.f; }
+    for (int t = 0; t + 1 < nk; ++t) ktile(NO{});
+    ktile(YES{});
+    epilogue(row0, n0);
+  }
+  if constexpr (GG) {
+    if (g.amax_out) amax_publish(g.amax_out, amax_run);
+  }
+#undef Q4_FENCE
+}
+
+// g.ntiles whole tiles (round-robin over g.ncu workgroups), then g.n_half half items (a second launch)
+template <int EPI>
+static int launch_pairs4(const Q8Args& g, hipStream_t s) {
+  if (g.ntiles > 0) {
+    hipLaunchKernelGGL((gemm_pairs4_kernel<EPI, false>), dim3(g.ntiles < g.ncu ? g.ntiles : g.ncu), dim3(256), 0, s, g);
+    TT_CHECK_LAUNCH("gemm_pairs4");
+  }
+  if (g.n_half > 0) {
+    Q8Args h = g;
+    h.ncu = g.n_half;
+    hipLaunchKernelGGL((gemm_pairs4_kernel<EPI, true>), dim3(g.n_half), dim3(256), 0, s, h);
+    TT_CHECK_LAUNCH("gemm_pairs4 (half tiles)");
+  }
+  return TT_OK;
+}
+
 template <int EPI, int DBG = 0>
 static int launch_pairs8s(const Q8Args& g, hipStream_t s) {
   hipLaunchKernelGGL((gemm_pairs8s_kernel<EPI, DBG>), dim3(g.ncu), dim3(512), 0, s, g);
@@ -1471,6 +1818,32 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
 #undef Q8S_DBG_CASE
   }
 #endif
+  // knob TT_Q4: 0 never; 1 every shape with at least one round of 128 x 128 tiles; 2 only the GELU epilogues (the long, VALU-bound ones: where
+  // hiding the epilogue under the other workgroup's main loop pays most) at K <= 768
+  const int q4 = tuning_knob(KNOB_Q4);
+  const bool q4_gelu = epi == Q8_PAIR_GELU || epi == Q8_BOTH_GELU;
+  if (kgroup == 1 && (q4 == 1 || (q4 == 2 && q4_gelu && K <= 768) || (q4 == 3 && K <= 768)) &&
+      (long long)((M + 127) / 128) * pl.ntn >= 2LL * device_cu_count()) {
+    // (experiment, default off) the four-wave kernel: 128 x 128 tiles, two workgroups per CU, at least one round of them
+    Q8Args g4 = g;
+    g4.ntiles = ((M + 127) / 128) * pl.ntn;
+    g4.ncu = 2 * device_cu_count();
+    g4.n_full = g4.n_half = 0; g4.ks_S = g4.ks_R = 0; g4.ks_ws = nullptr; g4.ks_cnt = nullptr;
+    {   // the left-over tiles as halves (a second launch) when they fit one round of workgroups
+      const int R4 = g4.ntiles / g4.ncu, rem4 = g4.ntiles - R4 * g4.ncu;
+      if (rem4 > 0 && 2 * rem4 <= g4.ncu && tuning_knob(KNOB_P8_NO_HALF) == 0) { g4.ntiles = R4 * g4.ncu; g4.n_half = 2 * rem4; }
+    }
+    switch (epi) {
+      case Q8_F32: return launch_pairs4<Q8_F32>(g4, s);
+      case Q8_F32_RES: return launch_pairs4<Q8_F32_RES>(g4, s);
+      case Q8_PAIR: return launch_pairs4<Q8_PAIR>(g4, s);
+      case Q8_PAIR_GELU: return launch_pairs4<Q8_PAIR_GELU>(g4, s);
+      case Q8_F32_GELUGRAD: return launch_pairs4<Q8_F32_GELUGRAD>(g4, s);
+      case Q8_BOTH: return launch_pairs4<Q8_BOTH>(g4, s);
+      case Q8_BOTH_GELU: return launch_pairs4<Q8_BOTH_GELU>(g4, s);
+      default: return 1;
+    }
+  }
   if (kgroup == 1) {
     switch (epi) {
       case Q8_F32: return launch_pairs8s<Q8_F32>(g, s);

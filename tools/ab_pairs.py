@@ -51,6 +51,9 @@ cases = [(25216, 1152, 384, 0, 0, 0, "qkv"), (25216, 384, 384, 0, 0, 1, "proj"),
          (18912, 384, 384, 0, 0, 1, "rest proj"), (18912, 1536, 384, 1, 1, 0, "rest fc1"),
          # C1 (2 clips x 2 frames = 788 rows): launch-latency regime of the general kernel
          (788, 1152, 384, 0, 1, 0, "C1 qkv"), (788, 384, 384, 0, 0, 1, "C1 proj"), (788, 1536, 384, 1, 1, 0, "C1 fc1"), (788, 384, 1536, 0, 0, 1, "C1 fc2")]
+if os.environ.get("TT_AB_CASES") == "exact":   # whole rounds for both tile geometries (256 x 128 on 256 CUs, 128 x 128 on 512 workgroups): the main loop without quantisation
+    cases = [(32768, 1024, 384, 0, 0, 0, "x f32 K384"), (32768, 1024, 384, 0, 1, 0, "x pair K384"), (32768, 1024, 384, 1, 1, 0, "x gelu K384"), (32768, 1024, 1536, 0, 0, 1, "x res K1536"),
+             (32768, 1024, 768, 0, 1, 0, "x pair K768")]
 tot = {n: 0.0 for n, _ in libs}
 for M, N, K, act, po, res, name in cases:
     x = split(torch.randn(M, K, device="cuda")); w = split(torch.randn(N, K, device="cuda") * 0.05)
