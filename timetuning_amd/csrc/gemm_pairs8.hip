@@ -1330,9 +1330,10 @@ __global__ __launch_bounds__(512) void gemm_pairs8s_kernel(Q8Args g) {
 #ifndef TT_Q4_SITES
 #define TT_Q4_SITES 2
 #endif
-// HALFK: the launch of the left-over tiles as HALVES (one half item per workgroup; a separate instantiation - both item kinds in one kernel
-// spilled 15 - 45 registers)
-template <int EPI, bool HALFK>
+// Half items (the left-over tiles cut in two: 64 x rows, x block 0 of every wave only) are a RUN-TIME property of an item here - uniform branches
+// around the second phase and the refresh sites; as a template parameter of the K-tile / epilogue lambdas (four + two copies of the code) the
+// kernel spilled 15 - 45 registers.
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
   constexpr int ROWB = 128, CPR = 8, WIN = 2, RPI = 8;
   constexpr int CHUNK_B = 128 * ROWB;       // 16 KB: 128 rows of one operand
@@ -1364,14 +1365,16 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
   if ((nwg & 7) == 0) wg = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
   // n_half > 0: g.n_full whole tiles per workgroup, then the left-over tiles cut into HALVES (64 x rows: x block 0 of every wave only),
   // workgroup h < n_half takes half h & 1 of tile n_full * nwg + h / 2 - a left-over round costs ~ 0.55 of a tile instead of a whole one
-  // (whole-tile launch: tiles [0, g.ntiles) round-robin; half launch: g.ntiles = the first left-over tile, workgroup h takes half h & 1 of
-  // tile g.ntiles + h / 2)
-  const int n_items = HALFK ? 1 : (wg < g.ntiles ? (g.ntiles - wg + nwg - 1) / nwg : 0);
+  // g.n_half > 0: g.n_full whole tiles per workgroup, then workgroup h < n_half takes half h & 1 of tile n_full * nwg + h / 2; else round-robin
+  const bool has_half = wg < g.n_half;
+  const int n_whole = g.n_half > 0 ? g.n_full : (wg < g.ntiles ? (g.ntiles - wg + nwg - 1) / nwg : 0);
+  const int n_items = n_whole + (has_half ? 1 : 0);
   if (n_items == 0) return;
-  auto item = [&](int it, int& row0, int& n0) {
-    const int tile = HALFK ? g.ntiles + (wg >> 1) : it * nwg + wg;
+  auto item = [&](int it, int& row0, int& n0, bool& half) {
+    half = has_half && it == n_whole;
+    const int tile = half ? g.n_full * nwg + (wg >> 1) : it * nwg + wg;
     const int mb = tile / g.ntn, ns = tile - mb * g.ntn;
-    row0 = mb * 128 + (HALFK ? (wg & 1) * 64 : 0);
+    row0 = mb * 128 + (half ? (wg & 1) * 64 : 0);
     n0 = ns * BN;
   };
 
@@ -1388,11 +1391,11 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
 
   // ---- DMA cursor: the K-tile whose pieces are issued next (two K-tiles ahead of the MFMAs)
   int d_item = 0, d_kt = 0;
-  bool d_done = false;
+  bool d_done = false, d_half = false;
   unsigned cur_w = OOB, cur_x = OOB;
   auto cursor_item = [&]() {
     int row0, n0;
-    item(d_item, row0, n0);
+    item(d_item, row0, n0, d_half);
     d_kt = 0;
     cur_w = (unsigned)n0 * (unsigned)K4;
     cur_x = (unsigned)row0 * (unsigned)K4;
@@ -1413,7 +1416,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
   auto site = [&](int k, int slot) {
     if (k < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (q8_lds_ptr_t)(smem + slot + k * 4096 + wave * 1024), 16, lane_voff + cur_w + (unsigned)k * site_step, 0, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (q8_lds_ptr_t)(smem + slot + CHUNK_B + (k - 4) * 4096 + wave * 1024), 16,
-                                                  (k >= 6 && HALFK) ? OOB : lane_voff + cur_x + (unsigned)(k - 4) * site_step, 0, 0, 0);   // (a half item has 64 x rows)
+                                                  (k >= 6 && d_half) ? OOB : lane_voff + cur_x + (unsigned)(k - 4) * site_step, 0, 0, 0);   // (a half item has 64 x rows)
   };
 
   // ---- fragment addressing (as gemm_pairs8s_kernel)
@@ -1421,7 +1424,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
   int fo[4];
 #pragma unroll
   for (int c4 = 0; c4 < 4; ++c4) fo[c4] = r * ROWB + (((2 * c4 + h) ^ f_sw) << 4);
-  const int x_slice = CHUNK_B + wr * (HALFK ? 32 : 64) * ROWB;
+  int x_slice = CHUNK_B + wr * 64 * ROWB;   // (a half item: wr * 32 - set per item)
   const int w_slice = wc * 64 * ROWB;
 
   f32x16 a1[2][2], a2[2][2];   // [x block][w block]
@@ -1433,9 +1436,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
   int s_cur = 0, s_nxt = SLOT_B;   // ring slots of K-tile t (refilled with t + 2 during iteration t) and t + 1 (read during iteration t)
   bool post_epi = false, post_half = false;
 #define Q4_FENCE() __builtin_amdgcn_sched_barrier(0)
-  auto ktile = [&](auto last_c) {
+  auto ktile = [&](auto last_c, const bool HALF) {
     constexpr bool LAST = decltype(last_c)::value;   // the item's last K-tile: no refresh (the fragments would be live across the epilogue)
-    constexpr bool HALF = HALFK;                     // a half item: x block 0 only, 12 MFMAs, all eight DMA sites and the W refresh in its one phase
+    // HALF (uniform, run time): x block 0 only - 12 MFMAs, the W refresh in its one phase
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (post_epi) {                                   // (the epilogue's stores are younger than the pieces waited for)
       if (post_half) q8_wait_vmcnt<ST_FULL / 2>(); else q8_wait_vmcnt<ST_FULL>();
@@ -1450,12 +1453,11 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
       Q4_FENCE();
       // the eight pieces of K-tile t + 2, all in the FIRST phase (TT_Q4_SITES = 2: two per slot; 1: one per slot over both phases): a piece
       // issued in the last slot had the whole memory latency exposed at the next iteration's wait
-      if constexpr (TT_Q4_SITES == 2 || HALF) { if constexpr (PH == 0) site(2 * q, s_cur); }
-      else site(4 * PH + q, s_cur);
+      if constexpr (PH == 0) site(2 * q, s_cur);
       Q4_FENCE();
       a1[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][ks], Xf[PH][ks], a1[PH][mt], 0, 0, 0);
       Q4_FENCE();
-      if constexpr ((TT_Q4_SITES == 2 || HALF) && PH == 0) site(2 * q + 1, s_cur);
+      if constexpr (PH == 0) site(2 * q + 1, s_cur);
       Q4_FENCE();
       a2[PH][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[mt][2 + ks], Xf[PH][ks], a2[PH][mt], 0, 0, 0);
       Q4_FENCE();
@@ -1463,13 +1465,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
         // in-place refresh from K-tile t + 1: X block PH's k-step ks is done once its second w block (mt = 1) is; in the last phase every
         // slot's own two W fragments are done behind its last MFMA
         if (mt == 1) { rd_x(s_nxt, PH, ks); rd_x(s_nxt, PH, 2 + ks); }
-        if constexpr (PH == 1 || HALF) { rd_w(s_nxt, mt, ks); rd_w(s_nxt, mt, 2 + ks); }
+        if (PH == 1 || HALF) { rd_w(s_nxt, mt, ks); rd_w(s_nxt, mt, 2 + ks); }
       }
       Q4_FENCE();
     };
     using PH0 = std::integral_constant<int, 0>; using PH1 = std::integral_constant<int, 1>;
     slot(PH0{}, 0); slot(PH0{}, 1); slot(PH0{}, 2); slot(PH0{}, 3);
-    if constexpr (!HALF) { slot(PH1{}, 0); slot(PH1{}, 1); slot(PH1{}, 2); slot(PH1{}, 3); }
+    if (!HALF) { slot(PH1{}, 0); slot(PH1{}, 1); slot(PH1{}, 2); slot(PH1{}, 3); }
     cursor_advance();
     const int t_ = s_cur; s_cur = s_nxt; s_nxt = t_;
   };
@@ -1484,10 +1486,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
   auto esw = [](int row) { return (row >> 2) & (CPRW - 1); };
   const unsigned out_bytes = (unsigned)g.M * (unsigned)g.N * 4u;
   float amax_run = 0.f;
-  auto epilogue = [&](int row0, int n0) {
-    constexpr bool half = HALFK;
-    constexpr int NT = half ? 2 : 4;
-    constexpr int nt = NT;
+  auto epilogue = [&](int row0, int n0, const bool half) {
+    constexpr int NT = 4;
+    const int nt = half ? 2 : NT;
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int r = lane_e & 31, h = lane_e >> 5;
@@ -1525,7 +1526,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-     {
+     if (j < nt) {
       const int ha = j >> 1, mt = j & 1;
       const int mbase = mrow(j), nbase = ncol(j);
       if constexpr (RES) {
@@ -1620,7 +1621,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
   using NO = std::false_type; using YES = std::true_type;
   for (int it = 0; it < n_items; ++it) {
     int row0, n0;
-    item(it, row0, n0);
+    bool c_half;
+    item(it, row0, n0, c_half);
+    x_slice = CHUNK_B + wr * (c_half ? 32 : 64) * ROWB;
     // the item's first fragments, exposed: its first K-tile is in s_cur (waited for by every wave before the barrier at the top of the
     // previous iteration - the first item: by the prologue)
 #pragma unroll
@@ -1628,7 +1631,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
       rd_w(s_cur, 0, c4);
       rd_w(s_cur, 1, c4);
       rd_x(s_cur, 0, c4);
-      if constexpr (!HALFK) rd_x(s_cur, 1, c4);
+      if (!c_half) rd_x(s_cur, 1, c4);
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1636,9 +1639,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { a1[a][m][e] = 0.f; a2[a][m][e] = 0.f; }
-    for (int t = 0; t + 1 < nk; ++t) ktile(NO{});
-    ktile(YES{});
-    epilogue(row0, n0);
+    for (int t = 0; t + 1 < nk; ++t) ktile(NO{}, c_half);
+    ktile(YES{}, c_half);
+    epilogue(row0, n0, c_half);
   }
   if constexpr (GG) {
     if (g.amax_out) amax_publish(g.amax_out, amax_run);
@@ -1646,19 +1649,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pairs4_kernel(Q8Args g) {
 #undef Q4_FENCE
 }
 
-// g.ntiles whole tiles (round-robin over g.ncu workgroups), then g.n_half half items (a second launch)
 template <int EPI>
 static int launch_pairs4(const Q8Args& g, hipStream_t s) {
-  if (g.ntiles > 0) {
-    hipLaunchKernelGGL((gemm_pairs4_kernel<EPI, false>), dim3(g.ntiles < g.ncu ? g.ntiles : g.ncu), dim3(256), 0, s, g);
-    TT_CHECK_LAUNCH("gemm_pairs4");
-  }
-  if (g.n_half > 0) {
-    Q8Args h = g;
-    h.ncu = g.n_half;
-    hipLaunchKernelGGL((gemm_pairs4_kernel<EPI, true>), dim3(g.n_half), dim3(256), 0, s, h);
-    TT_CHECK_LAUNCH("gemm_pairs4 (half tiles)");
-  }
+  hipLaunchKernelGGL((gemm_pairs4_kernel<EPI>), dim3(g.ncu), dim3(256), 0, s, g);
+  TT_CHECK_LAUNCH("gemm_pairs4");
   return TT_OK;
 }
 
@@ -1829,9 +1823,9 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
     g4.ntiles = ((M + 127) / 128) * pl.ntn;
     g4.ncu = 2 * device_cu_count();
     g4.n_full = g4.n_half = 0; g4.ks_S = g4.ks_R = 0; g4.ks_ws = nullptr; g4.ks_cnt = nullptr;
-    {   // the left-over tiles as halves (a second launch) when they fit one round of workgroups
+    {   // the left-over tiles as halves when they fit one round of workgroups
       const int R4 = g4.ntiles / g4.ncu, rem4 = g4.ntiles - R4 * g4.ncu;
-      if (rem4 > 0 && 2 * rem4 <= g4.ncu && tuning_knob(KNOB_P8_NO_HALF) == 0) { g4.ntiles = R4 * g4.ncu; g4.n_half = 2 * rem4; }
+      if (rem4 > 0 && 2 * rem4 <= g4.ncu && tuning_knob(KNOB_P8_NO_HALF) == 0) { g4.n_full = R4; g4.n_half = 2 * rem4; }
     }
     switch (epi) {
       case Q8_F32: return launch_pairs4<Q8_F32>(g4, s);
