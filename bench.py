@@ -151,11 +151,15 @@ def graph_check(model, opt, x, use_teacher):
     pg = [t.detach().clone() for t, _ in st["tensors"]]
     replayed = len(core._step_graphs) == n_graphs and n_graphs > 0   # (no new capture, no fall-back to the eager path: it WAS a replay)
     _restore(model, opt, st)
-    core._step_graph_on = False
+    from timetuning_amd import engine
+
+    # (the reference: the eager step on ONE stream - a captured step runs on one, engine.two_streams; what the side streams change is the
+    # K-split rounding of some launches' left-over tiles, tests/test_hip_timet.py::test_two_streams_equal_one_stream)
+    core._step_graph_on, keep_streams, engine.TWO_STREAMS = False, engine.TWO_STREAMS, False
     try:
         le = train_step(model, opt, x, use_teacher)
     finally:
-        core._step_graph_on = True
+        core._step_graph_on, engine.TWO_STREAMS = True, keep_streams
     ge = [p.grad.clone() for p in core.parameters() if p.grad is not None]
     torch.cuda.synchronize()
     ok = (replayed and float(lg.item()) == float(le.item()) and len(gg) == len(ge) and all(torch.equal(a, b) for a, b in zip(gg, ge))

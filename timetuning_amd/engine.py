@@ -396,13 +396,15 @@ def vit_params(vit, first: int, last: int, pos: Optional[torch.Tensor] = None):
 #   * the trainable blocks' forward: the frames that keep nothing (all but the target frames) and the kept target frames are separate chains
 #     already (vit_tokens' lo / hi); lo goes to the side stream.
 # Fork / join by stream waits on both sides of the section (every side-stream launch is bracketed by them: buffers allocated on one stream
-# and used on the other need no record_stream, and a captured step - TimeT.enable_step_graph - records the fork and the join as graph edges).
+# and used on the other need no record_stream).  A CAPTURED step (TimeT.enable_step_graph) stays on one stream: ``two_streams``.
 # Off: TT_SINGLE_STREAM=1, and whenever launches are being timed one by one (``ops.fine_grained()``: bench.py's roofline pass - a kernel that
 # shares the chip with another stream's kernel has no launch duration of its own).  Results: the frames of a batch are independent, so the two
 # halves compute what the whole batch computes - bit for bit wherever a launch's grid decomposition does not change an accumulation order
 # (the K-split of a K = 1536 launch's left-over tiles does: those rows agree to fp32 rounding; tests/test_hip_timet.py).
 TWO_STREAMS = __import__("os").environ.get("TT_SINGLE_STREAM") != "1"
-TWO_STREAMS_MIN_FRAMES = 32     # halves below 16 frames (3 152 token rows) no longer fill the chip: one stream
+# Below 64 frames of ViT-S/16 (16 clips x 4) a launched step is host-bound and the forks only cost: 12 clips 4.85 ms with the streams against
+# 3.96 on one, 8 clips 4.01 against 3.72; from 16 clips on they pay (4.52 against 4.68; 32 clips: -3 ... -8 %).
+TWO_STREAMS_MIN_FRAMES = int(__import__("os").environ.get("TT_TWO_STREAMS_MIN_FRAMES", "64"))   # (the environment variable: sweeps only)
 _SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
 
 
@@ -417,7 +419,11 @@ def side_stream(device, which: int = 0) -> "torch.cuda.Stream":
 
 
 def two_streams(device, frames: int) -> bool:
-    return TWO_STREAMS and torch.device(device).type == "cuda" and not ops.fine_grained() and frames >= TWO_STREAMS_MIN_FRAMES
+    """Side streams for this section?  Not while launches are timed one by one, not below TWO_STREAMS_MIN_FRAMES frames, and NOT under a
+    hipGraph capture: ROCm 7.2 replays a graph with forks and joins far slower than the launches it replaces (measured, round 6: C1 with
+    the fork / join captured 6.2 ms against 1.95 on one captured stream; 8 clips 7.6 against 3.1) - a captured step stays on one stream."""
+    return (TWO_STREAMS and torch.device(device).type == "cuda" and not ops.fine_grained() and frames >= TWO_STREAMS_MIN_FRAMES
+            and not torch.cuda.is_current_stream_capturing())
 
 
 def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None, save_blocks: Optional[Dict[int, dict]] = None,
