@@ -368,6 +368,17 @@ int tt_label_propagate(const float* xn, const float* seg0, int64_t* labels, doub
                        int D, int K, int n_last_frames, int radius, int topk, float temperature, int precision, void* workspace,
                        size_t workspace_bytes, tt_stream_t stream);
 size_t tt_label_propagate_workspace_bytes(int bs, int fs, int g, int D, int K, int n_last_frames);
+/* The same in two calls, for a caller that overlaps the halves with other work (round 6: the cosine similarities do not depend on seg0 - the
+ * training step computes them on a side stream beside the Sinkhorn solve that produces seg0):
+ *   tt_label_propagate_sims       the similarities of ALL target frames into `workspace` (tt_label_propagate_workspace_bytes).  Returns TT_OK,
+ *                                 or 1 when they do not fit one chunk of this workspace (nothing is written: call tt_label_propagate);
+ *   tt_label_propagate_from_sims  tt_label_propagate on a workspace tt_label_propagate_sims prepared (same shapes, same workspace).
+ * Together they launch exactly what tt_label_propagate launches. */
+int tt_label_propagate_sims(const float* xn, int bs, int fs, int g, int D, int K, int n_last_frames, int precision, void* workspace,
+                            size_t workspace_bytes, tt_stream_t stream);
+int tt_label_propagate_from_sims(const float* xn, const float* seg0, int64_t* labels, double* pmap_last, int bs, int fs, int g, int D, int K,
+                                 int n_last_frames, int radius, int topk, float temperature, void* workspace, size_t workspace_bytes,
+                                 tt_stream_t stream);
 
 /* ---- N4: label-propagation EVALUATION (mask_propagation.py:816-833, DAVIS protocol
  *      n_last_frames 4, size_mask_neighborhood 12, topk 5), reusing k14.

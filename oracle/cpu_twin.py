@@ -27,6 +27,7 @@ TWINS = ["sinkhorn", "ce_loss_fwd_bwd", "img_resample_h", "img_resample_v", "img
          "scale_tensors", "gemm_f32", "pos_embed_interpolate", "upsample_bilinear_tokens", "upsample_argmax_f32", "kmeans_accumulate",
          "kmeans_accumulate_workspace_bytes", "linear_bwd_data_planes", "linear_bwd_weight_planes", "linear_bwd_weight_planes_workspace_bytes",
          "foreground_mask", "foreground_mask_from_probs", "label_propagate", "label_propagate_maps", "label_propagate_workspace_bytes",
+         "label_propagate_sims", "label_propagate_from_sims",
          # round 4: the fp16-pair operands of the "f16x3" mode
          "split_pairs", "join_pairs", "layernorm_fwd_pairs", "linear_fwd_pairs", "linear_fwd_pairs_route", "attention_fwd_pairs", "split_pairs_dual",
          "split_pairs_dual_workspace_bytes", "transpose_pairs", "linear_bwd_data_pairs", "linear_bwd_weight_pairs",

@@ -1673,6 +1673,17 @@ int tt_cpu_label_propagate(const float* xn, const float* seg0, int64_t* labels, 
   (void)precision;
   return lp_cpu(xn, seg0, labels, pmap_last, NULL, bs, fs, g, D, K, n_last_frames, radius, topk, temperature);
 }
+/* (the two-call form: the twin keeps no similarities - the first half is a no-op, the second the whole propagation) */
+int tt_cpu_label_propagate_sims(const float* xn, int bs, int fs, int g, int D, int K, int n_last_frames, int precision, void* workspace,
+                                size_t workspace_bytes, tt_stream_t stream) {
+  (void)xn; (void)bs; (void)fs; (void)g; (void)D; (void)K; (void)n_last_frames; (void)precision; (void)workspace; (void)workspace_bytes; (void)stream;
+  return 0;
+}
+int tt_cpu_label_propagate_from_sims(const float* xn, const float* seg0, int64_t* labels, double* pmap_last, int bs, int fs, int g, int D, int K,
+                                     int n_last_frames, int radius, int topk, float temperature, void* workspace, size_t workspace_bytes,
+                                     tt_stream_t stream) {
+  return lp_cpu(xn, seg0, labels, pmap_last, NULL, bs, fs, g, D, K, n_last_frames, radius, topk, temperature);
+}
 int tt_cpu_label_propagate_maps(const float* xn, const float* seg0, double* pmap_all, int bs, int fs, int g, int D, int K, int n_last_frames,
                                 int radius, int topk, float temperature, int precision, void* workspace, size_t workspace_bytes,
                                 tt_stream_t stream) {

@@ -341,6 +341,43 @@ def test_label_propagation_batch(ops):
         assert (labels[b].cpu().numpy() != ref.argmax(1)).mean() <= 0.01
 
 
+def test_label_propagation_in_two_calls(ops, monkeypatch):
+    """tt_label_propagate_sims + tt_label_propagate_from_sims (the training step runs the first on a side stream, beside the Sinkhorn
+    solve that produces the seed) launch what tt_label_propagate launches: labels and map bit for bit the one-call form's, also when
+    the similarities were computed on another stream; when the similarities do not fit one chunk the first half declines (None)."""
+    bs, fs, g, D, K = 3, 4, 14, 384, 200
+    feats = rnd("lpf", fs, bs, g * g, D)
+    feats[1:] = 0.7 * feats[:1] + 0.3 * feats[1:]
+    q0 = dev(F.softmax(rnd("lpq", bs, g * g, K) * 3, -1))
+    xn = ops.l2norm_fwd(dev(feats.reshape(-1, D))).reshape(fs, bs, g * g, D)
+    for prec in ("f16x3", "f32"):
+        ops.set_gemm_precision(prec)
+        try:
+            labels, pmap = ops.label_propagate(xn, q0, return_pmap=True)
+            sims = ops.label_propagate_sims(xn, K)
+            assert sims is not None
+            l2, p2 = ops.label_propagate(xn, q0, return_pmap=True, sims=sims)
+            assert torch.equal(l2, labels) and torch.equal(p2, pmap), prec
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                sims = ops.label_propagate_sims(xn, K)
+                ready = torch.cuda.Event()
+                ready.record()
+            torch.cuda.current_stream().wait_event(ready)
+            l3, p3 = ops.label_propagate(xn, q0, return_pmap=True, sims=sims)
+            torch.cuda.current_stream().synchronize()
+            assert torch.equal(l3, labels) and torch.equal(p3, pmap), prec
+        finally:
+            ops.set_gemm_precision("f16x3")
+    # more than one chunk: 24 x 3 clips x 3 target frames x 196^2 x 4 B = 33 MB of similarities against a 4 MB cap
+    xn_w = xn.repeat(1, 24, 1, 1).contiguous()
+    monkeypatch.setenv("TT_LP_SIMS_CAP_MB", "4")
+    assert ops.label_propagate_sims(xn_w, K) is None
+    monkeypatch.delenv("TT_LP_SIMS_CAP_MB")
+    assert ops.label_propagate_sims(xn_w, K) is not None
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_davis_protocol_golden(ops, golden, tag):
     """N4: evaluation-protocol propagation (4 context frames, 25x25 window - 16 candidates per thread on the 28x28 grid -,

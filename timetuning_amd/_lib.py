@@ -148,6 +148,8 @@ SIGNATURES = {
     "tt_kmeans_assign": (c_i, [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_vp]),
     "tt_kmeans_accumulate_workspace_bytes": (c_sz, [c_ll, c_i, c_i]),
     "tt_kmeans_accumulate": (c_i, [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_vp, c_sz, c_vp]),
+    "tt_label_propagate_sims": (c_i, [c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "tt_label_propagate_from_sims": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
     "tt_label_propagate_maps": (c_i, [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_vp, c_sz, c_vp]),
     "tt_upsample_argmax": (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "tt_confusion_counts": (c_i, [c_vp, c_vp, c_ll, c_i, c_vp, c_vp]),

@@ -1677,6 +1677,7 @@ static int launch_pairs8(const Q8Args& g, hipStream_t s) {
 struct Q8Plan {
   int ntn, ncu, n_full, n_half, ks_S, ks_R;
   long long ntiles;
+  bool small;   // fewer tiles than the persistent kernels want: theirs only under the knob TT_Q4_SMALL (the four-wave kernel's 128 x 128 tiles)
 };
 // kgroup: the K-tiles a K-tile range must be a multiple of - 3 for gemm_pairs8_kernel (its ring advances three K-tiles per loop trip), 1 for
 // gemm_pairs8s_kernel (run-time ring slots, fragments refreshed in place)
@@ -1728,7 +1729,11 @@ static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_p
   // (measured, us, persistent / general kernel: 100 tiles [6272 x 512 x 1024, the head's third Linear] 28.7 / 41.7; 75 tiles [6304 x 384 x
   // 384 / x 1536] 16.0 / 12.9 and 38.7 / 35.2; 50 tiles [6272 x 256 x 512] 16.3 / 10.8)
   const int min_tiles = kgroup == 1 ? tuning_knob(KNOB_Q8_MIN_TILES) : ncu_dev / 2;
-  if (ntiles < min_tiles && ks_S == 0) return -1;
+  pl->small = false;
+  if (ntiles < min_tiles && ks_S == 0) {
+    if (kgroup != 1 || tuning_knob(KNOB_Q4_SMALL) == 0) return -1;
+    pl->small = true;
+  }
   int ncu = (int)(ntiles < ncu_dev ? ntiles : ncu_dev), n_full = 0, n_half = 0;
   if (ks_S >= 2) {
     ncu = R > 0 ? ncu_dev : (int)rem * ks_S;
@@ -1816,16 +1821,19 @@ int pairs8_try(const void* x_pairs, const void* w_pairs, const float* bias, cons
   // hiding the epilogue under the other workgroup's main loop pays most) at K <= 768
   const int q4 = tuning_knob(KNOB_Q4);
   const bool q4_gelu = epi == Q8_PAIR_GELU || epi == Q8_BOTH_GELU;
-  if (kgroup == 1 && (q4 == 1 || (q4 == 2 && q4_gelu && K <= 768) || (q4 == 3 && K <= 768)) &&
-      (long long)((M + 127) / 128) * pl.ntn >= 2LL * device_cu_count()) {
-    // (experiment, default off) the four-wave kernel: 128 x 128 tiles, two workgroups per CU, at least one round of them
+  if (kgroup == 1 && (pl.small || ((q4 == 1 || (q4 == 2 && q4_gelu && K <= 768) || (q4 == 3 && K <= 768)) &&
+                                   (long long)((M + 127) / 128) * pl.ntn >= 2LL * device_cu_count()))) {
+    // (experiment, default off) the four-wave kernel: 128 x 128 tiles, two workgroups per CU, at least one round of them - or (knob
+    // TT_Q4_SMALL) the grids of less than 96 256 x 128 tiles that otherwise go to the general kernel's 64 x 64 tiles, one workgroup per tile
     Q8Args g4 = g;
     g4.ntiles = ((M + 127) / 128) * pl.ntn;
-    g4.ncu = 2 * device_cu_count();
+    g4.ncu = g4.ntiles < 2 * device_cu_count() ? g4.ntiles : 2 * device_cu_count();
     g4.n_full = g4.n_half = 0; g4.ks_S = g4.ks_R = 0; g4.ks_ws = nullptr; g4.ks_cnt = nullptr;
     {   // the left-over tiles as halves when they fit one round of workgroups
       const int R4 = g4.ntiles / g4.ncu, rem4 = g4.ntiles - R4 * g4.ncu;
       if (rem4 > 0 && 2 * rem4 <= g4.ncu && tuning_knob(KNOB_P8_NO_HALF) == 0) { g4.n_full = R4; g4.n_half = 2 * rem4; }
+      // (TT_Q4_SMALL = 2: a grid of at most one workgroup per CU as twice as many half tiles)
+      if (pl.small && tuning_knob(KNOB_Q4_SMALL) == 2 && g4.ntiles <= device_cu_count()) { g4.ncu = 2 * g4.ntiles; g4.n_full = 0; g4.n_half = 2 * g4.ntiles; }
     }
     switch (epi) {
       case Q8_F32: return launch_pairs4<Q8_F32>(g4, s);

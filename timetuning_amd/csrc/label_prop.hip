@@ -374,8 +374,10 @@ extern "C" size_t tt_label_propagate_workspace_bytes(int bs, int fs, int g, int 
 
 static int lp_run(const char* who, const float* xn, const float* seg0, int64_t* labels, double* pmap_last, double* pmap_all, int bs,
                   int fs, int g, int D, int K, int n_last_frames, int radius, int topk, float temperature, int precision, void* workspace,
-                  size_t workspace_bytes, tt_stream_t stream) {
-  TT_REQUIRE(xn && seg0 && workspace, "%s: null pointer", who);
+                  size_t workspace_bytes, tt_stream_t stream, int phase = 0) {
+  // phase: 0 the whole propagation; 1 the similarities only (tt_label_propagate_sims: they do not depend on seg0 - a caller may compute them
+  // beside other work); 2 the propagation from similarities phase 1 left in `workspace`.  1 / 2 need every target frame in ONE chunk.
+  TT_REQUIRE(xn && (seg0 || phase == 1) && workspace, "%s: null pointer", who);
   TT_REQUIRE(precision >= TT_PRECISION_F32 && precision <= TT_PRECISION_BF16, "%s: precision must be 0, 1 or 2 (got %d)", who, precision);
   const int sims_bf16 = precision == TT_PRECISION_BF16;   // the "bf16" mode: the cosine similarities on bf16 MFMA (what torch.autocast makes of them)
   TT_REQUIRE(bs > 0 && fs >= 2 && g > 0 && D > 0 && K > 0, "%s: need fs >= 2 and positive sizes", who);
@@ -401,15 +403,20 @@ static int lp_run(const char* who, const float* xn, const float* seg0, int64_t* 
   double* segs = pmap_all ? pmap_all : reinterpret_cast<double*>(static_cast<char*>(workspace) + sims_bytes);
   const long long fstride = (long long)bs * n * K;
   const long long nn = (long long)n * n, frame = (long long)bs * n * D, per_t = (long long)bs * cmax * nn;
+  if (phase != 0 && T < fs - 1) {
+    if (phase == 1) return 1;   // (more than one chunk: nothing written - the caller runs the whole propagation in one call)
+    set_error("%s: the similarities of %d target frames do not fit one chunk of this workspace (chunk %d)", who, fs - 1, T);
+    return TT_EINVAL;
+  }
   for (int t0 = 1; t0 < fs; t0 += T) {
     const int t1 = t0 + T < fs ? t0 + T : fs;
     // ---- cosine similarities of the chunk, sims[t - t0][b][j] = xn[t][b] @ xn[ctx_j(t)][b]^T with ctx(t) = {0} + [lo_t, t),
     //      lo_t = max(1, t - n_last)  (mask_propagation.py:480-487: the first frame and the queue of the last n_last frames)
     // slot 0, the pairs (t, 0) of every t in the chunk: inner batch = clip, outer = t
-    int rc = launch_gemm_plain2(xn + t0 * frame, xn, sims, n, n, D, D, D, n, bs, t1 - t0, (long long)n * D, (long long)n * D,
-                                (long long)cmax * nn, frame, 0, per_t, sims_bf16, s);
+    int rc = phase == 2 ? TT_OK : launch_gemm_plain2(xn + t0 * frame, xn, sims, n, n, D, D, D, n, bs, t1 - t0, (long long)n * D, (long long)n * D,
+                                                     (long long)cmax * nn, frame, 0, per_t, sims_bf16, s);
     if (rc != TT_OK) return rc;
-    for (int d = 1; d <= n_last_frames; ++d) {
+    for (int d = 1; d <= n_last_frames && phase != 2; ++d) {
       // pairs (t, t - d), t - d >= 1.  While the queue is still filling (t <= n_last + 1: lo_t = 1) the slot is j = t - d and
       // moves with t; afterwards (lo_t = t - n_last) it is j = 1 + n_last - d
       const int a0 = t0 > d + 1 ? t0 : d + 1;
@@ -426,6 +433,7 @@ static int lp_run(const char* who, const float* xn, const float* seg0, int64_t* 
         if (rc != TT_OK) return rc;
       }
     }
+    if (phase == 1) return TT_OK;
     // ---- the maps, frame by frame: frame t's map is context for frame t + 1
     for (int t = t0; t < t1; ++t) {
       LpArgs a{};
@@ -471,6 +479,20 @@ extern "C" int tt_label_propagate(const float* xn, const float* seg0, int64_t* l
   TT_REQUIRE(labels, "label_propagate: null pointer");
   return lp_run("label_propagate", xn, seg0, labels, pmap_last, nullptr, bs, fs, g, D, K, n_last_frames, radius, topk, temperature,
                 precision, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tt_label_propagate_sims(const float* xn, int bs, int fs, int g, int D, int K, int n_last_frames, int precision, void* workspace,
+                                       size_t workspace_bytes, tt_stream_t stream) {
+  return lp_run("label_propagate_sims", xn, nullptr, nullptr, nullptr, nullptr, bs, fs, g, D, K, n_last_frames, 1, 1, 1.0f, precision, workspace,
+                workspace_bytes, stream, 1);
+}
+
+extern "C" int tt_label_propagate_from_sims(const float* xn, const float* seg0, int64_t* labels, double* pmap_last, int bs, int fs, int g, int D,
+                                            int K, int n_last_frames, int radius, int topk, float temperature, void* workspace,
+                                            size_t workspace_bytes, tt_stream_t stream) {
+  TT_REQUIRE(labels, "label_propagate_from_sims: null pointer");
+  return lp_run("label_propagate_from_sims", xn, seg0, labels, pmap_last, nullptr, bs, fs, g, D, K, n_last_frames, radius, topk, temperature,
+                TT_PRECISION_F32, workspace, workspace_bytes, stream, 2);
 }
 
 extern "C" int tt_label_propagate_maps(const float* xn, const float* seg0, double* pmap_all, int bs, int fs, int g, int D, int K,

@@ -405,6 +405,8 @@ TWO_STREAMS = __import__("os").environ.get("TT_SINGLE_STREAM") != "1"
 # Below 64 frames of ViT-S/16 (16 clips x 4) a launched step is host-bound and the forks only cost: 12 clips 4.85 ms with the streams against
 # 3.96 on one, 8 clips 4.01 against 3.72; from 16 clips on they pay (4.52 against 4.68; 32 clips: -3 ... -8 %).
 TWO_STREAMS_MIN_FRAMES = int(__import__("os").environ.get("TT_TWO_STREAMS_MIN_FRAMES", "64"))   # (the environment variable: sweeps only)
+# the label propagation's similarities on the side stream, beside the Sinkhorn solve (ops.label_propagate_sims); "0": in the propagation's call (A/B)
+LP_SIMS_ON_SIDE = __import__("os").environ.get("TT_LP_SIMS_SIDE", "1") != "0"
 _SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
 
 

@@ -631,8 +631,26 @@ def sinkhorn_from_q(Q, iters: int, row0: int = 0, rows_out: Optional[int] = None
     return q
 
 
-def label_propagate(xn, seg0, n_last_frames=7, radius=6, topk=5, temperature=0.1, return_pmap=False):
-    """xn [fs,bs,n,D] normalised tokens (time-major), seg0 [bs,n,K] -> labels [bs,n] int64 (+ pmap [bs,n,K] fp64)."""
+def label_propagate_sims(xn, K: int, n_last_frames=7):
+    """The first half of ``label_propagate`` - the cosine similarities of all target frames, which do not depend on the assignment - for a
+    caller that computes them beside other work (``label_propagate(..., sims=)`` takes the result).  None when they do not fit one chunk."""
+    lib = _lib.load()
+    _chk(xn, "xn")
+    fs, bs, n, D = xn.shape
+    g = int(round(n ** 0.5))
+    assert g * g == n
+    nb = lib.tt_label_propagate_workspace_bytes(bs, fs, g, D, K, n_last_frames)
+    ws = _ws(nb, xn.device)
+    rc = lib.tt_label_propagate_sims(_p(xn), bs, fs, g, D, K, n_last_frames, precision_code(), _p(ws), nb, _stream())
+    if rc == 1:
+        return None
+    _lib.check(rc, "tt_label_propagate_sims")
+    return ws
+
+
+def label_propagate(xn, seg0, n_last_frames=7, radius=6, topk=5, temperature=0.1, return_pmap=False, sims=None):
+    """xn [fs,bs,n,D] normalised tokens (time-major), seg0 [bs,n,K] -> labels [bs,n] int64 (+ pmap [bs,n,K] fp64).  ``sims``: the workspace
+    ``label_propagate_sims`` prepared for the same xn / K / n_last_frames."""
     lib = _lib.load()
     _chk(xn, "xn"); _chk(seg0, "seg0")
     fs, bs, n, D = xn.shape
@@ -642,6 +660,11 @@ def label_propagate(xn, seg0, n_last_frames=7, radius=6, topk=5, temperature=0.1
     labels = torch.empty((bs, n), dtype=torch.int64, device=xn.device)
     pmap = torch.empty((bs, n, K), dtype=torch.float64, device=xn.device) if return_pmap else None
     nb = lib.tt_label_propagate_workspace_bytes(bs, fs, g, D, K, n_last_frames)
+    if sims is not None:
+        assert sims.numel() >= nb, (sims.numel(), nb)
+        _lib.check(lib.tt_label_propagate_from_sims(_p(xn), _p(seg0), _p(labels), _p(pmap), bs, fs, g, D, K, n_last_frames, radius, topk,
+                                                    float(temperature), _p(sims), sims.numel(), _stream()), "tt_label_propagate_from_sims")
+        return (labels, pmap) if return_pmap else labels
     ws = _ws(nb, xn.device)
     _lib.check(lib.tt_label_propagate(_p(xn), _p(seg0), _p(labels), _p(pmap), bs, fs, g, D, K, n_last_frames, radius, topk,
                                       float(temperature), precision_code(), _p(ws), nb, _stream()), "tt_label_propagate")

@@ -656,6 +656,7 @@ class TimeT(nn.Module):
             return z_t, engine.prototype_scores(z_t, self.prototypes.data, sv_s), sv_h, sv_s   # scores [bs*n, K]
 
         tgt = None
+        lp_sims = lp_ready = None
         side = engine.side_stream(dev) if engine.two_streams(dev, Fr) else None
         if side is not None:
             if fe.head is not None and engine._head_pairs_ok(engine.head_linears(fe.head), tgt_rows.shape[0]):
@@ -663,6 +664,12 @@ class TimeT(nn.Module):
                     engine.weight_planes(lin_.weight, 2)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                # the label propagation's cosine similarities (independent of the assignment: 60 us at C2) first, beside the source head /
+                # scores / Sinkhorn of the other stream, which ends in the propagation that reads them
+                lp_sims = ops.label_propagate_sims(xn_bb, self.prototypes.shape[0], hp["n_last_frames"]) if engine.LP_SIMS_ON_SIDE else None
+                if lp_sims is not None:
+                    lp_ready = torch.cuda.Event()
+                    lp_ready.record()
                 tgt = target_chain()
 
         # ---- assignment source: teacher on frame 0 if present, else the student's frame 0 (no grad either way)
@@ -717,7 +724,9 @@ class TimeT(nn.Module):
             tgt = target_chain()
         K = self.prototypes.shape[0]
         q = engine.global_sinkhorn_end(gather, bs * n, hp["epsilon"], hp["iters"])              # [bs*n, K]
-        labels = ops.label_propagate(xn_bb, q.view(bs, n, K), hp["n_last_frames"], hp["radius"], hp["topk"], 0.1)
+        if lp_ready is not None:
+            torch.cuda.current_stream().wait_event(lp_ready)
+        labels = ops.label_propagate(xn_bb, q.view(bs, n, K), hp["n_last_frames"], hp["radius"], hp["topk"], 0.1, sims=lp_sims)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         z_tgt, scores_t, sv_head, sv_sc = tgt

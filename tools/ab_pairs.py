@@ -54,6 +54,10 @@ cases = [(25216, 1152, 384, 0, 0, 0, "qkv"), (25216, 384, 384, 0, 0, 1, "proj"),
 if os.environ.get("TT_AB_CASES") == "exact":   # whole rounds for both tile geometries (256 x 128 on 256 CUs, 128 x 128 on 512 workgroups): the main loop without quantisation
     cases = [(32768, 1024, 384, 0, 0, 0, "x f32 K384"), (32768, 1024, 384, 0, 1, 0, "x pair K384"), (32768, 1024, 384, 1, 1, 0, "x gelu K384"), (32768, 1024, 1536, 0, 0, 1, "x res K1536"),
              (32768, 1024, 768, 0, 1, 0, "x pair K768")]
+if os.environ.get("TT_AB_CASES") == "small":   # the C2 step's launches below 96 256 x 128 tiles (general kernel; knob TT_Q4_SMALL: the four-wave kernel)
+    cases = [(6304, 384, 384, 0, 0, 1, "kept proj"), (6304, 384, 1536, 0, 0, 1, "kept fc2"), (6304, 384, 384, 0, 0, 0, "dgrad proj"), (6304, 384, 1152, 0, 0, 0, "dgrad qkv"),
+             (6304, 384, 1536, 0, 0, 0, "dgrad fc1"), (6272, 384, 1024, 0, 0, 0, "dgrad hd1"), (6272, 256, 512, 0, 0, 0, "head 4"), (6272, 256, 512, 0, 1, 0, "head 4 pr"),
+             (12608, 384, 384, 0, 0, 1, "half proj"), (12608, 384, 1536, 0, 0, 1, "half fc2")]
 tot = {n: 0.0 for n, _ in libs}
 for M, N, K, act, po, res, name in cases:
     x = split(torch.randn(M, K, device="cuda")); w = split(torch.randn(N, K, device="cuda") * 0.05)
