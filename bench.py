@@ -560,6 +560,9 @@ def main():
         torch.cuda.set_device(0)
     device = torch.device("cuda", local if world > 1 else 0)
 
+    # the queue's permutations (torch.randperm from the CPU generator, time_tuning.py:259 of the reference) and the queue's initial rows come
+    # from torch's generators: seeded, so that a configuration's `loss` repeats from run to run (round 6: C3's wandered by +- 0.1 unseeded)
+    torch.manual_seed(20 + rank)
     bs, fs, K = a.batch_size, a.num_frames, a.num_clusters
     model = build_model(a.architecture, K, device, world=world)
     total_steps = a.steps + a.warmup + 200

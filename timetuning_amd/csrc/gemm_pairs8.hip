@@ -1725,7 +1725,9 @@ static int pairs8_plan(bool has_residual, bool has_y, bool has_pairs, bool has_p
     }
   }
   // a persistent grid that cannot fill the chip: the small-tile kernel does better.  Round 4: below half the CUs.  The symmetric kernel's
-  // half tiles cost ~ 0.55 of a whole one, so a grid of 2 x tiles half items pays a little earlier - knob TT_Q8_MIN_TILES, default 96
+  // half tiles cost ~ 0.55 of a whole one, so a grid of 2 x tiles half items pays a little earlier - knob TT_Q8_MIN_TILES, round 5's default 96; round 6: 128 - with the step's chains on three streams (engine.TWO_STREAMS) the 100-tile launches of the projection
+  // head do better on the general kernel's small workgroups, which share a CU with the other stream's kernel, than on one 160 KB workgroup per
+  // CU: C2 7.06 -> 7.03 ms, C4 18.25 -> 18.14, C3 / C5 unchanged (profiles/r06_step_knob_sweeps.txt), although alone the persistent kernel wins
   // (measured, us, persistent / general kernel: 100 tiles [6272 x 512 x 1024, the head's third Linear] 28.7 / 41.7; 75 tiles [6304 x 384 x
   // 384 / x 1536] 16.0 / 12.9 and 38.7 / 35.2; 50 tiles [6272 x 256 x 512] 16.3 / 10.8)
   const int min_tiles = kgroup == 1 ? tuning_knob(KNOB_Q8_MIN_TILES) : ncu_dev / 2;

@@ -408,15 +408,23 @@ TWO_STREAMS_MIN_FRAMES = int(__import__("os").environ.get("TT_TWO_STREAMS_MIN_FR
 # the label propagation's similarities on the side stream, beside the Sinkhorn solve (ops.label_propagate_sims); "0": in the propagation's call (A/B)
 LP_SIMS_ON_SIDE = __import__("os").environ.get("TT_LP_SIMS_SIDE", "1") != "0"
 _SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+# experiment (sweeps only): "p0:p1:p2:p3" = HIP stream priorities (0 default, -1 higher) of the side streams 0 .. 3 below; unset: 2 and 3 are
+# stream 0 and every priority is the default.  Measured (round 6, C2, profiles/r06_step_knob_sweeps.txt): four side streams of equal priority
+# 7.10 - 7.14 ms against 7.04 - 7.07 with two; the frames-that-keep-nothing chain and / or the teacher at -1: 7.08 - 7.11; all at -1: 7.05 - 7.10.
+_SIDE_PRIORITIES = [int(v) for v in __import__("os").environ["TT_SIDE_PRIORITIES"].split(":")] if __import__("os").environ.get("TT_SIDE_PRIORITIES") else None
 
 
 def side_stream(device, which: int = 0) -> "torch.cuda.Stream":
-    """The side stream(s) of a device: 0 = the second chain of a section (see TWO_STREAMS), 1 = the EMA teacher's blocks and head."""
+    """The side stream(s) of a device: 0 = the second chain of a section (see TWO_STREAMS), 1 = the EMA teacher's blocks and head; 2 = the
+    trainable blocks' frames that keep nothing, 3 = the weight gradients (both are stream 0 unless TT_SIDE_PRIORITIES separates them)."""
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
+    if _SIDE_PRIORITIES is None and which >= 2:
+        which = 0
     s = _SIDE_STREAMS.get((idx, which))
     if s is None:
-        s = _SIDE_STREAMS[(idx, which)] = torch.cuda.Stream(device=idx)
+        prio = _SIDE_PRIORITIES[which] if _SIDE_PRIORITIES is not None else 0
+        s = _SIDE_STREAMS[(idx, which)] = torch.cuda.Stream(device=idx, priority=prio)
     return s
 
 
@@ -494,7 +502,7 @@ def vit_tokens(vit, img: torch.Tensor, frame_map: Optional[torch.Tensor] = None,
             lo, hi = x[:save_from_frame], x[save_from_frame:]
             want_aux = last_block_aux is not None
             aux_lo, aux_hi = ({} if want_aux else None), ({} if want_aux else None)
-            cur, side = torch.cuda.current_stream(), side_stream(img.device)
+            cur, side = torch.cuda.current_stream(), side_stream(img.device, 2)
             # operands that are made lazily and cached (the pair / plane form of a weight at its first use) are made HERE, on this stream,
             # before the fork: made inside one chain they would be a cache hit for the other chain, on another stream, before they are written
             for rows in (lo.shape[0] * lo.shape[1], hi.shape[0] * hi.shape[1]):

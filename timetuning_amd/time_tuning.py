@@ -751,7 +751,7 @@ class TimeT(nn.Module):
         out = exchange.out
         prescaled = exchange.prescale_(dscores)   # 1 / W once, on the 5 MB loss gradient, instead of on every bucket
         if engine.two_streams(dev, bs * fs) and ops.pairs():
-            ops.wgrad_fork(engine.side_stream(dev))   # the weight-gradient products beside the data-gradient chain (joined below)
+            ops.wgrad_fork(engine.side_stream(dev, 3))   # the weight-gradient products beside the data-gradient chain (joined below)
         zn_t = sv_sc["zn"]
         grads[self.prototypes], _ = ops.wgrad_call(lambda: ops.linear_bwd_weight(dscores, zn_t, need_bias=False, dw_out=out(self.prototypes)),
                                                    keep=(dscores, zn_t))   # (a leaf too: beside the head's backward)
