@@ -26,6 +26,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#ifndef TT_AP_PACKED
+#define TT_AP_PACKED 1   // the probabilities' exp / split in packed fp32 instructions (0: the scalar form of round 5, for A/B builds)
+#endif
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+// (p - hi) 2^11 for two probabilities as fma(hi, -2^11, p 2^11), hi read AS fp16 by v_fma_mix_f32 (op_sel_hi = 1: an fp16 source, op_sel:
+// which half of its register) - no conversion back to fp32.  Exact, like the subtraction and the scaling it replaces: p 2^11 and hi 2^11
+// are exact and their difference has at most 13 significant bits.  (The compiler does not select the instruction by itself here.)
+__device__ __forceinline__ f32x2 pair_residual_scaled(f32x2 p_scaled, f16x2 hi2) {
+  const unsigned hb = __builtin_bit_cast(unsigned, hi2);
+  const float k = -kPairScale;
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "s"(k), "v"(p_scaled.x));
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "s"(k), "v"(p_scaled.y));
+  return (f32x2){r0, r1};
+}
 
 // TT_AP_DBG (timing studies only, tools/ap_ablate.py; 0 in the shipped build), a bit mask: 1 no score MFMAs, 2 no exp / split of the
 // probabilities, 4 no P V MFMAs, 8 no V fragment reads, 16 no K fragment reads, 32 no K / V DMA
@@ -199,9 +216,14 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
     // V^T gather addresses: block rows = keys key0 .. key0 + 3 (this lane supplies row q4), block columns = 16 dims of one 64-byte quarter
     // (hi or lo of a 32-dim group).  key0 = kt * 32 + 16 s + 4 h (+ 8) is a multiple of 4, so the quarter swizzle is q4 for every block:
     // four per-lane bases (quarter) + immediates (kt, s, the + 8 keys).
-    int vofs[4];   // [2 dt + plane]
+    // (round 6: the V image's base is part of the per-lane register and hidden from constant folding - the image sits 56 KB into the LDS
+    // array, and with its base folded into the immediates most of them passed the 16-bit offset field: a v_add_u32 per read)
+    lds_u8* vofs[4];   // [2 dt + plane]
 #pragma unroll
-    for (int qn = 0; qn < 4; ++qn) vofs[qn] = (4 * h + q4) * 256 + ((qn ^ q4) << 6) + (16 * g16 + 4 * p4) * 2;
+    for (int qn = 0; qn < 4; ++qn) {
+      vofs[qn] = (lds_u8*)Vs + ((4 * h + q4) * 256 + ((qn ^ q4) << 6) + (16 * g16 + 4 * p4) * 2);
+      asm volatile("" : "+v"(vofs[qn]));
+    }
     const int c8 = lane & 7;
     // O^T [64 d x 32 queries] = V^T P^T, three products per term, both 32-dim groups per key tile (four independent accumulator chains).
     // The probabilities of a key tile are made where they are consumed (round 5): exp, row sum and the split into (hi, lo) of tile kt + 1
@@ -216,6 +238,27 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       f16x8 ph[2], pl[2];
+#if TT_AP_PACKED
+      // exp, row sum and split of this key tile, two elements at a time in the packed fp32 instructions (round 6: the loop is VALU-bound -
+      // 16 elements cost ~ 160 issue slots as the compiler scheduled the scalar form, 64 of them the quarter-rate exponentials): scale and
+      // shift in one v_pk_fma_f32, hi = one v_cvt_pk_f16_f32, and lo = (p - hi) 2^11 as fma(hi, -2^11, p 2^11) - exact, like the subtraction
+      // it replaces (p 2^11 and hi 2^11 are exact, their difference has at most 13 significant bits), with hi read as fp16 by the mixed-
+      // precision fma (no conversion back).  Bits equal to split_pair's.
+#pragma unroll
+      for (int e2 = 0; e2 < 8; ++e2) {
+        const f32x2 sv = {sacc[kt][2 * e2], sacc[kt][2 * e2 + 1]};
+        const f32x2 t = __builtin_elementwise_fma(sv, (f32x2){c, c}, (f32x2){-mc, -mc});
+        const f32x2 p = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        sum += p.x;
+        sum += p.y;
+        const f16x2 h2 = __builtin_convertvector(p, f16x2);
+        const f32x2 pk = p * (f32x2){kPairScale, kPairScale};
+        const f32x2 r = pair_residual_scaled(pk, h2);
+        const f16x2 l2 = __builtin_convertvector(r, f16x2);
+        ph[e2 >> 2][2 * (e2 & 3)] = h2.x; ph[e2 >> 2][2 * (e2 & 3) + 1] = h2.y;
+        pl[e2 >> 2][2 * (e2 & 3)] = l2.x; pl[e2 >> 2][2 * (e2 & 3) + 1] = l2.y;
+      }
+#else
 #pragma unroll
       for (int e = 0; e < 16; ++e) {   // exp, row sum and split of this key tile
         const float p = (TT_AP_DBG & 2) ? sacc[kt][e] : __builtin_amdgcn_exp2f(fmaf(sacc[kt][e], c, -mc));
@@ -226,18 +269,19 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_kernel(const _Float16
         ph[e >> 3][e & 7] = hi_;
         pl[e >> 3][e & 7] = lo_;
       }
+#endif
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const unsigned char* vrow = Vs + (kt * 32 + 16 * s) * 256;
+        const int vrow = (kt * 32 + 16 * s) * 256;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           union { s16x4 s2[2]; f16x8 v; } vh, vl;
           if constexpr (TT_AP_DBG & 8) { vh.v = ph[s ^ 1]; vl.v = pl[s ^ 1]; }
           else {
-            vh.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + vofs[2 * dt]));
-            vh.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + 2048 + vofs[2 * dt]));
-            vl.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + vofs[2 * dt + 1]));
-            vl.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vrow + 2048 + vofs[2 * dt + 1]));
+            vh.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vofs[2 * dt] + vrow));
+            vh.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vofs[2 * dt] + vrow + 2048));
+            vl.s2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vofs[2 * dt + 1] + vrow));
+            vl.s2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vofs[2 * dt + 1] + vrow + 2048));
           }
           if constexpr (TT_AP_DBG & 4) { o1[dt][s] += (float)vh.v[0] * (float)ph[s][0]; o2[dt][s] += (float)vl.v[0] * (float)pl[s][0]; }
           else {
