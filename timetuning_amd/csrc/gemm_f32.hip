@@ -422,6 +422,16 @@ int gemm_tile_choice(int M, int N, int batch) {
     const double cost = (double)((tiles + 255) / 256) * (double)(bm * bn) * cfgs[c].pen;
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
+  // A grid of half a chip to a chip of workgroups is latency-bound by their K loops, and several of these small workgroups share a CU:
+  // the smallest tile then halves / quarters that loop at the same residency (round 6, in the step: the prototype-score products -
+  // 6272 x 200 x 256, 196 tiles of 128 x 64 - and their gradients: C2 -0.25 %, C2 in f32 -0.7 %; below 128 tiles - C1's launches -
+  // it measured no better: left alone; TT_TILE_RULE=0 restores the plain rule; profiles/r06_step_knob_sweeps.txt).
+  static const bool small_rule = [] { const char* e = getenv("TT_TILE_RULE"); return e ? atoi(e) != 0 : true; }();
+  if (small_rule) {
+    const long long bm = 64 * cfgs[best].wm, bn = 64 * cfgs[best].wn;
+    const long long t = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long long)batch;
+    if (t >= 128 && t < 256) best = 3;
+  }
   return best;
 }
 
