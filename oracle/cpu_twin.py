@@ -17,7 +17,7 @@ TWINS = ["sinkhorn", "ce_loss_fwd_bwd", "img_resample_h", "img_resample_v", "img
          # round 2: the hot path's row ops and (naive) matrix products
          "linear_fwd", "linear_bwd_data", "linear_bwd_weight", "layernorm_fwd", "l2norm_fwd", "normalize_rows_inplace", "attention_fwd",
          "adamw_step", "ema_update", "queue_push", "scale_rows_inplace", "sinkhorn_from_q", "split_planes", "count_mismatch",
-         "colsum", "add_inplace", "layernorm_bwd", "l2norm_bwd", "attention_bwd", "attention_bwd_bf16", "patch_embed_fwd", "affine_cols_inplace",
+         "colsum", "add_inplace", "layernorm_bwd", "l2norm_bwd", "attention_bwd", "attention_bwd_bf16", "attention_bwd_pairs", "attention_bwd_pairs_workspace_bytes", "patch_embed_fwd", "affine_cols_inplace",
          "transpose_planes", "transpose_planes_colsum", "transpose_planes_colsum_workspace_bytes", "layernorm_fwd_planes", "linear_fwd_planes", "attention_fwd_bf16", "patch_embed_fwd_planes",
          "patch_embed_planes_workspace_bytes",
          # the coarse entry points: the same sequences over the twins

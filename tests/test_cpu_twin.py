@@ -392,6 +392,9 @@ def _round2b_cases(side):
     side.run("attention_bwd", qkv, out, dout, lse, dqkv, Fa, Na, H, 64, 0.125, wsa, nbw, am_at, st, outs=(dqkv, am_at))
     assert am_at.max() == np.abs(dqkv).max()
     R["att_bwd"] = (qkv, dout, dqkv.copy(), am_at.max(keepdims=True))
+    dqkv_p, am_p, flag_p = np.empty_like(qkv), np.zeros(16 * 64, np.float32), np.zeros(1, np.int32)
+    side.run("attention_bwd_pairs", qkv, out, dout, lse, dqkv_p, Fa, Na, H, 64, 0.125, wsa, nbw, flag_p, am_p, st, outs=(dqkv_p, am_p))
+    R["att_bwd_pairs"] = (qkv, dout, dqkv_p.copy())
     dqkv_b = np.empty_like(qkv)
     side.run("attention_bwd_bf16", qkv, out, dout, lse, dqkv_b, Fa, Na, H, 64, 0.125, wsa, nbw, st, outs=(dqkv_b,))
     R["att_bwd_bf16"] = (qkv, dout, dqkv_b.copy())
@@ -485,6 +488,7 @@ def test_round2b_twins_against_torch(twin):
     o = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(2, 21, 128)
     (o * torch.from_numpy(dout).double()).sum().backward()
     assert _re(dqkv, qt.grad.numpy()) < 1e-5
+    assert _re(R["att_bwd_pairs"][2], qt.grad.numpy()) < 1e-5   # fp16 pairs: fp32-class
     # bf16 products: near the exact gradient (the rounding of q, k, v, dout, P and dS), and NOT equal to it
     e_bf = _re(R["att_bwd_bf16"][2], qt.grad.numpy())
     assert 1e-4 < e_bf < 2e-2, e_bf
@@ -530,7 +534,7 @@ def test_hip_library_equals_its_cpu_twin_round2b(twin):
 
     A = _round2b_cases(_Side(_lib.load(), "tt_", device="cuda"))
     B = _round2b_cases(_Side(twin, "tt_cpu_"))
-    for key in ("colsum_add", "ln_bwd", "l2_bwd", "att_bwd", "patch", "affine"):
+    for key in ("colsum_add", "ln_bwd", "l2_bwd", "att_bwd", "att_bwd_pairs", "patch", "affine"):
         for i, (a, b) in enumerate(zip(A[key], B[key])):
             if isinstance(a, np.ndarray) and a.dtype == np.float32:
                 assert _re(a, b) < 2e-5, (key, i, _re(a, b))

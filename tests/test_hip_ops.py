@@ -129,6 +129,16 @@ def test_attention_fwd_bwd(ops, Fr, N, H):
     assert rel_err(probs.cpu(), p_ref.detach()) < TOL   # N > 256: the row-per-wave probabilities kernel
     dqkv = ops.attention_bwd(dev(qkv), out, dev(do), lse, H)
     assert rel_err(dqkv.cpu(), qd.grad) < 5e-5
+    # the "f16x3" mode's backward (tt_attention_bwd_pairs: S and dP on three fp16 MFMAs per term): the same bound, not worse than the
+    # fp32-MFMA kernels by more than rounding noise - also on a gradient of 1e-7 (the power-of-two scale of dout) - and the same amax slot
+    for gs in (1.0, 1e-7):
+        e32 = rel_l2(ops.attention_bwd(dev(qkv), out, dev(do * gs), lse, H).cpu(), qd.grad * gs)
+        slot = torch.zeros(ops.AmaxPool.get(torch.device("cuda")).SLOT, device="cuda")
+        dq_p = ops.attention_bwd(dev(qkv), out, dev(do * gs), lse, H, amax_out=slot, pair_products=True)
+        assert rel_err(dq_p.cpu(), qd.grad * gs) < 5e-5, gs
+        assert rel_l2(dq_p.cpu(), qd.grad * gs) < max(2.0 * e32, 2e-6), (gs, rel_l2(dq_p.cpu(), qd.grad * gs), e32)
+        assert slot.max().item() == dq_p.abs().max().item()
+    ops.check_pair_range()
 
 
 def test_l2norm(ops):

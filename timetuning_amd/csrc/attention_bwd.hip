@@ -14,6 +14,16 @@
 // SAME data movement: element j of a lane's bf16 operand for k-step t is the fp32 kernel's register s = 4 t + j (any assignment of the
 // contraction index to (lane group, element) is valid as long as both operands use it), and a 16 x 16 accumulator tile is the B operand
 // of the wider MFMA as it stands (k = row = 4 g + e, four elements per lane).
+// PAIR = true (tt_attention_bwd_pairs, round 6: the "f16x3" mode's backward): the two ROW-WISE products of a tile - S = Q K^T and
+// dP = dO V^T, 32 of its 48 fp32 MFMAs - run on fp16 (hi, lo) pairs instead: three v_mfma_f32_16x16x16_f16 per group of four fp32 MFMAs
+// (hi hi into one accumulator, hi lo + lo hi into a second one, folded with the exact 2^-11: gemm_pairs8.hip), 48 matrix-pipe cycles
+// instead of 128.  Their chunk operands are split ONCE on the way into LDS, into a hi and a lo plane of fp16 rows in natural order, and
+// the contraction index is assigned so that a lane's sixteen elements are CONTIGUOUS (lane group g owns head dimensions 16 g .. 16 g + 15,
+// element j of k-step t is dimension 16 g + 4 t + j - any assignment is valid as long as both operands use it): a fragment is two
+// ds_read_b128 per plane, no unzip, where the fp32 form issues sixteen ds_read_b32.  The TRANSPOSED products (dQ^T += K^T dS^T; dV^T +=
+// dO^T P, dK^T += Q^T dS) stay on the fp32 MFMA with fp32 chunks: their operands are columns of the chunk, and P / dS are used as they
+// leave the accumulators.  dO is a GRADIENT (1e-3 ... 1e-8): it is multiplied by the power of two that brings max |dO| into [2^13, 2^14)
+// before the split (exact; the max is one small launch in front) and dP divided by it again.
 #include "common.hpp"
 
 namespace tt {
@@ -21,12 +31,59 @@ namespace tt {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ s16x4 pack_bf16(float a, float b, float c, float d) {
   const bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
   return __builtin_bit_cast(s16x4, v);
 }
 __device__ __forceinline__ f32x4 mma_bf16(s16x4 a, s16x4 b, f32x4 acc) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0); }
+
+// ---- fp16 pairs (PAIR = true)
+__device__ __forceinline__ bool split4(float a, float b, float c, float d, f16x4& hi, f16x4& lo) {   // returns "a hi is not finite"
+  _Float16 h0, l0, h1, l1, h2, l2, h3, l3;
+  split_pair(a, h0, l0); split_pair(b, h1, l1); split_pair(c, h2, l2); split_pair(d, h3, l3);
+  hi = (f16x4){h0, h1, h2, h3};
+  lo = (f16x4){l0, l1, l2, l3};
+  return pair_hi_bad(h0) || pair_hi_bad(h1) || pair_hi_bad(h2) || pair_hi_bad(h3);
+}
+// acc1 += ah bh, acc2 += ah bl + al bh (the lo halves carry 2^11: the product is acc1 + 2^-11 acc2)
+__device__ __forceinline__ void mma_pair(f16x4 ah, f16x4 al, f16x4 bh, f16x4 bl, f32x4& acc1, f32x4& acc2) {
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc1, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, acc2, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, acc2, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 fold_pair(f32x4 a1, f32x4 a2, float m) {   // (acc1 + 2^-11 acc2) m
+  return (f32x4){fmaf(a2[0], kPairInvScale, a1[0]) * m, fmaf(a2[1], kPairInvScale, a1[1]) * m, fmaf(a2[2], kPairInvScale, a1[2]) * m,
+                 fmaf(a2[3], kPairInvScale, a1[3]) * m};
+}
+// max |dO| (per-workgroup partials; both kernels fold them themselves - max is order-independent) and the scale it gives
+constexpr int kBwdAmaxParts = 256;
+__global__ __launch_bounds__(256) void attention_bwd_amax_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i);   // (n % 4 == 0: head_dim 64)
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float bwd_grad_scale(const float* __restrict__ part, int n_part, float* sred) {   // every thread of the workgroup calls it
+  float m = (int)threadIdx.x < n_part ? part[threadIdx.x] : 0.f;
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+  if (!(m > 0.f) || !(m < INFINITY)) return 1.0f;
+  int e = 13 - ilogbf(m);
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return ldexpf(1.0f, e);
+}
+constexpr int PSTR = 72;   // fp16 elements per row of a pair plane (64 + 8: conflict-free ds_read_b128 of 16 rows)
 
 constexpr int BHD = 64, BCH = 32, BSTR = 68;  // chunk rows, LDS row stride (16 g + i banks for the transposed reads)
 
@@ -47,16 +104,62 @@ __device__ __forceinline__ void tile_to_regs(const float* __restrict__ src, long
 #pragma unroll
   for (int s = 0; s < 16; ++s) r[s] = stage[(wave * 16 + li) * BSTR + 4 * s + g];
 }
+// ... with the contraction index assigned as the PAIR products use it: r[4 t + j] = tile[wave * 16 + (lane & 15)][16 (lane >> 4) + 4 t + j]
+__device__ __forceinline__ void tile_to_regs_contig(const float* __restrict__ src, long long ld, int row0, int nrows, float* stage,
+                                                    float (&r)[16], int tid) {
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + row < nrows) v = *reinterpret_cast<const float4*>(src + (long long)(row0 + row) * ld + c4);
+    *reinterpret_cast<float4*>(stage + row * BSTR + c4) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float4 v = *reinterpret_cast<const float4*>(stage + (wave * 16 + li) * BSTR + 16 * g + 4 * t);
+    r[4 * t] = v.x; r[4 * t + 1] = v.y; r[4 * t + 2] = v.z; r[4 * t + 3] = v.w;
+  }
+}
+// a float4 of a chunk row -> four fp16 his and four los (times s first) at the same position of the two planes
+__device__ __forceinline__ bool plane_write4(_Float16* hi_row, _Float16* lo_row, int c4, float4 v, float s) {
+  f16x4 h, l;
+  const bool bad = split4(v.x * s, v.y * s, v.z * s, v.w * s, h, l);
+  *reinterpret_cast<f16x4*>(hi_row + c4) = h;
+  *reinterpret_cast<f16x4*>(lo_row + c4) = l;
+  return bad;
+}
+// this lane's four k-step fragments of a plane row: elements 16 g .. 16 g + 15
+__device__ __forceinline__ void plane_frags(const _Float16* row, int g, f16x4 (&f)[4]) {
+  const f16x8 a = *reinterpret_cast<const f16x8*>(row + 16 * g), b = *reinterpret_cast<const f16x8*>(row + 16 * g + 8);
+  f[0] = (f16x4){a[0], a[1], a[2], a[3]};
+  f[1] = (f16x4){a[4], a[5], a[6], a[7]};
+  f[2] = (f16x4){b[0], b[1], b[2], b[3]};
+  f[3] = (f16x4){b[4], b[5], b[6], b[7]};
+}
 
-template <bool BF16>
+template <bool BF16, bool PAIR = false>
 __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                                const float* __restrict__ dout, const float* __restrict__ lse,
                                                                float* __restrict__ dqkv, float* __restrict__ delta, float* __restrict__ amax_out, int N, int H,
-                                                               int FH, float scale) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * BCH * BSTR + 64 * BSTR];
+                                                               int FH, float scale, const float* __restrict__ amax_part = nullptr, int n_part = 0,
+                                                               int* range_flag = nullptr) {
+  // PAIR: K fp32 [2][32][68] (the transposed product's operand) | four pair planes [2][32][72] fp16 (K hi, K lo, V hi, V lo), the
+  // prologue's stage on top of them
+  __shared__ __attribute__((aligned(16))) float smem[PAIR ? 2 * BCH * BSTR + 4 * BCH * PSTR : 4 * BCH * BSTR + 64 * BSTR];
+  __shared__ float sred[4];
+  float S = 1.0f;
+  if constexpr (PAIR) S = bwd_grad_scale(amax_part, n_part, sred);
+  bool bad = false;
   float* Ks = smem;                   // [2][32][68]
-  float* Vs = smem + 2 * BCH * BSTR;  // [2][32][68]
-  float* stage = smem + 4 * BCH * BSTR;
+  float* Vs = smem + 2 * BCH * BSTR;  // [2][32][68]  (PAIR: the planes start here)
+  float* stage = PAIR ? smem + 2 * BCH * BSTR : smem + 4 * BCH * BSTR;
+  _Float16* KH = reinterpret_cast<_Float16*>(smem + 2 * BCH * BSTR);
+  _Float16* KL = KH + 2 * BCH * PSTR;
+  _Float16* VH = KL + 2 * BCH * PSTR;
+  _Float16* VL = VH + 2 * BCH * PSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, qi = lane & 15, g = lane >> 4;
   int fh, tile64;
   if (!xcd_group_decode(blockIdx.x, (N + 63) / 64, FH, fh, tile64)) return;  // tiles of one (frame, head) share an XCD
@@ -66,9 +169,15 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
   const bool wave_active = q0 + wave * 16 < N;
 
   float qreg[16], doreg[16], oreg[16];
-  tile_to_regs(base, D3, q0, N, stage, qreg, tid);
-  tile_to_regs(dout + (long long)f * N * D + h * BHD, D, q0, N, stage, doreg, tid);
-  tile_to_regs(out + (long long)f * N * D + h * BHD, D, q0, N, stage, oreg, tid);
+  if constexpr (PAIR) {
+    tile_to_regs_contig(base, D3, q0, N, stage, qreg, tid);
+    tile_to_regs_contig(dout + (long long)f * N * D + h * BHD, D, q0, N, stage, doreg, tid);
+    tile_to_regs_contig(out + (long long)f * N * D + h * BHD, D, q0, N, stage, oreg, tid);
+  } else {
+    tile_to_regs(base, D3, q0, N, stage, qreg, tid);
+    tile_to_regs(dout + (long long)f * N * D + h * BHD, D, q0, N, stage, doreg, tid);
+    tile_to_regs(out + (long long)f * N * D + h * BHD, D, q0, N, stage, oreg, tid);
+  }
   float dl = 0.f;
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
@@ -78,11 +187,17 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
   dl += __shfl_xor(dl, 16, 64);
   dl += __shfl_xor(dl, 32, 64);
   s16x4 qpk[4], dopk[4];   // (BF16) the query-side operands, rounded once
+  f16x4 qh[4], ql[4], doh[4], dol[4];   // (PAIR) the same, split once; dO times S
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     qpk[t] = pack_bf16(qreg[4 * t], qreg[4 * t + 1], qreg[4 * t + 2], qreg[4 * t + 3]);
     dopk[t] = pack_bf16(doreg[4 * t], doreg[4 * t + 1], doreg[4 * t + 2], doreg[4 * t + 3]);
+    if constexpr (PAIR) {
+      bad |= split4(qreg[4 * t], qreg[4 * t + 1], qreg[4 * t + 2], qreg[4 * t + 3], qh[t], ql[t]);
+      bad |= split4(doreg[4 * t] * S, doreg[4 * t + 1] * S, doreg[4 * t + 2] * S, doreg[4 * t + 3] * S, doh[t], dol[t]);
+    }
   }
+  const float inv_s = 1.0f / S;   // (a power of two)
   const float lse_q = (q < N) ? lse[((long long)f * H + h) * N + q] : 0.f;
   if (q < N && g == 0) delta[((long long)f * H + h) * N + q] = dl;
 
@@ -104,7 +219,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
     for (int i = 0; i < 2; ++i) {
       const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
       *reinterpret_cast<float4*>(Ks + (buf * BCH + row) * BSTR + c4) = stk[i];
-      *reinterpret_cast<float4*>(Vs + (buf * BCH + row) * BSTR + c4) = stv[i];
+      if constexpr (PAIR) {
+        bad |= plane_write4(KH + (buf * BCH + row) * PSTR, KL + (buf * BCH + row) * PSTR, c4, stk[i], 1.0f);
+        bad |= plane_write4(VH + (buf * BCH + row) * PSTR, VL + (buf * BCH + row) * PSTR, c4, stv[i], 1.0f);
+      } else {
+        *reinterpret_cast<float4*>(Vs + (buf * BCH + row) * BSTR + c4) = stv[i];
+      }
     }
   };
 
@@ -113,6 +233,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
   for (int d = 0; d < 4; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nchunks = (N + BCH - 1) / BCH;
   gload(0);
+  if constexpr (PAIR) __syncthreads();   // (the planes lie on the stage the prologue was still reading)
   swrite(0);
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
@@ -124,7 +245,21 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
         const float* kp = Ks + (buf * BCH + 16 * t2 + qi) * BSTR + g;
         const float* vp = Vs + (buf * BCH + 16 * t2 + qi) * BSTR + g;
         f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (BF16) {
+        if constexpr (PAIR) {
+          f16x4 ah[4], al[4], bh[4], bl[4];
+          plane_frags(KH + (buf * BCH + 16 * t2 + qi) * PSTR, g, ah);
+          plane_frags(KL + (buf * BCH + 16 * t2 + qi) * PSTR, g, al);
+          plane_frags(VH + (buf * BCH + 16 * t2 + qi) * PSTR, g, bh);
+          plane_frags(VL + (buf * BCH + 16 * t2 + qi) * PSTR, g, bl);
+          f32x4 sa2 = (f32x4){0.f, 0.f, 0.f, 0.f}, dp2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            mma_pair(ah[t], al[t], qh[t], ql[t], sa, sa2);
+            mma_pair(bh[t], bl[t], doh[t], dol[t], dp, dp2);
+          }
+          sa = fold_pair(sa, sa2, 1.0f);
+          dp = fold_pair(dp, dp2, inv_s);
+        } else if constexpr (BF16) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             sa = mma_bf16(pack_bf16(kp[16 * t], kp[16 * t + 4], kp[16 * t + 8], kp[16 * t + 12]), qpk[t], sa);
@@ -174,18 +309,30 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
     }
   }
   if (amax_out) amax_publish(amax_out, am);   // (every lane of the wave is here: the max of what dqkv received, for the pair split of it)
+  if constexpr (PAIR) range_flag_raise(range_flag, bad);
 }
 
-template <bool BF16>
+template <bool BF16, bool PAIR = false>
 __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                float* __restrict__ dqkv, float* __restrict__ amax_out, int N, int H, int FH, float scale) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * BCH * BSTR + 64 * BSTR + 4 * BCH];
+                                                                float* __restrict__ dqkv, float* __restrict__ amax_out, int N, int H, int FH, float scale,
+                                                                const float* __restrict__ amax_part = nullptr, int n_part = 0, int* range_flag = nullptr) {
+  // PAIR: Q and dO fp32 [2][32][68] each (the transposed products' operands) | four pair planes [2][32][72] fp16 (Q hi, Q lo, dO hi,
+  // dO lo - dO times S), the prologue's stage on top of them | lse, delta
+  __shared__ __attribute__((aligned(16))) float smem[(PAIR ? 4 * BCH * BSTR + 4 * BCH * PSTR : 4 * BCH * BSTR + 64 * BSTR) + 4 * BCH];
+  __shared__ float sred[4];
+  float S = 1.0f;
+  if constexpr (PAIR) S = bwd_grad_scale(amax_part, n_part, sred);
+  bool bad = false;
   float* Qs = smem;                    // [2][32][68]
   float* Os = smem + 2 * BCH * BSTR;   // dO chunks [2][32][68]
   float* stage = smem + 4 * BCH * BSTR;
-  float* Ls = stage + 64 * BSTR;       // [2][32] lse, then [2][32] delta
+  float* Ls = stage + (PAIR ? 4 * BCH * PSTR : 64 * BSTR);       // [2][32] lse, then [2][32] delta
   float* Dl = Ls + 2 * BCH;
+  _Float16* QH = reinterpret_cast<_Float16*>(smem + 4 * BCH * BSTR);
+  _Float16* QL = QH + 2 * BCH * PSTR;
+  _Float16* OH = QL + 2 * BCH * PSTR;
+  _Float16* OL = OH + 2 * BCH * PSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ki = lane & 15, g = lane >> 4;
   int fh, tile64;
   if (!xcd_group_decode(blockIdx.x, (N + 63) / 64, FH, fh, tile64)) return;
@@ -196,16 +343,27 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
   const bool wave_active = k0 + wave * 16 < N;
 
   float kreg[16], vreg[16];
-  tile_to_regs(base + D, D3, k0, N, stage, kreg, tid);
-  tile_to_regs(base + 2 * D, D3, k0, N, stage, vreg, tid);
+  if constexpr (PAIR) {
+    tile_to_regs_contig(base + D, D3, k0, N, stage, kreg, tid);
+    tile_to_regs_contig(base + 2 * D, D3, k0, N, stage, vreg, tid);
+  } else {
+    tile_to_regs(base + D, D3, k0, N, stage, kreg, tid);
+    tile_to_regs(base + 2 * D, D3, k0, N, stage, vreg, tid);
+  }
 #pragma unroll
   for (int s = 0; s < 16; ++s) kreg[s] *= scale;
   s16x4 kpk[4], vpk[4];   // (BF16) the key-side operands, rounded once
+  f16x4 kh[4], kl[4], vh[4], vl[4];   // (PAIR) the same, split once
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     kpk[t] = pack_bf16(kreg[4 * t], kreg[4 * t + 1], kreg[4 * t + 2], kreg[4 * t + 3]);
     vpk[t] = pack_bf16(vreg[4 * t], vreg[4 * t + 1], vreg[4 * t + 2], vreg[4 * t + 3]);
+    if constexpr (PAIR) {
+      bad |= split4(kreg[4 * t], kreg[4 * t + 1], kreg[4 * t + 2], kreg[4 * t + 3], kh[t], kl[t]);
+      bad |= split4(vreg[4 * t], vreg[4 * t + 1], vreg[4 * t + 2], vreg[4 * t + 3], vh[t], vl[t]);
+    }
   }
+  const float inv_s = 1.0f / S;   // (a power of two)
 
   float4 stq[2], sto[2];
   float stl = 0.f, std_ = 0.f;
@@ -232,6 +390,10 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
       const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
       *reinterpret_cast<float4*>(Qs + (buf * BCH + row) * BSTR + c4) = stq[i];
       *reinterpret_cast<float4*>(Os + (buf * BCH + row) * BSTR + c4) = sto[i];
+      if constexpr (PAIR) {
+        bad |= plane_write4(QH + (buf * BCH + row) * PSTR, QL + (buf * BCH + row) * PSTR, c4, stq[i], 1.0f);
+        bad |= plane_write4(OH + (buf * BCH + row) * PSTR, OL + (buf * BCH + row) * PSTR, c4, sto[i], S);
+      }
     }
     if (tid < BCH) {
       Ls[buf * BCH + tid] = stl;
@@ -247,6 +409,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
   }
   const int nchunks = (N + BCH - 1) / BCH;
   gload(0);
+  if constexpr (PAIR) __syncthreads();   // (the planes lie on the stage the prologue was still reading)
   swrite(0);
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
@@ -258,7 +421,21 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
         const float* qp = Qs + (buf * BCH + 16 * t2 + ki) * BSTR + g;
         const float* op = Os + (buf * BCH + 16 * t2 + ki) * BSTR + g;
         f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (BF16) {
+        if constexpr (PAIR) {
+          f16x4 ah[4], al[4], bh[4], bl[4];
+          plane_frags(QH + (buf * BCH + 16 * t2 + ki) * PSTR, g, ah);
+          plane_frags(QL + (buf * BCH + 16 * t2 + ki) * PSTR, g, al);
+          plane_frags(OH + (buf * BCH + 16 * t2 + ki) * PSTR, g, bh);
+          plane_frags(OL + (buf * BCH + 16 * t2 + ki) * PSTR, g, bl);
+          f32x4 sa2 = (f32x4){0.f, 0.f, 0.f, 0.f}, dp2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            mma_pair(ah[t], al[t], kh[t], kl[t], sa, sa2);
+            mma_pair(bh[t], bl[t], vh[t], vl[t], dp, dp2);
+          }
+          sa = fold_pair(sa, sa2, 1.0f);
+          dp = fold_pair(dp, dp2, inv_s);
+        } else if constexpr (BF16) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             sa = mma_bf16(pack_bf16(qp[16 * t], qp[16 * t + 4], qp[16 * t + 8], qp[16 * t + 12]), kpk[t], sa);
@@ -320,6 +497,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
     }
   }
   if (amax_out) amax_publish(amax_out, am);
+  if constexpr (PAIR) range_flag_raise(range_flag, bad);
 }
 
 }  // namespace tt
@@ -351,6 +529,32 @@ static int attention_bwd_impl(const float* qkv, const float* out, const float* d
 extern "C" int tt_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N,
                                 int H, int hd, float scale, void* workspace, size_t workspace_bytes, float* amax_out, tt_stream_t stream) {
   return attention_bwd_impl<false>(qkv, out, dout, lse, dqkv, F, N, H, hd, scale, workspace, workspace_bytes, amax_out, stream);
+}
+
+extern "C" size_t tt_attention_bwd_pairs_workspace_bytes(int F, int N, int H, int hd) {
+  return tt_attention_bwd_workspace_bytes(F, N, H, hd) + kBwdAmaxParts * sizeof(float);
+}
+
+extern "C" int tt_attention_bwd_pairs(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N, int H, int hd,
+                                      float scale, void* workspace, size_t workspace_bytes, int* range_flag, float* amax_out, tt_stream_t stream) {
+  TT_REQUIRE(qkv && out && dout && lse && dqkv && workspace, "attention_bwd_pairs: null pointer");
+  TT_REQUIRE(hd == 64, "attention_bwd_pairs: head_dim must be 64 (got %d)", hd);
+  TT_REQUIRE(F > 0 && H > 0 && N > 0, "attention_bwd_pairs: bad shape");
+  TT_REQUIRE(workspace_bytes >= tt_attention_bwd_pairs_workspace_bytes(F, N, H, hd), "attention_bwd_pairs: workspace too small");
+  TT_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv) && aligned16(workspace), "attention_bwd_pairs: buffers must be 16-byte aligned");
+  hipStream_t s = as_stream(stream);
+  float* delta = static_cast<float*>(workspace);
+  float* part = delta + (size_t)F * H * N;
+  const long long n = (long long)F * N * H * hd;
+  const int n_part = (int)((n + 4095) / 4096 < kBwdAmaxParts ? (n + 4095) / 4096 : kBwdAmaxParts);
+  hipLaunchKernelGGL(attention_bwd_amax_kernel, dim3(n_part), dim3(256), 0, s, dout, n, part);
+  dim3 grid(xcd_group_grid(F * H, (N + 63) / 64));
+  hipLaunchKernelGGL((attention_bwd_dq_kernel<false, true>), grid, dim3(256), 0, s, qkv, out, dout, lse, dqkv, delta, amax_out, N, H, F * H, scale, part, n_part,
+                     range_flag);
+  hipLaunchKernelGGL((attention_bwd_dkv_kernel<false, true>), grid, dim3(256), 0, s, qkv, dout, lse, delta, dqkv, amax_out, N, H, F * H, scale, part, n_part,
+                     range_flag);
+  TT_CHECK_LAUNCH("attention_bwd_pairs");
+  return TT_OK;
 }
 
 extern "C" int tt_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N,

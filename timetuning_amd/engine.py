@@ -271,7 +271,7 @@ def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int,
         d_att, grads[blk.attn.proj.weight], grads[blk.attn.proj.bias] = _bwd_both_pairs(dx_mid, blk.attn.proj.weight, sv["attp"][r0:r1],
                                                                                         dy_amax=a_proj, **o(blk.attn.proj))
         dqkv = ops.attention_bwd(sv["qkv"].view(Fr, N, 3 * D)[f0:f1], sv["att"][f0:f1], d_att.view(f1 - f0, N, D), sv["lse"][f0:f1], num_heads,
-                                 amax_out=a_qkv)
+                                 amax_out=a_qkv, pair_products=ops.ATTN_BWD_PAIRS and D // num_heads == 64)
         d_h1, grads[blk.attn.qkv.weight], grads[blk.attn.qkv.bias] = _bwd_both_pairs(dqkv.view((f1 - f0) * N, 3 * D), blk.attn.qkv.weight,
                                                                                        sv["h1p"][r0:r1], dy_amax=a_qkv, **o(blk.attn.qkv))
         dx_in, grads[blk.norm1.weight], grads[blk.norm1.bias] = ops.layernorm_bwd(

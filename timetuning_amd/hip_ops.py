@@ -479,14 +479,25 @@ def attention_fwd(qkv, num_heads: int, save_lse=False, return_probs=False):
     return out, lse, probs
 
 
-def attention_bwd(qkv, out, dout, lse, num_heads: int, bf16_products: bool = False, amax_out=None):
+# the "f16x3" mode's attention backward with its row-wise products on fp16 pairs (tt_attention_bwd_pairs); "0": the fp32-MFMA kernels (A/B)
+ATTN_BWD_PAIRS = os.environ.get("TT_ATTN_BWD_PAIRS", "1") != "0"
+
+
+def attention_bwd(qkv, out, dout, lse, num_heads: int, bf16_products: bool = False, amax_out=None, pair_products: bool = False):
     """dqkv of the fused attention core from the forward's out / lse.  ``bf16_products``: the matrix products on bf16 MFMA
-    (tt_attention_bwd_bf16 - the "bf16" precision mode's backward; statistics, P and dS stay fp32)."""
+    (tt_attention_bwd_bf16 - the "bf16" precision mode's backward; statistics, P and dS stay fp32); ``pair_products``: S and dP on fp16
+    pairs (tt_attention_bwd_pairs - the "f16x3" mode's: fp32-class; the range flag is the pair entry points')."""
     lib = _lib.load()
     _chk(qkv, "qkv"); _chk(out, "out"); _chk(dout, "dout"); _chk(lse, "lse")
     F, N, D3 = qkv.shape
     hd = D3 // 3 // num_heads
     dqkv = torch.empty_like(qkv)
+    if pair_products and not bf16_products:
+        nb = lib.tt_attention_bwd_pairs_workspace_bytes(F, N, num_heads, hd)
+        ws = _ws(nb, qkv.device)
+        _lib.check(lib.tt_attention_bwd_pairs(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), F, N, num_heads, hd, float(hd ** -0.5), _p(ws), nb,
+                                              _p(range_flag(qkv.device)), _p(amax_out), _stream()), "tt_attention_bwd_pairs")
+        return dqkv
     nb = lib.tt_attention_bwd_workspace_bytes(F, N, num_heads, hd)
     ws = _ws(nb, qkv.device)
     if bf16_products:
