@@ -688,8 +688,9 @@ int tt_cpu_attention_bwd(const float* qkv, const float* out, const float* dout, 
 
 /* (tt_attention_bwd_pairs: fp32-class arithmetic on another MFMA - the twin is the fp32 backward; its range flag is never raised) */
 int tt_cpu_attention_bwd_pairs(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N, int H, int hd,
-                               float scale, void* workspace, size_t workspace_bytes, int* range_flag, float* amax_out, tt_stream_t stream) {
-  (void)range_flag;
+                               float scale, const float* dout_amax, void* workspace, size_t workspace_bytes, int* range_flag, float* amax_out,
+                               tt_stream_t stream) {
+  (void)range_flag; (void)dout_amax;
   return tt_cpu_attention_bwd(qkv, out, dout, lse, dqkv, F, N, H, hd, scale, workspace, workspace_bytes, amax_out, stream);
 }
 size_t tt_cpu_attention_bwd_pairs_workspace_bytes(int F, int N, int H, int hd) { (void)hd; return (size_t)F * H * N * sizeof(float) + 1024; }

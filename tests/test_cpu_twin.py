@@ -393,7 +393,7 @@ def _round2b_cases(side):
     assert am_at.max() == np.abs(dqkv).max()
     R["att_bwd"] = (qkv, dout, dqkv.copy(), am_at.max(keepdims=True))
     dqkv_p, am_p, flag_p = np.empty_like(qkv), np.zeros(16 * 64, np.float32), np.zeros(1, np.int32)
-    side.run("attention_bwd_pairs", qkv, out, dout, lse, dqkv_p, Fa, Na, H, 64, 0.125, wsa, nbw, flag_p, am_p, st, outs=(dqkv_p, am_p))
+    side.run("attention_bwd_pairs", qkv, out, dout, lse, dqkv_p, Fa, Na, H, 64, 0.125, None, wsa, nbw, flag_p, am_p, st, outs=(dqkv_p, am_p))
     R["att_bwd_pairs"] = (qkv, dout, dqkv_p.copy())
     dqkv_b = np.empty_like(qkv)
     side.run("attention_bwd_bf16", qkv, out, dout, lse, dqkv_b, Fa, Na, H, 64, 0.125, wsa, nbw, st, outs=(dqkv_b,))

@@ -105,7 +105,7 @@ SIGNATURES = {
     "tt_attention_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp, c_vp]),
     "tt_attention_bwd_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "tt_attention_bwd_bf16": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
-    "tt_attention_bwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "tt_attention_bwd_pairs": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp]),
     "tt_attention_bwd_pairs_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "tt_l2norm_fwd": (c_i, [c_vp, c_i, c_vp, c_vp, c_i, c_i, c_vp]),
     "tt_l2norm_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp]),

@@ -72,8 +72,9 @@ __global__ __launch_bounds__(256) void attention_bwd_amax_kernel(const float* __
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
+// (n_part < 0: the -n_part ways of a producer's amax slot, kAmaxStride floats apart - common.hpp amax_publish)
 __device__ __forceinline__ float bwd_grad_scale(const float* __restrict__ part, int n_part, float* sred) {   // every thread of the workgroup calls it
-  float m = (int)threadIdx.x < n_part ? part[threadIdx.x] : 0.f;
+  float m = n_part < 0 ? ((int)threadIdx.x < -n_part ? part[threadIdx.x * kAmaxStride] : 0.f) : ((int)threadIdx.x < n_part ? part[threadIdx.x] : 0.f);
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = m;
   __syncthreads();
@@ -536,7 +537,8 @@ extern "C" size_t tt_attention_bwd_pairs_workspace_bytes(int F, int N, int H, in
 }
 
 extern "C" int tt_attention_bwd_pairs(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N, int H, int hd,
-                                      float scale, void* workspace, size_t workspace_bytes, int* range_flag, float* amax_out, tt_stream_t stream) {
+                                      float scale, const float* dout_amax, void* workspace, size_t workspace_bytes, int* range_flag, float* amax_out,
+                                      tt_stream_t stream) {
   TT_REQUIRE(qkv && out && dout && lse && dqkv && workspace, "attention_bwd_pairs: null pointer");
   TT_REQUIRE(hd == 64, "attention_bwd_pairs: head_dim must be 64 (got %d)", hd);
   TT_REQUIRE(F > 0 && H > 0 && N > 0, "attention_bwd_pairs: bad shape");
@@ -544,10 +546,15 @@ extern "C" int tt_attention_bwd_pairs(const float* qkv, const float* out, const 
   TT_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv) && aligned16(workspace), "attention_bwd_pairs: buffers must be 16-byte aligned");
   hipStream_t s = as_stream(stream);
   float* delta = static_cast<float*>(workspace);
-  float* part = delta + (size_t)F * H * N;
+  const float* part = delta + (size_t)F * H * N;
   const long long n = (long long)F * N * H * hd;
-  const int n_part = (int)((n + 4095) / 4096 < kBwdAmaxParts ? (n + 4095) / 4096 : kBwdAmaxParts);
-  hipLaunchKernelGGL(attention_bwd_amax_kernel, dim3(n_part), dim3(256), 0, s, dout, n, part);
+  int n_part = (int)((n + 4095) / 4096 < kBwdAmaxParts ? (n + 4095) / 4096 : kBwdAmaxParts);
+  if (dout_amax) {   // the kernel that wrote dout left max |dout| in its amax slot: no pass
+    part = const_cast<float*>(dout_amax);
+    n_part = -kAmaxWays;
+  } else {
+    hipLaunchKernelGGL(attention_bwd_amax_kernel, dim3(n_part), dim3(256), 0, s, dout, n, const_cast<float*>(part));
+  }
   dim3 grid(xcd_group_grid(F * H, (N + 63) / 64));
   hipLaunchKernelGGL((attention_bwd_dq_kernel<false, true>), grid, dim3(256), 0, s, qkv, out, dout, lse, dqkv, delta, amax_out, N, H, F * H, scale, part, n_part,
                      range_flag);

@@ -268,10 +268,14 @@ def block_backward(dx_out: torch.Tensor, blk, num_heads: int, sv: dict, f0: int,
             d_h2, sv["x_mid"][r0:r1], blk.norm2.weight, sv["mean2"][r0:r1], sv["rstd2"][r0:r1], dx_accum=dx_out, amax_out=a_proj, **oln(blk.norm2))
         if after_mlp is not None:
             after_mlp()
+        att_pairs = ops.ATTN_BWD_PAIRS and D // num_heads == 64
+        # max |d_att| for the pair attention backward's scale: left by the proj data gradient when that runs on the general kernel anyway
+        # (the persistent kernel publishes a maximum from its gelu' epilogue only); otherwise the attention backward measures it itself
+        a_att = take() if (att_pairs and amax_pool is not None and not ops.linear_bwd_data_pairs_is_persistent(r1 - r0, D, D)) else None
         d_att, grads[blk.attn.proj.weight], grads[blk.attn.proj.bias] = _bwd_both_pairs(dx_mid, blk.attn.proj.weight, sv["attp"][r0:r1],
-                                                                                        dy_amax=a_proj, **o(blk.attn.proj))
+                                                                                        dy_amax=a_proj, dx_amax_out=a_att, **o(blk.attn.proj))
         dqkv = ops.attention_bwd(sv["qkv"].view(Fr, N, 3 * D)[f0:f1], sv["att"][f0:f1], d_att.view(f1 - f0, N, D), sv["lse"][f0:f1], num_heads,
-                                 amax_out=a_qkv, pair_products=ops.ATTN_BWD_PAIRS and D // num_heads == 64)
+                                 amax_out=a_qkv, pair_products=att_pairs, dout_amax=a_att)
         d_h1, grads[blk.attn.qkv.weight], grads[blk.attn.qkv.bias] = _bwd_both_pairs(dqkv.view((f1 - f0) * N, 3 * D), blk.attn.qkv.weight,
                                                                                        sv["h1p"][r0:r1], dy_amax=a_qkv, **o(blk.attn.qkv))
         dx_in, grads[blk.norm1.weight], grads[blk.norm1.bias] = ops.layernorm_bwd(

@@ -483,10 +483,11 @@ def attention_fwd(qkv, num_heads: int, save_lse=False, return_probs=False):
 ATTN_BWD_PAIRS = os.environ.get("TT_ATTN_BWD_PAIRS", "1") != "0"
 
 
-def attention_bwd(qkv, out, dout, lse, num_heads: int, bf16_products: bool = False, amax_out=None, pair_products: bool = False):
+def attention_bwd(qkv, out, dout, lse, num_heads: int, bf16_products: bool = False, amax_out=None, pair_products: bool = False, dout_amax=None):
     """dqkv of the fused attention core from the forward's out / lse.  ``bf16_products``: the matrix products on bf16 MFMA
     (tt_attention_bwd_bf16 - the "bf16" precision mode's backward; statistics, P and dS stay fp32); ``pair_products``: S and dP on fp16
-    pairs (tt_attention_bwd_pairs - the "f16x3" mode's: fp32-class; the range flag is the pair entry points')."""
+    pairs (tt_attention_bwd_pairs - the "f16x3" mode's: fp32-class; the range flag is the pair entry points'; ``dout_amax``: the amax
+    slot the kernel that wrote dout raised - without one the call measures max |dout| itself)."""
     lib = _lib.load()
     _chk(qkv, "qkv"); _chk(out, "out"); _chk(dout, "dout"); _chk(lse, "lse")
     F, N, D3 = qkv.shape
@@ -495,7 +496,7 @@ def attention_bwd(qkv, out, dout, lse, num_heads: int, bf16_products: bool = Fal
     if pair_products and not bf16_products:
         nb = lib.tt_attention_bwd_pairs_workspace_bytes(F, N, num_heads, hd)
         ws = _ws(nb, qkv.device)
-        _lib.check(lib.tt_attention_bwd_pairs(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), F, N, num_heads, hd, float(hd ** -0.5), _p(ws), nb,
+        _lib.check(lib.tt_attention_bwd_pairs(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), F, N, num_heads, hd, float(hd ** -0.5), _p(dout_amax), _p(ws), nb,
                                               _p(range_flag(qkv.device)), _p(amax_out), _stream()), "tt_attention_bwd_pairs")
         return dqkv
     nb = lib.tt_attention_bwd_workspace_bytes(F, N, num_heads, hd)
@@ -1285,6 +1286,11 @@ def wgrad_call(fn, keep=()):
     _WGRAD["keep"].append(keep)
     with torch.cuda.stream(side):
         return fn()
+
+
+def linear_bwd_data_pairs_is_persistent(M: int, N: int, K: int) -> bool:
+    """Would the data gradient dx [M, K] = dy [M, N] @ w of an nn.Linear(K -> N) run on the persistent pair kernel (plain fp32 epilogue)?"""
+    return _lib.load().tt_linear_fwd_pairs_route(M, K, N, 0, 0, 0, 1, 0, 0) == 8
 
 
 def linear_bwd_pairs(dy, wT_pairs, xT_pairs=None, gelu_pre=None, need_bias: bool = True, need_dx: bool = True, dw_out=None, db_out=None, x_pairs=None,
