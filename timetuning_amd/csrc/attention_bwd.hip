@@ -84,7 +84,10 @@ __device__ __forceinline__ float bwd_grad_scale(const float* __restrict__ part, 
   e = e > 100 ? 100 : (e < -100 ? -100 : e);
   return ldexpf(1.0f, e);
 }
-constexpr int PSTR = 72;   // fp16 elements per row of a pair plane (64 + 8: conflict-free ds_read_b128 of 16 rows)
+// fp16 elements per row of a pair plane: 128 bytes, no padding (with 16 bytes of it the dq kernel's 54 KB fit two workgroups per CU where
+// three of the fp32 form fit); the 16-byte chunks of row r sit at chunk ^ (r & 7) instead - rows r and r + 8 then meet in a bank (a
+// two-way conflict on eight reads per tile step) and every other pair of rows does not
+constexpr int PSTR = 64;
 
 constexpr int BHD = 64, BCH = 32, BSTR = 68;  // chunk rows, LDS row stride (16 g + i banks for the transposed reads)
 
@@ -125,16 +128,18 @@ __device__ __forceinline__ void tile_to_regs_contig(const float* __restrict__ sr
   }
 }
 // a float4 of a chunk row -> four fp16 his and four los (times s first) at the same position of the two planes
-__device__ __forceinline__ bool plane_write4(_Float16* hi_row, _Float16* lo_row, int c4, float4 v, float s) {
+__device__ __forceinline__ bool plane_write4(_Float16* hi_row, _Float16* lo_row, int row, int c4, float4 v, float s) {
   f16x4 h, l;
   const bool bad = split4(v.x * s, v.y * s, v.z * s, v.w * s, h, l);
-  *reinterpret_cast<f16x4*>(hi_row + c4) = h;
-  *reinterpret_cast<f16x4*>(lo_row + c4) = l;
+  const int at = (((c4 >> 3) ^ (row & 7)) << 3) + (c4 & 7);
+  *reinterpret_cast<f16x4*>(hi_row + at) = h;
+  *reinterpret_cast<f16x4*>(lo_row + at) = l;
   return bad;
 }
 // this lane's four k-step fragments of a plane row: elements 16 g .. 16 g + 15
-__device__ __forceinline__ void plane_frags(const _Float16* row, int g, f16x4 (&f)[4]) {
-  const f16x8 a = *reinterpret_cast<const f16x8*>(row + 16 * g), b = *reinterpret_cast<const f16x8*>(row + 16 * g + 8);
+__device__ __forceinline__ void plane_frags(const _Float16* row_ptr, int row, int g, f16x4 (&f)[4]) {
+  const f16x8 a = *reinterpret_cast<const f16x8*>(row_ptr + (((2 * g) ^ (row & 7)) << 3)),
+              b = *reinterpret_cast<const f16x8*>(row_ptr + (((2 * g + 1) ^ (row & 7)) << 3));
   f[0] = (f16x4){a[0], a[1], a[2], a[3]};
   f[1] = (f16x4){a[4], a[5], a[6], a[7]};
   f[2] = (f16x4){b[0], b[1], b[2], b[3]};
@@ -221,8 +226,8 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
       const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
       *reinterpret_cast<float4*>(Ks + (buf * BCH + row) * BSTR + c4) = stk[i];
       if constexpr (PAIR) {
-        bad |= plane_write4(KH + (buf * BCH + row) * PSTR, KL + (buf * BCH + row) * PSTR, c4, stk[i], 1.0f);
-        bad |= plane_write4(VH + (buf * BCH + row) * PSTR, VL + (buf * BCH + row) * PSTR, c4, stv[i], 1.0f);
+        bad |= plane_write4(KH + (buf * BCH + row) * PSTR, KL + (buf * BCH + row) * PSTR, row, c4, stk[i], 1.0f);
+        bad |= plane_write4(VH + (buf * BCH + row) * PSTR, VL + (buf * BCH + row) * PSTR, row, c4, stv[i], 1.0f);
       } else {
         *reinterpret_cast<float4*>(Vs + (buf * BCH + row) * BSTR + c4) = stv[i];
       }
@@ -248,10 +253,10 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
         f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (PAIR) {
           f16x4 ah[4], al[4], bh[4], bl[4];
-          plane_frags(KH + (buf * BCH + 16 * t2 + qi) * PSTR, g, ah);
-          plane_frags(KL + (buf * BCH + 16 * t2 + qi) * PSTR, g, al);
-          plane_frags(VH + (buf * BCH + 16 * t2 + qi) * PSTR, g, bh);
-          plane_frags(VL + (buf * BCH + 16 * t2 + qi) * PSTR, g, bl);
+          plane_frags(KH + (buf * BCH + 16 * t2 + qi) * PSTR, qi, g, ah);
+          plane_frags(KL + (buf * BCH + 16 * t2 + qi) * PSTR, qi, g, al);
+          plane_frags(VH + (buf * BCH + 16 * t2 + qi) * PSTR, qi, g, bh);
+          plane_frags(VL + (buf * BCH + 16 * t2 + qi) * PSTR, qi, g, bl);
           f32x4 sa2 = (f32x4){0.f, 0.f, 0.f, 0.f}, dp2 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
@@ -392,8 +397,8 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
       *reinterpret_cast<float4*>(Qs + (buf * BCH + row) * BSTR + c4) = stq[i];
       *reinterpret_cast<float4*>(Os + (buf * BCH + row) * BSTR + c4) = sto[i];
       if constexpr (PAIR) {
-        bad |= plane_write4(QH + (buf * BCH + row) * PSTR, QL + (buf * BCH + row) * PSTR, c4, stq[i], 1.0f);
-        bad |= plane_write4(OH + (buf * BCH + row) * PSTR, OL + (buf * BCH + row) * PSTR, c4, sto[i], S);
+        bad |= plane_write4(QH + (buf * BCH + row) * PSTR, QL + (buf * BCH + row) * PSTR, row, c4, stq[i], 1.0f);
+        bad |= plane_write4(OH + (buf * BCH + row) * PSTR, OL + (buf * BCH + row) * PSTR, row, c4, sto[i], S);
       }
     }
     if (tid < BCH) {
@@ -424,10 +429,10 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
         f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (PAIR) {
           f16x4 ah[4], al[4], bh[4], bl[4];
-          plane_frags(QH + (buf * BCH + 16 * t2 + ki) * PSTR, g, ah);
-          plane_frags(QL + (buf * BCH + 16 * t2 + ki) * PSTR, g, al);
-          plane_frags(OH + (buf * BCH + 16 * t2 + ki) * PSTR, g, bh);
-          plane_frags(OL + (buf * BCH + 16 * t2 + ki) * PSTR, g, bl);
+          plane_frags(QH + (buf * BCH + 16 * t2 + ki) * PSTR, ki, g, ah);
+          plane_frags(QL + (buf * BCH + 16 * t2 + ki) * PSTR, ki, g, al);
+          plane_frags(OH + (buf * BCH + 16 * t2 + ki) * PSTR, ki, g, bh);
+          plane_frags(OL + (buf * BCH + 16 * t2 + ki) * PSTR, ki, g, bl);
           f32x4 sa2 = (f32x4){0.f, 0.f, 0.f, 0.f}, dp2 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
