@@ -15,12 +15,12 @@
 // contraction index to (lane group, element) is valid as long as both operands use it), and a 16 x 16 accumulator tile is the B operand
 // of the wider MFMA as it stands (k = row = 4 g + e, four elements per lane).
 // PAIR = true (tt_attention_bwd_pairs, round 6: the "f16x3" mode's backward): the two ROW-WISE products of a tile - S = Q K^T and
-// dP = dO V^T, 32 of its 48 fp32 MFMAs - run on fp16 (hi, lo) pairs instead: three v_mfma_f32_16x16x16_f16 per group of four fp32 MFMAs
+// dP = dO V^T, 32 of its 48 fp32 MFMAs - run on fp16 (hi, lo) pairs instead: three v_mfma_f32_16x16x32_f16 per group of EIGHT fp32 MFMAs
 // (hi hi into one accumulator, hi lo + lo hi into a second one, folded with the exact 2^-11: gemm_pairs8.hip), 48 matrix-pipe cycles
-// instead of 128.  Their chunk operands are split ONCE on the way into LDS, into a hi and a lo plane of fp16 rows in natural order, and
+// instead of 256.  Their chunk operands are split ONCE on the way into LDS, into a hi and a lo plane of fp16 rows in natural order, and
 // the contraction index is assigned so that a lane's sixteen elements are CONTIGUOUS (lane group g owns head dimensions 16 g .. 16 g + 15,
-// element j of k-step t is dimension 16 g + 4 t + j - any assignment is valid as long as both operands use it): a fragment is two
-// ds_read_b128 per plane, no unzip, where the fp32 form issues sixteen ds_read_b32.  The TRANSPOSED products (dQ^T += K^T dS^T; dV^T +=
+// element j of k-step t is dimension 16 g + 8 t + j - any assignment is valid as long as both operands use it): a k-step's
+// fragment is ONE ds_read_b128 per plane, no unzip, where the fp32 form issues sixteen ds_read_b32.  The TRANSPOSED products (dQ^T += K^T dS^T; dV^T +=
 // dO^T P, dK^T += Q^T dS) stay on the fp32 MFMA with fp32 chunks: their operands are columns of the chunk, and P / dS are used as they
 // leave the accumulators.  dO is a GRADIENT (1e-3 ... 1e-8): it is multiplied by the power of two that brings max |dO| into [2^13, 2^14)
 // before the split (exact; the max is one small launch in front) and dP divided by it again.
@@ -48,11 +48,24 @@ __device__ __forceinline__ bool split4(float a, float b, float c, float d, f16x4
   lo = (f16x4){l0, l1, l2, l3};
   return pair_hi_bad(h0) || pair_hi_bad(h1) || pair_hi_bad(h2) || pair_hi_bad(h3);
 }
-// acc1 += ah bh, acc2 += ah bl + al bh (the lo halves carry 2^11: the product is acc1 + 2^-11 acc2)
-__device__ __forceinline__ void mma_pair(f16x4 ah, f16x4 al, f16x4 bh, f16x4 bl, f32x4& acc1, f32x4& acc2) {
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc1, 0, 0, 0);
-  acc2 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, acc2, 0, 0, 0);
-  acc2 = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, acc2, 0, 0, 0);
+// acc1 += ah bh, acc2 += ah bl + al bh (the lo halves carry 2^11: the product is acc1 + 2^-11 acc2) on v_mfma_f32_16x16x32_f16 (a lane
+// holds eight consecutive k)
+__device__ __forceinline__ void mma_pair8(f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl, f32x4& acc1, f32x4& acc2) {
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc1, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc2, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc2, 0, 0, 0);
+}
+__device__ __forceinline__ bool split8(const float* v, float s, f16x8& hi, f16x8& lo) {
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    _Float16 h, l;
+    split_pair(v[j] * s, h, l);
+    hi[j] = h;
+    lo[j] = l;
+    bad |= pair_hi_bad(h);
+  }
+  return bad;
 }
 __device__ __forceinline__ f32x4 fold_pair(f32x4 a1, f32x4 a2, float m) {   // (acc1 + 2^-11 acc2) m
   return (f32x4){fmaf(a2[0], kPairInvScale, a1[0]) * m, fmaf(a2[1], kPairInvScale, a1[1]) * m, fmaf(a2[2], kPairInvScale, a1[2]) * m,
@@ -136,14 +149,10 @@ __device__ __forceinline__ bool plane_write4(_Float16* hi_row, _Float16* lo_row,
   *reinterpret_cast<f16x4*>(lo_row + at) = l;
   return bad;
 }
-// this lane's four k-step fragments of a plane row: elements 16 g .. 16 g + 15
-__device__ __forceinline__ void plane_frags(const _Float16* row_ptr, int row, int g, f16x4 (&f)[4]) {
-  const f16x8 a = *reinterpret_cast<const f16x8*>(row_ptr + (((2 * g) ^ (row & 7)) << 3)),
-              b = *reinterpret_cast<const f16x8*>(row_ptr + (((2 * g + 1) ^ (row & 7)) << 3));
-  f[0] = (f16x4){a[0], a[1], a[2], a[3]};
-  f[1] = (f16x4){a[4], a[5], a[6], a[7]};
-  f[2] = (f16x4){b[0], b[1], b[2], b[3]};
-  f[3] = (f16x4){b[4], b[5], b[6], b[7]};
+// this lane's two k-step fragments of a plane row: elements 16 g .. 16 g + 7 and 16 g + 8 .. 16 g + 15 (one 16-byte chunk each)
+__device__ __forceinline__ void plane_frags(const _Float16* row_ptr, int row, int g, f16x8 (&f)[2]) {
+  f[0] = *reinterpret_cast<const f16x8*>(row_ptr + (((2 * g) ^ (row & 7)) << 3));
+  f[1] = *reinterpret_cast<const f16x8*>(row_ptr + (((2 * g + 1) ^ (row & 7)) << 3));
 }
 
 template <bool BF16, bool PAIR = false>
@@ -193,14 +202,17 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
   dl += __shfl_xor(dl, 16, 64);
   dl += __shfl_xor(dl, 32, 64);
   s16x4 qpk[4], dopk[4];   // (BF16) the query-side operands, rounded once
-  f16x4 qh[4], ql[4], doh[4], dol[4];   // (PAIR) the same, split once; dO times S
+  f16x8 qh[2], ql[2], doh[2], dol[2];   // (PAIR) the same, split once; dO times S
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     qpk[t] = pack_bf16(qreg[4 * t], qreg[4 * t + 1], qreg[4 * t + 2], qreg[4 * t + 3]);
     dopk[t] = pack_bf16(doreg[4 * t], doreg[4 * t + 1], doreg[4 * t + 2], doreg[4 * t + 3]);
-    if constexpr (PAIR) {
-      bad |= split4(qreg[4 * t], qreg[4 * t + 1], qreg[4 * t + 2], qreg[4 * t + 3], qh[t], ql[t]);
-      bad |= split4(doreg[4 * t] * S, doreg[4 * t + 1] * S, doreg[4 * t + 2] * S, doreg[4 * t + 3] * S, doh[t], dol[t]);
+  }
+  if constexpr (PAIR) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bad |= split8(qreg + 8 * t, 1.0f, qh[t], ql[t]);
+      bad |= split8(doreg + 8 * t, S, doh[t], dol[t]);
     }
   }
   const float inv_s = 1.0f / S;   // (a power of two)
@@ -252,16 +264,16 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
         const float* vp = Vs + (buf * BCH + 16 * t2 + qi) * BSTR + g;
         f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (PAIR) {
-          f16x4 ah[4], al[4], bh[4], bl[4];
+          f16x8 ah[2], al[2], bh[2], bl[2];
           plane_frags(KH + (buf * BCH + 16 * t2 + qi) * PSTR, qi, g, ah);
           plane_frags(KL + (buf * BCH + 16 * t2 + qi) * PSTR, qi, g, al);
           plane_frags(VH + (buf * BCH + 16 * t2 + qi) * PSTR, qi, g, bh);
           plane_frags(VL + (buf * BCH + 16 * t2 + qi) * PSTR, qi, g, bl);
           f32x4 sa2 = (f32x4){0.f, 0.f, 0.f, 0.f}, dp2 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            mma_pair(ah[t], al[t], qh[t], ql[t], sa, sa2);
-            mma_pair(bh[t], bl[t], doh[t], dol[t], dp, dp2);
+          for (int t = 0; t < 2; ++t) {
+            mma_pair8(ah[t], al[t], qh[t], ql[t], sa, sa2);
+            mma_pair8(bh[t], bl[t], doh[t], dol[t], dp, dp2);
           }
           sa = fold_pair(sa, sa2, 1.0f);
           dp = fold_pair(dp, dp2, inv_s);
@@ -359,14 +371,17 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
 #pragma unroll
   for (int s = 0; s < 16; ++s) kreg[s] *= scale;
   s16x4 kpk[4], vpk[4];   // (BF16) the key-side operands, rounded once
-  f16x4 kh[4], kl[4], vh[4], vl[4];   // (PAIR) the same, split once
+  f16x8 kh[2], kl[2], vh[2], vl[2];   // (PAIR) the same, split once
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     kpk[t] = pack_bf16(kreg[4 * t], kreg[4 * t + 1], kreg[4 * t + 2], kreg[4 * t + 3]);
     vpk[t] = pack_bf16(vreg[4 * t], vreg[4 * t + 1], vreg[4 * t + 2], vreg[4 * t + 3]);
-    if constexpr (PAIR) {
-      bad |= split4(kreg[4 * t], kreg[4 * t + 1], kreg[4 * t + 2], kreg[4 * t + 3], kh[t], kl[t]);
-      bad |= split4(vreg[4 * t], vreg[4 * t + 1], vreg[4 * t + 2], vreg[4 * t + 3], vh[t], vl[t]);
+  }
+  if constexpr (PAIR) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bad |= split8(kreg + 8 * t, 1.0f, kh[t], kl[t]);
+      bad |= split8(vreg + 8 * t, 1.0f, vh[t], vl[t]);
     }
   }
   const float inv_s = 1.0f / S;   // (a power of two)
@@ -428,16 +443,16 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
         const float* op = Os + (buf * BCH + 16 * t2 + ki) * BSTR + g;
         f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (PAIR) {
-          f16x4 ah[4], al[4], bh[4], bl[4];
+          f16x8 ah[2], al[2], bh[2], bl[2];
           plane_frags(QH + (buf * BCH + 16 * t2 + ki) * PSTR, ki, g, ah);
           plane_frags(QL + (buf * BCH + 16 * t2 + ki) * PSTR, ki, g, al);
           plane_frags(OH + (buf * BCH + 16 * t2 + ki) * PSTR, ki, g, bh);
           plane_frags(OL + (buf * BCH + 16 * t2 + ki) * PSTR, ki, g, bl);
           f32x4 sa2 = (f32x4){0.f, 0.f, 0.f, 0.f}, dp2 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            mma_pair(ah[t], al[t], kh[t], kl[t], sa, sa2);
-            mma_pair(bh[t], bl[t], vh[t], vl[t], dp, dp2);
+          for (int t = 0; t < 2; ++t) {
+            mma_pair8(ah[t], al[t], kh[t], kl[t], sa, sa2);
+            mma_pair8(bh[t], bl[t], vh[t], vl[t], dp, dp2);
           }
           sa = fold_pair(sa, sa2, 1.0f);
           dp = fold_pair(dp, dp2, inv_s);
