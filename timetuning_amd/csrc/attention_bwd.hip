@@ -21,8 +21,10 @@
 // the contraction index is assigned so that a lane's sixteen elements are CONTIGUOUS (lane group g owns head dimensions 16 g .. 16 g + 15,
 // element j of k-step t is dimension 16 g + 8 t + j - any assignment is valid as long as both operands use it): a k-step's
 // fragment is ONE ds_read_b128 per plane, no unzip, where the fp32 form issues sixteen ds_read_b32.  The TRANSPOSED products (dQ^T += K^T dS^T; dV^T +=
-// dO^T P, dK^T += Q^T dS) stay on the fp32 MFMA with fp32 chunks: their operands are columns of the chunk, and P / dS are used as they
-// leave the accumulators.  dO is a GRADIENT (1e-3 ... 1e-8): it is multiplied by the power of two that brings max |dO| into [2^13, 2^14)
+// dO^T P, dK^T += Q^T dS) contract over the chunk's ROWS: their chunk operands are written a second time, transposed ([dim][row], the
+// rows in the order the K = 32 fragment wants them - tplane_at), P and dS of BOTH 16-row tiles of a chunk are split where they leave the
+// accumulators and form the B fragment as they stand: one K = 32 group per 16 head dimensions and chunk.  dS = P (dP - delta) is split as
+// dS S 2^-10 (it is a sum over the 64 head dimensions of dO V: up to 64 max |V| times larger than dO).  dO is a GRADIENT (1e-3 ... 1e-8): it is multiplied by the power of two that brings max |dO| into [2^13, 2^14)
 // before the split (exact; the max is one small launch in front) and dP divided by it again.
 #include "common.hpp"
 
@@ -149,6 +151,29 @@ __device__ __forceinline__ bool plane_write4(_Float16* hi_row, _Float16* lo_row,
   *reinterpret_cast<f16x4*>(lo_row + at) = l;
   return bad;
 }
+// TRANSPOSED planes [dim 0 .. 63][32 chunk rows] (the operands of the products that contract over the chunk's rows: K^T, Q^T, dO^T): chunk
+// row r = 16 t2 + 4 g + e sits at position 8 g + 4 t2 + e of a plane row - the eight elements lane group g needs as its K = 32 fragment
+// (the B operand, P / dS, holds rows 4 g + e of tile t2 = 0 and of tile t2 = 1 in its accumulators) are ONE 16-byte chunk, chunk g, stored
+// at g ^ ((dim >> 2) & 3): conflict-free ds_read_b128 (16 lanes = 16 dims: four bank quarters x four chunk slots).
+constexpr int TSTR = 32;
+__device__ __forceinline__ int tplane_at(int dim, int r) {
+  const int gq = (r >> 2) & 3;
+  return dim * TSTR + ((gq ^ ((dim >> 2) & 3)) << 3) + ((r >> 4) << 2) + (r & 3);
+}
+__device__ __forceinline__ bool tplane_write4(_Float16* hi, _Float16* lo, int r, int c4, float4 v, float s) {
+  f16x4 h, l;
+  const bool bad = split4(v.x * s, v.y * s, v.z * s, v.w * s, h, l);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int at = tplane_at(c4 + i, r);
+    hi[at] = h[i];
+    lo[at] = l[i];
+  }
+  return bad;
+}
+__device__ __forceinline__ f16x8 tplane_frag(const _Float16* plane, int dim, int g) {
+  return *reinterpret_cast<const f16x8*>(plane + dim * TSTR + ((g ^ ((dim >> 2) & 3)) << 3));
+}
 // this lane's two k-step fragments of a plane row: elements 16 g .. 16 g + 7 and 16 g + 8 .. 16 g + 15 (one 16-byte chunk each)
 __device__ __forceinline__ void plane_frags(const _Float16* row_ptr, int row, int g, f16x8 (&f)[2]) {
   f[0] = *reinterpret_cast<const f16x8*>(row_ptr + (((2 * g) ^ (row & 7)) << 3));
@@ -161,20 +186,22 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
                                                                float* __restrict__ dqkv, float* __restrict__ delta, float* __restrict__ amax_out, int N, int H,
                                                                int FH, float scale, const float* __restrict__ amax_part = nullptr, int n_part = 0,
                                                                int* range_flag = nullptr) {
-  // PAIR: K fp32 [2][32][68] (the transposed product's operand) | four pair planes [2][32][72] fp16 (K hi, K lo, V hi, V lo), the
-  // prologue's stage on top of them
-  __shared__ __attribute__((aligned(16))) float smem[PAIR ? 2 * BCH * BSTR + 4 * BCH * PSTR : 4 * BCH * BSTR + 64 * BSTR];
+  // PAIR: four pair planes [2][32][64] fp16 (K hi, K lo, V hi, V lo; the prologue's stage on top of them) | two transposed planes
+  // [2][64][32] fp16 (K^T hi, lo)
+  __shared__ __attribute__((aligned(16))) float smem[PAIR ? 4 * BCH * PSTR + 2 * BHD * TSTR : 4 * BCH * BSTR + 64 * BSTR];
   __shared__ float sred[4];
   float S = 1.0f;
   if constexpr (PAIR) S = bwd_grad_scale(amax_part, n_part, sred);
   bool bad = false;
   float* Ks = smem;                   // [2][32][68]
   float* Vs = smem + 2 * BCH * BSTR;  // [2][32][68]  (PAIR: the planes start here)
-  float* stage = PAIR ? smem + 2 * BCH * BSTR : smem + 4 * BCH * BSTR;
-  _Float16* KH = reinterpret_cast<_Float16*>(smem + 2 * BCH * BSTR);
+  float* stage = PAIR ? smem : smem + 4 * BCH * BSTR;
+  _Float16* KH = reinterpret_cast<_Float16*>(smem);
   _Float16* KL = KH + 2 * BCH * PSTR;
   _Float16* VH = KL + 2 * BCH * PSTR;
   _Float16* VL = VH + 2 * BCH * PSTR;
+  _Float16* KTH = VL + 2 * BCH * PSTR;   // [2][64][32]
+  _Float16* KTL = KTH + 2 * BHD * TSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, qi = lane & 15, g = lane >> 4;
   int fh, tile64;
   if (!xcd_group_decode(blockIdx.x, (N + 63) / 64, FH, fh, tile64)) return;  // tiles of one (frame, head) share an XCD
@@ -216,6 +243,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
     }
   }
   const float inv_s = 1.0f / S;   // (a power of two)
+  const float S2 = S * 0.0009765625f;   // dS is split as dS S 2^-10: |dS| <= 64 max |dO| max |V|, i.e. dS S2 <= 1024 max |V| - inside fp16
   const float lse_q = (q < N) ? lse[((long long)f * H + h) * N + q] : 0.f;
   if (q < N && g == 0) delta[((long long)f * H + h) * N + q] = dl;
 
@@ -236,19 +264,23 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
-      *reinterpret_cast<float4*>(Ks + (buf * BCH + row) * BSTR + c4) = stk[i];
       if constexpr (PAIR) {
         bad |= plane_write4(KH + (buf * BCH + row) * PSTR, KL + (buf * BCH + row) * PSTR, row, c4, stk[i], 1.0f);
         bad |= plane_write4(VH + (buf * BCH + row) * PSTR, VL + (buf * BCH + row) * PSTR, row, c4, stv[i], 1.0f);
+        tplane_write4(KTH + buf * BHD * TSTR, KTL + buf * BHD * TSTR, row, c4, stk[i], 1.0f);
       } else {
+        *reinterpret_cast<float4*>(Ks + (buf * BCH + row) * BSTR + c4) = stk[i];
         *reinterpret_cast<float4*>(Vs + (buf * BCH + row) * BSTR + c4) = stv[i];
       }
     }
   };
 
-  f32x4 dq[4];
+  f32x4 dq[4], dq2[4];   // (dq2: PAIR's cross-term accumulators)
 #pragma unroll
-  for (int d = 0; d < 4; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int d = 0; d < 4; ++d) {
+    dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dq2[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   const int nchunks = (N + BCH - 1) / BCH;
   gload(0);
   if constexpr (PAIR) __syncthreads();   // (the planes lie on the stage the prologue was still reading)
@@ -258,6 +290,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
     const int buf = c & 1;
     if (c + 1 < nchunks) gload(c + 1);
     if (wave_active) {
+      float ds_all[8];   // (PAIR) dS of both 16-key tiles of the chunk: the K = 32 fragment of dQ^T += K^T dS^T
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         const float* kp = Ks + (buf * BCH + 16 * t2 + qi) * BSTR + g;
@@ -296,8 +329,11 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
           const int key = c * BCH + 16 * t2 + 4 * g + e;
           const float p = (key < N) ? fast_exp(sa[e] - lse_q) : 0.f;
           ds[e] = p * (dp[e] - dl);
+          ds_all[4 * t2 + e] = ds[e];
         }
-        if constexpr (BF16) {
+        if constexpr (PAIR) {
+          // (dQ^T += K^T dS^T behind the second tile, below)
+        } else if constexpr (BF16) {
           const float* kt = Ks + (buf * BCH + 16 * t2 + 4 * g) * BSTR + qi;
           const s16x4 dsp = pack_bf16(ds[0], ds[1], ds[2], ds[3]);
 #pragma unroll
@@ -312,11 +348,23 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
           }
         }
       }
+      if constexpr (PAIR) {   // dQ^T += K^T dS^T over the chunk's 32 keys: one K = 32 group per 16 head dimensions
+        f16x8 dsh, dsl;
+        bad |= split8(ds_all, S2, dsh, dsl);
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          mma_pair8(tplane_frag(KTH + buf * BHD * TSTR, 16 * d + qi, g), tplane_frag(KTL + buf * BHD * TSTR, 16 * d + qi, g), dsh, dsl, dq[d], dq2[d]);
+      }
     }
     if (c + 1 < nchunks) swrite(buf ^ 1);
     __syncthreads();
   }
   float am = 0.f;
+  if constexpr (PAIR) {
+    scale /= S2;   // (a power of two: exact)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dq[d] = fold_pair(dq[d], dq2[d], 1.0f);
+  }
   if (wave_active && q < N) {
     float* o = dqkv + ((long long)f * N + q) * D3 + h * BHD + 4 * g;
 #pragma unroll
@@ -331,26 +379,30 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
 }
 
 template <bool BF16, bool PAIR = false>
-__global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(256, PAIR ? 2 : 1) void attention_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 float* __restrict__ dqkv, float* __restrict__ amax_out, int N, int H, int FH, float scale,
                                                                 const float* __restrict__ amax_part = nullptr, int n_part = 0, int* range_flag = nullptr) {
-  // PAIR: Q and dO fp32 [2][32][68] each (the transposed products' operands) | four pair planes [2][32][72] fp16 (Q hi, Q lo, dO hi,
-  // dO lo - dO times S), the prologue's stage on top of them | lse, delta
-  __shared__ __attribute__((aligned(16))) float smem[(PAIR ? 4 * BCH * BSTR + 4 * BCH * PSTR : 4 * BCH * BSTR + 64 * BSTR) + 4 * BCH];
+  // PAIR: four pair planes [2][32][64] fp16 (Q hi, Q lo, dO hi, dO lo - dO times S; the prologue's stage on top of them) | four transposed
+  // planes [2][64][32] fp16 (Q^T hi, lo, dO^T hi, lo) | lse, delta
+  __shared__ __attribute__((aligned(16))) float smem[(PAIR ? 4 * BCH * PSTR + 4 * BHD * TSTR : 4 * BCH * BSTR + 64 * BSTR) + 4 * BCH];
   __shared__ float sred[4];
   float S = 1.0f;
   if constexpr (PAIR) S = bwd_grad_scale(amax_part, n_part, sred);
   bool bad = false;
   float* Qs = smem;                    // [2][32][68]
   float* Os = smem + 2 * BCH * BSTR;   // dO chunks [2][32][68]
-  float* stage = smem + 4 * BCH * BSTR;
-  float* Ls = stage + (PAIR ? 4 * BCH * PSTR : 64 * BSTR);       // [2][32] lse, then [2][32] delta
+  float* stage = PAIR ? smem : smem + 4 * BCH * BSTR;
+  float* Ls = PAIR ? smem + 4 * BCH * PSTR + 4 * BHD * TSTR : stage + 64 * BSTR;       // [2][32] lse, then [2][32] delta
   float* Dl = Ls + 2 * BCH;
-  _Float16* QH = reinterpret_cast<_Float16*>(smem + 4 * BCH * BSTR);
+  _Float16* QH = reinterpret_cast<_Float16*>(smem);
   _Float16* QL = QH + 2 * BCH * PSTR;
   _Float16* OH = QL + 2 * BCH * PSTR;
   _Float16* OL = OH + 2 * BCH * PSTR;
+  _Float16* QTH = OL + 2 * BCH * PSTR;   // [2][64][32] each
+  _Float16* QTL = QTH + 2 * BHD * TSTR;
+  _Float16* OTH = QTL + 2 * BHD * TSTR;
+  _Float16* OTL = OTH + 2 * BHD * TSTR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ki = lane & 15, g = lane >> 4;
   int fh, tile64;
   if (!xcd_group_decode(blockIdx.x, (N + 63) / 64, FH, fh, tile64)) return;
@@ -385,6 +437,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
     }
   }
   const float inv_s = 1.0f / S;   // (a power of two)
+  const float S2 = S * 0.0009765625f;   // (dS is split as dS S 2^-10: the dq kernel)
 
   float4 stq[2], sto[2];
   float stl = 0.f, std_ = 0.f;
@@ -409,11 +462,14 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int u = tid + 256 * i, row = u >> 4, c4 = (u & 15) * 4;
-      *reinterpret_cast<float4*>(Qs + (buf * BCH + row) * BSTR + c4) = stq[i];
-      *reinterpret_cast<float4*>(Os + (buf * BCH + row) * BSTR + c4) = sto[i];
       if constexpr (PAIR) {
         bad |= plane_write4(QH + (buf * BCH + row) * PSTR, QL + (buf * BCH + row) * PSTR, row, c4, stq[i], 1.0f);
         bad |= plane_write4(OH + (buf * BCH + row) * PSTR, OL + (buf * BCH + row) * PSTR, row, c4, sto[i], S);
+        tplane_write4(QTH + buf * BHD * TSTR, QTL + buf * BHD * TSTR, row, c4, stq[i], 1.0f);
+        tplane_write4(OTH + buf * BHD * TSTR, OTL + buf * BHD * TSTR, row, c4, sto[i], S);
+      } else {
+        *reinterpret_cast<float4*>(Qs + (buf * BCH + row) * BSTR + c4) = stq[i];
+        *reinterpret_cast<float4*>(Os + (buf * BCH + row) * BSTR + c4) = sto[i];
       }
     }
     if (tid < BCH) {
@@ -422,11 +478,13 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
     }
   };
 
-  f32x4 dk[4], dv[4];
+  f32x4 dk[4], dv[4], dk2[4], dv2[4];   // (dk2 / dv2: PAIR's cross-term accumulators)
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dk2[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dv2[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const int nchunks = (N + BCH - 1) / BCH;
   gload(0);
@@ -437,6 +495,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
     const int buf = c & 1;
     if (c + 1 < nchunks) gload(c + 1);
     if (wave_active) {
+      float p_all[8], ds_all[8];   // (PAIR) P and dS of both 16-query tiles of the chunk: the K = 32 fragments of dV^T += dO^T P, dK^T += Q^T dS
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         const float* qp = Qs + (buf * BCH + 16 * t2 + ki) * BSTR + g;
@@ -476,8 +535,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
           const bool ok = (c * BCH + ql < N) && (key < N);
           p[e] = ok ? fast_exp(sa[e] - Ls[buf * BCH + ql]) : 0.f;
           ds[e] = p[e] * (dp[e] - Dl[buf * BCH + ql]);
+          p_all[4 * t2 + e] = p[e];
+          ds_all[4 * t2 + e] = ds[e];
         }
-        if constexpr (BF16) {
+        if constexpr (PAIR) {
+          // (the transposed products behind the second tile, below)
+        } else if constexpr (BF16) {
           const float* ot = Os + (buf * BCH + 16 * t2 + 4 * g) * BSTR + ki;
           const float* qt = Qs + (buf * BCH + 16 * t2 + 4 * g) * BSTR + ki;
           const s16x4 pp = pack_bf16(p[0], p[1], p[2], p[3]), dsp = pack_bf16(ds[0], ds[1], ds[2], ds[3]);
@@ -499,18 +562,38 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
           }
         }
       }
+      if constexpr (PAIR) {   // dV^T += dO^T P, dK^T += Q^T dS over the chunk's 32 queries: one K = 32 group per 16 head dimensions each
+        f16x8 ph, pl, dsh, dsl;
+        split8(p_all, 1.0f, ph, pl);
+        bad |= split8(ds_all, S2, dsh, dsl);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          mma_pair8(tplane_frag(OTH + buf * BHD * TSTR, 16 * d + ki, g), tplane_frag(OTL + buf * BHD * TSTR, 16 * d + ki, g), ph, pl, dv[d], dv2[d]);
+          mma_pair8(tplane_frag(QTH + buf * BHD * TSTR, 16 * d + ki, g), tplane_frag(QTL + buf * BHD * TSTR, 16 * d + ki, g), dsh, dsl, dk[d], dk2[d]);
+        }
+      }
     }
     if (c + 1 < nchunks) swrite(buf ^ 1);
     __syncthreads();
   }
   float am = 0.f;
+  float vscale = 1.0f;
+  if constexpr (PAIR) {
+    scale /= S2;      // (powers of two: exact)
+    vscale = inv_s;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      dk[d] = fold_pair(dk[d], dk2[d], 1.0f);
+      dv[d] = fold_pair(dv[d], dv2[d], 1.0f);
+    }
+  }
   if (wave_active && key < N) {
     float* ok_ = dqkv + ((long long)f * N + key) * D3 + D + h * BHD + 4 * g;
     float* ov = ok_ + D;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const float4 wk_ = make_float4(dk[d][0] * scale, dk[d][1] * scale, dk[d][2] * scale, dk[d][3] * scale);
-      const float4 wv_ = make_float4(dv[d][0], dv[d][1], dv[d][2], dv[d][3]);
+      const float4 wv_ = make_float4(dv[d][0] * vscale, dv[d][1] * vscale, dv[d][2] * vscale, dv[d][3] * vscale);
       *reinterpret_cast<float4*>(ok_ + 16 * d) = wk_;
       *reinterpret_cast<float4*>(ov + 16 * d) = wv_;
       am = fmaxf(fmaxf(am, fmaxf(fabsf(wk_.x), fabsf(wk_.y))), fmaxf(fabsf(wk_.z), fabsf(wk_.w)));
