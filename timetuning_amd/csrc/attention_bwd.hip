@@ -181,7 +181,7 @@ __device__ __forceinline__ void plane_frags(const _Float16* row_ptr, int row, in
 }
 
 template <bool BF16, bool PAIR = false>
-__global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+__global__ __launch_bounds__(256, PAIR ? 3 : 1) void attention_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                                const float* __restrict__ dout, const float* __restrict__ lse,
                                                                float* __restrict__ dqkv, float* __restrict__ delta, float* __restrict__ amax_out, int N, int H,
                                                                int FH, float scale, const float* __restrict__ amax_part = nullptr, int n_part = 0,
