@@ -180,12 +180,13 @@ size_t tt_attention_bwd_workspace_bytes(int F, int N, int H, int hd);
  * Inputs and outputs stay fp32 in memory; same arguments and workspace as tt_attention_bwd. */
 int tt_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N, int H, int hd,
                           float scale, void* workspace, size_t workspace_bytes, tt_stream_t stream);
-/* The same backward with its two row-wise products per tile - S = Q K^T and dP = dO V^T, two thirds of the matrix work - on fp16-PAIR
- * operands (round 6: the "f16x3" mode's attention backward; fp32-class like tt_attention_bwd: three fp16 MFMAs per product term, two fp32
- * accumulators); the transposed products (dQ, dK, dV), lse, delta, P and dS stay fp32.  dout is a gradient: it is split as dout times
- * the power of two that brings max |dout| into [2^13, 2^14) - exact; dP is divided by it again.  dout_amax: the amax slot the kernel that
- * wrote dout raised (amax_out of tt_linear_bwd_data_pairs ...), or NULL - the call then measures the maximum itself (one small launch).
- * range_flag: the pair entry points' range flag (below) - raised when a hi half of q, k, v or the scaled dout is not finite.
+/* The same backward with its matrix products on fp16-PAIR operands (round 6: the "f16x3" mode's attention backward; fp32-class like
+ * tt_attention_bwd: q (scaled), k, v, dout, P and dS are split into (hi, lo) where they enter a product, three fp16 MFMAs per product term,
+ * two fp32 accumulators; lse, delta, P and dS themselves are fp32).  dout is a gradient: it is split as dout times the power of two S that
+ * brings max |dout| into [2^13, 2^14), dS = P (dP - delta) as dS S 2^-10 (exact; the outputs are divided by the scales again).  dout_amax:
+ * the amax slot the kernel that wrote dout raised (amax_out of tt_linear_bwd_data_pairs ...), or NULL - the call then measures the maximum
+ * itself (one small launch).  range_flag: the pair entry points' range flag (below) - raised when a hi half of q, k, v, the scaled dout
+ * or the scaled dS is not finite (dS: |v| beyond ~60).
  * Inputs and outputs fp32 in memory; workspace: tt_attention_bwd_pairs_workspace_bytes; amax_out as tt_attention_bwd. */
 int tt_attention_bwd_pairs(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N, int H, int hd,
                            float scale, const float* dout_amax, void* workspace, size_t workspace_bytes, int* range_flag, float* amax_out,
