@@ -36,7 +36,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 int device_cu_count();   // core.cpp: multiprocessors of the CURRENT device (looked up once per device id)
 // core.cpp: tuning knobs, read once from the environment (TT_<NAME>) and settable through tt_set_tuning_knob (A/B tools, tests)
-enum { KNOB_PLANES_VARIANT = 0, KNOB_P8_ORDER, KNOB_P8_NO_HALF, KNOB_P8_CLOCK_PRINT, KNOB_Q8_ORDER, KNOB_PAIRS_NO8, KNOB_PAIRS8_NO_KEPT, KNOB_Q8_KSPLIT, KNOB_ATTN_PAIRS_FLASH, KNOB_TN_WGS, KNOB_TN_XCD, KNOB_Q8_STREAM, KNOB_Q8_MIN_TILES, KNOB_SK_PERSIST, KNOB_ATTN_PAIRS_PERSIST, KNOB_PAIRS_NBUF, KNOB_Q4, KNOB_Q4_SMALL, KNOB_COUNT };
+enum { KNOB_PLANES_VARIANT = 0, KNOB_P8_ORDER, KNOB_P8_NO_HALF, KNOB_P8_CLOCK_PRINT, KNOB_Q8_ORDER, KNOB_PAIRS_NO8, KNOB_PAIRS8_NO_KEPT, KNOB_Q8_KSPLIT, KNOB_ATTN_PAIRS_FLASH, KNOB_TN_WGS, KNOB_TN_XCD, KNOB_Q8_STREAM, KNOB_Q8_MIN_TILES, KNOB_SK_PERSIST, KNOB_ATTN_PAIRS_PERSIST, KNOB_PAIRS_NBUF, KNOB_Q4, KNOB_Q4_SMALL, KNOB_SPLIT_ROWS, KNOB_COUNT };
 int tuning_knob(int which);
 
 // The K-split workspace of the persistent GEMMs (gemm_pairs8.hip / gemm_planes8.hip: fp32 partials of the left-over tiles + one arrival

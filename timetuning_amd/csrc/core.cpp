@@ -44,8 +44,8 @@ bool ksplit_ws_carve(void* ws, size_t bytes, KsplitWs* out) {
 // concurrent setenv from another Python thread, and a knob must not flip under a production run) - with an explicit setter for the A/B
 // tools and tests that compare settings inside one process.
 static const char* const kKnobNames[KNOB_COUNT] = {"TT_PLANES_VARIANT", "TT_P8_ORDER", "TT_P8_NO_HALF", "TT_P8_CLOCK_PRINT",
-                                                   "TT_Q8_ORDER",       "TT_PAIRS_NO8", "TT_PAIRS8_NO_KEPT", "TT_Q8_KSPLIT", "TT_ATTN_PAIRS_FLASH", "TT_TN_WGS", "TT_TN_XCD", "TT_Q8_STREAM", "TT_Q8_MIN_TILES", "TT_SK_PERSIST", "TT_ATTN_PAIRS_PERSIST", "TT_PAIRS_NBUF", "TT_Q4", "TT_Q4_SMALL"};
-static const int kKnobDefaults[KNOB_COUNT] = {0, 3, 0, 0, 3, 0, 0, 1, 0, 0, 1, 1, 128, 0, 1, 0, 0, 0};
+                                                   "TT_Q8_ORDER",       "TT_PAIRS_NO8", "TT_PAIRS8_NO_KEPT", "TT_Q8_KSPLIT", "TT_ATTN_PAIRS_FLASH", "TT_TN_WGS", "TT_TN_XCD", "TT_Q8_STREAM", "TT_Q8_MIN_TILES", "TT_SK_PERSIST", "TT_ATTN_PAIRS_PERSIST", "TT_PAIRS_NBUF", "TT_Q4", "TT_Q4_SMALL", "TT_SPLIT_ROWS"};
+static const int kKnobDefaults[KNOB_COUNT] = {0, 3, 0, 0, 3, 0, 0, 1, 0, 0, 1, 1, 128, 0, 1, 0, 0, 0, 1};
 static std::atomic<int> g_knobs[KNOB_COUNT];
 static std::once_flag g_knobs_once;
 static void knobs_init() {

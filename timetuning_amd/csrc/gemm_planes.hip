@@ -630,6 +630,75 @@ __global__ __launch_bounds__(256) void transpose_pairs_kernel(const void* __rest
   transpose_pairs_tile<SRC_PAIRS, ROW, SUM>(src_, dst_t, dst_row, R, C, Rpad, partial, blockIdx.x, blockIdx.y, amax_part, n_part, scale_out, range_flag);
 }
 
+// Row pairs (+ column partial sums) of an fp32 matrix WITHOUT a transposed output - what the transpose-free weight gradient leaves of a
+// dy's split (tt_split_pairs_dual_parts with dst_t == NULL: twelve launches of a C2 step, on the data-gradient chain).  The tile kernel
+// above moves such a matrix through LDS 4 bytes in and 2 + 2 bytes out per thread; this one streams it: a workgroup takes 64 rows x 128
+// columns, a lane 8 consecutive columns (two 16-byte loads, one 16-byte store of his and one of los: a pair group is 32 columns) of four
+// rows.  Same scale (the producer's amax slot or the max pass's partials), same partial layout [64-row block][C]; the column sums add
+// a thread's four rows, then the four row quarters of a wave (shuffles), then the four waves, in that fixed order.
+template <bool SUM>
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, _Float16* __restrict__ dst_row, int R, int C,
+                                                         float* __restrict__ partial, const float* __restrict__ amax_part, int n_part,
+                                                         float* __restrict__ scale_out, int* range_flag) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  __shared__ float sred[4];
+  __shared__ float red[4][128];
+  float S = 1.0f;
+  if (amax_part) {   // (uniform) as transpose_pairs_tile
+    float m = n_part < 0 ? ((int)threadIdx.x < -n_part ? amax_part[threadIdx.x * kAmaxStride] : 0.f)
+                         : ((int)threadIdx.x < n_part ? amax_part[threadIdx.x] : 0.f);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = m;
+    __syncthreads();
+    S = pair_scale_of(fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3])));
+    if (scale_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *scale_out = S;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.y * 128 + 8 * (lane & 15);
+  const int r0 = blockIdx.x * 64 + 16 * wave + (lane >> 4);
+  float cs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + 4 * i;
+    if (r < R) {
+      float v[8];
+      *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(src + (size_t)r * C + c);
+      *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(src + (size_t)r * C + c + 4);
+      f16x8 qh, ql;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        _Float16 hi, lo;
+        split_pair(v[j] * S, hi, lo);
+        bad |= pair_hi_bad(hi);
+        qh[j] = hi;
+        ql[j] = lo;
+        cs[j] += v[j];
+      }
+      _Float16* p = dst_row + (size_t)r * 2 * C + pair_index(c);
+      *reinterpret_cast<f16x8*>(p) = qh;
+      *reinterpret_cast<f16x8*>(p + 32) = ql;
+    }
+  }
+  range_flag_raise(range_flag, bad);
+  if constexpr (SUM) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cs[j] += __shfl_xor(cs[j], 16, 64);
+      cs[j] += __shfl_xor(cs[j], 32, 64);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[wave][8 * lane + j] = cs[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) partial[(size_t)blockIdx.x * C + blockIdx.y * 128 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
 // The same for a TABLE of fp32 matrices in one launch: the pair operands (row pairs for the forward / weight-gradient products, transposed
 // pairs for the data-gradient product) of every weight the optimizer just rewrote - two dozen small launches per step otherwise.
 struct PairTable {
@@ -1025,6 +1094,14 @@ static int split_pairs_dual_impl(const float* src, void* dst_t_pairs, void* dst_
     const long long n = (long long)R * C;
     n_part = (int)((n + 4095) / 4096 < kAmaxParts ? (n + 4095) / 4096 : kAmaxParts);
     hipLaunchKernelGGL(amax_partial_kernel, dim3(n_part), dim3(256), 0, s, src, n, amax_part);
+  }
+  if (dr && !dt && C % 128 == 0 && aligned16(src) && aligned16(dr) && tuning_knob(KNOB_SPLIT_ROWS) != 0) {   // row pairs only: the streaming kernel
+    const dim3 g2((Rpad + 63) / 64, C / 128);
+    if (colsum) hipLaunchKernelGGL((split_rows_kernel<true>), g2, block, 0, s, src, dr, R, C, partial, amax_part, n_part, scale_out, range_flag);
+    else hipLaunchKernelGGL((split_rows_kernel<false>), g2, block, 0, s, src, dr, R, C, nullptr, amax_part, n_part, scale_out, range_flag);
+    TT_CHECK_LAUNCH("split_rows");
+    if (colsum && !colsum_parts) return launch_colsum_fold(partial, colsum, (Rpad + 63) / 64, C, s);
+    return TT_OK;
   }
   if (dr && colsum) hipLaunchKernelGGL((transpose_pairs_kernel<false, true, true>), grid, block, 0, s, src, dt, dr, R, C, Rpad, partial, amax_part, n_part, scale_out, range_flag);
   else if (dr) hipLaunchKernelGGL((transpose_pairs_kernel<false, true, false>), grid, block, 0, s, src, dt, dr, R, C, Rpad, nullptr, amax_part, n_part, scale_out, range_flag);
