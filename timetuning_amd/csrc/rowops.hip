@@ -512,11 +512,28 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ p
   colsum_fold_block(partial, out, chunks, N, pstride, poff, blockIdx.x, red);
 }
 
-// dgamma and dbeta of the LayerNorm backward in ONE launch: partial[wg][2][D] -> dgamma[D] (y = 0), dbeta[D] (y = 1)
-__global__ __launch_bounds__(256) void colsum_stage2_pair(const float* __restrict__ partial, float* __restrict__ out0, float* __restrict__ out1,
-                                                          int chunks, int N) {
-  __shared__ float red[4][64];
-  colsum_fold_block(partial, blockIdx.y ? out1 : out0, chunks, N, 2 * N, blockIdx.y ? N : 0, blockIdx.x, red);
+// dgamma and dbeta of the LayerNorm backward in ONE launch: partial[wg][2][D] -> dgamma[D] (y = 0), dbeta[D] (y = 1).  SIXTEEN waves
+// split the chunks of a 64-column block (round 6: the launch sits on the data-gradient chain - 788 chunks at C2 were 197 dependent
+// batches of loads per thread with four waves, 12.5 us; fixed assignment and order: deterministic).
+__global__ __launch_bounds__(1024) void colsum_stage2_pair(const float* __restrict__ partial, float* __restrict__ out0, float* __restrict__ out1,
+                                                           int chunks, int N) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  const int poff = blockIdx.y ? N : 0;
+  float s = 0.f;
+  if (n < N) {
+#pragma unroll 8
+    for (int c = w; c < chunks; c += 16) s += partial[(long long)c * 2 * N + poff + n];
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) t += (red[i][lane] + red[i + 1][lane]) + (red[i + 2][lane] + red[i + 3][lane]);
+    (blockIdx.y ? out1 : out0)[n] = t;
+  }
 }
 
 // fold of partial[chunks][N] into out[N] for other translation units (the weight-gradient GEMM's fused bias gradient)
@@ -789,7 +806,7 @@ extern "C" int tt_layernorm_bwd(const float* dy, const float* x, const float* ga
     hipLaunchKernelGGL(layernorm_bwd_kernel, grid, block, 0, s, dy, x, gamma, mean, rstd, dx, partial, rows, D, rpw, add_to_dx, skip_group, amax_out);
   TT_CHECK_LAUNCH("layernorm_bwd");
   if (want) {
-    hipLaunchKernelGGL(colsum_stage2_pair, dim3((D + 63) / 64, 2), dim3(256), 0, as_stream(stream), partial, dgamma, dbeta, wgs, D);
+    hipLaunchKernelGGL(colsum_stage2_pair, dim3((D + 63) / 64, 2), dim3(1024), 0, as_stream(stream), partial, dgamma, dbeta, wgs, D);
     TT_CHECK_LAUNCH("layernorm_bwd.reduce");
   }
   return TT_OK;
