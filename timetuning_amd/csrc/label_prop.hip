@@ -237,7 +237,6 @@ __global__ __launch_bounds__(256) void label_prop_wave_kernel(LpArgs a) {
 
   float val[CPL];
   int src[CPL];   // context << 12 | source patch, -1 = no candidate
-  const float inv_temp = 1.0f / a.temp;
 #pragma unroll
   for (int j = 0; j < CTX; ++j) {
     const float* row = a.sims + (((long long)b * a.cs + j) * n + qi) * n;
@@ -248,7 +247,7 @@ __global__ __launch_bounds__(256) void label_prop_wave_kernel(LpArgs a) {
       src[i] = -1;
       if (j < a.c && lx < ww && y < wh) {
         const int sp = (y0 + y) * a.g + x0 + lx;
-        val[i] = fast_exp(row[sp] * inv_temp);   // (round 6: v_exp_f32 and a multiplication - the IEEE division + expf were a third of the kernel's instructions)
+        val[i] = expf(row[sp] / a.temp);
         src[i] = (j << 12) | sp;
       }
     }
