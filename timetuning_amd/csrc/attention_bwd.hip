@@ -14,18 +14,25 @@
 // SAME data movement: element j of a lane's bf16 operand for k-step t is the fp32 kernel's register s = 4 t + j (any assignment of the
 // contraction index to (lane group, element) is valid as long as both operands use it), and a 16 x 16 accumulator tile is the B operand
 // of the wider MFMA as it stands (k = row = 4 g + e, four elements per lane).
-// PAIR = true (tt_attention_bwd_pairs, round 6: the "f16x3" mode's backward): the two ROW-WISE products of a tile - S = Q K^T and
-// dP = dO V^T, 32 of its 48 fp32 MFMAs - run on fp16 (hi, lo) pairs instead: three v_mfma_f32_16x16x32_f16 per group of EIGHT fp32 MFMAs
-// (hi hi into one accumulator, hi lo + lo hi into a second one, folded with the exact 2^-11: gemm_pairs8.hip), 48 matrix-pipe cycles
-// instead of 256.  Their chunk operands are split ONCE on the way into LDS, into a hi and a lo plane of fp16 rows in natural order, and
-// the contraction index is assigned so that a lane's sixteen elements are CONTIGUOUS (lane group g owns head dimensions 16 g .. 16 g + 15,
-// element j of k-step t is dimension 16 g + 8 t + j - any assignment is valid as long as both operands use it): a k-step's
-// fragment is ONE ds_read_b128 per plane, no unzip, where the fp32 form issues sixteen ds_read_b32.  The TRANSPOSED products (dQ^T += K^T dS^T; dV^T +=
-// dO^T P, dK^T += Q^T dS) contract over the chunk's ROWS: their chunk operands are written a second time, transposed ([dim][row], the
-// rows in the order the K = 32 fragment wants them - tplane_at), P and dS of BOTH 16-row tiles of a chunk are split where they leave the
-// accumulators and form the B fragment as they stand: one K = 32 group per 16 head dimensions and chunk.  dS = P (dP - delta) is split as
-// dS S 2^-10 (it is a sum over the 64 head dimensions of dO V: up to 64 max |V| times larger than dO).  dO is a GRADIENT (1e-3 ... 1e-8): it is multiplied by the power of two that brings max |dO| into [2^13, 2^14)
-// before the split (exact; the max is one small launch in front) and dP divided by it again.
+// PAIR = true (tt_attention_bwd_pairs, round 6: the "f16x3" mode's backward): all five products of a tile on fp16 (hi, lo) pairs -
+// three v_mfma_f32_16x16x32_f16 per group of EIGHT fp32 MFMAs (hi hi into one accumulator, hi lo + lo hi into a second one, folded with
+// the exact 2^-11: gemm_pairs8.hip), 48 matrix-pipe cycles instead of 256.  What makes it pay is the operand layout (a first form that
+// kept the fp32 LDS layout and unzipped {hi, lo} words with v_perm_b32 was slower than the fp32 kernels):
+//   * the ROW-WISE products (S = Q K^T, dP = dO V^T) contract over the head dimension: their chunk operands are split ONCE on the way
+//     into LDS, into a hi and a lo plane of fp16 rows in natural order (128-byte rows, 16-byte chunks XOR-swizzled by row & 7), and the
+//     contraction index is assigned so that a lane's sixteen elements are CONTIGUOUS (lane group g owns head dimensions 16 g .. 16 g +
+//     15; element j of k-step t is dimension 16 g + 8 t + j - any assignment is valid as long as both operands use it): a k-step's
+//     fragment is ONE ds_read_b128 per plane where the fp32 form issues sixteen ds_read_b32;
+//   * the TRANSPOSED products (dQ^T += K^T dS^T; dV^T += dO^T P, dK^T += Q^T dS) contract over the chunk's ROWS: their chunk operands are
+//     written a second time, transposed ([dim][row], the rows in the order the K = 32 fragment wants them - tplane_at); P and dS of BOTH
+//     16-row tiles of a chunk are split where they leave the accumulators and are the B fragment as they stand: one K = 32 group per 16
+//     head dimensions and chunk;
+//   * dO is a GRADIENT (1e-3 ... 1e-8): it is multiplied by the power of two S that brings max |dO| into [2^13, 2^14) before the split
+//     (exact; the maximum comes from the amax slot of the kernel that wrote dO, or from one small launch in front) and dP is divided by
+//     it again; dS = P (dP - delta) is a sum over the 64 head dimensions of dO V, up to 64 max |V| times larger than dO: it is split as
+//     dS S 2^-10 (a dS beyond fp16's range - |V| of several tens - raises the caller's range flag);
+//   * registers are capped so that the dq kernel runs three and the dkv kernel two waves per SIMD (LDS: 49 KB / 66 KB per workgroup).
+// profiles/r06_attention_bwd_pairs.txt has every step of that with its measurement.
 #include "common.hpp"
 
 namespace tt {
