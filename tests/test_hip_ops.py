@@ -141,6 +141,30 @@ def test_attention_fwd_bwd(ops, Fr, N, H):
     ops.check_pair_range()
 
 
+def test_attention_bwd_pairs_scale_sources_and_range(ops):
+    """tt_attention_bwd_pairs: (1) max |dout| from a producer's amax slot gives the bits of the call's own max pass (the same power of
+    two); (2) values beyond what the fp16 halves can carry - here |v| beyond 65504 - raise the pair range flag (``PairRangeError``)
+    instead of passing silently."""
+    from timetuning_amd import hip_ops
+    Fr, N, H = 2, 197, 3
+    qkv = dev(rnd("apq", Fr, N, 3 * H * 64) * 1.2)
+    do = dev(rnd("apd", Fr, N, H * 64) * 3e-5)
+    out, lse, _ = ops.attention_fwd(qkv, H, save_lse=True)
+    own = ops.attention_bwd(qkv, out, do, lse, H, pair_products=True)
+    slot = torch.zeros(ops.AmaxPool.get(torch.device("cuda")).SLOT, device="cuda")
+    slot[::64][:16] = do.abs().max() * torch.tensor([1.0] + [0.3] * 15, device="cuda")   # the producer's 16 ways: their maximum is max |dout|
+    from_slot = ops.attention_bwd(qkv, out, do, lse, H, pair_products=True, dout_amax=slot)
+    assert torch.equal(own, from_slot)
+    ops.check_pair_range()
+    big = qkv.clone()
+    big[..., 2 * H * 64:] *= 1e5            # v
+    out_b, lse_b, _ = ops.attention_fwd(big, H, save_lse=True)
+    ops.attention_bwd(big, out_b, do, lse_b, H, pair_products=True)
+    with pytest.raises(hip_ops.PairRangeError):
+        ops.check_pair_range()
+    ops.check_pair_range()                  # (reset by the raise)
+
+
 def test_l2norm(ops):
     x, dxn = rnd("l2x", 700, 256) * 4, rnd("l2d", 700, 256)
     xd = x.double().requires_grad_(True)
