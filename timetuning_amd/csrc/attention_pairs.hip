@@ -32,6 +32,9 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define TT_AP_PACKED 1   // the probabilities' exp / split in packed fp32 instructions (0: the scalar form of round 5, for A/B builds)
 #endif
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
+#ifndef TT_APF_LOADERS
+#define TT_APF_LOADERS 1   // KV-tiled kernel: the waves without a query tile issue the stage's LDS-DMA (0: every wave its share; A/B builds)
+#endif
 // (p - hi) 2^11 for two probabilities as fma(hi, -2^11, p 2^11), hi read AS fp16 by v_fma_mix_f32 (op_sel_hi = 1: an fp16 source, op_sel:
 // which half of its register) - no conversion back to fp32.  Exact, like the subtraction and the scaling it replaces: p 2^11 and hi 2^11
 // are exact and their difference has at most 13 significant bits.  (The compiler does not select the instruction by itself here.)
@@ -382,14 +385,23 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_flash_kernel(const _F
   const _Float16* base = qkv + (long long)f * N * RS + hd * 128;
   const int nst = (N + SK - 1) / SK;
 
-  // K / V of stage st -> buffer st & 1: 32 + 32 pieces of 4 keys x 256 B, four of each per wave
+  // K / V of stage st -> buffer st & 1: 32 + 32 pieces of 4 keys x 256 B, four of each per wave - or (TT_APF_LOADERS, round 6) all of
+  // them by the waves that own no query tile in this block (785 tokens: 25 tiles on 4 x 8 waves leave one or two per block): an LDS-DMA
+  // instruction stalls its wave at the memory queue, and those waves have nothing else to do
   const int l_row = lane >> 4, l_slot = lane & 15;
+  const int t0 = blk * nqt / nb, t1 = (blk + 1) * nqt / nb;
+#if TT_APF_LOADERS
+  const int n_idle = 8 - (t1 - t0);
+#else
+  const int n_idle = 0;
+#endif
   auto issue_stage = [&](int st) {
     unsigned char* Kd = smem + (st & 1) * STAGE_B;
     unsigned char* Vd = Kd + SK * 256;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int piece = wave + 8 * i;
+    if (n_idle > 0 && wave < 8 - n_idle) return;   // (uniform per wave)
+    const int first = n_idle > 0 ? wave - (8 - n_idle) : wave, step = n_idle > 0 ? n_idle : 8;
+#pragma unroll 4
+    for (int piece = first; piece < 32; piece += step) {
       const int key = st * SK + piece * 4 + l_row;
       const int krow = key < N ? key : N - 1;
       const _Float16* src = base + (long long)krow * RS;
@@ -403,7 +415,6 @@ __global__ __launch_bounds__(512) void attention_fwd_pairs_flash_kernel(const _F
   };
   issue_stage(0);
 
-  const int t0 = blk * nqt / nb, t1 = (blk + 1) * nqt / nb;
   const int qt = t0 + wave;
   const bool active = qt < t1;
   const int query = qt * 32 + r;
