@@ -31,10 +31,16 @@ constexpr int SK_MAXWG = 256;  // buffer capacity
 // Workgroup-count policy, measured (tools/sk_sweep.py, K = 200): the best count grows with the problem - 64-96 at B = 6272
 // (one rank), 128 at 12544, 192 at 25088, 192-256 at 50176 (the 8-rank global problem, 337 -> 193 us) - because the
 // per-launch fold of the partial sums costs O(workgroups) while the sweep over E shrinks as 1/workgroups.
+// Round 6: the fold's loads go out in whole batches of SK_FOLD_BATCH = 64 partials (sk_iter_kernel), so the count is a multiple of 64: 128 at
+// B = 6272 (67.9 us per solve against 69.4 with 64), 128 at 12544, 192 - 256 beyond.
 static int sk_default_cap(int B) {
-  const int c = B / 98;
+  int c = (B / 98 + 63) / 64 * 64;   // ~ 98 rows per workgroup, up to a multiple of 64
+  if (B >= 4096 && c < 128) c = 128;
   return c < 64 ? 64 : (c > SK_MAXWG ? SK_MAXWG : c);
 }
+#ifndef SK_FOLD_BATCH
+#define SK_FOLD_BATCH 64
+#endif
 constexpr int SK_THREADS = 1024;
 constexpr int SK_WAVES = SK_THREADS / 64;
 
@@ -131,9 +137,27 @@ __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __rest
   for (int k = threadIdx.x; k < K; k += SK_THREADS) {
     float a = 1.0f;
     if (!uniform_a) {
+      // the fold of the previous launch's partials, in workgroup order (fixed: run-to-run bits) - the loads of 32 partials in flight at
+      // a time (round 6: with 16 the fold of 64 partials was four dependent batches of L2 latency at the head of every launch)
+      // (whole batches only: a zero-padded or clamped last batch measured 20 % slower than this - the workgroup counts are multiples of
+      // SK_FOLD_BATCH, sk_wgs; other counts finish in batches of 16 and singly)
       float u = 0.f;
-#pragma unroll 16
-      for (int w = 0; w < nwg_in; ++w) u += partial_in[(long long)w * K + k];
+      int w = 0;
+      for (; w + SK_FOLD_BATCH <= nwg_in; w += SK_FOLD_BATCH) {
+        float v[SK_FOLD_BATCH];
+#pragma unroll
+        for (int j = 0; j < SK_FOLD_BATCH; ++j) v[j] = partial_in[(long long)(w + j) * K + k];
+#pragma unroll
+        for (int j = 0; j < SK_FOLD_BATCH; ++j) u += v[j];
+      }
+      for (; w + 16 <= nwg_in; w += 16) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = partial_in[(long long)(w + j) * K + k];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) u += v[j];
+      }
+      for (; w < nwg_in; ++w) u += partial_in[(long long)w * K + k];
       a = (1.0f / (float)K) / u;
     }
     a_s[k] = a;
@@ -504,7 +528,15 @@ static int sinkhorn_impl(const float* scores, const float* Q, int q_rows_are_col
     cur ^= 1;
   }
   // last iteration's row step + column normalisation, written straight to q for the requested rows
-  const int owgs = sk_wgs(rows_out);
+  // (the output launch leaves no partials for anybody to fold: as many workgroups as give a wave its two rows - SK_LAST_WIDE, round 6)
+#ifndef SK_LAST_WIDE
+#define SK_LAST_WIDE 1
+#endif
+  int owgs = sk_wgs(rows_out);
+  if (SK_LAST_WIDE && rows_out <= 8192) {   // (6 272 rows: 71.1 -> 69.9 us per solve; 12 544: 83.2 -> 84.9; 50 176: no change)
+    owgs = (rows_out + 2 * SK_WAVES - 1) / (2 * SK_WAVES);
+    owgs = owgs > SK_MAXWG ? SK_MAXWG : (owgs < 1 ? 1 : owgs);   // (one workgroup per CU at most: 1 024 of them measured slower at 50 176 rows)
+  }
   const int orpw = (rows_out + owgs - 1) / owgs;
   hipLaunchKernelGGL((sk_iter_kernel<true>), dim3(owgs), dim3(SK_THREADS), 0, s, E, part[cur], (float*)nullptr, q_out, B_total, K, wgs,
                      orpw, row0, rows_out, iters == 0 ? 1 : 0, B_total);
