@@ -522,9 +522,16 @@ __global__ __launch_bounds__(1024) void colsum_stage2_pair(const float* __restri
   const int n = blockIdx.x * 64 + lane;
   const int poff = blockIdx.y ? N : 0;
   float s = 0.f;
-  if (n < N) {
-#pragma unroll 8
-    for (int c = w; c < chunks; c += 16) s += partial[(long long)c * 2 * N + poff + n];
+  if (n < N) {   // (whole batches of 16 loads in flight, then singly: same order)
+    int c = w;
+    for (; c + 16 * 15 < chunks; c += 16 * 16) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = partial[(long long)(c + 16 * j) * 2 * N + poff + n];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s += v[j];
+    }
+    for (; c < chunks; c += 16) s += partial[(long long)c * 2 * N + poff + n];
   }
   red[w][lane] = s;
   __syncthreads();
