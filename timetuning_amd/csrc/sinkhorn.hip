@@ -554,8 +554,23 @@ static int sinkhorn_impl(const float* scores, const float* Q, int q_rows_are_col
 __global__ __launch_bounds__(256) void sk_fold_kernel(const float* __restrict__ partial, float* __restrict__ u, int nwg, int K) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= K) return;
-  float s = 0.f;
-  for (int w = 0; w < nwg; ++w) s += partial[(long long)w * K + k];   // fixed order
+  float s = 0.f;   // fixed order; the loads in whole batches of SK_FOLD_BATCH (sk_iter_kernel), then of 16, then singly
+  int w = 0;
+  for (; w + SK_FOLD_BATCH <= nwg; w += SK_FOLD_BATCH) {
+    float v[SK_FOLD_BATCH];
+#pragma unroll
+    for (int j = 0; j < SK_FOLD_BATCH; ++j) v[j] = partial[(long long)(w + j) * K + k];
+#pragma unroll
+    for (int j = 0; j < SK_FOLD_BATCH; ++j) s += v[j];
+  }
+  for (; w + 16 <= nwg; w += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = partial[(long long)(w + j) * K + k];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += v[j];
+  }
+  for (; w < nwg; ++w) s += partial[(long long)w * K + k];
   u[k] = s;
 }
 
