@@ -44,6 +44,13 @@ static int sk_default_cap(int B) {
 constexpr int SK_THREADS = 1024;
 constexpr int SK_WAVES = SK_THREADS / 64;
 
+// launches one of the two instantiations (columns per lane 4 | 8) of a kernel templated on KPL
+#define SK_LAUNCH_KPL(KERNEL4, KERNEL8, grid, ...)                                                              \
+  do {                                                                                                           \
+    if (K <= 256) hipLaunchKernelGGL(KERNEL4, grid, dim3(SK_THREADS), 0, s, __VA_ARGS__);                        \
+    else hipLaunchKernelGGL(KERNEL8, grid, dim3(SK_THREADS), 0, s, __VA_ARGS__);                                 \
+  } while (0)
+
 static int sk_wgs(int B) {
   int w = (B + 2 * SK_WAVES - 1) / (2 * SK_WAVES);  // >= 2 rows per wave
   static const int cap_env = [] { const char* e = getenv("TT_SK_WGS"); return e ? atoi(e) : 0; }();  // tuning aid
@@ -51,11 +58,14 @@ static int sk_wgs(int B) {
   return w > cap ? cap : (w < 1 ? 1 : w);
 }
 
-// block-wide fold of per-wave register partials acc[SK_KPL] (lane owns k = lane + 64 i) into out[k]
-__device__ __forceinline__ void fold_waves(const float (&acc)[SK_KPL], float (*red)[64 * SK_KPL], float* __restrict__ out, int K) {
+// KPL = columns per lane (lane owns k = lane + 64 i, i < KPL): 4 for K <= 256 - the training shapes (K = 200): half the predicated loads
+// and registers of the general 8 (round 6) - 8 up to K = 512.
+// block-wide fold of per-wave register partials acc[KPL] (lane owns k = lane + 64 i) into out[k]
+template <int KPL>
+__device__ __forceinline__ void fold_waves(const float (&acc)[KPL], float (*red)[64 * KPL], float* __restrict__ out, int K) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < SK_KPL; ++i)
+  for (int i = 0; i < KPL; ++i)
     if (lane + 64 * i < K) red[wave][lane + 64 * i] = acc[i];
   __syncthreads();
   for (int k = threadIdx.x; k < K; k += SK_THREADS) {
@@ -67,17 +77,18 @@ __device__ __forceinline__ void fold_waves(const float (&acc)[SK_KPL], float (*r
 }
 
 // E = exp(scores/eps); partial[wg][k] = sum over this workgroup's rows of E[b][k]
+template <int KPL>
 __global__ __launch_bounds__(SK_THREADS) void sk_init_kernel(const float* __restrict__ scores, float* __restrict__ E,
                                                              float* __restrict__ partial, int B, int K, float eps, int rows_per_wg) {
-  __shared__ float red[SK_WAVES][64 * SK_KPL];
+  __shared__ float red[SK_WAVES][64 * KPL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_wg, r1 = min(B, r0 + rows_per_wg);
-  float acc[SK_KPL];
+  float acc[KPL];
 #pragma unroll
-  for (int i = 0; i < SK_KPL; ++i) acc[i] = 0.f;
+  for (int i = 0; i < KPL; ++i) acc[i] = 0.f;
   for (int b = r0 + wave; b < r1; b += SK_WAVES) {
 #pragma unroll
-    for (int i = 0; i < SK_KPL; ++i) {
+    for (int i = 0; i < KPL; ++i) {
       const int k = lane + 64 * i;
       if (k < K) {
         const float e = expf(scores[(long long)b * K + k] / eps);
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_init_kernel(const float* __rest
       }
     }
   }
-  fold_waves(acc, red, partial + (long long)blockIdx.x * K, K);
+  fold_waves<KPL>(acc, red, partial + (long long)blockIdx.x * K, K);
 }
 
 // The same from the positive matrix itself, Q[k][b] = exp(scores[b][k] / eps) as my_utils.sinkhorn receives it ([K][B], :246):
@@ -102,22 +113,23 @@ __global__ __launch_bounds__(256) void sk_transpose_kernel(const float* __restri
     if (b0 + r < B && k0 + c < K) E[(long long)(b0 + r) * K + k0 + c] = t[c][r];
 }
 
+template <int KPL>
 __global__ __launch_bounds__(SK_THREADS) void sk_init_from_e_kernel(const float* __restrict__ E, float* __restrict__ partial, int B, int K,
                                                                     int rows_per_wg) {
-  __shared__ float red[SK_WAVES][64 * SK_KPL];
+  __shared__ float red[SK_WAVES][64 * KPL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_wg, r1 = min(B, r0 + rows_per_wg);
-  float acc[SK_KPL];
+  float acc[KPL];
 #pragma unroll
-  for (int i = 0; i < SK_KPL; ++i) acc[i] = 0.f;
+  for (int i = 0; i < KPL; ++i) acc[i] = 0.f;
   for (int b = r0 + wave; b < r1; b += SK_WAVES) {
 #pragma unroll
-    for (int i = 0; i < SK_KPL; ++i) {
+    for (int i = 0; i < KPL; ++i) {
       const int k = lane + 64 * i;
       if (k < K) acc[i] += E[(long long)b * K + k];
     }
   }
-  fold_waves(acc, red, partial + (long long)blockIdx.x * K, K);
+  fold_waves<KPL>(acc, red, partial + (long long)blockIdx.x * K, K);
 }
 
 // (Round 6 tried to cut this kernel's two latency chains - the fold of the nwg_in x K partials spread over all 1024 threads in four slices
@@ -126,12 +138,12 @@ __global__ __launch_bounds__(SK_THREADS) void sk_init_from_e_kernel(const float*
 // iteration is ~ 6.7 us of which the fold of 64 partials is ~ 0.8; the rest is the launch of 64 - 96 sixteen-wave workgroups, two passes
 // over L2-resident rows and the drain.)
 // One Sinkhorn iteration (row step + column step) or, with LAST, the final column normalisation + output.
-template <bool LAST>
+template <bool LAST, int KPL>
 __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __restrict__ E, const float* __restrict__ partial_in,
                                                              float* __restrict__ partial_out, float* __restrict__ q_out, int B, int K,
                                                              int nwg_in, int rows_per_wg, int row0, int rows_out, int uniform_a, int b_norm) {
-  __shared__ float a_s[64 * SK_KPL];
-  __shared__ float red[SK_WAVES][64 * SK_KPL];
+  __shared__ float a_s[64 * KPL];
+  __shared__ float red[SK_WAVES][64 * KPL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // row step: a_k = (1/K) / u_k, u_k folded from the previous launch's partial sums in fixed order
   for (int k = threadIdx.x; k < K; k += SK_THREADS) {
@@ -163,9 +175,9 @@ __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __rest
     a_s[k] = a;
   }
   __syncthreads();
-  float a[SK_KPL], acc[SK_KPL];
+  float a[KPL], acc[KPL];
 #pragma unroll
-  for (int i = 0; i < SK_KPL; ++i) {
+  for (int i = 0; i < KPL; ++i) {
     const int k = lane + 64 * i;
     a[i] = (k < K) ? a_s[k] : 0.f;
     acc[i] = 0.f;
@@ -183,10 +195,10 @@ __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __rest
   for (int b = r0 + wave; b < r1; b += 2 * SK_WAVES) {
     const int b2 = b + SK_WAVES;
     const bool has2 = b2 < r1;
-    float e[SK_KPL], f[SK_KPL];
+    float e[KPL], f[KPL];
     float t = 0.f, t2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < SK_KPL; ++i) {
+    for (int i = 0; i < KPL; ++i) {
       const int k = lane + 64 * i;
       e[i] = (k < K) ? E[(long long)b * K + k] : 0.f;
       f[i] = (k < K && has2) ? E[(long long)b2 * K + k] : 0.f;
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __rest
     t2 = wave_sum(t2);
     if (LAST) {
 #pragma unroll
-      for (int i = 0; i < SK_KPL; ++i) {
+      for (int i = 0; i < KPL; ++i) {
         const int k = lane + 64 * i;
         if (k < K) {
           q_out[(long long)(b - row0) * K + k] = a[i] * e[i] / t;
@@ -208,11 +220,11 @@ __global__ __launch_bounds__(SK_THREADS) void sk_iter_kernel(const float* __rest
       const float bb = c / t;                 // column step
       const float bb2 = has2 ? c / t2 : 0.f;
 #pragma unroll
-      for (int i = 0; i < SK_KPL; ++i) acc[i] += e[i] * bb + f[i] * bb2;
+      for (int i = 0; i < KPL; ++i) acc[i] += e[i] * bb + f[i] * bb2;
     }
   }
   if (LAST) return;
-  fold_waves(acc, red, partial_out + (long long)blockIdx.x * K, K);
+  fold_waves<KPL>(acc, red, partial_out + (long long)blockIdx.x * K, K);
 }
 
 // ---- the whole solve in ONE launch ----------------------------------------------------------------------------------------------
@@ -517,14 +529,14 @@ static int sinkhorn_impl(const float* scores, const float* Q, int q_rows_are_col
   const int rpw = (B_total + wgs - 1) / wgs;
   if (Q) {
     if (!q_rows_are_columns) hipLaunchKernelGGL(sk_transpose_kernel, dim3((B_total + 63) / 64, (K + 63) / 64), dim3(256), 0, s, Q, Ews, B_total, K);
-    hipLaunchKernelGGL(sk_init_from_e_kernel, dim3(wgs), dim3(SK_THREADS), 0, s, E, part[0], B_total, K, rpw);
+    SK_LAUNCH_KPL(sk_init_from_e_kernel<4>, sk_init_from_e_kernel<8>, dim3(wgs), E, part[0], B_total, K, rpw);
   } else {
-    hipLaunchKernelGGL(sk_init_kernel, dim3(wgs), dim3(SK_THREADS), 0, s, scores, Ews, part[0], B_total, K, eps, rpw);
+    SK_LAUNCH_KPL(sk_init_kernel<4>, sk_init_kernel<8>, dim3(wgs), scores, Ews, part[0], B_total, K, eps, rpw);
   }
   int cur = 0;
   for (int it = 0; it + 1 < iters; ++it) {  // iterations 1 .. iters-1 (each prepares the next row step)
-    hipLaunchKernelGGL((sk_iter_kernel<false>), dim3(wgs), dim3(SK_THREADS), 0, s, E, part[cur], part[cur ^ 1], (float*)nullptr,
-                       B_total, K, wgs, rpw, 0, 0, 0, B_total);
+    SK_LAUNCH_KPL((sk_iter_kernel<false, 4>), (sk_iter_kernel<false, 8>), dim3(wgs), E, part[cur], part[cur ^ 1], (float*)nullptr, B_total, K, wgs,
+                  rpw, 0, 0, 0, B_total);
     cur ^= 1;
   }
   // last iteration's row step + column normalisation, written straight to q for the requested rows
@@ -538,8 +550,8 @@ static int sinkhorn_impl(const float* scores, const float* Q, int q_rows_are_col
     owgs = owgs > SK_MAXWG ? SK_MAXWG : (owgs < 1 ? 1 : owgs);   // (one workgroup per CU at most: 1 024 of them measured slower at 50 176 rows)
   }
   const int orpw = (rows_out + owgs - 1) / owgs;
-  hipLaunchKernelGGL((sk_iter_kernel<true>), dim3(owgs), dim3(SK_THREADS), 0, s, E, part[cur], (float*)nullptr, q_out, B_total, K, wgs,
-                     orpw, row0, rows_out, iters == 0 ? 1 : 0, B_total);
+  SK_LAUNCH_KPL((sk_iter_kernel<true, 4>), (sk_iter_kernel<true, 8>), dim3(owgs), E, part[cur], (float*)nullptr, q_out, B_total, K, wgs, orpw,
+                row0, rows_out, iters == 0 ? 1 : 0, B_total);
   TT_CHECK_LAUNCH("sinkhorn");
   return TT_OK;
 }
@@ -591,7 +603,7 @@ extern "C" int tt_sinkhorn_local_begin(const float* scores, float* u_out, int B_
   float* E = static_cast<float*>(workspace);
   float* part = E + (size_t)B_loc * K;
   const int wgs = sk_wgs(B_loc), rpw = (B_loc + wgs - 1) / wgs;
-  hipLaunchKernelGGL(sk_init_kernel, dim3(wgs), dim3(SK_THREADS), 0, s, scores, E, part, B_loc, K, eps, rpw);
+  SK_LAUNCH_KPL(sk_init_kernel<4>, sk_init_kernel<8>, dim3(wgs), scores, E, part, B_loc, K, eps, rpw);
   hipLaunchKernelGGL(sk_fold_kernel, dim3((K + 255) / 256), dim3(256), 0, s, part, u_out, wgs, K);
   TT_CHECK_LAUNCH("sinkhorn_local_begin");
   return TT_OK;
@@ -605,7 +617,7 @@ extern "C" int tt_sinkhorn_local_step(const float* u_in, float* u_out, int B_loc
   float* E = static_cast<float*>(workspace);
   float* part = E + (size_t)B_loc * K;
   const int wgs = sk_wgs(B_loc), rpw = (B_loc + wgs - 1) / wgs;
-  hipLaunchKernelGGL((sk_iter_kernel<false>), dim3(wgs), dim3(SK_THREADS), 0, s, E, u_in, part, (float*)nullptr, B_loc, K, 1, rpw, 0, 0, 0, B_total);
+  SK_LAUNCH_KPL((sk_iter_kernel<false, 4>), (sk_iter_kernel<false, 8>), dim3(wgs), E, u_in, part, (float*)nullptr, B_loc, K, 1, rpw, 0, 0, 0, B_total);
   hipLaunchKernelGGL(sk_fold_kernel, dim3((K + 255) / 256), dim3(256), 0, s, part, u_out, wgs, K);
   TT_CHECK_LAUNCH("sinkhorn_local_step");
   return TT_OK;
@@ -618,8 +630,8 @@ extern "C" int tt_sinkhorn_local_end(const float* u_in, float* q_out, int B_loc,
   hipStream_t s = as_stream(stream);
   const float* E = static_cast<const float*>(workspace);
   const int owgs = sk_wgs(rows_out), orpw = (rows_out + owgs - 1) / owgs;
-  hipLaunchKernelGGL((sk_iter_kernel<true>), dim3(owgs), dim3(SK_THREADS), 0, s, E, u_in, (float*)nullptr, q_out, B_loc, K, 1, orpw, 0, rows_out,
-                     u_in ? 0 : 1, B_loc);
+  SK_LAUNCH_KPL((sk_iter_kernel<true, 4>), (sk_iter_kernel<true, 8>), dim3(owgs), E, u_in, (float*)nullptr, q_out, B_loc, K, 1, orpw, 0, rows_out,
+                u_in ? 0 : 1, B_loc);
   TT_CHECK_LAUNCH("sinkhorn_local_end");
   return TT_OK;
 }
