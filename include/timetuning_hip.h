@@ -183,10 +183,10 @@ int tt_attention_bwd_bf16(const float* qkv, const float* out, const float* dout,
 /* The same backward with its matrix products on fp16-PAIR operands (round 6: the "f16x3" mode's attention backward; fp32-class like
  * tt_attention_bwd: q (scaled), k, v, dout, P and dS are split into (hi, lo) where they enter a product, three fp16 MFMAs per product term,
  * two fp32 accumulators; lse, delta, P and dS themselves are fp32).  dout is a gradient: it is split as dout times the power of two S that
- * brings max |dout| into [2^13, 2^14), dS = P (dP - delta) as dS S 2^-10 (exact; the outputs are divided by the scales again).  dout_amax:
+ * brings max |dout| into [2^13, 2^14), dS = P (dP - delta) as dS S 2^-12 (exact; the outputs are divided by the scales again).  dout_amax:
  * the amax slot the kernel that wrote dout raised (amax_out of tt_linear_bwd_data_pairs ...), or NULL - the call then measures the maximum
  * itself (one small launch).  range_flag: the pair entry points' range flag (below) - raised when a hi half of q, k, v, the scaled dout
- * or the scaled dS is not finite (dS: |v| beyond ~60).
+ * or the scaled dS is not finite (dS: |v| beyond ~128).
  * Inputs and outputs fp32 in memory; workspace: tt_attention_bwd_pairs_workspace_bytes; amax_out as tt_attention_bwd. */
 int tt_attention_bwd_pairs(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int F, int N, int H, int hd,
                            float scale, const float* dout_amax, void* workspace, size_t workspace_bytes, int* range_flag, float* amax_out,

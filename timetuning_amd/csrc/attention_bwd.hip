@@ -30,7 +30,7 @@
 //   * dO is a GRADIENT (1e-3 ... 1e-8): it is multiplied by the power of two S that brings max |dO| into [2^13, 2^14) before the split
 //     (exact; the maximum comes from the amax slot of the kernel that wrote dO, or from one small launch in front) and dP is divided by
 //     it again; dS = P (dP - delta) is a sum over the 64 head dimensions of dO V, up to 64 max |V| times larger than dO: it is split as
-//     dS S 2^-10 (a dS beyond fp16's range - |V| of several tens - raises the caller's range flag);
+//     dS S 2^-12 (a dS beyond fp16's range - |V| of a few hundred - raises the caller's range flag);
 //   * registers are capped so that the dq kernel runs three and the dkv kernel two waves per SIMD (LDS: 49 KB / 66 KB per workgroup).
 // profiles/r06_attention_bwd_pairs.txt has every step of that with its measurement.
 #include "common.hpp"
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, PAIR ? 3 : 1) void attention_bwd_dq_kernel(con
     }
   }
   const float inv_s = 1.0f / S;   // (a power of two)
-  const float S2 = S * 0.0009765625f;   // dS is split as dS S 2^-10: |dS| <= 64 max |dO| max |V|, i.e. dS S2 <= 1024 max |V| - inside fp16
+  const float S2 = S * 0.000244140625f;   // dS is split as dS S 2^-12: |dS| <= 2 x 64 max |dO| max |V|, i.e. dS S2 <= 512 max |V| - inside fp16 up to |V| = 128
   const float lse_q = (q < N) ? lse[((long long)f * H + h) * N + q] : 0.f;
   if (q < N && g == 0) delta[((long long)f * H + h) * N + q] = dl;
 
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256, PAIR ? 2 : 1) void attention_bwd_dkv_kernel(co
     }
   }
   const float inv_s = 1.0f / S;   // (a power of two)
-  const float S2 = S * 0.0009765625f;   // (dS is split as dS S 2^-10: the dq kernel)
+  const float S2 = S * 0.000244140625f;   // (dS is split as dS S 2^-12: the dq kernel)
 
   float4 stq[2], sto[2];
   float stl = 0.f, std_ = 0.f;
