@@ -577,7 +577,10 @@ def test_two_streams_equal_one_stream(cfg):
     concurrently (engine.TWO_STREAMS) compute what one stream computes.  Frames are independent, so with the one decomposition-dependent
     accumulation order taken out (the K-split of the left-over tiles of the persistent pair GEMM, knob TT_Q8_KSPLIT = 0) three training
     steps at BASELINE C2 / C3 size are BIT FOR BIT equal (losses, all gradients, all parameters); with the K-split as shipped the two runs
-    differ by fp32 rounding on the rows of those tiles only: relative L2 of every gradient < 2e-6."""
+    differ by fp32 rounding on the rows of those tiles only: relative L2 of every gradient < 2e-6.  (In that second part the two-stream run
+    takes the one-stream run's HARD LABELS: one of the 6 272 arg-maxes over the propagated maps is a near-tie inside fp32 rounding at step 3
+    of this seed, and one flipped label moves a gradient by 1.5e-2 - tools/probes/two_stream_labels.py; its own labels may differ from
+    them in at most 0.1 % of the patches.)"""
     from timetuning_amd import engine, hip_ops
     from tools.graph_vs_eager import CONFIGS, make
 
@@ -589,13 +592,19 @@ def test_two_streams_equal_one_stream(cfg):
         for ksplit, exact in ((0, True), (1, False)):
             hip_ops.set_tuning_knob("TT_Q8_KSPLIT", ksplit)
             runs = []
+            labels = []
             for two in (False, True):
                 engine.TWO_STREAMS = two
                 m, o = make(cfg, 8)
                 torch.manual_seed(5)
                 losses = []
                 for i in range(3):
-                    loss = m.get_loss(x)
+                    pin = labels[i] if (two and not exact) else None
+                    loss = m.get_loss(x, target_labels=pin)
+                    if not two:
+                        labels.append(m.last_aux["labels"].clone())
+                    elif pin is not None:
+                        assert (m.last_aux["labels"] != pin).float().mean().item() <= 1e-3
                     m.train_update(o, loss, i + 1 if queue else 0)
                     losses.append(loss.item())
                 runs.append((m, losses, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
